@@ -1,0 +1,208 @@
+// ORACLE (test infrastructure, CPU, f64) -- NOT part of the shipped product path.
+// C entry points (ctypes) over the CPU restatement.  Only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg may load this library; it is the checker, never the
+// thing measured or shipped.
+//
+// Pinning status: the reference is 100% Rust and no Rust toolchain exists in the build
+// image, so the reference cannot be compiled or run here (oracle/_ref is not buildable).
+// The restatement is pinned against every known-answer value the reference's own tests
+// hold for this path (tests/test_oracle_kat.py) and against the
+// reference's only golden numeric fixture (tests/golden/alias_audit_v0_5_1.json).
+// The melange-primitives Biquad boundary stays "parity unpinned" (see ow_voice.hpp).
+#include "ow_engine.hpp"
+#include <cstdio>
+
+using namespace owo;
+
+extern "C" {
+
+// ---- engine mirror (engine.rs public API) ----
+void* owo_engine_new(double sr) { return new WurliEngine(sr); }
+void owo_engine_free(void* e) { delete (WurliEngine*)e; }
+void owo_engine_set_sample_rate(void* e, double sr) { ((WurliEngine*)e)->set_sample_rate(sr); }
+void owo_engine_reset(void* e) { ((WurliEngine*)e)->reset(); }
+void owo_engine_warm_up(void* e) { ((WurliEngine*)e)->warm_up(); }
+void owo_engine_note_on(void* e, int note, float vel) { ((WurliEngine*)e)->note_on(note, vel); }
+void owo_engine_note_off(void* e, int note) { ((WurliEngine*)e)->note_off(note); }
+void owo_engine_set_sustain(void* e, int held) { ((WurliEngine*)e)->set_sustain(held != 0); }
+void owo_engine_set_volume(void* e, double v) { ((WurliEngine*)e)->set_volume(v); }
+void owo_engine_set_tremolo_depth(void* e, double v) { ((WurliEngine*)e)->set_tremolo_depth(v); }
+void owo_engine_set_speaker_character(void* e, double v) { ((WurliEngine*)e)->set_speaker_character(v); }
+void owo_engine_set_mlp_enabled(void* e, int on) { ((WurliEngine*)e)->set_mlp_enabled(on != 0); }
+void owo_engine_render(void* e, float* out, size_t len) { ((WurliEngine*)e)->render(out, len); }
+// render + tap of the pre-chain voice sum (f64), for stage-wise parity tests
+void owo_engine_render_tap(void* e, float* out, double* voice_sum, size_t len) {
+    WurliEngine* en = (WurliEngine*)e;
+    en->voice_sum_tap = voice_sum;
+    en->render(out, len);
+    en->voice_sum_tap = nullptr;
+}
+int owo_engine_count_state(void* e, int st) { return ((WurliEngine*)e)->count_state(st); }
+int owo_engine_active_voice_count(void* e) { return ((WurliEngine*)e)->active_voice_count(); }
+int owo_engine_steal_voice_count(void* e) { return ((WurliEngine*)e)->steal_voice_count(); }
+unsigned long long owo_engine_nan_guard_fires(void* e) { return ((WurliEngine*)e)->nan_guard_fires; }
+int owo_engine_slot_state(void* e, int slot) { return ((WurliEngine*)e)->voices[slot].state; }
+int owo_engine_slot_note(void* e, int slot) { return ((WurliEngine*)e)->voices[slot].midi_note; }
+
+// ---- offline / batch ----
+// Voice::render_note (voice.rs:191-221); returns number of samples written (<= cap)
+size_t owo_render_note(int midi, double vel, double dur_s, double sr, double* out, size_t cap) {
+    std::vector<double> v = render_note(midi, vel, dur_s, sr);
+    const size_t n = std::min(cap, v.size());
+    for (size_t i = 0; i < n; ++i) out[i] = v[i];
+    return v.size();
+}
+size_t owo_batch_render_job(int note, int vel_u8, double dur_s, double sr, double volume, double speaker_char, double r_ldr,
+                            int mlp, int poweramp, double* out, size_t cap) {
+    std::vector<double> v = batch_render_job(note, vel_u8, dur_s, sr, volume, speaker_char, r_ldr, mlp != 0, poweramp != 0);
+    const size_t n = std::min(cap, v.size());
+    for (size_t i = 0; i < n; ++i) out[i] = v[i];
+    return v.size();
+}
+
+// ---- unit-level hooks for the known-answer tests ----
+double owo_midi_to_freq(int m) { return midi_to_freq(m); }
+double owo_tip_mass_ratio(int m) { return tip_mass_ratio(m); }
+void owo_mode_ratios(double mu, double* out) { mode_ratios(mu, out); }
+double owo_reed_length_mm(int m) { return reed_length_mm(m); }
+void owo_reed_blank_dims(int m, double* wt) { reed_blank_dims(m, wt[0], wt[1]); }
+double owo_pickup_displacement_scale(int m) { return pickup_displacement_scale(m); }
+double owo_fundamental_decay_rate(int m) { return fundamental_decay_rate(m); }
+void owo_spatial_coupling(double mu, double len_mm, double* out) { spatial_coupling_coefficients(mu, len_mm, out); }
+double owo_output_scale(int m, double v) { return output_scale(m, v); }
+double owo_velocity_exponent(int m) { return velocity_exponent(m); }
+double owo_velocity_scurve(double v) { return velocity_scurve(v); }
+double owo_register_trim_db(int m) { return register_trim_db(m); }
+double owo_pickup_rms_proxy(double ds, double f0, double fc) { return pickup_rms_proxy(ds, f0, fc); }
+double owo_freq_detune(int m) { return freq_detune((uint8_t)m); }
+void owo_mode_amplitude_offsets(int m, double* out) { mode_amplitude_offsets((uint8_t)m, out); }
+double owo_dwell_time(double v, double f) { return dwell_time(v, f); }
+double owo_onset_ramp_time(double v, double f) { return onset_ramp_time(v, f); }
+void owo_dwell_attenuation(double v, double f, const double* ratios, double* out) { dwell_attenuation(v, f, ratios, out); }
+// out: 5 freq cents, 5 decay ratios, 1 ds
+void owo_mlp_infer(int midi, double vel, double* out) {
+    MlpCorrections c = mlp_infer(midi, vel);
+    for (int i = 0; i < 5; ++i) { out[i] = c.freq_offsets_cents[i]; out[5 + i] = c.decay_offsets[i]; }
+    out[10] = c.ds_correction;
+}
+// Packed voice parameter block after Voice::note_on -- compared field-by-field with the device note-on.
+// layout: [0..6] phase_inc, [7..13] amplitude, [14..20] decay_mult, [21..27] jitter_drift, [28..34] cos_inc, [35..41] sin_inc,
+//         42 onset_ramp_samples, 43 onset_ramp_inc, 44 onset_shape_exp, 45 jitter_state, 46 jitter_revert, 47 jitter_diffusion,
+//         48 pickup.beta, 49 pickup.displacement_scale, 50 post_pickup_gain, 51 noise.amplitude, 52 noise.decay, 53 noise.remaining,
+//         54..58 bpf b0,b1,b2,a1,a2
+void owo_voice_params(int midi, double vel, double sr, unsigned seed, int mlp, double* out) {
+    Voice v;
+    v.note_on(midi, vel, sr, seed, mlp != 0);
+    for (int m = 0; m < NUM_MODES; ++m) {
+        out[m] = v.reed.modes[m].phase_inc;
+        out[7 + m] = v.reed.modes[m].amplitude;
+        out[14 + m] = v.reed.modes[m].decay_mult;
+        out[21 + m] = v.reed.modes[m].jitter_drift;
+        out[28 + m] = v.reed.modes[m].cos_inc;
+        out[35 + m] = v.reed.modes[m].sin_inc;
+    }
+    out[42] = (double)v.reed.onset_ramp_samples;
+    out[43] = v.reed.onset_ramp_inc;
+    out[44] = v.reed.onset_shape_exp;
+    out[45] = (double)v.reed.jitter_state;
+    out[46] = v.reed.jitter_revert;
+    out[47] = v.reed.jitter_diffusion;
+    out[48] = v.pickup.beta;
+    out[49] = v.pickup.displacement_scale;
+    out[50] = v.post_pickup_gain;
+    out[51] = v.noise.amplitude;
+    out[52] = v.noise.decay_per_sample;
+    out[53] = (double)v.noise.remaining;
+    out[54] = v.noise.bpf.b0; out[55] = v.noise.bpf.b1; out[56] = v.noise.bpf.b2; out[57] = v.noise.bpf.a1; out[58] = v.noise.bpf.a2;
+}
+
+// pickup alone (pickup.rs tests): process buffer in place
+void owo_pickup_process(double sr, double ds, double* buf, size_t n) {
+    Pickup p;
+    p.init(sr);
+    p.displacement_scale = ds;
+    p.process(buf, n);
+}
+double owo_pickup_soft_saturate(double y) { return pickup_soft_saturate(y); }
+
+// reed alone (reed.rs tests)
+void owo_reed_render(double f0, const double* ratios, const double* amps, const double* decay, double onset, double vel, double sr,
+                     unsigned seed, double* out, size_t n) {
+    ModalReed r;
+    r.init(f0, ratios, amps, decay, onset, vel, sr, seed);
+    for (size_t i = 0; i < n; ++i) out[i] = 0.0;
+    r.render(out, n);
+}
+
+// biquad: kind 0=LP 1=HP 2=BP; filters x in place
+void owo_biquad_process(int kind, double fc, double q, double sr, double* x, size_t n) {
+    Biquad b = Biquad::make((Biquad::Kind)kind, fc, q, sr);
+    for (size_t i = 0; i < n; ++i) x[i] = b.process(x[i]);
+}
+
+// legacy preamp: DC operating point (8 node voltages + 2 Vbe) at R_ldr = 1 Mohm
+void owo_preamp_dc(double sr, double* v8_vnl2) {
+    DkPreamp p;
+    p.init(sr);
+    for (int i = 0; i < 8; ++i) v8_vnl2[i] = p.v_dc[i];
+    v8_vnl2[8] = p.main.v_nl[0];
+    v8_vnl2[9] = p.main.v_nl[1];
+}
+// preamp matrices for identity tests: s_base (64), a_neg_base (64), k (4), s_fb_fb
+void owo_preamp_matrices(double sr, double* s, double* aneg, double* k4, double* sfbfb) {
+    DkPreamp p;
+    p.init(sr);
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) { s[i * 8 + j] = p.s_base[i][j]; aneg[i * 8 + j] = p.a_neg_base[i][j]; }
+    k4[0] = p.k[0][0]; k4[1] = p.k[0][1]; k4[2] = p.k[1][0]; k4[3] = p.k[1][1];
+    *sfbfb = p.s_fb_fb;
+}
+// preamp run: per-sample input x[n] and R_ldr r[n] (r may be null -> static r_static after reset()) -> y[n]
+void owo_preamp_run(double sr, const double* x, const double* r, double r_static, double* y, size_t n) {
+    DkPreamp p;
+    p.init(sr);
+    if (!r) { p.reset(); p.set_ldr_resistance(r_static); }
+    for (size_t i = 0; i < n; ++i) {
+        if (r) p.set_ldr_resistance(r[i]);
+        y[i] = p.process_sample(x[i]);
+    }
+}
+
+// tremolo: n shunt-impedance samples at depth d after Tremolo::new(d, sr); optional osc voltage tap
+void owo_tremolo_run(double depth, double sr, double* r_out, size_t n) {
+    Tremolo* t = new Tremolo();
+    t->init(depth, sr);
+    for (size_t i = 0; i < n; ++i) r_out[i] = t->process();
+    delete t;
+}
+// raw oscillator voltage: state as after Tremolo::new(sr) settle, then n samples of v[OUT]
+void owo_tremolo_osc(double sr, double* v_out, size_t n) {
+    Tremolo* t = new Tremolo();
+    t->init(1.0, sr);
+    for (size_t i = 0; i < n; ++i) v_out[i] = t->osc.process_sample(0.0);
+    delete t;
+}
+// tremolo matrices after set_sample_rate(sr): s(49) k(16) s_ni(28) a_neg(49)
+void owo_tremolo_matrices(double sr, double* s, double* k, double* sni, double* aneg) {
+    TremCircuit c;
+    c.init_default();
+    if (std::fabs(sr - TREM_SAMPLE_RATE) > 0.5) c.set_sample_rate(sr);
+    for (int i = 0; i < 7; ++i) for (int j = 0; j < 7; ++j) { s[i * 7 + j] = c.s[i][j]; aneg[i * 7 + j] = c.a_neg[i][j]; }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) k[i * 4 + j] = c.k[i][j];
+    for (int i = 0; i < 7; ++i) for (int j = 0; j < 4; ++j) sni[i * 4 + j] = c.s_ni[i][j];
+}
+double owo_fast_exp(double x) { return fast_exp(x); }
+
+double owo_power_amp(double x) { PowerAmp p; return p.process(x); }
+void owo_speaker_run(double sr, double character, double* x, size_t n) {
+    Speaker s;
+    s.init(sr);
+    s.set_character(character);
+    for (size_t i = 0; i < n; ++i) x[i] = s.process(x[i]);
+}
+void owo_oversampler_roundtrip(const double* x, double* up, double* y, size_t n) {
+    Oversampler os;
+    os.upsample_2x(x, n, up);
+    os.downsample_2x(up, y, n);
+}
+
+}  // extern "C"
