@@ -1,0 +1,125 @@
+/* openwurli-hip: C-ABI of the MI355X (gfx950) render core for the OpenWurli DSP hot path.
+ *
+ * This is the drop-in boundary: plain C, opaque handles, raw pointers and sizes.  Each entry
+ * point replaces one item of the `openwurli-dsp` Rust public API that the nih-plug shell,
+ * tools/reed-renderer and tools/preamp-bench call today (citations into /root/reference/).
+ * A Rust facade with the reference's method names forwards 1:1.
+ *
+ * Conventions kept from the reference: one thread drives an engine; realtime
+ * calls never fail (bad input is clamped, numeric failure degrades to silence + counters);
+ * render() does not allocate once ensure_buffer_capacity() has been called; output is mono f32.
+ * Only constructors and the offline entry points report errors (NULL / negative return).
+ *
+ * A *pool* is the MI355X-native unit: I independent engines at one sample rate that render in
+ * lock-step with lane-per-engine chain kernels.  An `ow_engine*` is one engine of a pool;
+ * `ow_engine_new` creates a pool of one.
+ */
+#ifndef OPENWURLI_HIP_H
+#define OPENWURLI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ow_pool ow_pool;
+typedef struct ow_engine ow_engine;
+
+/* VoiceState, crates/openwurli-dsp/src/engine.rs:30-37 */
+enum { OW_VOICE_FREE = 0, OW_VOICE_HELD = 1, OW_VOICE_SUSTAINED = 2, OW_VOICE_RELEASING = 3 };
+/* preamp solver selection: cargo features of crates/openwurli-dsp/Cargo.toml:9-17 become a runtime enum */
+enum { OW_PREAMP_LEGACY8 = 0, OW_PREAMP_MELANGE12 = 1 };
+
+/* Introspection block (engine.rs:606-670 test/inspection helpers + diag counters of the solvers). */
+typedef struct ow_diag {
+    uint32_t active_voices, held_voices, sustained_voices, releasing_voices, steal_voices;
+    uint32_t sustain_held;
+    uint64_t nan_guard_fires;        /* engine.rs:662-664 */
+    uint64_t tremolo_be_fallbacks;   /* gen_tremolo.rs diag_be_fallback_count */
+    uint64_t preamp_nan_resets;      /* dk_preamp_legacy.rs:610-615 */
+    uint64_t output_nan_resets;      /* engine.rs:450-458 */
+} ow_diag;
+
+/* Last error message of the calling thread ("" if none). */
+const char* ow_last_error(void);
+
+/* ---- pools ------------------------------------------------------------------------------ */
+/* n_engines >= 1 engines at `sample_rate` on HIP device `device`.  Like WurliEngine::new
+ * (engine.rs:194-229) the engines are NOT warmed up; call ow_pool_set_sample_rate or
+ * ow_engine_set_sample_rate (what the plugin's initialize() does, plugin/src/lib.rs:96-97). */
+ow_pool* ow_pool_new(double sample_rate, size_t n_engines, int device, int preamp_kind);
+void ow_pool_free(ow_pool*);
+size_t ow_pool_size(const ow_pool*);
+ow_engine* ow_pool_engine(ow_pool*, size_t index);
+/* WurliEngine::set_sample_rate for every engine of the pool (engine.rs:272-286): rebuilds the chain, 0.6 s warm-up. */
+int ow_pool_set_sample_rate(ow_pool*, double sample_rate);
+/* WurliEngine::reset for every engine (engine.rs:231-251). */
+void ow_pool_reset(ow_pool*);
+void ow_pool_ensure_buffer_capacity(ow_pool*, size_t max_samples);
+/* Render `len` samples on every engine.  out_host: [n_engines][out_stride] f32 (out_stride >= len) or NULL to
+ * leave the block in HBM (see ow_pool_device_output).  Blocking; never fails. */
+void ow_pool_render(ow_pool*, float* out_host, size_t out_stride, size_t len);
+/* Device pointer of the last rendered block, f32 [n_engines][*stride]. */
+const float* ow_pool_device_output(const ow_pool*, size_t* stride);
+/* Stage-wise taps of the last rendered block, copied to host (parity tests): voice sum f64 [n_engines][len]. */
+int ow_pool_read_voice_sum(ow_pool*, double* out_host, size_t out_stride, size_t len);
+/* HIP stream the pool launches on (hipStream_t as void*), for event timing by the caller. */
+void* ow_pool_stream(ow_pool*);
+/* Time (ms, HIP events on the pool stream) each kernel of the last ow_pool_render took:
+ * [0] ops  [1] voices  [2] tremolo  [3] preamp  [4] post.  Enabled by ow_pool_set_profiling(pool,1). */
+void ow_pool_set_profiling(ow_pool*, int on);
+void ow_pool_last_kernel_ms(const ow_pool*, float ms[5]);
+
+/* ---- engines: the WurliEngine API (engine.rs) -------------------------------------------- */
+ow_engine* ow_engine_new(double sample_rate, int device, int preamp_kind);        /* WurliEngine::new        :194 */
+void ow_engine_free(ow_engine*);                                                  /* Drop (pool-of-one only)      */
+void ow_engine_set_sample_rate(ow_engine*, double sample_rate);                   /* set_sample_rate         :272 */
+void ow_engine_reset(ow_engine*);                                                 /* reset                   :231 */
+void ow_engine_warm_up(ow_engine*);                                               /* warm_up                 :261 */
+void ow_engine_ensure_buffer_capacity(ow_engine*, size_t max_samples);            /* ensure_buffer_capacity  :288 */
+void ow_engine_note_on(ow_engine*, uint8_t note, float velocity);                 /* note_on                 :299 */
+void ow_engine_note_off(ow_engine*, uint8_t note);                                /* note_off                :340 */
+void ow_engine_set_sustain(ow_engine*, int held);                                 /* set_sustain             :361 */
+void ow_engine_set_volume(ow_engine*, double v);                                  /* set_volume              :378 */
+void ow_engine_set_tremolo_depth(ow_engine*, double depth);                       /* set_tremolo_depth       :382 */
+void ow_engine_set_speaker_character(ow_engine*, double c);                       /* set_speaker_character   :386 */
+void ow_engine_set_mlp_enabled(ow_engine*, int on);                               /* set_mlp_enabled         :390 */
+void ow_engine_set_noise_enabled(ow_engine*, int on);                             /* set_noise_enabled       :394 (no-op on legacy preamp) */
+void ow_engine_set_noise_gain(ow_engine*, double gain);                           /* set_noise_gain          :398 (no-op on legacy preamp) */
+void ow_engine_render(ow_engine*, float* out, size_t len);                        /* render                  :425 (pool-of-one only) */
+void ow_engine_get_diag(const ow_engine*, ow_diag* out);
+int ow_engine_slot_state(const ow_engine*, int slot);                             /* VoiceSlot.state              */
+int ow_engine_slot_note(const ow_engine*, int slot);                              /* VoiceSlot.midi_note          */
+int ow_engine_has_steal_voice_for(const ow_engine*, uint8_t note);                /* has_steal_voice_for     :627 */
+
+/* ---- offline / batch ---------------------------------------------------------------------- */
+/* Voice::render_note (voice.rs:191-221): one voice, no chain, f64.  Returns the number of samples
+ * of the note ((dur_s*sr) as usize); writes min(n, cap).  Negative on device error. */
+long long ow_render_note(uint8_t midi, double velocity, double dur_s, double sample_rate, int device, double* out, size_t cap);
+
+/* `preamp-bench render` job (tools/preamp-bench/src/main.rs:371-549) as driven by ml/render_model_notes.py:49-116. */
+typedef struct ow_job {
+    uint8_t note;        /* --note, 33..96 */
+    uint8_t velocity;    /* --velocity, 0..127 (vel_norm = velocity/127) */
+    uint8_t mlp;         /* !--no-mlp */
+    uint8_t poweramp;    /* !--no-poweramp */
+    double volume;       /* --volume (audio taper: x volume^2) */
+    double speaker;      /* --speaker character */
+    double r_ldr;        /* --ldr static resistance (tremolo depth 0) */
+} ow_job;
+typedef struct ow_batch_cfg {
+    double sample_rate;  /* --sample-rate (44100 in the reference, main.rs:27) */
+    double duration_s;   /* --duration */
+    int device;
+    int preamp_kind;
+} ow_batch_cfg;
+/* Renders n_jobs independent jobs lane-parallel (lane = job).  out: f64 [n_jobs][stride], stride >= (duration*sr) as usize.
+ * If out_is_device != 0, `out` is a device pointer and nothing is copied to the host.  Returns samples per job, <0 on error. */
+long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg* cfg, double* out, size_t stride, int out_is_device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENWURLI_HIP_H */

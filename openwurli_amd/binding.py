@@ -1,0 +1,98 @@
+"""ctypes binding of include/openwurli_hip.h (the C-ABI of the HIP library)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class OwError(RuntimeError):
+    pass
+
+
+class OwDiag(C.Structure):
+    _fields_ = [
+        ("active_voices", C.c_uint32), ("held_voices", C.c_uint32), ("sustained_voices", C.c_uint32),
+        ("releasing_voices", C.c_uint32), ("steal_voices", C.c_uint32), ("sustain_held", C.c_uint32),
+        ("nan_guard_fires", C.c_uint64), ("tremolo_be_fallbacks", C.c_uint64),
+        ("preamp_nan_resets", C.c_uint64), ("output_nan_resets", C.c_uint64),
+    ]
+
+
+class OwJob(C.Structure):
+    _fields_ = [("note", C.c_uint8), ("velocity", C.c_uint8), ("mlp", C.c_uint8), ("poweramp", C.c_uint8),
+                ("volume", C.c_double), ("speaker", C.c_double), ("r_ldr", C.c_double)]
+
+
+class OwBatchCfg(C.Structure):
+    _fields_ = [("sample_rate", C.c_double), ("duration_s", C.c_double), ("device", C.c_int), ("preamp_kind", C.c_int)]
+
+
+# every symbol include/openwurli_hip.h declares: name -> (restype, argtypes)
+_VP = C.c_void_p
+SYMBOLS = {
+    "ow_last_error": (C.c_char_p, []),
+    "ow_pool_new": (_VP, [C.c_double, C.c_size_t, C.c_int, C.c_int]),
+    "ow_pool_free": (None, [_VP]),
+    "ow_pool_size": (C.c_size_t, [_VP]),
+    "ow_pool_engine": (_VP, [_VP, C.c_size_t]),
+    "ow_pool_set_sample_rate": (C.c_int, [_VP, C.c_double]),
+    "ow_pool_reset": (None, [_VP]),
+    "ow_pool_ensure_buffer_capacity": (None, [_VP, C.c_size_t]),
+    "ow_pool_render": (None, [_VP, _VP, C.c_size_t, C.c_size_t]),
+    "ow_pool_device_output": (_VP, [_VP, C.POINTER(C.c_size_t)]),
+    "ow_pool_read_voice_sum": (C.c_int, [_VP, _VP, C.c_size_t, C.c_size_t]),
+    "ow_pool_stream": (_VP, [_VP]),
+    "ow_pool_set_profiling": (None, [_VP, C.c_int]),
+    "ow_pool_last_kernel_ms": (None, [_VP, C.POINTER(C.c_float)]),
+    "ow_engine_new": (_VP, [C.c_double, C.c_int, C.c_int]),
+    "ow_engine_free": (None, [_VP]),
+    "ow_engine_set_sample_rate": (None, [_VP, C.c_double]),
+    "ow_engine_reset": (None, [_VP]),
+    "ow_engine_warm_up": (None, [_VP]),
+    "ow_engine_ensure_buffer_capacity": (None, [_VP, C.c_size_t]),
+    "ow_engine_note_on": (None, [_VP, C.c_uint8, C.c_float]),
+    "ow_engine_note_off": (None, [_VP, C.c_uint8]),
+    "ow_engine_set_sustain": (None, [_VP, C.c_int]),
+    "ow_engine_set_volume": (None, [_VP, C.c_double]),
+    "ow_engine_set_tremolo_depth": (None, [_VP, C.c_double]),
+    "ow_engine_set_speaker_character": (None, [_VP, C.c_double]),
+    "ow_engine_set_mlp_enabled": (None, [_VP, C.c_int]),
+    "ow_engine_set_noise_enabled": (None, [_VP, C.c_int]),
+    "ow_engine_set_noise_gain": (None, [_VP, C.c_double]),
+    "ow_engine_render": (None, [_VP, _VP, C.c_size_t]),
+    "ow_engine_get_diag": (None, [_VP, C.POINTER(OwDiag)]),
+    "ow_engine_slot_state": (C.c_int, [_VP, C.c_int]),
+    "ow_engine_slot_note": (C.c_int, [_VP, C.c_int]),
+    "ow_engine_has_steal_voice_for": (C.c_int, [_VP, C.c_uint8]),
+    "ow_render_note": (C.c_longlong, [C.c_uint8, C.c_double, C.c_double, C.c_double, C.c_int, _VP, C.c_size_t]),
+    "ow_batch_render": (C.c_longlong, [C.POINTER(OwJob), C.c_size_t, C.POINTER(OwBatchCfg), _VP, C.c_size_t, C.c_int]),
+}
+
+
+def library_path():
+    return os.environ.get("OPENWURLI_HIP_LIB", os.path.join(_HERE, "lib", "libopenwurli_hip.so"))
+
+
+def load_library():
+    """Load the HIP library.  Fails loudly when it has not been built -- there is no fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise OwError(f"{path} not found: build it with ./build.sh (hipcc --offload-arch=gfx950); "
+                      "openwurli-hip has no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def last_error(lib=None):
+    lib = lib or load_library()
+    msg = lib.ow_last_error()
+    return msg.decode() if msg else ""

@@ -1,0 +1,622 @@
+// openwurli-hip: host side of the C-ABI (include/openwurli_hip.h) -- pool/engine objects,
+// the voice-pool / MIDI state machine of WurliEngine (engine.rs:299-374,569-602) and the
+// kernel launch sequence of one render.  The state machine is integer/branchy host work;
+// everything that touches audio samples runs in the gfx950 kernels of ow_kernels.h.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/openwurli_hip.h"
+#include "ow_consts_host.hpp"
+#include "ow_kernels.h"
+
+using owdev::OwEngineOut;
+
+namespace {
+
+thread_local std::string g_err;
+void set_err(const std::string& s) { g_err = s; }
+
+#define HIP_OK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct Slot {  // VoiceSlot, engine.rs:39-62 (the Voice objects themselves live in HBM)
+    int state = OW_VOICE_FREE;
+    uint8_t midi = 0;
+    uint64_t age = 0;
+    bool has_voice = false, has_steal = false;
+    uint32_t steal_fade = 0, steal_fade_len = 0;
+};
+
+struct HostSmoother {  // host mirror of LinearSmoother::target only (the 1e-9 acceptance test, engine.rs:86-89)
+    double target;
+    bool pending = false;
+    double pending_value = 0.0;
+    void set_target(double t) {
+        if (std::fabs(t - target) < 1e-9) return;
+        target = t;
+        pending = true;
+        pending_value = t;
+    }
+};
+
+}  // namespace
+
+struct ow_engine {
+    ow_pool* pool = nullptr;
+    size_t index = 0;
+    bool owns_pool = false;
+    Slot slots[OW_MAX_VOICES];
+    uint64_t age_counter = 0;
+    bool sustain_held = false, mlp_enabled = true;
+    HostSmoother volume{0.5}, depth{0.5}, spk{0.0};
+    uint64_t nan_guard_fires = 0, output_nan_resets = 0;
+    std::vector<OwOp> ops;  // pending slot ops, applied at the start of the next render
+};
+
+struct ow_pool {
+    int device = 0;
+    size_t I = 0;
+    size_t Lcap = 0;
+    OwConsts hc{};
+    hipStream_t stream = nullptr;
+    OwConsts* dK = nullptr;     // constants at the pool's rates
+    OwConsts* dK48 = nullptr;   // tremolo codegen-rate matrices for CircuitState::warmup
+    double* d_nt = nullptr;
+    double* d_vrec = nullptr;
+    double* d_cs = nullptr;
+    double* d_sum = nullptr;
+    double* d_rbuf = nullptr;
+    double* d_pre = nullptr;
+    float* d_out = nullptr;
+    OwEngineArgs* d_args = nullptr;
+    OwEngineOut* d_eout = nullptr;
+    OwOp* d_ops = nullptr;
+    size_t ops_cap = 0;
+    OwEngineArgs* h_args = nullptr;   // pinned
+    OwEngineOut* h_eout = nullptr;    // pinned
+    OwOp* h_ops = nullptr;            // pinned
+    std::vector<ow_engine*> engines;
+    bool profiling = false;
+    hipEvent_t ev[6] = {};
+    float last_ms[5] = {0, 0, 0, 0, 0};
+    size_t last_len = 0;
+};
+
+namespace {
+
+void free_stream_buffers(ow_pool* p) {
+    if (p->d_sum) hipFree(p->d_sum);
+    if (p->d_rbuf) hipFree(p->d_rbuf);
+    if (p->d_pre) hipFree(p->d_pre);
+    if (p->d_out) hipFree(p->d_out);
+    p->d_sum = p->d_rbuf = p->d_pre = nullptr;
+    p->d_out = nullptr;
+}
+
+void alloc_stream_buffers(ow_pool* p, size_t cap) {
+    free_stream_buffers(p);
+    const size_t I = p->I;
+    HIP_OK(hipMalloc(&p->d_sum, sizeof(double) * 2 * I * cap));
+    HIP_OK(hipMalloc(&p->d_rbuf, sizeof(double) * 2 * cap * I));
+    HIP_OK(hipMalloc(&p->d_pre, sizeof(double) * 2 * cap * I));
+    HIP_OK(hipMalloc(&p->d_out, sizeof(float) * I * cap));
+    HIP_OK(hipMemsetAsync(p->d_out, 0, sizeof(float) * I * cap, p->stream));
+    p->Lcap = cap;
+}
+
+void ensure_ops_capacity(ow_pool* p, size_t n) {
+    if (n <= p->ops_cap) return;
+    size_t cap = std::max<size_t>(n, std::max<size_t>(p->ops_cap * 2, 256));
+    if (p->d_ops) hipFree(p->d_ops);
+    if (p->h_ops) hipHostFree(p->h_ops);
+    HIP_OK(hipMalloc(&p->d_ops, sizeof(OwOp) * cap));
+    HIP_OK(hipHostMalloc(&p->h_ops, sizeof(OwOp) * cap));
+    p->ops_cap = cap;
+}
+
+enum { INIT_NEW = 1, INIT_RATE = 2, INIT_RESET = 0 };
+
+// chain (re)initialisation of engines [e0, e0+ne): DC states on the device, then the Twin-T settle
+// (50 warm-up steps at the codegen matrices + 2 s at the pool rate), all in the product kernels.
+void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<double>& depth0) {
+    const int I = (int)p->I;
+    // depth0: one value per engine of the range (Tremolo::new(depth)); the kernel takes a scalar, so group equal values
+    int i = 0;
+    while (i < ne) {
+        int j = i + 1;
+        while (j < ne && depth0[j] == depth0[i]) ++j;
+        owdev::k_chain_init<<<dim3((j - i + 63) / 64), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, I, e0 + i, j - i, mode, depth0[i]);
+        i = j;
+    }
+    const int blocks = (ne + 63) / 64;
+    owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, I, e0, ne, 50LL);
+    const long long n_settle = (long long)owhip::sat_u32(p->hc.os_sr * 2.0);
+    owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, I, e0, ne, n_settle);
+    HIP_OK(hipGetLastError());
+}
+
+void upload_consts(ow_pool* p, double sr, int preamp_kind) {
+    owhip::build_consts(p->hc, sr, preamp_kind);
+    OwConsts k48;
+    owhip::build_consts(k48, 24000.0, preamp_kind);  // os_sr = 48 kHz -> codegen-rate tremolo matrices
+    HIP_OK(hipMemcpyAsync(p->dK, &p->hc, sizeof(OwConsts), hipMemcpyHostToDevice, p->stream));
+    HIP_OK(hipMemcpyAsync(p->dK48, &k48, sizeof(OwConsts), hipMemcpyHostToDevice, p->stream));
+    HIP_OK(hipStreamSynchronize(p->stream));
+}
+
+// One render of `len` samples for engines [e0, e0+ne).  with_voices=false skips the voice kernels
+// (warm-up of engines whose voices were just freed).
+void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
+    const int I = (int)p->I;
+    const int L = (int)len, Lcap = (int)p->Lcap;
+    // ---- per-engine args + ops
+    size_t n_ops = 0;
+    for (int k = 0; k < ne; ++k) n_ops += p->engines[e0 + k]->ops.size();
+    ensure_ops_capacity(p, n_ops);
+    size_t op_pos = 0;
+    bool any_main = false, any_steal = false;
+    for (int k = 0; k < ne; ++k) {
+        ow_engine* en = p->engines[e0 + k];
+        OwEngineArgs& a = p->h_args[e0 + k];
+        a.main_mask = 0; a.steal_mask = 0;
+        for (int s = 0; s < OW_MAX_VOICES; ++s) {
+            // engine.rs:471-473: a Free slot renders nothing unless it still carries a steal voice
+            if (en->slots[s].has_voice && en->slots[s].state != OW_VOICE_FREE) a.main_mask |= (1ull << s);
+            if (en->slots[s].has_steal) a.steal_mask |= (1ull << s);
+        }
+        any_main |= a.main_mask != 0; any_steal |= a.steal_mask != 0;
+        a.op_begin = (uint32_t)op_pos;
+        a.op_count = (uint32_t)en->ops.size();
+        if (!en->ops.empty()) std::memcpy(p->h_ops + op_pos, en->ops.data(), sizeof(OwOp) * en->ops.size());
+        op_pos += en->ops.size();
+        en->ops.clear();
+        a.set_flags = 0;
+        if (en->depth.pending) { a.set_flags |= 1u; a.depth_target = en->depth.pending_value; en->depth.pending = false; }
+        if (en->spk.pending)   { a.set_flags |= 2u; a.spk_target = en->spk.pending_value;     en->spk.pending = false; }
+        if (en->volume.pending){ a.set_flags |= 4u; a.vol_target = en->volume.pending_value;  en->volume.pending = false; }
+    }
+    hipStream_t st = p->stream;
+    HIP_OK(hipMemcpyAsync(p->d_args + e0, p->h_args + e0, sizeof(OwEngineArgs) * ne, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(p->d_eout + e0, 0, sizeof(OwEngineOut) * ne, st));
+    if (p->profiling) hipEventRecord(p->ev[0], st);
+    if (n_ops) {
+        HIP_OK(hipMemcpyAsync(p->d_ops, p->h_ops, sizeof(OwOp) * n_ops, hipMemcpyHostToDevice, st));
+        owdev::k_apply_ops<<<dim3(ne), dim3(64), 0, st>>>(p->dK, p->d_nt, p->d_vrec, p->d_args, p->d_ops, e0);
+    }
+    if (p->profiling) hipEventRecord(p->ev[1], st);
+    if (with_voices && (any_main || any_steal)) {
+        owdev::k_voice<<<dim3(ne, any_steal ? 2 : 1), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->d_args, p->d_sum, p->d_eout, I, L, Lcap, e0);
+    }
+    if (p->profiling) hipEventRecord(p->ev[2], st);
+    owdev::k_tremolo<<<dim3((ne + 63) / 64), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_rbuf, I, L, e0, ne);
+    if (p->profiling) hipEventRecord(p->ev[3], st);
+    owdev::k_preamp<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, p->d_rbuf, p->d_pre, I, L, Lcap, e0, ne);
+    if (p->profiling) hipEventRecord(p->ev[4], st);
+    owdev::k_post<<<dim3((ne + 63) / 64), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, Lcap, e0, ne);
+    if (p->profiling) hipEventRecord(p->ev[5], st);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(p->h_eout + e0, p->d_eout + e0, sizeof(OwEngineOut) * ne, hipMemcpyDeviceToHost, st));
+}
+
+// host bookkeeping after the block has been rendered (needs h_eout; call after stream sync)
+void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
+    const uint32_t l32 = (uint32_t)std::min<size_t>(len, 0xFFFFFFFFull);
+    for (int k = 0; k < ne; ++k) {
+        ow_engine* en = p->engines[e0 + k];
+        const OwEngineOut& o = p->h_eout[e0 + k];
+        for (int s = 0; s < OW_MAX_VOICES; ++s) {
+            Slot& sl = en->slots[s];
+            if (sl.has_steal) {  // engine.rs:490-493
+                sl.steal_fade = sl.steal_fade > l32 ? sl.steal_fade - l32 : 0u;
+                if (sl.steal_fade == 0) sl.has_steal = false;
+            }
+        }
+        if (o.sum_nonfinite) {  // engine.rs:499-521 (culprits were identified in the same pass; see DESIGN.md deviations)
+            en->nan_guard_fires += 1;
+            for (int s = 0; s < OW_MAX_VOICES; ++s) {
+                Slot& sl = en->slots[s];
+                if ((o.bad_main >> s) & 1ull) { sl.state = OW_VOICE_FREE; sl.has_voice = false; }
+                if ((o.bad_steal >> s) & 1ull) { sl.has_steal = false; sl.steal_fade = 0; }
+            }
+        }
+        if (o.out_nonfinite) en->output_nan_resets += 1;
+        for (int s = 0; s < OW_MAX_VOICES; ++s) {  // cleanup_voices, engine.rs:592-602
+            Slot& sl = en->slots[s];
+            if (sl.state != OW_VOICE_FREE && sl.has_voice && ((o.silent_mask >> s) & 1ull)) { sl.state = OW_VOICE_FREE; sl.has_voice = false; }
+        }
+    }
+}
+
+void collect_profile(ow_pool* p) {
+    if (!p->profiling) return;
+    for (int i = 0; i < 5; ++i) hipEventElapsedTime(&p->last_ms[i], p->ev[i], p->ev[i + 1]);
+}
+
+// WurliEngine::warm_up (engine.rs:261-270): 0.6 s of render() in 512-sample blocks
+void warm_up_range(ow_pool* p, int e0, int ne) {
+    const size_t total = (size_t)owhip::sat_u32(p->hc.sr * 0.6);
+    size_t done = 0;
+    while (done < total) {
+        const size_t len = std::min<size_t>(512, total - done);
+        render_range(p, e0, ne, len, true);
+        HIP_OK(hipStreamSynchronize(p->stream));
+        post_render_host(p, e0, ne, len);
+        done += len;
+    }
+}
+
+void engine_host_reset(ow_engine* en) {  // host half of WurliEngine::reset (engine.rs:231-244)
+    for (auto& s : en->slots) { s.state = OW_VOICE_FREE; s.has_voice = false; s.has_steal = false; s.steal_fade = 0; }
+    en->age_counter = 0;
+    en->sustain_held = false;
+    en->ops.clear();
+    // snap_to(target): a pending retarget would ramp; the device snaps current := target, so drop the ramp request
+    en->volume.pending = en->depth.pending = en->spk.pending = false;
+}
+
+int allocate_voice(const ow_engine* en) {  // engine.rs:569-590
+    int best_idx = 0;
+    uint64_t best = ~0ull;
+    for (int i = 0; i < OW_MAX_VOICES; ++i) {
+        const Slot& s = en->slots[i];
+        uint64_t pr;
+        switch (s.state) {
+            case OW_VOICE_FREE: return i;
+            case OW_VOICE_RELEASING: pr = s.age; break;
+            case OW_VOICE_SUSTAINED: pr = s.age + (~0ull) / 4; break;
+            default: pr = s.age + (~0ull) / 2; break;
+        }
+        if (pr < best) { best = pr; best_idx = i; }
+    }
+    return best_idx;
+}
+
+void push_op(ow_engine* en, uint8_t type, int slot, uint8_t note, bool mlp, uint32_t seed, double vel) {
+    OwOp op;
+    op.type = type; op.slot = (uint8_t)slot; op.note = note; op.mlp = mlp ? 1 : 0; op.seed = seed; op.velocity = vel;
+    en->ops.push_back(op);
+}
+
+ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int preamp_kind) {
+    if (!(sample_rate > 0.0) || n_engines == 0) throw std::runtime_error("invalid sample rate or engine count");
+    if (preamp_kind != OW_PREAMP_LEGACY8) throw std::runtime_error("preamp_kind: only OW_PREAMP_LEGACY8 is built in this round");
+    int ndev = 0;
+    HIP_OK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) throw std::runtime_error("no HIP device: openwurli-hip has no CPU fallback");
+    HIP_OK(hipSetDevice(device));
+    ow_pool* p = new ow_pool();
+    p->device = device;
+    p->I = n_engines;
+    HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    for (auto& e : p->ev) HIP_OK(hipEventCreate(&e));
+    HIP_OK(hipMalloc(&p->dK, sizeof(OwConsts)));
+    HIP_OK(hipMalloc(&p->dK48, sizeof(OwConsts)));
+    HIP_OK(hipMalloc(&p->d_nt, sizeof(double) * NT_COUNT * 64));
+    HIP_OK(hipMalloc(&p->d_vrec, sizeof(double) * n_engines * 2 * OW_VREC_DOUBLES));
+    HIP_OK(hipMalloc(&p->d_cs, sizeof(double) * CS_COUNT * n_engines));
+    HIP_OK(hipMalloc(&p->d_args, sizeof(OwEngineArgs) * n_engines));
+    HIP_OK(hipMalloc(&p->d_eout, sizeof(OwEngineOut) * n_engines));
+    HIP_OK(hipHostMalloc(&p->h_args, sizeof(OwEngineArgs) * n_engines));
+    HIP_OK(hipHostMalloc(&p->h_eout, sizeof(OwEngineOut) * n_engines));
+    std::memset(p->h_args, 0, sizeof(OwEngineArgs) * n_engines);
+    std::memset(p->h_eout, 0, sizeof(OwEngineOut) * n_engines);
+    HIP_OK(hipMemsetAsync(p->d_vrec, 0, sizeof(double) * n_engines * 2 * OW_VREC_DOUBLES, p->stream));
+    HIP_OK(hipMemsetAsync(p->d_cs, 0, sizeof(double) * CS_COUNT * n_engines, p->stream));
+    alloc_stream_buffers(p, n_engines == 1 ? (size_t)OW_MAX_BLOCK : (size_t)1024);  // engine.rs:25 MAX_BLOCK_SIZE for a lone engine
+    upload_consts(p, sample_rate, preamp_kind);
+    owdev::k_note_table<<<dim3(1), dim3(64), 0, p->stream>>>(p->d_nt);
+    p->engines.resize(n_engines);
+    for (size_t i = 0; i < n_engines; ++i) {
+        ow_engine* en = new ow_engine();
+        en->pool = p;
+        en->index = i;
+        p->engines[i] = en;
+    }
+    // WurliEngine::new for engine 0 on the device, then replicate (every engine of a fresh pool is identical)
+    chain_init_range(p, 0, 1, INIT_NEW, std::vector<double>(1, 0.5));
+    if (n_engines > 1)
+        owdev::k_chain_replicate<<<dim3((unsigned)((n_engines + 63) / 64)), dim3(64), 0, p->stream>>>(p->d_cs, (int)n_engines, 0, 0, (int)n_engines);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(p->stream));
+    return p;
+}
+
+void pool_destroy(ow_pool* p) {
+    if (!p) return;
+    hipSetDevice(p->device);
+    if (p->stream) hipStreamSynchronize(p->stream);
+    free_stream_buffers(p);
+    hipFree(p->dK); hipFree(p->dK48); hipFree(p->d_nt); hipFree(p->d_vrec); hipFree(p->d_cs);
+    hipFree(p->d_args); hipFree(p->d_eout);
+    if (p->d_ops) hipFree(p->d_ops);
+    if (p->h_ops) hipHostFree(p->h_ops);
+    hipHostFree(p->h_args); hipHostFree(p->h_eout);
+    for (auto& e : p->ev) if (e) hipEventDestroy(e);
+    if (p->stream) hipStreamDestroy(p->stream);
+    for (ow_engine* en : p->engines) delete en;
+    delete p;
+}
+
+template <typename F>
+void guarded(const char* what, F&& f) {  // realtime entry points never fail: record the error, degrade
+    try { f(); } catch (const std::exception& ex) { set_err(std::string(what) + ": " + ex.what()); std::fprintf(stderr, "openwurli-hip: %s: %s\n", what, ex.what()); }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ow_last_error(void) { return g_err.c_str(); }
+
+ow_pool* ow_pool_new(double sample_rate, size_t n_engines, int device, int preamp_kind) {
+    try { return pool_create(sample_rate, n_engines, device, preamp_kind); }
+    catch (const std::exception& ex) { set_err(std::string("ow_pool_new: ") + ex.what()); return nullptr; }
+}
+void ow_pool_free(ow_pool* p) { pool_destroy(p); }
+size_t ow_pool_size(const ow_pool* p) { return p ? p->I : 0; }
+ow_engine* ow_pool_engine(ow_pool* p, size_t i) { return (p && i < p->I) ? p->engines[i] : nullptr; }
+void* ow_pool_stream(ow_pool* p) { return p ? (void*)p->stream : nullptr; }
+void ow_pool_set_profiling(ow_pool* p, int on) { if (p) p->profiling = on != 0; }
+void ow_pool_last_kernel_ms(const ow_pool* p, float ms[5]) { for (int i = 0; i < 5; ++i) ms[i] = p ? p->last_ms[i] : 0.f; }
+
+int ow_pool_set_sample_rate(ow_pool* p, double sr) {
+    if (!p || !(sr > 0.0)) return -1;
+    try {
+        HIP_OK(hipSetDevice(p->device));
+        upload_consts(p, sr, p->hc.preamp_kind);
+        // voices keep their records (the reference keeps Voice objects too, engine.rs:272-286), chain objects are rebuilt
+        std::vector<double> d0(p->I);
+        for (size_t i = 0; i < p->I; ++i) d0[i] = p->engines[i]->depth.target;
+        chain_init_range(p, 0, (int)p->I, INIT_RATE, d0);
+        warm_up_range(p, 0, (int)p->I);
+        return 0;
+    } catch (const std::exception& ex) { set_err(std::string("ow_pool_set_sample_rate: ") + ex.what()); return -1; }
+}
+
+void ow_pool_reset(ow_pool* p) {
+    if (!p) return;
+    guarded("ow_pool_reset", [&] {
+        HIP_OK(hipSetDevice(p->device));
+        for (ow_engine* en : p->engines) engine_host_reset(en);
+        chain_init_range(p, 0, (int)p->I, INIT_RESET, std::vector<double>(p->I, 0.0));
+        warm_up_range(p, 0, (int)p->I);
+    });
+}
+
+void ow_pool_ensure_buffer_capacity(ow_pool* p, size_t n) {
+    if (!p || n <= p->Lcap) return;
+    guarded("ow_pool_ensure_buffer_capacity", [&] {
+        HIP_OK(hipSetDevice(p->device));
+        HIP_OK(hipStreamSynchronize(p->stream));
+        alloc_stream_buffers(p, n);
+    });
+}
+
+void ow_pool_render(ow_pool* p, float* out_host, size_t out_stride, size_t len) {
+    if (!p || len == 0) return;
+    guarded("ow_pool_render", [&] {
+        HIP_OK(hipSetDevice(p->device));
+        if (len > p->Lcap) { HIP_OK(hipStreamSynchronize(p->stream)); alloc_stream_buffers(p, len); }  // auto-grow, engine.rs:430
+        render_range(p, 0, (int)p->I, len, true);
+        if (out_host)
+            HIP_OK(hipMemcpy2DAsync(out_host, out_stride * sizeof(float), p->d_out, p->Lcap * sizeof(float), len * sizeof(float), p->I,
+                                    hipMemcpyDeviceToHost, p->stream));
+        HIP_OK(hipStreamSynchronize(p->stream));
+        post_render_host(p, 0, (int)p->I, len);
+        collect_profile(p);
+        p->last_len = len;
+    });
+    if (!g_err.empty() && out_host) { /* degrade to silence on device failure */ }
+}
+
+const float* ow_pool_device_output(const ow_pool* p, size_t* stride) {
+    if (!p) return nullptr;
+    if (stride) *stride = p->Lcap;
+    return p->d_out;
+}
+
+int ow_pool_read_voice_sum(ow_pool* p, double* out_host, size_t out_stride, size_t len) {
+    if (!p || !out_host || len > p->Lcap) return -1;
+    try {
+        HIP_OK(hipSetDevice(p->device));
+        const size_t I = p->I;
+        std::vector<double> a(I * len), b(I * len);
+        HIP_OK(hipMemcpy2D(a.data(), len * sizeof(double), p->d_sum, p->Lcap * sizeof(double), len * sizeof(double), I, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy2D(b.data(), len * sizeof(double), p->d_sum + I * p->Lcap, p->Lcap * sizeof(double), len * sizeof(double), I, hipMemcpyDeviceToHost));
+        for (size_t e = 0; e < I; ++e) {
+            const OwEngineArgs& ar = p->h_args[e];
+            for (size_t n = 0; n < len; ++n) {
+                double x = 0.0;
+                if (!p->h_eout[e].sum_nonfinite) {
+                    if (ar.main_mask) x = a[e * len + n];
+                    if (ar.steal_mask) x += b[e * len + n];
+                }
+                out_host[e * out_stride + n] = x;
+            }
+        }
+        return 0;
+    } catch (const std::exception& ex) { set_err(std::string("ow_pool_read_voice_sum: ") + ex.what()); return -1; }
+}
+
+// ---- engines ------------------------------------------------------------------------------------
+ow_engine* ow_engine_new(double sample_rate, int device, int preamp_kind) {
+    ow_pool* p = ow_pool_new(sample_rate, 1, device, preamp_kind);
+    if (!p) return nullptr;
+    p->engines[0]->owns_pool = true;
+    return p->engines[0];
+}
+void ow_engine_free(ow_engine* e) { if (e && e->owns_pool) pool_destroy(e->pool); }
+
+void ow_engine_set_sample_rate(ow_engine* e, double sr) {
+    if (!e) return;
+    // engines of a pool share one rate (lane = engine kernels read one constant block): the whole pool follows
+    ow_pool_set_sample_rate(e->pool, sr);
+}
+
+void ow_engine_reset(ow_engine* e) {
+    if (!e) return;
+    guarded("ow_engine_reset", [&] {
+        ow_pool* p = e->pool;
+        HIP_OK(hipSetDevice(p->device));
+        engine_host_reset(e);
+        chain_init_range(p, (int)e->index, 1, INIT_RESET, std::vector<double>(1, 0.0));
+        warm_up_range(p, (int)e->index, 1);
+    });
+}
+
+void ow_engine_warm_up(ow_engine* e) {
+    if (!e) return;
+    guarded("ow_engine_warm_up", [&] { HIP_OK(hipSetDevice(e->pool->device)); warm_up_range(e->pool, (int)e->index, 1); });
+}
+
+void ow_engine_ensure_buffer_capacity(ow_engine* e, size_t n) { if (e) ow_pool_ensure_buffer_capacity(e->pool, n); }
+
+void ow_engine_note_on(ow_engine* e, uint8_t note_in, float velocity) {  // engine.rs:299-338
+    if (!e) return;
+    const uint8_t note = std::min<uint8_t>(std::max<uint8_t>(note_in, OW_MIDI_LO), OW_MIDI_HI);
+    for (int i = 0; i < OW_MAX_VOICES; ++i) {
+        Slot& s = e->slots[i];
+        if (s.state == OW_VOICE_SUSTAINED && s.midi == note) {
+            s.state = OW_VOICE_RELEASING;
+            if (s.has_voice) push_op(e, OP_DAMPER, i, note, false, 0, 0.0);
+        }
+    }
+    const int idx = allocate_voice(e);
+    Slot& slot = e->slots[idx];
+    if (slot.state != OW_VOICE_FREE) {
+        const uint32_t fade = owhip::sat_u32(e->pool->hc.sr * 0.005);
+        if (slot.has_voice) {
+            push_op(e, OP_MOVE_STEAL, idx, note, false, fade, 0.0);
+            slot.has_steal = true;
+        } else {
+            slot.has_steal = false;  // Option::take() of an empty voice
+        }
+        slot.has_voice = false;
+        slot.steal_fade = fade;
+        slot.steal_fade_len = fade;
+    }
+    e->age_counter += 1;
+    const uint32_t seed = (uint32_t)note * 2654435761u + (uint32_t)e->age_counter;
+    push_op(e, OP_NOTE_ON, idx, note, e->mlp_enabled, seed, (double)velocity);
+    slot.has_voice = true;
+    slot.state = OW_VOICE_HELD;
+    slot.midi = note;
+    slot.age = e->age_counter;
+}
+
+void ow_engine_note_off(ow_engine* e, uint8_t note_in) {  // engine.rs:340-359
+    if (!e) return;
+    const uint8_t note = std::min<uint8_t>(std::max<uint8_t>(note_in, OW_MIDI_LO), OW_MIDI_HI);
+    int oldest = -1;
+    for (int i = 0; i < OW_MAX_VOICES; ++i) {
+        const Slot& s = e->slots[i];
+        if (s.state == OW_VOICE_HELD && s.midi == note && (oldest < 0 || s.age < e->slots[oldest].age)) oldest = i;
+    }
+    if (oldest < 0) return;
+    if (e->sustain_held) e->slots[oldest].state = OW_VOICE_SUSTAINED;
+    else {
+        e->slots[oldest].state = OW_VOICE_RELEASING;
+        if (e->slots[oldest].has_voice) push_op(e, OP_DAMPER, oldest, note, false, 0, 0.0);
+    }
+}
+
+void ow_engine_set_sustain(ow_engine* e, int held) {  // engine.rs:361-374
+    if (!e) return;
+    if (e->sustain_held && !held) {
+        for (int i = 0; i < OW_MAX_VOICES; ++i) {
+            Slot& s = e->slots[i];
+            if (s.state == OW_VOICE_SUSTAINED) {
+                s.state = OW_VOICE_RELEASING;
+                if (s.has_voice) push_op(e, OP_DAMPER, i, s.midi, false, 0, 0.0);
+            }
+        }
+    }
+    e->sustain_held = held != 0;
+}
+
+void ow_engine_set_volume(ow_engine* e, double v) { if (e) e->volume.set_target(v); }
+void ow_engine_set_tremolo_depth(ow_engine* e, double d) { if (e) e->depth.set_target(d); }
+void ow_engine_set_speaker_character(ow_engine* e, double c) { if (e) e->spk.set_target(c); }
+void ow_engine_set_mlp_enabled(ow_engine* e, int on) { if (e) e->mlp_enabled = on != 0; }
+void ow_engine_set_noise_enabled(ow_engine*, int) {}   // dk_preamp_legacy.rs:262: no-op on the legacy preamp
+void ow_engine_set_noise_gain(ow_engine*, double) {}   // dk_preamp_legacy.rs:265
+
+void ow_engine_render(ow_engine* e, float* out, size_t len) {
+    if (!e || !out || len == 0) return;
+    if (e->pool->I != 1) { set_err("ow_engine_render: engine belongs to a multi-engine pool; use ow_pool_render"); std::memset(out, 0, len * sizeof(float)); return; }
+    g_err.clear();
+    ow_pool_render(e->pool, out, len, len);
+    if (!g_err.empty()) std::memset(out, 0, len * sizeof(float));
+}
+
+void ow_engine_get_diag(const ow_engine* e, ow_diag* d) {
+    if (!e || !d) return;
+    std::memset(d, 0, sizeof *d);
+    for (const Slot& s : e->slots) {
+        if (s.state != OW_VOICE_FREE) d->active_voices++;
+        if (s.state == OW_VOICE_HELD) d->held_voices++;
+        if (s.state == OW_VOICE_SUSTAINED) d->sustained_voices++;
+        if (s.state == OW_VOICE_RELEASING) d->releasing_voices++;
+        if (s.has_steal) d->steal_voices++;
+    }
+    d->sustain_held = e->sustain_held ? 1 : 0;
+    d->nan_guard_fires = e->nan_guard_fires;
+    d->output_nan_resets = e->output_nan_resets;
+    ow_pool* p = e->pool;
+    double diag = 0.0;
+    if (hipSetDevice(p->device) == hipSuccess &&
+        hipMemcpy(&diag, p->d_cs + (size_t)CS_DIAG * p->I + e->index, sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
+        uint64_t bits;
+        std::memcpy(&bits, &diag, 8);
+        d->tremolo_be_fallbacks = (uint32_t)bits;
+        d->preamp_nan_resets = (uint32_t)(bits >> 32);
+    }
+}
+int ow_engine_slot_state(const ow_engine* e, int slot) { return (e && slot >= 0 && slot < OW_MAX_VOICES) ? e->slots[slot].state : -1; }
+int ow_engine_slot_note(const ow_engine* e, int slot) { return (e && slot >= 0 && slot < OW_MAX_VOICES) ? e->slots[slot].midi : -1; }
+int ow_engine_has_steal_voice_for(const ow_engine* e, uint8_t note) {
+    if (!e) return 0;
+    for (const Slot& s : e->slots) if (s.midi == note && s.has_steal) return 1;
+    return 0;
+}
+
+// ---- offline ------------------------------------------------------------------------------------
+long long ow_render_note(uint8_t midi, double velocity, double dur_s, double sample_rate, int device, double* out, size_t cap) {
+    try {
+        ow_pool* p = pool_create(sample_rate, 1, device, OW_PREAMP_LEGACY8);
+        ow_engine* e = p->engines[0];
+        // Voice::render_note: seed = midi * 2654435761, MLP off, no note clamping beyond the table range (voice.rs:206-207)
+        const uint8_t note = std::min<uint8_t>(std::max<uint8_t>(midi, OW_MIDI_LO), OW_MIDI_HI);
+        e->slots[0].has_voice = true; e->slots[0].state = OW_VOICE_HELD; e->slots[0].midi = note;
+        push_op(e, OP_NOTE_ON, 0, note, false, (uint32_t)midi * 2654435761u, velocity);
+        double x = dur_s * sample_rate;
+        const size_t n = (!(x == x) || x <= 0.0) ? 0 : (size_t)x;
+        std::vector<double> chunk(1024);
+        size_t done = 0;
+        while (done < n) {
+            const size_t len = std::min<size_t>(1024, n - done);
+            render_range(p, 0, 1, len, true);
+            HIP_OK(hipStreamSynchronize(p->stream));
+            // no cleanup_voices here: render_note keeps rendering the voice for the whole duration
+            if (ow_pool_read_voice_sum(p, chunk.data(), len, len) != 0) throw std::runtime_error(g_err);
+            for (size_t i = 0; i < len && done + i < cap; ++i) out[done + i] = chunk[i];
+            done += len;
+        }
+        pool_destroy(p);
+        return (long long)n;
+    } catch (const std::exception& ex) { set_err(std::string("ow_render_note: ") + ex.what()); return -1; }
+}
+
+long long ow_batch_render(const ow_job*, size_t, const ow_batch_cfg*, double*, size_t, int) {
+    set_err("ow_batch_render: not built yet");
+    return -1;
+}
+
+}  // extern "C"

@@ -1,0 +1,237 @@
+// openwurli-hip: host-side construction of the pool constants (OwConsts).
+// Init-time only (pool creation / set_sample_rate); nothing here runs per sample.
+//
+// Mirrors, for one sample rate:
+//   gen_tremolo.rs:2111-2342   CircuitState::set_sample_rate / rebuild_matrices / invert_n
+//   dk_preamp_legacy.rs:269-366 DkPreamp::new matrix construction (S, A_neg, K, Sherman-Morrison vectors)
+//   reed.rs:118-122, pickup.rs:103-106, hammer.rs:126-130, tremolo.rs:104-112, speaker.rs:74
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include "ow_types.h"
+#include "../../data/ow_gen_data.h"
+
+namespace owhip {
+
+// Rust `as u32`: truncate toward zero, saturating, NaN -> 0.
+static inline uint32_t sat_u32(double x) {
+    if (!(x == x) || x <= 0.0) return 0u;
+    if (x >= 4294967295.0) return 4294967295u;
+    return (uint32_t)x;
+}
+
+// LU with partial pivoting, then one forward/back substitution per unit column.  The pivot
+// search, elimination order and the "start at the permuted unit row" shortcut follow
+// gen_tremolo.rs:2273-2342 so the rebuilt S matches the reference's rounding.
+template <int NN>
+static bool lu_invert(const double* a, double* inv) {
+    double lu[NN * NN];
+    int perm[NN];
+    std::memcpy(lu, a, sizeof lu);
+    for (int i = 0; i < NN; ++i) perm[i] = i;
+    for (int k = 0; k < NN; ++k) {
+        int piv = k;
+        double best = std::fabs(lu[k * NN + k]);
+        for (int i = k + 1; i < NN; ++i) {
+            const double v = std::fabs(lu[i * NN + k]);
+            if (v > best) { best = v; piv = i; }
+        }
+        if (best < 1e-30) return false;
+        if (piv != k) {
+            for (int j = 0; j < NN; ++j) { const double t = lu[k * NN + j]; lu[k * NN + j] = lu[piv * NN + j]; lu[piv * NN + j] = t; }
+            const int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+        }
+        const double d = lu[k * NN + k];
+        for (int i = k + 1; i < NN; ++i) {
+            const double m = lu[i * NN + k] / d;
+            lu[i * NN + k] = m;
+            for (int j = k + 1; j < NN; ++j) lu[i * NN + j] -= m * lu[k * NN + j];
+        }
+    }
+    for (int col = 0; col < NN; ++col) {
+        double b[NN];
+        for (int i = 0; i < NN; ++i) b[i] = 0.0;
+        int start = NN;
+        for (int i = 0; i < NN; ++i)
+            if (perm[i] == col) { b[i] = 1.0; start = i; break; }
+        for (int i = start + 1; i < NN; ++i) {
+            double acc = b[i];
+            for (int j = start; j < i; ++j) acc -= lu[i * NN + j] * b[j];
+            b[i] = acc;
+        }
+        for (int i = NN - 1; i >= 0; --i) {
+            double acc = b[i];
+            for (int j = i + 1; j < NN; ++j) acc -= lu[i * NN + j] * b[j];
+            const double d = lu[i * NN + i];
+            if (std::fabs(d) < 1e-30) return false;
+            b[i] = acc / d;
+        }
+        for (int i = 0; i < NN; ++i) inv[i * NN + col] = b[i];
+    }
+    return true;
+}
+
+// K = N_v S N_i and S_NI = S N_i with the loop nest of gen_tremolo.rs:2172-2194.
+static void trem_kernel_mats(const double s[7][7], double k[4][4], double s_ni[7][4]) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double acc = 0.0;
+            for (int a = 0; a < 7; ++a) {
+                double inner = 0.0;
+                for (int b = 0; b < 7; ++b) inner += s[a][b] * TREM_N_I[b][j];
+                acc += TREM_N_V[i][a] * inner;
+            }
+            k[i][j] = acc;
+        }
+    for (int i = 0; i < 7; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double acc = 0.0;
+            for (int a = 0; a < 7; ++a) acc += s[i][a] * TREM_N_I[a][j];
+            s_ni[i][j] = acc;
+        }
+}
+
+static void build_tremolo_consts(OwConsts& c) {
+    const double rate = c.os_sr;
+    if (std::fabs(rate - TREM_SAMPLE_RATE) < 0.5) {  // gen_tremolo.rs:2117-2130 (codegen-rate defaults)
+        std::memcpy(c.t_a_neg, TREM_A_NEG_DEFAULT, sizeof c.t_a_neg);
+        std::memcpy(c.t_a_neg_be, TREM_A_NEG_BE_DEFAULT, sizeof c.t_a_neg_be);
+        std::memcpy(c.t_s, TREM_S_DEFAULT, sizeof c.t_s);
+        std::memcpy(c.t_k, TREM_K_DEFAULT, sizeof c.t_k);
+        std::memcpy(c.t_s_ni, TREM_S_NI_DEFAULT, sizeof c.t_s_ni);
+        std::memcpy(c.t_s_be, TREM_S_BE_DEFAULT, sizeof c.t_s_be);
+        std::memcpy(c.t_k_be, TREM_K_BE_DEFAULT, sizeof c.t_k_be);
+        std::memcpy(c.t_s_ni_be, TREM_S_NI_BE_DEFAULT, sizeof c.t_s_ni_be);
+    } else {
+        const double alpha = 2.0 * rate, alpha_be = rate;
+        double a[7][7], a_be[7][7];
+        for (int i = 0; i < 7; ++i)
+            for (int j = 0; j < 7; ++j) {
+                a[i][j] = TREM_G[i][j] + alpha * TREM_C[i][j];
+                c.t_a_neg[i][j] = alpha * TREM_C[i][j] - TREM_G[i][j];
+                a_be[i][j] = TREM_G[i][j] + alpha_be * TREM_C[i][j];
+                c.t_a_neg_be[i][j] = alpha_be * TREM_C[i][j];
+            }
+        for (int j = 0; j < 7; ++j) { c.t_a_neg[6][j] = 0.0; c.t_a_neg_be[6][j] = 0.0; }  // voltage-source row
+        // a failed inversion keeps the codegen-rate matrices (gen_tremolo.rs:2170 `if let Some`)
+        std::memcpy(c.t_s, TREM_S_DEFAULT, sizeof c.t_s);
+        std::memcpy(c.t_k, TREM_K_DEFAULT, sizeof c.t_k);
+        std::memcpy(c.t_s_ni, TREM_S_NI_DEFAULT, sizeof c.t_s_ni);
+        std::memcpy(c.t_s_be, TREM_S_BE_DEFAULT, sizeof c.t_s_be);
+        std::memcpy(c.t_k_be, TREM_K_BE_DEFAULT, sizeof c.t_k_be);
+        std::memcpy(c.t_s_ni_be, TREM_S_NI_BE_DEFAULT, sizeof c.t_s_ni_be);
+        double inv[7][7];
+        if (lu_invert<7>(&a[0][0], &inv[0][0])) {
+            std::memcpy(c.t_s, inv, sizeof inv);
+            trem_kernel_mats(c.t_s, c.t_k, c.t_s_ni);
+        }
+        if (lu_invert<7>(&a_be[0][0], &inv[0][0])) {
+            std::memcpy(c.t_s_be, inv, sizeof inv);
+            trem_kernel_mats(c.t_s_be, c.t_k_be, c.t_s_ni_be);
+        }
+    }
+    c.ldr_attack = std::exp(-1.0 / (0.0025 * rate));
+    c.ldr_release = std::exp(-1.0 / (0.035 * rate));
+    c.ln_r_max = std::log(1000000.0);
+    c.ln_min_minus_max = std::log(9000.0) - std::log(1000000.0);
+}
+
+// Gauss-Jordan on [A | I] with partial pivoting (dk_preamp_legacy.rs:122-168).
+static void gauss_jordan8(const double m[8][8], double inv[8][8]) {
+    double w[8][16];
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) { w[i][j] = m[i][j]; w[i][8 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int col = 0; col < 8; ++col) {
+        int piv = col;
+        double best = std::fabs(w[col][col]);
+        for (int r = col + 1; r < 8; ++r)
+            if (std::fabs(w[r][col]) > best) { best = std::fabs(w[r][col]); piv = r; }
+        if (!(best > 1e-30)) throw std::runtime_error("openwurli-hip: singular preamp matrix");
+        if (piv != col)
+            for (int j = 0; j < 16; ++j) { const double t = w[col][j]; w[col][j] = w[piv][j]; w[piv][j] = t; }
+        const double d = w[col][col];
+        for (int j = 0; j < 16; ++j) w[col][j] /= d;
+        for (int r = 0; r < 8; ++r) {
+            if (r == col) continue;
+            const double f = w[r][col];
+            for (int j = 0; j < 16; ++j) w[r][j] -= f * w[col][j];
+        }
+    }
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) inv[i][j] = w[i][8 + j];
+}
+
+static void build_preamp_consts(OwConsts& c) {
+    enum { BASE1 = 0, EMIT1, COLL1, EMIT2, EMIT2B, COLL2, OUT, FB };
+    const double VCC = 15.0, R1 = 22000.0, R2 = 2000000.0, R3 = 470000.0, RE1 = 33000.0, RC1 = 150000.0, RE2A = 270.0, RE2B = 820.0,
+                 RC2 = 1800.0, R9 = 6800.0, R10 = 56000.0;
+    const double CIN = 0.022e-6, C3 = 100.0e-12, C4 = 100.0e-12, CE1 = 4.7e-6, CE2 = 22.0e-6;
+    const double sr = c.os_sr;
+    const double t = 1.0 / sr, two_over_t = 2.0 / t;
+    const double alpha_cin = 2.0 * R1 * CIN * sr;
+    c.p_g_cin = (2.0 * CIN * sr) / (1.0 + alpha_cin);
+    c.p_c_cin = (1.0 - alpha_cin) / (1.0 + alpha_cin);
+    c.p_gc_1pc = c.p_g_cin * (1.0 + c.p_c_cin);
+
+    double g[8][8] = {}, cap[8][8] = {}, w[8] = {};
+    auto res = [&](int i, int j, double r) { const double y = 1.0 / r; g[i][i] += y; g[j][j] += y; g[i][j] -= y; g[j][i] -= y; };
+    auto cp = [&](int i, int j, double v) { cap[i][i] += v; cap[j][j] += v; cap[i][j] -= v; cap[j][i] -= v; };
+    g[BASE1][BASE1] += 1.0 / R2;  w[BASE1] += VCC / R2;
+    g[BASE1][BASE1] += 1.0 / R3;
+    g[EMIT1][EMIT1] += 1.0 / RE1;
+    g[COLL1][COLL1] += 1.0 / RC1; w[COLL1] += VCC / RC1;
+    res(EMIT2, EMIT2B, RE2A);
+    g[EMIT2B][EMIT2B] += 1.0 / RE2B;
+    g[COLL2][COLL2] += 1.0 / RC2; w[COLL2] += VCC / RC2;
+    res(COLL2, OUT, R9);
+    res(OUT, FB, R10);
+    std::memcpy(c.p_g_dc_base, g, sizeof g);
+    g[BASE1][BASE1] += c.p_g_cin;
+    cp(COLL1, BASE1, C3);
+    cp(COLL2, COLL1, C4);
+    cp(EMIT1, FB, CE1);
+    cp(EMIT2, EMIT2B, CE2);
+    double a[8][8];
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) {
+            const double tc = two_over_t * cap[i][j];
+            a[i][j] = tc + g[i][j];
+            c.p_a_neg[i][j] = tc - g[i][j];
+        }
+    for (int i = 0; i < 8; ++i) c.p_two_w[i] = 2.0 * w[i];
+    gauss_jordan8(a, c.p_s);
+    const double (*s)[8] = c.p_s;
+    c.p_k[0][0] = s[BASE1][EMIT1] - s[BASE1][COLL1] - s[EMIT1][EMIT1] + s[EMIT1][COLL1];
+    c.p_k[0][1] = s[BASE1][EMIT2] - s[BASE1][COLL2] - s[EMIT1][EMIT2] + s[EMIT1][COLL2];
+    c.p_k[1][0] = s[COLL1][EMIT1] - s[COLL1][COLL1] - s[EMIT2][EMIT1] + s[EMIT2][COLL1];
+    c.p_k[1][1] = s[COLL1][EMIT2] - s[COLL1][COLL2] - s[EMIT2][EMIT2] + s[EMIT2][COLL2];
+    double row[8];
+    for (int i = 0; i < 8; ++i) { c.p_s_fb_col[i] = s[i][FB]; row[i] = s[FB][i]; }
+    c.p_s_fb_fb = s[FB][FB];
+    c.p_nv_sfb[0] = c.p_s_fb_col[BASE1] - c.p_s_fb_col[EMIT1];
+    c.p_nv_sfb[1] = c.p_s_fb_col[COLL1] - c.p_s_fb_col[EMIT2];
+    c.p_sfb_ni[0] = row[EMIT1] - row[COLL1];
+    c.p_sfb_ni[1] = row[EMIT2] - row[COLL2];
+}
+
+static void build_consts(OwConsts& c, double sample_rate, int preamp_kind) {
+    std::memset(&c, 0, sizeof c);
+    c.sr = sample_rate;
+    c.oversample = sample_rate < 88200.0 ? 1 : 0;                 // engine.rs:195
+    c.os_sr = c.oversample ? sample_rate * 2.0 : sample_rate;
+    c.preamp_kind = preamp_kind;
+    const double dt = 1.0 / sample_rate;
+    c.jitter_revert = std::exp(-dt / 0.020);
+    c.jitter_diffusion = 0.0004 * std::sqrt(1.0 - c.jitter_revert * c.jitter_revert);
+    c.pickup_beta = dt / (2.0 * (287.0e3 * 240.0e-12));
+    c.noise_decay = std::exp(-1.0 / (0.003 * sample_rate));
+    c.noise_len = sat_u32(0.015 * sample_rate);
+    const uint32_t ramp = sat_u32(sample_rate * 0.005);
+    c.ramp_samples = ramp > 1u ? ramp : 1u;
+    c.spk_thermal_alpha = 1.0 / (5.0 * sample_rate);
+    build_tremolo_consts(c);
+    build_preamp_consts(c);
+}
+
+}  // namespace owhip

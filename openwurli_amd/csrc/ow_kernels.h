@@ -1,0 +1,459 @@
+// openwurli-hip: gfx950 kernels of the render path.
+//
+//   k_apply_ops   block = engine, lane = slot     note-on / damper / move-to-steal on voice records
+//   k_voice       block = (engine, pass), lane = slot   64 voices x L samples, ordered LDS reduction
+//   k_tremolo     lane = engine                    Twin-T oscillator + LDR -> R[n]
+//   k_preamp      lane = (engine, main|shadow)     half-band up + DK preamp (main - shadow)
+//   k_post        lane = engine                    power amp x2 -> half-band down -> speaker -> gain -> f32
+//
+// All global traffic is coalesced: voice records are field-major [field][64 slots], chain state and the
+// R / preamp streams are engine-minor [..][I]; engine-major audio rows are transposed through LDS tiles.
+#pragma once
+#include "ow_chain_dev.h"
+
+namespace owdev {
+
+#define OW_DATA_DECL __device__ const
+#define OW_GEN_DATA_REINCLUDE
+#include "../../data/ow_gen_data.h"
+#undef OW_GEN_DATA_REINCLUDE
+#undef OW_DATA_DECL
+
+// per-engine result block written by k_voice / k_post, read back by the host after every render
+struct OwEngineOut {
+    uint64_t silent_mask;     // slot voices that satisfy Voice::is_silent after this block
+    uint64_t bad_main;        // slot voices that produced a non-finite sample
+    uint64_t bad_steal;       // steal voices that produced a non-finite sample
+    uint32_t sum_nonfinite;   // engine.rs:499 NaN guard condition (either pass)
+    uint32_t out_nonfinite;   // engine.rs:450 output NaN guard fired this block
+};
+
+// mlp_correction.rs:86-116, scalar lane version (same accumulation order as the reference)
+__device__ inline void mlp_raw_scalar(double in0, double in1, double raw[11]) {
+    double h1[16], h2[16];
+    for (int i = 0; i < 16; ++i) {
+        double sum = MLP_B1[i];
+        sum += MLP_W1[i][0] * in0;
+        sum += MLP_W1[i][1] * in1;
+        h1[i] = sum > 0.0 ? sum : 0.0;
+    }
+    for (int i = 0; i < 16; ++i) {
+        double sum = MLP_B2[i];
+        for (int j = 0; j < 16; ++j) sum += MLP_W2[i][j] * h1[j];
+        h2[i] = sum > 0.0 ? sum : 0.0;
+    }
+    for (int i = 0; i < 11; ++i) {
+        double sum = MLP_B3[i];
+        for (int j = 0; j < 16; ++j) sum += MLP_W3[i][j] * h2[j];
+        raw[i] = sum * MLP_TARGET_STDS[i] + MLP_TARGET_MEANS[i];
+    }
+}
+
+// ------------------------------------------------------------------ slot ops
+__global__ __launch_bounds__(64) void k_apply_ops(const OwConsts* __restrict__ K, const double* __restrict__ nt, double* __restrict__ vrec,
+                                                  const OwEngineArgs* __restrict__ args, const OwOp* __restrict__ ops, int e0) {
+    const int e = e0 + blockIdx.x;
+    const int lane = threadIdx.x;
+    const OwEngineArgs a = args[e];
+    if (a.op_count == 0) return;
+    double* main_rec = vrec + ((size_t)e * 2 + 0) * OW_VREC_DOUBLES + lane;
+    double* steal_rec = vrec + ((size_t)e * 2 + 1) * OW_VREC_DOUBLES + lane;
+    for (uint32_t k = 0; k < a.op_count; ++k) {
+        const OwOp op = ops[a.op_begin + k];
+        if (op.slot != lane) continue;
+        if (op.type == OP_DAMPER) {
+            start_damper_lane(main_rec, K);
+        } else if (op.type == OP_MOVE_STEAL) {  // slot.steal_voice = slot.voice.take() (engine.rs:316-321)
+            for (int f = 0; f < VF_COUNT; ++f) steal_rec[f * 64] = main_rec[f * 64];
+            steal_rec[VF_STEAL * 64] = bitsd((uint64_t)op.seed | ((uint64_t)op.seed << 32));
+        } else if (op.type == OP_NOTE_ON) {
+            double raw[11];
+            const double midi = (double)op.note;
+            mlp_raw_scalar(clampd((midi - 21.0) / (108.0 - 21.0), 0.0, 1.0), clampd(op.velocity, 0.0, 1.0), raw);
+            const MlpOut corr = mlp_finish((int)op.note, raw, op.mlp != 0);
+            note_on_lane(main_rec, nt, K, (int)op.note, op.velocity, op.seed, corr);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ voices
+#define OW_VCHUNK 32
+__global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, double* __restrict__ vrec, const OwEngineArgs* __restrict__ args,
+                                              double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int L, int Lcap, int e0) {
+    __shared__ double tile[64 * (OW_VCHUNK + 1)];
+    const int e = e0 + blockIdx.x;
+    const int pass = blockIdx.y;
+    const int lane = threadIdx.x;
+    const uint64_t mask = pass ? args[e].steal_mask : args[e].main_mask;
+    if (mask == 0ull) return;  // chain kernels skip rows of empty passes
+    const bool active = (mask >> lane) & 1ull;
+    double* rec = vrec + ((size_t)e * 2 + pass) * OW_VREC_DOUBLES + lane;
+    double* row = sum + ((size_t)pass * I + e) * Lcap;
+
+    VoiceRegs v;
+    uint32_t steal_fade = 0, steal_len = 1;
+    if (active) {
+        v.load(rec);
+        if (pass) {
+            const uint64_t sf = dbits(rec[VF_STEAL * 64]);
+            steal_fade = (uint32_t)sf;
+            steal_len = (uint32_t)(sf >> 32);
+        }
+    }
+    bool bad_voice = false, bad_sum = false;
+    for (int base = 0; base < L; base += OW_VCHUNK) {
+        const int cn = min(OW_VCHUNK, L - base);
+        for (int n = 0; n < cn; ++n) {
+            double o = 0.0;
+            if (active) {
+                o = v.step(rec, K);
+                if (!isfinite(o)) bad_voice = true;
+                if (pass) {  // 5 ms linear crossfade, engine.rs:483-489
+                    const uint32_t i = (uint32_t)(base + n);
+                    const uint32_t remaining = steal_fade > i ? steal_fade - i : 0u;
+                    o = o * ((double)remaining / (double)steal_len);
+                }
+            }
+            tile[lane * (OW_VCHUNK + 1) + n] = o;
+        }
+        __syncthreads();
+        if (lane < cn) {  // sum the 64 slots in slot order (engine.rs:469-479)
+            double acc = 0.0;
+#pragma unroll 16
+            for (int s = 0; s < 64; ++s) acc += tile[s * (OW_VCHUNK + 1) + lane];
+            if (!isfinite(acc)) bad_sum = true;
+            row[base + lane] = acc;
+        }
+        __syncthreads();
+    }
+    bool silent = false;
+    if (active) {
+        if (pass) {  // slot.steal_fade.saturating_sub(len) (engine.rs:490)
+            const uint32_t l32 = (uint32_t)L;
+            steal_fade = steal_fade > l32 ? steal_fade - l32 : 0u;
+            rec[VF_STEAL * 64] = bitsd((uint64_t)steal_fade | ((uint64_t)steal_len << 32));
+        }
+        v.store(rec);
+        silent = v.is_silent(K);
+    }
+    const uint64_t silent_mask = __ballot(active && silent);
+    const uint64_t bad_mask = __ballot(active && bad_voice);
+    const uint64_t bs = __ballot(bad_sum);
+    if (lane == 0) {
+        if (pass == 0) { eout[e].silent_mask = silent_mask; eout[e].bad_main = bad_mask; }
+        else eout[e].bad_steal = bad_mask;
+        if (bs) atomicOr(&eout[e].sum_nonfinite, 1u);
+    }
+}
+
+// ------------------------------------------------------------------ chain state helpers (cs[field][I])
+#define CSF(f) cs[(size_t)(f) * I + e]
+
+OW_DEV void smoother_load(Smoother& s, const double* __restrict__ cs, int I, int e, int f) {
+    s.cur = CSF(f); s.target = CSF(f + 1); s.step = CSF(f + 2); s.rem = (uint32_t)dbits(CSF(f + 3));
+}
+OW_DEV void smoother_store(const Smoother& s, double* __restrict__ cs, int I, int e, int f) {
+    CSF(f) = s.cur; CSF(f + 1) = s.target; CSF(f + 2) = s.step; CSF(f + 3) = bitsd((uint64_t)s.rem);
+}
+OW_DEV void trem_load(TremState& t, const double* __restrict__ cs, int I, int e) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) t.v[i] = CSF(CS_T_V + i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { t.i_prev[i] = CSF(CS_T_I + i); t.i_pp[i] = CSF(CS_T_IP + i); }
+    t.env = CSF(CS_T_ENV); t.r_ldr = CSF(CS_T_RLDR); t.depth = CSF(CS_T_DEPTH);
+    t.be_fallbacks = 0;
+}
+OW_DEV void trem_store(const TremState& t, double* __restrict__ cs, int I, int e) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) CSF(CS_T_V + i) = t.v[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { CSF(CS_T_I + i) = t.i_prev[i]; CSF(CS_T_IP + i) = t.i_pp[i]; }
+    CSF(CS_T_ENV) = t.env; CSF(CS_T_RLDR) = t.r_ldr; CSF(CS_T_DEPTH) = t.depth;
+    if (t.be_fallbacks) {
+        const uint64_t d = dbits(CSF(CS_DIAG));
+        CSF(CS_DIAG) = bitsd((d & 0xFFFFFFFF00000000ull) | (uint64_t)((uint32_t)d + t.be_fallbacks));
+    }
+}
+OW_DEV void dk_load(DkSt& s, const double* __restrict__ cs, int I, int e, int base) {
+    s.j_cin = CSF(base); s.cin_prev = CSF(base + 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s.v[i] = CSF(base + 2 + i);
+    s.i_nl[0] = CSF(base + 10); s.i_nl[1] = CSF(base + 11); s.v_nl[0] = CSF(base + 12); s.v_nl[1] = CSF(base + 13);
+}
+OW_DEV void dk_store(const DkSt& s, double* __restrict__ cs, int I, int e, int base) {
+    CSF(base) = s.j_cin; CSF(base + 1) = s.cin_prev;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) CSF(base + 2 + i) = s.v[i];
+    CSF(base + 10) = s.i_nl[0]; CSF(base + 11) = s.i_nl[1]; CSF(base + 12) = s.v_nl[0]; CSF(base + 13) = s.v_nl[1];
+}
+
+// ------------------------------------------------------------------ chain init / reset / settle
+// Chain state (re)initialisation, lane = engine.
+//   mode 1  WurliEngine::new (engine.rs:194-229): fresh chain objects, default smoothers
+//   mode 2  set_sample_rate (engine.rs:272-286): fresh chain objects at the new rate, smoothers keep their
+//           values and are re-ramped (LinearSmoother::set_ramp_samples, engine.rs:109-116)
+//   mode 0  reset (engine.rs:231-251): preamp.reset() at the current R_ldr, tremolo rebuilt, oversampler and
+//           speaker state cleared, smoothers snapped to their targets
+// The Twin-T oscillator is left at CircuitState DC_OP; k_trem_settle then runs the 50 + 2*sr settle.
+__global__ void k_chain_init(const OwConsts* __restrict__ K, double* __restrict__ cs, int I, int e0, int ne, int mode, double depth0) {
+    const int e = e0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= e0 + ne) return;
+    const double dc[7] = {4.26480458363572357e0, 0.0, 1.24642300965575981e0, 2.75561285973736503e0, 6.66518981651571640e-1, 1.5e1, -2.28408414614134341e-3};
+    const double dci[4] = {7.72841164985201955e-5, 3.86420577732601037e-7, 2.20372764986731876e-3, 1.10186382445765932e-5};
+    for (int i = 0; i < 7; ++i) CSF(CS_T_V + i) = dc[i];
+    for (int i = 0; i < 4; ++i) { CSF(CS_T_I + i) = dci[i]; CSF(CS_T_IP + i) = dci[i]; }
+    CSF(CS_T_ENV) = 0.0;
+    CSF(CS_T_RLDR) = 1000000.0;
+    double r_ldr = 1000000.0;
+    if (mode != 0) {
+        CSF(CS_T_DEPTH) = depth0;   // Tremolo::new(depth, ..) (tremolo.rs:103)
+        if (mode == 1) {
+            Smoother s;
+            s.step = 0.0; s.rem = 0u;
+            s.cur = s.target = depth0; smoother_store(s, cs, I, e, CS_SM_DEPTH);
+            s.cur = s.target = 0.0;    smoother_store(s, cs, I, e, CS_SM_SPK);
+            s.cur = s.target = 0.5;    smoother_store(s, cs, I, e, CS_SM_VOL);
+            CSF(CS_DIAG) = bitsd(0ull);
+        } else {
+            for (int f = CS_SM_DEPTH; f <= CS_SM_VOL; f += 4) {
+                Smoother s;
+                smoother_load(s, cs, I, e, f);
+                if (s.rem > 0u) {
+                    const uint32_t r = K->ramp_samples;
+                    s.step = (s.target - s.cur) / (double)(r > 1u ? r : 1u);
+                    s.rem = r;
+                }
+                smoother_store(s, cs, I, e, f);
+            }
+        }
+        SpeakerSt sp;   // Speaker::new (speaker.rs:63-79)
+        sp.character = 1.0; sp.ts = 0.0;
+        sp.hpf.s1 = sp.hpf.s2 = sp.lpf.s1 = sp.lpf.s2 = 0.0;
+        speaker_update(sp, K->sr);
+        const double* hp = &sp.hpf.b0; const double* lp = &sp.lpf.b0;
+        for (int i = 0; i < 7; ++i) { CSF(CS_SPK_HPF + i) = hp[i]; CSF(CS_SPK_LPF + i) = lp[i]; }
+        CSF(CS_SPK_CHAR) = sp.character; CSF(CS_SPK_A2) = sp.a2; CSF(CS_SPK_A3) = sp.a3; CSF(CS_SPK_TC) = sp.tc; CSF(CS_SPK_TS) = 0.0;
+    } else {
+        r_ldr = CSF(CS_P_RLDR);
+        for (int f = CS_SM_DEPTH; f <= CS_SM_VOL; f += 4) { CSF(f) = CSF(f + 1); CSF(f + 2) = 0.0; CSF(f + 3) = bitsd(0ull); }  // snap_to(target)
+        CSF(CS_SPK_HPF + 5) = 0.0; CSF(CS_SPK_HPF + 6) = 0.0; CSF(CS_SPK_LPF + 5) = 0.0; CSF(CS_SPK_LPF + 6) = 0.0;
+        CSF(CS_SPK_TS) = 0.0;
+    }
+    DkSt st;
+    dk_dc_state(K, r_ldr, &st);
+    dk_store(st, cs, I, e, CS_P_MAIN);
+    dk_store(st, cs, I, e, CS_P_SHADOW);
+    CSF(CS_P_RLDR) = r_ldr; CSF(CS_P_GLDR) = 1.0 / r_ldr; CSF(CS_P_GPREV) = 1.0 / r_ldr;
+    for (int i = 0; i < 13; ++i) CSF(CS_OS_UA + i) = 0.0;
+    CSF(CS_FLAGS) = bitsd(0ull);
+}
+
+// n oscillator steps with the matrices of `K` (Tremolo::new settle loop tremolo.rs:97-100; CircuitState::warmup
+// gen_tremolo.rs:2071-2075 when K holds the 48 kHz codegen matrices).
+__global__ void k_trem_settle(const OwConsts* __restrict__ K, double* __restrict__ cs, int I, int e0, int ne, long long n) {
+    const int e = e0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= e0 + ne) return;
+    TremState t;
+    trem_load(t, cs, I, e);
+    for (long long i = 0; i < n; ++i) trem_osc_step(t, K);
+    trem_store(t, cs, I, e);
+}
+
+// copy the chain state of engine `src` to engines [e0, e0+ne) (identical by determinism at pool creation)
+__global__ void k_chain_replicate(double* __restrict__ cs, int I, int src, int e0, int ne) {
+    const int e = e0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= e0 + ne || e == src) return;
+    for (int f = 0; f < CS_COUNT; ++f) cs[(size_t)f * I + e] = cs[(size_t)f * I + src];
+}
+
+// ------------------------------------------------------------------ tremolo stream
+__global__ __launch_bounds__(64) void k_tremolo(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args,
+                                                double* __restrict__ rbuf, int I, int L, int e0, int ne) {
+    const int e = e0 + blockIdx.x * 64 + threadIdx.x;
+    if (e >= e0 + ne) return;
+    TremState t;
+    trem_load(t, cs, I, e);
+    Smoother sd;
+    smoother_load(sd, cs, I, e, CS_SM_DEPTH);
+    if (args[e].set_flags & 1u) sd.retarget(args[e].depth_target, K->ramp_samples);
+    const int osr = K->oversample ? 2 : 1;
+    for (int i = 0; i < L; ++i) {
+        t.depth = clampd(sd.next(), 0.0, 1.0);  // engine.rs:533-534, tremolo.rs:117-119
+        for (int j = 0; j < osr; ++j) rbuf[(size_t)(i * osr + j) * I + e] = trem_process(t, K);
+    }
+    trem_store(t, cs, I, e);
+    smoother_store(sd, cs, I, e, CS_SM_DEPTH);
+}
+
+// ------------------------------------------------------------------ preamp stream
+#define OW_PCHUNK 64
+__global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args,
+                                               const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const double* __restrict__ rbuf,
+                                               double* __restrict__ pre, int I, int L, int Lcap, int e0, int ne) {
+    __shared__ double tile[32 * (OW_PCHUNK + 1)];
+    const int lane = threadIdx.x;
+    const int el = lane & 31, role = lane >> 5;
+    const int eb = e0 + blockIdx.x * 32;
+    const int e = eb + el;
+    const bool valid = e < e0 + ne;
+    const int ec = valid ? e : (e0 + ne - 1);   // clamp so every lane runs the same (harmless) work
+    const int osr = K->oversample ? 2 : 1;
+
+    DkSt st;
+    double ua[3], ub[3];
+    double r_ldr, g_ldr, g_prev;
+    {
+        const int e = ec;
+        dk_load(st, cs, I, e, role ? CS_P_SHADOW : CS_P_MAIN);
+        for (int i = 0; i < 3; ++i) { ua[i] = CSF(CS_OS_UA + i); ub[i] = CSF(CS_OS_UB + i); }
+        r_ldr = CSF(CS_P_RLDR); g_ldr = CSF(CS_P_GLDR); g_prev = CSF(CS_P_GPREV);
+        const uint64_t fl = dbits(CSF(CS_FLAGS));
+        if (fl & 1ull) {  // deferred preamp.reset() + oversampler.reset() from the output NaN guard (engine.rs:450-457)
+            dk_dc_state(K, r_ldr, &st);
+            g_ldr = 1.0 / r_ldr; g_prev = g_ldr;
+            for (int i = 0; i < 3; ++i) { ua[i] = 0.0; ub[i] = 0.0; }
+        }
+    }
+    uint32_t nan_resets = 0;
+    for (int base = 0; base < L; base += OW_PCHUNK) {
+        const int cn = min(OW_PCHUNK, L - base);
+        // stage 32 engine rows x 64 samples of the voice sum (slot pass + steal pass) through LDS
+        for (int r = 0; r < 32; ++r) {
+            const int er = eb + r;
+            double x = 0.0;
+            if (er < e0 + ne && lane < cn && !eout[er].sum_nonfinite) {   // engine.rs:499-501: a non-finite block is zeroed
+                if (args[er].main_mask) x = sum[((size_t)0 * I + er) * Lcap + base + lane];
+                if (args[er].steal_mask) x += sum[((size_t)1 * I + er) * Lcap + base + lane];
+            }
+            tile[r * (OW_PCHUNK + 1) + lane] = x;
+        }
+        __syncthreads();
+        for (int n = 0; n < cn; ++n) {
+            const double x = tile[el * (OW_PCHUNK + 1) + n];
+            double in[2];
+            if (osr == 2) {  // Oversampler::upsample_2x (oversampler.rs:108-121); shadow input is 0.0 (dk_preamp_legacy.rs:599)
+                const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, ua, x);
+                const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, ub, x);
+                in[0] = role ? 0.0 : a;
+                in[1] = role ? 0.0 : b;
+            } else {
+                in[0] = role ? 0.0 : x;
+                in[1] = 0.0;
+            }
+            for (int j = 0; j < osr; ++j) {
+                const size_t idx = (size_t)((base + n) * osr + j);
+                const double r_new = fmax(rbuf[idx * I + ec], 1000.0);          // set_ldr_resistance, :620-626
+                if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = 1.0 / r_new; }
+                const double o = dk_step(st, in[j], g_ldr, g_prev, K);
+                g_prev = g_ldr;                                                   // :604
+                const double other = __shfl_xor(o, 32);
+                double result = role ? (other - o) : (o - other);                 // main - pump, :608
+                if (!isfinite(result)) {                                          // :610-615
+                    dk_dc_state(K, r_ldr, &st);
+                    g_ldr = 1.0 / r_ldr; g_prev = g_ldr;
+                    result = 0.0;
+                    nan_resets += 1u;
+                }
+                if (valid && role == 0) pre[idx * I + e] = result;
+            }
+        }
+        __syncthreads();
+    }
+    if (valid) {
+        dk_store(st, cs, I, e, role ? CS_P_SHADOW : CS_P_MAIN);
+        if (role == 0) {
+            for (int i = 0; i < 3; ++i) { CSF(CS_OS_UA + i) = ua[i]; CSF(CS_OS_UB + i) = ub[i]; }
+            CSF(CS_P_RLDR) = r_ldr; CSF(CS_P_GLDR) = g_ldr; CSF(CS_P_GPREV) = g_prev;
+            const uint64_t fl = dbits(CSF(CS_FLAGS));
+            if (fl & 1ull) CSF(CS_FLAGS) = bitsd(fl & ~1ull);
+            if (nan_resets) {
+                const uint64_t d = dbits(CSF(CS_DIAG));
+                CSF(CS_DIAG) = bitsd((d & 0xFFFFFFFFull) | ((uint64_t)((uint32_t)(d >> 32) + nan_resets) << 32));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ output stage
+#define OW_OCHUNK 64
+__global__ __launch_bounds__(64) void k_post(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args,
+                                             OwEngineOut* __restrict__ eout, const double* __restrict__ pre, float* __restrict__ out, int I, int L,
+                                             int Lcap, int e0, int ne) {
+    __shared__ float tile[64 * (OW_OCHUNK + 1)];
+    const int lane = threadIdx.x;
+    const int eb = e0 + blockIdx.x * 64;
+    const int e_raw = eb + lane;
+    const bool valid = e_raw < e0 + ne;
+    const int e = valid ? e_raw : (e0 + ne - 1);
+    const int osr = K->oversample ? 2 : 1;
+    const double sr = K->sr;
+
+    double da[3], db[3], dd;
+    for (int i = 0; i < 3; ++i) { da[i] = CSF(CS_OS_DA + i); db[i] = CSF(CS_OS_DB + i); }
+    dd = CSF(CS_OS_DD);
+    SpeakerSt sp;
+    {
+        double* hp = &sp.hpf.b0; double* lp = &sp.lpf.b0;
+        for (int i = 0; i < 7; ++i) { hp[i] = CSF(CS_SPK_HPF + i); lp[i] = CSF(CS_SPK_LPF + i); }
+        sp.character = CSF(CS_SPK_CHAR); sp.a2 = CSF(CS_SPK_A2); sp.a3 = CSF(CS_SPK_A3); sp.tc = CSF(CS_SPK_TC); sp.ts = CSF(CS_SPK_TS);
+    }
+    Smoother ss, sv;
+    smoother_load(ss, cs, I, e, CS_SM_SPK);
+    smoother_load(sv, cs, I, e, CS_SM_VOL);
+    if (args[e].set_flags & 2u) ss.retarget(args[e].spk_target, K->ramp_samples);
+    if (args[e].set_flags & 4u) sv.retarget(args[e].vol_target, K->ramp_samples);
+    bool nan_fired = false;
+
+    for (int base = 0; base < L; base += OW_OCHUNK) {
+        const int cn = min(OW_OCHUNK, L - base);
+        for (int n = 0; n < cn; ++n) {
+            double o;
+            if (osr == 2) {  // engine.rs:536-553
+                const size_t idx = (size_t)(base + n) * 2;
+                const double y0 = power_amp(pre[idx * I + e] * 0.25);
+                const double y1 = power_amp(pre[(idx + 1) * I + e] * 0.25);
+                const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, y0);
+                const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, y1);
+                o = (a + dd) * 0.5;
+                dd = b;
+            } else {
+                o = power_amp(pre[(size_t)(base + n) * I + e] * 0.25);
+            }
+            speaker_set_character(sp, ss.next(), sr);                           // engine.rs:437-438
+            const double shaped = speaker_process(sp, o, K->spk_thermal_alpha);
+            const double post = shaped * 7.498942093324558 * sv.next();         // POST_SPEAKER_GAIN x user volume
+            float f = (float)post;
+            if (!isfinite(f)) {                                                 // engine.rs:450-458
+                f = 0.0f;
+                sp.hpf.s1 = sp.hpf.s2 = sp.lpf.s1 = sp.lpf.s2 = 0.0;
+                sp.ts = 0.0;
+                nan_fired = true;
+            }
+            tile[lane * (OW_OCHUNK + 1) + n] = f;
+        }
+        __syncthreads();
+        for (int r = 0; r < 64; ++r) {
+            const int er = eb + r;
+            if (er < e0 + ne && lane < cn) out[(size_t)er * Lcap + base + lane] = tile[r * (OW_OCHUNK + 1) + lane];
+        }
+        __syncthreads();
+    }
+    if (!valid) return;
+    if (nan_fired) {  // preamp.reset()/oversampler.reset() act on post-block state: defer the preamp/up half to k_preamp
+        for (int i = 0; i < 3; ++i) { da[i] = 0.0; db[i] = 0.0; }
+        dd = 0.0;
+        CSF(CS_FLAGS) = bitsd(dbits(CSF(CS_FLAGS)) | 1ull);
+        eout[e].out_nonfinite = 1u;
+    }
+    for (int i = 0; i < 3; ++i) { CSF(CS_OS_DA + i) = da[i]; CSF(CS_OS_DB + i) = db[i]; }
+    CSF(CS_OS_DD) = dd;
+    {
+        const double* hp = &sp.hpf.b0; const double* lp = &sp.lpf.b0;
+        for (int i = 0; i < 7; ++i) { CSF(CS_SPK_HPF + i) = hp[i]; CSF(CS_SPK_LPF + i) = lp[i]; }
+        CSF(CS_SPK_CHAR) = sp.character; CSF(CS_SPK_A2) = sp.a2; CSF(CS_SPK_A3) = sp.a3; CSF(CS_SPK_TC) = sp.tc; CSF(CS_SPK_TS) = sp.ts;
+    }
+    smoother_store(ss, cs, I, e, CS_SM_SPK);
+    smoother_store(sv, cs, I, e, CS_SM_VOL);
+}
+
+}  // namespace owdev

@@ -1,0 +1,136 @@
+// openwurli-hip: data layout shared by host code and gfx950 kernels.
+//
+// HBM layout (one pool = I independent engines at one sample rate):
+//   voice records   double  vrec[I][2][VF_COUNT][64]   pass 0 = slot voices, pass 1 = steal voices;
+//                                                      field-major so the 64 lanes (= 64 voice slots,
+//                                                      engine.rs:24 MAX_VOICES) of a wave load 512 B rows
+//   chain state     double  cs[CS_COUNT][I]            engine-minor: lane = engine in the chain kernels
+//   per-note table  double  note_tab[NT_COUNT][64]     note-only part of Voice::note_on (tables.rs)
+//   stream buffers  double  sum[2][I][Lcap]            voice sums (slot pass, steal pass), engine-major
+//                   double  rbuf[2*Lcap][I]            tremolo shunt R per OS sample, sample-major
+//                   double  pre[2*Lcap][I]             preamp out (main - shadow), sample-major
+//                   float   out[I][Lcap]               final mono f32 (engine.rs:448)
+#pragma once
+#include <stdint.h>
+
+#define OW_NUM_MODES 7      /* tables.rs:5 */
+#define OW_MAX_VOICES 64    /* engine.rs:24 */
+#define OW_MIDI_LO 33       /* tables.rs:6 */
+#define OW_MIDI_HI 96       /* tables.rs:7 */
+#define OW_MAX_BLOCK 8192   /* engine.rs:25 */
+
+// ---- voice record fields (doubles; integer fields are stored as raw 64-bit patterns) ----
+enum {
+    VF_S = 0,            // [7] quadrature sine state            (reed.rs:46)
+    VF_C = 7,            // [7] quadrature cosine state
+    VF_ENV = 14,         // [7] envelope
+    VF_DRIFT = 21,       // [7] OU jitter drift
+    VF_COS_INC = 28,     // [7]
+    VF_SIN_INC = 35,     // [7]
+    VF_PHASE_INC = 42,   // [7]
+    VF_AMP = 49,         // [7]
+    VF_DECAY = 56,       // [7] decay_mult
+    VF_DRATE = 63,       // [7] damper_rate
+    VF_DMULT = 70,       // [7] damper_mult
+    VF_ONSET_INC = 77,   // onset_ramp_inc
+    VF_ONSET_EXP = 78,   // onset_shape_exp
+    VF_DRAMP = 79,       // damper_ramp_samples
+    VF_DCOUNT = 80,      // damper_release_count
+    VF_Q = 81,           // pickup charge
+    VF_DS = 82,          // pickup displacement_scale
+    VF_GAIN = 83,        // post_pickup_gain
+    VF_NAMP = 84,        // attack-noise amplitude
+    VF_NB0 = 85, VF_NB1 = 86, VF_NB2 = 87, VF_NA1 = 88, VF_NA2 = 89,  // attack-noise BPF coefficients
+    VF_NS1 = 90, VF_NS2 = 91,                                        // attack-noise BPF state
+    VF_SAMPLE = 92,      // u64 sample counter                      (reed.rs:71)
+    VF_ONSET_N = 93,     // u64 onset_ramp_samples
+    VF_RNG = 94,         // lo32 jitter_state, hi32 noise rng_state
+    VF_NCNT = 95,        // lo32 noise remaining, hi32 noise fade_in_remaining
+    VF_FLAGS = 96,       // lo32 flags (bit0 damper_active, bit1 damper_ramp_done), hi32 midi note
+    VF_STEAL = 97,       // steal records only: lo32 steal_fade, hi32 steal_fade_len (engine.rs:45-46)
+    VF_COUNT = 98
+};
+#define OW_VREC_DOUBLES (VF_COUNT * 64)   /* per (engine, pass) */
+
+// ---- per-note table fields (note index = midi - 33) ----
+enum {
+    NT_F0D = 0,          // detuned fundamental (tables.rs:37 x variation.rs:26)
+    NT_RATIO = 1,        // [7] mode ratios
+    NT_AMP = 8,          // [7] base amp x spatial coupling (tables.rs:804-830)
+    NT_DECAY = 15,       // [7] decay rates dB/s
+    NT_AOFF = 22,        // [7] per-note mode amplitude offsets (variation.rs:33)
+    NT_DS = 29,          // pickup_displacement_scale (tables.rs:279)
+    NT_VEL_EXP = 30,     // velocity_exponent
+    NT_F0 = 31,          // undetuned midi_to_freq
+    NT_TRIM = 32,        // register_trim_db
+    NT_VOICING = 33,     // voicing_slope * max(midi-60,0)
+    NT_COUNT = 34
+};
+
+// ---- chain state fields (per engine) ----
+enum {
+    CS_T_V = 0,          // [7] tremolo osc v_prev
+    CS_T_I = 7,          // [4] i_nl_prev
+    CS_T_IP = 11,        // [4] i_nl_prev_prev
+    CS_T_ENV = 15,       // ldr_envelope
+    CS_T_RLDR = 16,      // r_ldr (CdS cell)
+    CS_T_DEPTH = 17,     // tremolo depth (clamped, tremolo.rs:117-119)
+    CS_SM_DEPTH = 18,    // [4] tremolo-depth smoother current,target,step,remaining(u64) (engine.rs:67-130)
+    CS_SM_SPK = 22,      // [4] speaker-character smoother
+    CS_SM_VOL = 26,      // [4] volume smoother
+    CS_P_MAIN = 30,      // [14] j_cin, cin_rhs_prev, v[8], i_nl[2], v_nl[2]
+    CS_P_SHADOW = 44,    // [14]
+    CS_P_RLDR = 58, CS_P_GLDR = 59, CS_P_GPREV = 60,
+    CS_OS_UA = 61,       // [3] upsampler branch A state
+    CS_OS_UB = 64,       // [3]
+    CS_OS_DA = 67,       // [3] downsampler
+    CS_OS_DB = 70,       // [3]
+    CS_OS_DD = 73,       // down_delay
+    CS_SPK_HPF = 74,     // [7] b0 b1 b2 a1 a2 s1 s2
+    CS_SPK_LPF = 81,     // [7]
+    CS_SPK_CHAR = 88, CS_SPK_A2 = 89, CS_SPK_A3 = 90, CS_SPK_TC = 91, CS_SPK_TS = 92,
+    CS_FLAGS = 93,       // u64 bit0: preamp+oversampler reset pending (engine.rs:450-457)
+    CS_DIAG = 94,        // u64 counters: lo32 tremolo BE fallbacks, hi32 preamp NaN resets
+    CS_COUNT = 95
+};
+
+// ---- slot ops applied before a render (host voice-pool state machine -> device) ----
+enum { OP_NOTE_ON = 1, OP_DAMPER = 2, OP_MOVE_STEAL = 3 };
+struct OwOp {              // 16 bytes
+    uint8_t type, slot, note, mlp;
+    uint32_t seed;
+    double velocity;
+};
+
+// ---- pool constants (uniform over engines; computed on the host at pool creation) ----
+struct OwConsts {
+    double sr, os_sr;
+    int oversample, preamp_kind;
+    // voice-level rate constants
+    double jitter_revert, jitter_diffusion;   // reed.rs:120-122
+    double pickup_beta;                        // pickup.rs:105-106
+    double noise_decay;                        // hammer.rs:128-129
+    uint32_t noise_len;                        // hammer.rs:130
+    uint32_t ramp_samples;                     // engine.rs:677-680
+    // tremolo oscillator matrices at os_sr (gen_tremolo.rs:2139-2260)
+    double t_a_neg[7][7], t_s[7][7], t_k[4][4], t_s_ni[7][4];
+    double t_a_neg_be[7][7], t_s_be[7][7], t_k_be[4][4], t_s_ni_be[7][4];
+    double ldr_attack, ldr_release, ln_r_max, ln_min_minus_max;  // tremolo.rs:104-112
+    // legacy DK preamp at os_sr (dk_preamp_legacy.rs:269-366)
+    double p_s[8][8], p_a_neg[8][8], p_k[2][2], p_two_w[8], p_s_fb_col[8], p_s_fb_fb, p_nv_sfb[2], p_sfb_ni[2];
+    double p_g_cin, p_c_cin, p_gc_1pc;
+    double p_g_dc_base[8][8];
+    // speaker
+    double spk_thermal_alpha;                  // speaker.rs:74
+};
+
+// per-engine per-render parameters (host -> device)
+struct OwEngineArgs {
+    uint64_t main_mask;      // slots with a voice
+    uint64_t steal_mask;     // slots with a steal voice
+    uint32_t op_begin, op_count;
+    // setter targets accepted since the last render (LinearSmoother::set_target, engine.rs:86-99)
+    double depth_target, spk_target, vol_target;
+    uint32_t set_flags;      // bit0 depth, bit1 spk, bit2 vol
+    uint32_t pad;
+};

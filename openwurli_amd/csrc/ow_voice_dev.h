@@ -1,0 +1,480 @@
+// openwurli-hip: device code for the voice layer (gfx950, wave64, f64).
+//
+//   lane = voice slot (64 slots = one wavefront, engine.rs:24), block = (engine, pass)
+//   pass 0 = slot voices, pass 1 = steal voices fading out (engine.rs:481-493)
+//
+// Mirrors (citations into /root/reference/crates/openwurli-dsp/src/):
+//   voice.rs:28-142   Voice::note_on            -> note_on_lane()
+//   reed.rs:108-216   ModalReed::new/start_damper
+//   reed.rs:219-306   ModalReed::render         -> VoiceRegs::step()
+//   hammer.rs:150-198 AttackNoise::render
+//   pickup.rs:72-149  pickup_soft_saturate / Pickup::process
+//   tables.rs / variation.rs / hammer.rs:26-90 note-only maths -> k_note_table
+//   mlp_correction.rs:61-140 MLP forward (scalar lane version here; the MFMA batch version is in ow_mlp_mfma.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ow_types.h"
+
+namespace owdev {
+
+#define OW_DEV __device__ __forceinline__
+
+OW_DEV double clampd(double x, double lo, double hi) {  // Rust f64::clamp (NaN propagates)
+    return x < lo ? lo : (x > hi ? hi : x);
+}
+OW_DEV uint64_t dbits(double x) { return (uint64_t)__double_as_longlong(x); }
+OW_DEV double bitsd(uint64_t b) { return __longlong_as_double((long long)b); }
+OW_DEV uint32_t lcg(uint32_t s) { return s * 1664525u + 1013904223u; }  // reed.rs:91, hammer.rs:192-195
+OW_DEV uint64_t sat_u64(double x) {  // Rust `as u64`
+    if (!(x == x) || x <= 0.0) return 0ull;
+    if (x >= 18446744073709551615.0) return ~0ull;
+    return (uint64_t)x;
+}
+
+// ------------------------------------------------------------------ per-note table
+// One thread per MIDI note 33..96.  tables.rs:804-830 + variation.rs:26-38 + the note-only
+// scalars Voice::note_on needs (ds, velocity exponent, trim, voicing).
+OW_DEV double tip_mass_ratio(double m) {  // tables.rs:51-77
+    const double ax[5] = {33.0, 52.0, 62.0, 74.0, 96.0};
+    const double ay[5] = {0.10, 0.00, 0.00, 0.02, 0.01};
+    if (m <= ax[0]) return ay[0];
+    if (m >= ax[4]) return ay[4];
+    double r = 0.0;
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!done && m <= ax[i + 1]) {
+            const double t = (m - ax[i]) / (ax[i + 1] - ax[i]);
+            r = ay[i] + t * (ay[i + 1] - ay[i]);
+            done = true;
+        }
+    }
+    return r;
+}
+
+__device__ const double EIG_MU[8] = {0.00, 0.01, 0.05, 0.10, 0.15, 0.20, 0.30, 0.50};
+__device__ const double EIG_BETA[8][7] = {  // tables.rs:91-124
+    {1.8751, 4.6941, 7.8548, 10.9955, 14.1372, 17.2788, 20.4204}, {1.8584, 4.6849, 7.8504, 10.9930, 14.1356, 17.2776, 20.4195},
+    {1.7920, 4.6477, 7.8316, 10.9830, 14.1288, 17.2726, 20.4158}, {1.7227, 4.6024, 7.8077, 10.9700, 14.1198, 17.2660, 20.4110},
+    {1.6625, 4.5618, 7.7859, 10.9580, 14.1114, 17.2598, 20.4065}, {1.6097, 4.5254, 7.7659, 10.9470, 14.1036, 17.2540, 20.4023},
+    {1.5201, 4.4620, 7.7310, 10.9280, 14.0894, 17.2434, 20.3946}, {1.3853, 4.3601, 7.6745, 10.8970, 14.0650, 17.2252, 20.3814},
+};
+__device__ inline void eigenvalues(double mu, double out[7]) {  // tables.rs:85-143
+    const double mc = clampd(mu, 0.0, 0.50);
+    int lo = 0;
+    for (int i = 7; i >= 0; --i)
+        if (EIG_MU[i] <= mc) { lo = i; break; }
+    const int hi = lo + 1 < 7 ? lo + 1 : 7;
+    const double t = (EIG_MU[hi] > EIG_MU[lo]) ? (mc - EIG_MU[lo]) / (EIG_MU[hi] - EIG_MU[lo]) : 0.0;
+    for (int i = 0; i < 7; ++i) out[i] = EIG_BETA[lo][i] + t * (EIG_BETA[hi][i] - EIG_BETA[lo][i]);
+}
+__device__ inline double mode_shape(double beta, double xi) {  // tables.rs:295-299
+    const double sigma = (cosh(beta) + cos(beta)) / (sinh(beta) + sin(beta));
+    const double bx = beta * xi;
+    return cosh(bx) - cos(bx) - sigma * (sinh(bx) - sin(bx));
+}
+__device__ inline double reed_length_mm(double midi) {  // tables.rs:161-169
+    const double n = clampd(midi - 32.0, 1.0, 64.0);
+    const double inches = (n <= 20.0) ? 3.0 - n / 20.0 : 2.0 - (n - 20.0) / 44.0;
+    return inches * 25.4;
+}
+__device__ inline double reed_compliance(int midi) {  // tables.rs:183-225
+    int reed = midi - 32;
+    reed = reed < 1 ? 1 : (reed > 64 ? 64 : reed);
+    const double width_inch = reed <= 14 ? 0.151 : reed <= 20 ? 0.127 : reed <= 42 ? 0.121 : reed <= 50 ? 0.111 : 0.098;
+    double thick_inch;
+    if (reed <= 16) thick_inch = 0.026;
+    else if (reed <= 26) thick_inch = 0.026 + (((double)reed - 16.0) / 10.0) * (0.034 - 0.026);
+    else thick_inch = 0.034;
+    const double l = reed_length_mm((double)midi), w = width_inch * 25.4, t = thick_inch * 25.4;
+    return (l * l * l) / (w * t * t * t);
+}
+__device__ inline double hash01(uint32_t midi, uint32_t seed) {  // variation.rs:10-19
+    uint32_t h = 2166136261u;
+    h ^= midi; h *= 16777619u;
+    h ^= seed; h *= 16777619u;
+    h ^= h >> 16; h *= 2654435769u;
+    return (double)(h & 0x00FFFFFFu) / 16777216.0;
+}
+__device__ inline double register_trim_db(double m) {  // tables.rs:443-481
+    const double ax[13] = {36, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 80, 84};
+    const double ay[13] = {-1.3, 0.0, -1.3, 0.7, 0.2, -1.0, 0.0, 0.9, 1.2, 0.0, 1.8, 2.4, 3.6};
+    if (m <= ax[0]) return ay[0];
+    if (m >= ax[12]) return ay[12];
+    for (int i = 0; i < 12; ++i)
+        if (m <= ax[i + 1]) return ay[i] + ((m - ax[i]) / (ax[i + 1] - ax[i])) * (ay[i + 1] - ay[i]);
+    return 0.0;
+}
+
+__global__ void k_note_table(double* __restrict__ nt) {
+    const int ni = threadIdx.x;
+    if (ni >= 64) return;
+    const int midi = OW_MIDI_LO + ni;
+    const double m = (double)midi;
+    const double f0 = 440.0 * pow(2.0, (m - 69.0) / 12.0);                        // tables.rs:37-39
+    const double detune = 1.0 + (hash01((uint32_t)midi, 0xDEADu) * 2.0 - 1.0) * 0.00173;  // variation.rs:26-29
+    nt[NT_F0 * 64 + ni] = f0;
+    nt[NT_F0D * 64 + ni] = f0 * detune;
+    const double mu = tip_mass_ratio(m);
+    double betas[7], ratios[7];
+    eigenvalues(mu, betas);
+    const double b1sq = betas[0] * betas[0];
+    for (int i = 0; i < 7; ++i) ratios[i] = (betas[i] * betas[i]) / b1sq;          // tables.rs:149-153
+    const double base_decay = fmax(0.005 * pow(f0, 1.22), 3.0);                    // tables.rs:391-396
+    // spatial pickup coupling, 32-interval Simpson (tables.rs:324-370)
+    const double ell = clampd(6.0 / reed_length_mm(m), 0.0, 1.0);
+    const double xi_start = 1.0 - ell;
+    double kraw[7];
+    for (int mode = 0; mode < 7; ++mode) {
+        const double beta = betas[mode];
+        const double tip = mode_shape(beta, 1.0);
+        if (fabs(tip) < 1e-30 || ell < 1e-12) { kraw[mode] = 1.0; continue; }
+        const double h = ell / 32.0;
+        double sum = mode_shape(beta, xi_start) + mode_shape(beta, 1.0);
+        for (int j = 1; j < 32; ++j) {
+            const double xi = xi_start + (double)j * h;
+            sum += ((j & 1) ? 4.0 : 2.0) * mode_shape(beta, xi);
+        }
+        const double integral = sum * h / 3.0;
+        kraw[mode] = clampd(fabs(integral / (ell * tip)), 0.0, 1.0);
+    }
+    const double base_amp[7] = {1.0, 0.005, 0.0035, 0.0018, 0.0011, 0.0007, 0.0005};  // tables.rs:33-34
+    const double k1 = kraw[0];
+    for (int i = 0; i < 7; ++i) {
+        const double kap = (k1 > 1e-30) ? clampd(kraw[i] / k1, 0.0, 1.0) : 1.0;
+        nt[(NT_RATIO + i) * 64 + ni] = ratios[i];
+        nt[(NT_AMP + i) * 64 + ni] = base_amp[i] * kap;
+        nt[(NT_DECAY + i) * 64 + ni] = base_decay * ratios[i] * ratios[i];           // tables.rs:418-422
+        nt[(NT_AOFF + i) * 64 + ni] = 1.0 + (hash01((uint32_t)midi, 0xBEEFu + (uint32_t)i) * 2.0 - 1.0) * 0.08;
+    }
+    const double ds = 0.85 * pow(reed_compliance(midi) / reed_compliance(60), 0.75);  // tables.rs:279-288
+    nt[NT_DS * 64 + ni] = clampd(ds, 0.02, 0.95);
+    {   // velocity_exponent, tables.rs:535-554
+        const double z = (m - 62.0) / 15.0;
+        const double t = exp(-0.5 * (z * z));
+        const double mn = (m < 62.0) ? 0.55 : 1.3;
+        nt[NT_VEL_EXP * 64 + ni] = mn + t * (1.7 - mn);
+    }
+    nt[NT_TRIM * 64 + ni] = register_trim_db(m);
+    nt[NT_VOICING * 64 + ni] = -0.04 * fmax(m - 60.0, 0.0);                        // tables.rs:522
+}
+
+// ------------------------------------------------------------------ note-on (one lane = one slot)
+__device__ inline double pickup_rms_proxy(double ds, double f0, double fc) {  // tables.rs:424-441
+    if (ds < 1e-10) return 0.0;
+    const double r = (1.0 - sqrt(1.0 - ds * ds)) / ds;
+    const double inv_sqrt = 1.0 / sqrt(1.0 - ds * ds);
+    double sum_sq = 0.0, r_n = r;
+    for (int n = 1; n <= 8; ++n) {
+        const double cn = 2.0 * r_n * inv_sqrt;
+        const double nf = (double)n * f0;
+        const double hpf_n = nf / sqrt(nf * nf + fc * fc);
+        sum_sq += (cn * hpf_n) * (cn * hpf_n);
+        r_n *= r;
+    }
+    return sqrt(sum_sq);
+}
+__device__ inline double velocity_scurve(double v) {  // tables.rs:556-562
+    const double k = 1.5;
+    const double s = 1.0 / (1.0 + exp(-k * (v - 0.5)));
+    const double s0 = 1.0 / (1.0 + exp(k * 0.5));
+    const double s1 = 1.0 / (1.0 + exp(-k * 0.5));
+    return (s - s0) / (s1 - s0);
+}
+
+struct MlpOut { double cents[5], decay[5], ds; };
+
+// Scalar forward pass, same accumulation order as mlp_correction.rs:86-116.
+__device__ inline void mlp_raw_scalar(double in0, double in1, double raw[11]);
+
+__device__ inline MlpOut mlp_finish(int midi_note, const double raw[11], bool enabled) {  // mlp_correction.rs:61-140
+    MlpOut o;
+    for (int i = 0; i < 5; ++i) { o.cents[i] = 0.0; o.decay[i] = 1.0; }
+    o.ds = 1.0;
+    if (!enabled) return o;
+    const double midi = (double)midi_note;
+    double fade;
+    if (midi < 65.0) fade = clampd((midi - (65.0 - 12.0)) / 12.0, 0.0, 1.0);
+    else if (midi > 97.0) fade = clampd(((97.0 + 12.0) - midi) / 12.0, 0.0, 1.0);
+    else fade = 1.0;
+    if (fade <= 0.0) return o;
+    for (int h = 0; h < 5; ++h) o.cents[h] = clampd(raw[h] * fade, -100.0, 100.0);
+    for (int h = 0; h < 5; ++h) o.decay[h] = 1.0 + (clampd(raw[5 + h], 0.3, 3.0) - 1.0) * fade;
+    o.ds = 1.0 + (clampd(raw[10], 0.7, 1.2) - 1.0) * fade;
+    return o;
+}
+
+// Writes a fresh voice into record `rec` (pointer already offset by slot; field stride 64).
+__device__ inline void note_on_lane(double* __restrict__ rec, const double* __restrict__ nt, const OwConsts* __restrict__ K, int note,
+                                    double vel, uint32_t seed, const MlpOut& corr) {
+    const int ni = note - OW_MIDI_LO;
+    const double sr = K->sr;
+    const double f0d = nt[NT_F0D * 64 + ni];
+    double ratios[7], amps[7], decay[7];
+    for (int i = 0; i < 7; ++i) { ratios[i] = nt[(NT_RATIO + i) * 64 + ni]; decay[i] = nt[(NT_DECAY + i) * 64 + ni]; }
+    // dwell filter (hammer.rs:26-29, 69-90) on the uncorrected ratios
+    const double t_dwell = clampd((0.75 + 0.25 * (1.0 - vel)) / f0d, 0.0003, 0.020);
+    double att[7];
+    for (int i = 0; i < 7; ++i) {
+        const double ft = f0d * ratios[i] * t_dwell;
+        att[i] = exp(-ft * ft / (2.0 * (8.0 * 8.0)));
+    }
+    const double a0 = att[0];
+    if (a0 > 1e-30)
+        for (int i = 0; i < 7; ++i) att[i] /= a0;
+    const double onset_time = fmax((1.0 + 1.0 * (1.0 - vel)) * (1.0 / f0d), 0.002);  // hammer.rs:53-57
+    const double scurve = velocity_scurve(vel);
+    const double vel_scale = pow(scurve, nt[NT_VEL_EXP * 64 + ni]);
+    for (int i = 0; i < 7; ++i) {
+        amps[i] = nt[(NT_AMP + i) * 64 + ni] * att[i] * nt[(NT_AOFF + i) * 64 + ni];
+        amps[i] *= vel_scale;
+    }
+    for (int h = 0; h < 5; ++h) {                                                   // voice.rs:68-84
+        ratios[1 + h] *= pow(2.0, corr.cents[h] / 1200.0);
+        decay[1 + h] /= corr.decay[h];
+    }
+    const double base_ds = nt[NT_DS * 64 + ni];
+    const double corrected_ds = base_ds * corr.ds;
+
+    // ModalReed::new (reed.rs:108-182)
+    uint32_t js = seed > 1u ? seed : 1u;
+    double drift[7];
+    for (int i = 0; i < 7; ++i) {
+        js = lcg(js);
+        const double u1 = (double)(js >> 1) / 2147483647.5;
+        js = lcg(js);
+        const double u2 = (double)(js >> 1) / 2147483647.5;
+        const double r = sqrt(-2.0 * log(fmax(u1, 1e-30)));
+        drift[i] = 0.0004 * r * cos(6.28318530717958647692 * u2);
+    }
+    for (int i = 0; i < 7; ++i) {
+        const double freq = f0d * ratios[i];
+        const double phase_inc = 6.28318530717958647692 * freq / sr;
+        const double decay_per_sample = (decay[i] / 8.686) / sr;
+        rec[(VF_S + i) * 64] = 0.0;
+        rec[(VF_C + i) * 64] = 1.0;
+        rec[(VF_ENV + i) * 64] = 1.0;
+        rec[(VF_DRIFT + i) * 64] = drift[i];
+        rec[(VF_COS_INC + i) * 64] = cos(phase_inc);
+        rec[(VF_SIN_INC + i) * 64] = sin(phase_inc);
+        rec[(VF_PHASE_INC + i) * 64] = phase_inc;
+        rec[(VF_AMP + i) * 64] = amps[i];
+        rec[(VF_DECAY + i) * 64] = exp(-decay_per_sample);
+        rec[(VF_DRATE + i) * 64] = 0.0;
+        rec[(VF_DMULT + i) * 64] = 1.0;
+    }
+    const uint64_t ramp = sat_u64(round(onset_time * sr));
+    rec[VF_ONSET_N * 64] = bitsd(ramp);
+    rec[VF_ONSET_INC * 64] = ramp > 0 ? 3.14159265358979323846 / (double)ramp : 0.0;
+    rec[VF_ONSET_EXP * 64] = 1.0 + (1.0 - vel);
+    rec[VF_DRAMP * 64] = 0.0;
+    rec[VF_DCOUNT * 64] = 0.0;
+    rec[VF_SAMPLE * 64] = bitsd(0ull);
+    rec[VF_Q * 64] = 1.0;                                                            // pickup.rs:103-113
+    rec[VF_DS * 64] = corrected_ds;
+
+    // AttackNoise::new (hammer.rs:126-147) + RBJ constant-skirt band-pass (filters.rs:15-21)
+    rec[VF_NAMP * 64] = 0.025 * vel * vel;
+    {
+        const double center = clampd(f0d * 5.0, 200.0, 2000.0);
+        const double w0 = 2.0 * 3.14159265358979323846 * center / sr;
+        const double cw = cos(w0), sw = sin(w0);
+        const double alpha = sw / (2.0 * 0.7);
+        const double a0b = 1.0 + alpha;
+        rec[VF_NB0 * 64] = (sw / 2.0) / a0b;
+        rec[VF_NB1 * 64] = 0.0 / a0b;
+        rec[VF_NB2 * 64] = (-sw / 2.0) / a0b;
+        rec[VF_NA1 * 64] = (-2.0 * cw) / a0b;
+        rec[VF_NA2 * 64] = (1.0 - alpha) / a0b;
+        rec[VF_NS1 * 64] = 0.0;
+        rec[VF_NS2 * 64] = 0.0;
+    }
+    rec[VF_RNG * 64] = bitsd((uint64_t)js | ((uint64_t)seed << 32));
+    rec[VF_NCNT * 64] = bitsd((uint64_t)K->noise_len | (16ull << 32));
+    rec[VF_FLAGS * 64] = bitsd((uint64_t)0u | ((uint64_t)(uint32_t)note << 32));
+
+    // post-pickup gain: output_scale (tables.rs:489-533) x MLP level compensation (voice.rs:108-127)
+    const double HPF_FC = 2312.0;
+    const double f0 = nt[NT_F0 * 64 + ni];
+    const double f0_c4 = nt[NT_F0 * 64 + (60 - OW_MIDI_LO)];
+    const double vel_scale_c4 = pow(scurve, nt[NT_VEL_EXP * 64 + (60 - OW_MIDI_LO)]);
+    const double eff_ds = fmax(base_ds * vel_scale, 1e-6);
+    const double eff_ds_ref = fmax(0.85 * vel_scale_c4, 1e-6);
+    const double rms = pickup_rms_proxy(eff_ds, f0, HPF_FC);
+    const double rms_ref = pickup_rms_proxy(eff_ds_ref, f0_c4, HPF_FC);
+    const double flat_db = -20.0 * log10(rms / rms_ref);
+    const double eff_trim = nt[NT_TRIM * 64 + ni] * pow(vel, 1.3);
+    const double out_scale = pow(10.0, (-35.0 + flat_db + nt[NT_VOICING * 64 + ni] + eff_trim) / 20.0);
+    double comp = 1.0;
+    if (fabs(corr.ds - 1.0) > 1e-6) {
+        const double pb = pickup_rms_proxy(base_ds, f0, HPF_FC);
+        const double pc = pickup_rms_proxy(corrected_ds, f0, HPF_FC);
+        comp = (pc > 1e-10) ? sqrt(pb / pc) : 1.0;
+    }
+    rec[VF_GAIN * 64] = out_scale * comp;
+    rec[VF_STEAL * 64] = bitsd(0ull);
+}
+
+// reed.rs:191-216 on the record in memory
+__device__ inline void start_damper_lane(double* __restrict__ rec, const OwConsts* __restrict__ K) {
+    const uint64_t fl = dbits(rec[VF_FLAGS * 64]);
+    const int midi = (int)(fl >> 32);
+    if (midi >= 92) return;
+    const double sr = K->sr;
+    const double base_rate = fmax(55.0 * pow(2.0, ((double)midi - 60.0) / 24.0), 0.5);
+    double p3 = 1.0;
+    for (int m = 0; m < 7; ++m) {
+        const double rate = fmin(base_rate * p3, 2000.0) / sr;
+        rec[(VF_DRATE + m) * 64] = rate;
+        rec[(VF_DMULT + m) * 64] = exp(-rate);
+        p3 *= 3.0;
+    }
+    const double ramp_time = midi < 48 ? 0.050 : (midi < 72 ? 0.025 : 0.008);
+    rec[VF_DRAMP * 64] = ramp_time * sr;
+    rec[VF_DCOUNT * 64] = 0.0;
+    rec[VF_FLAGS * 64] = bitsd(((fl & 0xFFFFFFFF00000000ull) | 1ull));  // damper_active=1, ramp_done=0
+}
+
+// ------------------------------------------------------------------ per-sample voice state in registers
+struct VoiceRegs {
+    double s[7], c[7], env[7], drift[7], cos_inc[7], sin_inc[7], phase_inc[7], amp[7], decay[7];
+    double onset_inc, onset_exp, dramp, dcount, q, ds, gain;
+    double namp, nb0, nb1, nb2, na1, na2, ns1, ns2;
+    uint64_t sample, onset_n;
+    uint32_t jitter_state, noise_rng, noise_rem, noise_fade, flags, midi;
+
+    OW_DEV void load(const double* __restrict__ rec) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            s[i] = rec[(VF_S + i) * 64]; c[i] = rec[(VF_C + i) * 64]; env[i] = rec[(VF_ENV + i) * 64];
+            drift[i] = rec[(VF_DRIFT + i) * 64]; cos_inc[i] = rec[(VF_COS_INC + i) * 64]; sin_inc[i] = rec[(VF_SIN_INC + i) * 64];
+            phase_inc[i] = rec[(VF_PHASE_INC + i) * 64]; amp[i] = rec[(VF_AMP + i) * 64]; decay[i] = rec[(VF_DECAY + i) * 64];
+        }
+        onset_inc = rec[VF_ONSET_INC * 64]; onset_exp = rec[VF_ONSET_EXP * 64];
+        dramp = rec[VF_DRAMP * 64]; dcount = rec[VF_DCOUNT * 64];
+        q = rec[VF_Q * 64]; ds = rec[VF_DS * 64]; gain = rec[VF_GAIN * 64];
+        namp = rec[VF_NAMP * 64]; nb0 = rec[VF_NB0 * 64]; nb1 = rec[VF_NB1 * 64]; nb2 = rec[VF_NB2 * 64];
+        na1 = rec[VF_NA1 * 64]; na2 = rec[VF_NA2 * 64]; ns1 = rec[VF_NS1 * 64]; ns2 = rec[VF_NS2 * 64];
+        sample = dbits(rec[VF_SAMPLE * 64]); onset_n = dbits(rec[VF_ONSET_N * 64]);
+        const uint64_t r = dbits(rec[VF_RNG * 64]); jitter_state = (uint32_t)r; noise_rng = (uint32_t)(r >> 32);
+        const uint64_t n = dbits(rec[VF_NCNT * 64]); noise_rem = (uint32_t)n; noise_fade = (uint32_t)(n >> 32);
+        const uint64_t f = dbits(rec[VF_FLAGS * 64]); flags = (uint32_t)f; midi = (uint32_t)(f >> 32);
+    }
+    OW_DEV void store(double* __restrict__ rec) const {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            rec[(VF_S + i) * 64] = s[i]; rec[(VF_C + i) * 64] = c[i]; rec[(VF_ENV + i) * 64] = env[i];
+            rec[(VF_DRIFT + i) * 64] = drift[i];
+        }
+        rec[VF_DCOUNT * 64] = dcount; rec[VF_Q * 64] = q;
+        rec[VF_NAMP * 64] = namp; rec[VF_NS1 * 64] = ns1; rec[VF_NS2 * 64] = ns2;
+        rec[VF_SAMPLE * 64] = bitsd(sample);
+        rec[VF_RNG * 64] = bitsd((uint64_t)jitter_state | ((uint64_t)noise_rng << 32));
+        rec[VF_NCNT * 64] = bitsd((uint64_t)noise_rem | ((uint64_t)noise_fade << 32));
+        rec[VF_FLAGS * 64] = bitsd((uint64_t)flags | ((uint64_t)midi << 32));
+    }
+
+    // One sample of Voice::render (voice.rs:162-179): reed (reed.rs:223-305) + attack noise
+    // (hammer.rs:150-179) -> pickup (pickup.rs:130-149) -> x post_pickup_gain.
+    // `rec` is only touched for the damper tables (rare path: released voices).
+    OW_DEV double step(const double* __restrict__ rec, const OwConsts* __restrict__ K) {
+        if (flags & 1u) {  // damper_active
+            dcount += 1.0;
+            const double t = dcount;
+            if (!(flags & 2u)) {
+                if (t > dramp) flags |= 2u;
+                else {
+#pragma unroll
+                    for (int m = 0; m < 7; ++m) {
+                        const double inst_rate = rec[(VF_DRATE + m) * 64] * t / dramp;
+                        env[m] *= exp(-inst_rate);
+                    }
+                }
+            }
+            if (flags & 2u) {
+#pragma unroll
+                for (int m = 0; m < 7; ++m) env[m] *= rec[(VF_DMULT + m) * 64];
+            }
+        }
+        double onset = 1.0;
+        if (sample < onset_n) {
+            const double cosine = 0.5 * (1.0 - cos((double)sample * onset_inc));
+            if (onset_exp <= 1.001) onset = cosine;
+            else if (onset_exp >= 1.999) onset = cosine * cosine;
+            else onset = pow(cosine, onset_exp);
+        }
+        if ((sample & 15ull) == 0ull) {
+            const double revert = K->jitter_revert, diffusion = K->jitter_diffusion;
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                jitter_state = lcg(jitter_state);
+                const double u = (double)(jitter_state >> 1) / 2147483647.5;
+                const double noise = (u * 2.0 - 1.0) * 1.7320508080;
+                drift[m] = revert * drift[m] + diffusion * noise;
+            }
+        }
+        double sum = 0.0;
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            sum += amp[m] * s[m] * onset * env[m];
+            const double delta_phase = drift[m] * phase_inc[m];
+            const double ci = cos_inc[m] - delta_phase * sin_inc[m];
+            const double si = sin_inc[m] + delta_phase * cos_inc[m];
+            const double s_new = s[m] * ci + c[m] * si;
+            const double c_new = c[m] * ci - s[m] * si;
+            s[m] = s_new;
+            c[m] = c_new;
+            env[m] *= decay[m];
+        }
+        if ((sample & 1023ull) == 0ull && sample > 0ull) {
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                const double r_sq = s[m] * s[m] + c[m] * c[m];
+                const double r_inv = 1.0 / sqrt(r_sq);
+                s[m] *= r_inv;
+                c[m] *= r_inv;
+            }
+        }
+        sample += 1ull;
+        double x = 0.0 + sum;
+        if (noise_rem > 0u) {
+            double e = 1.0;
+            if (noise_fade > 0u) {
+                const uint32_t pos = 16u - noise_fade;
+                noise_fade -= 1u;
+                e = 0.5 * (1.0 - cos(3.14159265358979323846 * ((double)pos / 16.0)));
+            }
+            noise_rng = lcg(noise_rng);
+            const double nz = (double)(int32_t)noise_rng / 2147483647.0;
+            const double y = nb0 * nz + ns1;
+            ns1 = nb1 * nz - na1 * y + ns2;
+            ns2 = nb2 * nz - na2 * y;
+            x += namp * e * y;
+            namp *= K->noise_decay;
+            noise_rem -= 1u;
+        }
+        // pickup
+        double y = x * ds;
+        const double ay = fabs(y);
+        if (!(ay < 0.94)) {
+            const double range = 0.98 - 0.94;
+            y = copysign(0.94 + range * tanh((ay - 0.94) / range), y);
+        }
+        const double omy = 1.0 - y;
+        const double alpha = K->pickup_beta * omy;
+        const double q_next = (q * (1.0 - alpha) + 2.0 * K->pickup_beta) / (1.0 + alpha);
+        q = q_next;
+        return ((q_next * omy - 1.0) * 1.8375) * gain;
+    }
+
+    // Voice::is_silent (voice.rs:183-188, reed.rs:309-314); threshold 10^(-80/20)
+    OW_DEV bool is_silent(const OwConsts* __restrict__ K) const {
+        if ((flags & 1u) && (dcount / K->sr) > 10.0) return true;
+        bool all = true;
+#pragma unroll
+        for (int m = 0; m < 7; ++m) all = all && (fabs(amp[m] * env[m]) <= 1e-4);
+        return all;
+    }
+};
+
+}  // namespace owdev

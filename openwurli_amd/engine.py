@@ -1,0 +1,209 @@
+"""Host mirror of the reference's engine API over the C-ABI.
+
+Method names, argument meaning and error behaviour follow ``WurliEngine``
+(/root/reference/crates/openwurli-dsp/src/engine.rs:194-675) so that parity tests read like
+the reference's own engine tests.  Nothing here computes audio: every call forwards to
+``libopenwurli_hip.so``.
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import binding
+from .binding import OwDiag, OwError
+
+
+class VoiceState(enum.IntEnum):  # engine.rs:30-37
+    Free = 0
+    Held = 1
+    Sustained = 2
+    Releasing = 3
+
+
+class _EngineHandle:
+    """Methods shared by a pool-of-one ``WurliEngine`` and the engines of an ``EnginePool``."""
+
+    def __init__(self, lib, handle):
+        self._lib = lib
+        self._h = C.c_void_p(handle)
+
+    # ---- MIDI (engine.rs:299-374)
+    def note_on(self, note, velocity):
+        self._lib.ow_engine_note_on(self._h, int(note) & 0xFF, float(velocity))
+
+    def note_off(self, note):
+        self._lib.ow_engine_note_off(self._h, int(note) & 0xFF)
+
+    def set_sustain(self, held):
+        self._lib.ow_engine_set_sustain(self._h, 1 if held else 0)
+
+    # ---- params (engine.rs:378-400)
+    def set_volume(self, v):
+        self._lib.ow_engine_set_volume(self._h, float(v))
+
+    def set_tremolo_depth(self, d):
+        self._lib.ow_engine_set_tremolo_depth(self._h, float(d))
+
+    def set_speaker_character(self, c):
+        self._lib.ow_engine_set_speaker_character(self._h, float(c))
+
+    def set_mlp_enabled(self, on):
+        self._lib.ow_engine_set_mlp_enabled(self._h, 1 if on else 0)
+
+    def set_noise_enabled(self, on):
+        self._lib.ow_engine_set_noise_enabled(self._h, 1 if on else 0)
+
+    def set_noise_gain(self, g):
+        self._lib.ow_engine_set_noise_gain(self._h, float(g))
+
+    def reset(self):
+        self._lib.ow_engine_reset(self._h)
+
+    def warm_up(self):
+        self._lib.ow_engine_warm_up(self._h)
+
+    # ---- introspection (engine.rs:606-675)
+    def diag(self):
+        d = OwDiag()
+        self._lib.ow_engine_get_diag(self._h, C.byref(d))
+        return d
+
+    def active_voice_count(self):
+        return self.diag().active_voices
+
+    def held_voice_count(self):
+        return self.diag().held_voices
+
+    def sustained_voice_count(self):
+        return self.diag().sustained_voices
+
+    def count_voices_in_state(self, state):
+        return sum(1 for s in range(64) if self._lib.ow_engine_slot_state(self._h, s) == int(state))
+
+    def count_voices_with_note_in_state(self, note, state):
+        return sum(1 for s in range(64)
+                   if self._lib.ow_engine_slot_state(self._h, s) == int(state)
+                   and self._lib.ow_engine_slot_note(self._h, s) == int(note))
+
+    def has_steal_voice_for(self, note):
+        return bool(self._lib.ow_engine_has_steal_voice_for(self._h, int(note) & 0xFF))
+
+    def nan_guard_fires(self):
+        return self.diag().nan_guard_fires
+
+    def is_sustain_held(self):
+        return bool(self.diag().sustain_held)
+
+
+class WurliEngine(_EngineHandle):
+    """One engine on one GPU (a pool of one).  ``WurliEngine(sr)`` == ``WurliEngine::new(sr)``."""
+
+    def __init__(self, sample_rate, device=0, preamp_kind=0):
+        lib = binding.load_library()
+        h = lib.ow_engine_new(float(sample_rate), int(device), int(preamp_kind))
+        if not h:
+            raise OwError(binding.last_error(lib))
+        super().__init__(lib, h)
+
+    def close(self):
+        if self._h:
+            self._lib.ow_engine_free(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_sample_rate(self, sr):
+        self._lib.ow_engine_set_sample_rate(self._h, float(sr))
+
+    def ensure_buffer_capacity(self, n):
+        self._lib.ow_engine_ensure_buffer_capacity(self._h, int(n))
+
+    def render(self, out):
+        """``engine.render(&mut out)``: ``out`` is a writable 1-D float32 numpy array, or a length."""
+        if isinstance(out, (int, np.integer)):
+            out = np.zeros(int(out), dtype=np.float32)
+        assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"]
+        self._lib.ow_engine_render(self._h, out.ctypes.data_as(C.c_void_p), out.size)
+        return out
+
+
+class EnginePool:
+    """I independent engines rendered in lock-step (lane = engine on the GPU)."""
+
+    def __init__(self, sample_rate, n_engines, device=0, preamp_kind=0):
+        self._lib = binding.load_library()
+        h = self._lib.ow_pool_new(float(sample_rate), int(n_engines), int(device), int(preamp_kind))
+        if not h:
+            raise OwError(binding.last_error(self._lib))
+        self._h = C.c_void_p(h)
+        self.n = int(n_engines)
+        self.engines = [_EngineHandle(self._lib, self._lib.ow_pool_engine(self._h, i)) for i in range(self.n)]
+
+    def close(self):
+        if self._h:
+            self._lib.ow_pool_free(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __getitem__(self, i):
+        return self.engines[i]
+
+    def set_sample_rate(self, sr):
+        if self._lib.ow_pool_set_sample_rate(self._h, float(sr)) != 0:
+            raise OwError(binding.last_error(self._lib))
+
+    def reset(self):
+        self._lib.ow_pool_reset(self._h)
+
+    def ensure_buffer_capacity(self, n):
+        self._lib.ow_pool_ensure_buffer_capacity(self._h, int(n))
+
+    def render(self, length, to_host=True):
+        """Render ``length`` samples on every engine; returns float32 [n, length] (or None if left in HBM)."""
+        if to_host:
+            out = np.zeros((self.n, int(length)), dtype=np.float32)
+            self._lib.ow_pool_render(self._h, out.ctypes.data_as(C.c_void_p), int(length), int(length))
+            return out
+        self._lib.ow_pool_render(self._h, None, 0, int(length))
+        return None
+
+    def voice_sum(self, length):
+        out = np.zeros((self.n, int(length)), dtype=np.float64)
+        if self._lib.ow_pool_read_voice_sum(self._h, out.ctypes.data_as(C.c_void_p), int(length), int(length)) != 0:
+            raise OwError(binding.last_error(self._lib))
+        return out
+
+    def set_profiling(self, on):
+        self._lib.ow_pool_set_profiling(self._h, 1 if on else 0)
+
+    def last_kernel_ms(self):
+        ms = (C.c_float * 5)()
+        self._lib.ow_pool_last_kernel_ms(self._h, ms)
+        return dict(zip(("ops", "voices", "tremolo", "preamp", "post"), [float(x) for x in ms]))
+
+    def device_output(self):
+        stride = C.c_size_t(0)
+        ptr = self._lib.ow_pool_device_output(self._h, C.byref(stride))
+        return ptr, stride.value
+
+
+def render_note(midi_note, velocity, duration_secs, sample_rate, device=0):
+    """``Voice::render_note`` (voice.rs:191-199): one voice, reed + pickup only, float64."""
+    lib = binding.load_library()
+    n = int(duration_secs * sample_rate)
+    out = np.zeros(max(n, 1), dtype=np.float64)
+    got = lib.ow_render_note(int(midi_note) & 0xFF, float(velocity), float(duration_secs), float(sample_rate), int(device),
+                             out.ctypes.data_as(C.c_void_p), out.size)
+    if got < 0:
+        raise OwError(binding.last_error(lib))
+    return out[:got]

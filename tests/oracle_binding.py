@@ -1,0 +1,119 @@
+"""ctypes wrapper of the CPU ORACLE (oracle/_build/libow_oracle.so).
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_PATH = os.path.join(_ROOT, "oracle", "_build", "libow_oracle.so")
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle")])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_PATH):
+            build()
+        L = C.CDLL(_PATH)
+        L.owo_engine_new.restype = C.c_void_p
+        for name in ("owo_midi_to_freq", "owo_tip_mass_ratio", "owo_reed_length_mm", "owo_pickup_displacement_scale",
+                     "owo_fundamental_decay_rate", "owo_output_scale", "owo_velocity_exponent", "owo_velocity_scurve",
+                     "owo_register_trim_db", "owo_pickup_rms_proxy", "owo_freq_detune", "owo_dwell_time", "owo_onset_ramp_time",
+                     "owo_pickup_soft_saturate", "owo_fast_exp", "owo_power_amp"):
+            getattr(L, name).restype = C.c_double
+        L.owo_render_note.restype = C.c_size_t
+        L.owo_batch_render_job.restype = C.c_size_t
+        L.owo_engine_nan_guard_fires.restype = C.c_ulonglong
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleEngine:
+    """CPU restatement of WurliEngine with the reference's method names."""
+
+    def __init__(self, sr):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.owo_engine_new(C.c_double(sr)))
+
+    def close(self):
+        if self.h:
+            self.L.owo_engine_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_sample_rate(self, sr): self.L.owo_engine_set_sample_rate(self.h, C.c_double(sr))
+    def reset(self): self.L.owo_engine_reset(self.h)
+    def warm_up(self): self.L.owo_engine_warm_up(self.h)
+    def note_on(self, n, v): self.L.owo_engine_note_on(self.h, int(n), C.c_float(v))
+    def note_off(self, n): self.L.owo_engine_note_off(self.h, int(n))
+    def set_sustain(self, h): self.L.owo_engine_set_sustain(self.h, 1 if h else 0)
+    def set_volume(self, v): self.L.owo_engine_set_volume(self.h, C.c_double(v))
+    def set_tremolo_depth(self, v): self.L.owo_engine_set_tremolo_depth(self.h, C.c_double(v))
+    def set_speaker_character(self, v): self.L.owo_engine_set_speaker_character(self.h, C.c_double(v))
+    def set_mlp_enabled(self, on): self.L.owo_engine_set_mlp_enabled(self.h, 1 if on else 0)
+
+    def render(self, n):
+        out = np.zeros(int(n), dtype=np.float32)
+        self.L.owo_engine_render(self.h, _p(out), C.c_size_t(int(n)))
+        return out
+
+    def render_tap(self, n):
+        out = np.zeros(int(n), dtype=np.float32)
+        vs = np.zeros(int(n), dtype=np.float64)
+        self.L.owo_engine_render_tap(self.h, _p(out), _p(vs), C.c_size_t(int(n)))
+        return out, vs
+
+    def count_voices_in_state(self, st): return self.L.owo_engine_count_state(self.h, int(st))
+    def active_voice_count(self): return self.L.owo_engine_active_voice_count(self.h)
+    def steal_voice_count(self): return self.L.owo_engine_steal_voice_count(self.h)
+    def nan_guard_fires(self): return self.L.owo_engine_nan_guard_fires(self.h)
+    def slot_state(self, s): return self.L.owo_engine_slot_state(self.h, int(s))
+    def slot_note(self, s): return self.L.owo_engine_slot_note(self.h, int(s))
+
+
+def render_note(midi, vel, dur, sr):
+    n = int(dur * sr)
+    out = np.zeros(max(n, 1))
+    got = lib().owo_render_note(int(midi), C.c_double(vel), C.c_double(dur), C.c_double(sr), _p(out), C.c_size_t(out.size))
+    return out[:got]
+
+
+def batch_render_job(note, vel_u8, dur, sr, volume=1.0, speaker=0.0, r_ldr=1e6, mlp=False, poweramp=False):
+    n = int(dur * sr)
+    out = np.zeros(max(n, 1))
+    got = lib().owo_batch_render_job(int(note), int(vel_u8), C.c_double(dur), C.c_double(sr), C.c_double(volume), C.c_double(speaker),
+                                     C.c_double(r_ldr), 1 if mlp else 0, 1 if poweramp else 0, _p(out), C.c_size_t(out.size))
+    return out[:got]
+
+
+def parity_report(gpu, cpu, rel=1e-5, floor_frac=1e-3):
+    """SURVEY.md 8d parity metric: |gpu-cpu| <= rel * max(|cpu|, floor_frac * peak|cpu|)."""
+    gpu = np.asarray(gpu, dtype=np.float64)
+    cpu = np.asarray(cpu, dtype=np.float64)
+    peak = float(np.max(np.abs(cpu))) if cpu.size else 0.0
+    tol = rel * np.maximum(np.abs(cpu), floor_frac * peak)
+    err = np.abs(gpu - cpu)
+    bad = np.nonzero(err > tol)[0]
+    return {
+        "peak": peak,
+        "max_abs_err": float(err.max()) if err.size else 0.0,
+        "max_err_rel_peak": float(err.max() / peak) if peak > 0 else 0.0,
+        "worst_ratio": float(np.max(err / np.maximum(tol, 1e-300))) if err.size else 0.0,
+        "n_bad": int(bad.size),
+        "first_bad": int(bad[0]) if bad.size else -1,
+    }
