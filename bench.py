@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Throughput bench of the OpenWurli DSP hot path on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d config 2, scaled out per configs[4]):
+  I independent engine instances per GPU, each 64 voices (all keys 33..96 struck at t=0,
+  note_off+note_on re-strike of all 64 every 1.0 s so that 64 voices stay alive), 48 kHz host
+  rate (2x oversampled chain at 96 kHz), full chain: tremolo + legacy DK preamp + behavioural
+  power amp + speaker, volume 0.5, tremolo depth 0.5, MLP on, buffers of 512 samples, events
+  split sample-accurately like the plugin does (plugin/src/lib.rs:128-149).
+  Instance k plays velocity (40 + (37 k mod 88))/127 (config 5 decorrelation).
+
+One "step" = one 512-sample buffer rendered by every instance of every rank.  `value` =
+output samples per second over all instances of all ranks (weak scaling: I per GPU fixed).
+The rendered audio stays in HBM (inputs resident, no PCIe in the timed region except the
+per-step event list and the 32-byte-per-engine status block the host state machine needs).
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the roofline arithmetic.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SR = 48000.0
+BUF = 512
+EPOCH = 48000          # re-strike period in samples
+NOTES = list(range(33, 97))
+
+# Algorithmic f64 flops per OUTPUT sample of one 64-voice engine (restated in DESIGN.md):
+FLOPS_VOICES = 64 * 130            # 7 modes x 16 + jitter 3 + pickup 13 + gain/sum 2 per voice-sample
+FLOPS_TREMOLO = 2 * (1000 + 25)    # Twin-T NR step + LDR law per OS sample, 2 OS samples
+FLOPS_PREAMP = 2 * 1400 + 24       # main+shadow dk_step per OS sample + half-band up
+FLOPS_POST = 2 * 90 + 24 + 45      # power amp x2 + half-band down + speaker/gain
+FLOPS_PER_SAMPLE = FLOPS_VOICES + FLOPS_TREMOLO + FLOPS_PREAMP + FLOPS_POST
+PEAK_FP64_VALU_TFLOPS = 78.6       # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (MI355X FP64 vector)
+
+
+def instance_velocity(k):
+    return (40 + (37 * k) % 88) / 127.0
+
+
+def build_events(n_inst, kind):
+    """kind 'strike' = note_on all keys; 'restrike' = note_off then note_on per key (config 2)."""
+    from openwurli_amd import binding
+    per = len(NOTES) * (2 if kind == "restrike" else 1)
+    ev = np.zeros(n_inst * per, dtype=np.dtype(binding.MIDI_DTYPE))
+    i = 0
+    for k in range(n_inst):
+        v = instance_velocity(k)
+        for n in NOTES:
+            if kind == "restrike":
+                ev[i] = (k, 1, n, 0, 0.0)
+                i += 1
+            ev[i] = (k, 0, n, 0, v)
+            i += 1
+    return ev
+
+
+class Script:
+    """Sample-accurate event script: renders one 512-sample step, splitting at epoch boundaries."""
+
+    def __init__(self, pool, n_inst):
+        self.pool = pool
+        self.pos = 0
+        self.ev_strike = build_events(n_inst, "strike")
+        self.ev_restrike = build_events(n_inst, "restrike")
+        self.kernel_ms = np.zeros(5)
+        self.kernel_launches = 0
+
+    def step(self, profile=False):
+        done = 0
+        while done < BUF:
+            if self.pos % EPOCH == 0:
+                self.pool.midi(self.ev_strike if self.pos == 0 else self.ev_restrike)
+            nxt = min(BUF - done, EPOCH - (self.pos % EPOCH))
+            self.pool.render(nxt, to_host=False)
+            if profile:
+                ms = self.pool.last_kernel_ms()
+                self.kernel_ms += np.array([ms["ops"], ms["voices"], ms["tremolo"], ms["preamp"], ms["post"]]) * (nxt / BUF)
+            self.pos += nxt
+            done += nxt
+        if profile:
+            self.kernel_launches += 1
+
+
+def cpu_baseline(seconds_audio=1.0):
+    """Oracle (CPU restatement, kind 'port') on the host cores: one cfg-2 instance per thread."""
+    import oracle_binding as ob
+    ob.lib()
+    cores = os.cpu_count() or 1
+    n = int(SR * seconds_audio)
+
+    def work(k, out):
+        e = ob.OracleEngine(SR)
+        e.set_volume(0.5); e.set_tremolo_depth(0.5); e.set_speaker_character(0.0); e.set_mlp_enabled(True)
+        for nn in NOTES:
+            e.note_on(nn, instance_velocity(k))
+        t0 = time.perf_counter()
+        done = 0
+        while done < n:
+            e.render(BUF)
+            done += BUF
+        out[k] = (done, time.perf_counter() - t0)
+        e.close()
+
+    # single thread first (the reference's own single-thread design)
+    r1 = {}
+    work(0, r1)
+    single = r1[0][0] / r1[0][1]
+    res = {}
+    th = [threading.Thread(target=work, args=(k, res)) for k in range(cores)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    total = sum(v[0] for v in res.values())
+    return {
+        "value": total / wall, "unit": "samples/s", "cores": cores, "kind": "port",
+        "sample": f"{cores} threads x 1 cfg-2 instance (64 voices, full chain) x {seconds_audio:.1f} s audio, buffers of {BUF}; "
+                  f"oracle = C++ f64 restatement (reference Rust is not buildable in this image)",
+        "single_thread_value": single,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--instances", type=int, default=int(os.environ.get("OW_BENCH_INSTANCES", "4096")), help="engine instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    import openwurli_amd as ow
+    n_inst = args.instances
+    pool = ow.EnginePool(SR, n_inst, device=local_rank)
+    pool.set_sample_rate(SR)          # the plugin's initialize(): chain build + 0.6 s warm-up (not timed)
+    pool.ensure_buffer_capacity(BUF)
+    for k in range(n_inst):
+        e = pool[k]
+        e.set_volume(0.5); e.set_tremolo_depth(0.5); e.set_speaker_character(0.0); e.set_mlp_enabled(True)
+    script = Script(pool, n_inst)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        script.step()
+    pool.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        script.step(profile=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    pool.set_profiling(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # single-instance latency figure (what one plugin instance would see), rank 0 only, not part of `value`
+    single = None
+    cpu = None
+    if rank == 0:
+        one = ow.EnginePool(SR, 1, device=local_rank)
+        one.set_sample_rate(SR)
+        s1 = Script(one, 1)
+        for _ in range(3):
+            s1.step()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            s1.step()
+        single = 20 * BUF / (time.perf_counter() - t1)
+        one.close()
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+
+    if rank == 0:
+        total_samples = args.steps * BUF * n_inst * world
+        value = total_samples / elapsed
+        kms = script.kernel_ms / max(script.kernel_launches, 1)     # average ms per step, per kernel
+        names = ["ops", "voices", "tremolo", "preamp", "post"]
+        flops = {"ops": 0.0, "voices": FLOPS_VOICES, "tremolo": FLOPS_TREMOLO, "preamp": FLOPS_PREAMP, "post": FLOPS_POST}
+        dom = names[int(np.argmax(kms))]
+        dom_ms = float(kms[names.index(dom)])
+        achieved = flops[dom] * BUF * n_inst / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                if tj.get("instances") == n_inst:
+                    traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "audio samples/s, 64-voice full chain (x real-time @48 kHz = value / 48000)",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "cfg2: 64-voice all-keys-sustained (1.0 s re-strike), 48 kHz host / 96 kHz chain, full chain "
+                            "(tremolo+legacy DK preamp+behavioural power amp+speaker), MLP on, buffers of 512",
+                "instances_per_gpu": n_inst, "buffer": BUF, "parallelism": f"{world} x independent pools (no data-path collective)",
+            },
+            "x_realtime_aggregate": value / SR,
+            "single_instance_samples_per_s": single,
+            "roofline": {
+                "bound": "valu_f64", "kernel": "k_" + ("voice" if dom == "voices" else dom), "achieved": achieved,
+                "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
+                "kernel_ms_per_step": {n: float(k) for n, k in zip(names, kms)},
+                "whole_chain_frac": FLOPS_PER_SAMPLE * value / world / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                "note": "path is FP64-VALU/latency bound (not HBM, not MFMA); achieved = algorithmic f64 flops of the dominant "
+                        "kernel per launch / its HIP-event duration",
+            },
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    pool.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

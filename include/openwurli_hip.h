@@ -61,10 +61,23 @@ void ow_pool_ensure_buffer_capacity(ow_pool*, size_t max_samples);
 /* Render `len` samples on every engine.  out_host: [n_engines][out_stride] f32 (out_stride >= len) or NULL to
  * leave the block in HBM (see ow_pool_device_output).  Blocking; never fails. */
 void ow_pool_render(ow_pool*, float* out_host, size_t out_stride, size_t len);
+/* Sample-accurate MIDI for many engines in one call: the plugin's handle_event (plugin/src/lib.rs:49-62)
+ * applied in array order.  type 0 = NoteOn(note, value=velocity 0..1), 1 = NoteOff(note), 2 = sustain (value >= 0.5 = held). */
+typedef struct ow_midi_event {
+    uint32_t engine;
+    uint8_t type;
+    uint8_t note;
+    uint16_t reserved;
+    float value;
+} ow_midi_event;
+void ow_pool_midi(ow_pool*, const ow_midi_event* events, size_t n_events);
 /* Device pointer of the last rendered block, f32 [n_engines][*stride]. */
 const float* ow_pool_device_output(const ow_pool*, size_t* stride);
 /* Stage-wise taps of the last rendered block, copied to host (parity tests): voice sum f64 [n_engines][len]. */
 int ow_pool_read_voice_sum(ow_pool*, double* out_host, size_t out_stride, size_t len);
+/* Preamp output (main - shadow, before the power amp) of the last block at the chain rate: f64 [n_engines][n_os],
+ * n_os = len * (oversampled ? 2 : 1). */
+int ow_pool_read_preamp_out(ow_pool*, double* out_host, size_t out_stride, size_t n_os);
 /* HIP stream the pool launches on (hipStream_t as void*), for event timing by the caller. */
 void* ow_pool_stream(ow_pool*);
 /* Time (ms, HIP events on the pool stream) each kernel of the last ow_pool_render took:

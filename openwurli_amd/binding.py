@@ -24,6 +24,13 @@ class OwJob(C.Structure):
                 ("volume", C.c_double), ("speaker", C.c_double), ("r_ldr", C.c_double)]
 
 
+class OwMidiEvent(C.Structure):
+    _fields_ = [("engine", C.c_uint32), ("type", C.c_uint8), ("note", C.c_uint8), ("reserved", C.c_uint16), ("value", C.c_float)]
+
+
+MIDI_DTYPE = [("engine", "<u4"), ("type", "u1"), ("note", "u1"), ("reserved", "<u2"), ("value", "<f4")]
+
+
 class OwBatchCfg(C.Structure):
     _fields_ = [("sample_rate", C.c_double), ("duration_s", C.c_double), ("device", C.c_int), ("preamp_kind", C.c_int)]
 
@@ -40,8 +47,10 @@ SYMBOLS = {
     "ow_pool_reset": (None, [_VP]),
     "ow_pool_ensure_buffer_capacity": (None, [_VP, C.c_size_t]),
     "ow_pool_render": (None, [_VP, _VP, C.c_size_t, C.c_size_t]),
+    "ow_pool_midi": (None, [_VP, _VP, C.c_size_t]),
     "ow_pool_device_output": (_VP, [_VP, C.POINTER(C.c_size_t)]),
     "ow_pool_read_voice_sum": (C.c_int, [_VP, _VP, C.c_size_t, C.c_size_t]),
+    "ow_pool_read_preamp_out": (C.c_int, [_VP, _VP, C.c_size_t, C.c_size_t]),
     "ow_pool_stream": (_VP, [_VP]),
     "ow_pool_set_profiling": (None, [_VP, C.c_int]),
     "ow_pool_last_kernel_ms": (None, [_VP, C.POINTER(C.c_float)]),

@@ -445,6 +445,19 @@ int ow_pool_read_voice_sum(ow_pool* p, double* out_host, size_t out_stride, size
     } catch (const std::exception& ex) { set_err(std::string("ow_pool_read_voice_sum: ") + ex.what()); return -1; }
 }
 
+int ow_pool_read_preamp_out(ow_pool* p, double* out_host, size_t out_stride, size_t n_os) {
+    if (!p || !out_host || n_os > 2 * p->Lcap) return -1;
+    try {
+        HIP_OK(hipSetDevice(p->device));
+        const size_t I = p->I;
+        std::vector<double> a(I * n_os);
+        HIP_OK(hipMemcpy(a.data(), p->d_pre, sizeof(double) * I * n_os, hipMemcpyDeviceToHost));  // [n_os][I]
+        for (size_t e = 0; e < I; ++e)
+            for (size_t n = 0; n < n_os; ++n) out_host[e * out_stride + n] = a[n * I + e];
+        return 0;
+    } catch (const std::exception& ex) { set_err(std::string("ow_pool_read_preamp_out: ") + ex.what()); return -1; }
+}
+
 // ---- engines ------------------------------------------------------------------------------------
 ow_engine* ow_engine_new(double sample_rate, int device, int preamp_kind) {
     ow_pool* p = ow_pool_new(sample_rate, 1, device, preamp_kind);
@@ -585,6 +598,20 @@ int ow_engine_has_steal_voice_for(const ow_engine* e, uint8_t note) {
     if (!e) return 0;
     for (const Slot& s : e->slots) if (s.midi == note && s.has_steal) return 1;
     return 0;
+}
+
+void ow_pool_midi(ow_pool* p, const ow_midi_event* ev, size_t n) {
+    if (!p || !ev) return;
+    for (size_t i = 0; i < n; ++i) {
+        if (ev[i].engine >= p->I) continue;
+        ow_engine* e = p->engines[ev[i].engine];
+        switch (ev[i].type) {
+            case 0: ow_engine_note_on(e, ev[i].note, ev[i].value); break;
+            case 1: ow_engine_note_off(e, ev[i].note); break;
+            case 2: ow_engine_set_sustain(e, ev[i].value >= 0.5f); break;
+            default: break;
+        }
+    }
 }
 
 // ---- offline ------------------------------------------------------------------------------------

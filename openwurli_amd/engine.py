@@ -177,9 +177,20 @@ class EnginePool:
         self._lib.ow_pool_render(self._h, None, 0, int(length))
         return None
 
+    def midi(self, events):
+        """Apply a numpy structured array of events (dtype binding.MIDI_DTYPE) in order."""
+        ev = np.ascontiguousarray(events, dtype=np.dtype(binding.MIDI_DTYPE))
+        self._lib.ow_pool_midi(self._h, ev.ctypes.data_as(C.c_void_p), ev.size)
+
     def voice_sum(self, length):
         out = np.zeros((self.n, int(length)), dtype=np.float64)
         if self._lib.ow_pool_read_voice_sum(self._h, out.ctypes.data_as(C.c_void_p), int(length), int(length)) != 0:
+            raise OwError(binding.last_error(self._lib))
+        return out
+
+    def preamp_out(self, n_os):
+        out = np.zeros((self.n, int(n_os)), dtype=np.float64)
+        if self._lib.ow_pool_read_preamp_out(self._h, out.ctypes.data_as(C.c_void_p), int(n_os), int(n_os)) != 0:
             raise OwError(binding.last_error(self._lib))
         return out
 

@@ -95,13 +95,20 @@ inline void stamp_resistor(Mat8 g, int i, int j, double r) {  // :641-647
 inline void stamp_capacitor(Mat8 c, int i, int j, double cap) {  // :649-654
     c[i][i] += cap; c[j][j] += cap; c[i][j] -= cap; c[j][i] -= cap;
 }
+// OW_ORACLE_EXP_PERTURB builds a sensitivity variant whose BJT exp() is off by one ulp: it measures how far the
+// reference algorithm's own output moves under a libm that differs in the last bit (tests/test_oracle_sensitivity.py).
+#ifdef OW_ORACLE_EXP_PERTURB
+inline double bjt_exp(double x) { return std::exp(x) * (1.0 + 2.2e-16); }
+#else
+inline double bjt_exp(double x) { return std::exp(x); }
+#endif
 inline double bjt_ic(double vbe) {  // :663-666
     const double v = rclamp(vbe, -1.0, VBE_MAX);
-    return IS * (std::exp(v / VT) - 1.0);
+    return IS * (bjt_exp(v / VT) - 1.0);
 }
 inline void bjt_ic_gm(double vbe, double& ic, double& gm) {  // :686-690
     const double v = rclamp(vbe, -1.0, VBE_MAX);
-    const double e = std::exp(v / VT);
+    const double e = bjt_exp(v / VT);
     ic = IS * (e - 1.0);
     gm = IS_OVER_VT * e;
 }

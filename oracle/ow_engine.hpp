@@ -237,6 +237,8 @@ struct WurliEngine {
 
     // engine.rs:466-567.  `voice_sum_tap` (optional) receives sum_buf (pre-chain) for parity tests.
     double* voice_sum_tap = nullptr;
+    double* preamp_tap = nullptr;   // optional: preamp output per chain-rate sample (before the power amp)
+    double* r_tap = nullptr;        // optional: tremolo shunt R per chain-rate sample
     void render_voices_to_preamp_out(size_t offset, size_t len) {
         for (size_t i = 0; i < len; ++i) sum_buf[i] = 0.0;
         for (auto& slot : voices) {
@@ -292,6 +294,8 @@ struct WurliEngine {
                     const double r = tremolo.process();
                     preamp.set_ldr_resistance(r);
                     const double pre = preamp.process_sample(up_buf[idx]);
+                    if (preamp_tap) preamp_tap[idx] = pre;
+                    if (r_tap) r_tap[idx] = r;
                     up_buf[idx] = power_amp.process(pre * FIXED_CIRCUIT_DRIVE);
                 }
             }
@@ -303,6 +307,8 @@ struct WurliEngine {
                 const double r = tremolo.process();
                 preamp.set_ldr_resistance(r);
                 const double pre = preamp.process_sample(sum_buf[i]);
+                if (preamp_tap) preamp_tap[i] = pre;
+                if (r_tap) r_tap[i] = r;
                 out_buf[offset + i] = power_amp.process(pre * FIXED_CIRCUIT_DRIVE);
             }
         }

@@ -37,6 +37,13 @@ void owo_engine_render_tap(void* e, float* out, double* voice_sum, size_t len) {
     en->render(out, len);
     en->voice_sum_tap = nullptr;
 }
+// render + taps: voice sum [len], preamp out [len*osr], tremolo R [len*osr] (any may be null)
+void owo_engine_render_taps(void* e, float* out, double* voice_sum, double* preamp_out, double* r_out, size_t len) {
+    WurliEngine* en = (WurliEngine*)e;
+    en->voice_sum_tap = voice_sum; en->preamp_tap = preamp_out; en->r_tap = r_out;
+    en->render(out, len);
+    en->voice_sum_tap = nullptr; en->preamp_tap = nullptr; en->r_tap = nullptr;
+}
 int owo_engine_count_state(void* e, int st) { return ((WurliEngine*)e)->count_state(st); }
 int owo_engine_active_voice_count(void* e) { return ((WurliEngine*)e)->active_voice_count(); }
 int owo_engine_steal_voice_count(void* e) { return ((WurliEngine*)e)->steal_voice_count(); }

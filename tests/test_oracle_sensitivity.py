@@ -1,0 +1,30 @@
+"""Measures the reference ALGORITHM's own indeterminacy on the CPU oracle: the legacy preamp's Newton loop stops at
+|f| < 1e-9 V (dk_preamp_legacy.rs:500), and the shadow solver's warm start "sticks" until its residual crosses that
+threshold.  A libm whose exp() differs in the last bit therefore moves the output by a few 1e-10 -- independent of
+signal level.  This is the absolute floor the GPU parity tests add to the 1e-5 relative bar."""
+import numpy as np
+
+
+def _run(oracle, perturbed):
+    e = oracle.OracleEngine(48000.0, perturbed=perturbed)
+    e.set_volume(0.5); e.set_tremolo_depth(0.5); e.set_speaker_character(0.0); e.set_mlp_enabled(True)
+    for n in (45, 60, 64, 79):
+        e.note_on(n, 0.8)
+    outs, pres = [], []
+    for _ in range(16):
+        o, _, p, _ = e.render_taps(256)
+        outs.append(o.astype(np.float64)); pres.append(p)
+    e.close()
+    return np.concatenate(outs), np.concatenate(pres)
+
+
+def test_one_ulp_exp_moves_the_reference_by_less_than_the_floor(oracle):
+    o0, p0 = _run(oracle, False)
+    o1, p1 = _run(oracle, True)
+    d_out = np.max(np.abs(o1 - o0))
+    d_pre = np.max(np.abs(p1 - p0))
+    assert d_pre > 1e-12          # the effect exists (it is not rounding noise of ~1e-16 * 8 V)
+    assert d_pre < oracle.ABS_FLOOR_PREAMP, d_pre
+    assert d_out < oracle.ABS_FLOOR_OUTPUT, d_out
+    # and it is tiny against the 1e-5 relative bar at musical level
+    assert d_out / np.max(np.abs(o0)) < 1e-5 * 1e-1
