@@ -50,18 +50,22 @@ def instance_velocity(k):
 def build_events(n_inst, kind):
     """kind 'strike' = note_on all keys; 'restrike' = note_off then note_on per key (config 2)."""
     from openwurli_amd import binding
+    notes = np.array(NOTES, dtype=np.uint8)
+    vel = np.array([instance_velocity(k) for k in range(n_inst)], dtype=np.float32)
     per = len(NOTES) * (2 if kind == "restrike" else 1)
-    ev = np.zeros(n_inst * per, dtype=np.dtype(binding.MIDI_DTYPE))
-    i = 0
-    for k in range(n_inst):
-        v = instance_velocity(k)
-        for n in NOTES:
-            if kind == "restrike":
-                ev[i] = (k, 1, n, 0, 0.0)
-                i += 1
-            ev[i] = (k, 0, n, 0, v)
-            i += 1
-    return ev
+    ev = np.zeros((n_inst, per), dtype=np.dtype(binding.MIDI_DTYPE))
+    ev["engine"] = np.arange(n_inst, dtype=np.uint32)[:, None]
+    if kind == "restrike":
+        ev["type"][:, 0::2] = 1
+        ev["note"][:, 0::2] = notes[None, :]
+        ev["type"][:, 1::2] = 0
+        ev["note"][:, 1::2] = notes[None, :]
+        ev["value"][:, 1::2] = vel[:, None]
+    else:
+        ev["type"] = 0
+        ev["note"] = notes[None, :]
+        ev["value"] = vel[:, None]
+    return ev.reshape(-1)
 
 
 class Script:
@@ -74,14 +78,20 @@ class Script:
         self.ev_restrike = build_events(n_inst, "restrike")
         self.kernel_ms = np.zeros(5)
         self.kernel_launches = 0
+        self.t_midi = 0.0
+        self.t_render = 0.0
 
     def step(self, profile=False):
         done = 0
         while done < BUF:
+            t0 = time.perf_counter()
             if self.pos % EPOCH == 0:
                 self.pool.midi(self.ev_strike if self.pos == 0 else self.ev_restrike)
+            t1 = time.perf_counter()
             nxt = min(BUF - done, EPOCH - (self.pos % EPOCH))
             self.pool.render(nxt, to_host=False)
+            self.t_midi += t1 - t0
+            self.t_render += time.perf_counter() - t1
             if profile:
                 ms = self.pool.last_kernel_ms()
                 self.kernel_ms += np.array([ms["ops"], ms["voices"], ms["tremolo"], ms["preamp"], ms["post"]]) * (nxt / BUF)
@@ -137,7 +147,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--instances", type=int, default=int(os.environ.get("OW_BENCH_INSTANCES", "4096")), help="engine instances per GPU")
+    ap.add_argument("--instances", type=int, default=int(os.environ.get("OW_BENCH_INSTANCES", "65536")), help="engine instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -158,7 +168,8 @@ def main():
     pool = ow.EnginePool(SR, n_inst, device=local_rank)
     pool.set_sample_rate(SR)          # the plugin's initialize(): chain build + 0.6 s warm-up (not timed)
     pool.ensure_buffer_capacity(BUF)
-    for k in range(n_inst):
+    # volume 0.5 / tremolo depth 0.5 / speaker character 0.0 / MLP on are the engine defaults (engine.rs:221-224)
+    for k in range(min(n_inst, 4096)):
         e = pool[k]
         e.set_volume(0.5); e.set_tremolo_depth(0.5); e.set_speaker_character(0.0); e.set_mlp_enabled(True)
     script = Script(pool, n_inst)
@@ -229,6 +240,7 @@ def main():
                 "instances_per_gpu": n_inst, "buffer": BUF, "parallelism": f"{world} x independent pools (no data-path collective)",
             },
             "x_realtime_aggregate": value / SR,
+            "host_midi_s": script.t_midi, "render_calls_s": script.t_render, "elapsed_s": elapsed,
             "single_instance_samples_per_s": single,
             "roofline": {
                 "bound": "valu_f64", "kernel": "k_" + ("voice" if dom == "voices" else dom), "achieved": achieved,

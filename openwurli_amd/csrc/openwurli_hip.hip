@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/openwurli_hip.h"
@@ -58,6 +59,17 @@ struct ow_engine {
     HostSmoother volume{0.5}, depth{0.5}, spk{0.0};
     uint64_t nan_guard_fires = 0, output_nan_resets = 0;
     std::vector<OwOp> ops;  // pending slot ops, applied at the start of the next render
+    // bit s set <=> slot s renders a voice / a steal voice (engine.rs:471-493); kept incrementally
+    uint64_t main_mask = 0, steal_mask = 0;
+    uint8_t* dirty = nullptr;   // -> pool->dirty[index]: engine has pending ops / setter targets / changed masks
+    void sync_masks(int s) {
+        const Slot& sl = slots[s];
+        const uint64_t b = 1ull << s;
+        if (sl.has_voice && sl.state != OW_VOICE_FREE) main_mask |= b; else main_mask &= ~b;
+        if (sl.has_steal) steal_mask |= b; else steal_mask &= ~b;
+        if (dirty) *dirty = 1;
+    }
+    void touch() { if (dirty) *dirty = 1; }
 };
 
 struct ow_pool {
@@ -65,7 +77,9 @@ struct ow_pool {
     size_t I = 0;
     size_t Lcap = 0;
     OwConsts hc{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // voices -> preamp -> output stage
+    hipStream_t stream_trem = nullptr; // tremolo oscillator: no audio input (tremolo.rs:121), runs beside the voices
+    hipEvent_t ev_args = nullptr, ev_trem = nullptr;
     OwConsts* dK = nullptr;     // constants at the pool's rates
     OwConsts* dK48 = nullptr;   // tremolo codegen-rate matrices for CircuitState::warmup
     double* d_nt = nullptr;
@@ -83,8 +97,10 @@ struct ow_pool {
     OwEngineOut* h_eout = nullptr;    // pinned
     OwOp* h_ops = nullptr;            // pinned
     std::vector<ow_engine*> engines;
+    std::vector<uint8_t> dirty;       // per engine: host state changed since the args were last uploaded
+    bool args_stale = true;           // device args still hold one-shot fields of the previous block
     bool profiling = false;
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[8] = {};
     float last_ms[5] = {0, 0, 0, 0, 0};
     size_t last_len = 0;
 };
@@ -156,51 +172,71 @@ void upload_consts(ow_pool* p, double sr, int preamp_kind) {
 void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
     const int I = (int)p->I;
     const int L = (int)len, Lcap = (int)p->Lcap;
-    // ---- per-engine args + ops
+    // ---- per-engine args + ops: only engines whose host state changed are touched (the rest keep their
+    // uploaded args; a steady-state step of a large pool does no per-engine host work here)
     size_t n_ops = 0;
-    for (int k = 0; k < ne; ++k) n_ops += p->engines[e0 + k]->ops.size();
+    bool any_dirty = false;
+    for (int k = 0; k < ne; ++k) {
+        if (!p->dirty[e0 + k]) continue;
+        any_dirty = true;
+        n_ops += p->engines[e0 + k]->ops.size();
+    }
     ensure_ops_capacity(p, n_ops);
     size_t op_pos = 0;
-    bool any_main = false, any_steal = false;
-    for (int k = 0; k < ne; ++k) {
-        ow_engine* en = p->engines[e0 + k];
-        OwEngineArgs& a = p->h_args[e0 + k];
-        a.main_mask = 0; a.steal_mask = 0;
-        for (int s = 0; s < OW_MAX_VOICES; ++s) {
+    if (any_dirty || p->args_stale) {
+        for (int k = 0; k < ne; ++k) {
+            OwEngineArgs& a = p->h_args[e0 + k];
+            if (!p->dirty[e0 + k]) {
+                if (a.op_count || a.set_flags) { a.op_count = 0; a.set_flags = 0; }
+                continue;
+            }
+            ow_engine* en = p->engines[e0 + k];
             // engine.rs:471-473: a Free slot renders nothing unless it still carries a steal voice
-            if (en->slots[s].has_voice && en->slots[s].state != OW_VOICE_FREE) a.main_mask |= (1ull << s);
-            if (en->slots[s].has_steal) a.steal_mask |= (1ull << s);
+            a.main_mask = en->main_mask; a.steal_mask = en->steal_mask;
+            a.op_begin = (uint32_t)op_pos;
+            a.op_count = (uint32_t)en->ops.size();
+            if (!en->ops.empty()) std::memcpy(p->h_ops + op_pos, en->ops.data(), sizeof(OwOp) * en->ops.size());
+            op_pos += en->ops.size();
+            en->ops.clear();
+            a.set_flags = 0;
+            if (en->depth.pending) { a.set_flags |= 1u; a.depth_target = en->depth.pending_value; en->depth.pending = false; }
+            if (en->spk.pending)   { a.set_flags |= 2u; a.spk_target = en->spk.pending_value;     en->spk.pending = false; }
+            if (en->volume.pending){ a.set_flags |= 4u; a.vol_target = en->volume.pending_value;  en->volume.pending = false; }
+            p->dirty[e0 + k] = 0;
         }
-        any_main |= a.main_mask != 0; any_steal |= a.steal_mask != 0;
-        a.op_begin = (uint32_t)op_pos;
-        a.op_count = (uint32_t)en->ops.size();
-        if (!en->ops.empty()) std::memcpy(p->h_ops + op_pos, en->ops.data(), sizeof(OwOp) * en->ops.size());
-        op_pos += en->ops.size();
-        en->ops.clear();
-        a.set_flags = 0;
-        if (en->depth.pending) { a.set_flags |= 1u; a.depth_target = en->depth.pending_value; en->depth.pending = false; }
-        if (en->spk.pending)   { a.set_flags |= 2u; a.spk_target = en->spk.pending_value;     en->spk.pending = false; }
-        if (en->volume.pending){ a.set_flags |= 4u; a.vol_target = en->volume.pending_value;  en->volume.pending = false; }
     }
-    hipStream_t st = p->stream;
-    HIP_OK(hipMemcpyAsync(p->d_args + e0, p->h_args + e0, sizeof(OwEngineArgs) * ne, hipMemcpyHostToDevice, st));
+    bool any_main = false, any_steal = false;
+    for (int k = 0; k < ne; ++k) { any_main |= p->h_args[e0 + k].main_mask != 0; any_steal |= p->h_args[e0 + k].steal_mask != 0; }
+    hipStream_t st = p->stream, tt = p->stream_trem;
+    // args carry one-shot fields (ops, setter targets): upload when anything changed, and once more afterwards to clear them
+    if (any_dirty || p->args_stale) {
+        HIP_OK(hipMemcpyAsync(p->d_args + e0, p->h_args + e0, sizeof(OwEngineArgs) * ne, hipMemcpyHostToDevice, st));
+        p->args_stale = any_dirty;
+    }
+    HIP_OK(hipEventRecord(p->ev_args, st));
+    // tremolo stream: needs only the args (depth retarget) -- overlaps the voice kernels
+    HIP_OK(hipStreamWaitEvent(tt, p->ev_args, 0));
+    if (p->profiling) HIP_OK(hipEventRecord(p->ev[6], tt));
+    owdev::k_tremolo<<<dim3((ne + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, p->d_args, p->d_rbuf, I, L, e0, ne);
+    if (p->profiling) HIP_OK(hipEventRecord(p->ev[7], tt));
+    HIP_OK(hipEventRecord(p->ev_trem, tt));
     HIP_OK(hipMemsetAsync(p->d_eout + e0, 0, sizeof(OwEngineOut) * ne, st));
-    if (p->profiling) hipEventRecord(p->ev[0], st);
+    if (p->profiling) HIP_OK(hipEventRecord(p->ev[0], st));
     if (n_ops) {
         HIP_OK(hipMemcpyAsync(p->d_ops, p->h_ops, sizeof(OwOp) * n_ops, hipMemcpyHostToDevice, st));
         owdev::k_apply_ops<<<dim3(ne), dim3(64), 0, st>>>(p->dK, p->d_nt, p->d_vrec, p->d_args, p->d_ops, e0);
     }
-    if (p->profiling) hipEventRecord(p->ev[1], st);
+    if (p->profiling) HIP_OK(hipEventRecord(p->ev[1], st));
     if (with_voices && (any_main || any_steal)) {
         owdev::k_voice<<<dim3(ne, any_steal ? 2 : 1), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->d_args, p->d_sum, p->d_eout, I, L, Lcap, e0);
     }
-    if (p->profiling) hipEventRecord(p->ev[2], st);
-    owdev::k_tremolo<<<dim3((ne + 63) / 64), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_rbuf, I, L, e0, ne);
-    if (p->profiling) hipEventRecord(p->ev[3], st);
+    if (p->profiling) HIP_OK(hipEventRecord(p->ev[2], st));
+    HIP_OK(hipStreamWaitEvent(st, p->ev_trem, 0));
+    if (p->profiling) HIP_OK(hipEventRecord(p->ev[3], st));
     owdev::k_preamp<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, p->d_rbuf, p->d_pre, I, L, Lcap, e0, ne);
-    if (p->profiling) hipEventRecord(p->ev[4], st);
+    if (p->profiling) HIP_OK(hipEventRecord(p->ev[4], st));
     owdev::k_post<<<dim3((ne + 63) / 64), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, Lcap, e0, ne);
-    if (p->profiling) hipEventRecord(p->ev[5], st);
+    if (p->profiling) HIP_OK(hipEventRecord(p->ev[5], st));
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(p->h_eout + e0, p->d_eout + e0, sizeof(OwEngineOut) * ne, hipMemcpyDeviceToHost, st));
 }
@@ -209,13 +245,17 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
 void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
     const uint32_t l32 = (uint32_t)std::min<size_t>(len, 0xFFFFFFFFull);
     for (int k = 0; k < ne; ++k) {
-        ow_engine* en = p->engines[e0 + k];
         const OwEngineOut& o = p->h_eout[e0 + k];
-        for (int s = 0; s < OW_MAX_VOICES; ++s) {
-            Slot& sl = en->slots[s];
-            if (sl.has_steal) {  // engine.rs:490-493
+        const OwEngineArgs& a = p->h_args[e0 + k];
+        // fast path on the contiguous status/args arrays: nothing to book-keep for this engine
+        if (!a.steal_mask && !(o.silent_mask & a.main_mask) && !o.sum_nonfinite && !o.out_nonfinite) continue;
+        ow_engine* en = p->engines[e0 + k];
+        if (en->steal_mask) {  // engine.rs:490-493
+            for (uint64_t m = en->steal_mask; m; m &= m - 1) {
+                const int s = __builtin_ctzll(m);
+                Slot& sl = en->slots[s];
                 sl.steal_fade = sl.steal_fade > l32 ? sl.steal_fade - l32 : 0u;
-                if (sl.steal_fade == 0) sl.has_steal = false;
+                if (sl.steal_fade == 0) { sl.has_steal = false; en->sync_masks(s); }
             }
         }
         if (o.sum_nonfinite) {  // engine.rs:499-521 (culprits were identified in the same pass; see DESIGN.md deviations)
@@ -224,19 +264,25 @@ void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
                 Slot& sl = en->slots[s];
                 if ((o.bad_main >> s) & 1ull) { sl.state = OW_VOICE_FREE; sl.has_voice = false; }
                 if ((o.bad_steal >> s) & 1ull) { sl.has_steal = false; sl.steal_fade = 0; }
+                en->sync_masks(s);
             }
         }
         if (o.out_nonfinite) en->output_nan_resets += 1;
-        for (int s = 0; s < OW_MAX_VOICES; ++s) {  // cleanup_voices, engine.rs:592-602
+        for (uint64_t m = o.silent_mask & en->main_mask; m; m &= m - 1) {  // cleanup_voices, engine.rs:592-602
+            const int s = __builtin_ctzll(m);
             Slot& sl = en->slots[s];
-            if (sl.state != OW_VOICE_FREE && sl.has_voice && ((o.silent_mask >> s) & 1ull)) { sl.state = OW_VOICE_FREE; sl.has_voice = false; }
+            if (sl.state != OW_VOICE_FREE && sl.has_voice) { sl.state = OW_VOICE_FREE; sl.has_voice = false; en->sync_masks(s); }
         }
     }
 }
 
 void collect_profile(ow_pool* p) {
     if (!p->profiling) return;
-    for (int i = 0; i < 5; ++i) hipEventElapsedTime(&p->last_ms[i], p->ev[i], p->ev[i + 1]);
+    hipEventElapsedTime(&p->last_ms[0], p->ev[0], p->ev[1]);   // ops
+    hipEventElapsedTime(&p->last_ms[1], p->ev[1], p->ev[2]);   // voices
+    hipEventElapsedTime(&p->last_ms[2], p->ev[6], p->ev[7]);   // tremolo (own stream)
+    hipEventElapsedTime(&p->last_ms[3], p->ev[3], p->ev[4]);   // preamp
+    hipEventElapsedTime(&p->last_ms[4], p->ev[4], p->ev[5]);   // post
 }
 
 // WurliEngine::warm_up (engine.rs:261-270): 0.6 s of render() in 512-sample blocks
@@ -254,6 +300,8 @@ void warm_up_range(ow_pool* p, int e0, int ne) {
 
 void engine_host_reset(ow_engine* en) {  // host half of WurliEngine::reset (engine.rs:231-244)
     for (auto& s : en->slots) { s.state = OW_VOICE_FREE; s.has_voice = false; s.has_steal = false; s.steal_fade = 0; }
+    en->main_mask = 0; en->steal_mask = 0;
+    en->touch();
     en->age_counter = 0;
     en->sustain_held = false;
     en->ops.clear();
@@ -282,6 +330,7 @@ void push_op(ow_engine* en, uint8_t type, int slot, uint8_t note, bool mlp, uint
     OwOp op;
     op.type = type; op.slot = (uint8_t)slot; op.note = note; op.mlp = mlp ? 1 : 0; op.seed = seed; op.velocity = vel;
     en->ops.push_back(op);
+    en->touch();
 }
 
 ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int preamp_kind) {
@@ -295,7 +344,10 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     p->device = device;
     p->I = n_engines;
     HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&p->stream_trem, hipStreamNonBlocking));
     for (auto& e : p->ev) HIP_OK(hipEventCreate(&e));
+    HIP_OK(hipEventCreateWithFlags(&p->ev_args, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&p->ev_trem, hipEventDisableTiming));
     HIP_OK(hipMalloc(&p->dK, sizeof(OwConsts)));
     HIP_OK(hipMalloc(&p->dK48, sizeof(OwConsts)));
     HIP_OK(hipMalloc(&p->d_nt, sizeof(double) * NT_COUNT * 64));
@@ -313,10 +365,12 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     upload_consts(p, sample_rate, preamp_kind);
     owdev::k_note_table<<<dim3(1), dim3(64), 0, p->stream>>>(p->d_nt);
     p->engines.resize(n_engines);
+    p->dirty.assign(n_engines, 1);
     for (size_t i = 0; i < n_engines; ++i) {
         ow_engine* en = new ow_engine();
         en->pool = p;
         en->index = i;
+        en->dirty = &p->dirty[i];
         p->engines[i] = en;
     }
     // WurliEngine::new for engine 0 on the device, then replicate (every engine of a fresh pool is identical)
@@ -339,6 +393,9 @@ void pool_destroy(ow_pool* p) {
     if (p->h_ops) hipHostFree(p->h_ops);
     hipHostFree(p->h_args); hipHostFree(p->h_eout);
     for (auto& e : p->ev) if (e) hipEventDestroy(e);
+    if (p->ev_args) hipEventDestroy(p->ev_args);
+    if (p->ev_trem) hipEventDestroy(p->ev_trem);
+    if (p->stream_trem) hipStreamDestroy(p->stream_trem);
     if (p->stream) hipStreamDestroy(p->stream);
     for (ow_engine* en : p->engines) delete en;
     delete p;
@@ -522,6 +579,7 @@ void ow_engine_note_on(ow_engine* e, uint8_t note_in, float velocity) {  // engi
     slot.state = OW_VOICE_HELD;
     slot.midi = note;
     slot.age = e->age_counter;
+    e->sync_masks(idx);
 }
 
 void ow_engine_note_off(ow_engine* e, uint8_t note_in) {  // engine.rs:340-359
@@ -554,9 +612,9 @@ void ow_engine_set_sustain(ow_engine* e, int held) {  // engine.rs:361-374
     e->sustain_held = held != 0;
 }
 
-void ow_engine_set_volume(ow_engine* e, double v) { if (e) e->volume.set_target(v); }
-void ow_engine_set_tremolo_depth(ow_engine* e, double d) { if (e) e->depth.set_target(d); }
-void ow_engine_set_speaker_character(ow_engine* e, double c) { if (e) e->spk.set_target(c); }
+void ow_engine_set_volume(ow_engine* e, double v) { if (e) { e->volume.set_target(v); if (e->volume.pending) e->touch(); } }
+void ow_engine_set_tremolo_depth(ow_engine* e, double d) { if (e) { e->depth.set_target(d); if (e->depth.pending) e->touch(); } }
+void ow_engine_set_speaker_character(ow_engine* e, double c) { if (e) { e->spk.set_target(c); if (e->spk.pending) e->touch(); } }
 void ow_engine_set_mlp_enabled(ow_engine* e, int on) { if (e) e->mlp_enabled = on != 0; }
 void ow_engine_set_noise_enabled(ow_engine*, int) {}   // dk_preamp_legacy.rs:262: no-op on the legacy preamp
 void ow_engine_set_noise_gain(ow_engine*, double) {}   // dk_preamp_legacy.rs:265
@@ -600,18 +658,36 @@ int ow_engine_has_steal_voice_for(const ow_engine* e, uint8_t note) {
     return 0;
 }
 
+static void midi_apply_one(ow_pool* p, const ow_midi_event& ev) {
+    ow_engine* e = p->engines[ev.engine];
+    switch (ev.type) {
+        case 0: ow_engine_note_on(e, ev.note, ev.value); break;
+        case 1: ow_engine_note_off(e, ev.note); break;
+        case 2: ow_engine_set_sustain(e, ev.value >= 0.5f); break;
+        default: break;
+    }
+}
+
 void ow_pool_midi(ow_pool* p, const ow_midi_event* ev, size_t n) {
     if (!p || !ev) return;
-    for (size_t i = 0; i < n; ++i) {
-        if (ev[i].engine >= p->I) continue;
-        ow_engine* e = p->engines[ev[i].engine];
-        switch (ev[i].type) {
-            case 0: ow_engine_note_on(e, ev[i].note, ev[i].value); break;
-            case 1: ow_engine_note_off(e, ev[i].note); break;
-            case 2: ow_engine_set_sustain(e, ev[i].value >= 0.5f); break;
-            default: break;
-        }
+    // Engines are independent state machines: large event lists are applied by several host threads, each owning a
+    // contiguous range of engines and walking the list in array order (per-engine order is what matters).
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t T = std::min<size_t>(hw ? hw : 1, 32);
+    if (n < 4096 || p->I < 2 * T) T = 1;
+    if (T == 1) {
+        for (size_t i = 0; i < n; ++i) if (ev[i].engine < p->I) midi_apply_one(p, ev[i]);
+        return;
     }
+    std::vector<std::thread> th;
+    const size_t per = (p->I + T - 1) / T;
+    for (size_t t = 0; t < T; ++t) {
+        const uint32_t lo = (uint32_t)(t * per), hi = (uint32_t)std::min(p->I, (t + 1) * per);
+        th.emplace_back([=] {
+            for (size_t i = 0; i < n; ++i) if (ev[i].engine >= lo && ev[i].engine < hi) midi_apply_one(p, ev[i]);
+        });
+    }
+    for (auto& x : th) x.join();
 }
 
 // ---- offline ------------------------------------------------------------------------------------
@@ -622,6 +698,7 @@ long long ow_render_note(uint8_t midi, double velocity, double dur_s, double sam
         // Voice::render_note: seed = midi * 2654435761, MLP off, no note clamping beyond the table range (voice.rs:206-207)
         const uint8_t note = std::min<uint8_t>(std::max<uint8_t>(midi, OW_MIDI_LO), OW_MIDI_HI);
         e->slots[0].has_voice = true; e->slots[0].state = OW_VOICE_HELD; e->slots[0].midi = note;
+        e->sync_masks(0);
         push_op(e, OP_NOTE_ON, 0, note, false, (uint32_t)midi * 2654435761u, velocity);
         double x = dur_s * sample_rate;
         const size_t n = (!(x == x) || x <= 0.0) ? 0 : (size_t)x;

@@ -28,14 +28,17 @@ OW_DEV double fast_exp(double x0) {  // gen_tremolo.rs:1140-1166 (pure arithmeti
     return p * pow2n;
 }
 
-OW_DEV double pnjlim(double vnew, double vold, double vt, double vcrit) {  // gen_tremolo.rs:1203-1218
-    if (vnew > vcrit && fabs(vnew - vold) > vt + vt) {
-        if (vold >= 0.0) {
-            const double arg = 1.0 + (vnew - vold) / vt;
-            return arg > 0.0 ? vold + vt * log(arg) : vcrit;
-        }
-        return vt * log(vnew / vt);
+// The logarithmic branch only fires on large forward steps above vcrit (start-up transients); out of line so the
+// two inlined log() bodies per call site do not bloat the Newton loop.
+__device__ __noinline__ double pnjlim_limited(double vnew, double vold, double vt, double vcrit) {
+    if (vold >= 0.0) {
+        const double arg = 1.0 + (vnew - vold) / vt;
+        return arg > 0.0 ? vold + vt * log(arg) : vcrit;
     }
+    return vt * log(vnew / vt);
+}
+OW_DEV double pnjlim(double vnew, double vold, double vt, double vcrit) {  // gen_tremolo.rs:1203-1218
+    if (vnew > vcrit && fabs(vnew - vold) > vt + vt) return pnjlim_limited(vnew, vold, vt, vcrit);
     return vnew;
 }
 

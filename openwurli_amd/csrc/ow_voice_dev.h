@@ -335,6 +335,22 @@ __device__ inline void start_damper_lane(double* __restrict__ rec, const OwConst
     rec[VF_FLAGS * 64] = bitsd(((fl & 0xFFFFFFFF00000000ull) | 1ull));  // damper_active=1, ramp_done=0
 }
 
+// Rare-phase transcendentals are kept out of line so their temporaries do not inflate the register
+// footprint of the steady-state loop (onset ramp: first ~1-2 periods; damper ramp: 8-50 ms after note-off;
+// attack noise fade-in: 16 samples; pickup saturation: only |y| >= 0.94).
+__device__ __noinline__ double onset_gain(double n, double onset_inc, double onset_exp) {  // reed.rs:251-264
+    const double cosine = 0.5 * (1.0 - cos(n * onset_inc));
+    if (onset_exp <= 1.001) return cosine;
+    if (onset_exp >= 1.999) return cosine * cosine;
+    return pow(cosine, onset_exp);
+}
+__device__ __noinline__ double exp_neg(double x) { return exp(-x); }                         // reed.rs:238
+__device__ __noinline__ double noise_fade_env(double t) { return 0.5 * (1.0 - cos(3.14159265358979323846 * t)); }  // hammer.rs:165
+__device__ __noinline__ double pickup_saturate_hi(double y, double ay) {                      // pickup.rs:76-79
+    const double range = 0.98 - 0.94;
+    return copysign(0.94 + range * tanh((ay - 0.94) / range), y);
+}
+
 // ------------------------------------------------------------------ per-sample voice state in registers
 struct VoiceRegs {
     double s[7], c[7], env[7], drift[7], cos_inc[7], sin_inc[7], phase_inc[7], amp[7], decay[7];
@@ -387,7 +403,7 @@ struct VoiceRegs {
 #pragma unroll
                     for (int m = 0; m < 7; ++m) {
                         const double inst_rate = rec[(VF_DRATE + m) * 64] * t / dramp;
-                        env[m] *= exp(-inst_rate);
+                        env[m] *= exp_neg(inst_rate);
                     }
                 }
             }
@@ -397,12 +413,7 @@ struct VoiceRegs {
             }
         }
         double onset = 1.0;
-        if (sample < onset_n) {
-            const double cosine = 0.5 * (1.0 - cos((double)sample * onset_inc));
-            if (onset_exp <= 1.001) onset = cosine;
-            else if (onset_exp >= 1.999) onset = cosine * cosine;
-            else onset = pow(cosine, onset_exp);
-        }
+        if (sample < onset_n) onset = onset_gain((double)sample, onset_inc, onset_exp);
         if ((sample & 15ull) == 0ull) {
             const double revert = K->jitter_revert, diffusion = K->jitter_diffusion;
 #pragma unroll
@@ -442,7 +453,7 @@ struct VoiceRegs {
             if (noise_fade > 0u) {
                 const uint32_t pos = 16u - noise_fade;
                 noise_fade -= 1u;
-                e = 0.5 * (1.0 - cos(3.14159265358979323846 * ((double)pos / 16.0)));
+                e = noise_fade_env((double)pos / 16.0);
             }
             noise_rng = lcg(noise_rng);
             const double nz = (double)(int32_t)noise_rng / 2147483647.0;
@@ -456,10 +467,7 @@ struct VoiceRegs {
         // pickup
         double y = x * ds;
         const double ay = fabs(y);
-        if (!(ay < 0.94)) {
-            const double range = 0.98 - 0.94;
-            y = copysign(0.94 + range * tanh((ay - 0.94) / range), y);
-        }
+        if (!(ay < 0.94)) y = pickup_saturate_hi(y, ay);
         const double omy = 1.0 - y;
         const double alpha = K->pickup_beta * omy;
         const double q_next = (q * (1.0 - alpha) + 2.0 * K->pickup_beta) / (1.0 + alpha);

@@ -142,7 +142,7 @@ class EnginePool:
             raise OwError(binding.last_error(self._lib))
         self._h = C.c_void_p(h)
         self.n = int(n_engines)
-        self.engines = [_EngineHandle(self._lib, self._lib.ow_pool_engine(self._h, i)) for i in range(self.n)]
+        self._engines = {}
 
     def close(self):
         if self._h:
@@ -156,7 +156,12 @@ class EnginePool:
             pass
 
     def __getitem__(self, i):
-        return self.engines[i]
+        i = int(i)
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        if i not in self._engines:
+            self._engines[i] = _EngineHandle(self._lib, self._lib.ow_pool_engine(self._h, i))
+        return self._engines[i]
 
     def set_sample_rate(self, sr):
         if self._lib.ow_pool_set_sample_rate(self._h, float(sr)) != 0:
