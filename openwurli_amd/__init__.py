@@ -7,6 +7,6 @@ importing works anywhere, constructing an engine without the built library or wi
 HIP device raises.
 """
 from .binding import load_library, library_path, OwError  # noqa: F401
-from .engine import WurliEngine, EnginePool, VoiceState, render_note  # noqa: F401
+from .engine import WurliEngine, EnginePool, VoiceState, render_note, batch_render  # noqa: F401
 
-__all__ = ["load_library", "library_path", "OwError", "WurliEngine", "EnginePool", "VoiceState", "render_note"]
+__all__ = ["load_library", "library_path", "OwError", "WurliEngine", "EnginePool", "VoiceState", "render_note", "batch_render"]

@@ -13,6 +13,7 @@
 #include "../../include/openwurli_hip.h"
 #include "ow_consts_host.hpp"
 #include "ow_kernels.h"
+#include "ow_job_kernels.h"
 
 using owdev::OwEngineOut;
 
@@ -718,9 +719,49 @@ long long ow_render_note(uint8_t midi, double velocity, double dur_s, double sam
     } catch (const std::exception& ex) { set_err(std::string("ow_render_note: ") + ex.what()); return -1; }
 }
 
-long long ow_batch_render(const ow_job*, size_t, const ow_batch_cfg*, double*, size_t, int) {
-    set_err("ow_batch_render: not built yet");
-    return -1;
+long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg* cfg, double* out, size_t stride, int out_is_device) {
+    try {
+        if (!jobs || !cfg || !out || n_jobs == 0) throw std::runtime_error("null argument");
+        if (cfg->preamp_kind != OW_PREAMP_LEGACY8) throw std::runtime_error("preamp_kind: only OW_PREAMP_LEGACY8 is built in this round");
+        const double x = cfg->duration_s * cfg->sample_rate;
+        const size_t n = (!(x == x) || x <= 0.0) ? 0 : (size_t)x;                 // (duration * sample_rate) as usize, main.rs:411
+        if (n == 0) return 0;
+        if (stride < n) throw std::runtime_error("stride smaller than the job length");
+        int ndev = 0;
+        HIP_OK(hipGetDeviceCount(&ndev));
+        if (ndev <= 0) throw std::runtime_error("no HIP device: openwurli-hip has no CPU fallback");
+        HIP_OK(hipSetDevice(cfg->device));
+        OwConsts hc;
+        owhip::build_consts(hc, cfg->sample_rate, cfg->preamp_kind);
+        std::vector<owdev::OwJobDev> hj(n_jobs);
+        for (size_t i = 0; i < n_jobs; ++i) {
+            hj[i].note = jobs[i].note; hj[i].velocity = jobs[i].velocity; hj[i].mlp = jobs[i].mlp; hj[i].poweramp = jobs[i].poweramp;
+            hj[i].pad = 0; hj[i].volume = jobs[i].volume; hj[i].speaker = jobs[i].speaker; hj[i].r_ldr = jobs[i].r_ldr;
+        }
+        OwConsts* dK = nullptr; double* d_nt = nullptr; double* d_vrec = nullptr; owdev::OwJobDev* d_jobs = nullptr;
+        double* d_reed = nullptr; double* d_out = nullptr;
+        const size_t vblocks = (n_jobs + 63) / 64;
+        hipStream_t st;
+        HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIP_OK(hipMalloc(&dK, sizeof(OwConsts)));
+        HIP_OK(hipMalloc(&d_nt, sizeof(double) * NT_COUNT * 64));
+        HIP_OK(hipMalloc(&d_vrec, sizeof(double) * vblocks * OW_VREC_DOUBLES));
+        HIP_OK(hipMalloc(&d_jobs, sizeof(owdev::OwJobDev) * n_jobs));
+        HIP_OK(hipMalloc(&d_reed, sizeof(double) * n_jobs * n));
+        if (out_is_device) d_out = out; else HIP_OK(hipMalloc(&d_out, sizeof(double) * n_jobs * stride));
+        HIP_OK(hipMemcpyAsync(dK, &hc, sizeof(OwConsts), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(d_jobs, hj.data(), sizeof(owdev::OwJobDev) * n_jobs, hipMemcpyHostToDevice, st));
+        owdev::k_note_table<<<dim3(1), dim3(64), 0, st>>>(d_nt);
+        owdev::k_job_voice<<<dim3((unsigned)vblocks), dim3(64), 0, st>>>(dK, d_nt, d_vrec, d_jobs, d_reed, (int)n_jobs, (long long)n, (long long)n);
+        owdev::k_job_chain<<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_reed, d_out, (int)n_jobs, (long long)n, (long long)stride);
+        HIP_OK(hipGetLastError());
+        if (!out_is_device) HIP_OK(hipMemcpyAsync(out, d_out, sizeof(double) * n_jobs * stride, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        hipFree(dK); hipFree(d_nt); hipFree(d_vrec); hipFree(d_jobs); hipFree(d_reed);
+        if (!out_is_device) hipFree(d_out);
+        hipStreamDestroy(st);
+        return (long long)n;
+    } catch (const std::exception& ex) { set_err(std::string("ow_batch_render: ") + ex.what()); return -1; }
 }
 
 }  // extern "C"

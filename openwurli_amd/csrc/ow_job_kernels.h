@@ -1,0 +1,133 @@
+// openwurli-hip: batch-render kernels (lane = job).
+//
+// One job = `preamp-bench render` (tools/preamp-bench/src/main.rs:371-549) as driven by
+// ml/render_model_notes.py:49-116: one voice (seed note*2654435761) -> fresh legacy preamp after
+// reset() + set_ldr_resistance(r) (static LDR, tremolo depth 0) with per-sample 2x oversampling ->
+// x volume^2 -> optional power amp at BASE rate -> Speaker(character) -> x POST_SPEAKER_GAIN, f64.
+// Jobs share no state, so a wavefront renders 64 voices (k_job_voice) or 32 main/shadow preamp
+// lane pairs (k_job_chain) of different jobs in lock-step.
+#pragma once
+#include "ow_kernels.h"
+
+namespace owdev {
+
+struct OwJobDev {           // device copy of ow_job
+    uint8_t note, velocity, mlp, poweramp;
+    uint32_t pad;
+    double volume, speaker, r_ldr;
+};
+
+// Voice::note_on + Voice::render for n samples, lane = job.  reed[job][n] (row stride `stride`).
+__global__ __launch_bounds__(64) void k_job_voice(const OwConsts* __restrict__ K, const double* __restrict__ nt, double* __restrict__ vrec,
+                                                  const OwJobDev* __restrict__ jobs, double* __restrict__ reed, int n_jobs, long long n,
+                                                  long long stride) {
+    __shared__ double tile[64 * (OW_VCHUNK + 1)];
+    const int lane = threadIdx.x;
+    const int jb = blockIdx.x * 64;
+    const int j = jb + lane;
+    const bool active = j < n_jobs;
+    double* rec = vrec + (size_t)blockIdx.x * OW_VREC_DOUBLES + lane;
+    VoiceRegs v;
+    if (active) {
+        const OwJobDev jd = jobs[j];
+        const int note = jd.note < OW_MIDI_LO ? OW_MIDI_LO : (jd.note > OW_MIDI_HI ? OW_MIDI_HI : jd.note);
+        const double vel = (double)jd.velocity / 127.0;                    // main.rs:403
+        double raw[11];
+        mlp_raw_scalar(clampd(((double)note - 21.0) / (108.0 - 21.0), 0.0, 1.0), clampd(vel, 0.0, 1.0), raw);
+        const MlpOut corr = mlp_finish(note, raw, jd.mlp != 0);
+        note_on_lane(rec, nt, K, note, vel, (uint32_t)jd.note * 2654435761u, corr);   // main.rs:404-405
+        v.load(rec);
+    }
+    for (long long base = 0; base < n; base += OW_VCHUNK) {
+        const int cn = (int)((n - base) < OW_VCHUNK ? (n - base) : OW_VCHUNK);
+        for (int s = 0; s < cn; ++s) tile[lane * (OW_VCHUNK + 1) + s] = active ? v.step(rec, K) : 0.0;
+        __syncthreads();
+        // transposed, coalesced store: 2 job rows per pass (32 samples each)
+        for (int r = (lane >> 5); r < 64; r += 2) {
+            const int s = lane & 31;
+            if (jb + r < n_jobs && s < cn) reed[(size_t)(jb + r) * stride + base + s] = tile[r * (OW_VCHUNK + 1) + s];
+        }
+        __syncthreads();
+    }
+}
+
+// Preamp + output stage, lane pair (job, main|shadow): 32 jobs per wavefront.
+__global__ __launch_bounds__(64) void k_job_chain(const OwConsts* __restrict__ K, const OwJobDev* __restrict__ jobs, const double* __restrict__ reed,
+                                                  double* __restrict__ out, int n_jobs, long long n, long long stride) {
+    __shared__ double tin[32 * (OW_PCHUNK + 1)];
+    __shared__ double tout[32 * (OW_PCHUNK + 1)];
+    const int lane = threadIdx.x;
+    const int jl = lane & 31, role = lane >> 5;
+    const int jb = blockIdx.x * 32;
+    const int j = jb + jl;
+    const bool valid = j < n_jobs;
+    const OwJobDev jd = jobs[valid ? j : n_jobs - 1];
+    const int osr = K->oversample ? 2 : 1;
+    const double sr = K->sr;
+
+    // DkPreamp::new(preamp_sr); preamp.reset(); preamp.set_ldr_resistance(r_ldr)  (main.rs:432-441)
+    DkSt st;
+    double r_ldr = 1000000.0;
+    dk_dc_state(K, r_ldr, &st);                       // new() and reset() both solve DC at the initial 1 Mohm
+    double g_ldr = 1.0 / r_ldr, g_prev = g_ldr;
+    {
+        const double r_new = fmax(jd.r_ldr, 1000.0);
+        if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = 1.0 / r_new; }
+    }
+    double ua[3] = {0, 0, 0}, ub[3] = {0, 0, 0}, da[3] = {0, 0, 0}, db[3] = {0, 0, 0}, dd = 0.0;
+    SpeakerSt sp;                                      // Speaker::new(sr); set_character(c)  (main.rs:483-484)
+    sp.character = 1.0; sp.ts = 0.0;
+    sp.hpf.s1 = sp.hpf.s2 = sp.lpf.s1 = sp.lpf.s2 = 0.0;
+    speaker_update(sp, sr);
+    speaker_set_character(sp, jd.speaker, sr);
+    const double vol2_a = jd.volume;
+
+    for (long long base = 0; base < n; base += OW_PCHUNK) {
+        const int cn = (int)((n - base) < OW_PCHUNK ? (n - base) : OW_PCHUNK);
+        for (int r = 0; r < 32; ++r) {
+            double x = 0.0;
+            if (jb + r < n_jobs && lane < cn) x = reed[(size_t)(jb + r) * stride + base + lane];
+            tin[r * (OW_PCHUNK + 1) + lane] = x;
+        }
+        __syncthreads();
+        for (int s = 0; s < cn; ++s) {
+            const double x = tin[jl * (OW_PCHUNK + 1) + s];
+            double pre;
+            if (osr == 2) {                            // main.rs:445-466: per-sample up(1) -> 2x process -> down(1)
+                const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, ua, x);
+                const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, ub, x);
+                double p[2];
+                const double in[2] = {role ? 0.0 : a, role ? 0.0 : b};
+                for (int k = 0; k < 2; ++k) {
+                    const double o = dk_step(st, in[k], g_ldr, g_prev, K);
+                    g_prev = g_ldr;
+                    const double other = __shfl_xor(o, 32);
+                    double res = role ? (other - o) : (o - other);
+                    if (!isfinite(res)) { dk_dc_state(K, r_ldr, &st); g_ldr = 1.0 / r_ldr; g_prev = g_ldr; res = 0.0; }
+                    p[k] = res;
+                }
+                const double fa = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, p[0]);
+                const double fb = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, p[1]);
+                pre = (fa + dd) * 0.5;
+                dd = fb;
+            } else {
+                const double o = dk_step(st, role ? 0.0 : x, g_ldr, g_prev, K);
+                g_prev = g_ldr;
+                const double other = __shfl_xor(o, 32);
+                pre = role ? (other - o) : (o - other);
+                if (!isfinite(pre)) { dk_dc_state(K, r_ldr, &st); g_ldr = 1.0 / r_ldr; g_prev = g_ldr; pre = 0.0; }
+            }
+            // main.rs:487-496: volume^2 (audio taper) -> optional power amp at base rate -> speaker -> PSG
+            const double att = pre * vol2_a * vol2_a;
+            const double amp = jd.poweramp ? power_amp(att) : att;
+            const double y = speaker_process(sp, amp, K->spk_thermal_alpha) * 7.498942093324558;
+            if (role == 0) tout[jl * (OW_PCHUNK + 1) + s] = y;
+        }
+        __syncthreads();
+        for (int r = 0; r < 32; ++r)
+            if (jb + r < n_jobs && lane < cn) out[(size_t)(jb + r) * stride + base + lane] = tout[r * (OW_PCHUNK + 1) + lane];
+        __syncthreads();
+    }
+}
+
+}  // namespace owdev

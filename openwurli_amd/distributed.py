@@ -1,0 +1,70 @@
+"""Multi-GPU driver for the batch-render path: independent note x velocity jobs are dealt
+round-robin over the ranks (job j -> rank j mod G, which balances bass/treble cost), every rank renders its
+shard with the lane = job kernels, and ONE gather collective brings the f32 result slabs to rank 0
+(``torch.distributed`` backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+There is no collective anywhere in the data path.
+
+The realtime engine path does not shard (one engine = one wavefront of voices + one serial chain):
+many instances are independent replicas, see bench.py.
+"""
+import numpy as np
+
+
+def shard_indices(n_jobs, rank, world):
+    """Indices of the jobs rank ``rank`` renders: j = rank, rank + world, ..."""
+    return list(range(rank, n_jobs, world))
+
+
+def unshard(slabs, n_jobs, world):
+    """Inverse of ``shard_indices``: slabs[r] is [len(shard_indices(n_jobs, r, world)) (padded), n] -> [n_jobs, n]."""
+    n = slabs[0].shape[1]
+    out = np.zeros((n_jobs, n), dtype=slabs[0].dtype)
+    for r in range(world):
+        idx = shard_indices(n_jobs, r, world)
+        out[idx] = slabs[r][:len(idx)]
+    return out
+
+
+def batch_render_sharded(jobs, sample_rate, duration_s, render_fn=None, device=None, group=None):
+    """Render ``jobs`` across the ranks of the default process group; rank 0 returns float32 [n_jobs, n], others None.
+
+    ``render_fn(local_jobs) -> array [n_local, n]`` defaults to the HIP batch renderer; tests inject a CPU stand-in
+    to exercise the sharding + gather logic under gloo.
+    """
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    jobs = list(jobs)
+    n_jobs = len(jobs)
+    n = int(duration_s * sample_rate)
+    mine = shard_indices(n_jobs, rank, world)
+    n_pad = (n_jobs + world - 1) // world          # equal-sized slabs so one gather suffices
+    backend = dist.get_backend(group)
+    on_gpu = backend == "nccl"
+    dev = torch.device("cuda", device if device is not None else torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    slab = torch.zeros((n_pad, n), dtype=torch.float32, device=dev)
+    if mine:
+        if render_fn is None:
+            from . import engine
+            if on_gpu:
+                # render straight into a torch-owned HBM buffer (f64), then narrow to the f32 slab: no host round trip
+                tmp = torch.empty((len(mine), n), dtype=torch.float64, device=dev)
+                engine.batch_render([jobs[i] for i in mine], sample_rate, duration_s, device=dev.index, out_device_ptr=tmp.data_ptr(), stride=n)
+                torch.cuda.synchronize(dev)
+                slab[:len(mine)] = tmp.to(torch.float32)
+            else:
+                raise RuntimeError("the HIP renderer needs the nccl backend (a GPU per rank); pass render_fn for CPU tests")
+        else:
+            local = np.asarray(render_fn([jobs[i] for i in mine]), dtype=np.float32)
+            slab[:len(mine)] = torch.from_numpy(local).to(dev)
+    gathered = [torch.zeros_like(slab) for _ in range(world)] if rank == 0 else None
+    dist.gather(slab, gathered, dst=0, group=group)     # the one exchange step
+    if rank != 0:
+        return None
+    return unshard([g.cpu().numpy() for g in gathered], n_jobs, world)
+
+
+def model_notes_job_list(notes=range(33, 97), velocities=(20, 35, 50, 65, 80, 95, 110, 127)):
+    """The job grid of ml/render_model_notes.py:26,106-114 (64 notes x 8 velocity buckets)."""
+    return [{"note": n, "velocity": v, "mlp": False, "poweramp": False, "volume": 1.0, "speaker": 0.0, "r_ldr": 1e6}
+            for n in notes for v in velocities]

@@ -223,3 +223,33 @@ def render_note(midi_note, velocity, duration_secs, sample_rate, device=0):
     if got < 0:
         raise OwError(binding.last_error(lib))
     return out[:got]
+
+
+def batch_render(jobs, sample_rate=44100.0, duration_s=2.0, device=0, preamp_kind=0, out_device_ptr=None, stride=None):
+    """``preamp-bench render`` for a list of jobs (tools/preamp-bench/src/main.rs:371-549), lane = job on the GPU.
+
+    ``jobs``: iterable of dicts with keys note, velocity (0..127) and optional mlp, poweramp, volume, speaker, r_ldr
+    (defaults = what ml/render_model_notes.py:57-73 passes: --volume 1.0 --no-poweramp --no-mlp --speaker 0.0, LDR 1 Mohm).
+    Returns float64 [n_jobs, n]; with ``out_device_ptr`` the result stays in HBM at that address and None is returned.
+    """
+    lib = binding.load_library()
+    jobs = list(jobs)
+    arr = (binding.OwJob * len(jobs))()
+    for i, j in enumerate(jobs):
+        arr[i].note = int(j["note"]); arr[i].velocity = int(j["velocity"])
+        arr[i].mlp = 1 if j.get("mlp", False) else 0
+        arr[i].poweramp = 1 if j.get("poweramp", False) else 0
+        arr[i].volume = float(j.get("volume", 1.0)); arr[i].speaker = float(j.get("speaker", 0.0)); arr[i].r_ldr = float(j.get("r_ldr", 1e6))
+    cfg = binding.OwBatchCfg(float(sample_rate), float(duration_s), int(device), int(preamp_kind))
+    n = int(duration_s * sample_rate)
+    stride = int(stride or n)
+    if out_device_ptr is not None:
+        got = lib.ow_batch_render(arr, len(jobs), C.byref(cfg), C.c_void_p(out_device_ptr), stride, 1)
+        if got < 0:
+            raise OwError(binding.last_error(lib))
+        return None
+    out = np.zeros((len(jobs), stride), dtype=np.float64)
+    got = lib.ow_batch_render(arr, len(jobs), C.byref(cfg), out.ctypes.data_as(C.c_void_p), stride, 0)
+    if got < 0:
+        raise OwError(binding.last_error(lib))
+    return out[:, :got]

@@ -117,10 +117,10 @@ def render_note(midi, vel, dur, sr):
     return out[:got]
 
 
-def batch_render_job(note, vel_u8, dur, sr, volume=1.0, speaker=0.0, r_ldr=1e6, mlp=False, poweramp=False):
+def batch_render_job(note, vel_u8, dur, sr, volume=1.0, speaker=0.0, r_ldr=1e6, mlp=False, poweramp=False, perturbed=False):
     n = int(dur * sr)
     out = np.zeros(max(n, 1))
-    got = lib().owo_batch_render_job(int(note), int(vel_u8), C.c_double(dur), C.c_double(sr), C.c_double(volume), C.c_double(speaker),
+    got = (lib_perturbed() if perturbed else lib()).owo_batch_render_job(int(note), int(vel_u8), C.c_double(dur), C.c_double(sr), C.c_double(volume), C.c_double(speaker),
                                      C.c_double(r_ldr), 1 if mlp else 0, 1 if poweramp else 0, _p(out), C.c_size_t(out.size))
     return out[:got]
 
@@ -130,6 +130,9 @@ def batch_render_job(note, vel_u8, dur, sr, volume=1.0, speaker=0.0, r_ldr=1e6, 
 # node by ~5e-10 V and the output by ~5e-10 (tests/test_oracle_sensitivity.py measures it on the CPU oracle alone).
 ABS_FLOOR_OUTPUT = 2e-9
 ABS_FLOOR_PREAMP = 2e-9
+# batch jobs (`preamp-bench render`): output = preamp x volume^2 x 7.5 with a static LDR, so the same indeterminacy
+# shows up ~10x larger (measured ~1.1e-8 by test_oracle_sensitivity.py)
+ABS_FLOOR_BATCH = 3e-8
 
 
 def parity_report(gpu, cpu, rel=1e-5, floor_frac=1e-3, abs_floor=0.0):

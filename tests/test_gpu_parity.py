@@ -253,3 +253,42 @@ def test_properties_full_size(hiplib):
     ratio = np.max(np.abs(a), axis=1) / np.max(np.abs(c), axis=1)
     assert np.all(np.abs(ratio - 2.0) < 0.04)
     assert not np.array_equal(a[0], a[1])                   # instances with different velocities differ
+
+
+# ------------------------------------------------------------------ batch path (config 4)
+@pytest.mark.parametrize("sr", [44100.0, 48000.0])
+def test_batch_render_jobs(hiplib, oracle, sr):
+    """16-job subset of config 4: notes {33,48,60,72,84,91,96,40} x velocities {50,127}, render_model_notes flags."""
+    import openwurli_amd as ow
+    jobs = [{"note": n, "velocity": v} for n in (33, 48, 60, 72, 84, 91, 96, 40) for v in (50, 127)]
+    dur = 0.75
+    g = ow.batch_render(jobs, sample_rate=sr, duration_s=dur)
+    assert g.shape == (16, int(dur * sr))
+    for i, j in enumerate(jobs):
+        c = oracle.batch_render_job(j["note"], j["velocity"], dur, sr)
+        _check(oracle.parity_report(g[i], c, abs_floor=oracle.ABS_FLOOR_BATCH), ("job", j, sr))
+
+
+def test_batch_render_variants(hiplib, oracle):
+    """Non-default job flags: MLP on, power amp on (base rate, drive = volume^2), speaker character, low static LDR,
+    and a job count that is not a multiple of the wavefront (ragged last block)."""
+    import openwurli_amd as ow
+    jobs = [{"note": 40 + 3 * k, "velocity": 30 + 5 * k, "mlp": k % 2 == 0, "poweramp": k % 3 == 0, "volume": 0.4 + 0.03 * k,
+             "speaker": (k % 4) / 4.0, "r_ldr": 19000.0 if k % 5 == 0 else 1e6} for k in range(19)]
+    dur, sr = 0.4, 48000.0
+    g = ow.batch_render(jobs, sample_rate=sr, duration_s=dur)
+    for i, j in enumerate(jobs):
+        c = oracle.batch_render_job(j["note"], j["velocity"], dur, sr, volume=j["volume"], speaker=j["speaker"], r_ldr=j["r_ldr"],
+                                    mlp=j["mlp"], poweramp=j["poweramp"])
+        _check(oracle.parity_report(g[i], c, abs_floor=oracle.ABS_FLOOR_BATCH), ("variant", i, j))
+
+
+def test_batch_wav_quantiser_round_trip(hiplib, oracle):
+    """24-bit WAV quantiser of preamp-bench (round, clamp: main.rs:941-957) applied to GPU and oracle renders agrees to 1 LSB."""
+    import openwurli_amd as ow
+    g = ow.batch_render([{"note": 60, "velocity": 127}], sample_rate=44100.0, duration_s=0.5)[0]
+    c = oracle.batch_render_job(60, 127, 0.5, 44100.0)
+    mx = 2 ** 23 - 1
+    qg = np.clip(np.round(g * mx), -mx, mx).astype(np.int64)
+    qc = np.clip(np.round(c * mx), -mx, mx).astype(np.int64)
+    assert np.max(np.abs(qg - qc)) <= 1

@@ -28,3 +28,13 @@ def test_one_ulp_exp_moves_the_reference_by_less_than_the_floor(oracle):
     assert d_out < oracle.ABS_FLOOR_OUTPUT, d_out
     # and it is tiny against the 1e-5 relative bar at musical level
     assert d_out / np.max(np.abs(o0)) < 1e-5 * 1e-1
+
+
+def test_batch_job_floor(oracle):
+    worst = 0.0
+    for note, vel in ((96, 50), (60, 127), (33, 50), (84, 127)):
+        a = oracle.batch_render_job(note, vel, 0.75, 44100.0)
+        b = oracle.batch_render_job(note, vel, 0.75, 44100.0, perturbed=True)
+        worst = max(worst, float(np.max(np.abs(a - b))))
+        assert np.max(np.abs(a - b)) / np.max(np.abs(a)) < 1e-5 * 0.2     # far inside the 1e-5 bar relative to peak
+    assert 1e-10 < worst < oracle.ABS_FLOOR_BATCH, worst
