@@ -224,9 +224,9 @@ def main():
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp):
             try:
-                tj = json.load(open(tp))
-                if tj.get("instances") == n_inst:
-                    traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tp))      # PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) measured per engine
+                per_engine = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_engine_launch")
+                traffic = per_engine * n_inst if per_engine is not None else None
             except Exception:
                 traffic = None
         line = {
