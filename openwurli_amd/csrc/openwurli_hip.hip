@@ -229,6 +229,8 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
     }
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[1], st));
     if (with_voices && (any_main || any_steal)) {
+        // steady-state engines take the lean kernel; k_voice picks up engines with voices in a transient phase and all steal voices
+        if (any_main) owdev::k_voice_steady<<<dim3(ne), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->d_args, p->d_sum, p->d_eout, I, L, Lcap, e0);
         owdev::k_voice<<<dim3(ne, any_steal ? 2 : 1), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->d_args, p->d_sum, p->d_eout, I, L, Lcap, e0);
     }
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[2], st));

@@ -26,6 +26,8 @@ struct OwEngineOut {
     uint64_t bad_steal;       // steal voices that produced a non-finite sample
     uint32_t sum_nonfinite;   // engine.rs:499 NaN guard condition (either pass)
     uint32_t out_nonfinite;   // engine.rs:450 output NaN guard fired this block
+    uint32_t steady_done;     // k_voice_steady rendered the slot pass of this engine (k_voice skips it)
+    uint32_t pad;
 };
 
 // mlp_correction.rs:86-116, scalar lane version (same accumulation order as the reference)
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
     const int lane = threadIdx.x;
     const uint64_t mask = pass ? args[e].steal_mask : args[e].main_mask;
     if (mask == 0ull) return;  // chain kernels skip rows of empty passes
+    if (pass == 0 && eout[e].steady_done) return;  // k_voice_steady already rendered this engine's slot voices
     const bool active = (mask >> lane) & 1ull;
     double* rec = vrec + ((size_t)e * 2 + pass) * OW_VREC_DOUBLES + lane;
     double* row = sum + ((size_t)pass * I + e) * Lcap;
@@ -106,8 +109,7 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
         for (int n = 0; n < cn; ++n) {
             double o = 0.0;
             if (active) {
-                o = v.step(rec, K);
-                if (!isfinite(o)) bad_voice = true;
+                o = v.step<false>(rec, K);
                 if (pass) {  // 5 ms linear crossfade, engine.rs:483-489
                     const uint32_t i = (uint32_t)(base + n);
                     const uint32_t remaining = steal_fade > i ? steal_fade - i : 0u;
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
             }
             tile[lane * (OW_VCHUNK + 1) + n] = o;
         }
+        if (active && !v.state_finite()) bad_voice = true;
         __syncthreads();
         if (lane < cn) {  // sum the 64 slots in slot order (engine.rs:469-479)
             double acc = 0.0;
@@ -142,6 +145,143 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
     if (lane == 0) {
         if (pass == 0) { eout[e].silent_mask = silent_mask; eout[e].bad_main = bad_mask; }
         else eout[e].bad_steal = bad_mask;
+        if (bs) atomicOr(&eout[e].sum_nonfinite, 1u);
+    }
+}
+
+
+// ------------------------------------------------------------------ voices, steady-state fast path
+// Slot voices of engines in which NO voice is inside a damper phase, an onset ramp or an attack-noise burst: the
+// per-sample work is then exactly {OU jitter every 16 samples, 7-mode rotation, renorm every 1024, pickup}.  Those
+// conditions are monotone between events, so one test at block start covers the whole block.  The kernel carries
+// only the fields that path needs (fewer registers) and has no phase tests in its sample loop; engines that fail the
+// test are left to k_voice.  Arithmetic per block is the same as VoiceRegs::step<true>.
+struct VoiceSteady {
+    double s[7], c[7], env[7], drift[7], cos_inc[7], sin_inc[7], phase_inc[7], amp[7], decay[7];
+    double q, ds, gain;
+    uint64_t sample;
+    uint32_t jitter_state;
+
+    OW_DEV double step(const OwConsts* __restrict__ K) {
+#ifndef OW_STRICT_FP
+#pragma clang fp contract(fast)
+#endif
+        const uint32_t lo = (uint32_t)sample;
+        if ((lo & 15u) == 0u) {
+            const double revert = K->jitter_revert, diffusion = K->jitter_diffusion;
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                jitter_state = lcg(jitter_state);
+                const double u = (double)(jitter_state >> 1) / 2147483647.5;
+                const double noise = (u * 2.0 - 1.0) * 1.7320508080;
+                drift[m] = revert * drift[m] + diffusion * noise;
+            }
+        }
+        double sum = 0.0;
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            sum += amp[m] * s[m] * env[m];                 // onset == 1.0 (x * 1.0 == x)
+            const double delta_phase = drift[m] * phase_inc[m];
+            const double ci = cos_inc[m] - delta_phase * sin_inc[m];
+            const double si = sin_inc[m] + delta_phase * cos_inc[m];
+            const double s_new = s[m] * ci + c[m] * si;
+            const double c_new = c[m] * ci - s[m] * si;
+            s[m] = s_new;
+            c[m] = c_new;
+            env[m] *= decay[m];
+        }
+        if ((lo & 1023u) == 0u && sample > 0ull) {
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                const double r_sq = s[m] * s[m] + c[m] * c[m];
+                const double r_inv = 1.0 / sqrt(r_sq);
+                s[m] *= r_inv;
+                c[m] *= r_inv;
+            }
+        }
+        sample += 1ull;
+        const double x = 0.0 + sum;
+        double y = x * ds;
+        const double ay = fabs(y);
+        if (!(ay < 0.94)) y = pickup_saturate_hi(y, ay);
+        const double omy = 1.0 - y;
+        const double alpha = K->pickup_beta * omy;
+        const double q_next = (q * (1.0 - alpha) + 2.0 * K->pickup_beta) / (1.0 + alpha);
+        q = q_next;
+        return ((q_next * omy - 1.0) * 1.8375) * gain;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict__ K, double* __restrict__ vrec, const OwEngineArgs* __restrict__ args,
+                                                     double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int L, int Lcap, int e0) {
+    __shared__ double tile[64 * (OW_VCHUNK + 1)];
+    const int e = e0 + blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint64_t mask = args[e].main_mask;
+    if (mask == 0ull) return;
+    const bool active = (mask >> lane) & 1ull;
+    double* rec = vrec + ((size_t)e * 2) * OW_VREC_DOUBLES + lane;
+    bool transient = false;
+    uint32_t flags = 0;
+    if (active) {
+        flags = (uint32_t)dbits(rec[VF_FLAGS * 64]);
+        const uint64_t smp = dbits(rec[VF_SAMPLE * 64]), onset_n = dbits(rec[VF_ONSET_N * 64]);
+        const uint32_t noise_rem = (uint32_t)dbits(rec[VF_NCNT * 64]);
+        transient = (flags & 1u) || smp < onset_n || noise_rem > 0u;
+    }
+    if (__any(transient)) return;          // eout[e].steady_done stays 0: k_voice renders this engine
+    double* row = sum + (size_t)e * Lcap;  // pass 0 rows
+    VoiceSteady v;
+    uint32_t noise_rng = 0;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            v.s[i] = rec[(VF_S + i) * 64]; v.c[i] = rec[(VF_C + i) * 64]; v.env[i] = rec[(VF_ENV + i) * 64];
+            v.drift[i] = rec[(VF_DRIFT + i) * 64]; v.cos_inc[i] = rec[(VF_COS_INC + i) * 64]; v.sin_inc[i] = rec[(VF_SIN_INC + i) * 64];
+            v.phase_inc[i] = rec[(VF_PHASE_INC + i) * 64]; v.amp[i] = rec[(VF_AMP + i) * 64]; v.decay[i] = rec[(VF_DECAY + i) * 64];
+        }
+        v.q = rec[VF_Q * 64]; v.ds = rec[VF_DS * 64]; v.gain = rec[VF_GAIN * 64];
+        v.sample = dbits(rec[VF_SAMPLE * 64]);
+        const uint64_t r = dbits(rec[VF_RNG * 64]);
+        v.jitter_state = (uint32_t)r; noise_rng = (uint32_t)(r >> 32);
+    }
+    bool bad_sum = false;
+    for (int base = 0; base < L; base += OW_VCHUNK) {
+        const int cn = min(OW_VCHUNK, L - base);
+        for (int n = 0; n < cn; ++n) tile[lane * (OW_VCHUNK + 1) + n] = active ? v.step(K) : 0.0;
+        __syncthreads();
+        if (lane < cn) {  // sum the 64 slots in slot order (engine.rs:469-479)
+            double acc = 0.0;
+#pragma unroll 16
+            for (int s = 0; s < 64; ++s) acc += tile[s * (OW_VCHUNK + 1) + lane];
+            if (!isfinite(acc)) bad_sum = true;
+            row[base + lane] = acc;
+        }
+        __syncthreads();
+    }
+    bool silent = false, bad_voice = false;
+    if (active) {
+        bool fin = isfinite(v.q);
+        bool all_quiet = true;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            rec[(VF_S + i) * 64] = v.s[i]; rec[(VF_C + i) * 64] = v.c[i]; rec[(VF_ENV + i) * 64] = v.env[i]; rec[(VF_DRIFT + i) * 64] = v.drift[i];
+            fin = fin && isfinite(v.s[i]) && isfinite(v.c[i]) && isfinite(v.env[i]);
+            all_quiet = all_quiet && (fabs(v.amp[i] * v.env[i]) <= 1e-4);
+        }
+        rec[VF_Q * 64] = v.q;
+        rec[VF_SAMPLE * 64] = bitsd(v.sample);
+        rec[VF_RNG * 64] = bitsd((uint64_t)v.jitter_state | ((uint64_t)noise_rng << 32));
+        bad_voice = !fin;
+        silent = all_quiet;                // damper inactive here, so only the -80 dB test of Voice::is_silent applies
+    }
+    const uint64_t silent_mask = __ballot(active && silent);
+    const uint64_t bad_mask = __ballot(active && bad_voice);
+    const uint64_t bs = __ballot(bad_sum);
+    if (lane == 0) {
+        eout[e].silent_mask = silent_mask;
+        eout[e].bad_main = bad_mask;
+        eout[e].steady_done = 1u;
         if (bs) atomicOr(&eout[e].sum_nonfinite, 1u);
     }
 }

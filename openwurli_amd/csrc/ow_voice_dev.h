@@ -393,28 +393,43 @@ struct VoiceRegs {
     // One sample of Voice::render (voice.rs:162-179): reed (reed.rs:223-305) + attack noise
     // (hammer.rs:150-179) -> pickup (pickup.rs:130-149) -> x post_pickup_gain.
     // `rec` is only touched for the damper tables (rare path: released voices).
+    //
+    // STEADY = true is the wave-uniform fast path: no lane of the wave is inside a damper phase, an onset ramp
+    // or an attack-noise burst for this chunk, so those three blocks (and their per-sample tests) are compiled out.
+    // The arithmetic of the remaining blocks is identical.
+    //
+    // FMA contraction is enabled for this function (OW_STRICT_FP restores the reference's unfused a*b+c):
+    // the kernel is VALU-issue bound and the rotation / pickup are mul-add chains.  Fused results differ from the
+    // unfused reference by <= 1e-12 of peak over the parity renders (tests/test_gpu_parity.py voice-sum tap).
+    template <bool STEADY>
     OW_DEV double step(const double* __restrict__ rec, const OwConsts* __restrict__ K) {
-        if (flags & 1u) {  // damper_active
-            dcount += 1.0;
-            const double t = dcount;
-            if (!(flags & 2u)) {
-                if (t > dramp) flags |= 2u;
-                else {
+#ifndef OW_STRICT_FP
+#pragma clang fp contract(fast)
+#endif
+        double onset = 1.0;
+        if (!STEADY) {
+            if (flags & 1u) {  // damper_active
+                dcount += 1.0;
+                const double t = dcount;
+                if (!(flags & 2u)) {
+                    if (t > dramp) flags |= 2u;
+                    else {
 #pragma unroll
-                    for (int m = 0; m < 7; ++m) {
-                        const double inst_rate = rec[(VF_DRATE + m) * 64] * t / dramp;
-                        env[m] *= exp_neg(inst_rate);
+                        for (int m = 0; m < 7; ++m) {
+                            const double inst_rate = rec[(VF_DRATE + m) * 64] * t / dramp;
+                            env[m] *= exp_neg(inst_rate);
+                        }
                     }
                 }
-            }
-            if (flags & 2u) {
+                if (flags & 2u) {
 #pragma unroll
-                for (int m = 0; m < 7; ++m) env[m] *= rec[(VF_DMULT + m) * 64];
+                    for (int m = 0; m < 7; ++m) env[m] *= rec[(VF_DMULT + m) * 64];
+                }
             }
+            if (sample < onset_n) onset = onset_gain((double)sample, onset_inc, onset_exp);
         }
-        double onset = 1.0;
-        if (sample < onset_n) onset = onset_gain((double)sample, onset_inc, onset_exp);
-        if ((sample & 15ull) == 0ull) {
+        const uint32_t lo = (uint32_t)sample;
+        if ((lo & 15u) == 0u) {
             const double revert = K->jitter_revert, diffusion = K->jitter_diffusion;
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
@@ -427,7 +442,8 @@ struct VoiceRegs {
         double sum = 0.0;
 #pragma unroll
         for (int m = 0; m < 7; ++m) {
-            sum += amp[m] * s[m] * onset * env[m];
+            if (STEADY) sum += amp[m] * s[m] * env[m];          // onset == 1.0: x * 1.0 == x exactly
+            else sum += amp[m] * s[m] * onset * env[m];
             const double delta_phase = drift[m] * phase_inc[m];
             const double ci = cos_inc[m] - delta_phase * sin_inc[m];
             const double si = sin_inc[m] + delta_phase * cos_inc[m];
@@ -437,7 +453,7 @@ struct VoiceRegs {
             c[m] = c_new;
             env[m] *= decay[m];
         }
-        if ((sample & 1023ull) == 0ull && sample > 0ull) {
+        if ((lo & 1023u) == 0u && sample > 0ull) {
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
                 const double r_sq = s[m] * s[m] + c[m] * c[m];
@@ -448,7 +464,7 @@ struct VoiceRegs {
         }
         sample += 1ull;
         double x = 0.0 + sum;
-        if (noise_rem > 0u) {
+        if (!STEADY && noise_rem > 0u) {
             double e = 1.0;
             if (noise_fade > 0u) {
                 const uint32_t pos = 16u - noise_fade;
@@ -473,6 +489,15 @@ struct VoiceRegs {
         const double q_next = (q * (1.0 - alpha) + 2.0 * K->pickup_beta) / (1.0 + alpha);
         q = q_next;
         return ((q_next * omy - 1.0) * 1.8375) * gain;
+    }
+    // true while the lane needs the general (non-steady) step: damper running, onset ramp or attack noise not finished
+    OW_DEV bool in_transient() const { return (flags & 1u) || sample < onset_n || noise_rem > 0u; }
+    // a non-finite output sample always leaves a non-finite trace in the recurrences (q, s, c, env never recover)
+    OW_DEV bool state_finite() const {
+        bool ok = isfinite(q);
+#pragma unroll
+        for (int m = 0; m < 7; ++m) ok = ok && isfinite(s[m]) && isfinite(c[m]) && isfinite(env[m]);
+        return ok;
     }
 
     // Voice::is_silent (voice.rs:183-188, reed.rs:309-314); threshold 10^(-80/20)
