@@ -107,6 +107,12 @@ int ow_engine_slot_state(const ow_engine*, int slot);                           
 int ow_engine_slot_note(const ow_engine*, int slot);                              /* VoiceSlot.midi_note          */
 int ow_engine_has_steal_voice_for(const ow_engine*, uint8_t note);                /* has_steal_voice_for     :627 */
 
+/* ---- diagnostics ------------------------------------------------------------------------- */
+/* Raw (pre-fade, pre-clamp) outputs of the note-on MLP (mlp_correction.rs:86-116) for n (note, velocity) pairs:
+ * out[n][11].  use_mfma = 1 runs the wavefront-batched v_mfma_f64_16x16x4_f64 path that k_apply_ops uses,
+ * 0 the scalar lane path (batch jobs).  Returns 0, <0 on device error. */
+int ow_debug_mlp_raw(const uint8_t* notes, const double* velocities, size_t n, double* out, int use_mfma, int device);
+
 /* ---- offline / batch ---------------------------------------------------------------------- */
 /* Voice::render_note (voice.rs:191-221): one voice, no chain, f64.  Returns the number of samples
  * of the note ((dur_s*sr) as usize); writes min(n, cap).  Negative on device error. */

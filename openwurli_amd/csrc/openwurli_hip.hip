@@ -14,6 +14,7 @@
 #include "ow_consts_host.hpp"
 #include "ow_kernels.h"
 #include "ow_job_kernels.h"
+#include "ow_mlp_mfma.h"
 
 using owdev::OwEngineOut;
 
@@ -691,6 +692,23 @@ void ow_pool_midi(ow_pool* p, const ow_midi_event* ev, size_t n) {
         });
     }
     for (auto& x : th) x.join();
+}
+
+// ---- diagnostics ---------------------------------------------------------------------------------
+int ow_debug_mlp_raw(const uint8_t* notes, const double* velocities, size_t n, double* out, int use_mfma, int device) {
+    try {
+        if (!notes || !velocities || !out || n == 0) throw std::runtime_error("null argument");
+        HIP_OK(hipSetDevice(device));
+        uint8_t* dn = nullptr; double* dv = nullptr; double* dout = nullptr;
+        HIP_OK(hipMalloc(&dn, n)); HIP_OK(hipMalloc(&dv, n * sizeof(double))); HIP_OK(hipMalloc(&dout, n * 11 * sizeof(double)));
+        HIP_OK(hipMemcpy(dn, notes, n, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(dv, velocities, n * sizeof(double), hipMemcpyHostToDevice));
+        owdev::k_debug_mlp<<<dim3((unsigned)((n + 63) / 64)), dim3(64)>>>(dn, dv, (int)n, dout, use_mfma);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpy(out, dout, n * 11 * sizeof(double), hipMemcpyDeviceToHost));
+        hipFree(dn); hipFree(dv); hipFree(dout);
+        return 0;
+    } catch (const std::exception& ex) { set_err(std::string("ow_debug_mlp_raw: ") + ex.what()); return -1; }
 }
 
 // ---- offline ------------------------------------------------------------------------------------

@@ -120,6 +120,18 @@ OW_DEV bool solve4(double a[4][4], double b[4]) {
     return !singular;
 }
 
+// Trapezoidal-step matrices of the Twin-T solver staged in LDS: 110 wave-uniform f64 constants do not fit the 102 SGPRs
+// (they spilled through v_readlane/v_writelane); a uniform-address ds_read broadcasts one value to the whole wavefront.
+struct TremMats {
+    double a_neg[7][7], s[7][7], k[4][4], s_ni[7][4];
+};
+OW_DEV void trem_mats_load(TremMats* __restrict__ m, const OwConsts* __restrict__ K, int tid, int nthreads) {
+    double* dst = (double*)m;
+    for (int i = tid; i < 49; i += nthreads) { dst[i] = (&K->t_a_neg[0][0])[i]; dst[49 + i] = (&K->t_s[0][0])[i]; }
+    for (int i = tid; i < 16; i += nthreads) dst[98 + i] = (&K->t_k[0][0])[i];
+    for (int i = tid; i < 28; i += nthreads) dst[114 + i] = (&K->t_s_ni[0][0])[i];
+}
+
 struct TremState {
     double v[7], i_prev[4], i_pp[4];
     double env, r_ldr, depth;
@@ -269,12 +281,12 @@ __device__ __noinline__ void trem_be_fallback(const OwConsts* __restrict__ K, co
 
 // gen_tremolo.rs:2353-3116 with input == 0.0 (Tremolo always drives the oscillator with silence,
 // tremolo.rs:183).  Returns v[OUT].
-__device__ inline double trem_osc_step(TremState& st, const OwConsts* __restrict__ K) {
+__device__ inline double trem_osc_step(TremState& st, const OwConsts* __restrict__ K, const TremMats* __restrict__ M) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) st.v[i] = st.v[i] + 1e-25 - 1e-25;
 #pragma unroll
     for (int i = 0; i < 4; ++i) st.i_prev[i] = st.i_prev[i] + 1e-25 - 1e-25;
-    const double (*__restrict__ an)[7] = K->t_a_neg;
+    const double (*__restrict__ an)[7] = M->a_neg;
     double rhs[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 15.0};  // RHS_CONST (gen_tremolo.rs:1055-1063)
     rhs[0] += an[0][0] * st.v[0];
     rhs[0] += an[0][1] * st.v[1];
@@ -306,7 +318,7 @@ __device__ inline double trem_osc_step(TremState& st, const OwConsts* __restrict
     for (int i = 0; i < 7; ++i) {
         double sum = 0.0;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) sum += K->t_s[i][j] * rhs[j];
+        for (int j = 0; j < 7; ++j) sum += M->s[i][j] * rhs[j];
         v_pred[i] = sum;
     }
     double p[4];  // N_V entries are exactly +-1 (gen_tremolo.rs:479-516)
@@ -317,13 +329,13 @@ __device__ inline double trem_osc_step(TremState& st, const OwConsts* __restrict
     double i_nl[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) i_nl[i] = 2.0 * st.i_prev[i] - st.i_pp[i];
-    const bool converged = trem_nr<false>(p, K->t_k, i_nl);
+    const bool converged = trem_nr<false>(p, M->k, i_nl);
     double v[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         double x = v_pred[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x += K->t_s_ni[i][j] * i_nl[j];
+        for (int j = 0; j < 4; ++j) x += M->s_ni[i][j] * i_nl[j];
         v[i] = x;
     }
     if (!converged) {
@@ -350,8 +362,8 @@ __device__ inline double trem_osc_step(TremState& st, const OwConsts* __restrict
 }
 
 // Tremolo::process (tremolo.rs:121-167): returns the shunt impedance seen by fb_junction.
-__device__ inline double trem_process(TremState& st, const OwConsts* __restrict__ K) {
-    const double v_out = trem_osc_step(st, K);
+__device__ inline double trem_process(TremState& st, const OwConsts* __restrict__ K, const TremMats* __restrict__ M) {
+    const double v_out = trem_osc_step(st, K, M);
     const double led = clampd((10.95 - v_out) / (10.95 - 0.70), 0.0, 1.0);
     const double coeff = led > st.env ? K->ldr_attack : K->ldr_release;
     st.env = led + coeff * (st.env - led);

@@ -52,28 +52,46 @@ __device__ inline void mlp_raw_scalar(double in0, double in1, double raw[11]) {
 }
 
 // ------------------------------------------------------------------ slot ops
+__device__ inline void mlp_raw_mfma(double* __restrict__ h, double in0, double in1, double raw[11]);   // ow_mlp_mfma.h
+
+// Ops of one engine are applied in queue order per slot.  The wavefront advances in rounds: every lane takes its next
+// pending op; the note-ons of a round share ONE batched MLP evaluation on the f64 matrix cores (ow_mlp_mfma.h).
 __global__ __launch_bounds__(64) void k_apply_ops(const OwConsts* __restrict__ K, const double* __restrict__ nt, double* __restrict__ vrec,
                                                   const OwEngineArgs* __restrict__ args, const OwOp* __restrict__ ops, int e0) {
+    __shared__ double h[64 * 17];
     const int e = e0 + blockIdx.x;
     const int lane = threadIdx.x;
     const OwEngineArgs a = args[e];
     if (a.op_count == 0) return;
     double* main_rec = vrec + ((size_t)e * 2 + 0) * OW_VREC_DOUBLES + lane;
     double* steal_rec = vrec + ((size_t)e * 2 + 1) * OW_VREC_DOUBLES + lane;
-    for (uint32_t k = 0; k < a.op_count; ++k) {
-        const OwOp op = ops[a.op_begin + k];
-        if (op.slot != lane) continue;
+    uint32_t cursor = 0;
+    for (;;) {
+        OwOp op;
+        op.type = 0;
+        while (cursor < a.op_count) {            // next op addressed to this slot
+            const OwOp cand = ops[a.op_begin + cursor];
+            ++cursor;
+            if (cand.slot == lane) { op = cand; break; }
+        }
+        if (!__any(op.type != 0)) break;
+        const bool is_on = op.type == OP_NOTE_ON;
+        if (__any(is_on)) {                      // wave-uniform: one MFMA batch for all note-ons of this round
+            const double midi = is_on ? (double)op.note : 60.0;
+            const double in0 = clampd((midi - 21.0) / (108.0 - 21.0), 0.0, 1.0);
+            const double in1 = is_on ? clampd(op.velocity, 0.0, 1.0) : 0.0;
+            double raw[11];
+            mlp_raw_mfma(h, in0, in1, raw);
+            if (is_on) {
+                const MlpOut corr = mlp_finish((int)op.note, raw, op.mlp != 0);
+                note_on_lane(main_rec, nt, K, (int)op.note, op.velocity, op.seed, corr);
+            }
+        }
         if (op.type == OP_DAMPER) {
             start_damper_lane(main_rec, K);
         } else if (op.type == OP_MOVE_STEAL) {  // slot.steal_voice = slot.voice.take() (engine.rs:316-321)
             for (int f = 0; f < VF_COUNT; ++f) steal_rec[f * 64] = main_rec[f * 64];
             steal_rec[VF_STEAL * 64] = bitsd((uint64_t)op.seed | ((uint64_t)op.seed << 32));
-        } else if (op.type == OP_NOTE_ON) {
-            double raw[11];
-            const double midi = (double)op.note;
-            mlp_raw_scalar(clampd((midi - 21.0) / (108.0 - 21.0), 0.0, 1.0), clampd(op.velocity, 0.0, 1.0), raw);
-            const MlpOut corr = mlp_finish((int)op.note, raw, op.mlp != 0);
-            note_on_lane(main_rec, nt, K, (int)op.note, op.velocity, op.seed, corr);
         }
     }
 }
@@ -335,7 +353,7 @@ OW_DEV void dk_store(const DkSt& s, double* __restrict__ cs, int I, int e, int b
 //   mode 0  reset (engine.rs:231-251): preamp.reset() at the current R_ldr, tremolo rebuilt, oversampler and
 //           speaker state cleared, smoothers snapped to their targets
 // The Twin-T oscillator is left at CircuitState DC_OP; k_trem_settle then runs the 50 + 2*sr settle.
-__global__ void k_chain_init(const OwConsts* __restrict__ K, double* __restrict__ cs, int I, int e0, int ne, int mode, double depth0) {
+__global__ __launch_bounds__(64) void k_chain_init(const OwConsts* __restrict__ K, double* __restrict__ cs, int I, int e0, int ne, int mode, double depth0) {
     const int e = e0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= e0 + ne) return;
     const double dc[7] = {4.26480458363572357e0, 0.0, 1.24642300965575981e0, 2.75561285973736503e0, 6.66518981651571640e-1, 1.5e1, -2.28408414614134341e-3};
@@ -390,12 +408,19 @@ __global__ void k_chain_init(const OwConsts* __restrict__ K, double* __restrict_
 
 // n oscillator steps with the matrices of `K` (Tremolo::new settle loop tremolo.rs:97-100; CircuitState::warmup
 // gen_tremolo.rs:2071-2075 when K holds the 48 kHz codegen matrices).
-__global__ void k_trem_settle(const OwConsts* __restrict__ K, double* __restrict__ cs, int I, int e0, int ne, long long n) {
+__global__ __launch_bounds__(64) void k_trem_settle(const OwConsts* __restrict__ K, double* __restrict__ cs, int I, int e0, int ne, long long n) {
+    __shared__ TremMats M;
+    trem_mats_load(&M, K, threadIdx.x, blockDim.x);
+    __syncthreads();
     const int e = e0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= e0 + ne) return;
     TremState t;
     trem_load(t, cs, I, e);
-    for (long long i = 0; i < n; ++i) trem_osc_step(t, K);
+    for (long long i = 0; i < n; ++i) {
+        int z = 0;
+        asm volatile("" : "+v"(z));        // opaque zero: keeps the LDS reads inside the loop (no hoist into 200 live VGPRs)
+        trem_osc_step(t, K, &M + z);
+    }
     trem_store(t, cs, I, e);
 }
 
@@ -409,6 +434,9 @@ __global__ void k_chain_replicate(double* __restrict__ cs, int I, int src, int e
 // ------------------------------------------------------------------ tremolo stream
 __global__ __launch_bounds__(64) void k_tremolo(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args,
                                                 double* __restrict__ rbuf, int I, int L, int e0, int ne) {
+    __shared__ TremMats M;
+    trem_mats_load(&M, K, threadIdx.x, 64);
+    __syncthreads();
     const int e = e0 + blockIdx.x * 64 + threadIdx.x;
     if (e >= e0 + ne) return;
     TremState t;
@@ -419,7 +447,11 @@ __global__ __launch_bounds__(64) void k_tremolo(const OwConsts* __restrict__ K, 
     const int osr = K->oversample ? 2 : 1;
     for (int i = 0; i < L; ++i) {
         t.depth = clampd(sd.next(), 0.0, 1.0);  // engine.rs:533-534, tremolo.rs:117-119
-        for (int j = 0; j < osr; ++j) rbuf[(size_t)(i * osr + j) * I + e] = trem_process(t, K);
+        for (int j = 0; j < osr; ++j) {
+            int z = 0;
+            asm volatile("" : "+v"(z));    // opaque zero: keeps the LDS reads inside the loop
+            rbuf[(size_t)(i * osr + j) * I + e] = trem_process(t, K, &M + z);
+        }
     }
     trem_store(t, cs, I, e);
     smoother_store(sd, cs, I, e, CS_SM_DEPTH);

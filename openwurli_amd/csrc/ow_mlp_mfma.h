@@ -1,0 +1,86 @@
+// openwurli-hip: note-on MLP (2 -> 16 -> 16 -> 11, mlp_correction.rs:86-116) for a whole wavefront of note-ons on the
+// f64 matrix cores: v_mfma_f64_16x16x4_f64, D(16x16) = A(16x4) * B(4x16) + C.
+//
+//   lane = voice slot.  Layer 1 (K = 2) is two scalar MACs per hidden unit.  Layers 2 and 3 are 16x16 (x16 voices)
+//   tiles: A = weight block W[:, 4c..4c+3], B = activations of 16 voices, K = 16 in four MFMA steps, four voice tiles
+//   per wavefront -> 32 MFMAs replace 2 x 432 scalar multiply-adds per lane.  Activations cross lanes through a
+//   64 x 17 LDS tile (row = voice, padded).
+//
+// Fragment layout (cdna_hip_programming.md section 3, f64 form): A: lane l holds A[i = l & 15][k = l >> 4];
+// B: lane l holds B[k = l >> 4][j = l & 15]; C/D: lane l, register r holds D[row = (l >> 4) + 4 r][col = l & 15].
+// The bias enters as the C operand, so each output is bias + sum_k (fused multiply-adds); it differs from the scalar
+// reference order by f64 rounding only (checked against the scalar path by tests/test_gpu_parity.py::test_mlp_mfma).
+#pragma once
+#include "ow_kernels.h"
+
+namespace owdev {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// h: LDS tile [64][17]; on entry row v holds the 16 input activations of voice v, on exit the 16 outputs.
+// W: [rows][16] row-major weights (rows <= 16), bias[rows].  relu: apply max(x, 0).
+__device__ inline void mlp_layer_mfma(double* __restrict__ h, const double (*__restrict__ W)[16], const double* __restrict__ bias, int rows, bool relu) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    v4f64 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {            // voice tile t = voices 16t .. 16t+15
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = kq + 4 * r;
+            acc[t][r] = row < rows ? bias[row] : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {        // K chunk: hidden units 4c .. 4c+3
+            const double a = i < rows ? W[i][4 * c + kq] : 0.0;
+            const double b = h[(16 * t + i) * 17 + 4 * c + kq];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double x = acc[t][r];
+            if (relu) x = x > 0.0 ? x : 0.0;
+            h[(16 * t + i) * 17 + kq + 4 * r] = x;
+        }
+    __syncthreads();
+}
+
+// raw[11] for every lane (inputs in0/in1 per lane; lanes without a note-on may pass zeros).  Must be called by all
+// 64 lanes of the block in uniform control flow.  h = LDS scratch of 64*17 doubles.
+__device__ inline void mlp_raw_mfma(double* __restrict__ h, double in0, double in1, double raw[11]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {           // layer 1: affine + ReLU, same order as the scalar reference
+        double sum = MLP_B1[i];
+        sum += MLP_W1[i][0] * in0;
+        sum += MLP_W1[i][1] * in1;
+        h[lane * 17 + i] = sum > 0.0 ? sum : 0.0;
+    }
+    __syncthreads();
+    mlp_layer_mfma(h, MLP_W2, MLP_B2, 16, true);
+    mlp_layer_mfma(h, MLP_W3, MLP_B3, 11, false);
+#pragma unroll
+    for (int i = 0; i < 11; ++i) raw[i] = h[lane * 17 + i] * MLP_TARGET_STDS[i] + MLP_TARGET_MEANS[i];
+    __syncthreads();
+}
+
+// debug/test kernel: raw MLP outputs for n (note, velocity) pairs, scalar or MFMA path
+__global__ __launch_bounds__(64) void k_debug_mlp(const uint8_t* __restrict__ notes, const double* __restrict__ vels, int n, double* __restrict__ out, int use_mfma) {
+    __shared__ double h[64 * 17];
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    const bool valid = idx < n;
+    const double midi = valid ? (double)notes[idx] : 60.0;
+    const double vel = valid ? vels[idx] : 0.0;
+    const double in0 = clampd((midi - 21.0) / (108.0 - 21.0), 0.0, 1.0), in1 = clampd(vel, 0.0, 1.0);
+    double raw[11];
+    if (use_mfma) mlp_raw_mfma(h, in0, in1, raw);
+    else mlp_raw_scalar(in0, in1, raw);
+    if (valid)
+        for (int i = 0; i < 11; ++i) out[(size_t)idx * 11 + i] = raw[i];
+}
+
+}  // namespace owdev

@@ -292,3 +292,37 @@ def test_batch_wav_quantiser_round_trip(hiplib, oracle):
     qg = np.clip(np.round(g * mx), -mx, mx).astype(np.int64)
     qc = np.clip(np.round(c * mx), -mx, mx).astype(np.int64)
     assert np.max(np.abs(qg - qc)) <= 1
+
+
+# ------------------------------------------------------------------ note-on MLP on the f64 matrix cores
+def test_mlp_mfma(hiplib, oracle):
+    """v_mfma_f64_16x16x4_f64 batch MLP (what k_apply_ops runs) vs the scalar lane path vs the oracle's clamped outputs."""
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    n = 200                                                   # not a multiple of 64: ragged last wavefront
+    notes = rng.integers(21, 109, size=n).astype(np.uint8)
+    vels = rng.random(n)
+    raw_m = np.zeros((n, 11)); raw_s = np.zeros((n, 11))
+    assert hiplib.ow_debug_mlp_raw(notes.ctypes.data_as(C.c_void_p), vels.ctypes.data_as(C.c_void_p), n, raw_m.ctypes.data_as(C.c_void_p), 1, 0) == 0
+    assert hiplib.ow_debug_mlp_raw(notes.ctypes.data_as(C.c_void_p), vels.ctypes.data_as(C.c_void_p), n, raw_s.ctypes.data_as(C.c_void_p), 0, 0) == 0
+    assert np.all(np.isfinite(raw_m))
+    scale = np.maximum(np.abs(raw_s), 1.0)
+    assert np.max(np.abs(raw_m - raw_s) / scale) < 1e-13       # same network, different summation order / fusion
+    # oracle's finished corrections (fade + clamps, mlp_correction.rs:118-133) from the MFMA raw outputs
+    L = oracle.lib()
+    out = np.zeros(11)
+    for i in range(n):
+        midi = int(notes[i])
+        L.owo_mlp_infer(midi, C.c_double(vels[i]), out.ctypes.data_as(C.c_void_p))
+        if midi < 65:
+            fade = min(max((midi - 53) / 12.0, 0.0), 1.0)
+        elif midi > 97:
+            fade = min(max((109 - midi) / 12.0, 0.0), 1.0)
+        else:
+            fade = 1.0
+        if fade <= 0:
+            continue
+        cents = np.clip(raw_m[i, :5] * fade, -100, 100)
+        decay = 1.0 + (np.clip(raw_m[i, 5:10], 0.3, 3.0) - 1.0) * fade
+        ds = 1.0 + (np.clip(raw_m[i, 10], 0.7, 1.2) - 1.0) * fade
+        assert np.max(np.abs(cents - out[:5])) < 1e-10 and np.max(np.abs(decay - out[5:10])) < 1e-12 and abs(ds - out[10]) < 1e-12
