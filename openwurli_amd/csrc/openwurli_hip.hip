@@ -15,6 +15,7 @@
 #include "ow_kernels.h"
 #include "ow_job_kernels.h"
 #include "ow_mlp_mfma.h"
+#include "ow_melange_dev.h"
 
 using owdev::OwEngineOut;
 
@@ -87,6 +88,7 @@ struct ow_pool {
     double* d_nt = nullptr;
     double* d_vrec = nullptr;
     double* d_cs = nullptr;
+    double* d_mel_settled = nullptr;  // melange preamp: settled codegen-rate state (18 doubles)
     double* d_sum = nullptr;
     double* d_rbuf = nullptr;
     double* d_pre = nullptr;
@@ -153,6 +155,8 @@ void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<do
         owdev::k_chain_init<<<dim3((j - i + 63) / 64), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, I, e0 + i, j - i, mode, depth0[i]);
         i = j;
     }
+    if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)   // DkPreamp::new / reset of the melange adapter: settled state at the chain rate
+        owdev::k_mel_init<<<dim3((2 * ne + 63) / 64), dim3(64), 0, p->stream>>>(p->d_cs, p->d_mel_settled, I, e0, ne);
     const int blocks = (ne + 63) / 64;
     owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, I, e0, ne, 50LL);
     const long long n_settle = (long long)owhip::sat_u32(p->hc.os_sr * 2.0);
@@ -237,7 +241,11 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[2], st));
     HIP_OK(hipStreamWaitEvent(st, p->ev_trem, 0));
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[3], st));
-    owdev::k_preamp<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, p->d_rbuf, p->d_pre, I, L, Lcap, e0, ne);
+    if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)
+        owdev::k_preamp_mel<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, p->d_rbuf,
+                                                                      p->d_pre, I, L, Lcap, e0, ne);
+    else
+        owdev::k_preamp<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, p->d_rbuf, p->d_pre, I, L, Lcap, e0, ne);
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[4], st));
     owdev::k_post<<<dim3((ne + 63) / 64), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, Lcap, e0, ne);
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[5], st));
@@ -339,7 +347,7 @@ void push_op(ow_engine* en, uint8_t type, int slot, uint8_t note, bool mlp, uint
 
 ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int preamp_kind) {
     if (!(sample_rate > 0.0) || n_engines == 0) throw std::runtime_error("invalid sample rate or engine count");
-    if (preamp_kind != OW_PREAMP_LEGACY8) throw std::runtime_error("preamp_kind: only OW_PREAMP_LEGACY8 is built in this round");
+    if (preamp_kind != OW_PREAMP_LEGACY8 && preamp_kind != OW_PREAMP_MELANGE12) throw std::runtime_error("unknown preamp_kind");
     int ndev = 0;
     HIP_OK(hipGetDeviceCount(&ndev));
     if (ndev <= 0) throw std::runtime_error("no HIP device: openwurli-hip has no CPU fallback");
@@ -368,6 +376,11 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     alloc_stream_buffers(p, n_engines == 1 ? (size_t)OW_MAX_BLOCK : (size_t)1024);  // engine.rs:25 MAX_BLOCK_SIZE for a lone engine
     upload_consts(p, sample_rate, preamp_kind);
     owdev::k_note_table<<<dim3(1), dim3(64), 0, p->stream>>>(p->d_nt);
+    if (preamp_kind == OW_PREAMP_MELANGE12) {
+        HIP_OK(hipMalloc(&p->d_mel_settled, sizeof(double) * 18));
+        // settled-state cache of the adapter (melange_adapter.rs:12-20): 176 400 steps at the 48 kHz codegen tables
+        owdev::k_mel_settle<<<dim3(1), dim3(64), 0, p->stream>>>(p->dK48, p->d_mel_settled);
+    }
     p->engines.resize(n_engines);
     p->dirty.assign(n_engines, 1);
     for (size_t i = 0; i < n_engines; ++i) {
@@ -392,6 +405,7 @@ void pool_destroy(ow_pool* p) {
     if (p->stream) hipStreamSynchronize(p->stream);
     free_stream_buffers(p);
     hipFree(p->dK); hipFree(p->dK48); hipFree(p->d_nt); hipFree(p->d_vrec); hipFree(p->d_cs);
+    if (p->d_mel_settled) hipFree(p->d_mel_settled);
     hipFree(p->d_args); hipFree(p->d_eout);
     if (p->d_ops) hipFree(p->d_ops);
     if (p->h_ops) hipHostFree(p->h_ops);

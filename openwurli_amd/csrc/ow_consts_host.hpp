@@ -215,6 +215,51 @@ static void build_preamp_consts(OwConsts& c) {
     c.p_sfb_ni[1] = row[EMIT2] - row[COLL2];
 }
 
+// melange 12-node preamp: S0 = A^-1 at (chain rate, nominal 100 kOhm pot) with the reference's LU (gen_preamp.rs:1990-2062,
+// 2117-2219; codegen tables within 0.5 Hz of 48 kHz, :1941-1957), plus the rank-one vectors of the R_ldr entry A[6][6].
+static void build_melange_consts(OwConsts& c) {
+    const double rate = c.os_sr;
+    if (std::fabs(rate - PRE_SAMPLE_RATE) < 0.5) {
+        std::memcpy(c.m_s0, PRE_S_DEFAULT, sizeof c.m_s0);
+        std::memcpy(c.m_aneg0, PRE_A_NEG_DEFAULT, sizeof c.m_aneg0);
+        std::memcpy(c.m_k0, PRE_K_DEFAULT, sizeof c.m_k0);
+        std::memcpy(c.m_sni0, PRE_S_NI_DEFAULT, sizeof c.m_sni0);
+    } else {
+        const double alpha = 2.0 * (rate * 1.0);
+        double a[12][12];
+        for (int i = 0; i < 12; ++i)
+            for (int j = 0; j < 12; ++j) {
+                a[i][j] = PRE_G[i][j] + alpha * PRE_C[i][j];
+                c.m_aneg0[i][j] = (i == 11) ? 0.0 : alpha * PRE_C[i][j] - PRE_G[i][j];
+            }
+        if (!lu_invert<12>(&a[0][0], &c.m_s0[0][0]))
+            for (int i = 0; i < 12; ++i) for (int j = 0; j < 12; ++j) c.m_s0[i][j] = (i == j) ? 1.0 : 0.0;   // identity fallback (:2142-2148)
+        for (int i = 0; i < 12; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double sum = 0.0;
+                for (int k = 0; k < 12; ++k) sum += c.m_s0[i][k] * PRE_N_I[j][k];
+                c.m_sni0[i][j] = sum;
+            }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double sum = 0.0;
+                for (int n = 0; n < 12; ++n) sum += PRE_N_V[i][n] * c.m_sni0[n][j];
+                c.m_k0[i][j] = sum;
+            }
+    }
+    for (int i = 0; i < 12; ++i) { c.m_u[i] = c.m_s0[i][6]; c.m_w[i] = c.m_s0[6][i]; }
+    c.m_s66 = c.m_s0[6][6];
+    c.m_g_nom = PRE_POT_0_G_NOM;
+    for (int j = 0; j < 3; ++j) {
+        double sum = 0.0;
+        for (int k = 0; k < 12; ++k) sum += c.m_w[k] * PRE_N_I[j][k];
+        c.m_wn[j] = sum;
+        double s2 = 0.0;
+        for (int n = 0; n < 12; ++n) s2 += PRE_N_V[j][n] * c.m_u[n];
+        c.m_nvu[j] = s2;
+    }
+}
+
 static void build_consts(OwConsts& c, double sample_rate, int preamp_kind) {
     std::memset(&c, 0, sizeof c);
     c.sr = sample_rate;
@@ -232,6 +277,7 @@ static void build_consts(OwConsts& c, double sample_rate, int preamp_kind) {
     c.spk_thermal_alpha = 1.0 / (5.0 * sample_rate);
     build_tremolo_consts(c);
     build_preamp_consts(c);
+    build_melange_consts(c);
 }
 
 }  // namespace owhip

@@ -1,0 +1,459 @@
+// openwurli-hip: melange 12-node DK preamp (cargo feature `melange-preamp` of the reference), device code.
+//
+//   lane = (engine, main|shadow) as in k_preamp.
+//
+// The reference re-inverts the 12x12 system matrix (LU, partial pivoting) on every sample whose R_ldr moved
+// (gen_preamp.rs:1990-2062, 3408-3411) -- i.e. on every 96 kHz sample while the tremolo runs, in both states.  R_ldr
+// enters the MNA matrix in exactly one entry, A[6][6] += 1/R - 1/R_nom, so the inverse is a rank-one update of the
+// inverse at the nominal 100 kOhm (Sherman-Morrison):
+//     S(R) = S0 - c u w^T,   c = dg / (1 + dg S0[6][6]),  u = S0[:,6],  w = S0[6,:],  dg = 1/R - 1/R_nom
+// and S(R) rhs, K(R) = N_v S(R) N_i, S(R) N_i i_nl follow from pool-uniform constants (S0, u, w, w N_i, N_v u) without
+// ever forming a per-engine matrix.  This is the same construction the reference's own legacy solver uses for R_ldr
+// (dk_preamp_legacy.rs:196-214).  It is mathematically identical to the reference's per-sample LU and differs from it
+// by f64 rounding of a different (shorter) operation sequence; the measured deviation from the literal-LU oracle is in
+// DESIGN.md section 2.  S0 itself is the reference's LU inverse at (chain rate, 100 kOhm), built on the host.
+// The BE-fallback matrices are never rebuilt by the reference (gen_preamp.rs:2058-2061): codegen tables.
+//
+// Mirrors gen_preamp.rs:1973-1984 (set_runtime_R), :3041-3095 (build_rhs), :3122-3357 (solve_nonlinear),
+// :3399-3663 (process_sample), dk_preamp/melange_adapter.rs:12-94.  Thermal noise (off by default) is not built.
+#pragma once
+#include "ow_kernels.h"
+
+namespace owdev {
+
+struct MelSt {
+    double v[12], ip[3], ipp[3], input_prev, pot;
+    uint32_t be_cooldown;
+    uint32_t nan_resets, be_fallbacks;
+};
+
+// pool-uniform trapezoidal constants at the chain rate and the nominal pot, staged in LDS
+struct MelMats {
+    double s0[12][12], aneg0[12][12], k0[3][3], sni0[12][3];
+    double u[12], w[12], wn[3], nvu[3], s66, g_nom;
+};
+OW_DEV void mel_mats_load(MelMats* __restrict__ m, const OwConsts* __restrict__ K, int tid, int nthreads) {
+    double* dst = (double*)m;
+    const double* src = &K->m_s0[0][0];
+    for (int i = tid; i < (int)(sizeof(MelMats) / sizeof(double)); i += nthreads) dst[i] = src[i];
+}
+
+// solve_nonlinear (gen_preamp.rs:3122-3357) with the 3x3 kernel in registers; returns last_nr_iterations (265 = failed)
+__device__ inline uint32_t mel_solve_nl(const double p[3], const double kk[3][3], const double ip[3], const double ipp[3], double i_nl[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) i_nl[i] = 2.0 * ip[i] - ipp[i];
+    for (int iter = 0; iter < 265; ++iter) {
+        double vd[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) vd[q] = p[q] + kk[q][0] * i_nl[0] + kk[q][1] * i_nl[1] + kk[q][2] * i_nl[2];
+        const double nvt0 = PRE_DEVICE_0_N_VT;
+        const double vcl = clampd(vd[0], -40.0 * nvt0, 40.0 * nvt0);
+        double idev[3], jdev[3];
+        idev[0] = PRE_DEVICE_0_IS * (fast_exp(vcl / nvt0) - 1.0);
+        jdev[0] = (PRE_DEVICE_0_IS / nvt0) * fast_exp(vcl / nvt0);
+        const double e1 = fast_exp((vd[1] * 1.0) / (PRE_DEVICE_1_NF * PRE_DEVICE_1_VT));
+        idev[1] = PRE_DEVICE_1_IS * (e1 - 1.0) * 1.0;
+        jdev[1] = PRE_DEVICE_1_IS / (PRE_DEVICE_1_NF * PRE_DEVICE_1_VT) * e1;
+        const double e2 = fast_exp((vd[2] * 1.0) / (PRE_DEVICE_2_NF * PRE_DEVICE_2_VT));
+        idev[2] = PRE_DEVICE_2_IS * (e2 - 1.0) * 1.0;
+        jdev[2] = PRE_DEVICE_2_IS / (PRE_DEVICE_2_NF * PRE_DEVICE_2_VT) * e2;
+        const double f[3] = {i_nl[0] - idev[0], i_nl[1] - idev[1], i_nl[2] - idev[2]};
+        double a[3][3], b[3] = {f[0], f[1], f[2]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) a[i][j] = (i == j ? 1.0 : 0.0) - jdev[i] * kk[i][j];
+        bool singular = false;
+#pragma unroll
+        for (int col = 0; col < 3; ++col) {
+            int max_row = col;
+            double max_val = fabs(a[col][col]);
+#pragma unroll
+            for (int row = col + 1; row < 3; ++row) {
+                const double v = fabs(a[row][col]);
+                if (v > max_val) { max_val = v; max_row = row; }
+            }
+            if (!singular && max_val < 1e-15) singular = true;
+            if (!singular) {
+#pragma unroll
+                for (int row = col + 1; row < 3; ++row) {
+                    const bool sw = (max_row == row);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const double x = a[col][j], y = a[row][j];
+                        a[col][j] = sw ? y : x;
+                        a[row][j] = sw ? x : y;
+                    }
+                    const double x = b[col], y = b[row];
+                    b[col] = sw ? y : x;
+                    b[row] = sw ? x : y;
+                }
+                const double pivot = a[col][col];
+#pragma unroll
+                for (int row = col + 1; row < 3; ++row) {
+                    const double factor = a[row][col] / pivot;
+#pragma unroll
+                    for (int j = col + 1; j < 3; ++j) a[row][j] -= factor * a[col][j];
+                    b[row] -= factor * b[col];
+                }
+            }
+        }
+        if (!singular) {
+#pragma unroll
+            for (int i = 2; i >= 0; --i) {
+                double sum = b[i];
+#pragma unroll
+                for (int j = i + 1; j < 3; ++j) sum -= a[i][j] * b[j];
+                if (!singular && fabs(a[i][i]) < 1e-15) singular = true;
+                if (!singular) b[i] = sum / a[i][i];
+            }
+        }
+        if (!singular) {
+            double dv[3], al[3] = {1.0, 1.0, 1.0};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) dv[q] = -(kk[q][0] * b[0] + kk[q][1] * b[1] + kk[q][2] * b[2]);
+            const double vts[3] = {PRE_DEVICE_0_N_VT, PRE_DEVICE_1_VT, PRE_DEVICE_2_VT};
+            const double vcr[3] = {PRE_DEVICE_0_VCRIT, PRE_DEVICE_1_VCRIT, PRE_DEVICE_2_VCRIT};
+            bool any_limited = false;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (fabs(dv[q]) > 1e-4) {
+                    const double v_lim = pnjlim(vd[q] + dv[q], vd[q], vts[q], vcr[q]);
+                    const double ratio = fmax((v_lim - vd[q]) / dv[q], 0.01);
+                    if (ratio < al[q]) { al[q] = ratio; if (ratio < 1.0) any_limited = true; }
+                }
+            }
+            double as = fmin(al[0], fmin(al[1], al[2]));
+            if (as < 1.0) any_limited = true;
+            const double max_di = fmax(fmax(fabs(b[0]), fabs(b[1])), fabs(b[2]));
+            if (max_di * as > 0.1) as = fmin(fmax(0.1 / max_di, 0.01), as);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) i_nl[q] -= as * b[q];
+            bool conv = true;
+            if (!any_limited) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const double step = dv[q] * as;
+                    const double thr = 1e-3 * fmax(fabs(vd[q]), fabs(vd[q] + step)) + 1e-6;
+                    if (fabs(step) > thr) conv = false;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const double i_thr = 1e-3 * fmax(fmax(fabs(i_nl[q]), fabs(idev[q])), 1e-9) + 1e-12;
+                if (fabs(f[q]) > i_thr) conv = false;
+            }
+            if (conv) return (uint32_t)iter;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const double cl = fmax(fabs(i_nl[q]) * 0.1, 0.01);
+                i_nl[q] -= clampd(f[q] * 0.5, -cl, cl);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (!isfinite(i_nl[q])) i_nl[q] = ip[q];
+    return 265u;
+}
+
+// Backward-Euler fallback (gen_preamp.rs:3483-3572) with the never-rebuilt 48 kHz / 100 kOhm codegen tables.
+__device__ __noinline__ uint32_t mel_be_fallback(const MelSt& st, double input, double vn[12], double i_nl[3]) {
+    double rhs[12], vp[12], p[3];
+    for (int i = 0; i < 12; ++i) {
+        double sum = PRE_RHS_CONST_BE[i];
+        for (int j = 0; j < 12; ++j) sum += PRE_A_NEG_BE_DEFAULT[i][j] * st.v[j];
+        for (int j = 0; j < 3; ++j) sum += PRE_N_I[j][i] * st.ip[j];
+        rhs[i] = sum;
+    }
+    rhs[0] += input / PRE_INPUT_RESISTANCE;
+    for (int i = 0; i < 12; ++i) {
+        double sum = 0.0;
+        for (int j = 0; j < 12; ++j) sum += PRE_S_BE_DEFAULT[i][j] * rhs[j];
+        vp[i] = sum;
+    }
+    for (int i = 0; i < 3; ++i) {
+        double sum = 0.0;
+        for (int j = 0; j < 12; ++j) sum += PRE_N_V[i][j] * vp[j];
+        p[i] = sum;
+    }
+    double kb[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) kb[i][j] = PRE_K_BE_DEFAULT[i][j];
+    const uint32_t it = mel_solve_nl(p, kb, st.ip, st.ipp, i_nl);
+    for (int i = 0; i < 12; ++i) {
+        double x = vp[i];
+        for (int j = 0; j < 3; ++j) x += PRE_S_NI_BE_DEFAULT[i][j] * i_nl[j];
+        vn[i] = x;
+    }
+    return it;
+}
+
+// gen_preamp::process_sample (gen_preamp.rs:3399-3663), noise disabled.  Returns the OUT node voltage.
+__device__ inline double mel_process(MelSt& st, double input_in, const MelMats* __restrict__ M) {
+    const double input = isfinite(input_in) ? clampd(input_in, -100.0, 100.0) : 0.0;
+    // rank-one factor of the current R_ldr (replaces the lazy rebuild_matrices of the reference)
+    const double dg = 1.0 / st.pot - M->g_nom;
+    const double c = dg / (1.0 + dg * M->s66);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) st.v[i] = st.v[i] + 1e-25 - 1e-25;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st.ip[i] = st.ip[i] + 1e-25 - 1e-25;
+    const bool force_be = st.be_cooldown > 0u;
+    if (st.be_cooldown > 0u) st.be_cooldown -= 1u;
+    const double* v = st.v;
+#define AN(i, j) M->aneg0[i][j]
+    const double an66 = AN(6, 6) - dg;                               // A_neg = alpha C - G_eff: only [6][6] depends on R
+    double rhs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 15.0};     // RHS_CONST (gen_preamp.rs:760-773)
+    rhs[0] += AN(0, 0) * v[0] + AN(0, 1) * v[1];
+    rhs[1] += AN(1, 0) * v[0] + AN(1, 1) * v[1] + AN(1, 2) * v[2];
+    rhs[2] += AN(2, 1) * v[1] + AN(2, 2) * v[2] + AN(2, 3) * v[3] + AN(2, 4) * v[4] + AN(2, 5) * v[5];
+    rhs[3] += AN(3, 2) * v[2] + AN(3, 3) * v[3] + AN(3, 4) * v[4] + AN(3, 7) * v[7] + AN(3, 11) * v[11];
+    rhs[4] += AN(4, 2) * v[2] + AN(4, 3) * v[3] + AN(4, 4) * v[4] + AN(4, 7) * v[7] + AN(4, 8) * v[8];
+    rhs[5] += AN(5, 2) * v[2] + AN(5, 5) * v[5] + AN(5, 6) * v[6];
+    rhs[6] += AN(6, 5) * v[5] + an66 * v[6] + AN(6, 10) * v[10];
+    rhs[7] += AN(7, 3) * v[3] + AN(7, 4) * v[4] + AN(7, 7) * v[7] + AN(7, 10) * v[10];
+    rhs[8] += AN(8, 4) * v[4] + AN(8, 8) * v[8] + AN(8, 9) * v[9];
+    rhs[9] += AN(9, 8) * v[8] + AN(9, 9) * v[9];
+    rhs[10] += AN(10, 6) * v[6] + AN(10, 7) * v[7] + AN(10, 10) * v[10];
+#undef AN
+    rhs[2] += PRE_N_I[0][2] * st.ip[0];
+    rhs[2] += PRE_N_I[1][2] * st.ip[1];
+    rhs[4] += PRE_N_I[1][4] * st.ip[1];
+    rhs[4] += PRE_N_I[2][4] * st.ip[2];
+    rhs[5] += PRE_N_I[1][5] * st.ip[1];
+    rhs[7] += PRE_N_I[2][7] * st.ip[2];
+    rhs[8] += PRE_N_I[2][8] * st.ip[2];
+    rhs[0] += (input + st.input_prev) / PRE_INPUT_RESISTANCE;
+    // v_pred = S(R) rhs = S0 rhs - c u (w . rhs)
+    double wr = 0.0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) wr += M->w[j] * rhs[j];
+    const double cwr = c * wr;
+    double v_pred[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) sum += M->s0[i][j] * rhs[j];
+        v_pred[i] = sum - cwr * M->u[i];
+    }
+    const double p[3] = {-v_pred[2], v_pred[2] - v_pred[5], v_pred[4] - v_pred[8]};
+    double kk[3][3];                                                  // K(R) = K0 - c (N_v u)(w N_i)^T
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) kk[i][j] = M->k0[i][j] - c * M->nvu[i] * M->wn[j];
+    double i_nl[3];
+    uint32_t last_it = mel_solve_nl(p, kk, st.ip, st.ipp, i_nl);
+    const double cwi = c * (M->wn[0] * i_nl[0] + M->wn[1] * i_nl[1] + M->wn[2] * i_nl[2]);
+    double vn[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {                                     // v = v_pred + S(R) N_i i_nl
+        double x = v_pred[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) x += M->sni0[i][j] * i_nl[j];
+        vn[i] = x - cwi * M->u[i];
+    }
+    const bool nr_failed = last_it >= 265u;
+    bool ringing = false;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) ringing = ringing || (fabs(vn[i]) > 55.0);
+    if (nr_failed || ringing || force_be) {
+        if (ringing || nr_failed) st.be_cooldown = 64u;
+        st.be_fallbacks += 1u;
+        last_it = mel_be_fallback(st, input, vn, i_nl);
+    }
+    {   // voltage-damp net (gen_preamp.rs:3576-3613); threshold = fma(max|DC_OP|, 0.05, 2.0), the path's one explicit mul_add
+        double max_delta = 0.0;
+#pragma unroll
+        for (int i = 0; i < 11; ++i) { const double d = fabs(vn[i] - st.v[i]); if (d > max_delta) max_delta = d; }
+        double max_dc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 11; ++i) { const double a = fabs(PRE_DC_OP[i]); if (a > max_dc) max_dc = a; }
+        const double thr = fma(max_dc, 0.05, 2.0);
+        if (max_delta > thr) {
+            const double damp = fmax(thr / max_delta, 0.01);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) vn[i] = st.v[i] + damp * (vn[i] - st.v[i]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) i_nl[i] = st.ip[i] + damp * (i_nl[i] - st.ip[i]);
+        }
+    }
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) finite = finite && isfinite(vn[i]);
+    if (!finite) {                                          // gen_preamp.rs:3616-3636
+#pragma unroll
+        for (int i = 0; i < 12; ++i) st.v[i] = PRE_DC_OP[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { st.ip[i] = PRE_DC_NL_I[i]; st.ipp[i] = PRE_DC_NL_I[i]; }
+        st.input_prev = 0.0;
+        st.pot = 9.99999999999999854e4;
+        st.be_cooldown = 0u;
+        st.nan_resets += 1u;
+        return clampd(PRE_DC_OP[10] * 1.0, -10.0, 10.0);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) st.v[i] = vn[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { st.ipp[i] = st.ip[i]; st.ip[i] = i_nl[i]; }
+    st.input_prev = input;
+    const double raw = isfinite(vn[10]) ? vn[10] : 0.0;
+    return raw * 1.0;
+}
+
+OW_DEV void mel_set_r(MelSt& st, double r_in) {  // set_runtime_R_r_ldr, gen_preamp.rs:1973-1984
+    if (!isfinite(r_in)) return;
+    const double r = clampd(r_in, 1000.0, 1000000.0);
+    if (fabs(r - st.pot) < 1e-12) return;
+    st.pot = r;
+}
+
+// chain-state slots of the melange states: 21 doubles + 1 packed word each
+enum { CSM_V = 0, CSM_IP = 12, CSM_IPP = 15, CSM_INPREV = 18, CSM_POT = 19, CSM_WORD = 20, CSM_COUNT = 21 };
+OW_DEV void mel_load(MelSt& s, const double* __restrict__ cs, int I, int e, int base) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s.v[i] = CSF(base + CSM_V + i);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { s.ip[i] = CSF(base + CSM_IP + i); s.ipp[i] = CSF(base + CSM_IPP + i); }
+    s.input_prev = CSF(base + CSM_INPREV); s.pot = CSF(base + CSM_POT);
+    s.be_cooldown = (uint32_t)dbits(CSF(base + CSM_WORD));
+    s.nan_resets = 0; s.be_fallbacks = 0;
+}
+OW_DEV void mel_store(const MelSt& s, double* __restrict__ cs, int I, int e, int base) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) CSF(base + CSM_V + i) = s.v[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { CSF(base + CSM_IP + i) = s.ip[i]; CSF(base + CSM_IPP + i) = s.ipp[i]; }
+    CSF(base + CSM_INPREV) = s.input_prev; CSF(base + CSM_POT) = s.pot;
+    CSF(base + CSM_WORD) = bitsd((uint64_t)s.be_cooldown);
+}
+
+// init_state (melange_adapter.rs:22-29): the settled codegen-rate state; set_sample_rate only swaps matrices (pool constants here)
+__device__ inline void mel_init_state(MelSt& st, const double* __restrict__ settled) {
+    for (int i = 0; i < 12; ++i) st.v[i] = settled[i];
+    for (int i = 0; i < 3; ++i) { st.ip[i] = settled[12 + i]; st.ipp[i] = settled[15 + i]; }
+    st.input_prev = 0.0;
+    st.pot = 9.99999999999999854e4;
+    st.be_cooldown = 0u;
+}
+
+// CircuitState::default() + 176 400 zero-input samples at the codegen rate (melange_adapter.rs:14-20): one lane.
+// K48 holds the 48 kHz codegen tables as its melange constants.
+__global__ __launch_bounds__(64) void k_mel_settle(const OwConsts* __restrict__ K48, double* __restrict__ settled) {
+    __shared__ MelMats M;
+    mel_mats_load(&M, K48, threadIdx.x, 64);
+    __syncthreads();
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    MelSt st;
+    for (int i = 0; i < 12; ++i) st.v[i] = PRE_DC_OP[i];
+    for (int i = 0; i < 3; ++i) { st.ip[i] = PRE_DC_NL_I[i]; st.ipp[i] = PRE_DC_NL_I[i]; }
+    st.input_prev = 0.0; st.pot = 9.99999999999999854e4; st.be_cooldown = 0u; st.nan_resets = 0; st.be_fallbacks = 0;
+    for (int n = 0; n < 176400; ++n) {
+        int z = 0;
+        asm volatile("" : "+v"(z));
+        mel_process(st, 0.0, &M + z);
+    }
+    for (int i = 0; i < 12; ++i) settled[i] = st.v[i];
+    for (int i = 0; i < 3; ++i) { settled[12 + i] = st.ip[i]; settled[15 + i] = st.ipp[i]; }
+}
+
+// DkPreamp::new / reset for engines [e0, e0+ne): both states from the settled state
+__global__ __launch_bounds__(64) void k_mel_init(double* __restrict__ cs, const double* __restrict__ settled, int I, int e0, int ne) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= 2 * ne) return;
+    const int e = e0 + (t % ne), role = t / ne;
+    MelSt st;
+    mel_init_state(st, settled);
+    mel_store(st, cs, I, e, role ? CS_M_SHADOW : CS_M_MAIN);
+}
+
+// Preamp stream with the melange solver: same staging / lane-pair structure as k_preamp.
+__global__ __launch_bounds__(64) void k_preamp_mel(const OwConsts* __restrict__ K, double* __restrict__ cs,
+                                                   const double* __restrict__ settled, const OwEngineArgs* __restrict__ args,
+                                                   const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const double* __restrict__ rbuf,
+                                                   double* __restrict__ pre, int I, int L, int Lcap, int e0, int ne) {
+    __shared__ double tile[32 * (OW_PCHUNK + 1)];
+    __shared__ MelMats M;
+    mel_mats_load(&M, K, threadIdx.x, 64);
+    __syncthreads();
+    const int lane = threadIdx.x;
+    const int el = lane & 31, role = lane >> 5;
+    const int eb = e0 + blockIdx.x * 32;
+    const int e = eb + el;
+    const bool valid = e < e0 + ne;
+    const int ec = valid ? e : (e0 + ne - 1);
+    const int osr = K->oversample ? 2 : 1;
+
+    MelSt st;
+    double ua[3], ub[3];
+    {
+        const int e = ec;
+        mel_load(st, cs, I, e, role ? CS_M_SHADOW : CS_M_MAIN);
+        for (int i = 0; i < 3; ++i) { ua[i] = CSF(CS_OS_UA + i); ub[i] = CSF(CS_OS_UB + i); }
+        const uint64_t fl = dbits(CSF(CS_FLAGS));
+        if (fl & 1ull) {  // deferred preamp.reset() + oversampler.reset() from the output NaN guard (engine.rs:450-457)
+            mel_init_state(st, settled);
+            for (int i = 0; i < 3; ++i) { ua[i] = 0.0; ub[i] = 0.0; }
+        }
+    }
+    uint32_t adapter_resets = 0;
+    for (int base = 0; base < L; base += OW_PCHUNK) {
+        const int cn = min(OW_PCHUNK, L - base);
+        for (int r = 0; r < 32; ++r) {
+            const int er = eb + r;
+            double x = 0.0;
+            if (er < e0 + ne && lane < cn && !eout[er].sum_nonfinite) {
+                if (args[er].main_mask) x = sum[((size_t)0 * I + er) * Lcap + base + lane];
+                if (args[er].steal_mask) x += sum[((size_t)1 * I + er) * Lcap + base + lane];
+            }
+            tile[r * (OW_PCHUNK + 1) + lane] = x;
+        }
+        __syncthreads();
+        for (int n = 0; n < cn; ++n) {
+            const double x = tile[el * (OW_PCHUNK + 1) + n];
+            double in[2];
+            if (osr == 2) {
+                const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, ua, x);
+                const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, ub, x);
+                in[0] = role ? 0.0 : a;
+                in[1] = role ? 0.0 : b;
+            } else {
+                in[0] = role ? 0.0 : x;
+                in[1] = 0.0;
+            }
+            for (int j = 0; j < osr; ++j) {
+                const size_t s_idx = (size_t)((base + n) * osr + j);
+                mel_set_r(st, rbuf[s_idx * I + ec]);                               // melange_adapter.rs:82-85
+                int z = 0;
+                asm volatile("" : "+v"(z));                                        // keep the LDS constant reads inside the loop
+                const double o = mel_process(st, in[j], &M + z);
+                const double other = __shfl_xor(o, 32);
+                double result = role ? (other - o) : (o - other);                  // main - pump (:74-76)
+                if (!isfinite(result)) {                                           // :77-80
+                    mel_init_state(st, settled);
+                    result = 0.0;
+                    adapter_resets += 1u;
+                }
+                if (valid && role == 0) pre[s_idx * I + e] = result;
+            }
+        }
+        __syncthreads();
+    }
+    if (valid) {
+        mel_store(st, cs, I, e, role ? CS_M_SHADOW : CS_M_MAIN);
+        if (role == 0) {
+            for (int i = 0; i < 3; ++i) { CSF(CS_OS_UA + i) = ua[i]; CSF(CS_OS_UB + i) = ub[i]; }
+            const uint64_t fl = dbits(CSF(CS_FLAGS));
+            if (fl & 1ull) CSF(CS_FLAGS) = bitsd(fl & ~1ull);
+            const uint32_t nr = adapter_resets + st.nan_resets;
+            if (nr) {
+                const uint64_t d = dbits(CSF(CS_DIAG));
+                CSF(CS_DIAG) = bitsd((d & 0xFFFFFFFFull) | ((uint64_t)((uint32_t)(d >> 32) + nr) << 32));
+            }
+        }
+    }
+}
+
+}  // namespace owdev

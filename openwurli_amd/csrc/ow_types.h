@@ -91,7 +91,9 @@ enum {
     CS_SPK_CHAR = 88, CS_SPK_A2 = 89, CS_SPK_A3 = 90, CS_SPK_TC = 91, CS_SPK_TS = 92,
     CS_FLAGS = 93,       // u64 bit0: preamp+oversampler reset pending (engine.rs:450-457)
     CS_DIAG = 94,        // u64 counters: lo32 tremolo BE fallbacks, hi32 preamp NaN resets
-    CS_COUNT = 95
+    CS_M_MAIN = 95,      // [21] melange 12-node preamp, main state: v_prev[12] i_nl_prev[3] i_nl_prev_prev[3] input_prev pot word
+    CS_M_SHADOW = 116,   // [21] shadow state
+    CS_COUNT = 137
 };
 
 // ---- slot ops applied before a render (host voice-pool state machine -> device) ----
@@ -122,6 +124,10 @@ struct OwConsts {
     double p_g_dc_base[8][8];
     // speaker
     double spk_thermal_alpha;                  // speaker.rs:74
+    // melange 12-node preamp at os_sr and the nominal 100 kOhm pot (gen_preamp.rs:1990-2062) + Sherman-Morrison vectors for R_ldr.
+    // Field order = struct MelMats (ow_melange_dev.h), copied to LDS as one block.
+    double m_s0[12][12], m_aneg0[12][12], m_k0[3][3], m_sni0[12][3];
+    double m_u[12], m_w[12], m_wn[3], m_nvu[3], m_s66, m_g_nom;
 };
 
 // per-engine per-render parameters (host -> device)

@@ -6,6 +6,7 @@
 #pragma once
 #include "ow_chain.hpp"
 #include "ow_tremolo.hpp"
+#include "ow_melange.hpp"
 #include <memory>
 
 namespace owo {
@@ -58,7 +59,13 @@ inline uint32_t ramp_samples_for_rate(double sr) { return std::max(as_u32(sr * 0
 struct WurliEngine {
     VoiceSlot voices[MAX_VOICES];
     uint64_t age_counter = 0;
-    DkPreamp preamp;
+    DkPreamp preamp;          // default solver (dk_preamp/mod.rs:14-15)
+    MelangePreamp mel;        // `--features melange-preamp` solver (dk_preamp/melange_adapter.rs)
+    int preamp_kind = 0;      // 0 = legacy 8-node, 1 = melange 12-node
+    void pre_init(double sr) { if (preamp_kind) mel.init(sr); else preamp.init(sr); }
+    void pre_reset() { if (preamp_kind) mel.reset(); else preamp.reset(); }
+    void pre_set_ldr(double r) { if (preamp_kind) mel.set_ldr_resistance(r); else preamp.set_ldr_resistance(r); }
+    double pre_process(double x) { return preamp_kind ? mel.process_sample(x) : preamp.process_sample(x); }
     Tremolo tremolo;
     Oversampler oversampler;
     PowerAmp power_amp;
@@ -70,11 +77,12 @@ struct WurliEngine {
     uint64_t nan_guard_fires = 0;
 
     // engine.rs:194-229
-    explicit WurliEngine(double sr) {
+    explicit WurliEngine(double sr, int kind = 0) {
+        preamp_kind = kind;
         oversample = sr < 88200.0;
         const double os_sr = oversample ? sr * 2.0 : sr;
         const uint32_t ramp = ramp_samples_for_rate(sr);
-        preamp.init(os_sr);
+        pre_init(os_sr);
         tremolo.init(0.5, os_sr);
         speaker.init(sr);
         voice_buf.assign(MAX_BLOCK_SIZE, 0.0);
@@ -91,7 +99,7 @@ struct WurliEngine {
     // engine.rs:231-251
     void reset() {
         for (auto& s : voices) { s.state = VS_FREE; s.voice.reset(); s.steal_voice.reset(); s.steal_fade = 0; }
-        preamp.reset();
+        pre_reset();
         tremolo.reset();
         oversampler.reset();
         speaker.reset();
@@ -118,7 +126,7 @@ struct WurliEngine {
         sample_rate = sr;
         oversample = sr < 88200.0;
         os_sample_rate = oversample ? sr * 2.0 : sr;
-        preamp.init(os_sample_rate);
+        pre_init(os_sample_rate);
         tremolo.init(tremolo_depth.target, os_sample_rate);
         oversampler.reset();
         speaker.init(sr);
@@ -226,7 +234,7 @@ struct WurliEngine {
             const float sample = (float)post_gain;
             if (std::isfinite(sample)) out[i] = sample;
             else {
-                preamp.reset();
+                pre_reset();
                 oversampler.reset();
                 speaker.reset();
                 out[i] = 0.0f;
@@ -292,8 +300,8 @@ struct WurliEngine {
                 for (int j = 0; j < 2; ++j) {
                     const size_t idx = i * 2 + j;
                     const double r = tremolo.process();
-                    preamp.set_ldr_resistance(r);
-                    const double pre = preamp.process_sample(up_buf[idx]);
+                    pre_set_ldr(r);
+                    const double pre = pre_process(up_buf[idx]);
                     if (preamp_tap) preamp_tap[idx] = pre;
                     if (r_tap) r_tap[idx] = r;
                     up_buf[idx] = power_amp.process(pre * FIXED_CIRCUIT_DRIVE);
@@ -305,8 +313,8 @@ struct WurliEngine {
                 const double depth = tremolo_depth.next();
                 tremolo.set_depth(depth);
                 const double r = tremolo.process();
-                preamp.set_ldr_resistance(r);
-                const double pre = preamp.process_sample(sum_buf[i]);
+                pre_set_ldr(r);
+                const double pre = pre_process(sum_buf[i]);
                 if (preamp_tap) preamp_tap[i] = pre;
                 if (r_tap) r_tap[i] = r;
                 out_buf[offset + i] = power_amp.process(pre * FIXED_CIRCUIT_DRIVE);

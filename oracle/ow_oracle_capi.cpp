@@ -18,6 +18,7 @@ extern "C" {
 
 // ---- engine mirror (engine.rs public API) ----
 void* owo_engine_new(double sr) { return new WurliEngine(sr); }
+void* owo_engine_new_kind(double sr, int preamp_kind) { return new WurliEngine(sr, preamp_kind); }
 void owo_engine_free(void* e) { delete (WurliEngine*)e; }
 void owo_engine_set_sample_rate(void* e, double sr) { ((WurliEngine*)e)->set_sample_rate(sr); }
 void owo_engine_reset(void* e) { ((WurliEngine*)e)->reset(); }
@@ -198,6 +199,39 @@ void owo_tremolo_matrices(double sr, double* s, double* k, double* sni, double* 
     for (int i = 0; i < 7; ++i) for (int j = 0; j < 4; ++j) sni[i * 4 + j] = c.s_ni[i][j];
 }
 double owo_fast_exp(double x) { return fast_exp(x); }
+
+// melange 12-node preamp (main - shadow) run: per-sample input x[n], R_ldr r[n] (null -> untouched 100 kOhm nominal)
+void owo_melange_run(double sr, const double* x, const double* r, double* y, size_t n) {
+    MelangePreamp* p = new MelangePreamp();
+    p->init(sr);
+    for (size_t i = 0; i < n; ++i) {
+        if (r) p->set_ldr_resistance(r[i]);
+        y[i] = p->process_sample(x[i]);
+    }
+    delete p;
+}
+// single CircuitState from CircuitState::default(): n zero-input steps, returns v_prev (12) + i_nl_prev (3) + diag counters (3)
+void owo_melange_default_steps(size_t n, double* out18) {
+    MelState* s = new MelState();
+    s->init_default();
+    for (size_t i = 0; i < n; ++i) s->process_sample(0.0);
+    for (int i = 0; i < 12; ++i) out18[i] = s->v_prev[i];
+    for (int i = 0; i < 3; ++i) out18[12 + i] = s->i_nl_prev[i];
+    out18[15] = (double)s->diag_be_fallback_count; out18[16] = (double)s->diag_nan_reset_count; out18[17] = (double)s->diag_voltage_damp_count;
+    delete s;
+}
+// rebuilt trapezoidal matrices at (sr, r): s(144) k(9) s_ni(36) a_neg(144)
+void owo_melange_matrices(double sr, double r, double* s, double* k, double* sni, double* aneg) {
+    MelState* st = new MelState();
+    st->init_default();
+    st->current_sample_rate = sr;
+    st->pot_0_resistance = r;
+    st->rebuild_matrices();
+    for (int i = 0; i < 12; ++i) for (int j = 0; j < 12; ++j) { s[i * 12 + j] = st->s[i][j]; aneg[i * 12 + j] = st->a_neg[i][j]; }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) k[i * 3 + j] = st->k[i][j];
+    for (int i = 0; i < 12; ++i) for (int j = 0; j < 3; ++j) sni[i * 3 + j] = st->s_ni[i][j];
+    delete st;
+}
 
 double owo_power_amp(double x) { PowerAmp p; return p.process(x); }
 void owo_speaker_run(double sr, double character, double* x, size_t n) {

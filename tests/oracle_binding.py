@@ -23,6 +23,7 @@ def build():
 def _configure(L):
     if True:
         L.owo_engine_new.restype = C.c_void_p
+        L.owo_engine_new_kind.restype = C.c_void_p
         for name in ("owo_midi_to_freq", "owo_tip_mass_ratio", "owo_reed_length_mm", "owo_pickup_displacement_scale",
                      "owo_fundamental_decay_rate", "owo_output_scale", "owo_velocity_exponent", "owo_velocity_scurve",
                      "owo_register_trim_db", "owo_pickup_rms_proxy", "owo_freq_detune", "owo_dwell_time", "owo_onset_ramp_time",
@@ -60,9 +61,9 @@ def _p(a):
 class OracleEngine:
     """CPU restatement of WurliEngine with the reference's method names."""
 
-    def __init__(self, sr, perturbed=False):
+    def __init__(self, sr, perturbed=False, preamp_kind=0):
         self.L = lib_perturbed() if perturbed else lib()
-        self.h = C.c_void_p(self.L.owo_engine_new(C.c_double(sr)))
+        self.h = C.c_void_p(self.L.owo_engine_new_kind(C.c_double(sr), int(preamp_kind)))
 
     def close(self):
         if self.h:
@@ -133,6 +134,10 @@ ABS_FLOOR_PREAMP = 2e-9
 # batch jobs (`preamp-bench render`): output = preamp x volume^2 x 7.5 with a static LDR, so the same indeterminacy
 # shows up ~10x larger (measured ~1.1e-8 by test_oracle_sensitivity.py)
 ABS_FLOOR_BATCH = 3e-8
+# melange 12-node solver (literal per-sample LU in the oracle, rank-one update on the GPU): measured GPU deviation 7e-10 at the
+# preamp node; the oracle's own response to a one-ulp R_ldr change is measured by test_oracle_sensitivity.py::test_melange_floor
+ABS_FLOOR_MELANGE_PREAMP = 5e-9
+ABS_FLOOR_MELANGE_OUTPUT = 5e-9
 
 
 def parity_report(gpu, cpu, rel=1e-5, floor_frac=1e-3, abs_floor=0.0):

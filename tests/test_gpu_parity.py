@@ -326,3 +326,52 @@ def test_mlp_mfma(hiplib, oracle):
         decay = 1.0 + (np.clip(raw_m[i, 5:10], 0.3, 3.0) - 1.0) * fade
         ds = 1.0 + (np.clip(raw_m[i, 10], 0.7, 1.2) - 1.0) * fade
         assert np.max(np.abs(cents - out[:5])) < 1e-10 and np.max(np.abs(decay - out[5:10])) < 1e-12 and abs(ds - out[10]) < 1e-12
+
+
+# ------------------------------------------------------------------ melange 12-node preamp (second solver)
+def test_melange_engine_parity(hiplib, oracle):
+    import openwurli_amd as ow
+    sr = 48000.0
+    g = ow.EnginePool(sr, 2, preamp_kind=1)
+    cs = [oracle.OracleEngine(sr, preamp_kind=1) for _ in range(2)]
+    g.set_sample_rate(sr)
+    for c in cs:
+        c.set_sample_rate(sr)
+    for k in range(2):
+        for e in (g[k], cs[k]):
+            e.set_volume(0.5); e.set_tremolo_depth(0.5 + 0.5 * k); e.set_speaker_character(0.0)
+            for n in (48, 60, 67) if k == 0 else (40, 72, 76, 91):
+                e.note_on(n, 0.8)
+    for b in range(12):
+        go = g.render(512)
+        gp = g.preamp_out(1024)
+        for k in range(2):
+            co, _, cp, _ = cs[k].render_taps(512)
+            _check(oracle.parity_report(gp[k], cp, abs_floor=oracle.ABS_FLOOR_MELANGE_PREAMP), ("melange preamp", b, k))
+            _check(oracle.parity_report(go[k], co, abs_floor=oracle.ABS_FLOOR_MELANGE_OUTPUT), ("melange out", b, k))
+    for k in range(2):
+        d = g[k].diag()
+        assert d.preamp_nan_resets == 0
+    g.close()
+
+
+def test_melange_static_ldr_and_reset(hiplib, oracle):
+    import openwurli_amd as ow
+    sr = 44100.0
+    g = ow.EnginePool(sr, 1, preamp_kind=1)
+    c = oracle.OracleEngine(sr, preamp_kind=1)
+    for e in (g[0], c):
+        e.set_tremolo_depth(0.0)             # static shunt: matrices rebuilt only while the depth smoother ramps
+        e.note_on(57, 0.9)
+    for b in range(6):
+        go = g.render(512)[0]
+        co = c.render(512)
+        _check(oracle.parity_report(go, co, abs_floor=oracle.ABS_FLOOR_MELANGE_OUTPUT), ("melange static", b))
+    g[0].reset(); c.reset()
+    for e in (g[0], c):
+        e.note_on(64, 0.7)
+    for b in range(6):
+        go = g.render(512)[0]
+        co = c.render(512)
+        _check(oracle.parity_report(go, co, abs_floor=oracle.ABS_FLOOR_MELANGE_OUTPUT), ("melange reset", b))
+    g.close()

@@ -451,3 +451,61 @@ def test_reed_renderer_properties(oracle):
     assert np.array_equal(x, oracle.render_note(60, 100 / 127.0, 0.5, 44100.0))
     q = (np.clip(x, -1, 1) * (2 ** 23 - 1)).astype(np.int32)         # truncating 24-bit quantiser (main.rs:118-123)
     assert np.max(np.abs(q)) < 2 ** 23
+
+
+# ---------------------------------------------------------------- melange 12-node preamp (dk_preamp/mod.rs:100-117, gen_preamp.rs)
+def test_melange_dc_op_is_a_fixed_point(oracle):
+    """a zero-input step from the baked DC_OP must stay at DC_OP (to the codegen solver tolerance)."""
+    L = oracle.lib()
+    o0 = np.zeros(18); o1 = np.zeros(18); o2 = np.zeros(18)
+    L.owo_melange_default_steps(C.c_size_t(0), _p(o0))
+    L.owo_melange_default_steps(C.c_size_t(1), _p(o1))
+    L.owo_melange_default_steps(C.c_size_t(176400), _p(o2))
+    assert np.max(np.abs(o1[:12] - o0[:12])) < 1e-6
+    assert np.max(np.abs(o2[:12] - o0[:12])) < 1e-4
+    assert np.all(o2[15:] == 0)                       # no BE fallback, NaN reset or voltage damping while settling
+
+
+def test_melange_gain_matches_published_endpoints_and_legacy(oracle):
+    """dk_preamp/mod.rs:100-117 (melange vs legacy within 2 dB at both LDR endpoints) and CHANGELOG.md:206 (6.51 / 12.61 dB)."""
+    L = oracle.lib()
+    sr = 88200.0
+    n = int(sr * 0.5)
+    ramp = int(sr * 0.2)
+    x = 1e-3 * np.sin(2 * np.pi * 1000.0 * np.arange(n) / sr)
+
+    def rms_db(y):
+        return 20 * np.log10(np.sqrt(np.mean(y[-n // 4:] ** 2)) / np.sqrt(np.mean(x[-n // 4:] ** 2)))
+
+    def mel(r):
+        rr = np.full(n, r)
+        rr[:ramp] = 1e5 + (r - 1e5) * np.arange(ramp) / ramp       # ramp from the 100 kOhm nominal like mel_gain() in the reference
+        xx = x.copy(); xx[:ramp] = 0.0
+        y = np.zeros(n)
+        L.owo_melange_run(d(sr), _p(xx), _p(rr), _p(y), C.c_size_t(n))
+        return rms_db(y)
+
+    def leg(r):
+        y = np.zeros(n)
+        L.owo_preamp_run(d(sr), _p(x), None, d(r), _p(y), C.c_size_t(n))
+        return rms_db(y)
+    g_hi, g_lo = mel(1e6), mel(19000.0)
+    assert abs(g_hi - 6.51) < 0.1 and abs(g_lo - 12.61) < 0.1
+    assert abs(g_hi - leg(1e6)) < 2.0 and abs(g_lo - leg(19000.0)) < 2.0
+
+
+def test_melange_rebuild_matches_numpy_inverse(oracle):
+    L = oracle.lib()
+    s = np.zeros(144); k = np.zeros(9); sni = np.zeros(36); an = np.zeros(144)
+    L.owo_melange_matrices(d(96000.0), d(19000.0), _p(s), _p(k), _p(sni), _p(an))
+    S = s.reshape(12, 12)
+    s2 = np.zeros(144)
+    L.owo_melange_matrices(d(96000.0), d(1e6), _p(s2), _p(k), _p(sni), _p(an))
+    S2 = s2.reshape(12, 12)
+    # R_ldr enters A in exactly one entry: the difference of the inverses is rank one (what the GPU path exploits)
+    A1, A2 = np.linalg.inv(S), np.linalg.inv(S2)
+    D = A1 - A2
+    mask = np.ones_like(D, dtype=bool); mask[6, 6] = False
+    assert np.max(np.abs(D[mask])) < 1e-9 * np.max(np.abs(A1))
+    assert abs(D[6, 6] - (1 / 19000.0 - 1 / 1e6)) < 1e-6 * (1 / 19000.0)      # limited by the conditioning of numpy's re-inversion
+    assert np.linalg.matrix_rank(S - S2, tol=1e-9 * np.max(np.abs(S))) == 1

@@ -38,3 +38,22 @@ def test_batch_job_floor(oracle):
         worst = max(worst, float(np.max(np.abs(a - b))))
         assert np.max(np.abs(a - b)) / np.max(np.abs(a)) < 1e-5 * 0.2     # far inside the 1e-5 bar relative to peak
     assert 1e-10 < worst < oracle.ABS_FLOOR_BATCH, worst
+
+
+def test_melange_floor(oracle):
+    """Melange 12-node preamp: response of the literal-LU oracle to R_ldr moving by one ulp."""
+    def run(perturbed):
+        e = oracle.OracleEngine(48000.0, perturbed=perturbed, preamp_kind=1)
+        e.set_tremolo_depth(0.5)
+        for n in (48, 60, 67):
+            e.note_on(n, 0.8)
+        outs, pres = [], []
+        for _ in range(12):
+            o, _, p, _ = e.render_taps(512)
+            outs.append(o.astype(np.float64)); pres.append(p)
+        e.close()
+        return np.concatenate(outs), np.concatenate(pres)
+    o0, p0 = run(False)
+    o1, p1 = run(True)
+    assert np.max(np.abs(p1 - p0)) < oracle.ABS_FLOOR_MELANGE_PREAMP
+    assert np.max(np.abs(o1 - o0)) < 2e-8          # f32 rounding flips at |x| ~ 0.1 are 7.5e-9
