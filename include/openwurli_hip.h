@@ -107,6 +107,18 @@ int ow_engine_slot_state(const ow_engine*, int slot);                           
 int ow_engine_slot_note(const ow_engine*, int slot);                              /* VoiceSlot.midi_note          */
 int ow_engine_has_steal_voice_for(const ow_engine*, uint8_t note);                /* has_steal_voice_for     :627 */
 
+/* ---- host-logic test hooks ------------------------------------------------------------------ */
+/* A detached engine: the host voice-pool / MIDI state machine (engine.rs:299-374,569-602) without a pool or a device.
+ * note_on / note_off / set_sustain / get_diag / slot_* work on it; the slot ops it would send to the GPU can be taken
+ * out, and the post-render bookkeeping can be driven with an explicit "silent" mask.  Used by the CPU-only tests. */
+ow_engine* ow_test_engine_new(double sample_rate);
+void ow_test_engine_free(ow_engine*);
+/* Copies up to cap pending ops (type 1 = note-on, 2 = damper, 3 = move-to-steal; seed = fade length for type 3), clears the queue,
+ * returns the number that were pending. */
+size_t ow_test_engine_take_ops(ow_engine*, uint8_t* type, uint8_t* slot, uint8_t* note, uint32_t* seed, double* velocity, size_t cap);
+void ow_test_engine_after_render(ow_engine*, size_t len, uint64_t silent_mask);
+uint64_t ow_test_engine_masks(const ow_engine*, int which /* 0 = slot voices, 1 = steal voices */);
+
 /* ---- diagnostics ------------------------------------------------------------------------- */
 /* Raw (pre-fade, pre-clamp) outputs of the note-on MLP (mlp_correction.rs:86-116) for n (note, velocity) pairs:
  * out[n][11].  use_mfma = 1 runs the wavefront-batched v_mfma_f64_16x16x4_f64 path that k_apply_ops uses,

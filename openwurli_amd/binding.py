@@ -74,6 +74,11 @@ SYMBOLS = {
     "ow_engine_slot_state": (C.c_int, [_VP, C.c_int]),
     "ow_engine_slot_note": (C.c_int, [_VP, C.c_int]),
     "ow_engine_has_steal_voice_for": (C.c_int, [_VP, C.c_uint8]),
+    "ow_test_engine_new": (_VP, [C.c_double]),
+    "ow_test_engine_free": (None, [_VP]),
+    "ow_test_engine_take_ops": (C.c_size_t, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t]),
+    "ow_test_engine_after_render": (None, [_VP, C.c_size_t, C.c_uint64]),
+    "ow_test_engine_masks": (C.c_uint64, [_VP, C.c_int]),
     "ow_debug_mlp_raw": (C.c_int, [_VP, _VP, C.c_size_t, _VP, C.c_int, C.c_int]),
     "ow_render_note": (C.c_longlong, [C.c_uint8, C.c_double, C.c_double, C.c_double, C.c_int, _VP, C.c_size_t]),
     "ow_batch_render": (C.c_longlong, [C.POINTER(OwJob), C.c_size_t, C.POINTER(OwBatchCfg), _VP, C.c_size_t, C.c_int]),

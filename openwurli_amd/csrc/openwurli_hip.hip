@@ -64,6 +64,7 @@ struct ow_engine {
     std::vector<OwOp> ops;  // pending slot ops, applied at the start of the next render
     // bit s set <=> slot s renders a voice / a steal voice (engine.rs:471-493); kept incrementally
     uint64_t main_mask = 0, steal_mask = 0;
+    double sr = 0.0;            // host sample rate (steal crossfade length, engine.rs:318)
     uint8_t* dirty = nullptr;   // -> pool->dirty[index]: engine has pending ops / setter targets / changed masks
     void sync_masks(int s) {
         const Slot& sl = slots[s];
@@ -253,6 +254,34 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
     HIP_OK(hipMemcpyAsync(p->h_eout + e0, p->d_eout + e0, sizeof(OwEngineOut) * ne, hipMemcpyDeviceToHost, st));
 }
 
+// host bookkeeping of ONE engine after a block: steal-fade countdown (engine.rs:490-493), NaN-guard frees (engine.rs:499-521,
+// culprits identified in the same pass) and cleanup_voices (engine.rs:592-602)
+void engine_post_render(ow_engine* en, uint32_t l32, const OwEngineOut& o) {
+    if (en->steal_mask) {
+        for (uint64_t m = en->steal_mask; m; m &= m - 1) {
+            const int s = __builtin_ctzll(m);
+            Slot& sl = en->slots[s];
+            sl.steal_fade = sl.steal_fade > l32 ? sl.steal_fade - l32 : 0u;
+            if (sl.steal_fade == 0) { sl.has_steal = false; en->sync_masks(s); }
+        }
+    }
+    if (o.sum_nonfinite) {
+        en->nan_guard_fires += 1;
+        for (int s = 0; s < OW_MAX_VOICES; ++s) {
+            Slot& sl = en->slots[s];
+            if ((o.bad_main >> s) & 1ull) { sl.state = OW_VOICE_FREE; sl.has_voice = false; }
+            if ((o.bad_steal >> s) & 1ull) { sl.has_steal = false; sl.steal_fade = 0; }
+            en->sync_masks(s);
+        }
+    }
+    if (o.out_nonfinite) en->output_nan_resets += 1;
+    for (uint64_t m = o.silent_mask & en->main_mask; m; m &= m - 1) {
+        const int s = __builtin_ctzll(m);
+        Slot& sl = en->slots[s];
+        if (sl.state != OW_VOICE_FREE && sl.has_voice) { sl.state = OW_VOICE_FREE; sl.has_voice = false; en->sync_masks(s); }
+    }
+}
+
 // host bookkeeping after the block has been rendered (needs h_eout; call after stream sync)
 void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
     const uint32_t l32 = (uint32_t)std::min<size_t>(len, 0xFFFFFFFFull);
@@ -261,30 +290,7 @@ void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
         const OwEngineArgs& a = p->h_args[e0 + k];
         // fast path on the contiguous status/args arrays: nothing to book-keep for this engine
         if (!a.steal_mask && !(o.silent_mask & a.main_mask) && !o.sum_nonfinite && !o.out_nonfinite) continue;
-        ow_engine* en = p->engines[e0 + k];
-        if (en->steal_mask) {  // engine.rs:490-493
-            for (uint64_t m = en->steal_mask; m; m &= m - 1) {
-                const int s = __builtin_ctzll(m);
-                Slot& sl = en->slots[s];
-                sl.steal_fade = sl.steal_fade > l32 ? sl.steal_fade - l32 : 0u;
-                if (sl.steal_fade == 0) { sl.has_steal = false; en->sync_masks(s); }
-            }
-        }
-        if (o.sum_nonfinite) {  // engine.rs:499-521 (culprits were identified in the same pass; see DESIGN.md deviations)
-            en->nan_guard_fires += 1;
-            for (int s = 0; s < OW_MAX_VOICES; ++s) {
-                Slot& sl = en->slots[s];
-                if ((o.bad_main >> s) & 1ull) { sl.state = OW_VOICE_FREE; sl.has_voice = false; }
-                if ((o.bad_steal >> s) & 1ull) { sl.has_steal = false; sl.steal_fade = 0; }
-                en->sync_masks(s);
-            }
-        }
-        if (o.out_nonfinite) en->output_nan_resets += 1;
-        for (uint64_t m = o.silent_mask & en->main_mask; m; m &= m - 1) {  // cleanup_voices, engine.rs:592-602
-            const int s = __builtin_ctzll(m);
-            Slot& sl = en->slots[s];
-            if (sl.state != OW_VOICE_FREE && sl.has_voice) { sl.state = OW_VOICE_FREE; sl.has_voice = false; en->sync_masks(s); }
-        }
+        engine_post_render(p->engines[e0 + k], l32, o);
     }
 }
 
@@ -388,6 +394,7 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
         en->pool = p;
         en->index = i;
         en->dirty = &p->dirty[i];
+        en->sr = sample_rate;
         p->engines[i] = en;
     }
     // WurliEngine::new for engine 0 on the device, then replicate (every engine of a fresh pool is identical)
@@ -446,6 +453,7 @@ int ow_pool_set_sample_rate(ow_pool* p, double sr) {
     try {
         HIP_OK(hipSetDevice(p->device));
         upload_consts(p, sr, p->hc.preamp_kind);
+        for (ow_engine* en : p->engines) en->sr = sr;
         // voices keep their records (the reference keeps Voice objects too, engine.rs:272-286), chain objects are rebuilt
         std::vector<double> d0(p->I);
         for (size_t i = 0; i < p->I; ++i) d0[i] = p->engines[i]->depth.target;
@@ -579,7 +587,7 @@ void ow_engine_note_on(ow_engine* e, uint8_t note_in, float velocity) {  // engi
     const int idx = allocate_voice(e);
     Slot& slot = e->slots[idx];
     if (slot.state != OW_VOICE_FREE) {
-        const uint32_t fade = owhip::sat_u32(e->pool->hc.sr * 0.005);
+        const uint32_t fade = owhip::sat_u32(e->sr * 0.005);
         if (slot.has_voice) {
             push_op(e, OP_MOVE_STEAL, idx, note, false, fade, 0.0);
             slot.has_steal = true;
@@ -660,7 +668,7 @@ void ow_engine_get_diag(const ow_engine* e, ow_diag* d) {
     d->output_nan_resets = e->output_nan_resets;
     ow_pool* p = e->pool;
     double diag = 0.0;
-    if (hipSetDevice(p->device) == hipSuccess &&
+    if (p && hipSetDevice(p->device) == hipSuccess &&
         hipMemcpy(&diag, p->d_cs + (size_t)CS_DIAG * p->I + e->index, sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
         uint64_t bits;
         std::memcpy(&bits, &diag, 8);
@@ -707,6 +715,32 @@ void ow_pool_midi(ow_pool* p, const ow_midi_event* ev, size_t n) {
     }
     for (auto& x : th) x.join();
 }
+
+// ---- host-logic test hooks (no device) -----------------------------------------------------------
+ow_engine* ow_test_engine_new(double sample_rate) {
+    ow_engine* e = new ow_engine();
+    e->sr = sample_rate;
+    return e;
+}
+void ow_test_engine_free(ow_engine* e) { if (e && !e->pool) delete e; }
+size_t ow_test_engine_take_ops(ow_engine* e, uint8_t* type, uint8_t* slot, uint8_t* note, uint32_t* seed, double* velocity, size_t cap) {
+    if (!e) return 0;
+    const size_t n = std::min(cap, e->ops.size());
+    for (size_t i = 0; i < n; ++i) {
+        type[i] = e->ops[i].type; slot[i] = e->ops[i].slot; note[i] = e->ops[i].note; seed[i] = e->ops[i].seed; velocity[i] = e->ops[i].velocity;
+    }
+    const size_t total = e->ops.size();
+    e->ops.clear();
+    return total;
+}
+void ow_test_engine_after_render(ow_engine* e, size_t len, uint64_t silent_mask) {
+    if (!e) return;
+    OwEngineOut o;
+    std::memset(&o, 0, sizeof o);
+    o.silent_mask = silent_mask;
+    engine_post_render(e, (uint32_t)std::min<size_t>(len, 0xFFFFFFFFull), o);
+}
+uint64_t ow_test_engine_masks(const ow_engine* e, int which) { return e ? (which ? e->steal_mask : e->main_mask) : 0; }
 
 // ---- diagnostics ---------------------------------------------------------------------------------
 int ow_debug_mlp_raw(const uint8_t* notes, const double* velocities, size_t n, double* out, int use_mfma, int device) {
