@@ -83,7 +83,12 @@ struct ow_pool {
     OwConsts hc{};
     hipStream_t stream = nullptr;      // voices -> preamp -> output stage
     hipStream_t stream_trem = nullptr; // tremolo oscillator: no audio input (tremolo.rs:121), runs beside the voices
-    hipEvent_t ev_args = nullptr, ev_trem = nullptr;
+    hipEvent_t ev_trem[2] = {nullptr, nullptr};   // one per rbuf half
+    // The tremolo oscillator is produced one block ahead (speculating that the next block has the same length); the
+    // tremolo rows of the chain state are backed up first so a mis-speculation can be rolled back.
+    double* d_trem_backup = nullptr;   // [18][I]
+    int rb_cur = 0;                    // rbuf half holding the R samples of the block being rendered
+    struct { bool valid = false; int e0 = 0, ne = 0, n_os = 0; } spec;
     OwConsts* dK = nullptr;     // constants at the pool's rates
     OwConsts* dK48 = nullptr;   // tremolo codegen-rate matrices for CircuitState::warmup
     double* d_nt = nullptr;
@@ -112,7 +117,17 @@ struct ow_pool {
 
 namespace {
 
+// Drop a pending block-ahead tremolo result: restore the oscillator rows it advanced and drain the tremolo stream.
+void invalidate_spec(ow_pool* p) {
+    if (p->spec.valid) {
+        hipMemcpyAsync(p->d_cs, p->d_trem_backup, sizeof(double) * 18 * p->I, hipMemcpyDeviceToDevice, p->stream_trem);
+        p->spec.valid = false;
+    }
+    if (p->stream_trem) hipStreamSynchronize(p->stream_trem);
+}
+
 void free_stream_buffers(ow_pool* p) {
+    invalidate_spec(p);
     if (p->d_sum) hipFree(p->d_sum);
     if (p->d_rbuf) hipFree(p->d_rbuf);
     if (p->d_pre) hipFree(p->d_pre);
@@ -125,7 +140,7 @@ void alloc_stream_buffers(ow_pool* p, size_t cap) {
     free_stream_buffers(p);
     const size_t I = p->I;
     HIP_OK(hipMalloc(&p->d_sum, sizeof(double) * 2 * I * cap));
-    HIP_OK(hipMalloc(&p->d_rbuf, sizeof(double) * 2 * cap * I));
+    HIP_OK(hipMalloc(&p->d_rbuf, sizeof(double) * 2 * (2 * cap * I)));   // two halves (current block, block ahead)
     HIP_OK(hipMalloc(&p->d_pre, sizeof(double) * 2 * cap * I));
     HIP_OK(hipMalloc(&p->d_out, sizeof(float) * I * cap));
     HIP_OK(hipMemsetAsync(p->d_out, 0, sizeof(float) * I * cap, p->stream));
@@ -147,6 +162,8 @@ enum { INIT_NEW = 1, INIT_RATE = 2, INIT_RESET = 0 };
 // chain (re)initialisation of engines [e0, e0+ne): DC states on the device, then the Twin-T settle
 // (50 warm-up steps at the codegen matrices + 2 s at the pool rate), all in the product kernels.
 void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<double>& depth0) {
+    invalidate_spec(p);
+    HIP_OK(hipStreamSynchronize(p->stream));
     const int I = (int)p->I;
     // depth0: one value per engine of the range (Tremolo::new(depth)); the kernel takes a scalar, so group equal values
     int i = 0;
@@ -163,9 +180,11 @@ void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<do
     const long long n_settle = (long long)owhip::sat_u32(p->hc.os_sr * 2.0);
     owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, I, e0, ne, n_settle);
     HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(p->stream));   // the tremolo stream picks these rows up next (init-time sync)
 }
 
 void upload_consts(ow_pool* p, double sr, int preamp_kind) {
+    invalidate_spec(p);
     owhip::build_consts(p->hc, sr, preamp_kind);
     OwConsts k48;
     owhip::build_consts(k48, 24000.0, preamp_kind);  // os_sr = 48 kHz -> codegen-rate tremolo matrices
@@ -220,13 +239,32 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
         HIP_OK(hipMemcpyAsync(p->d_args + e0, p->h_args + e0, sizeof(OwEngineArgs) * ne, hipMemcpyHostToDevice, st));
         p->args_stale = any_dirty;
     }
-    HIP_OK(hipEventRecord(p->ev_args, st));
-    // tremolo stream: needs only the args (depth retarget) -- overlaps the voice kernels
-    HIP_OK(hipStreamWaitEvent(tt, p->ev_args, 0));
-    if (p->profiling) HIP_OK(hipEventRecord(p->ev[6], tt));
-    owdev::k_tremolo<<<dim3((ne + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, p->d_args, p->d_rbuf, I, L, e0, ne);
-    if (p->profiling) HIP_OK(hipEventRecord(p->ev[7], tt));
-    HIP_OK(hipEventRecord(p->ev_trem, tt));
+    // ---- tremolo stream: CdS cell resistance of this block (already there if the block-ahead speculation hit)
+    const int n_os = L * (p->hc.oversample ? 2 : 1);
+    const size_t rb_half = (size_t)2 * p->Lcap * p->I;
+    const bool hit = p->spec.valid && p->spec.e0 == e0 && p->spec.ne == ne && p->spec.n_os == n_os;
+    if (p->spec.valid && !hit) {   // mis-speculated (different block length / engine range): roll the oscillator back
+        HIP_OK(hipMemcpyAsync(p->d_cs, p->d_trem_backup, sizeof(double) * 18 * p->I, hipMemcpyDeviceToDevice, tt));
+        p->spec.valid = false;
+    }
+    if (hit) {
+        p->rb_cur ^= 1;            // the half the speculation filled
+    } else {
+        owdev::k_tremolo<<<dim3((ne + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, p->d_rbuf + p->rb_cur * rb_half, I, n_os, e0, ne);
+        HIP_OK(hipEventRecord(p->ev_trem[p->rb_cur], tt));
+    }
+    const double* rb_now = p->d_rbuf + p->rb_cur * rb_half;
+    const int rb_now_idx = p->rb_cur;
+    // ---- next block, speculatively: back up the oscillator rows, then run ahead into the other half
+    {
+        const int nxt = p->rb_cur ^ 1;
+        HIP_OK(hipMemcpyAsync(p->d_trem_backup, p->d_cs, sizeof(double) * 18 * p->I, hipMemcpyDeviceToDevice, tt));
+        if (p->profiling) HIP_OK(hipEventRecord(p->ev[6], tt));
+        owdev::k_tremolo<<<dim3((ne + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, p->d_rbuf + nxt * rb_half, I, n_os, e0, ne);
+        if (p->profiling) HIP_OK(hipEventRecord(p->ev[7], tt));
+        HIP_OK(hipEventRecord(p->ev_trem[nxt], tt));
+        p->spec.valid = true; p->spec.e0 = e0; p->spec.ne = ne; p->spec.n_os = n_os;
+    }
     HIP_OK(hipMemsetAsync(p->d_eout + e0, 0, sizeof(OwEngineOut) * ne, st));
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[0], st));
     if (n_ops) {
@@ -240,13 +278,13 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
         owdev::k_voice<<<dim3(ne, any_steal ? 2 : 1), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->d_args, p->d_sum, p->d_eout, I, L, Lcap, e0);
     }
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[2], st));
-    HIP_OK(hipStreamWaitEvent(st, p->ev_trem, 0));
+    HIP_OK(hipStreamWaitEvent(st, p->ev_trem[rb_now_idx], 0));
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[3], st));
     if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)
-        owdev::k_preamp_mel<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, p->d_rbuf,
+        owdev::k_preamp_mel<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
                                                                       p->d_pre, I, L, Lcap, e0, ne);
     else
-        owdev::k_preamp<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, p->d_rbuf, p->d_pre, I, L, Lcap, e0, ne);
+        owdev::k_preamp<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, rb_now, p->d_pre, I, L, Lcap, e0, ne);
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[4], st));
     owdev::k_post<<<dim3((ne + 63) / 64), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, Lcap, e0, ne);
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[5], st));
@@ -364,8 +402,8 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&p->stream_trem, hipStreamNonBlocking));
     for (auto& e : p->ev) HIP_OK(hipEventCreate(&e));
-    HIP_OK(hipEventCreateWithFlags(&p->ev_args, hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags(&p->ev_trem, hipEventDisableTiming));
+    for (auto& e : p->ev_trem) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_OK(hipMalloc(&p->d_trem_backup, sizeof(double) * 18 * n_engines));
     HIP_OK(hipMalloc(&p->dK, sizeof(OwConsts)));
     HIP_OK(hipMalloc(&p->dK48, sizeof(OwConsts)));
     HIP_OK(hipMalloc(&p->d_nt, sizeof(double) * NT_COUNT * 64));
@@ -418,8 +456,8 @@ void pool_destroy(ow_pool* p) {
     if (p->h_ops) hipHostFree(p->h_ops);
     hipHostFree(p->h_args); hipHostFree(p->h_eout);
     for (auto& e : p->ev) if (e) hipEventDestroy(e);
-    if (p->ev_args) hipEventDestroy(p->ev_args);
-    if (p->ev_trem) hipEventDestroy(p->ev_trem);
+    for (auto& e : p->ev_trem) if (e) hipEventDestroy(e);
+    if (p->d_trem_backup) hipFree(p->d_trem_backup);
     if (p->stream_trem) hipStreamDestroy(p->stream_trem);
     if (p->stream) hipStreamDestroy(p->stream);
     for (ow_engine* en : p->engines) delete en;
@@ -672,8 +710,12 @@ void ow_engine_get_diag(const ow_engine* e, ow_diag* d) {
         hipMemcpy(&diag, p->d_cs + (size_t)CS_DIAG * p->I + e->index, sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
         uint64_t bits;
         std::memcpy(&bits, &diag, 8);
-        d->tremolo_be_fallbacks = (uint32_t)bits;
         d->preamp_nan_resets = (uint32_t)(bits >> 32);
+        double be = 0.0;   // counts the block-ahead samples too
+        if (hipMemcpy(&be, p->d_cs + (size_t)CS_T_BE * p->I + e->index, sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
+            std::memcpy(&bits, &be, 8);
+            d->tremolo_be_fallbacks = bits;
+        }
     }
 }
 int ow_engine_slot_state(const ow_engine* e, int slot) { return (e && slot >= 0 && slot < OW_MAX_VOICES) ? e->slots[slot].state : -1; }

@@ -134,7 +134,7 @@ OW_DEV void trem_mats_load(TremMats* __restrict__ m, const OwConsts* __restrict_
 
 struct TremState {
     double v[7], i_prev[4], i_pp[4];
-    double env, r_ldr, depth;
+    double env, r_ldr;
     uint32_t be_fallbacks;
 };
 
@@ -361,8 +361,9 @@ __device__ inline double trem_osc_step(TremState& st, const OwConsts* __restrict
     return v[0];
 }
 
-// Tremolo::process (tremolo.rs:121-167): returns the shunt impedance seen by fb_junction.
-__device__ inline double trem_process(TremState& st, const OwConsts* __restrict__ K, const TremMats* __restrict__ M) {
+// Tremolo::process, oscillator half (tremolo.rs:121-146): LED drive -> CdS envelope -> power-law cell resistance r_ldr.
+// It has no audio input and no dependence on the depth knob, so it is produced a block ahead (k_tremolo).
+__device__ inline double trem_cell_r(TremState& st, const OwConsts* __restrict__ K, const TremMats* __restrict__ M) {
     const double v_out = trem_osc_step(st, K, M);
     const double led = clampd((10.95 - v_out) / (10.95 - 0.70), 0.0, 1.0);
     const double coeff = led > st.env ? K->ldr_attack : K->ldr_release;
@@ -370,10 +371,14 @@ __device__ inline double trem_process(TremState& st, const OwConsts* __restrict_
     const double drive = clampd(st.env, 0.0, 1.0);
     if (drive < 1e-6) st.r_ldr = 1000000.0;
     else st.r_ldr = exp(K->ln_r_max + K->ln_min_minus_max * pow(drive, 0.9));
-    const double r_upper = 50000.0 * (1.0 - st.depth);
-    const double r_lower = 50000.0 * st.depth;
+    return st.r_ldr;
+}
+// Tremolo::shunt_impedance (tremolo.rs:152-167): the vibrato-pot divider seen by fb_junction, applied where the preamp consumes R.
+OW_DEV double trem_shunt(double depth, double r_ldr) {
+    const double r_upper = 50000.0 * (1.0 - depth);
+    const double r_lower = 50000.0 * depth;
     const double top = r_upper > 0.0 ? r_upper * 18000.0 / (r_upper + 18000.0) : 0.0;
-    const double branch = 680.0 + st.r_ldr;
+    const double branch = 680.0 + r_ldr;
     const double low = r_lower > 0.0 ? r_lower * branch / (r_lower + branch) : 0.0;
     return top + low;
 }

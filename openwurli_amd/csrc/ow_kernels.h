@@ -318,7 +318,7 @@ OW_DEV void trem_load(TremState& t, const double* __restrict__ cs, int I, int e)
     for (int i = 0; i < 7; ++i) t.v[i] = CSF(CS_T_V + i);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { t.i_prev[i] = CSF(CS_T_I + i); t.i_pp[i] = CSF(CS_T_IP + i); }
-    t.env = CSF(CS_T_ENV); t.r_ldr = CSF(CS_T_RLDR); t.depth = CSF(CS_T_DEPTH);
+    t.env = CSF(CS_T_ENV); t.r_ldr = CSF(CS_T_RLDR);
     t.be_fallbacks = 0;
 }
 OW_DEV void trem_store(const TremState& t, double* __restrict__ cs, int I, int e) {
@@ -326,11 +326,8 @@ OW_DEV void trem_store(const TremState& t, double* __restrict__ cs, int I, int e
     for (int i = 0; i < 7; ++i) CSF(CS_T_V + i) = t.v[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { CSF(CS_T_I + i) = t.i_prev[i]; CSF(CS_T_IP + i) = t.i_pp[i]; }
-    CSF(CS_T_ENV) = t.env; CSF(CS_T_RLDR) = t.r_ldr; CSF(CS_T_DEPTH) = t.depth;
-    if (t.be_fallbacks) {
-        const uint64_t d = dbits(CSF(CS_DIAG));
-        CSF(CS_DIAG) = bitsd((d & 0xFFFFFFFF00000000ull) | (uint64_t)((uint32_t)d + t.be_fallbacks));
-    }
+    CSF(CS_T_ENV) = t.env; CSF(CS_T_RLDR) = t.r_ldr;
+    if (t.be_fallbacks) CSF(CS_T_BE) = bitsd(dbits(CSF(CS_T_BE)) + (uint64_t)t.be_fallbacks);
 }
 OW_DEV void dk_load(DkSt& s, const double* __restrict__ cs, int I, int e, int base) {
     s.j_cin = CSF(base); s.cin_prev = CSF(base + 1);
@@ -362,9 +359,9 @@ __global__ __launch_bounds__(64) void k_chain_init(const OwConsts* __restrict__ 
     for (int i = 0; i < 4; ++i) { CSF(CS_T_I + i) = dci[i]; CSF(CS_T_IP + i) = dci[i]; }
     CSF(CS_T_ENV) = 0.0;
     CSF(CS_T_RLDR) = 1000000.0;
+    if (mode == 1) CSF(CS_T_BE) = bitsd(0ull);
     double r_ldr = 1000000.0;
     if (mode != 0) {
-        CSF(CS_T_DEPTH) = depth0;   // Tremolo::new(depth, ..) (tremolo.rs:103)
         if (mode == 1) {
             Smoother s;
             s.step = 0.0; s.rem = 0u;
@@ -432,8 +429,9 @@ __global__ void k_chain_replicate(double* __restrict__ cs, int I, int src, int e
 }
 
 // ------------------------------------------------------------------ tremolo stream
-__global__ __launch_bounds__(64) void k_tremolo(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args,
-                                                double* __restrict__ rbuf, int I, int L, int e0, int ne) {
+// CdS cell resistance for n_os chain-rate samples (no audio input, no depth dependence): runs a block ahead of the audio.
+__global__ __launch_bounds__(64) void k_tremolo(const OwConsts* __restrict__ K, double* __restrict__ cs, double* __restrict__ rbuf, int I, int n_os,
+                                                int e0, int ne) {
     __shared__ TremMats M;
     trem_mats_load(&M, K, threadIdx.x, 64);
     __syncthreads();
@@ -441,20 +439,12 @@ __global__ __launch_bounds__(64) void k_tremolo(const OwConsts* __restrict__ K, 
     if (e >= e0 + ne) return;
     TremState t;
     trem_load(t, cs, I, e);
-    Smoother sd;
-    smoother_load(sd, cs, I, e, CS_SM_DEPTH);
-    if (args[e].set_flags & 1u) sd.retarget(args[e].depth_target, K->ramp_samples);
-    const int osr = K->oversample ? 2 : 1;
-    for (int i = 0; i < L; ++i) {
-        t.depth = clampd(sd.next(), 0.0, 1.0);  // engine.rs:533-534, tremolo.rs:117-119
-        for (int j = 0; j < osr; ++j) {
-            int z = 0;
-            asm volatile("" : "+v"(z));    // opaque zero: keeps the LDS reads inside the loop
-            rbuf[(size_t)(i * osr + j) * I + e] = trem_process(t, K, &M + z);
-        }
+    for (int i = 0; i < n_os; ++i) {
+        int z = 0;
+        asm volatile("" : "+v"(z));    // opaque zero: keeps the LDS reads inside the loop
+        rbuf[(size_t)i * I + e] = trem_cell_r(t, K, &M + z);
     }
     trem_store(t, cs, I, e);
-    smoother_store(sd, cs, I, e, CS_SM_DEPTH);
 }
 
 // ------------------------------------------------------------------ preamp stream
@@ -474,8 +464,11 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
     DkSt st;
     double ua[3], ub[3];
     double r_ldr, g_ldr, g_prev;
+    Smoother sd;
     {
         const int e = ec;
+        smoother_load(sd, cs, I, e, CS_SM_DEPTH);
+        if (args[e].set_flags & 1u) sd.retarget(args[e].depth_target, K->ramp_samples);
         dk_load(st, cs, I, e, role ? CS_P_SHADOW : CS_P_MAIN);
         for (int i = 0; i < 3; ++i) { ua[i] = CSF(CS_OS_UA + i); ub[i] = CSF(CS_OS_UB + i); }
         r_ldr = CSF(CS_P_RLDR); g_ldr = CSF(CS_P_GLDR); g_prev = CSF(CS_P_GPREV);
@@ -502,6 +495,7 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
         __syncthreads();
         for (int n = 0; n < cn; ++n) {
             const double x = tile[el * (OW_PCHUNK + 1) + n];
+            const double depth = clampd(sd.next(), 0.0, 1.0);   // engine.rs:533-534, tremolo.rs:117-119
             double in[2];
             if (osr == 2) {  // Oversampler::upsample_2x (oversampler.rs:108-121); shadow input is 0.0 (dk_preamp_legacy.rs:599)
                 const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, ua, x);
@@ -514,7 +508,7 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
             }
             for (int j = 0; j < osr; ++j) {
                 const size_t idx = (size_t)((base + n) * osr + j);
-                const double r_new = fmax(rbuf[idx * I + ec], 1000.0);          // set_ldr_resistance, :620-626
+                const double r_new = fmax(trem_shunt(depth, rbuf[idx * I + ec]), 1000.0);   // tremolo.rs:152-167; set_ldr_resistance, :620-626
                 if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = 1.0 / r_new; }
                 const double o = dk_step(st, in[j], g_ldr, g_prev, K);
                 g_prev = g_ldr;                                                   // :604
@@ -536,6 +530,7 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
         if (role == 0) {
             for (int i = 0; i < 3; ++i) { CSF(CS_OS_UA + i) = ua[i]; CSF(CS_OS_UB + i) = ub[i]; }
             CSF(CS_P_RLDR) = r_ldr; CSF(CS_P_GLDR) = g_ldr; CSF(CS_P_GPREV) = g_prev;
+            smoother_store(sd, cs, I, e, CS_SM_DEPTH);
             const uint64_t fl = dbits(CSF(CS_FLAGS));
             if (fl & 1ull) CSF(CS_FLAGS) = bitsd(fl & ~1ull);
             if (nan_resets) {

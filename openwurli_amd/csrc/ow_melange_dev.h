@@ -388,8 +388,11 @@ __global__ __launch_bounds__(64) void k_preamp_mel(const OwConsts* __restrict__ 
 
     MelSt st;
     double ua[3], ub[3];
+    Smoother sd;
     {
         const int e = ec;
+        smoother_load(sd, cs, I, e, CS_SM_DEPTH);
+        if (args[e].set_flags & 1u) sd.retarget(args[e].depth_target, K->ramp_samples);
         mel_load(st, cs, I, e, role ? CS_M_SHADOW : CS_M_MAIN);
         for (int i = 0; i < 3; ++i) { ua[i] = CSF(CS_OS_UA + i); ub[i] = CSF(CS_OS_UB + i); }
         const uint64_t fl = dbits(CSF(CS_FLAGS));
@@ -413,6 +416,7 @@ __global__ __launch_bounds__(64) void k_preamp_mel(const OwConsts* __restrict__ 
         __syncthreads();
         for (int n = 0; n < cn; ++n) {
             const double x = tile[el * (OW_PCHUNK + 1) + n];
+            const double depth = clampd(sd.next(), 0.0, 1.0);   // engine.rs:533-534
             double in[2];
             if (osr == 2) {
                 const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, ua, x);
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(64) void k_preamp_mel(const OwConsts* __restrict__ 
             }
             for (int j = 0; j < osr; ++j) {
                 const size_t s_idx = (size_t)((base + n) * osr + j);
-                mel_set_r(st, rbuf[s_idx * I + ec]);                               // melange_adapter.rs:82-85
+                mel_set_r(st, trem_shunt(depth, rbuf[s_idx * I + ec]));            // tremolo.rs:152-167; melange_adapter.rs:82-85
                 int z = 0;
                 asm volatile("" : "+v"(z));                                        // keep the LDS constant reads inside the loop
                 const double o = mel_process(st, in[j], &M + z);
@@ -445,6 +449,7 @@ __global__ __launch_bounds__(64) void k_preamp_mel(const OwConsts* __restrict__ 
         mel_store(st, cs, I, e, role ? CS_M_SHADOW : CS_M_MAIN);
         if (role == 0) {
             for (int i = 0; i < 3; ++i) { CSF(CS_OS_UA + i) = ua[i]; CSF(CS_OS_UB + i) = ub[i]; }
+            smoother_store(sd, cs, I, e, CS_SM_DEPTH);
             const uint64_t fl = dbits(CSF(CS_FLAGS));
             if (fl & 1ull) CSF(CS_FLAGS) = bitsd(fl & ~1ull);
             const uint32_t nr = adapter_resets + st.nan_resets;

@@ -7,7 +7,8 @@
 //   chain state     double  cs[CS_COUNT][I]            engine-minor: lane = engine in the chain kernels
 //   per-note table  double  note_tab[NT_COUNT][64]     note-only part of Voice::note_on (tables.rs)
 //   stream buffers  double  sum[2][I][Lcap]            voice sums (slot pass, steal pass), engine-major
-//                   double  rbuf[2*Lcap][I]            tremolo shunt R per OS sample, sample-major
+//                   double  rbuf[2][2*Lcap][I]         CdS cell resistance per OS sample, sample-major; two halves: the tremolo
+//                                                      oscillator has no audio input and runs one block ahead
 //                   double  pre[2*Lcap][I]             preamp out (main - shadow), sample-major
 //                   float   out[I][Lcap]               final mono f32 (engine.rs:448)
 #pragma once
@@ -74,7 +75,7 @@ enum {
     CS_T_IP = 11,        // [4] i_nl_prev_prev
     CS_T_ENV = 15,       // ldr_envelope
     CS_T_RLDR = 16,      // r_ldr (CdS cell)
-    CS_T_DEPTH = 17,     // tremolo depth (clamped, tremolo.rs:117-119)
+    CS_T_BE = 17,        // u64 tremolo BE-fallback counter (gen_tremolo.rs diag_be_fallback_count); rows 0..17 = all state k_tremolo touches
     CS_SM_DEPTH = 18,    // [4] tremolo-depth smoother current,target,step,remaining(u64) (engine.rs:67-130)
     CS_SM_SPK = 22,      // [4] speaker-character smoother
     CS_SM_VOL = 26,      // [4] volume smoother
@@ -90,7 +91,7 @@ enum {
     CS_SPK_LPF = 81,     // [7]
     CS_SPK_CHAR = 88, CS_SPK_A2 = 89, CS_SPK_A3 = 90, CS_SPK_TC = 91, CS_SPK_TS = 92,
     CS_FLAGS = 93,       // u64 bit0: preamp+oversampler reset pending (engine.rs:450-457)
-    CS_DIAG = 94,        // u64 counters: lo32 tremolo BE fallbacks, hi32 preamp NaN resets
+    CS_DIAG = 94,        // u64 counters: hi32 preamp NaN resets
     CS_M_MAIN = 95,      // [21] melange 12-node preamp, main state: v_prev[12] i_nl_prev[3] i_nl_prev_prev[3] input_prev pot word
     CS_M_SHADOW = 116,   // [21] shadow state
     CS_COUNT = 137
