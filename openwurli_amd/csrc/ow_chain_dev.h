@@ -420,14 +420,20 @@ OW_DEV void dk_ic_gm(double vbe, double& ic, double& gm) {  // :686-690
 
 // dk_step, dk_preamp_legacy.rs:447-554.  Node order BASE1,EMIT1,COLL1,EMIT2,EMIT2B,COLL2,OUT,FB.
 __device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_ldr_prev, const OwConsts* __restrict__ K) {
+    // rhs = A_neg v (dk_preamp_legacy.rs:466).  A_neg = 2C/T - G has 20 structural non-zeros (resistor/capacitor stamps,
+    // :283-309); the reference multiplies the zeros too, which adds exact +-0.0 terms, so skipping them is bit-identical
+    // for finite v (a non-finite v still propagates through its node's own diagonal entry).
+    const double (*__restrict__ an)[8] = K->p_a_neg;
+    const double* v = st.v;
     double rhs[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        double sum = 0.0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sum += K->p_a_neg[i][j] * st.v[j];
-        rhs[i] = sum;
-    }
+    rhs[0] = 0.0 + an[0][0] * v[0] + an[0][2] * v[2];
+    rhs[1] = 0.0 + an[1][1] * v[1] + an[1][7] * v[7];
+    rhs[2] = 0.0 + an[2][0] * v[0] + an[2][2] * v[2] + an[2][5] * v[5];
+    rhs[3] = 0.0 + an[3][3] * v[3] + an[3][4] * v[4];
+    rhs[4] = 0.0 + an[4][3] * v[3] + an[4][4] * v[4];
+    rhs[5] = 0.0 + an[5][2] * v[2] + an[5][5] * v[5] + an[5][6] * v[6];
+    rhs[6] = 0.0 + an[6][5] * v[5] + an[6][6] * v[6] + an[6][7] * v[7];
+    rhs[7] = 0.0 + an[7][1] * v[1] + an[7][6] * v[6] + an[7][7] * v[7];
     rhs[7] -= g_ldr_prev * st.v[7];
     const double cin_now = K->p_g_cin * input + st.j_cin;
     rhs[0] += cin_now + st.cin_prev;

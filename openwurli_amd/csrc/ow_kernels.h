@@ -176,9 +176,22 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
 // test are left to k_voice.  Arithmetic per block is the same as VoiceRegs::step<true>.
 struct VoiceSteady {
     double s[7], c[7], env[7], drift[7], cos_inc[7], sin_inc[7], phase_inc[7], amp[7], decay[7];
+    double ci[7], si[7];   // jitter-corrected rotation (reed.rs:281-283): depends on drift only, which changes every 16 samples
     double q, ds, gain;
     uint64_t sample;
     uint32_t jitter_state;
+
+    OW_DEV void update_rotation() {
+#ifndef OW_STRICT_FP
+#pragma clang fp contract(fast)
+#endif
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            const double delta_phase = drift[m] * phase_inc[m];
+            ci[m] = cos_inc[m] - delta_phase * sin_inc[m];
+            si[m] = sin_inc[m] + delta_phase * cos_inc[m];
+        }
+    }
 
     OW_DEV double step(const OwConsts* __restrict__ K) {
 #ifndef OW_STRICT_FP
@@ -194,16 +207,14 @@ struct VoiceSteady {
                 const double noise = (u * 2.0 - 1.0) * 1.7320508080;
                 drift[m] = revert * drift[m] + diffusion * noise;
             }
+            update_rotation();
         }
         double sum = 0.0;
 #pragma unroll
         for (int m = 0; m < 7; ++m) {
             sum += amp[m] * s[m] * env[m];                 // onset == 1.0 (x * 1.0 == x)
-            const double delta_phase = drift[m] * phase_inc[m];
-            const double ci = cos_inc[m] - delta_phase * sin_inc[m];
-            const double si = sin_inc[m] + delta_phase * cos_inc[m];
-            const double s_new = s[m] * ci + c[m] * si;
-            const double c_new = c[m] * ci - s[m] * si;
+            const double s_new = s[m] * ci[m] + c[m] * si[m];
+            const double c_new = c[m] * ci[m] - s[m] * si[m];
             s[m] = s_new;
             c[m] = c_new;
             env[m] *= decay[m];
@@ -262,6 +273,7 @@ __global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict_
         v.sample = dbits(rec[VF_SAMPLE * 64]);
         const uint64_t r = dbits(rec[VF_RNG * 64]);
         v.jitter_state = (uint32_t)r; noise_rng = (uint32_t)(r >> 32);
+        v.update_rotation();
     }
     bool bad_sum = false;
     for (int base = 0; base < L; base += OW_VCHUNK) {
