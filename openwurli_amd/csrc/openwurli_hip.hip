@@ -16,6 +16,8 @@
 #include "ow_job_kernels.h"
 #include "ow_mlp_mfma.h"
 #include "ow_melange_dev.h"
+#include <map>
+#include <mutex>
 
 using owdev::OwEngineOut;
 
@@ -155,6 +157,31 @@ void ensure_ops_capacity(ow_pool* p, size_t n) {
     HIP_OK(hipMalloc(&p->d_ops, sizeof(OwOp) * cap));
     HIP_OK(hipHostMalloc(&p->h_ops, sizeof(OwOp) * cap));
     p->ops_cap = cap;
+}
+
+// Settled state of the melange preamp (melange_adapter.rs:12-20): rate-independent (always computed at the 48 kHz codegen
+// tables), so it is produced once per device by k_mel_settle and cached, like the reference's OnceLock.
+std::mutex g_mel_mu;
+std::map<int, std::vector<double>> g_mel_settled;
+void mel_settled_to_device(int device, double* d_dst, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_mel_mu);
+    auto it = g_mel_settled.find(device);
+    if (it == g_mel_settled.end()) {
+        OwConsts k48;
+        owhip::build_consts(k48, 24000.0, OW_PREAMP_MELANGE12);   // os_sr = 48 kHz -> codegen tables
+        OwConsts* dk = nullptr;
+        HIP_OK(hipMalloc(&dk, sizeof(OwConsts)));
+        HIP_OK(hipMemcpyAsync(dk, &k48, sizeof(OwConsts), hipMemcpyHostToDevice, st));
+        owdev::k_mel_settle<<<dim3(1), dim3(64), 0, st>>>(dk, d_dst);
+        std::vector<double> h(18);
+        HIP_OK(hipMemcpyAsync(h.data(), d_dst, sizeof(double) * 18, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        hipFree(dk);
+        g_mel_settled[device] = h;
+        return;
+    }
+    HIP_OK(hipMemcpyAsync(d_dst, it->second.data(), sizeof(double) * 18, hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
 }
 
 enum { INIT_NEW = 1, INIT_RATE = 2, INIT_RESET = 0 };
@@ -422,8 +449,7 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     owdev::k_note_table<<<dim3(1), dim3(64), 0, p->stream>>>(p->d_nt);
     if (preamp_kind == OW_PREAMP_MELANGE12) {
         HIP_OK(hipMalloc(&p->d_mel_settled, sizeof(double) * 18));
-        // settled-state cache of the adapter (melange_adapter.rs:12-20): 176 400 steps at the 48 kHz codegen tables
-        owdev::k_mel_settle<<<dim3(1), dim3(64), 0, p->stream>>>(p->dK48, p->d_mel_settled);
+        mel_settled_to_device(device, p->d_mel_settled, p->stream);
     }
     p->engines.resize(n_engines);
     p->dirty.assign(n_engines, 1);
@@ -832,7 +858,7 @@ long long ow_render_note(uint8_t midi, double velocity, double dur_s, double sam
 long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg* cfg, double* out, size_t stride, int out_is_device) {
     try {
         if (!jobs || !cfg || !out || n_jobs == 0) throw std::runtime_error("null argument");
-        if (cfg->preamp_kind != OW_PREAMP_LEGACY8) throw std::runtime_error("preamp_kind: only OW_PREAMP_LEGACY8 is built in this round");
+        if (cfg->preamp_kind != OW_PREAMP_LEGACY8 && cfg->preamp_kind != OW_PREAMP_MELANGE12) throw std::runtime_error("unknown preamp_kind");
         const double x = cfg->duration_s * cfg->sample_rate;
         const size_t n = (!(x == x) || x <= 0.0) ? 0 : (size_t)x;                 // (duration * sample_rate) as usize, main.rs:411
         if (n == 0) return 0;
@@ -863,11 +889,21 @@ long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg*
         HIP_OK(hipMemcpyAsync(d_jobs, hj.data(), sizeof(owdev::OwJobDev) * n_jobs, hipMemcpyHostToDevice, st));
         owdev::k_note_table<<<dim3(1), dim3(64), 0, st>>>(d_nt);
         owdev::k_job_voice<<<dim3((unsigned)vblocks), dim3(64), 0, st>>>(dK, d_nt, d_vrec, d_jobs, d_reed, (int)n_jobs, (long long)n, (long long)n);
-        owdev::k_job_chain<<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_reed, d_out, (int)n_jobs, (long long)n, (long long)stride);
+        double* d_settled = nullptr;
+        if (cfg->preamp_kind == OW_PREAMP_MELANGE12) {
+            HIP_OK(hipMalloc(&d_settled, sizeof(double) * 18));
+            mel_settled_to_device(cfg->device, d_settled, st);
+            owdev::k_job_chain<true><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_reed, d_out, d_settled, (int)n_jobs, (long long)n,
+                                                                                                (long long)stride);
+        } else {
+            owdev::k_job_chain<false><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_reed, d_out, nullptr, (int)n_jobs, (long long)n,
+                                                                                                 (long long)stride);
+        }
         HIP_OK(hipGetLastError());
         if (!out_is_device) HIP_OK(hipMemcpyAsync(out, d_out, sizeof(double) * n_jobs * stride, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         hipFree(dK); hipFree(d_nt); hipFree(d_vrec); hipFree(d_jobs); hipFree(d_reed);
+        if (d_settled) hipFree(d_settled);
         if (!out_is_device) hipFree(d_out);
         hipStreamDestroy(st);
         return (long long)n;

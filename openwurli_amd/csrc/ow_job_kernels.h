@@ -8,6 +8,7 @@
 // lane pairs (k_job_chain) of different jobs in lock-step.
 #pragma once
 #include "ow_kernels.h"
+#include "ow_melange_dev.h"
 
 namespace owdev {
 
@@ -51,11 +52,15 @@ __global__ __launch_bounds__(64) void k_job_voice(const OwConsts* __restrict__ K
     }
 }
 
-// Preamp + output stage, lane pair (job, main|shadow): 32 jobs per wavefront.
+// Preamp + output stage, lane pair (job, main|shadow): 32 jobs per wavefront.  MEL selects the melange 12-node solver
+// (`--features melange-preamp` build of preamp-bench) instead of the legacy 8-node one.
+template <bool MEL>
 __global__ __launch_bounds__(64) void k_job_chain(const OwConsts* __restrict__ K, const OwJobDev* __restrict__ jobs, const double* __restrict__ reed,
-                                                  double* __restrict__ out, int n_jobs, long long n, long long stride) {
+                                                  double* __restrict__ out, const double* __restrict__ settled, int n_jobs, long long n, long long stride) {
     __shared__ double tin[32 * (OW_PCHUNK + 1)];
     __shared__ double tout[32 * (OW_PCHUNK + 1)];
+    __shared__ MelMats M;
+    if (MEL) { mel_mats_load(&M, K, threadIdx.x, 64); __syncthreads(); }
     const int lane = threadIdx.x;
     const int jl = lane & 31, role = lane >> 5;
     const int jb = blockIdx.x * 32;
@@ -67,13 +72,38 @@ __global__ __launch_bounds__(64) void k_job_chain(const OwConsts* __restrict__ K
 
     // DkPreamp::new(preamp_sr); preamp.reset(); preamp.set_ldr_resistance(r_ldr)  (main.rs:432-441)
     DkSt st;
+    MelSt ms;
     double r_ldr = 1000000.0;
-    dk_dc_state(K, r_ldr, &st);                       // new() and reset() both solve DC at the initial 1 Mohm
     double g_ldr = 1.0 / r_ldr, g_prev = g_ldr;
-    {
+    if (MEL) {
+        mel_init_state(ms, settled);                  // new() and reset() both clone the settled state (melange_adapter.rs:22-29,88-93)
+        ms.nan_resets = 0; ms.be_fallbacks = 0;
+        mel_set_r(ms, jd.r_ldr);
+    } else {
+        dk_dc_state(K, r_ldr, &st);                   // new() and reset() both solve DC at the initial 1 Mohm
         const double r_new = fmax(jd.r_ldr, 1000.0);
         if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = 1.0 / r_new; }
     }
+    // one preamp sample for this lane's state (main: audio, shadow: 0.0), returns main - pump with the adapter's NaN reset
+    auto preamp_step = [&](double x) -> double {
+        double o;
+        if (MEL) {
+            int z = 0;
+            asm volatile("" : "+v"(z));
+            o = mel_process(ms, x, &M + z);
+        } else {
+            o = dk_step(st, x, g_ldr, g_prev, K);
+            g_prev = g_ldr;
+        }
+        const double other = __shfl_xor(o, 32);
+        double res = role ? (other - o) : (o - other);
+        if (!isfinite(res)) {
+            if (MEL) { mel_init_state(ms, settled); }
+            else { dk_dc_state(K, r_ldr, &st); g_ldr = 1.0 / r_ldr; g_prev = g_ldr; }
+            res = 0.0;
+        }
+        return res;
+    };
     double ua[3] = {0, 0, 0}, ub[3] = {0, 0, 0}, da[3] = {0, 0, 0}, db[3] = {0, 0, 0}, dd = 0.0;
     SpeakerSt sp;                                      // Speaker::new(sr); set_character(c)  (main.rs:483-484)
     sp.character = 1.0; sp.ts = 0.0;
@@ -98,24 +128,13 @@ __global__ __launch_bounds__(64) void k_job_chain(const OwConsts* __restrict__ K
                 const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, ub, x);
                 double p[2];
                 const double in[2] = {role ? 0.0 : a, role ? 0.0 : b};
-                for (int k = 0; k < 2; ++k) {
-                    const double o = dk_step(st, in[k], g_ldr, g_prev, K);
-                    g_prev = g_ldr;
-                    const double other = __shfl_xor(o, 32);
-                    double res = role ? (other - o) : (o - other);
-                    if (!isfinite(res)) { dk_dc_state(K, r_ldr, &st); g_ldr = 1.0 / r_ldr; g_prev = g_ldr; res = 0.0; }
-                    p[k] = res;
-                }
+                for (int k = 0; k < 2; ++k) p[k] = preamp_step(in[k]);
                 const double fa = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, p[0]);
                 const double fb = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, p[1]);
                 pre = (fa + dd) * 0.5;
                 dd = fb;
             } else {
-                const double o = dk_step(st, role ? 0.0 : x, g_ldr, g_prev, K);
-                g_prev = g_ldr;
-                const double other = __shfl_xor(o, 32);
-                pre = role ? (other - o) : (o - other);
-                if (!isfinite(pre)) { dk_dc_state(K, r_ldr, &st); g_ldr = 1.0 / r_ldr; g_prev = g_ldr; pre = 0.0; }
+                pre = preamp_step(role ? 0.0 : x);
             }
             // main.rs:487-496: volume^2 (audio taper) -> optional power amp at base rate -> speaker -> PSG
             const double att = pre * vol2_a * vol2_a;

@@ -335,7 +335,7 @@ struct WurliEngine {
 // tools/preamp-bench/src/main.rs:371-549 with --no-poweramp, --tremolo-depth 0 (static LDR),
 // parametrised by mlp / speaker character / volume / r_ldr.  Output: final_output f64.
 inline std::vector<double> batch_render_job(int note, int velocity_u8, double duration, double sr, double volume,
-                                            double speaker_char, double r_ldr, bool mlp, bool poweramp) {
+                                            double speaker_char, double r_ldr, bool mlp, bool poweramp, int preamp_kind = 0) {
     const bool do_os = sr < 88200.0;
     const double preamp_sr = do_os ? sr * 2.0 : sr;
     const double vel_norm = (double)velocity_u8 / 127.0;
@@ -346,10 +346,12 @@ inline std::vector<double> batch_render_job(int note, int velocity_u8, double du
     std::vector<double> reed(n, 0.0);
     for (size_t off = 0; off < n; off += 1024) voice.render(reed.data() + off, std::min((size_t)1024, n - off));
 
-    DkPreamp preamp;
-    preamp.init(preamp_sr);
-    preamp.reset();
-    preamp.set_ldr_resistance(r_ldr);
+    DkPreamp legacy;
+    MelangePreamp mel;
+    if (preamp_kind) { mel.init(preamp_sr); mel.reset(); mel.set_ldr_resistance(r_ldr); }
+    else { legacy.init(preamp_sr); legacy.reset(); legacy.set_ldr_resistance(r_ldr); }
+    struct { DkPreamp* l; MelangePreamp* m; double process_sample(double x) { return m ? m->process_sample(x) : l->process_sample(x); } }
+        preamp{preamp_kind ? nullptr : &legacy, preamp_kind ? &mel : nullptr};
     std::vector<double> pre(n, 0.0);
     if (do_os) {
         Oversampler os;

@@ -68,6 +68,14 @@ size_t owo_batch_render_job(int note, int vel_u8, double dur_s, double sr, doubl
     return v.size();
 }
 
+size_t owo_batch_render_job_kind(int note, int vel_u8, double dur_s, double sr, double volume, double speaker_char, double r_ldr,
+                                 int mlp, int poweramp, int preamp_kind, double* out, size_t cap) {
+    std::vector<double> v = batch_render_job(note, vel_u8, dur_s, sr, volume, speaker_char, r_ldr, mlp != 0, poweramp != 0, preamp_kind);
+    const size_t n = std::min(cap, v.size());
+    for (size_t i = 0; i < n; ++i) out[i] = v[i];
+    return v.size();
+}
+
 // ---- unit-level hooks for the known-answer tests ----
 double owo_midi_to_freq(int m) { return midi_to_freq(m); }
 double owo_tip_mass_ratio(int m) { return tip_mass_ratio(m); }

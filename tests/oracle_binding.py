@@ -31,6 +31,7 @@ def _configure(L):
             getattr(L, name).restype = C.c_double
         L.owo_render_note.restype = C.c_size_t
         L.owo_batch_render_job.restype = C.c_size_t
+        L.owo_batch_render_job_kind.restype = C.c_size_t
         L.owo_engine_nan_guard_fires.restype = C.c_ulonglong
     return L
 
@@ -118,11 +119,12 @@ def render_note(midi, vel, dur, sr):
     return out[:got]
 
 
-def batch_render_job(note, vel_u8, dur, sr, volume=1.0, speaker=0.0, r_ldr=1e6, mlp=False, poweramp=False, perturbed=False):
+def batch_render_job(note, vel_u8, dur, sr, volume=1.0, speaker=0.0, r_ldr=1e6, mlp=False, poweramp=False, perturbed=False, preamp_kind=0):
     n = int(dur * sr)
     out = np.zeros(max(n, 1))
-    got = (lib_perturbed() if perturbed else lib()).owo_batch_render_job(int(note), int(vel_u8), C.c_double(dur), C.c_double(sr), C.c_double(volume), C.c_double(speaker),
-                                     C.c_double(r_ldr), 1 if mlp else 0, 1 if poweramp else 0, _p(out), C.c_size_t(out.size))
+    got = (lib_perturbed() if perturbed else lib()).owo_batch_render_job_kind(
+        int(note), int(vel_u8), C.c_double(dur), C.c_double(sr), C.c_double(volume), C.c_double(speaker), C.c_double(r_ldr),
+        1 if mlp else 0, 1 if poweramp else 0, int(preamp_kind), _p(out), C.c_size_t(out.size))
     return out[:got]
 
 

@@ -377,3 +377,17 @@ def test_melange_static_ldr_and_reset(hiplib, oracle):
         co = c.render(512)
         _check(oracle.parity_report(go, co, abs_floor=oracle.ABS_FLOOR_MELANGE_OUTPUT), ("melange reset", b))
     g.close()
+
+
+def test_batch_render_melange(hiplib, oracle):
+    """preamp-bench render built with `--features melange-preamp`: static LDR at several values incl. the 100 kOhm nominal."""
+    import openwurli_amd as ow
+    jobs = [{"note": n, "velocity": v, "r_ldr": r} for (n, v, r) in
+            ((48, 100, 1e6), (60, 127, 1e6), (72, 50, 19000.0), (84, 90, 1e5), (91, 127, 47000.0))]
+    dur, sr = 0.4, 44100.0
+    g = ow.batch_render(jobs, sample_rate=sr, duration_s=dur, preamp_kind=1)
+    for i, j in enumerate(jobs):
+        c = oracle.batch_render_job(j["note"], j["velocity"], dur, sr, r_ldr=j["r_ldr"], preamp_kind=1)
+        rep = oracle.parity_report(g[i], c, abs_floor=oracle.ABS_FLOOR_MELANGE_OUTPUT * 4)
+        _check(rep, ("melange job", j))
+        assert rep["max_err_rel_peak"] < 1e-5
