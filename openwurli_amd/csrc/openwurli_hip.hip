@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -752,6 +753,23 @@ int ow_engine_has_steal_voice_for(const ow_engine* e, uint8_t note) {
     return 0;
 }
 
+// Host threads worth starting: the CPU count capped by the cgroup CPU quota (cpu.max "quota period").  A container limited
+// to 16 CPUs on a 256-thread host gets throttled for whole scheduler periods when 64 threads burst at once.
+static size_t effective_cpus() {
+    size_t n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long long period = 0;
+        if (std::fscanf(f, "%31s %lld", quota, &period) == 2 && period > 0 && std::strcmp(quota, "max") != 0) {
+            const long long q = std::atoll(quota);
+            if (q > 0) n = std::min<size_t>(n, (size_t)std::max<long long>(1, q / period));
+        }
+        std::fclose(f);
+    }
+    return n;
+}
+
 static void midi_apply_one(ow_pool* p, const ow_midi_event& ev) {
     ow_engine* e = p->engines[ev.engine];
     switch (ev.type) {
@@ -766,20 +784,53 @@ void ow_pool_midi(ow_pool* p, const ow_midi_event* ev, size_t n) {
     if (!p || !ev) return;
     // Engines are independent state machines: large event lists are applied by several host threads, each owning a
     // contiguous range of engines and walking the list in array order (per-engine order is what matters).
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t T = std::min<size_t>(hw ? hw : 1, 32);
+    size_t T = std::min<size_t>(effective_cpus(), 64);
     if (n < 4096 || p->I < 2 * T) T = 1;
     if (T == 1) {
         for (size_t i = 0; i < n; ++i) if (ev[i].engine < p->I) midi_apply_one(p, ev[i]);
         return;
     }
+    // Fast path: a list grouped by engine (non-decreasing engine index, the usual layout of a batched script) is cut into T
+    // contiguous slices at engine boundaries, so each thread touches only its own events.  The grouping is verified first, in
+    // parallel; an ungrouped list falls back to every thread scanning the whole list for its engine range.
     std::vector<std::thread> th;
-    const size_t per = (p->I + T - 1) / T;
+    std::vector<uint8_t> ok(T, 1);
     for (size_t t = 0; t < T; ++t) {
-        const uint32_t lo = (uint32_t)(t * per), hi = (uint32_t)std::min(p->I, (t + 1) * per);
-        th.emplace_back([=] {
-            for (size_t i = 0; i < n; ++i) if (ev[i].engine >= lo && ev[i].engine < hi) midi_apply_one(p, ev[i]);
+        const size_t i0 = std::max<size_t>(n * t / T, 1), i1 = n * (t + 1) / T;
+        th.emplace_back([=, &ok] {
+            uint8_t good = 1;
+            for (size_t i = i0; i < i1; ++i) good &= (uint8_t)(ev[i].engine >= ev[i - 1].engine);
+            ok[t] = good;
         });
+    }
+    for (auto& x : th) x.join();
+    th.clear();
+    bool grouped = true;
+    for (size_t t = 0; t < T; ++t) grouped = grouped && ok[t];
+    if (grouped) {
+        std::vector<size_t> cut(T + 1);
+        cut[0] = 0; cut[T] = n;
+        for (size_t t = 1; t < T; ++t) {   // first event of the engine that owns position n*t/T belongs to the slice on the right
+            size_t i = n * t / T;
+            const uint32_t eng = ev[i].engine;
+            i = (size_t)(std::lower_bound(ev, ev + i, eng, [](const ow_midi_event& a, uint32_t b) { return a.engine < b; }) - ev);
+            cut[t] = std::max(i, cut[t - 1]);
+        }
+        for (size_t t = 0; t < T; ++t) {
+            const size_t i0 = cut[t], i1 = cut[t + 1];
+            if (i0 >= i1) continue;
+            th.emplace_back([=] {
+                for (size_t i = i0; i < i1; ++i) if (ev[i].engine < p->I) midi_apply_one(p, ev[i]);
+            });
+        }
+    } else {
+        const size_t per = (p->I + T - 1) / T;
+        for (size_t t = 0; t < T; ++t) {
+            const uint32_t lo = (uint32_t)(t * per), hi = (uint32_t)std::min(p->I, (t + 1) * per);
+            th.emplace_back([=] {
+                for (size_t i = 0; i < n; ++i) if (ev[i].engine >= lo && ev[i].engine < hi) midi_apply_one(p, ev[i]);
+            });
+        }
     }
     for (auto& x : th) x.join();
 }

@@ -132,8 +132,10 @@ OW_DEV void trem_mats_load(TremMats* __restrict__ m, const OwConsts* __restrict_
     for (int i = tid; i < 28; i += nthreads) dst[114 + i] = (&K->t_s_ni[0][0])[i];
 }
 
-struct TremState {
-    double v[7], i_prev[4], i_pp[4];
+// DC operating point of the Twin-T (gen_tremolo.rs DC_OP / DC_NL_I): v[0..6], i_nl[0..3]
+__device__ const double OW_TREM_DC[11] = {4.26480458363572357e0, 0.0, 1.24642300965575981e0, 2.75561285973736503e0, 6.66518981651571640e-1, 1.5e1, -2.28408414614134341e-3,
+                                          7.72841164985201955e-5, 3.86420577732601037e-7, 2.20372764986731876e-3, 1.10186382445765932e-5};
+struct TremState {   // register-resident part; v / i_prev / i_pp live in TremPark
     double env, r_ldr;
     uint32_t be_fallbacks;
 };
@@ -141,8 +143,11 @@ struct TremState {
 // NR sweep shared by the trapezoidal solve (sparse v_d as emitted, gen_tremolo.rs:2423-2438) and the
 // BE fallback (dense v_d, :2798-2817).  Returns true when converged within MAX_ITER (=50).
 template <bool BE>
-__device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk)[4], double i_nl[4]) {
+__device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk0)[4], double i_nl[4]) {
     for (int iter = 0; iter < 50; ++iter) {
+        int z = 0;
+        asm volatile("" : "+v"(z));   // opaque zero: K is re-read from LDS every sweep instead of held in 32 VGPRs
+        const double (*__restrict__ kk)[4] = kk0 + z;
         double vd[4];
         vd[0] = p[0] + kk[0][0] * i_nl[0] + kk[0][1] * i_nl[1] + kk[0][2] * i_nl[2] + kk[0][3] * i_nl[3];
         if (BE) {
@@ -157,12 +162,15 @@ __device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk
         const Bjt d1 = bjt_eval(vd[2], vd[3]);
         const double f[4] = {i_nl[0] - d0.ic, i_nl[1] - d0.ib, i_nl[2] - d1.ic, i_nl[3] - d1.ib};
         double a[4][4];
+        int z1 = 0;
+        asm volatile("" : "+v"(z1));
+        const double (*__restrict__ kj)[4] = kk0 + z1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            a[0][j] = (j == 0 ? 1.0 : 0.0) - d0.j0 * kk[0][j] - d0.j1 * kk[1][j];
-            a[1][j] = (j == 1 ? 1.0 : 0.0) - d0.j2 * kk[0][j] - d0.j3 * kk[1][j];
-            a[2][j] = (j == 2 ? 1.0 : 0.0) - d1.j0 * kk[2][j] - d1.j1 * kk[3][j];
-            a[3][j] = (j == 3 ? 1.0 : 0.0) - d1.j2 * kk[2][j] - d1.j3 * kk[3][j];
+            a[0][j] = (j == 0 ? 1.0 : 0.0) - d0.j0 * kj[0][j] - d0.j1 * kj[1][j];
+            a[1][j] = (j == 1 ? 1.0 : 0.0) - d0.j2 * kj[0][j] - d0.j3 * kj[1][j];
+            a[2][j] = (j == 2 ? 1.0 : 0.0) - d1.j0 * kj[2][j] - d1.j1 * kj[3][j];
+            a[3][j] = (j == 3 ? 1.0 : 0.0) - d1.j2 * kj[2][j] - d1.j3 * kj[3][j];
         }
         double b[4] = {f[0], f[1], f[2], f[3]};
         const bool ok = solve4(a, b);
@@ -171,6 +179,9 @@ __device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk
                 double i_trial[4], dv_trial[4], v_lim[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) i_trial[q] = i_nl[q] - b[q];
+                int z2 = 0;
+                asm volatile("" : "+v"(z2));
+                const double (*__restrict__ kk)[4] = kk0 + z2;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const double v_trial = p[q] + kk[q][0] * i_trial[0] + kk[q][1] * i_trial[1] + kk[q][2] * i_trial[2] + kk[q][3] * i_trial[3];
@@ -246,8 +257,9 @@ __device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk
     return false;
 }
 
-// Backward-Euler retry (gen_tremolo.rs:2755-3080).  Never taken in normal operation; kept out of line.
-__device__ __noinline__ void trem_be_fallback(const OwConsts* __restrict__ K, const double v_prev[7], const double i_prev[4], const double i_pp[4],
+// Backward-Euler retry (gen_tremolo.rs:2755-3080).  Never taken in normal operation; inlined behind __builtin_expect so the
+// register allocator places its spills inside this cold block (a noinline callee cannot be register-capped).
+__device__ inline void trem_be_fallback(const OwConsts* __restrict__ K, const double v_prev[7], const double i_prev[4], const double i_pp[4],
                                               double v_out[7], double i_nl[4]) {
     double rhs[7], vp[7], p[4];
     const double rc_be[7] = {0, 0, 0, 0, 0, 0, 15.0};
@@ -281,90 +293,112 @@ __device__ __noinline__ void trem_be_fallback(const OwConsts* __restrict__ K, co
 
 // gen_tremolo.rs:2353-3116 with input == 0.0 (Tremolo always drives the oscillator with silence,
 // tremolo.rs:183).  Returns v[OUT].
-__device__ inline double trem_osc_step(TremState& st, const OwConsts* __restrict__ K, const TremMats* __restrict__ M) {
+// LDS home of the oscillator state of one wavefront (lane-minor): the 15 state doubles and v_pred live here, not in VGPRs,
+// so the Newton sweep runs with ~40 fewer live registers and the kernel fits beside two voice wavefronts on a SIMD.
+struct TremPark {
+    double v[7][64], ip[4][64], ipp[4][64], vp[7][64];
+};
+__device__ inline TremPark* park_opaque(TremPark* P) {
+    int z = 0;
+    asm volatile("" : "+v"(z));   // opaque zero: no store-to-load forwarding through registers
+    return P + z;
+}
+
+__device__ inline double trem_osc_step(TremState& st, TremPark* __restrict__ P0, const OwConsts* __restrict__ K, const TremMats* __restrict__ M) {
+    const int ln = threadIdx.x & 63;
+    double p[4], i_nl[4];
+    {
+        TremPark* P = park_opaque(P0);
+        double sv[7], ip[4];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) st.v[i] = st.v[i] + 1e-25 - 1e-25;
+        for (int i = 0; i < 7; ++i) { sv[i] = P->v[i][ln] + 1e-25 - 1e-25; P->v[i][ln] = sv[i]; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) st.i_prev[i] = st.i_prev[i] + 1e-25 - 1e-25;
-    const double (*__restrict__ an)[7] = M->a_neg;
-    double rhs[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 15.0};  // RHS_CONST (gen_tremolo.rs:1055-1063)
-    rhs[0] += an[0][0] * st.v[0];
-    rhs[0] += an[0][1] * st.v[1];
-    rhs[0] += an[0][3] * st.v[3];
-    rhs[0] += an[0][5] * st.v[5];
-    rhs[1] += an[1][0] * st.v[0];
-    rhs[1] += an[1][1] * st.v[1];
-    rhs[1] += an[1][2] * st.v[2];
-    rhs[2] += an[2][1] * st.v[1];
-    rhs[2] += an[2][2] * st.v[2];
-    rhs[2] += an[2][3] * st.v[3];
-    rhs[3] += an[3][0] * st.v[0];
-    rhs[3] += an[3][2] * st.v[2];
-    rhs[3] += an[3][3] * st.v[3];
-    rhs[4] += an[4][4] * st.v[4];
-    rhs[5] += an[5][0] * st.v[0];
-    rhs[5] += an[5][5] * st.v[5];
-    rhs[5] += an[5][6] * st.v[6];
-    // N_I entries are exactly +-1 (gen_tremolo.rs:519-562)
-    rhs[0] += -1.0 * st.i_prev[0];
-    rhs[0] += -1.0 * st.i_prev[2];
-    rhs[2] += -1.0 * st.i_prev[1];
-    rhs[4] += 1.0 * st.i_prev[0];
-    rhs[4] += 1.0 * st.i_prev[1];
-    rhs[4] += -1.0 * st.i_prev[3];
-    rhs[0] += (0.0 + 0.0) * (1.0 / 1.0e7);  // input source, input == input_prev == 0
-    double v_pred[7];
+        for (int i = 0; i < 4; ++i) { ip[i] = P->ip[i][ln] + 1e-25 - 1e-25; P->ip[i][ln] = ip[i]; }
+        const double (*__restrict__ an)[7] = M->a_neg;
+        double rhs[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 15.0};  // RHS_CONST (gen_tremolo.rs:1055-1063)
+        rhs[0] += an[0][0] * sv[0];
+        rhs[0] += an[0][1] * sv[1];
+        rhs[0] += an[0][3] * sv[3];
+        rhs[0] += an[0][5] * sv[5];
+        rhs[1] += an[1][0] * sv[0];
+        rhs[1] += an[1][1] * sv[1];
+        rhs[1] += an[1][2] * sv[2];
+        rhs[2] += an[2][1] * sv[1];
+        rhs[2] += an[2][2] * sv[2];
+        rhs[2] += an[2][3] * sv[3];
+        rhs[3] += an[3][0] * sv[0];
+        rhs[3] += an[3][2] * sv[2];
+        rhs[3] += an[3][3] * sv[3];
+        rhs[4] += an[4][4] * sv[4];
+        rhs[5] += an[5][0] * sv[0];
+        rhs[5] += an[5][5] * sv[5];
+        rhs[5] += an[5][6] * sv[6];
+        // N_I entries are exactly +-1 (gen_tremolo.rs:519-562)
+        rhs[0] += -1.0 * ip[0];
+        rhs[0] += -1.0 * ip[2];
+        rhs[2] += -1.0 * ip[1];
+        rhs[4] += 1.0 * ip[0];
+        rhs[4] += 1.0 * ip[1];
+        rhs[4] += -1.0 * ip[3];
+        rhs[0] += (0.0 + 0.0) * (1.0 / 1.0e7);  // input source, input == input_prev == 0
+        double v_pred[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        double sum = 0.0;
+        for (int i = 0; i < 7; ++i) {
+            double sum = 0.0;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) sum += M->s[i][j] * rhs[j];
-        v_pred[i] = sum;
+            for (int j = 0; j < 7; ++j) sum += M->s[i][j] * rhs[j];
+            v_pred[i] = sum;
+            P->vp[i][ln] = sum;
+        }
+        // N_V entries are exactly +-1 (gen_tremolo.rs:479-516)
+        p[0] = 1.0 * v_pred[2] + -1.0 * v_pred[4];
+        p[1] = -1.0 * v_pred[0] + 1.0 * v_pred[2];
+        p[2] = 1.0 * v_pred[4];
+        p[3] = -1.0 * v_pred[0] + 1.0 * v_pred[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) i_nl[i] = 2.0 * ip[i] - P->ipp[i][ln];
     }
-    double p[4];  // N_V entries are exactly +-1 (gen_tremolo.rs:479-516)
-    p[0] = 1.0 * v_pred[2] + -1.0 * v_pred[4];
-    p[1] = -1.0 * v_pred[0] + 1.0 * v_pred[2];
-    p[2] = 1.0 * v_pred[4];
-    p[3] = -1.0 * v_pred[0] + 1.0 * v_pred[4];
-    double i_nl[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) i_nl[i] = 2.0 * st.i_prev[i] - st.i_pp[i];
     const bool converged = trem_nr<false>(p, M->k, i_nl);
+    TremPark* P = park_opaque(P0);
     double v[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-        double x = v_pred[i];
+        double x = P->vp[i][ln];
 #pragma unroll
         for (int j = 0; j < 4; ++j) x += M->s_ni[i][j] * i_nl[j];
         v[i] = x;
     }
-    if (!converged) {
+    if (__builtin_expect(!converged, 0)) {
         st.be_fallbacks += 1u;
-        trem_be_fallback(K, st.v, st.i_prev, st.i_pp, v, i_nl);
+        double v_prev[7], i_prev[4], i_pp[4];
+        for (int i = 0; i < 7; ++i) v_prev[i] = P->v[i][ln];
+        for (int i = 0; i < 4; ++i) { i_prev[i] = P->ip[i][ln]; i_pp[i] = P->ipp[i][ln]; }
+        trem_be_fallback(K, v_prev, i_prev, i_pp, v, i_nl);
     }
     bool finite = true;
 #pragma unroll
     for (int i = 0; i < 7; ++i) finite = finite && isfinite(v[i]);
-    if (!finite) {  // NaN reset to the baked DC operating point (gen_tremolo.rs:3083-3093)
-        const double dc[7] = {4.26480458363572357e0, 0.0, 1.24642300965575981e0, 2.75561285973736503e0, 6.66518981651571640e-1, 1.5e1, -2.28408414614134341e-3};
-        const double dci[4] = {7.72841164985201955e-5, 3.86420577732601037e-7, 2.20372764986731876e-3, 1.10186382445765932e-5};
+    if (__builtin_expect(!finite, 0)) {  // NaN reset to the baked DC operating point (gen_tremolo.rs:3083-3093); constants read from memory on this cold path
+        int z = 0;
+        asm volatile("" : "+v"(z));
+        const double* dc = OW_TREM_DC + z;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) st.v[i] = dc[i];
+        for (int i = 0; i < 7; ++i) P->v[i][ln] = dc[i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { st.i_prev[i] = dci[i]; st.i_pp[i] = dci[i]; }
-        return 4.26480458363572357e0;
+        for (int i = 0; i < 4; ++i) { P->ip[i][ln] = dc[7 + i]; P->ipp[i][ln] = dc[7 + i]; }
+        return dc[0];
     }
 #pragma unroll
-    for (int i = 0; i < 7; ++i) st.v[i] = v[i];
+    for (int i = 0; i < 7; ++i) P->v[i][ln] = v[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { st.i_pp[i] = st.i_prev[i]; st.i_prev[i] = i_nl[i]; }
+    for (int i = 0; i < 4; ++i) { P->ipp[i][ln] = P->ip[i][ln]; P->ip[i][ln] = i_nl[i]; }
     return v[0];
 }
 
 // Tremolo::process, oscillator half (tremolo.rs:121-146): LED drive -> CdS envelope -> power-law cell resistance r_ldr.
 // It has no audio input and no dependence on the depth knob, so it is produced a block ahead (k_tremolo).
-__device__ inline double trem_cell_r(TremState& st, const OwConsts* __restrict__ K, const TremMats* __restrict__ M) {
-    const double v_out = trem_osc_step(st, K, M);
+__device__ inline double trem_cell_r(TremState& st, TremPark* __restrict__ P, const OwConsts* __restrict__ K, const TremMats* __restrict__ M) {
+    const double v_out = trem_osc_step(st, P, K, M);
     const double led = clampd((10.95 - v_out) / (10.95 - 0.70), 0.0, 1.0);
     const double coeff = led > st.env ? K->ldr_attack : K->ldr_release;
     st.env = led + coeff * (st.env - led);
@@ -419,6 +453,8 @@ OW_DEV void dk_ic_gm(double vbe, double& ic, double& gm) {  // :686-690
 }
 
 // dk_step, dk_preamp_legacy.rs:447-554.  Node order BASE1,EMIT1,COLL1,EMIT2,EMIT2B,COLL2,OUT,FB.
+// (Staging the 114 wave-uniform constants in LDS instead of spilled SGPRs was measured slower: the ds_read latency is exposed
+// with two wavefronts per SIMD, the v_readlane of a spilled SGPR is not.)
 __device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_ldr_prev, const OwConsts* __restrict__ K) {
     // rhs = A_neg v (dk_preamp_legacy.rs:466).  A_neg = 2C/T - G has 20 structural non-zeros (resistor/capacitor stamps,
     // :283-309); the reference multiplies the zeros too, which adds exact +-0.0 terms, so skipping them is bit-identical

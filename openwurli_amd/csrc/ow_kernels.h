@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void k_apply_ops(const OwConsts* __restrict__ K
 }
 
 // ------------------------------------------------------------------ voices
-#define OW_VCHUNK 32
+#define OW_VCHUNK 24   // 64 voices x 24 samples x f64 = 12.8 KB tile: 8 voice blocks + 4 tremolo blocks fit the 160 KB LDS of a CU
 __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, double* __restrict__ vrec, const OwEngineArgs* __restrict__ args,
                                               double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int L, int Lcap, int e0) {
     __shared__ double tile[64 * (OW_VCHUNK + 1)];
@@ -178,6 +178,8 @@ struct VoiceSteady {
     double s[7], c[7], env[7], drift[7], cos_inc[7], sin_inc[7], phase_inc[7], amp[7], decay[7];
     double ci[7], si[7];   // jitter-corrected rotation (reed.rs:281-283): depends on drift only, which changes every 16 samples
     double q, ds, gain;
+    double beta, revert, diffusion;   // K->pickup_beta / jitter_revert / jitter_diffusion, read once: a K-> load inside the sample loop is
+                                      // re-issued every sample (the noinline saturate call may write memory) and stalls the wave on lgkmcnt
     uint64_t sample;
     uint32_t jitter_state;
 
@@ -193,13 +195,15 @@ struct VoiceSteady {
         }
     }
 
-    OW_DEV double step(const OwConsts* __restrict__ K) {
+    // One reed sample is split in three so the kernel can software-pipeline it: the pickup division chain of sample n-1
+    // (pickup(), ~25 dependent f64 ops) is emitted in the same basic block as the 7 independent rotations of sample n
+    // (advance()), with the rare branches (jitter / renormalise / saturate) at the block edges.  Same arithmetic, same order
+    // per value as VoiceRegs::step<true>; only the instruction interleaving changes.
+    OW_DEV void jitter() {                                   // reed.rs:262-283, every 16th sample of this voice
 #ifndef OW_STRICT_FP
 #pragma clang fp contract(fast)
 #endif
-        const uint32_t lo = (uint32_t)sample;
-        if ((lo & 15u) == 0u) {
-            const double revert = K->jitter_revert, diffusion = K->jitter_diffusion;
+        if (((uint32_t)sample & 15u) == 0u) {
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
                 jitter_state = lcg(jitter_state);
@@ -209,6 +213,12 @@ struct VoiceSteady {
             }
             update_rotation();
         }
+    }
+    OW_DEV double advance() {                                // modal sum + rotation; returns the pickup displacement y
+#ifndef OW_STRICT_FP
+#pragma clang fp contract(fast)
+#endif
+        const uint32_t lo = (uint32_t)sample;
         double sum = 0.0;
 #pragma unroll
         for (int m = 0; m < 7; ++m) {
@@ -219,6 +229,9 @@ struct VoiceSteady {
             c[m] = c_new;
             env[m] *= decay[m];
         }
+        const double x = 0.0 + sum;
+        double y = x * ds;
+        const double ay = fabs(y);
         if ((lo & 1023u) == 0u && sample > 0ull) {
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
@@ -229,13 +242,16 @@ struct VoiceSteady {
             }
         }
         sample += 1ull;
-        const double x = 0.0 + sum;
-        double y = x * ds;
-        const double ay = fabs(y);
         if (!(ay < 0.94)) y = pickup_saturate_hi(y, ay);
+        return y;
+    }
+    OW_DEV double pickup(double y) {                         // pickup.rs 1/(1-y) bilinear HPF + voice gain
+#ifndef OW_STRICT_FP
+#pragma clang fp contract(fast)
+#endif
         const double omy = 1.0 - y;
-        const double alpha = K->pickup_beta * omy;
-        const double q_next = (q * (1.0 - alpha) + 2.0 * K->pickup_beta) / (1.0 + alpha);
+        const double alpha = beta * omy;
+        const double q_next = (q * (1.0 - alpha) + 2.0 * beta) / (1.0 + alpha);
         q = q_next;
         return ((q_next * omy - 1.0) * 1.8375) * gain;
     }
@@ -261,6 +277,7 @@ __global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict_
     if (__any(transient)) return;          // eout[e].steady_done stays 0: k_voice renders this engine
     double* row = sum + (size_t)e * Lcap;  // pass 0 rows
     VoiceSteady v;
+    v.beta = K->pickup_beta; v.revert = K->jitter_revert; v.diffusion = K->jitter_diffusion;
     uint32_t noise_rng = 0;
     if (active) {
 #pragma unroll
@@ -276,9 +293,22 @@ __global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict_
         v.update_rotation();
     }
     bool bad_sum = false;
+    if (!active) {   // rows of the tile belong to one lane each: idle slots contribute +0.0 to the ordered sum
+        for (int n = 0; n < OW_VCHUNK; ++n) tile[lane * (OW_VCHUNK + 1) + n] = 0.0;
+    }
     for (int base = 0; base < L; base += OW_VCHUNK) {
         const int cn = min(OW_VCHUNK, L - base);
-        for (int n = 0; n < cn; ++n) tile[lane * (OW_VCHUNK + 1) + n] = active ? v.step(K) : 0.0;
+        if (active) {
+            double* trow = tile + lane * (OW_VCHUNK + 1);
+            v.jitter();
+            double y = v.advance();
+            for (int n = 1; n < cn; ++n) {
+                v.jitter();
+                trow[n - 1] = v.pickup(y);
+                y = v.advance();
+            }
+            trow[cn - 1] = v.pickup(y);
+        }
         __syncthreads();
         if (lane < cn) {  // sum the 64 slots in slot order (engine.rs:469-479)
             double acc = 0.0;
@@ -325,19 +355,22 @@ OW_DEV void smoother_load(Smoother& s, const double* __restrict__ cs, int I, int
 OW_DEV void smoother_store(const Smoother& s, double* __restrict__ cs, int I, int e, int f) {
     CSF(f) = s.cur; CSF(f + 1) = s.target; CSF(f + 2) = s.step; CSF(f + 3) = bitsd((uint64_t)s.rem);
 }
-OW_DEV void trem_load(TremState& t, const double* __restrict__ cs, int I, int e) {
+OW_DEV void trem_load(TremState& t, TremPark* __restrict__ P, const double* __restrict__ cs, int I, int e) {
+    const int ln = threadIdx.x & 63;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) t.v[i] = CSF(CS_T_V + i);
+    for (int i = 0; i < 7; ++i) P->v[i][ln] = CSF(CS_T_V + i);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { t.i_prev[i] = CSF(CS_T_I + i); t.i_pp[i] = CSF(CS_T_IP + i); }
+    for (int i = 0; i < 4; ++i) { P->ip[i][ln] = CSF(CS_T_I + i); P->ipp[i][ln] = CSF(CS_T_IP + i); }
     t.env = CSF(CS_T_ENV); t.r_ldr = CSF(CS_T_RLDR);
     t.be_fallbacks = 0;
 }
-OW_DEV void trem_store(const TremState& t, double* __restrict__ cs, int I, int e) {
+OW_DEV void trem_store(const TremState& t, TremPark* __restrict__ P0, double* __restrict__ cs, int I, int e) {
+    const int ln = threadIdx.x & 63;
+    const TremPark* P = park_opaque(P0);
 #pragma unroll
-    for (int i = 0; i < 7; ++i) CSF(CS_T_V + i) = t.v[i];
+    for (int i = 0; i < 7; ++i) CSF(CS_T_V + i) = P->v[i][ln];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { CSF(CS_T_I + i) = t.i_prev[i]; CSF(CS_T_IP + i) = t.i_pp[i]; }
+    for (int i = 0; i < 4; ++i) { CSF(CS_T_I + i) = P->ip[i][ln]; CSF(CS_T_IP + i) = P->ipp[i][ln]; }
     CSF(CS_T_ENV) = t.env; CSF(CS_T_RLDR) = t.r_ldr;
     if (t.be_fallbacks) CSF(CS_T_BE) = bitsd(dbits(CSF(CS_T_BE)) + (uint64_t)t.be_fallbacks);
 }
@@ -419,18 +452,19 @@ __global__ __launch_bounds__(64) void k_chain_init(const OwConsts* __restrict__ 
 // gen_tremolo.rs:2071-2075 when K holds the 48 kHz codegen matrices).
 __global__ __launch_bounds__(64) void k_trem_settle(const OwConsts* __restrict__ K, double* __restrict__ cs, int I, int e0, int ne, long long n) {
     __shared__ TremMats M;
+    __shared__ TremPark P;   // oscillator state of this wavefront (LDS-resident, see ow_chain_dev.h)
     trem_mats_load(&M, K, threadIdx.x, blockDim.x);
     __syncthreads();
     const int e = e0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= e0 + ne) return;
     TremState t;
-    trem_load(t, cs, I, e);
+    trem_load(t, &P, cs, I, e);
     for (long long i = 0; i < n; ++i) {
         int z = 0;
         asm volatile("" : "+v"(z));        // opaque zero: keeps the LDS reads inside the loop (no hoist into 200 live VGPRs)
-        trem_osc_step(t, K, &M + z);
+        trem_osc_step(t, &P, K, &M + z);
     }
-    trem_store(t, cs, I, e);
+    trem_store(t, &P, cs, I, e);
 }
 
 // copy the chain state of engine `src` to engines [e0, e0+ne) (identical by determinism at pool creation)
@@ -445,18 +479,19 @@ __global__ void k_chain_replicate(double* __restrict__ cs, int I, int src, int e
 __global__ __launch_bounds__(64) void k_tremolo(const OwConsts* __restrict__ K, double* __restrict__ cs, double* __restrict__ rbuf, int I, int n_os,
                                                 int e0, int ne) {
     __shared__ TremMats M;
+    __shared__ TremPark P;   // oscillator state of this wavefront (LDS-resident, see ow_chain_dev.h)
     trem_mats_load(&M, K, threadIdx.x, 64);
     __syncthreads();
     const int e = e0 + blockIdx.x * 64 + threadIdx.x;
     if (e >= e0 + ne) return;
     TremState t;
-    trem_load(t, cs, I, e);
+    trem_load(t, &P, cs, I, e);
     for (int i = 0; i < n_os; ++i) {
         int z = 0;
         asm volatile("" : "+v"(z));    // opaque zero: keeps the LDS reads inside the loop
-        rbuf[(size_t)i * I + e] = trem_cell_r(t, K, &M + z);
+        rbuf[(size_t)i * I + e] = trem_cell_r(t, &P, K, &M + z);
     }
-    trem_store(t, cs, I, e);
+    trem_store(t, &P, cs, I, e);
 }
 
 // ------------------------------------------------------------------ preamp stream
@@ -492,21 +527,42 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
         }
     }
     uint32_t nan_resets = 0;
+    // per-lane staging flags of engine row (lane & 31): bit0 = slot pass present, bit1 = steal pass present; 0 when the row is
+    // past the range or its block is non-finite (engine.rs:499-501 zeroes it).  Broadcast per row with v_readlane below, so the
+    // staging loop has no scalar loads and no branches and the row loads of a group are all in flight together.
+    int rowflag = 0;
+    {
+        const int er = eb + el;
+        if (er < e0 + ne && !eout[er].sum_nonfinite) rowflag = (args[er].main_mask ? 1 : 0) | (args[er].steal_mask ? 2 : 0);
+    }
+    const int e_last = e0 + ne - 1;
+    // R[n] is read one host sample ahead (registers), so its global-load latency is hidden behind the previous sample's solve
+    double rn[2];
+    rn[0] = rbuf[(size_t)0 * I + ec];
+    rn[1] = osr == 2 ? rbuf[(size_t)1 * I + ec] : 0.0;
     for (int base = 0; base < L; base += OW_PCHUNK) {
         const int cn = min(OW_PCHUNK, L - base);
         // stage 32 engine rows x 64 samples of the voice sum (slot pass + steal pass) through LDS
+        const int col = base + min(lane, cn - 1);
+#pragma unroll 8
         for (int r = 0; r < 32; ++r) {
-            const int er = eb + r;
-            double x = 0.0;
-            if (er < e0 + ne && lane < cn && !eout[er].sum_nonfinite) {   // engine.rs:499-501: a non-finite block is zeroed
-                if (args[er].main_mask) x = sum[((size_t)0 * I + er) * Lcap + base + lane];
-                if (args[er].steal_mask) x += sum[((size_t)1 * I + er) * Lcap + base + lane];
-            }
+            const int er = min(eb + r, e_last);
+            const int fl = __builtin_amdgcn_readlane(rowflag, r);
+            const double a = sum[((size_t)0 * I + er) * Lcap + col];
+            const double b = sum[((size_t)1 * I + er) * Lcap + col];
+            double x = (fl & 1) ? a : 0.0;
+            x = (fl & 2) ? x + b : x;
             tile[r * (OW_PCHUNK + 1) + lane] = x;
         }
         __syncthreads();
         for (int n = 0; n < cn; ++n) {
             const double x = tile[el * (OW_PCHUNK + 1) + n];
+            const double rc[2] = {rn[0], rn[1]};
+            {
+                const size_t nx = (size_t)min(base + n + 1, L - 1) * osr;
+                rn[0] = rbuf[nx * I + ec];
+                if (osr == 2) rn[1] = rbuf[(nx + 1) * I + ec];
+            }
             const double depth = clampd(sd.next(), 0.0, 1.0);   // engine.rs:533-534, tremolo.rs:117-119
             double in[2];
             if (osr == 2) {  // Oversampler::upsample_2x (oversampler.rs:108-121); shadow input is 0.0 (dk_preamp_legacy.rs:599)
@@ -520,7 +576,7 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
             }
             for (int j = 0; j < osr; ++j) {
                 const size_t idx = (size_t)((base + n) * osr + j);
-                const double r_new = fmax(trem_shunt(depth, rbuf[idx * I + ec]), 1000.0);   // tremolo.rs:152-167; set_ldr_resistance, :620-626
+                const double r_new = fmax(trem_shunt(depth, rc[j]), 1000.0);   // tremolo.rs:152-167; set_ldr_resistance, :620-626
                 if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = 1.0 / r_new; }
                 const double o = dk_step(st, in[j], g_ldr, g_prev, K);
                 g_prev = g_ldr;                                                   // :604
@@ -583,20 +639,29 @@ __global__ __launch_bounds__(64) void k_post(const OwConsts* __restrict__ K, dou
     if (args[e].set_flags & 4u) sv.retarget(args[e].vol_target, K->ramp_samples);
     bool nan_fired = false;
 
+    // the preamp stream is read one host sample ahead (registers): hides the global-load latency behind the previous sample
+    double pn[2];
+    pn[0] = pre[(size_t)0 * I + e];
+    pn[1] = osr == 2 ? pre[(size_t)1 * I + e] : 0.0;
     for (int base = 0; base < L; base += OW_OCHUNK) {
         const int cn = min(OW_OCHUNK, L - base);
         for (int n = 0; n < cn; ++n) {
+            const double pc0 = pn[0], pc1 = pn[1];
+            {
+                const size_t nx = (size_t)min(base + n + 1, L - 1) * osr;
+                pn[0] = pre[nx * I + e];
+                if (osr == 2) pn[1] = pre[(nx + 1) * I + e];
+            }
             double o;
             if (osr == 2) {  // engine.rs:536-553
-                const size_t idx = (size_t)(base + n) * 2;
-                const double y0 = power_amp(pre[idx * I + e] * 0.25);
-                const double y1 = power_amp(pre[(idx + 1) * I + e] * 0.25);
+                const double y0 = power_amp(pc0 * 0.25);
+                const double y1 = power_amp(pc1 * 0.25);
                 const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, y0);
                 const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, y1);
                 o = (a + dd) * 0.5;
                 dd = b;
             } else {
-                o = power_amp(pre[(size_t)(base + n) * I + e] * 0.25);
+                o = power_amp(pc0 * 0.25);
             }
             speaker_set_character(sp, ss.next(), sr);                           // engine.rs:437-438
             const double shaped = speaker_process(sp, o, K->spk_thermal_alpha);

@@ -226,6 +226,51 @@ def test_config2_all_keys_restrike_against_oracle(hiplib, oracle):
     g.close()
 
 
+def test_pool_midi_threaded_paths_agree(hiplib):
+    """ow_pool_midi applies large event lists on several host threads: a list grouped by engine (sliced at engine
+    boundaries), the same events interleaved across engines (every thread filters the list), and per-engine calls must
+    leave the pool in the same state -- per-engine event order is all that matters."""
+    import openwurli_amd as ow
+    from openwurli_amd import binding
+    n_eng, sr = 160, 48000.0
+    rng = np.random.default_rng(11)
+    per = 40
+    ev = np.zeros((n_eng, per), dtype=np.dtype(binding.MIDI_DTYPE))
+    ev["engine"] = np.arange(n_eng, dtype=np.uint32)[:, None]
+    ev["note"] = rng.integers(33, 97, size=(n_eng, per))
+    ev["type"] = rng.choice([0, 0, 0, 1, 2], size=(n_eng, per))
+    ev["value"] = rng.uniform(0.2, 1.0, size=(n_eng, per)).astype(np.float32)
+    grouped = ev.reshape(-1)
+    interleaved = np.ascontiguousarray(ev.T).reshape(-1)      # engine index cycles: ungrouped, same per-engine order
+    assert grouped.size >= 4096
+
+    def run(mode):
+        p = ow.EnginePool(sr, n_eng)
+        if mode == "grouped":
+            p.midi(grouped)
+        elif mode == "interleaved":
+            p.midi(interleaved)
+        else:
+            for k in range(n_eng):
+                for x in ev[k]:
+                    if x["type"] == 0:
+                        p[k].note_on(int(x["note"]), float(x["value"]))
+                    elif x["type"] == 1:
+                        p[k].note_off(int(x["note"]))
+                    else:
+                        p[k].set_sustain(bool(x["value"] >= 0.5))
+        out = np.concatenate([p.render(256) for _ in range(3)], axis=1)
+        counts = [p[k].active_voice_count() for k in range(n_eng)]
+        p.close()
+        return out, counts
+    a, ca = run("grouped")
+    b, cb = run("interleaved")
+    c, cc = run("calls")
+    assert ca == cb == cc
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert np.max(np.abs(a)) > 1e-3
+
+
 # ------------------------------------------------------------------ size-independent properties at full size
 def test_properties_full_size(hiplib):
     """64-voice instances at the bench size: determinism (two pools, same script -> bit-identical), volume linearity
