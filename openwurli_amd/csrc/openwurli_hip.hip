@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <emmintrin.h>
 #include <string>
 #include <thread>
 #include <vector>
@@ -33,9 +34,8 @@ void set_err(const std::string& s) { g_err = s; }
         if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
-struct Slot {  // VoiceSlot, engine.rs:39-62 (the Voice objects themselves live in HBM)
-    int state = OW_VOICE_FREE;
-    uint8_t midi = 0;
+struct Slot {  // VoiceSlot, engine.rs:39-62 (the Voice objects themselves live in HBM); state and note live in ow_engine's
+               // st_mask[] / midi_of[] so the per-event searches are mask operations, not 64-slot walks
     uint64_t age = 0;
     bool has_voice = false, has_steal = false;
     uint32_t steal_fade = 0, steal_fade_len = 0;
@@ -60,6 +60,28 @@ struct ow_engine {
     size_t index = 0;
     bool owns_pool = false;
     Slot slots[OW_MAX_VOICES];
+    // slot state as four disjoint bitmasks indexed by OW_VOICE_* (exactly one bit set per slot) and the slot notes as 64 bytes:
+    // note_on / note_off / allocate_voice become ctz / SSE2 byte-compare instead of scans over 2 KB of slots
+    uint64_t st_mask[4] = {~0ull, 0, 0, 0};
+    alignas(16) uint8_t midi_of[OW_MAX_VOICES] = {0};
+    int state_of(int s) const {
+        const uint64_t b = 1ull << s;
+        return (st_mask[1] & b) ? 1 : (st_mask[2] & b) ? 2 : (st_mask[3] & b) ? 3 : 0;
+    }
+    void set_state(int s, int st) {
+        const uint64_t b = 1ull << s;
+        st_mask[0] &= ~b; st_mask[1] &= ~b; st_mask[2] &= ~b; st_mask[3] &= ~b;
+        st_mask[st] |= b;
+    }
+    uint64_t note_match(uint8_t note) const {   // bit s set <=> midi_of[s] == note
+        const __m128i n = _mm_set1_epi8((char)note);
+        uint64_t m = 0;
+        for (int k = 0; k < 4; ++k) {
+            const __m128i v = _mm_load_si128((const __m128i*)(midi_of + 16 * k));
+            m |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(v, n)) << (16 * k);
+        }
+        return m;
+    }
     uint64_t age_counter = 0;
     bool sustain_held = false, mlp_enabled = true;
     HostSmoother volume{0.5}, depth{0.5}, spk{0.0};
@@ -72,7 +94,7 @@ struct ow_engine {
     void sync_masks(int s) {
         const Slot& sl = slots[s];
         const uint64_t b = 1ull << s;
-        if (sl.has_voice && sl.state != OW_VOICE_FREE) main_mask |= b; else main_mask &= ~b;
+        if (sl.has_voice && !(st_mask[OW_VOICE_FREE] & b)) main_mask |= b; else main_mask &= ~b;
         if (sl.has_steal) steal_mask |= b; else steal_mask &= ~b;
         if (dirty) *dirty = 1;
     }
@@ -221,6 +243,23 @@ void upload_consts(ow_pool* p, double sr, int preamp_kind) {
     HIP_OK(hipStreamSynchronize(p->stream));
 }
 
+// Host threads worth starting: the CPU count capped by the cgroup CPU quota (cpu.max "quota period").  A container limited
+// to 16 CPUs on a 256-thread host gets throttled for whole scheduler periods when 64 threads burst at once.
+static size_t effective_cpus() {
+    size_t n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long long period = 0;
+        if (std::fscanf(f, "%31s %lld", quota, &period) == 2 && period > 0 && std::strcmp(quota, "max") != 0) {
+            const long long q = std::atoll(quota);
+            if (q > 0) n = std::min<size_t>(n, (size_t)std::max<long long>(1, q / period));
+        }
+        std::fclose(f);
+    }
+    return n;
+}
+
 // One render of `len` samples for engines [e0, e0+ne).  with_voices=false skips the voice kernels
 // (warm-up of engines whose voices were just freed).
 void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
@@ -228,36 +267,61 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
     const int L = (int)len, Lcap = (int)p->Lcap;
     // ---- per-engine args + ops: only engines whose host state changed are touched (the rest keep their
     // uploaded args; a steady-state step of a large pool does no per-engine host work here)
-    size_t n_ops = 0;
-    bool any_dirty = false;
-    for (int k = 0; k < ne; ++k) {
-        if (!p->dirty[e0 + k]) continue;
-        any_dirty = true;
-        n_ops += p->engines[e0 + k]->ops.size();
-    }
-    ensure_ops_capacity(p, n_ops);
-    size_t op_pos = 0;
-    if (any_dirty || p->args_stale) {
-        for (int k = 0; k < ne; ++k) {
-            OwEngineArgs& a = p->h_args[e0 + k];
-            if (!p->dirty[e0 + k]) {
-                if (a.op_count || a.set_flags) { a.op_count = 0; a.set_flags = 0; }
-                continue;
-            }
-            ow_engine* en = p->engines[e0 + k];
-            // engine.rs:471-473: a Free slot renders nothing unless it still carries a steal voice
-            a.main_mask = en->main_mask; a.steal_mask = en->steal_mask;
-            a.op_begin = (uint32_t)op_pos;
-            a.op_count = (uint32_t)en->ops.size();
-            if (!en->ops.empty()) std::memcpy(p->h_ops + op_pos, en->ops.data(), sizeof(OwOp) * en->ops.size());
-            op_pos += en->ops.size();
-            en->ops.clear();
-            a.set_flags = 0;
-            if (en->depth.pending) { a.set_flags |= 1u; a.depth_target = en->depth.pending_value; en->depth.pending = false; }
-            if (en->spk.pending)   { a.set_flags |= 2u; a.spk_target = en->spk.pending_value;     en->spk.pending = false; }
-            if (en->volume.pending){ a.set_flags |= 4u; a.vol_target = en->volume.pending_value;  en->volume.pending = false; }
-            p->dirty[e0 + k] = 0;
+    // Large pools split the range over host threads: slice t counts its pending ops, a prefix sum places the slices in h_ops,
+    // then every slice packs its own engines (a 65536-engine re-strike moves ~8 M ops; one thread took ~100 ms for it).
+    size_t n_dirty = 0;
+    for (int k = 0; k < ne; ++k) n_dirty += p->dirty[e0 + k];     // dirty[] holds 0/1
+    size_t T = (n_dirty >= 4096) ? std::min<size_t>(effective_cpus(), 32) : 1;
+    const int per = (int)((ne + T - 1) / T);
+    std::vector<size_t> cnt(T + 1, 0);
+    std::vector<uint8_t> dirty_t(T, 0);
+    auto count_slice = [&](size_t t) {
+        size_t c = 0; uint8_t d = 0;
+        const int k1 = std::min(ne, (int)(t + 1) * per);
+        for (int k = (int)t * per; k < k1; ++k) {
+            if (!p->dirty[e0 + k]) continue;
+            d = 1;
+            c += p->engines[e0 + k]->ops.size();
         }
+        cnt[t + 1] = c; dirty_t[t] = d;
+    };
+    auto run_slices = [&](auto&& fn) {
+        if (T == 1) { fn((size_t)0); return; }
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < T; ++t) th.emplace_back([&fn, t] { fn(t); });
+        for (auto& x : th) x.join();
+    };
+    run_slices(count_slice);
+    bool any_dirty = false;
+    for (size_t t = 0; t < T; ++t) { any_dirty = any_dirty || dirty_t[t]; cnt[t + 1] += cnt[t]; }
+    const size_t n_ops = cnt[T];
+    ensure_ops_capacity(p, n_ops);
+    if (any_dirty || p->args_stale) {
+        auto pack_slice = [&](size_t t) {
+            size_t op_pos = cnt[t];
+            const int k1 = std::min(ne, (int)(t + 1) * per);
+            for (int k = (int)t * per; k < k1; ++k) {
+                OwEngineArgs& a = p->h_args[e0 + k];
+                if (!p->dirty[e0 + k]) {
+                    if (a.op_count || a.set_flags) { a.op_count = 0; a.set_flags = 0; }
+                    continue;
+                }
+                ow_engine* en = p->engines[e0 + k];
+                // engine.rs:471-473: a Free slot renders nothing unless it still carries a steal voice
+                a.main_mask = en->main_mask; a.steal_mask = en->steal_mask;
+                a.op_begin = (uint32_t)op_pos;
+                a.op_count = (uint32_t)en->ops.size();
+                if (!en->ops.empty()) std::memcpy(p->h_ops + op_pos, en->ops.data(), sizeof(OwOp) * en->ops.size());
+                op_pos += en->ops.size();
+                en->ops.clear();
+                a.set_flags = 0;
+                if (en->depth.pending) { a.set_flags |= 1u; a.depth_target = en->depth.pending_value; en->depth.pending = false; }
+                if (en->spk.pending)   { a.set_flags |= 2u; a.spk_target = en->spk.pending_value;     en->spk.pending = false; }
+                if (en->volume.pending){ a.set_flags |= 4u; a.vol_target = en->volume.pending_value;  en->volume.pending = false; }
+                p->dirty[e0 + k] = 0;
+            }
+        };
+        run_slices(pack_slice);
     }
     bool any_main = false, any_steal = false;
     for (int k = 0; k < ne; ++k) { any_main |= p->h_args[e0 + k].main_mask != 0; any_steal |= p->h_args[e0 + k].steal_mask != 0; }
@@ -335,7 +399,7 @@ void engine_post_render(ow_engine* en, uint32_t l32, const OwEngineOut& o) {
         en->nan_guard_fires += 1;
         for (int s = 0; s < OW_MAX_VOICES; ++s) {
             Slot& sl = en->slots[s];
-            if ((o.bad_main >> s) & 1ull) { sl.state = OW_VOICE_FREE; sl.has_voice = false; }
+            if ((o.bad_main >> s) & 1ull) { en->set_state(s, OW_VOICE_FREE); sl.has_voice = false; }
             if ((o.bad_steal >> s) & 1ull) { sl.has_steal = false; sl.steal_fade = 0; }
             en->sync_masks(s);
         }
@@ -344,7 +408,7 @@ void engine_post_render(ow_engine* en, uint32_t l32, const OwEngineOut& o) {
     for (uint64_t m = o.silent_mask & en->main_mask; m; m &= m - 1) {
         const int s = __builtin_ctzll(m);
         Slot& sl = en->slots[s];
-        if (sl.state != OW_VOICE_FREE && sl.has_voice) { sl.state = OW_VOICE_FREE; sl.has_voice = false; en->sync_masks(s); }
+        if (en->state_of(s) != OW_VOICE_FREE && sl.has_voice) { en->set_state(s, OW_VOICE_FREE); sl.has_voice = false; en->sync_masks(s); }
     }
 }
 
@@ -383,7 +447,8 @@ void warm_up_range(ow_pool* p, int e0, int ne) {
 }
 
 void engine_host_reset(ow_engine* en) {  // host half of WurliEngine::reset (engine.rs:231-244)
-    for (auto& s : en->slots) { s.state = OW_VOICE_FREE; s.has_voice = false; s.has_steal = false; s.steal_fade = 0; }
+    for (auto& s : en->slots) { s.has_voice = false; s.has_steal = false; s.steal_fade = 0; }
+    en->st_mask[0] = ~0ull; en->st_mask[1] = en->st_mask[2] = en->st_mask[3] = 0;
     en->main_mask = 0; en->steal_mask = 0;
     en->touch();
     en->age_counter = 0;
@@ -394,18 +459,16 @@ void engine_host_reset(ow_engine* en) {  // host half of WurliEngine::reset (eng
 }
 
 int allocate_voice(const ow_engine* en) {  // engine.rs:569-590
+    // first free slot, else the oldest voice of the lowest-priority non-empty class (releasing < sustained < held); ages are
+    // unique, so this is the slot the reference's min_by_key over (class, age) returns
+    if (en->st_mask[OW_VOICE_FREE]) return __builtin_ctzll(en->st_mask[OW_VOICE_FREE]);
+    const uint64_t cls = en->st_mask[OW_VOICE_RELEASING] ? en->st_mask[OW_VOICE_RELEASING]
+                       : en->st_mask[OW_VOICE_SUSTAINED] ? en->st_mask[OW_VOICE_SUSTAINED] : en->st_mask[OW_VOICE_HELD];
     int best_idx = 0;
     uint64_t best = ~0ull;
-    for (int i = 0; i < OW_MAX_VOICES; ++i) {
-        const Slot& s = en->slots[i];
-        uint64_t pr;
-        switch (s.state) {
-            case OW_VOICE_FREE: return i;
-            case OW_VOICE_RELEASING: pr = s.age; break;
-            case OW_VOICE_SUSTAINED: pr = s.age + (~0ull) / 4; break;
-            default: pr = s.age + (~0ull) / 2; break;
-        }
-        if (pr < best) { best = pr; best_idx = i; }
+    for (uint64_t m = cls; m; m &= m - 1) {
+        const int i = __builtin_ctzll(m);
+        if (en->slots[i].age < best) { best = en->slots[i].age; best_idx = i; }
     }
     return best_idx;
 }
@@ -642,16 +705,16 @@ void ow_engine_ensure_buffer_capacity(ow_engine* e, size_t n) { if (e) ow_pool_e
 void ow_engine_note_on(ow_engine* e, uint8_t note_in, float velocity) {  // engine.rs:299-338
     if (!e) return;
     const uint8_t note = std::min<uint8_t>(std::max<uint8_t>(note_in, OW_MIDI_LO), OW_MIDI_HI);
-    for (int i = 0; i < OW_MAX_VOICES; ++i) {
-        Slot& s = e->slots[i];
-        if (s.state == OW_VOICE_SUSTAINED && s.midi == note) {
-            s.state = OW_VOICE_RELEASING;
-            if (s.has_voice) push_op(e, OP_DAMPER, i, note, false, 0, 0.0);
+    if (e->st_mask[OW_VOICE_SUSTAINED]) {
+        for (uint64_t m = e->st_mask[OW_VOICE_SUSTAINED] & e->note_match(note); m; m &= m - 1) {
+            const int i = __builtin_ctzll(m);
+            e->set_state(i, OW_VOICE_RELEASING);
+            if (e->slots[i].has_voice) push_op(e, OP_DAMPER, i, note, false, 0, 0.0);
         }
     }
     const int idx = allocate_voice(e);
     Slot& slot = e->slots[idx];
-    if (slot.state != OW_VOICE_FREE) {
+    if (e->state_of(idx) != OW_VOICE_FREE) {
         const uint32_t fade = owhip::sat_u32(e->sr * 0.005);
         if (slot.has_voice) {
             push_op(e, OP_MOVE_STEAL, idx, note, false, fade, 0.0);
@@ -667,8 +730,8 @@ void ow_engine_note_on(ow_engine* e, uint8_t note_in, float velocity) {  // engi
     const uint32_t seed = (uint32_t)note * 2654435761u + (uint32_t)e->age_counter;
     push_op(e, OP_NOTE_ON, idx, note, e->mlp_enabled, seed, (double)velocity);
     slot.has_voice = true;
-    slot.state = OW_VOICE_HELD;
-    slot.midi = note;
+    e->set_state(idx, OW_VOICE_HELD);
+    e->midi_of[idx] = note;
     slot.age = e->age_counter;
     e->sync_masks(idx);
 }
@@ -677,14 +740,15 @@ void ow_engine_note_off(ow_engine* e, uint8_t note_in) {  // engine.rs:340-359
     if (!e) return;
     const uint8_t note = std::min<uint8_t>(std::max<uint8_t>(note_in, OW_MIDI_LO), OW_MIDI_HI);
     int oldest = -1;
-    for (int i = 0; i < OW_MAX_VOICES; ++i) {
-        const Slot& s = e->slots[i];
-        if (s.state == OW_VOICE_HELD && s.midi == note && (oldest < 0 || s.age < e->slots[oldest].age)) oldest = i;
+    if (!e->st_mask[OW_VOICE_HELD]) return;
+    for (uint64_t m = e->st_mask[OW_VOICE_HELD] & e->note_match(note); m; m &= m - 1) {
+        const int i = __builtin_ctzll(m);
+        if (oldest < 0 || e->slots[i].age < e->slots[oldest].age) oldest = i;
     }
     if (oldest < 0) return;
-    if (e->sustain_held) e->slots[oldest].state = OW_VOICE_SUSTAINED;
+    if (e->sustain_held) e->set_state(oldest, OW_VOICE_SUSTAINED);
     else {
-        e->slots[oldest].state = OW_VOICE_RELEASING;
+        e->set_state(oldest, OW_VOICE_RELEASING);
         if (e->slots[oldest].has_voice) push_op(e, OP_DAMPER, oldest, note, false, 0, 0.0);
     }
 }
@@ -692,12 +756,10 @@ void ow_engine_note_off(ow_engine* e, uint8_t note_in) {  // engine.rs:340-359
 void ow_engine_set_sustain(ow_engine* e, int held) {  // engine.rs:361-374
     if (!e) return;
     if (e->sustain_held && !held) {
-        for (int i = 0; i < OW_MAX_VOICES; ++i) {
-            Slot& s = e->slots[i];
-            if (s.state == OW_VOICE_SUSTAINED) {
-                s.state = OW_VOICE_RELEASING;
-                if (s.has_voice) push_op(e, OP_DAMPER, i, s.midi, false, 0, 0.0);
-            }
+        for (uint64_t m = e->st_mask[OW_VOICE_SUSTAINED]; m; m &= m - 1) {   // ascending slot order, as the reference iterates
+            const int i = __builtin_ctzll(m);
+            e->set_state(i, OW_VOICE_RELEASING);
+            if (e->slots[i].has_voice) push_op(e, OP_DAMPER, i, e->midi_of[i], false, 0, 0.0);
         }
     }
     e->sustain_held = held != 0;
@@ -721,13 +783,11 @@ void ow_engine_render(ow_engine* e, float* out, size_t len) {
 void ow_engine_get_diag(const ow_engine* e, ow_diag* d) {
     if (!e || !d) return;
     std::memset(d, 0, sizeof *d);
-    for (const Slot& s : e->slots) {
-        if (s.state != OW_VOICE_FREE) d->active_voices++;
-        if (s.state == OW_VOICE_HELD) d->held_voices++;
-        if (s.state == OW_VOICE_SUSTAINED) d->sustained_voices++;
-        if (s.state == OW_VOICE_RELEASING) d->releasing_voices++;
-        if (s.has_steal) d->steal_voices++;
-    }
+    d->active_voices = (uint32_t)__builtin_popcountll(~e->st_mask[OW_VOICE_FREE]);
+    d->held_voices = (uint32_t)__builtin_popcountll(e->st_mask[OW_VOICE_HELD]);
+    d->sustained_voices = (uint32_t)__builtin_popcountll(e->st_mask[OW_VOICE_SUSTAINED]);
+    d->releasing_voices = (uint32_t)__builtin_popcountll(e->st_mask[OW_VOICE_RELEASING]);
+    for (const Slot& s : e->slots) if (s.has_steal) d->steal_voices++;
     d->sustain_held = e->sustain_held ? 1 : 0;
     d->nan_guard_fires = e->nan_guard_fires;
     d->output_nan_resets = e->output_nan_resets;
@@ -745,29 +805,12 @@ void ow_engine_get_diag(const ow_engine* e, ow_diag* d) {
         }
     }
 }
-int ow_engine_slot_state(const ow_engine* e, int slot) { return (e && slot >= 0 && slot < OW_MAX_VOICES) ? e->slots[slot].state : -1; }
-int ow_engine_slot_note(const ow_engine* e, int slot) { return (e && slot >= 0 && slot < OW_MAX_VOICES) ? e->slots[slot].midi : -1; }
+int ow_engine_slot_state(const ow_engine* e, int slot) { return (e && slot >= 0 && slot < OW_MAX_VOICES) ? e->state_of(slot) : -1; }
+int ow_engine_slot_note(const ow_engine* e, int slot) { return (e && slot >= 0 && slot < OW_MAX_VOICES) ? e->midi_of[slot] : -1; }
 int ow_engine_has_steal_voice_for(const ow_engine* e, uint8_t note) {
     if (!e) return 0;
-    for (const Slot& s : e->slots) if (s.midi == note && s.has_steal) return 1;
+    for (int i = 0; i < OW_MAX_VOICES; ++i) if (e->midi_of[i] == note && e->slots[i].has_steal) return 1;
     return 0;
-}
-
-// Host threads worth starting: the CPU count capped by the cgroup CPU quota (cpu.max "quota period").  A container limited
-// to 16 CPUs on a 256-thread host gets throttled for whole scheduler periods when 64 threads burst at once.
-static size_t effective_cpus() {
-    size_t n = std::thread::hardware_concurrency();
-    if (n == 0) n = 1;
-    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        char quota[32] = {0};
-        long long period = 0;
-        if (std::fscanf(f, "%31s %lld", quota, &period) == 2 && period > 0 && std::strcmp(quota, "max") != 0) {
-            const long long q = std::atoll(quota);
-            if (q > 0) n = std::min<size_t>(n, (size_t)std::max<long long>(1, q / period));
-        }
-        std::fclose(f);
-    }
-    return n;
 }
 
 static void midi_apply_one(ow_pool* p, const ow_midi_event& ev) {
@@ -785,6 +828,7 @@ void ow_pool_midi(ow_pool* p, const ow_midi_event* ev, size_t n) {
     // Engines are independent state machines: large event lists are applied by several host threads, each owning a
     // contiguous range of engines and walking the list in array order (per-engine order is what matters).
     size_t T = std::min<size_t>(effective_cpus(), 64);
+    if (const char* env = std::getenv("OW_MIDI_THREADS")) { const long v = std::atol(env); if (v >= 1 && v <= 256) T = (size_t)v; }
     if (n < 4096 || p->I < 2 * T) T = 1;
     if (T == 1) {
         for (size_t i = 0; i < n; ++i) if (ev[i].engine < p->I) midi_apply_one(p, ev[i]);
@@ -885,7 +929,7 @@ long long ow_render_note(uint8_t midi, double velocity, double dur_s, double sam
         ow_engine* e = p->engines[0];
         // Voice::render_note: seed = midi * 2654435761, MLP off, no note clamping beyond the table range (voice.rs:206-207)
         const uint8_t note = std::min<uint8_t>(std::max<uint8_t>(midi, OW_MIDI_LO), OW_MIDI_HI);
-        e->slots[0].has_voice = true; e->slots[0].state = OW_VOICE_HELD; e->slots[0].midi = note;
+        e->slots[0].has_voice = true; e->set_state(0, OW_VOICE_HELD); e->midi_of[0] = note;
         e->sync_masks(0);
         push_op(e, OP_NOTE_ON, 0, note, false, (uint32_t)midi * 2654435761u, velocity);
         double x = dur_s * sample_rate;

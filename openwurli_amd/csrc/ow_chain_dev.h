@@ -30,7 +30,7 @@ OW_DEV double fast_exp(double x0) {  // gen_tremolo.rs:1140-1166 (pure arithmeti
 
 // The logarithmic branch only fires on large forward steps above vcrit (start-up transients); out of line so the
 // two inlined log() bodies per call site do not bloat the Newton loop.
-__device__ __noinline__ double pnjlim_limited(double vnew, double vold, double vt, double vcrit) {
+__device__ __noinline__ __attribute__((const)) double pnjlim_limited(double vnew, double vold, double vt, double vcrit) {
     if (vold >= 0.0) {
         const double arg = 1.0 + (vnew - vold) / vt;
         return arg > 0.0 ? vold + vt * log(arg) : vcrit;
@@ -455,7 +455,16 @@ OW_DEV void dk_ic_gm(double vbe, double& ic, double& gm) {  // :686-690
 // dk_step, dk_preamp_legacy.rs:447-554.  Node order BASE1,EMIT1,COLL1,EMIT2,EMIT2B,COLL2,OUT,FB.
 // (Staging the 114 wave-uniform constants in LDS instead of spilled SGPRs was measured slower: the ds_read latency is exposed
 // with two wavefronts per SIMD, the v_readlane of a spilled SGPR is not.)
-__device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_ldr_prev, const OwConsts* __restrict__ K) {
+// k_reload(): the same pointer behind an opaque scalar zero.  dk_step reads its 114 wave-uniform constants through four of
+// these, so each group is fetched by a few s_load_dwordx16 from the scalar cache where it is used, instead of all 228 SGPRs
+// being live across the sample loop, spilled to VGPR lanes and read back with ~290 v_readlane per sample.
+__device__ inline const OwConsts* k_reload(const OwConsts* K) {
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return K + z;
+}
+__device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_ldr_prev, const OwConsts* __restrict__ K0) {
+    const OwConsts* __restrict__ K = k_reload(K0);
     // rhs = A_neg v (dk_preamp_legacy.rs:466).  A_neg = 2C/T - G has 20 structural non-zeros (resistor/capacitor stamps,
     // :283-309); the reference multiplies the zeros too, which adds exact +-0.0 terms, so skipping them is bit-identical
     // for finite v (a non-finite v still propagates through its node's own diagonal entry).
@@ -480,13 +489,25 @@ __device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_
 #pragma unroll
     for (int i = 0; i < 8; ++i) rhs[i] += K->p_two_w[i];
     double vpb[8];
+    {
+        const OwConsts* __restrict__ Kb = k_reload(K0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        double sum = 0.0;
+        for (int i = 0; i < 4; ++i) {
+            double sum = 0.0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sum += K->p_s[i][j] * rhs[j];
-        vpb[i] = sum;
+            for (int j = 0; j < 8; ++j) sum += Kb->p_s[i][j] * rhs[j];
+            vpb[i] = sum;
+        }
+        const OwConsts* __restrict__ Kc = k_reload(K0);
+#pragma unroll
+        for (int i = 4; i < 8; ++i) {
+            double sum = 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += Kc->p_s[i][j] * rhs[j];
+            vpb[i] = sum;
+        }
     }
+    K = k_reload(K0);
     const double sm_k = g_ldr / (1.0 + K->p_s_fb_fb * g_ldr);
     const double sm_vpred = sm_k * vpb[7];
     double v_pred[8];
@@ -513,6 +534,7 @@ __device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_
         vn1 -= inv_det * (j00 * f1 - j10 * f0);
     }
     const double ic0 = dk_ic(vn0), ic1 = dk_ic(vn1);
+    K = k_reload(K0);
     const double dot = K->p_sfb_ni[0] * ic0 + K->p_sfb_ni[1] * ic1;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

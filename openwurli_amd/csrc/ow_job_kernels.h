@@ -28,6 +28,7 @@ __global__ __launch_bounds__(64) void k_job_voice(const OwConsts* __restrict__ K
     const int j = jb + lane;
     const bool active = j < n_jobs;
     double* rec = vrec + (size_t)blockIdx.x * OW_VREC_DOUBLES + lane;
+    const VoiceUniform U(K);
     VoiceRegs v;
     if (active) {
         const OwJobDev jd = jobs[j];
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(64) void k_job_voice(const OwConsts* __restrict__ K
     }
     for (long long base = 0; base < n; base += OW_VCHUNK) {
         const int cn = (int)((n - base) < OW_VCHUNK ? (n - base) : OW_VCHUNK);
-        for (int s = 0; s < cn; ++s) tile[lane * (OW_VCHUNK + 1) + s] = active ? v.step<false>(rec, K) : 0.0;
+        for (int s = 0; s < cn; ++s) tile[lane * (OW_VCHUNK + 1) + s] = active ? v.step<false>(rec, U) : 0.0;
         __syncthreads();
         // transposed, coalesced store: 2 job rows per pass (32 samples each)
         for (int r = (lane >> 5); r < 64; r += 2) {

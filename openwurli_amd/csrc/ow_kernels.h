@@ -111,6 +111,7 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
     double* rec = vrec + ((size_t)e * 2 + pass) * OW_VREC_DOUBLES + lane;
     double* row = sum + ((size_t)pass * I + e) * Lcap;
 
+    const VoiceUniform U(K);
     VoiceRegs v;
     uint32_t steal_fade = 0, steal_len = 1;
     if (active) {
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
         for (int n = 0; n < cn; ++n) {
             double o = 0.0;
             if (active) {
-                o = v.step<false>(rec, K);
+                o = v.step<false>(rec, U);
                 if (pass) {  // 5 ms linear crossfade, engine.rs:483-489
                     const uint32_t i = (uint32_t)(base + n);
                     const uint32_t remaining = steal_fade > i ? steal_fade - i : 0u;

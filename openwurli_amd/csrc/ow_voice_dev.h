@@ -338,20 +338,28 @@ __device__ inline void start_damper_lane(double* __restrict__ rec, const OwConst
 // Rare-phase transcendentals are kept out of line so their temporaries do not inflate the register
 // footprint of the steady-state loop (onset ramp: first ~1-2 periods; damper ramp: 8-50 ms after note-off;
 // attack noise fade-in: 16 samples; pickup saturation: only |y| >= 0.94).
-__device__ __noinline__ double onset_gain(double n, double onset_inc, double onset_exp) {  // reed.rs:251-264
+__device__ __noinline__ __attribute__((const)) double onset_gain(double n, double onset_inc, double onset_exp) {  // reed.rs:251-264
     const double cosine = 0.5 * (1.0 - cos(n * onset_inc));
     if (onset_exp <= 1.001) return cosine;
     if (onset_exp >= 1.999) return cosine * cosine;
     return pow(cosine, onset_exp);
 }
-__device__ __noinline__ double exp_neg(double x) { return exp(-x); }                         // reed.rs:238
-__device__ __noinline__ double noise_fade_env(double t) { return 0.5 * (1.0 - cos(3.14159265358979323846 * t)); }  // hammer.rs:165
-__device__ __noinline__ double pickup_saturate_hi(double y, double ay) {                      // pickup.rs:76-79
+__device__ __noinline__ __attribute__((const)) double exp_neg(double x) { return exp(-x); }                         // reed.rs:238
+__device__ __noinline__ __attribute__((const)) double noise_fade_env(double t) { return 0.5 * (1.0 - cos(3.14159265358979323846 * t)); }  // hammer.rs:165
+__device__ __noinline__ __attribute__((const)) double pickup_saturate_hi(double y, double ay) {                      // pickup.rs:76-79
     const double range = 0.98 - 0.94;
     return copysign(0.94 + range * tanh((ay - 0.94) / range), y);
 }
 
 // ------------------------------------------------------------------ per-sample voice state in registers
+// The four pool constants the per-sample voice step reads, fetched once per kernel: a K-> load inside the sample loop is re-issued
+// every sample (it cannot be hoisted past the out-of-line calls and the record stores) and stalls the wavefront on lgkmcnt.
+struct VoiceUniform {
+    double beta, revert, diffusion, noise_decay;
+    OW_DEV explicit VoiceUniform(const OwConsts* __restrict__ K)
+        : beta(K->pickup_beta), revert(K->jitter_revert), diffusion(K->jitter_diffusion), noise_decay(K->noise_decay) {}
+};
+
 struct VoiceRegs {
     double s[7], c[7], env[7], drift[7], cos_inc[7], sin_inc[7], phase_inc[7], amp[7], decay[7];
     double onset_inc, onset_exp, dramp, dcount, q, ds, gain;
@@ -402,7 +410,7 @@ struct VoiceRegs {
     // the kernel is VALU-issue bound and the rotation / pickup are mul-add chains.  Fused results differ from the
     // unfused reference by <= 1e-12 of peak over the parity renders (tests/test_gpu_parity.py voice-sum tap).
     template <bool STEADY>
-    OW_DEV double step(const double* __restrict__ rec, const OwConsts* __restrict__ K) {
+    OW_DEV double step(const double* __restrict__ rec, const VoiceUniform& U) {
 #ifndef OW_STRICT_FP
 #pragma clang fp contract(fast)
 #endif
@@ -430,7 +438,7 @@ struct VoiceRegs {
         }
         const uint32_t lo = (uint32_t)sample;
         if ((lo & 15u) == 0u) {
-            const double revert = K->jitter_revert, diffusion = K->jitter_diffusion;
+            const double revert = U.revert, diffusion = U.diffusion;
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
                 jitter_state = lcg(jitter_state);
@@ -477,7 +485,7 @@ struct VoiceRegs {
             ns1 = nb1 * nz - na1 * y + ns2;
             ns2 = nb2 * nz - na2 * y;
             x += namp * e * y;
-            namp *= K->noise_decay;
+            namp *= U.noise_decay;
             noise_rem -= 1u;
         }
         // pickup
@@ -485,8 +493,8 @@ struct VoiceRegs {
         const double ay = fabs(y);
         if (!(ay < 0.94)) y = pickup_saturate_hi(y, ay);
         const double omy = 1.0 - y;
-        const double alpha = K->pickup_beta * omy;
-        const double q_next = (q * (1.0 - alpha) + 2.0 * K->pickup_beta) / (1.0 + alpha);
+        const double alpha = U.beta * omy;
+        const double q_next = (q * (1.0 - alpha) + 2.0 * U.beta) / (1.0 + alpha);
         q = q_next;
         return ((q_next * omy - 1.0) * 1.8375) * gain;
     }
