@@ -378,7 +378,10 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
     else
         owdev::k_preamp<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, rb_now, p->d_pre, I, L, Lcap, e0, ne);
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[4], st));
-    owdev::k_post<<<dim3((ne + 63) / 64), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, Lcap, e0, ne);
+    if (p->hc.oversample)
+        owdev::k_post<true><<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, Lcap, e0, ne);
+    else
+        owdev::k_post<false><<<dim3((ne + 63) / 64), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, Lcap, e0, ne);
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[5], st));
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(p->h_eout + e0, p->d_eout + e0, sizeof(OwEngineOut) * ne, hipMemcpyDeviceToHost, st));

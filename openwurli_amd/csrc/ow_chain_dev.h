@@ -84,6 +84,9 @@ OW_DEV bool solve4(double a[4][4], double b[4]) {
         }
         if (!singular && max_val < 1e-15) singular = true;
         if (!singular) {
+            // row exchange only when some lane of the wavefront picked an off-diagonal pivot (wave-uniform branch): the selects
+            // below are no-ops for every other lane, and most sweeps need no exchange at all
+            if (__builtin_amdgcn_ballot_w64(max_row != col) != 0ull) {
 #pragma unroll
             for (int row = col + 1; row < 4; ++row) {
                 const bool sw = (max_row == row);
@@ -96,6 +99,7 @@ OW_DEV bool solve4(double a[4][4], double b[4]) {
                 const double x = b[col], y = b[row];
                 b[col] = sw ? y : x;
                 b[row] = sw ? x : y;
+            }
             }
             const double pivot = a[col][col];
 #pragma unroll
@@ -615,6 +619,13 @@ __device__ __noinline__ void dk_dc_state(const OwConsts* __restrict__ K, double 
     out->cin_prev = K->p_g_cin * out->v[0];
     out->i_nl[0] = dk_ic(vn0); out->i_nl[1] = dk_ic(vn1);
     out->v_nl[0] = vn0; out->v_nl[1] = vn1;
+}
+// st = DC state.  The out-of-line solver writes a temporary: handing it &st would pin the hot loop's state to scratch memory
+// (8 scratch loads + 8 stores per oversampled sample in k_preamp before this wrapper existed).
+__device__ inline void dk_dc_reset(const OwConsts* __restrict__ K, double r_ldr, DkSt& st) {
+    DkSt tmp;
+    dk_dc_state(K, r_ldr, &tmp);
+    st = tmp;
 }
 
 // ------------------------------------------------------------------ oversampler (oversampler.rs:17-45)

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64) void k_job_chain(const OwConsts* __restrict__ K
         ms.nan_resets = 0; ms.be_fallbacks = 0;
         mel_set_r(ms, jd.r_ldr);
     } else {
-        dk_dc_state(K, r_ldr, &st);                   // new() and reset() both solve DC at the initial 1 Mohm
+        dk_dc_reset(K, r_ldr, st);                   // new() and reset() both solve DC at the initial 1 Mohm
         const double r_new = fmax(jd.r_ldr, 1000.0);
         if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = 1.0 / r_new; }
     }
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void k_job_chain(const OwConsts* __restrict__ K
         double res = role ? (other - o) : (o - other);
         if (!isfinite(res)) {
             if (MEL) { mel_init_state(ms, settled); }
-            else { dk_dc_state(K, r_ldr, &st); g_ldr = 1.0 / r_ldr; g_prev = g_ldr; }
+            else { dk_dc_reset(K, r_ldr, st); g_ldr = 1.0 / r_ldr; g_prev = g_ldr; }
             res = 0.0;
         }
         return res;

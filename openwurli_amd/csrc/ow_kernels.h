@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64) void k_chain_init(const OwConsts* __restrict__ 
         CSF(CS_SPK_TS) = 0.0;
     }
     DkSt st;
-    dk_dc_state(K, r_ldr, &st);
+    dk_dc_reset(K, r_ldr, st);
     dk_store(st, cs, I, e, CS_P_MAIN);
     dk_store(st, cs, I, e, CS_P_SHADOW);
     CSF(CS_P_RLDR) = r_ldr; CSF(CS_P_GLDR) = 1.0 / r_ldr; CSF(CS_P_GPREV) = 1.0 / r_ldr;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
         r_ldr = CSF(CS_P_RLDR); g_ldr = CSF(CS_P_GLDR); g_prev = CSF(CS_P_GPREV);
         const uint64_t fl = dbits(CSF(CS_FLAGS));
         if (fl & 1ull) {  // deferred preamp.reset() + oversampler.reset() from the output NaN guard (engine.rs:450-457)
-            dk_dc_state(K, r_ldr, &st);
+            dk_dc_reset(K, r_ldr, st);
             g_ldr = 1.0 / r_ldr; g_prev = g_ldr;
             for (int i = 0; i < 3; ++i) { ua[i] = 0.0; ub[i] = 0.0; }
         }
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
                 const double other = __shfl_xor(o, 32);
                 double result = role ? (other - o) : (o - other);                 // main - pump, :608
                 if (!isfinite(result)) {                                          // :610-615
-                    dk_dc_state(K, r_ldr, &st);
+                    dk_dc_reset(K, r_ldr, st);
                     g_ldr = 1.0 / r_ldr; g_prev = g_ldr;
                     result = 0.0;
                     nan_resets += 1u;
@@ -612,17 +612,26 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
 
 // ------------------------------------------------------------------ output stage
 #define OW_OCHUNK 64
+// SPLIT (2x oversampled chain): lanes = (engine, oversample phase), 32 engines per wavefront.  The behavioural power amp is
+// stateless (power_amp.rs:206), so the two chain-rate samples of one output sample are solved by the two lanes of a pair and
+// exchanged with one __shfl_xor; both lanes then run the identical half-band / speaker recurrence (no divergence), the phase-0
+// lane owns the state and the output.  Twice the wavefronts of the lane=engine layout, each with ~60 % of the instructions.
+template <bool SPLIT>
 __global__ __launch_bounds__(64) void k_post(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args,
                                              OwEngineOut* __restrict__ eout, const double* __restrict__ pre, float* __restrict__ out, int I, int L,
                                              int Lcap, int e0, int ne) {
-    __shared__ float tile[64 * (OW_OCHUNK + 1)];
+    constexpr int NROWS = SPLIT ? 32 : 64;
+    __shared__ float tile[NROWS * (OW_OCHUNK + 1)];
     const int lane = threadIdx.x;
-    const int eb = e0 + blockIdx.x * 64;
-    const int e_raw = eb + lane;
+    const int el = SPLIT ? (lane & 31) : lane;
+    const int phase = SPLIT ? (lane >> 5) : 0;
+    const int eb = e0 + blockIdx.x * NROWS;
+    const int e_raw = eb + el;
     const bool valid = e_raw < e0 + ne;
     const int e = valid ? e_raw : (e0 + ne - 1);
-    const int osr = K->oversample ? 2 : 1;
+    const int osr = SPLIT ? 2 : 1;
     const double sr = K->sr;
+    const double thermal_alpha = K->spk_thermal_alpha;
 
     double da[3], db[3], dd;
     for (int i = 0; i < 3; ++i) { da[i] = CSF(CS_OS_DA + i); db[i] = CSF(CS_OS_DB + i); }
@@ -641,31 +650,26 @@ __global__ __launch_bounds__(64) void k_post(const OwConsts* __restrict__ K, dou
     bool nan_fired = false;
 
     // the preamp stream is read one host sample ahead (registers): hides the global-load latency behind the previous sample
-    double pn[2];
-    pn[0] = pre[(size_t)0 * I + e];
-    pn[1] = osr == 2 ? pre[(size_t)1 * I + e] : 0.0;
+    double pn = pre[(size_t)phase * I + e];
     for (int base = 0; base < L; base += OW_OCHUNK) {
         const int cn = min(OW_OCHUNK, L - base);
         for (int n = 0; n < cn; ++n) {
-            const double pc0 = pn[0], pc1 = pn[1];
-            {
-                const size_t nx = (size_t)min(base + n + 1, L - 1) * osr;
-                pn[0] = pre[nx * I + e];
-                if (osr == 2) pn[1] = pre[(nx + 1) * I + e];
-            }
+            const double pc = pn;
+            pn = pre[((size_t)min(base + n + 1, L - 1) * osr + phase) * I + e];
+            const double y = power_amp(pc * 0.25);
             double o;
-            if (osr == 2) {  // engine.rs:536-553
-                const double y0 = power_amp(pc0 * 0.25);
-                const double y1 = power_amp(pc1 * 0.25);
+            if (SPLIT) {  // engine.rs:536-553
+                const double yo = __shfl_xor(y, 32);
+                const double y0 = phase ? yo : y, y1 = phase ? y : yo;
                 const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, y0);
                 const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, y1);
                 o = (a + dd) * 0.5;
                 dd = b;
             } else {
-                o = power_amp(pc0 * 0.25);
+                o = y;
             }
             speaker_set_character(sp, ss.next(), sr);                           // engine.rs:437-438
-            const double shaped = speaker_process(sp, o, K->spk_thermal_alpha);
+            const double shaped = speaker_process(sp, o, thermal_alpha);
             const double post = shaped * 7.498942093324558 * sv.next();         // POST_SPEAKER_GAIN x user volume
             float f = (float)post;
             if (!isfinite(f)) {                                                 // engine.rs:450-458
@@ -674,16 +678,16 @@ __global__ __launch_bounds__(64) void k_post(const OwConsts* __restrict__ K, dou
                 sp.ts = 0.0;
                 nan_fired = true;
             }
-            tile[lane * (OW_OCHUNK + 1) + n] = f;
+            if (phase == 0) tile[el * (OW_OCHUNK + 1) + n] = f;
         }
         __syncthreads();
-        for (int r = 0; r < 64; ++r) {
+        for (int r = 0; r < NROWS; ++r) {
             const int er = eb + r;
             if (er < e0 + ne && lane < cn) out[(size_t)er * Lcap + base + lane] = tile[r * (OW_OCHUNK + 1) + lane];
         }
         __syncthreads();
     }
-    if (!valid) return;
+    if (!valid || phase != 0) return;
     if (nan_fired) {  // preamp.reset()/oversampler.reset() act on post-block state: defer the preamp/up half to k_preamp
         for (int i = 0; i < 3; ++i) { da[i] = 0.0; db[i] = 0.0; }
         dd = 0.0;
