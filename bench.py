@@ -40,6 +40,7 @@ FLOPS_TREMOLO = 2 * (1000 + 25)    # Twin-T NR step + LDR law per OS sample, 2 O
 FLOPS_PREAMP = 2 * 1400 + 24       # main+shadow dk_step per OS sample + half-band up
 FLOPS_POST = 2 * 90 + 24 + 45      # power amp x2 + half-band down + speaker/gain
 FLOPS_PER_SAMPLE = FLOPS_VOICES + FLOPS_TREMOLO + FLOPS_PREAMP + FLOPS_POST
+KERNEL_OF = {"ops": "k_apply_ops", "voices": "k_voice_steady", "tremolo": "k_tremolo", "preamp": "k_preamp", "post": "k_post"}
 PEAK_FP64_VALU_TFLOPS = 78.6       # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (MI355X FP64 vector)
 
 
@@ -101,11 +102,24 @@ class Script:
             self.kernel_launches += 1
 
 
+def effective_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (cpu.max).  The GPU boxes expose 256
+    hardware threads but run the job under a 16-CPU quota; starting 256 threads there only adds throttling."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            n = max(1, min(n, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(seconds_audio=1.0):
     """Oracle (CPU restatement, kind 'port') on the host cores: one cfg-2 instance per thread."""
     import oracle_binding as ob
     ob.lib()
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     n = int(SR * seconds_audio)
 
     def work(k, out):
@@ -136,7 +150,7 @@ def cpu_baseline(seconds_audio=1.0):
     total = sum(v[0] for v in res.values())
     return {
         "value": total / wall, "unit": "samples/s", "cores": cores, "kind": "port",
-        "sample": f"{cores} threads x 1 cfg-2 instance (64 voices, full chain) x {seconds_audio:.1f} s audio, buffers of {BUF}; "
+        "sample": f"{cores} threads (= usable CPUs: affinity capped by the cgroup quota) x 1 cfg-2 instance (64 voices, full chain) x {seconds_audio:.1f} s audio, buffers of {BUF}; "
                   f"oracle = C++ f64 restatement (reference Rust is not buildable in this image)",
         "single_thread_value": single,
     }
@@ -243,7 +257,7 @@ def main():
             "host_midi_s": script.t_midi, "render_calls_s": script.t_render, "elapsed_s": elapsed,
             "single_instance_samples_per_s": single,
             "roofline": {
-                "bound": "valu_f64", "kernel": "k_" + ("voice" if dom == "voices" else dom), "achieved": achieved,
+                "bound": "valu_f64", "kernel": KERNEL_OF[dom], "achieved": achieved,
                 "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
                 "kernel_ms_per_step": {n: float(k) for n, k in zip(names, kms)},
                 "whole_chain_frac": FLOPS_PER_SAMPLE * value / world / 1e12 / PEAK_FP64_VALU_TFLOPS,

@@ -12,7 +12,7 @@ def main():
     for path in files:
         with open(path) as f:
             for r in csv.DictReader(f):
-                name = r["Kernel_Name"].split("(")[0].replace("owdev::", "")
+                name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("owdev::", "")
                 if not name.startswith("k_"):
                     continue
                 key = (name, int(r["Grid_Size"]))

@@ -12,7 +12,7 @@ def main():
     meta = {}
     with open(path) as f:
         for r in csv.DictReader(f):
-            name = r["Kernel_Name"].split("(")[0].replace("owdev::", "")
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("owdev::", "")
             key = (name, int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]))
             rows[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
             meta[key] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"])
@@ -30,7 +30,7 @@ def main():
         rr = sorted(csv.DictReader(f), key=lambda r: int(r["Start_Timestamp"]))
     big = max((int(r["Grid_Size_X"]) for r in rr if "k_voice_steady" in r["Kernel_Name"]), default=0)
     for r in rr:
-        name = r["Kernel_Name"].split("(")[0].replace("owdev::", "")
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("owdev::", "")
         if name.startswith("k_") and int(r["Grid_Size_X"]) * 64 >= big:
             tail[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     lines += ["", "Timed region only (last 20 launches of each pool-sized kernel):", "",
