@@ -180,6 +180,42 @@ def test_engine_other_rates(hiplib, oracle, sr):
     g.close()
 
 
+def test_engine_ragged_block_lengths(hiplib, oracle):
+    """Block lengths around every internal chunk size (voice tile 24, chain tiles 64, the one-sample software pipeline of the
+    steady voice loop) and up to MAX_BLOCK_SIZE (engine.rs:25), with note events in between: transient -> steady hand-over
+    between k_voice and k_voice_steady happens at arbitrary block boundaries.  The block-ahead tremolo mis-speculates on every
+    length change, so its rollback is exercised throughout."""
+    import openwurli_amd as ow
+    sr = 48000.0
+    g, cs = _both(ow, oracle, sr, n=2)
+    for k in range(2):
+        for e in (g[k], cs[k]):
+            e.set_tremolo_depth(0.8); e.set_volume(0.6)
+            for n in (36 + k, 55, 60, 64, 67 + k, 90):
+                e.note_on(n, 0.4 + 0.3 * k)
+    lengths = [1, 1, 2, 23, 24, 25, 47, 48, 49, 63, 64, 65, 100, 1, 511, 513, 1000, 3, 8192, 17]
+    for i, length in enumerate(lengths):
+        if i == 7:
+            for k in range(2):
+                for e in (g[k], cs[k]):
+                    e.note_off(60); e.note_on(72, 0.9)
+        if i == 13:
+            for k in range(2):
+                for e in (g[k], cs[k]):
+                    e.note_on(60, 0.7); e.set_sustain(True); e.note_off(55)
+        go = g.render(length)
+        gv = g.voice_sum(length)
+        for k, c in enumerate(cs):
+            co, cv, _, _ = c.render_taps(length)
+            assert go[k].size == length
+            _check(oracle.parity_report(go[k], co, abs_floor=oracle.ABS_FLOOR_OUTPUT), ("ragged out", i, length, k))
+            # f64 voice sum: 1e-12 of the block peak, with an absolute floor of 1e-15 (signal scale 1e-2; a 1-sample block
+            # inside the onset ramp peaks at 4e-8, where one ulp of the OCML-vs-glibc cos() is already 1e-10 of "peak")
+            _check(oracle.parity_report(gv[k], cv, rel=1e-12, floor_frac=1.0, abs_floor=1e-15), ("ragged voice_sum", i, length, k))
+    assert g.render(0).shape == (2, 0)
+    g.close()
+
+
 def test_pool_of_independent_engines(hiplib, oracle):
     """Lane = engine kernels: 5 engines with different scripts in one pool vs 5 separate oracle engines."""
     import openwurli_amd as ow
