@@ -150,6 +150,35 @@ typedef struct ow_batch_cfg {
  * If out_is_device != 0, `out` is a device pointer and nothing is copied to the host.  Returns samples per job, <0 on error. */
 long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg* cfg, double* out, size_t stride, int out_is_device);
 
+/* ---- ML-pipeline stage after the batch render --------------------------------- */
+/* 24-bit PCM quantisers of the reference's two WAV writers.  OW_WAV_ROUND: preamp-bench write_wav_24bit
+ * (tools/preamp-bench/src/main.rs:941-957): (sample * scale * (2^23-1)).round() as i32, clamped to +-(2^23-1); Rust round() is
+ * half-away-from-zero and the cast saturates (NaN -> 0).  OW_WAV_TRUNCATE: reed-renderer write_wav
+ * (tools/reed-renderer/src/main.rs:110-126): (s.clamp(-1,1) * (2^23-1)) as i32, truncation toward zero (scale ignored). */
+enum { OW_WAV_ROUND = 0, OW_WAV_TRUNCATE = 1 };
+int ow_wav24_quantize(const double* samples, size_t n, double scale, int mode, int32_t* out);
+/* Mono 24-bit PCM WAV file with that quantiser.  Container as hound 3.5.1 (Cargo.lock) writes it for 24-bit data:
+ * RIFF/WAVE, 40-byte WAVE_FORMAT_EXTENSIBLE "fmt " chunk (PCM sub-format, 24 valid bits, channel mask 0x4), "data" chunk of
+ * little-endian 3-byte samples.  Returns 0, <0 on I/O error. */
+int ow_wav24_write(const char* path, const double* samples, size_t n, uint32_t sample_rate, double scale, int mode);
+
+/* extract_harmonics_fft (ml/goertzel_utils.py:60-107) on many segments at once, as extract_model_features
+ * (ml/render_model_notes.py:118-237) applies it to each rendered note: amplitude and frequency of the peak bin of the
+ * Hann-windowed, 4x zero-padded spectrum inside +-search_pct of each harmonic h*f0, h = 1..n_harmonics (<= OW_MAX_HARMONICS);
+ * harmonics at or above sr/2 - 100 Hz, or without a bin in the band, report amplitude 1e-20 at h*f0.  Also the RMS of every
+ * segment (max(sqrt(mean(x^2)), 1e-20); n_harmonics = 0 asks for the RMS only). */
+#define OW_MAX_HARMONICS 8
+typedef struct ow_segment {
+    uint32_t row;          /* audio row (job) */
+    uint32_t start, end;   /* sample range [start, end) inside the row */
+    uint32_t n_harmonics;  /* 0..OW_MAX_HARMONICS */
+    double f0;             /* fundamental the harmonics are searched around */
+} ow_segment;
+/* audio: f64 [n_rows][stride] (device pointer if audio_is_device != 0, e.g. the output of ow_batch_render).
+ * amps, freqs: [n_segs][OW_MAX_HARMONICS] (entries past n_harmonics are 0); rms: [n_segs] or NULL.  Returns 0, <0 on error. */
+int ow_extract_harmonics(const double* audio, size_t n_rows, size_t stride, double sample_rate, const ow_segment* segs, size_t n_segs,
+                         double search_pct, int device, int audio_is_device, double* amps, double* freqs, double* rms);
+
 #ifdef __cplusplus
 }
 #endif

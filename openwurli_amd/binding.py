@@ -37,6 +37,14 @@ class OwBatchCfg(C.Structure):
 
 # every symbol include/openwurli_hip.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
+class OwSegment(C.Structure):
+    _fields_ = [("row", C.c_uint32), ("start", C.c_uint32), ("end", C.c_uint32), ("n_harmonics", C.c_uint32), ("f0", C.c_double)]
+
+
+SEGMENT_DTYPE = [("row", "<u4"), ("start", "<u4"), ("end", "<u4"), ("n_harmonics", "<u4"), ("f0", "<f8")]
+MAX_HARMONICS = 8
+WAV_ROUND, WAV_TRUNCATE = 0, 1
+
 SYMBOLS = {
     "ow_last_error": (C.c_char_p, []),
     "ow_pool_new": (_VP, [C.c_double, C.c_size_t, C.c_int, C.c_int]),
@@ -82,6 +90,10 @@ SYMBOLS = {
     "ow_debug_mlp_raw": (C.c_int, [_VP, _VP, C.c_size_t, _VP, C.c_int, C.c_int]),
     "ow_render_note": (C.c_longlong, [C.c_uint8, C.c_double, C.c_double, C.c_double, C.c_int, _VP, C.c_size_t]),
     "ow_batch_render": (C.c_longlong, [C.POINTER(OwJob), C.c_size_t, C.POINTER(OwBatchCfg), _VP, C.c_size_t, C.c_int]),
+    "ow_wav24_quantize": (C.c_int, [_VP, C.c_size_t, C.c_double, C.c_int, _VP]),
+    "ow_wav24_write": (C.c_int, [C.c_char_p, _VP, C.c_size_t, C.c_uint32, C.c_double, C.c_int]),
+    "ow_extract_harmonics": (C.c_int, [_VP, C.c_size_t, C.c_size_t, C.c_double, _VP, C.c_size_t, C.c_double, C.c_int, C.c_int,
+                                       _VP, _VP, _VP]),
 }
 
 

@@ -4,6 +4,7 @@
 // everything that touches audio samples runs in the gfx950 kernels of ow_kernels.h.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +19,7 @@
 #include "ow_job_kernels.h"
 #include "ow_mlp_mfma.h"
 #include "ow_melange_dev.h"
+#include "ow_features.h"
 #include <map>
 #include <mutex>
 
@@ -1006,6 +1008,153 @@ long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg*
         hipStreamDestroy(st);
         return (long long)n;
     } catch (const std::exception& ex) { set_err(std::string("ow_batch_render: ") + ex.what()); return -1; }
+}
+
+// ---- ML-pipeline stage after the batch render ---------------------------------------------------------------
+int ow_wav24_quantize(const double* samples, size_t n, double scale, int mode, int32_t* out) {
+    if ((!samples || !out) && n) { set_err("ow_wav24_quantize: null argument"); return -1; }
+    if (mode != OW_WAV_ROUND && mode != OW_WAV_TRUNCATE) { set_err("ow_wav24_quantize: unknown mode"); return -1; }
+    const double mx = 8388607.0;
+    for (size_t i = 0; i < n; ++i) {
+        double v;
+        if (mode == OW_WAV_ROUND) {          // main.rs:951-954: round half away from zero, saturating cast, clamp
+            v = std::round(samples[i] * scale * mx);
+        } else {                             // reed-renderer main.rs:119-123: clamp to +-1, scale, truncate toward zero
+            const double c = samples[i] < -1.0 ? -1.0 : (samples[i] > 1.0 ? 1.0 : samples[i]);
+            v = std::trunc(c * mx);
+        }
+        if (!(v == v)) v = 0.0;              // Rust `as i32`: NaN -> 0
+        out[i] = (int32_t)(v < -mx ? -mx : (v > mx ? mx : v));
+    }
+    return 0;
+}
+
+int ow_wav24_write(const char* path, const double* samples, size_t n, uint32_t sample_rate, double scale, int mode) {
+    if (!path || (!samples && n)) { set_err("ow_wav24_write: null argument"); return -1; }
+    std::vector<int32_t> q(n);
+    if (ow_wav24_quantize(samples, n, scale, mode, q.data()) != 0) return -1;
+    const uint32_t data_bytes = (uint32_t)(n * 3);
+    std::vector<uint8_t> buf;
+    buf.reserve(68 + data_bytes + 1);
+    auto u16 = [&](uint32_t v) { buf.push_back((uint8_t)v); buf.push_back((uint8_t)(v >> 8)); };
+    auto u32 = [&](uint32_t v) { u16(v & 0xFFFFu); u16(v >> 16); };
+    auto tag = [&](const char* t) { buf.insert(buf.end(), t, t + 4); };
+    tag("RIFF"); u32(4 + (8 + 40) + (8 + data_bytes + (data_bytes & 1))); tag("WAVE");
+    tag("fmt "); u32(40);
+    u16(0xFFFE);                 // WAVE_FORMAT_EXTENSIBLE
+    u16(1);                      // channels
+    u32(sample_rate);
+    u32(sample_rate * 3);        // bytes per second
+    u16(3);                      // block align
+    u16(24);                     // bits per sample (container)
+    u16(22);                     // cbSize
+    u16(24);                     // valid bits
+    u32(0x4);                    // channel mask: front centre
+    static const uint8_t pcm_guid[16] = {0x01, 0x00, 0x00, 0x00, 0x00, 0x00, 0x10, 0x00, 0x80, 0x00, 0x00, 0xAA, 0x00, 0x38, 0x9B, 0x71};
+    buf.insert(buf.end(), pcm_guid, pcm_guid + 16);
+    tag("data"); u32(data_bytes);
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t v = (uint32_t)q[i];
+        buf.push_back((uint8_t)v); buf.push_back((uint8_t)(v >> 8)); buf.push_back((uint8_t)(v >> 16));
+    }
+    if (data_bytes & 1) buf.push_back(0);
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { set_err(std::string("ow_wav24_write: cannot open ") + path); return -2; }
+    const bool ok = std::fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    if (std::fclose(f) != 0 || !ok) { set_err(std::string("ow_wav24_write: short write to ") + path); return -3; }
+    return 0;
+}
+
+int ow_extract_harmonics(const double* audio, size_t n_rows, size_t stride, double sample_rate, const ow_segment* segs, size_t n_segs,
+                         double search_pct, int device, int audio_is_device, double* amps, double* freqs, double* rms) {
+    try {
+        if (!audio || !segs || !amps || !freqs) throw std::runtime_error("null argument");
+        if (!(sample_rate > 0.0) || !(search_pct >= 0.0)) throw std::runtime_error("invalid sample rate or search band");
+        if (n_segs == 0) return 0;
+        std::vector<owdev::OwSegDev> hs(n_segs);
+        std::vector<owdev::OwBinsDev> hb;
+        std::vector<double> vals(n_segs);
+        uint64_t off = 0;
+        for (size_t i = 0; i < n_segs; ++i) {
+            const ow_segment& g = segs[i];
+            if (g.row >= n_rows || g.end <= g.start || g.end > stride || g.n_harmonics > OW_MAX_HARMONICS)
+                throw std::runtime_error("segment " + std::to_string(i) + " out of range");
+            const uint32_t n = g.end - g.start;
+            if (n > (1u << 22)) throw std::runtime_error("segment longer than 2^22 samples");
+            hs[i].row = g.row; hs[i].start = g.start; hs[i].n = n; hs[i].n_harm = g.n_harmonics; hs[i].xw_off = off;
+            off += n;
+            // numpy's axis: rfftfreq(nfft, d = 1/sr) = arange(nfft/2 + 1) * (1 / (nfft * d)); mask = (axis >= f_lo) & (axis <= f_hi)
+            const uint64_t nfft = 4ull * n, nb = nfft / 2 + 1;
+            const double val = 1.0 / ((double)nfft * (1.0 / sample_rate));
+            vals[i] = val;
+            for (uint32_t h = 0; h < g.n_harmonics; ++h) {
+                owdev::OwBinsDev b;
+                b.seg = (uint32_t)i; b.k_lo = 1; b.k_hi = 0; b.pad = 0;
+                const double fh = g.f0 * (double)(h + 1);
+                if (!(fh >= sample_rate / 2 - 100)) {
+                    const double f_lo = fh * (1.0 - search_pct), f_hi = fh * (1.0 + search_pct);
+                    double q = f_lo / val;
+                    uint64_t k = (q > 0.0 && q < (double)nb) ? (uint64_t)q : (q >= (double)nb ? nb : 0);
+                    while (k > 0 && (double)(k - 1) * val >= f_lo) --k;
+                    while (k < nb && (double)k * val < f_lo) ++k;
+                    const uint64_t k_lo = k;
+                    while (k < nb && (double)k * val <= f_hi) ++k;
+                    if (k > k_lo) { b.k_lo = (uint32_t)k_lo; b.k_hi = (uint32_t)(k - 1); }
+                }
+                hb.push_back(b);
+            }
+        }
+        HIP_OK(hipSetDevice(device));
+        hipStream_t st;
+        HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        double* d_audio = nullptr; double* d_xw = nullptr; double* d_ss = nullptr;
+        owdev::OwSegDev* d_segs = nullptr; owdev::OwBinsDev* d_bins = nullptr; owdev::OwPeakDev* d_peaks = nullptr;
+        if (audio_is_device) d_audio = const_cast<double*>(audio);
+        else {
+            HIP_OK(hipMalloc(&d_audio, sizeof(double) * n_rows * stride));
+            HIP_OK(hipMemcpyAsync(d_audio, audio, sizeof(double) * n_rows * stride, hipMemcpyHostToDevice, st));
+        }
+        HIP_OK(hipMalloc(&d_xw, sizeof(double) * std::max<uint64_t>(off, 1)));
+        HIP_OK(hipMalloc(&d_ss, sizeof(double) * n_segs));
+        HIP_OK(hipMalloc(&d_segs, sizeof(owdev::OwSegDev) * n_segs));
+        HIP_OK(hipMemcpyAsync(d_segs, hs.data(), sizeof(owdev::OwSegDev) * n_segs, hipMemcpyHostToDevice, st));
+        owdev::k_feat_window<<<dim3((unsigned)n_segs), dim3(256), 0, st>>>(d_audio, stride, d_segs, d_xw, d_ss);
+        std::vector<owdev::OwPeakDev> peaks(hb.size());
+        if (!hb.empty()) {
+            HIP_OK(hipMalloc(&d_bins, sizeof(owdev::OwBinsDev) * hb.size()));
+            HIP_OK(hipMalloc(&d_peaks, sizeof(owdev::OwPeakDev) * hb.size()));
+            HIP_OK(hipMemcpyAsync(d_bins, hb.data(), sizeof(owdev::OwBinsDev) * hb.size(), hipMemcpyHostToDevice, st));
+            owdev::k_feat_peaks<<<dim3((unsigned)hb.size()), dim3(256), 0, st>>>(d_segs, d_bins, d_xw, d_peaks);
+            HIP_OK(hipMemcpyAsync(peaks.data(), d_peaks, sizeof(owdev::OwPeakDev) * hb.size(), hipMemcpyDeviceToHost, st));
+        }
+        std::vector<double> ss(n_segs);
+        HIP_OK(hipMemcpyAsync(ss.data(), d_ss, sizeof(double) * n_segs, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(st));
+        size_t bi = 0;
+        for (size_t i = 0; i < n_segs; ++i) {
+            const double N = (double)hs[i].n;
+            for (uint32_t h = 0; h < OW_MAX_HARMONICS; ++h) {
+                double a = 0.0, f = 0.0;
+                if (h < hs[i].n_harm) {
+                    const owdev::OwBinsDev& b = hb[bi];
+                    if (b.k_lo <= b.k_hi) {
+                        a = std::hypot(peaks[bi].re, peaks[bi].im) * 2.0 / N / 0.5;   // np.abs(rfft) * 2.0 / N / 0.5
+                        f = (double)peaks[bi].k * vals[i];
+                    } else { a = 1e-20; f = segs[i].f0 * (double)(h + 1); }
+                    ++bi;
+                }
+                amps[i * OW_MAX_HARMONICS + h] = a; freqs[i * OW_MAX_HARMONICS + h] = f;
+            }
+            if (rms) rms[i] = std::max(std::sqrt(ss[i] / N), 1e-20);
+        }
+        if (!audio_is_device) hipFree(d_audio);
+        hipFree(d_xw); hipFree(d_ss); hipFree(d_segs);
+        if (d_bins) hipFree(d_bins);
+        if (d_peaks) hipFree(d_peaks);
+        hipStreamDestroy(st);
+        return 0;
+    } catch (const std::exception& ex) { set_err(std::string("ow_extract_harmonics: ") + ex.what()); return -1; }
 }
 
 }  // extern "C"

@@ -27,3 +27,9 @@ def hiplib():
         import subprocess
         subprocess.check_call(["bash", os.path.join(ROOT, "build.sh")])
     return openwurli_amd.load_library()
+
+
+@pytest.fixture(scope="session")
+def hiplib_host(hiplib):
+    """Same library, for tests that only call its host-side entry points (WAV writer, quantisers): they need no device."""
+    return hiplib
