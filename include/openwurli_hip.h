@@ -175,9 +175,13 @@ typedef struct ow_segment {
     double f0;             /* fundamental the harmonics are searched around */
 } ow_segment;
 /* audio: f64 [n_rows][stride] (device pointer if audio_is_device != 0, e.g. the output of ow_batch_render).
+ * wav24_mode: OW_WAV_ROUND / OW_WAV_TRUNCATE analyse what a 24-bit WAV written with that quantiser and read back as float
+ * (int / 2^23, libsndfile's PCM_24 normalisation used by the script's load_audio, goertzel_utils.py:11-17) would contain;
+ * OW_WAV_NONE analyses the samples as they are.
  * amps, freqs: [n_segs][OW_MAX_HARMONICS] (entries past n_harmonics are 0); rms: [n_segs] or NULL.  Returns 0, <0 on error. */
+#define OW_WAV_NONE (-1)
 int ow_extract_harmonics(const double* audio, size_t n_rows, size_t stride, double sample_rate, const ow_segment* segs, size_t n_segs,
-                         double search_pct, int device, int audio_is_device, double* amps, double* freqs, double* rms);
+                         double search_pct, int wav24_mode, int device, int audio_is_device, double* amps, double* freqs, double* rms);
 
 #ifdef __cplusplus
 }

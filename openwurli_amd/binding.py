@@ -43,7 +43,7 @@ class OwSegment(C.Structure):
 
 SEGMENT_DTYPE = [("row", "<u4"), ("start", "<u4"), ("end", "<u4"), ("n_harmonics", "<u4"), ("f0", "<f8")]
 MAX_HARMONICS = 8
-WAV_ROUND, WAV_TRUNCATE = 0, 1
+WAV_NONE, WAV_ROUND, WAV_TRUNCATE = -1, 0, 1
 
 SYMBOLS = {
     "ow_last_error": (C.c_char_p, []),
@@ -92,7 +92,7 @@ SYMBOLS = {
     "ow_batch_render": (C.c_longlong, [C.POINTER(OwJob), C.c_size_t, C.POINTER(OwBatchCfg), _VP, C.c_size_t, C.c_int]),
     "ow_wav24_quantize": (C.c_int, [_VP, C.c_size_t, C.c_double, C.c_int, _VP]),
     "ow_wav24_write": (C.c_int, [C.c_char_p, _VP, C.c_size_t, C.c_uint32, C.c_double, C.c_int]),
-    "ow_extract_harmonics": (C.c_int, [_VP, C.c_size_t, C.c_size_t, C.c_double, _VP, C.c_size_t, C.c_double, C.c_int, C.c_int,
+    "ow_extract_harmonics": (C.c_int, [_VP, C.c_size_t, C.c_size_t, C.c_double, _VP, C.c_size_t, C.c_double, C.c_int, C.c_int, C.c_int,
                                        _VP, _VP, _VP]),
 }
 

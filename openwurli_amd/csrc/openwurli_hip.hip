@@ -1066,9 +1066,10 @@ int ow_wav24_write(const char* path, const double* samples, size_t n, uint32_t s
 }
 
 int ow_extract_harmonics(const double* audio, size_t n_rows, size_t stride, double sample_rate, const ow_segment* segs, size_t n_segs,
-                         double search_pct, int device, int audio_is_device, double* amps, double* freqs, double* rms) {
+                         double search_pct, int wav24_mode, int device, int audio_is_device, double* amps, double* freqs, double* rms) {
     try {
         if (!audio || !segs || !amps || !freqs) throw std::runtime_error("null argument");
+        if (wav24_mode != OW_WAV_NONE && wav24_mode != OW_WAV_ROUND && wav24_mode != OW_WAV_TRUNCATE) throw std::runtime_error("unknown wav24_mode");
         if (!(sample_rate > 0.0) || !(search_pct >= 0.0)) throw std::runtime_error("invalid sample rate or search band");
         if (n_segs == 0) return 0;
         std::vector<owdev::OwSegDev> hs(n_segs);
@@ -1118,7 +1119,7 @@ int ow_extract_harmonics(const double* audio, size_t n_rows, size_t stride, doub
         HIP_OK(hipMalloc(&d_ss, sizeof(double) * n_segs));
         HIP_OK(hipMalloc(&d_segs, sizeof(owdev::OwSegDev) * n_segs));
         HIP_OK(hipMemcpyAsync(d_segs, hs.data(), sizeof(owdev::OwSegDev) * n_segs, hipMemcpyHostToDevice, st));
-        owdev::k_feat_window<<<dim3((unsigned)n_segs), dim3(256), 0, st>>>(d_audio, stride, d_segs, d_xw, d_ss);
+        owdev::k_feat_window<<<dim3((unsigned)n_segs), dim3(256), 0, st>>>(d_audio, stride, d_segs, d_xw, d_ss, wav24_mode);
         std::vector<owdev::OwPeakDev> peaks(hb.size());
         if (!hb.empty()) {
             HIP_OK(hipMalloc(&d_bins, sizeof(owdev::OwBinsDev) * hb.size()));

@@ -35,7 +35,7 @@ struct OwPeakDev {
 #define OW_PI 3.14159265358979323846
 
 __global__ __launch_bounds__(256) void k_feat_window(const double* __restrict__ audio, size_t stride, const OwSegDev* __restrict__ segs,
-                                                     double* __restrict__ xw, double* __restrict__ sumsq) {
+                                                     double* __restrict__ xw, double* __restrict__ sumsq, int wav24_mode) {
     __shared__ double red[4];
     const OwSegDev s = segs[blockIdx.x];
     const double* x = audio + (size_t)s.row * stride + s.start;
@@ -43,7 +43,13 @@ __global__ __launch_bounds__(256) void k_feat_window(const double* __restrict__ 
     const double m1 = (double)s.n - 1.0;
     double acc = 0.0;
     for (uint32_t i = threadIdx.x; i < s.n; i += 256) {
-        const double v = x[i];
+        double v = x[i];
+        if (wav24_mode >= 0) {   // what a 24-bit WAV of this sample reads back as: quantiser of the reference's writer, then int / 2^23
+            const double mx = 8388607.0;
+            double q = wav24_mode == 0 ? round(v * mx) : trunc(fmin(fmax(v, -1.0), 1.0) * mx);   // Rust round(): half away from zero
+            if (!(q == q)) q = 0.0;
+            v = fmin(fmax(q, -mx), mx) * (1.0 / 8388608.0);
+        }
         acc += v * v;
         // np.hanning(M): n = arange(1-M, M, 2); 0.5 + 0.5*cos(pi*n/(M-1))   (M == 1 -> ones)
         const double nn = (double)(1 - (int64_t)s.n + 2 * (int64_t)i);

@@ -50,10 +50,15 @@ def write_wav_24bit(path, samples, sample_rate, scale=1.0, mode="round"):
         raise OwError(binding.last_error(lib))
 
 
-def extract_segments(audio, sample_rate, segments, search_pct=0.01, device=0):
+_WAV_MODES = {None: binding.WAV_NONE, "round": binding.WAV_ROUND, "truncate": binding.WAV_TRUNCATE}
+
+
+def extract_segments(audio, sample_rate, segments, search_pct=0.01, device=0, wav24=None):
     """`extract_harmonics_fft` on many segments in one call.
 
     audio: float64 [rows, stride]; segments: iterable of (row, start, end, n_harmonics, f0).
+    wav24: None analyses the samples as given; "round" / "truncate" analyses what a 24-bit WAV written with that quantiser
+    reads back as (the reference script always goes through the file).
     Returns (amps [n, 8], freqs [n, 8], rms [n])."""
     lib = binding.load_library()
     a = np.ascontiguousarray(audio, dtype=np.float64)
@@ -65,7 +70,7 @@ def extract_segments(audio, sample_rate, segments, search_pct=0.01, device=0):
     if n == 0:
         return amps, freqs, rms
     rc = lib.ow_extract_harmonics(a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], float(sample_rate),
-                                  seg.ctypes.data_as(C.c_void_p), n, float(search_pct), int(device), 0,
+                                  seg.ctypes.data_as(C.c_void_p), n, float(search_pct), _WAV_MODES[wav24], int(device), 0,
                                   amps.ctypes.data_as(C.c_void_p), freqs.ctypes.data_as(C.c_void_p), rms.ctypes.data_as(C.c_void_p))
     if rc != 0:
         raise OwError(binding.last_error(lib))
@@ -97,9 +102,10 @@ def _note_segments(row, n_samples, sr, f0):
     return out
 
 
-def extract_model_features(audio, sr, pairs, device=0):
+def extract_model_features(audio, sr, pairs, device=0, wav24="round"):
     """`extract_model_features(wav_paths, pairs)` (render_model_notes.py:118-237) on renders that are still in memory:
-    audio[j] is the note of pairs[j] = (midi, velocity), starting at t = 0.  One GPU call for all notes."""
+    audio[j] is the note of pairs[j] = (midi, velocity), starting at t = 0.  One GPU call for all notes.
+    wav24="round" (default) reproduces the script's WAV round trip (preamp-bench writes, soundfile reads) without the files."""
     a = np.ascontiguousarray(audio, dtype=np.float64)
     n_samples = a.shape[1]
     plan, flat = [], []
@@ -107,7 +113,7 @@ def extract_model_features(audio, sr, pairs, device=0):
         segs = _note_segments(j, n_samples, sr, midi_to_freq(midi))
         plan.append([None if s is None else len(flat) + sum(1 for t in segs[:i] if t is not None) for i, s in enumerate(segs)])
         flat.extend(s for s in segs if s is not None)
-    amps, freqs, rms = extract_segments(a, sr, flat, 0.01, device)
+    amps, freqs, rms = extract_segments(a, sr, flat, 0.01, device, wav24)
     features = {}
     for j, (midi, vel) in enumerate(pairs):
         idx = plan[j]

@@ -74,10 +74,14 @@ def test_extract_model_features_matches_oracle(hiplib):
     sr = 44100.0
     pairs = [(36, 35), (48, 127), (60, 80), (72, 65), (91, 110), (96, 20)]
     audio = ow.batch_render([{"note": n, "velocity": v} for n, v in pairs], sample_rate=sr, duration_s=2.0)
-    got = features.extract_model_features(audio, sr, pairs)
+    got = features.extract_model_features(audio, sr, pairs)          # default: through the 24-bit WAV quantiser, like the script
+    raw = features.extract_model_features(audio, sr, pairs, wav24=None)
     assert list(got) == pairs
+    assert any(got[p]["windows"]["sustain"]["amps_linear"] != raw[p]["windows"]["sustain"]["amps_linear"] for p in pairs)
     for j, (midi, vel) in enumerate(pairs):
-        ref = fo.model_features(audio[j], sr, midi, vel)
+        r0 = fo.model_features(audio[j], sr, midi, vel)
+        assert np.allclose(raw[(midi, vel)]["windows"]["sustain"]["amps_linear"], r0["windows"]["sustain"]["amps_linear"], rtol=0, atol=1.01e-8)
+        ref = fo.model_features(fo.quantize_round(audio[j]) / 8388608.0, sr, midi, vel)   # what soundfile reads back from the WAV
         f = got[(midi, vel)]
         assert f["midi_note"] == midi and f["velocity_midi"] == vel and f["f0"] == ref["f0"] and f["duration_s"] == ref["duration_s"]
         for name in ("attack", "early_sustain", "sustain"):
@@ -115,8 +119,8 @@ def test_features_full_size_properties(hiplib):
             if f0 * h < sr / 2:
                 x += (v / 127.0) / h ** 1.5 * np.exp(-t * (2.0 + 0.5 * h)) * np.sin(2 * np.pi * f0 * h * t + 0.3 * h)
         audio[j] = 0.2 * x
-    a1 = features.extract_model_features(audio, sr, pairs)
-    a2 = features.extract_model_features(0.5 * audio, sr, pairs)
+    a1 = features.extract_model_features(audio, sr, pairs, wav24=None)
+    a2 = features.extract_model_features(0.5 * audio, sr, pairs, wav24=None)
     for key in (pairs[0], pairs[100], pairs[300], pairs[-1]):
         w1, w2 = a1[key]["windows"]["sustain"], a2[key]["windows"]["sustain"]
         assert w1["freqs_hz"] == w2["freqs_hz"]
