@@ -99,8 +99,13 @@ void ow_engine_set_volume(ow_engine*, double v);                                
 void ow_engine_set_tremolo_depth(ow_engine*, double depth);                       /* set_tremolo_depth       :382 */
 void ow_engine_set_speaker_character(ow_engine*, double c);                       /* set_speaker_character   :386 */
 void ow_engine_set_mlp_enabled(ow_engine*, int on);                               /* set_mlp_enabled         :390 */
-void ow_engine_set_noise_enabled(ow_engine*, int on);                             /* set_noise_enabled       :394 (no-op on legacy preamp) */
-void ow_engine_set_noise_gain(ow_engine*, double gain);                           /* set_noise_gain          :398 (no-op on legacy preamp) */
+void ow_engine_set_noise_enabled(ow_engine*, int on);                             /* set_noise_enabled       :394 (melange preamp; no-op on legacy) */
+void ow_engine_set_noise_gain(ow_engine*, double gain);                           /* set_noise_gain          :398 (-> set_thermal_gain; no-op on legacy) */
+/* gen_preamp::CircuitState::set_seed (gen_preamp.rs:2094-2100) of this engine's main preamp state: restarts its 11 thermal-noise
+ * streams from `seed` (0 = the process-wide clock entropy every engine starts from, like the reference) and clears the lag.  Not
+ * reachable through WurliEngine in the reference (whose noise is therefore never reproducible); exported so parity can be tested.
+ * Survives reset / set_sample_rate.  No-op on the legacy preamp. */
+void ow_engine_set_noise_seed(ow_engine*, uint64_t seed);
 void ow_engine_render(ow_engine*, float* out, size_t len);                        /* render                  :425 (pool-of-one only) */
 void ow_engine_get_diag(const ow_engine*, ow_diag* out);
 int ow_engine_slot_state(const ow_engine*, int slot);                             /* VoiceSlot.state              */

@@ -77,6 +77,7 @@ SYMBOLS = {
     "ow_engine_set_mlp_enabled": (None, [_VP, C.c_int]),
     "ow_engine_set_noise_enabled": (None, [_VP, C.c_int]),
     "ow_engine_set_noise_gain": (None, [_VP, C.c_double]),
+    "ow_engine_set_noise_seed": (None, [_VP, C.c_uint64]),
     "ow_engine_render": (None, [_VP, _VP, C.c_size_t]),
     "ow_engine_get_diag": (None, [_VP, C.POINTER(OwDiag)]),
     "ow_engine_slot_state": (C.c_int, [_VP, C.c_int]),

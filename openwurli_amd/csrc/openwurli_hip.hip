@@ -4,6 +4,7 @@
 // everything that touches audio samples runs in the gfx950 kernels of ow_kernels.h.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +30,17 @@ namespace {
 
 thread_local std::string g_err;
 void set_err(const std::string& s) { g_err = s; }
+
+// Master seed 0 of the reference = "entropy from the system clock" (gen_preamp.rs:1512-1521), taken once per process because
+// every preamp clones one cached state (melange_adapter.rs:12-29).  OW_NOISE_SEED overrides it (reproducible runs).
+uint64_t process_noise_seed() {
+    static const uint64_t seed = []() -> uint64_t {
+        if (const char* env = std::getenv("OW_NOISE_SEED")) { const unsigned long long v = std::strtoull(env, nullptr, 0); if (v) return (uint64_t)v; }
+        const uint64_t t = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+        return t ? t : (uint64_t)0x0123456789ABCDEFull;
+    }();
+    return seed;
+}
 
 #define HIP_OK(expr)                                                                                   \
     do {                                                                                               \
@@ -86,6 +98,8 @@ struct ow_engine {
     }
     uint64_t age_counter = 0;
     bool sustain_held = false, mlp_enabled = true;
+    bool noise_on = false;          // melange preamp thermal noise (engine.rs:394-400); DkPreamp::new starts with off / 1.0
+    double thermal_gain = 1.0;
     HostSmoother volume{0.5}, depth{0.5}, spk{0.0};
     uint64_t nan_guard_fires = 0, output_nan_resets = 0;
     std::vector<OwOp> ops;  // pending slot ops, applied at the start of the next render
@@ -122,6 +136,7 @@ struct ow_pool {
     double* d_vrec = nullptr;
     double* d_cs = nullptr;
     double* d_mel_settled = nullptr;  // melange preamp: settled codegen-rate state (18 doubles)
+    double* d_noise = nullptr;        // melange preamp: thermal-noise state of the main solver states, [NZ_COUNT][I]
     double* d_sum = nullptr;
     double* d_rbuf = nullptr;
     double* d_pre = nullptr;
@@ -226,7 +241,7 @@ void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<do
         i = j;
     }
     if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)   // DkPreamp::new / reset of the melange adapter: settled state at the chain rate
-        owdev::k_mel_init<<<dim3((2 * ne + 63) / 64), dim3(64), 0, p->stream>>>(p->d_cs, p->d_mel_settled, I, e0, ne);
+        owdev::k_mel_init<<<dim3((2 * ne + 63) / 64), dim3(64), 0, p->stream>>>(p->d_cs, p->d_mel_settled, p->d_noise, I, e0, ne);
     const int blocks = (ne + 63) / 64;
     owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, I, e0, ne, 50LL);
     const long long n_settle = (long long)owhip::sat_u32(p->hc.os_sr * 2.0);
@@ -311,6 +326,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
                 ow_engine* en = p->engines[e0 + k];
                 // engine.rs:471-473: a Free slot renders nothing unless it still carries a steal voice
                 a.main_mask = en->main_mask; a.steal_mask = en->steal_mask;
+                a.noise_on = en->noise_on ? 1u : 0u; a.thermal_gain = en->thermal_gain;
                 a.op_begin = (uint32_t)op_pos;
                 a.op_count = (uint32_t)en->ops.size();
                 if (!en->ops.empty()) std::memcpy(p->h_ops + op_pos, en->ops.data(), sizeof(OwOp) * en->ops.size());
@@ -376,7 +392,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[3], st));
     if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)
         owdev::k_preamp_mel<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
-                                                                      p->d_pre, I, L, Lcap, e0, ne);
+                                                                      p->d_pre, p->d_noise, I, L, Lcap, e0, ne);
     else
         owdev::k_preamp<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, rb_now, p->d_pre, I, L, Lcap, e0, ne);
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[4], st));
@@ -519,6 +535,13 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     if (preamp_kind == OW_PREAMP_MELANGE12) {
         HIP_OK(hipMalloc(&p->d_mel_settled, sizeof(double) * 18));
         mel_settled_to_device(device, p->d_mel_settled, p->stream);
+        // Noise streams: the reference clones one process-wide state whose RNGs were seeded from the clock (master seed 0,
+        // gen_preamp.rs:1512-1521 via melange_adapter.rs:12-29), so every engine of a process starts on the same streams.
+        HIP_OK(hipMalloc(&p->d_noise, sizeof(double) * NZ_COUNT * n_engines));
+        HIP_OK(hipMemsetAsync(p->d_noise, 0, sizeof(double) * NZ_COUNT * n_engines, p->stream));
+        std::vector<uint64_t> seeds(n_engines, process_noise_seed());
+        HIP_OK(hipMemcpyAsync(p->d_noise + (size_t)NZ_SEED * n_engines, seeds.data(), sizeof(uint64_t) * n_engines, hipMemcpyHostToDevice, p->stream));
+        HIP_OK(hipStreamSynchronize(p->stream));
     }
     p->engines.resize(n_engines);
     p->dirty.assign(n_engines, 1);
@@ -534,6 +557,8 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     chain_init_range(p, 0, 1, INIT_NEW, std::vector<double>(1, 0.5));
     if (n_engines > 1)
         owdev::k_chain_replicate<<<dim3((unsigned)((n_engines + 63) / 64)), dim3(64), 0, p->stream>>>(p->d_cs, (int)n_engines, 0, 0, (int)n_engines);
+    if (p->d_noise)   // the replicated chain state does not carry the noise columns: seed every engine's streams
+        owdev::k_mel_noise_seed<<<dim3((unsigned)((n_engines + 63) / 64)), dim3(64), 0, p->stream>>>(p->d_noise, (int)n_engines, 0, (int)n_engines);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(p->stream));
     return p;
@@ -546,6 +571,7 @@ void pool_destroy(ow_pool* p) {
     free_stream_buffers(p);
     hipFree(p->dK); hipFree(p->dK48); hipFree(p->d_nt); hipFree(p->d_vrec); hipFree(p->d_cs);
     if (p->d_mel_settled) hipFree(p->d_mel_settled);
+    if (p->d_noise) hipFree(p->d_noise);
     hipFree(p->d_args); hipFree(p->d_eout);
     if (p->d_ops) hipFree(p->d_ops);
     if (p->h_ops) hipHostFree(p->h_ops);
@@ -586,7 +612,11 @@ int ow_pool_set_sample_rate(ow_pool* p, double sr) {
     try {
         HIP_OK(hipSetDevice(p->device));
         upload_consts(p, sr, p->hc.preamp_kind);
-        for (ow_engine* en : p->engines) en->sr = sr;
+        for (ow_engine* en : p->engines) {
+            en->sr = sr;
+            en->noise_on = false; en->thermal_gain = 1.0;   // set_sample_rate builds a new DkPreamp (engine.rs:276): noise off, gain 1.0
+            en->touch();
+        }
         // voices keep their records (the reference keeps Voice objects too, engine.rs:272-286), chain objects are rebuilt
         std::vector<double> d0(p->I);
         for (size_t i = 0; i < p->I; ++i) d0[i] = p->engines[i]->depth.target;
@@ -774,8 +804,26 @@ void ow_engine_set_volume(ow_engine* e, double v) { if (e) { e->volume.set_targe
 void ow_engine_set_tremolo_depth(ow_engine* e, double d) { if (e) { e->depth.set_target(d); if (e->depth.pending) e->touch(); } }
 void ow_engine_set_speaker_character(ow_engine* e, double c) { if (e) { e->spk.set_target(c); if (e->spk.pending) e->touch(); } }
 void ow_engine_set_mlp_enabled(ow_engine* e, int on) { if (e) e->mlp_enabled = on != 0; }
-void ow_engine_set_noise_enabled(ow_engine*, int) {}   // dk_preamp_legacy.rs:262: no-op on the legacy preamp
-void ow_engine_set_noise_gain(ow_engine*, double) {}   // dk_preamp_legacy.rs:265
+// Thermal noise of the melange preamp's main state; no-ops on the legacy solver (dk_preamp_legacy.rs:262-265)
+void ow_engine_set_noise_enabled(ow_engine* e, int on) {
+    if (!e || !e->pool || e->pool->hc.preamp_kind != OW_PREAMP_MELANGE12) return;
+    if (e->noise_on != (on != 0)) { e->noise_on = on != 0; e->touch(); }
+}
+void ow_engine_set_noise_gain(ow_engine* e, double gain) {
+    if (!e || !e->pool || e->pool->hc.preamp_kind != OW_PREAMP_MELANGE12) return;
+    if (e->thermal_gain != gain) { e->thermal_gain = gain; e->touch(); }
+}
+void ow_engine_set_noise_seed(ow_engine* e, uint64_t seed) {
+    if (!e || !e->pool || !e->pool->d_noise) return;
+    guarded("ow_engine_set_noise_seed", [&] {
+        ow_pool* p = e->pool;
+        HIP_OK(hipSetDevice(p->device));
+        const uint64_t resolved = seed ? seed : process_noise_seed();
+        HIP_OK(hipMemcpyAsync(p->d_noise + (size_t)NZ_SEED * p->I + e->index, &resolved, sizeof resolved, hipMemcpyHostToDevice, p->stream));
+        owdev::k_mel_noise_seed<<<dim3(1), dim3(64), 0, p->stream>>>(p->d_noise, (int)p->I, (int)e->index, 1);
+        HIP_OK(hipStreamSynchronize(p->stream));
+    });
+}
 
 void ow_engine_render(ow_engine* e, float* out, size_t len) {
     if (!e || !out || len == 0) return;

@@ -250,6 +250,7 @@ static void build_melange_consts(OwConsts& c) {
     for (int i = 0; i < 12; ++i) { c.m_u[i] = c.m_s0[i][6]; c.m_w[i] = c.m_s0[6][i]; }
     c.m_s66 = c.m_s0[6][6];
     c.m_g_nom = PRE_POT_0_G_NOM;
+    c.m_noise_scale = std::sqrt(8.0 * 1.380649e-23 * 290.0 * (rate * 1.0));   // noise_fs = sample_rate * OVERSAMPLING_FACTOR
     for (int j = 0; j < 3; ++j) {
         double sum = 0.0;
         for (int k = 0; k < 12; ++k) sum += c.m_w[k] * PRE_N_I[j][k];

@@ -15,7 +15,7 @@
 // The BE-fallback matrices are never rebuilt by the reference (gen_preamp.rs:2058-2061): codegen tables.
 //
 // Mirrors gen_preamp.rs:1973-1984 (set_runtime_R), :3041-3095 (build_rhs), :3122-3357 (solve_nonlinear),
-// :3399-3663 (process_sample), dk_preamp/melange_adapter.rs:12-94.  Thermal noise (off by default) is not built.
+// :3399-3663 (process_sample), dk_preamp/melange_adapter.rs:12-94; thermal noise :1434-1561, 3433-3461, 3522-3535.
 #pragma once
 #include "ow_kernels.h"
 
@@ -158,8 +158,95 @@ __device__ inline uint32_t mel_solve_nl(const double p[3], const double kk[3][3]
     return 265u;
 }
 
+
+// ---- thermal noise of the main state (gen_preamp.rs:1465-1561).  `nz` points at this engine's column of a [NZ_COUNT][stride]
+// array of f64 bit patterns: the global noise buffer (stride I) or the block's LDS copy (stride 32).  Out of line: the path is
+// off by default and must not cost the noise-free loop registers.
+__device__ inline uint64_t nz_splitmix64(uint64_t& st) {                     // :1493-1499
+    st += 0x9E3779B97F4A7C15ull;
+    uint64_t z = st;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// set_seed / the RNG half of reset (:1865-1874, 2094-2100): streams from the engine's master seed, caches and lag cleared
+__device__ __noinline__ void nz_reseed(double* nz, int stride) {
+    uint64_t sm = dbits(nz[(size_t)NZ_SEED * stride]);
+    (void)nz_splitmix64(sm);
+    for (int k = 0; k < 11; ++k) {
+        uint64_t s4[4];
+        for (int q = 0; q < 4; ++q) s4[q] = nz_splitmix64(sm);
+        if (!(s4[0] | s4[1] | s4[2] | s4[3])) s4[0] = 1;
+        for (int q = 0; q < 4; ++q) nz[(size_t)(NZ_RNG + 4 * k + q) * stride] = bitsd(s4[q]);
+        nz[(size_t)(NZ_CACHE + k) * stride] = 0.0;
+        nz[(size_t)(NZ_WPREV + k) * stride] = 0.0;
+        nz[(size_t)(NZ_LAST + k) * stride] = 0.0;
+    }
+    nz[(size_t)NZ_VALID * stride] = bitsd(0ull);
+}
+__device__ __noinline__ void nz_clear_lag(double* nz, int stride) {               // NaN reset of process_sample (:3625-3627)
+    for (int k = 0; k < 11; ++k) { nz[(size_t)(NZ_WPREV + k) * stride] = 0.0; nz[(size_t)(NZ_LAST + k) * stride] = 0.0; }
+}
+__device__ inline double nz_next_f64(double* nz, int stride, int k) {        // xoshiro256++ (:1467-1489)
+    uint64_t s0 = dbits(nz[(size_t)(NZ_RNG + 4 * k) * stride]), s1 = dbits(nz[(size_t)(NZ_RNG + 4 * k + 1) * stride]);
+    uint64_t s2 = dbits(nz[(size_t)(NZ_RNG + 4 * k + 2) * stride]), s3 = dbits(nz[(size_t)(NZ_RNG + 4 * k + 3) * stride]);
+    const uint64_t sum = s0 + s3;
+    const uint64_t result = ((sum << 23) | (sum >> 41)) + s0;
+    const uint64_t t = s1 << 17;
+    s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;
+    s2 ^= t;
+    s3 = (s3 << 45) | (s3 >> 19);
+    nz[(size_t)(NZ_RNG + 4 * k) * stride] = bitsd(s0); nz[(size_t)(NZ_RNG + 4 * k + 1) * stride] = bitsd(s1);
+    nz[(size_t)(NZ_RNG + 4 * k + 2) * stride] = bitsd(s2); nz[(size_t)(NZ_RNG + 4 * k + 3) * stride] = bitsd(s3);
+    return (double)(result >> 11) * (1.0 / 9007199254740992.0);
+}
+// One sample of the two-draw thermal stamp (:3433-3452): i_n[k] = w_new + w_prev into NZ_LAST, w_prev <- w_new.
+__device__ __noinline__ void nz_draw(double* nz, int stride, double scale_half, double sqrt_inv_r10) {
+    uint64_t valid = dbits(nz[(size_t)NZ_VALID * stride]);
+    for (int k = 0; k < 11; ++k) {
+        double g;
+        if ((valid >> k) & 1ull) {                                            // Marsaglia polar: cached second value (:1547-1561)
+            valid &= ~(1ull << k);
+            g = nz[(size_t)(NZ_CACHE + k) * stride];
+        } else {
+            // The reference loops until a pair falls inside the unit disc (p = pi/4 per try).  Bounded here so that a corrupt
+            // (all-zero) generator state can never hang a wavefront: 128 rejections in a row have probability 1e-86.
+            g = 0.0;
+            for (int tries = 0; tries < 128; ++tries) {
+                const double u = 2.0 * nz_next_f64(nz, stride, k) - 1.0;
+                const double v = 2.0 * nz_next_f64(nz, stride, k) - 1.0;
+                const double ss = u * u + v * v;
+                if (ss > 0.0 && ss < 1.0) {
+                    const double factor = sqrt(-2.0 * log(ss) / ss);
+                    nz[(size_t)(NZ_CACHE + k) * stride] = v * factor;
+                    valid |= 1ull << k;
+                    g = u * factor;
+                    break;
+                }
+            }
+        }
+        const double sir = k == 10 ? sqrt_inv_r10 : PRE_NOISE_THERMAL_SQRT_INV_R_DEFAULT[k];
+        const double w_new = scale_half * sir * g;
+        const double i_n = w_new + nz[(size_t)(NZ_WPREV + k) * stride];
+        nz[(size_t)(NZ_WPREV + k) * stride] = w_new;
+        nz[(size_t)(NZ_LAST + k) * stride] = i_n;
+    }
+    nz[(size_t)NZ_VALID * stride] = bitsd(valid);
+}
+// rhs[ni-1] += i_n; rhs[nj-1] -= i_n for the 11 sources in order (:3443-3451); indices are compile-time after unrolling
+__device__ inline void nz_stamp(double rhs[12], const double* nz, int stride) {
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const double i_n = nz[(size_t)(NZ_LAST + k) * stride];
+        const int ni = (int)PRE_NOISE_THERMAL_NODE_I[k], nj = (int)PRE_NOISE_THERMAL_NODE_J[k];
+        if (ni > 0) rhs[ni - 1] += i_n;
+        if (nj > 0) rhs[nj - 1] -= i_n;
+    }
+}
+
 // Backward-Euler fallback (gen_preamp.rs:3483-3572) with the never-rebuilt 48 kHz / 100 kOhm codegen tables.
-__device__ __noinline__ uint32_t mel_be_fallback(const MelSt& st, double input, double vn[12], double i_nl[3]) {
+// nz != nullptr: replay of this sample's thermal stamp (:3522-3535).
+__device__ __noinline__ uint32_t mel_be_fallback(const MelSt& st, double input, double vn[12], double i_nl[3], const double* nz, int nz_stride) {
     double rhs[12], vp[12], p[3];
     for (int i = 0; i < 12; ++i) {
         double sum = PRE_RHS_CONST_BE[i];
@@ -168,6 +255,13 @@ __device__ __noinline__ uint32_t mel_be_fallback(const MelSt& st, double input, 
         rhs[i] = sum;
     }
     rhs[0] += input / PRE_INPUT_RESISTANCE;
+    if (nz)
+        for (int k = 0; k < 11; ++k) {
+            const double i_n = nz[(size_t)(NZ_LAST + k) * nz_stride];
+            const int ni = (int)PRE_NOISE_THERMAL_NODE_I[k], nj = (int)PRE_NOISE_THERMAL_NODE_J[k];
+            if (ni > 0) rhs[ni - 1] += i_n;
+            if (nj > 0) rhs[nj - 1] -= i_n;
+        }
     for (int i = 0; i < 12; ++i) {
         double sum = 0.0;
         for (int j = 0; j < 12; ++j) sum += PRE_S_BE_DEFAULT[i][j] * rhs[j];
@@ -189,8 +283,9 @@ __device__ __noinline__ uint32_t mel_be_fallback(const MelSt& st, double input, 
     return it;
 }
 
-// gen_preamp::process_sample (gen_preamp.rs:3399-3663), noise disabled.  Returns the OUT node voltage.
-__device__ inline double mel_process(MelSt& st, double input_in, const MelMats* __restrict__ M) {
+// gen_preamp::process_sample (gen_preamp.rs:3399-3663).  Returns the OUT node voltage.
+// nz: this sample's thermal stamp (already drawn into NZ_LAST by nz_draw) or nullptr when the state draws no noise.
+__device__ inline double mel_process(MelSt& st, double input_in, const MelMats* __restrict__ M, const double* nz = nullptr, int nz_stride = 0) {
     const double input = isfinite(input_in) ? clampd(input_in, -100.0, 100.0) : 0.0;
     // rank-one factor of the current R_ldr (replaces the lazy rebuild_matrices of the reference)
     const double dg = 1.0 / st.pot - M->g_nom;
@@ -225,6 +320,7 @@ __device__ inline double mel_process(MelSt& st, double input_in, const MelMats* 
     rhs[7] += PRE_N_I[2][7] * st.ip[2];
     rhs[8] += PRE_N_I[2][8] * st.ip[2];
     rhs[0] += (input + st.input_prev) / PRE_INPUT_RESISTANCE;
+    if (nz) nz_stamp(rhs, nz, nz_stride);
     // v_pred = S(R) rhs = S0 rhs - c u (w . rhs)
     double wr = 0.0;
 #pragma unroll
@@ -262,7 +358,7 @@ __device__ inline double mel_process(MelSt& st, double input_in, const MelMats* 
     if (nr_failed || ringing || force_be) {
         if (ringing || nr_failed) st.be_cooldown = 64u;
         st.be_fallbacks += 1u;
-        last_it = mel_be_fallback(st, input, vn, i_nl);
+        last_it = mel_be_fallback(st, input, vn, i_nl, nz, nz_stride);
     }
     {   // voltage-damp net (gen_preamp.rs:3576-3613); threshold = fma(max|DC_OP|, 0.05, 2.0), the path's one explicit mul_add
         double max_delta = 0.0;
@@ -360,22 +456,30 @@ __global__ __launch_bounds__(64) void k_mel_settle(const OwConsts* __restrict__ 
 }
 
 // DkPreamp::new / reset for engines [e0, e0+ne): both states from the settled state
-__global__ __launch_bounds__(64) void k_mel_init(double* __restrict__ cs, const double* __restrict__ settled, int I, int e0, int ne) {
+__global__ __launch_bounds__(64) void k_mel_init(double* __restrict__ cs, const double* __restrict__ settled, double* __restrict__ noise, int I,
+                                                 int e0, int ne) {
     const int t = blockIdx.x * 64 + threadIdx.x;
     if (t >= 2 * ne) return;
     const int e = e0 + (t % ne), role = t / ne;
     MelSt st;
     mel_init_state(st, settled);
     mel_store(st, cs, I, e, role ? CS_M_SHADOW : CS_M_MAIN);
+    if (role == 0 && noise) nz_reseed(noise + e, I);   // a fresh state restarts its noise streams from the engine's master seed
+}
+// gen_preamp::set_seed for engines [e0, e0+ne): NZ_SEED was written by the host
+__global__ __launch_bounds__(64) void k_mel_noise_seed(double* __restrict__ noise, int I, int e0, int ne) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t < ne) nz_reseed(noise + e0 + t, I);
 }
 
 // Preamp stream with the melange solver: same staging / lane-pair structure as k_preamp.
 __global__ __launch_bounds__(64) void k_preamp_mel(const OwConsts* __restrict__ K, double* __restrict__ cs,
                                                    const double* __restrict__ settled, const OwEngineArgs* __restrict__ args,
                                                    const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const double* __restrict__ rbuf,
-                                                   double* __restrict__ pre, int I, int L, int Lcap, int e0, int ne) {
+                                                   double* __restrict__ pre, double* __restrict__ noise, int I, int L, int Lcap, int e0, int ne) {
     __shared__ double tile[32 * (OW_PCHUNK + 1)];
     __shared__ MelMats M;
+    __shared__ double NZL[NZ_COUNT * 32];   // thermal-noise columns of the block's 32 main states (used only when some engine has noise on)
     mel_mats_load(&M, K, threadIdx.x, 64);
     __syncthreads();
     const int lane = threadIdx.x;
@@ -402,6 +506,18 @@ __global__ __launch_bounds__(64) void k_preamp_mel(const OwConsts* __restrict__ 
         }
     }
     uint32_t adapter_resets = 0;
+    // thermal noise: only the main state draws (melange_adapter.rs:50-57); block-rate switch and gain (engine.rs:394-400)
+    const bool nz_mine = noise != nullptr && valid && role == 0;
+    const bool nz_on = nz_mine && args[ec].noise_on != 0u;
+    const double scale_half = K->m_noise_scale * 1.0 * args[ec].thermal_gain * 0.5;   // scale * noise_gain * thermal_gain * 0.5 (:3435)
+    const bool nz_loaded = nz_on;          // the column lives in LDS for the block
+    double* nzcol = NZL + el;
+    bool nz_need_reseed = false, nz_need_clear = false;
+    if (nz_loaded)
+        for (int r = 0; r < NZ_COUNT; ++r) nzcol[r * 32] = noise[(size_t)r * I + e];
+    if (nz_mine && (dbits(CSF(CS_FLAGS)) & 1ull)) {   // the deferred preamp.reset() above re-created the main state
+        if (nz_loaded) nz_reseed(nzcol, 32); else nz_need_reseed = true;
+    }
     for (int base = 0; base < L; base += OW_PCHUNK) {
         const int cn = min(OW_PCHUNK, L - base);
         for (int r = 0; r < 32; ++r) {
@@ -432,11 +548,23 @@ __global__ __launch_bounds__(64) void k_preamp_mel(const OwConsts* __restrict__ 
                 mel_set_r(st, trem_shunt(depth, rbuf[s_idx * I + ec]));            // tremolo.rs:152-167; melange_adapter.rs:82-85
                 int z = 0;
                 asm volatile("" : "+v"(z));                                        // keep the LDS constant reads inside the loop
-                const double o = mel_process(st, in[j], &M + z);
+                const double* nzp = nullptr;
+                if (nz_on && scale_half != 0.0) {
+                    // sqrt(1/R) of the LDR source follows set_runtime_R (:1983); the untouched nominal pot keeps the baked literal
+                    const double sir10 = st.pot == 9.99999999999999854e4 ? PRE_NOISE_THERMAL_SQRT_INV_R_DEFAULT[10] : sqrt(1.0 / st.pot);
+                    nz_draw(nzcol, 32, scale_half, sir10);
+                    nzp = nzcol;
+                }
+                const uint32_t nan_before = st.nan_resets;
+                const double o = mel_process(st, in[j], &M + z, nzp, 32);
+                if (nz_mine && st.nan_resets != nan_before) {                      // process_sample's NaN reset clears the lag (:3625-3627)
+                    if (nz_loaded) nz_clear_lag(nzcol, 32); else nz_need_clear = true;
+                }
                 const double other = __shfl_xor(o, 32);
                 double result = role ? (other - o) : (o - other);                  // main - pump (:74-76)
-                if (!isfinite(result)) {                                           // :77-80
+                if (!isfinite(result)) {                                           // :77-80, reset(): both states from init_state
                     mel_init_state(st, settled);
+                    if (nz_mine) { if (nz_loaded) nz_reseed(nzcol, 32); else nz_need_reseed = true; }
                     result = 0.0;
                     adapter_resets += 1u;
                 }
@@ -444,6 +572,12 @@ __global__ __launch_bounds__(64) void k_preamp_mel(const OwConsts* __restrict__ 
             }
         }
         __syncthreads();
+    }
+    if (nz_loaded) {
+        for (int r = 0; r < NZ_COUNT; ++r) noise[(size_t)r * I + e] = nzcol[r * 32];
+    } else if (nz_mine) {
+        if (nz_need_reseed) nz_reseed(noise + e, I);
+        else if (nz_need_clear) nz_clear_lag(noise + e, I);
     }
     if (valid) {
         mel_store(st, cs, I, e, role ? CS_M_SHADOW : CS_M_MAIN);

@@ -129,9 +129,22 @@ struct OwConsts {
     // Field order = struct MelMats (ow_melange_dev.h), copied to LDS as one block.
     double m_s0[12][12], m_aneg0[12][12], m_k0[3][3], m_sni0[12][3];
     double m_u[12], m_w[12], m_wn[3], m_nvu[3], m_s66, m_g_nom;
+    double m_noise_scale;    // sqrt(8 k_B T fs_chain), T = 290 K (gen_preamp.rs:1752,1936)
 };
 
 // per-engine per-render parameters (host -> device)
+// Thermal-noise state of the melange preamp's main solver state, one column per engine in a separate [NZ_COUNT][I] buffer
+// (gen_preamp.rs:1708-1745): 11 xoshiro256++ streams, Marsaglia-polar second values, two-draw lag, BE-replay cache.
+enum OwNoiseRow {
+    NZ_RNG = 0,        // [11][4] u64 bit patterns
+    NZ_CACHE = 44,     // [11] cached second gaussian
+    NZ_WPREV = 55,     // [11] previous draw (Nyquist-zeroing two-draw stamp)
+    NZ_LAST = 66,      // [11] last stamped i_n (replayed by the BE fallback)
+    NZ_VALID = 77,     // bit k: NZ_CACHE[k] holds a value
+    NZ_SEED = 78,      // u64 master seed of this engine (already resolved: never 0)
+    NZ_COUNT = 79
+};
+
 struct OwEngineArgs {
     uint64_t main_mask;      // slots with a voice
     uint64_t steal_mask;     // slots with a steal voice
@@ -139,5 +152,6 @@ struct OwEngineArgs {
     // setter targets accepted since the last render (LinearSmoother::set_target, engine.rs:86-99)
     double depth_target, spk_target, vol_target;
     uint32_t set_flags;      // bit0 depth, bit1 spk, bit2 vol
-    uint32_t pad;
+    uint32_t noise_on;       // melange preamp thermal noise enabled (engine.rs:394; block-rate, persists)
+    double thermal_gain;     // set_noise_gain -> set_thermal_gain (engine.rs:398-399)
 };

@@ -57,6 +57,10 @@ class _EngineHandle:
     def set_noise_gain(self, g):
         self._lib.ow_engine_set_noise_gain(self._h, float(g))
 
+    def set_noise_seed(self, seed):
+        """gen_preamp::set_seed of the melange preamp's main state (0 = process-wide clock entropy, the reference's only mode)."""
+        self._lib.ow_engine_set_noise_seed(self._h, int(seed))
+
     def reset(self):
         self._lib.ow_engine_reset(self._h)
 

@@ -219,6 +219,10 @@ struct WurliEngine {
     void set_tremolo_depth(double d) { tremolo_depth.set_target(d); }
     void set_speaker_character(double c) { speaker_character.set_target(c); }
     void set_mlp_enabled(bool on) { mlp_enabled = on; }
+    // engine.rs:394-400: thermal noise of the melange preamp (no-ops on the legacy solver)
+    void set_noise_enabled(bool on) { if (preamp_kind) mel.set_noise_enabled(on); }
+    void set_noise_gain(double g) { if (preamp_kind) mel.set_thermal_gain(g); }
+    void set_noise_seed(uint64_t seed) { if (preamp_kind) mel.set_noise_seed(seed); }   // extension (gen_preamp::set_seed, not reachable through WurliEngine)
 
     // engine.rs:425-462
     void render(float* out, size_t len) {

@@ -18,6 +18,7 @@
 #include "ow_tremolo.hpp"   // fast_exp, pnjlim (identical text in both generated files)
 #include <cmath>
 
+#include <chrono>
 namespace owo {
 
 constexpr int PN = 12, PM = 3;
@@ -30,6 +31,76 @@ struct MelState {
     double s_be[PN][PN], k_be[PM][PM], s_ni_be[PN][PM], a_neg_be[PN][PN];
     double pot_0_resistance, current_sample_rate;
     bool matrices_dirty;
+    // ---- authentic circuit noise, phase 1 = thermal (gen_preamp.rs:1434-1561, state :1708-1745) ----
+    struct Xoshiro256pp {   // :1465-1490
+        uint64_t s[4];
+        static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+        uint64_t next_u64() {
+            const uint64_t result = rotl(s[0] + s[3], 23) + s[0];
+            const uint64_t t = s[1] << 17;
+            s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+            s[2] ^= t;
+            s[3] = rotl(s[3], 45);
+            return result;
+        }
+        double next_f64() { return (double)(next_u64() >> 11) * (1.0 / (double)(1ull << 53)); }
+    };
+    static constexpr int NT = 11;                       // NOISE_THERMAL_N
+    Xoshiro256pp noise_rng[NT];
+    bool noise_cache_valid[NT];
+    double noise_cache[NT];
+    bool noise_enabled;
+    double noise_gain, thermal_gain, temperature_k;
+    uint64_t noise_master_seed;
+    double noise_thermal_scale, noise_fs;
+    double noise_sqrt_inv_r[NT], noise_w_prev[NT], noise_last_i_n[NT];
+
+    static uint64_t splitmix64(uint64_t& st) {          // :1493-1499
+        st += 0x9E3779B97F4A7C15ull;
+        uint64_t z = st;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    // master == 0 draws entropy from the system clock in the reference (:1512-1521); the oracle does the same once per process
+    static uint64_t entropy_seed() {
+        static const uint64_t e = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                                      std::chrono::system_clock::now().time_since_epoch()).count();
+        return e ? e : 0x0123456789ABCDEFull;
+    }
+    void seed_noise_rngs(uint64_t master) {             // seed_noise_rngs_salted(master, 0), :1511-1536
+        uint64_t sm = master == 0 ? entropy_seed() : master;
+        (void)splitmix64(sm);
+        for (int k = 0; k < NT; ++k) {
+            for (int q = 0; q < 4; ++q) noise_rng[k].s[q] = splitmix64(sm);
+            if (!(noise_rng[k].s[0] | noise_rng[k].s[1] | noise_rng[k].s[2] | noise_rng[k].s[3])) noise_rng[k].s[0] = 1;
+        }
+    }
+    double gaussian(int k) {                            // Marsaglia polar, second value cached (:1547-1561)
+        if (noise_cache_valid[k]) { noise_cache_valid[k] = false; return noise_cache[k]; }
+        for (;;) {
+            const double u = 2.0 * noise_rng[k].next_f64() - 1.0;
+            const double v = 2.0 * noise_rng[k].next_f64() - 1.0;
+            const double ss = u * u + v * v;
+            if (ss > 0.0 && ss < 1.0) {
+                const double factor = std::sqrt(-2.0 * std::log(ss) / ss);
+                noise_cache[k] = v * factor; noise_cache_valid[k] = true;
+                return u * factor;
+            }
+        }
+    }
+    void noise_clear_lag() { for (int k = 0; k < NT; ++k) { noise_w_prev[k] = 0.0; noise_last_i_n[k] = 0.0; } }
+    void set_seed(uint64_t master) {                    // :2094-2100
+        noise_master_seed = master;
+        seed_noise_rngs(master);
+        for (int k = 0; k < NT; ++k) noise_cache_valid[k] = false;
+        noise_clear_lag();
+    }
+    static void noise_stamp(double rhs[PN], int k, double i_n) {   // :3443-3451
+        const int ni = (int)PRE_NOISE_THERMAL_NODE_I[k], nj = (int)PRE_NOISE_THERMAL_NODE_J[k];
+        if (ni > 0) rhs[ni - 1] += i_n;
+        if (nj > 0) rhs[nj - 1] -= i_n;
+    }
 
     void init_default() {  // gen_preamp.rs:1748-1821
         for (int i = 0; i < PN; ++i) v_prev[i] = PRE_DC_OP[i];
@@ -44,11 +115,21 @@ struct MelState {
         pot_0_resistance = 9.99999999999999854e4;
         current_sample_rate = PRE_SAMPLE_RATE;
         matrices_dirty = false;
+        noise_fs = PRE_SAMPLE_RATE * 1.0;                                   // SAMPLE_RATE * OVERSAMPLING_FACTOR
+        temperature_k = 290.0;
+        noise_thermal_scale = std::sqrt(8.0 * 1.380649e-23 * 290.0 * noise_fs);
+        noise_master_seed = 0;
+        seed_noise_rngs(0);
+        for (int k = 0; k < NT; ++k) { noise_cache_valid[k] = false; noise_cache[k] = 0.0; noise_sqrt_inv_r[k] = PRE_NOISE_THERMAL_SQRT_INV_R_DEFAULT[k]; }
+        noise_enabled = false; noise_gain = 1.0; thermal_gain = 1.0;
+        noise_clear_lag();
     }
 
     void set_sample_rate(double sr) {  // :1930-1961
         if (!(sr > 0.0 && std::isfinite(sr))) return;
         current_sample_rate = sr;
+        noise_fs = sr * 1.0;                                                // :1935-1936
+        noise_thermal_scale = std::sqrt(8.0 * 1.380649e-23 * temperature_k * noise_fs);
         if (std::fabs(sr - PRE_SAMPLE_RATE) < 0.5) {
             std::memcpy(s, PRE_S_DEFAULT, sizeof s); std::memcpy(a_neg, PRE_A_NEG_DEFAULT, sizeof a_neg);
             std::memcpy(k, PRE_K_DEFAULT, sizeof k); std::memcpy(s_ni, PRE_S_NI_DEFAULT, sizeof s_ni);
@@ -64,6 +145,7 @@ struct MelState {
         if (std::fabs(r - pot_0_resistance) < 1e-12) return;
         pot_0_resistance = r;
         matrices_dirty = true;
+        noise_sqrt_inv_r[10] = std::sqrt(1.0 / r);                          // :1983
     }
 
     static bool invert_n(const double a[PN][PN], double result[PN][PN]) {  // :2117-2219; returns singular flag
@@ -280,6 +362,24 @@ struct MelState {
         rhs[8] += PRE_N_I[2][8] * i_nl_prev[2];
         rhs[0] += (input + input_prev) / PRE_INPUT_RESISTANCE;
 
+        if (noise_enabled) {   // two-draw thermal stamp w_new + w_prev (:3433-3461)
+            const double scale_half = noise_thermal_scale * noise_gain * thermal_gain * 0.5;
+            if (scale_half != 0.0) {
+                for (int k = 0; k < NT; ++k) {
+                    const double g = gaussian(k);
+                    const double w_new = scale_half * noise_sqrt_inv_r[k] * g;
+                    const double i_n = w_new + noise_w_prev[k];
+                    noise_w_prev[k] = w_new;
+                    noise_last_i_n[k] = i_n;
+                    noise_stamp(rhs, k, i_n);
+                }
+            } else {
+                for (int k = 0; k < NT; ++k) noise_last_i_n[k] = 0.0;
+            }
+        } else {
+            for (int k = 0; k < NT; ++k) noise_last_i_n[k] = 0.0;
+        }
+
         double v_pred[PN];
         for (int i = 0; i < PN; ++i) {
             double sum = 0.0;
@@ -309,6 +409,8 @@ struct MelState {
                 rhs_be[i] = sum;
             }
             rhs_be[0] += input / PRE_INPUT_RESISTANCE;
+            if (noise_enabled)                                              // BE replay of the trap stamp (:3522-3535)
+                for (int k = 0; k < NT; ++k) noise_stamp(rhs_be, k, noise_last_i_n[k]);
             double v_pred_be[PN];
             for (int i = 0; i < PN; ++i) {
                 double sum = 0.0;
@@ -348,6 +450,7 @@ struct MelState {
             input_prev = 0.0;
             pot_0_resistance = 9.99999999999999854e4;
             be_cooldown = 0;
+            noise_clear_lag();                                              // :3625-3627 (RNG state preserved)
             diag_nan_reset_count += 1;
             return rclamp(PRE_DC_OP[10] * 1.0, -10.0, 10.0);
         }
@@ -364,6 +467,17 @@ struct MelState {
 struct MelangePreamp {
     MelState main, shadow;
     double sample_rate = 0;
+    bool noise_enabled = false;          // melange_adapter.rs:35-36,45-46
+    double thermal_gain = 1.0;
+    bool have_seed = false;              // extension mirrored by the HIP library: an explicit per-engine seed (gen_preamp::set_seed)
+    uint64_t seed = 0;
+    void set_noise_enabled(bool on) { noise_enabled = on; main.noise_enabled = on; }             // :54-57 (main only)
+    void set_thermal_gain(double g) { thermal_gain = g; main.thermal_gain = g; }                 // :65-68
+    void set_noise_seed(uint64_t s) { have_seed = true; seed = s; main.set_seed(s); }
+    void reapply_noise() {                                                                       // :91-92
+        main.noise_enabled = noise_enabled; main.thermal_gain = thermal_gain;
+        if (have_seed) main.set_seed(seed);
+    }
     static const MelState& settled() {
         static MelState st;
         static bool done = false;
@@ -379,7 +493,8 @@ struct MelangePreamp {
         if (std::fabs(sr - PRE_SAMPLE_RATE) > 0.5) s.set_sample_rate(sr);
         return s;
     }
-    void init(double sr) { sample_rate = sr; main = init_state(sr); shadow = init_state(sr); }
+    // DkPreamp::new (:40-48): noise off, gain 1.0 -- WurliEngine::set_sample_rate builds a new preamp and so drops both settings
+    void init(double sr) { sample_rate = sr; noise_enabled = false; thermal_gain = 1.0; main = init_state(sr); shadow = init_state(sr); reapply_noise(); }
     double process_sample(double input) {
         const double m = main.process_sample(input);
         const double pump = shadow.process_sample(0.0);
@@ -393,7 +508,7 @@ struct MelangePreamp {
 #endif
         main.set_runtime_r_ldr(r); shadow.set_runtime_r_ldr(r);
     }
-    void reset() { main = init_state(sample_rate); shadow = init_state(sample_rate); }
+    void reset() { main = init_state(sample_rate); shadow = init_state(sample_rate); reapply_noise(); }
 };
 
 }  // namespace owo

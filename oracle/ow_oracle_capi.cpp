@@ -30,6 +30,16 @@ void owo_engine_set_volume(void* e, double v) { ((WurliEngine*)e)->set_volume(v)
 void owo_engine_set_tremolo_depth(void* e, double v) { ((WurliEngine*)e)->set_tremolo_depth(v); }
 void owo_engine_set_speaker_character(void* e, double v) { ((WurliEngine*)e)->set_speaker_character(v); }
 void owo_engine_set_mlp_enabled(void* e, int on) { ((WurliEngine*)e)->set_mlp_enabled(on != 0); }
+void owo_engine_set_noise_enabled(void* e, int on) { ((WurliEngine*)e)->set_noise_enabled(on != 0); }
+void owo_engine_set_noise_gain(void* e, double g) { ((WurliEngine*)e)->set_noise_gain(g); }
+void owo_engine_set_noise_seed(void* e, unsigned long long seed) { ((WurliEngine*)e)->set_noise_seed((uint64_t)seed); }
+// KAT hook: first n u64 outputs of thermal stream k after seeding with `master`, and n gaussians of that stream
+void owo_noise_stream(unsigned long long master, int k, int n, unsigned long long* u64_out, double* gauss_out) {
+    owo::MelState st; st.init_default(); st.set_seed((uint64_t)master);
+    owo::MelState g = st;
+    for (int i = 0; i < n; ++i) u64_out[i] = st.noise_rng[k].next_u64();
+    for (int i = 0; i < n; ++i) gauss_out[i] = g.gaussian(k);
+}
 void owo_engine_render(void* e, float* out, size_t len) { ((WurliEngine*)e)->render(out, len); }
 // render + tap of the pre-chain voice sum (f64), for stage-wise parity tests
 void owo_engine_render_tap(void* e, float* out, double* voice_sum, size_t len) {
@@ -215,6 +225,17 @@ void owo_melange_run(double sr, const double* x, const double* r, double* y, siz
     for (size_t i = 0; i < n; ++i) {
         if (r) p->set_ldr_resistance(r[i]);
         y[i] = p->process_sample(x[i]);
+    }
+    delete p;
+}
+// same with the thermal noise of the main state on (seed != 0: deterministic), gain = thermal_gain
+void owo_melange_run_noise(double sr, const double* x, const double* r, double* y, size_t n, unsigned long long seed, double gain) {
+    MelangePreamp* p = new MelangePreamp();
+    p->init(sr);
+    p->set_noise_seed((uint64_t)seed); p->set_noise_enabled(true); p->set_thermal_gain(gain);
+    for (size_t i = 0; i < n; ++i) {
+        if (r) p->set_ldr_resistance(r[i]);
+        y[i] = p->process_sample(x ? x[i] : 0.0);
     }
     delete p;
 }

@@ -84,6 +84,9 @@ class OracleEngine:
     def set_tremolo_depth(self, v): self.L.owo_engine_set_tremolo_depth(self.h, C.c_double(v))
     def set_speaker_character(self, v): self.L.owo_engine_set_speaker_character(self.h, C.c_double(v))
     def set_mlp_enabled(self, on): self.L.owo_engine_set_mlp_enabled(self.h, 1 if on else 0)
+    def set_noise_enabled(self, on): self.L.owo_engine_set_noise_enabled(self.h, 1 if on else 0)
+    def set_noise_gain(self, g): self.L.owo_engine_set_noise_gain(self.h, C.c_double(g))
+    def set_noise_seed(self, seed): self.L.owo_engine_set_noise_seed(self.h, C.c_ulonglong(int(seed)))
 
     def render(self, n):
         out = np.zeros(int(n), dtype=np.float32)

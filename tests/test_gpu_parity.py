@@ -438,6 +438,98 @@ def test_melange_engine_parity(hiplib, oracle):
     g.close()
 
 
+def test_melange_thermal_noise_parity(hiplib, oracle):
+    """set_noise_enabled / set_noise_gain on the melange preamp (engine.rs:394-400; gen_preamp.rs:3433-3461): the 11 resistor
+    noise currents are integer-exact xoshiro256++ streams shaped by Marsaglia polar (log, sqrt), so with a fixed seed
+    (ow_engine_set_noise_seed = gen_preamp::set_seed, which WurliEngine itself never calls) the GPU must follow the oracle
+    sample for sample: same floors as the noise-free melange test.  Covers idle hiss, notes over hiss, gain changes at block
+    rate, switching off and on (lag kept), reset (streams restart, settings kept) and set_sample_rate (settings dropped)."""
+    import openwurli_amd as ow
+    sr = 48000.0
+    g = ow.EnginePool(sr, 3, preamp_kind=1)
+    cs = [oracle.OracleEngine(sr, preamp_kind=1) for _ in range(3)]
+    g.set_sample_rate(sr)
+    for c in cs:
+        c.set_sample_rate(sr)
+    seeds = (12345, 0xDEADBEEFCAFE, 777)
+    for k in range(3):
+        for e in (g[k], cs[k]):
+            e.set_noise_seed(seeds[k])
+            e.set_tremolo_depth(0.5 * k)
+            e.set_noise_gain((1.0, 0.05, 30.0)[k])
+            if k != 1:
+                e.set_noise_enabled(True)          # engine 1 stays silent until block 6
+
+    def compare(tag, blocks, length=512):
+        idle_peak = 0.0
+        for b in range(blocks):
+            go = g.render(length)
+            gp = g.preamp_out(2 * length)
+            for k in range(3):
+                co, _, cp, _ = cs[k].render_taps(length)
+                rp = oracle.parity_report(gp[k], cp, abs_floor=oracle.ABS_FLOOR_MELANGE_PREAMP)
+                ro = oracle.parity_report(go[k], co, abs_floor=oracle.ABS_FLOOR_MELANGE_OUTPUT)
+                _check(rp, (tag, "preamp", b, k)); _check(ro, (tag, "out", b, k))
+            idle_peak = max(idle_peak, float(np.max(np.abs(go[0]))))
+        return go, idle_peak
+
+    out, idle = compare("idle hiss", 4)
+    assert 1e-5 < idle < 1e-3 and np.max(np.abs(out[1])) == 0.0        # ~-91 dBFS RMS at gain 1 (CHANGELOG: -86 dBFS before the 0.6.0 gain change)
+    assert np.max(np.abs(out[2])) > 10 * np.max(np.abs(out[0]))        # gain 30x
+    for k in range(3):
+        for e in (g[k], cs[k]):
+            e.note_on(60 + 4 * k, 0.7)
+    compare("notes over hiss", 2, 333)
+    for e in (g[1], cs[1]):
+        e.set_noise_enabled(True)
+    for e in (g[0], cs[0]):
+        e.set_noise_enabled(False)
+    for e in (g[2], cs[2]):
+        e.set_noise_gain(0.0)                                           # scale_half == 0: no draws, streams frozen
+    compare("switches", 3)
+    for e in (g[0], cs[0]):
+        e.set_noise_enabled(True)
+    for e in (g[2], cs[2]):
+        e.set_noise_gain(2.0)
+    compare("back on", 2)
+    for k in range(3):
+        g[k].reset(); cs[k].reset()                                     # streams restart from the engine's seed, settings survive
+    out, _ = compare("after reset", 2)
+    assert np.max(np.abs(out[0])) > 1e-6
+    g.set_sample_rate(44100.0)
+    for c in cs:
+        c.set_sample_rate(44100.0)                                      # DkPreamp::new: noise off again
+    out, _ = compare("after rate change", 1, 441)
+    assert all(np.max(np.abs(out[k])) < 1e-7 for k in range(3))         # no hiss: the new DkPreamp starts with noise off
+    g.close()
+
+
+def test_melange_noise_streams_are_deterministic_and_independent(hiplib):
+    """Same seed -> bit-identical render; different seeds -> different hiss; default = one process-wide seed for every engine
+    (the reference clones one cached state, melange_adapter.rs:12-29)."""
+    import openwurli_amd as ow
+    sr = 48000.0
+
+    def run(seeds, init=True):
+        p = ow.EnginePool(sr, len(seeds), preamp_kind=1)
+        if init:
+            p.set_sample_rate(sr)
+        for k, s in enumerate(seeds):
+            if s is not None:
+                p[k].set_noise_seed(s)
+            p[k].set_noise_enabled(True)
+        out = np.concatenate([p.render(256) for _ in range(4)], axis=1)
+        p.close()
+        return out
+    a = run([5, 5, 6, None, None])
+    b = run([5, 5, 6, None, None])
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[0], a[1]) and not np.array_equal(a[0], a[2])
+    assert np.array_equal(a[3], a[4]) and np.max(np.abs(a[3])) > 1e-6
+    c = run([None] * 70, init=False)                    # a fresh pool (engines replicated from engine 0, no set_sample_rate call)
+    assert np.max(np.abs(c[69])) > 1e-6 and np.array_equal(c[0], c[69])
+
+
 def test_melange_static_ldr_and_reset(hiplib, oracle):
     import openwurli_amd as ow
     sr = 44100.0
