@@ -111,11 +111,12 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
     double* rec = vrec + ((size_t)e * 2 + pass) * OW_VREC_DOUBLES + lane;
     double* row = sum + ((size_t)pass * I + e) * Lcap;
 
-    const VoiceUniform U(K);
+    __shared__ double ncoef[5 * 64];
     VoiceRegs v;
     uint32_t steal_fade = 0, steal_len = 1;
     if (active) {
         v.load(rec);
+        for (int i = 0; i < 5; ++i) ncoef[i * 64 + lane] = rec[(VF_NB0 + i) * 64];   // read back by this lane only
         if (pass) {
             const uint64_t sf = dbits(rec[VF_STEAL * 64]);
             steal_fade = (uint32_t)sf;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
         for (int n = 0; n < cn; ++n) {
             double o = 0.0;
             if (active) {
-                o = v.step<false>(rec, U);
+                o = v.step<false>(rec, ncoef + lane);
                 if (pass) {  // 5 ms linear crossfade, engine.rs:483-489
                     const uint32_t i = (uint32_t)(base + n);
                     const uint32_t remaining = steal_fade > i ? steal_fade - i : 0u;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
             rec[VF_STEAL * 64] = bitsd((uint64_t)steal_fade | ((uint64_t)steal_len << 32));
         }
         v.store(rec);
-        silent = v.is_silent(K);
+        silent = v.is_silent(rec);
     }
     const uint64_t silent_mask = __ballot(active && silent);
     const uint64_t bad_mask = __ballot(active && bad_voice);
@@ -179,8 +180,8 @@ struct VoiceSteady {
     double s[7], c[7], env[7], drift[7], cos_inc[7], sin_inc[7], phase_inc[7], amp[7], decay[7];
     double ci[7], si[7];   // jitter-corrected rotation (reed.rs:281-283): depends on drift only, which changes every 16 samples
     double q, ds, gain;
-    double beta, revert, diffusion;   // K->pickup_beta / jitter_revert / jitter_diffusion, read once: a K-> load inside the sample loop is
-                                      // re-issued every sample (the noinline saturate call may write memory) and stalls the wave on lgkmcnt
+    double beta, revert, diffusion;   // the voice's own pickup beta / jitter constants (VF_BETA..), read once per kernel: a load inside the
+                                      // sample loop is re-issued every sample (the noinline saturate call may write memory) and stalls the wave
     uint64_t sample;
     uint32_t jitter_state;
 
@@ -278,7 +279,6 @@ __global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict_
     if (__any(transient)) return;          // eout[e].steady_done stays 0: k_voice renders this engine
     double* row = sum + (size_t)e * Lcap;  // pass 0 rows
     VoiceSteady v;
-    v.beta = K->pickup_beta; v.revert = K->jitter_revert; v.diffusion = K->jitter_diffusion;
     uint32_t noise_rng = 0;
     if (active) {
 #pragma unroll
@@ -288,6 +288,7 @@ __global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict_
             v.phase_inc[i] = rec[(VF_PHASE_INC + i) * 64]; v.amp[i] = rec[(VF_AMP + i) * 64]; v.decay[i] = rec[(VF_DECAY + i) * 64];
         }
         v.q = rec[VF_Q * 64]; v.ds = rec[VF_DS * 64]; v.gain = rec[VF_GAIN * 64];
+        v.beta = rec[VF_BETA * 64]; v.revert = rec[VF_JREV * 64]; v.diffusion = rec[VF_JDIFF * 64];
         v.sample = dbits(rec[VF_SAMPLE * 64]);
         const uint64_t r = dbits(rec[VF_RNG * 64]);
         v.jitter_state = (uint32_t)r; noise_rng = (uint32_t)(r >> 32);

@@ -49,7 +49,13 @@ enum {
     VF_NCNT = 95,        // lo32 noise remaining, hi32 noise fade_in_remaining
     VF_FLAGS = 96,       // lo32 flags (bit0 damper_active, bit1 damper_ramp_done), hi32 midi note
     VF_STEAL = 97,       // steal records only: lo32 steal_fade, hi32 steal_fade_len (engine.rs:45-46)
-    VF_COUNT = 98
+    // constants of the sample rate the voice was struck at: a Voice keeps them for life, also across WurliEngine::set_sample_rate
+    VF_BETA = 98,        // pickup beta = 1/(2 sr tau)             (pickup.rs:30-60)
+    VF_JREV = 99,        // OU jitter mean reversion                 (reed.rs:150-160)
+    VF_JDIFF = 100,      // OU jitter diffusion
+    VF_NDECAY = 101,     // attack-noise decay per sample            (hammer.rs:129-133)
+    VF_VSR = 102,        // that sample rate (10 s damper safety timeout, voice.rs:183-188)
+    VF_COUNT = 103
 };
 #define OW_VREC_DOUBLES (VF_COUNT * 64)   /* per (engine, pass) */
 

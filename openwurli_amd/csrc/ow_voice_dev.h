@@ -275,6 +275,8 @@ __device__ inline void note_on_lane(double* __restrict__ rec, const double* __re
 
     // AttackNoise::new (hammer.rs:126-147) + RBJ constant-skirt band-pass (filters.rs:15-21)
     rec[VF_NAMP * 64] = 0.025 * vel * vel;
+    rec[VF_BETA * 64] = K->pickup_beta; rec[VF_JREV * 64] = K->jitter_revert; rec[VF_JDIFF * 64] = K->jitter_diffusion;
+    rec[VF_NDECAY * 64] = K->noise_decay; rec[VF_VSR * 64] = sr;
     {
         const double center = clampd(f0d * 5.0, 200.0, 2000.0);
         const double w0 = 2.0 * 3.14159265358979323846 * center / sr;
@@ -320,7 +322,7 @@ __device__ inline void start_damper_lane(double* __restrict__ rec, const OwConst
     const uint64_t fl = dbits(rec[VF_FLAGS * 64]);
     const int midi = (int)(fl >> 32);
     if (midi >= 92) return;
-    const double sr = K->sr;
+    const double sr = rec[VF_VSR * 64];   // Voice::note_off passes the voice's own rate (voice.rs:157), not the engine's current one
     const double base_rate = fmax(55.0 * pow(2.0, ((double)midi - 60.0) / 24.0), 0.5);
     double p3 = 1.0;
     for (int m = 0; m < 7; ++m) {
@@ -352,18 +354,11 @@ __device__ __noinline__ __attribute__((const)) double pickup_saturate_hi(double 
 }
 
 // ------------------------------------------------------------------ per-sample voice state in registers
-// The four pool constants the per-sample voice step reads, fetched once per kernel: a K-> load inside the sample loop is re-issued
-// every sample (it cannot be hoisted past the out-of-line calls and the record stores) and stalls the wavefront on lgkmcnt.
-struct VoiceUniform {
-    double beta, revert, diffusion, noise_decay;
-    OW_DEV explicit VoiceUniform(const OwConsts* __restrict__ K)
-        : beta(K->pickup_beta), revert(K->jitter_revert), diffusion(K->jitter_diffusion), noise_decay(K->noise_decay) {}
-};
-
 struct VoiceRegs {
     double s[7], c[7], env[7], drift[7], cos_inc[7], sin_inc[7], phase_inc[7], amp[7], decay[7];
     double onset_inc, onset_exp, dramp, dcount, q, ds, gain;
-    double namp, nb0, nb1, nb2, na1, na2, ns1, ns2;
+    double namp, ns1, ns2;              // attack noise: amplitude and BPF state; the five BPF coefficients stay in the record / LDS
+    double beta, jrev, jdiff, ndecay;   // per-voice rate constants (fixed at note-on; loaded once per kernel, never re-read in the sample loop)
     uint64_t sample, onset_n;
     uint32_t jitter_state, noise_rng, noise_rem, noise_fade, flags, midi;
 
@@ -377,8 +372,9 @@ struct VoiceRegs {
         onset_inc = rec[VF_ONSET_INC * 64]; onset_exp = rec[VF_ONSET_EXP * 64];
         dramp = rec[VF_DRAMP * 64]; dcount = rec[VF_DCOUNT * 64];
         q = rec[VF_Q * 64]; ds = rec[VF_DS * 64]; gain = rec[VF_GAIN * 64];
-        namp = rec[VF_NAMP * 64]; nb0 = rec[VF_NB0 * 64]; nb1 = rec[VF_NB1 * 64]; nb2 = rec[VF_NB2 * 64];
-        na1 = rec[VF_NA1 * 64]; na2 = rec[VF_NA2 * 64]; ns1 = rec[VF_NS1 * 64]; ns2 = rec[VF_NS2 * 64];
+        beta = rec[VF_BETA * 64]; jrev = rec[VF_JREV * 64]; jdiff = rec[VF_JDIFF * 64]; ndecay = rec[VF_NDECAY * 64];
+        namp = rec[VF_NAMP * 64];
+        ns1 = rec[VF_NS1 * 64]; ns2 = rec[VF_NS2 * 64];
         sample = dbits(rec[VF_SAMPLE * 64]); onset_n = dbits(rec[VF_ONSET_N * 64]);
         const uint64_t r = dbits(rec[VF_RNG * 64]); jitter_state = (uint32_t)r; noise_rng = (uint32_t)(r >> 32);
         const uint64_t n = dbits(rec[VF_NCNT * 64]); noise_rem = (uint32_t)n; noise_fade = (uint32_t)(n >> 32);
@@ -410,7 +406,9 @@ struct VoiceRegs {
     // the kernel is VALU-issue bound and the rotation / pickup are mul-add chains.  Fused results differ from the
     // unfused reference by <= 1e-12 of peak over the parity renders (tests/test_gpu_parity.py voice-sum tap).
     template <bool STEADY>
-    OW_DEV double step(const double* __restrict__ rec, const VoiceUniform& U) {
+    // ncoef: the lane's attack-noise BPF coefficients b0, b1, b2, a1, a2 at ncoef[i * 64] (an LDS copy of VF_NB0..VF_NA2: they are
+    // needed only during the first 15 ms of a note and would otherwise hold ten VGPRs for the whole kernel)
+    OW_DEV double step(const double* __restrict__ rec, const double* __restrict__ ncoef) {
 #ifndef OW_STRICT_FP
 #pragma clang fp contract(fast)
 #endif
@@ -438,7 +436,7 @@ struct VoiceRegs {
         }
         const uint32_t lo = (uint32_t)sample;
         if ((lo & 15u) == 0u) {
-            const double revert = U.revert, diffusion = U.diffusion;
+            const double revert = jrev, diffusion = jdiff;
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
                 jitter_state = lcg(jitter_state);
@@ -481,11 +479,11 @@ struct VoiceRegs {
             }
             noise_rng = lcg(noise_rng);
             const double nz = (double)(int32_t)noise_rng / 2147483647.0;
-            const double y = nb0 * nz + ns1;
-            ns1 = nb1 * nz - na1 * y + ns2;
-            ns2 = nb2 * nz - na2 * y;
+            const double y = ncoef[0] * nz + ns1;
+            ns1 = ncoef[64] * nz - ncoef[192] * y + ns2;
+            ns2 = ncoef[128] * nz - ncoef[256] * y;
             x += namp * e * y;
-            namp *= U.noise_decay;
+            namp *= ndecay;
             noise_rem -= 1u;
         }
         // pickup
@@ -493,8 +491,8 @@ struct VoiceRegs {
         const double ay = fabs(y);
         if (!(ay < 0.94)) y = pickup_saturate_hi(y, ay);
         const double omy = 1.0 - y;
-        const double alpha = U.beta * omy;
-        const double q_next = (q * (1.0 - alpha) + 2.0 * U.beta) / (1.0 + alpha);
+        const double alpha = beta * omy;
+        const double q_next = (q * (1.0 - alpha) + 2.0 * beta) / (1.0 + alpha);
         q = q_next;
         return ((q_next * omy - 1.0) * 1.8375) * gain;
     }
@@ -509,8 +507,8 @@ struct VoiceRegs {
     }
 
     // Voice::is_silent (voice.rs:183-188, reed.rs:309-314); threshold 10^(-80/20)
-    OW_DEV bool is_silent(const OwConsts* __restrict__ K) const {
-        if ((flags & 1u) && (dcount / K->sr) > 10.0) return true;
+    OW_DEV bool is_silent(const double* __restrict__ rec) const {
+        if ((flags & 1u) && (dcount / rec[VF_VSR * 64]) > 10.0) return true;
         bool all = true;
 #pragma unroll
         for (int m = 0; m < 7; ++m) all = all && (fabs(amp[m] * env[m]) <= 1e-4);

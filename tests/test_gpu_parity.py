@@ -216,6 +216,28 @@ def test_engine_ragged_block_lengths(hiplib, oracle):
     g.close()
 
 
+def test_voices_keep_their_rate_constants_across_set_sample_rate(hiplib, oracle):
+    """WurliEngine::set_sample_rate (engine.rs:272-286) rebuilds the chain but keeps the Voice objects: a voice struck at 48 kHz
+    goes on with its 48 kHz phase increments, decay multipliers, pickup beta and jitter constants while the engine now runs at
+    44.1 kHz (it sounds flat -- that is the reference's behaviour), and warm_up() renders 0.6 s of it.  New notes use the new rate."""
+    import openwurli_amd as ow
+    g, cs = _both(ow, oracle, 48000.0)
+    es = (g[0], cs[0])
+    for e in es:
+        e.set_tremolo_depth(0.3)
+        for n in (45, 64, 88):
+            e.note_on(n, 0.7)
+    _render_compare(oracle, g, cs, 3, 512, "before rate change")
+    g.set_sample_rate(44100.0); cs[0].set_sample_rate(44100.0)
+    _render_compare(oracle, g, cs, 3, 441, "old voices at the new rate")
+    for e in es:
+        e.note_off(64); e.note_on(52, 0.9)
+    _render_compare(oracle, g, cs, 4, 441, "old and new voices")
+    g.set_sample_rate(96000.0); cs[0].set_sample_rate(96000.0)           # no oversampling from here
+    _render_compare(oracle, g, cs, 2, 960, "second change")
+    g.close()
+
+
 def test_pool_of_independent_engines(hiplib, oracle):
     """Lane = engine kernels: 5 engines with different scripts in one pool vs 5 separate oracle engines."""
     import openwurli_amd as ow
