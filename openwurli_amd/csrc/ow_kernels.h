@@ -304,6 +304,7 @@ __global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict_
             double* trow = tile + lane * (OW_VCHUNK + 1);
             v.jitter();
             double y = v.advance();
+#pragma unroll 2   // two samples per trip: the compiler renames the pipelined state instead of copying it back (7 v_mov_b64 per sample)
             for (int n = 1; n < cn; ++n) {
                 v.jitter();
                 trow[n - 1] = v.pickup(y);
