@@ -261,6 +261,10 @@ def main():
                 "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
                 "kernel_ms_per_step": {n: float(k) for n, k in zip(names, kms)},
                 "whole_chain_frac": FLOPS_PER_SAMPLE * value / world / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                # k_tremolo (block ahead, own stream) runs INSIDE the voice kernel's interval and shares its SIMDs, so the interval's
+                # arithmetic is voices + tremolo; `frac` above charges the whole interval to the voice kernel alone
+                "voices_plus_tremolo_frac": ((FLOPS_VOICES + FLOPS_TREMOLO) * BUF * n_inst / (float(kms[1]) * 1e-3) / 1e12
+                                             / PEAK_FP64_VALU_TFLOPS if kms[1] > 0 else None),
                 # the contract's own vocabulary, for reference: PMC HBM bytes of the dominant kernel / its duration against 8 TB/s
                 "hbm": ({"achieved": traffic / (dom_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "frac": traffic / (dom_ms * 1e-3) / 1e9 / 8000.0} if traffic and dom_ms > 0 else None),
