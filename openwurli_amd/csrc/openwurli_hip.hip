@@ -125,6 +125,7 @@ struct ow_pool {
     hipStream_t stream = nullptr;      // voices -> preamp -> output stage
     hipStream_t stream_trem = nullptr; // tremolo oscillator: no audio input (tremolo.rs:121), runs beside the voices
     hipEvent_t ev_trem[2] = {nullptr, nullptr};   // one per rbuf half
+    hipEvent_t ev_ops = nullptr;                  // k_apply_ops of the current block issued (gates the block-ahead tremolo)
     // The tremolo oscillator is produced one block ahead (speculating that the next block has the same length); the
     // tremolo rows of the chain state are backed up first so a mis-speculation can be rolled back.
     double* d_trem_backup = nullptr;   // [18][I]
@@ -148,6 +149,8 @@ struct ow_pool {
     OwEngineArgs* h_args = nullptr;   // pinned
     OwEngineOut* h_eout = nullptr;    // pinned
     OwOp* h_ops = nullptr;            // pinned
+    uint32_t* d_op_engines = nullptr; // engines that have pending ops this block (k_apply_ops runs one block per entry)
+    uint32_t* h_op_engines = nullptr; // pinned, I entries
     std::vector<ow_engine*> engines;
     std::vector<uint8_t> dirty;       // per engine: host state changed since the args were last uploaded
     bool args_stale = true;           // device args still hold one-shot fields of the previous block
@@ -191,7 +194,9 @@ void alloc_stream_buffers(ow_pool* p, size_t cap) {
 
 void ensure_ops_capacity(ow_pool* p, size_t n) {
     if (n <= p->ops_cap) return;
-    size_t cap = std::max<size_t>(n, std::max<size_t>(p->ops_cap * 2, 256));
+    // A re-strike queues 3 ops per key (damper, move-to-steal, note-on) where the first strike queued 1: growing to exactly n would
+    // re-allocate ~200 MB of pinned + device memory (tens of ms) on the first re-strike of a big pool, so leave that headroom at once.
+    size_t cap = std::max<size_t>(3 * n, std::max<size_t>(p->ops_cap * 2, 256));
     if (p->d_ops) hipFree(p->d_ops);
     if (p->h_ops) hipHostFree(p->h_ops);
     HIP_OK(hipMalloc(&p->d_ops, sizeof(OwOp) * cap));
@@ -366,7 +371,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
     const double* rb_now = p->d_rbuf + p->rb_cur * rb_half;
     const int rb_now_idx = p->rb_cur;
     // ---- next block, speculatively: back up the oscillator rows, then run ahead into the other half
-    {
+    auto launch_block_ahead = [&] {
         const int nxt = p->rb_cur ^ 1;
         HIP_OK(hipMemcpyAsync(p->d_trem_backup, p->d_cs, sizeof(double) * 18 * p->I, hipMemcpyDeviceToDevice, tt));
         if (p->profiling) HIP_OK(hipEventRecord(p->ev[6], tt));
@@ -374,12 +379,24 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
         if (p->profiling) HIP_OK(hipEventRecord(p->ev[7], tt));
         HIP_OK(hipEventRecord(p->ev_trem[nxt], tt));
         p->spec.valid = true; p->spec.e0 = e0; p->spec.ne = ne; p->spec.n_os = n_os;
-    }
+    };
+    // Without note events the oscillator goes first, so its 1 024 wavefronts (one per SIMD) are resident before the voice kernel
+    // fills the rest.  k_apply_ops keeps the MLP weights in ~500 registers per lane and cannot share a SIMD with a tremolo
+    // wavefront: with note events the oscillator starts after that (short) kernel instead of holding it up for a whole launch.
+    if (!n_ops) launch_block_ahead();
     HIP_OK(hipMemsetAsync(p->d_eout + e0, 0, sizeof(OwEngineOut) * ne, st));
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[0], st));
     if (n_ops) {
         HIP_OK(hipMemcpyAsync(p->d_ops, p->h_ops, sizeof(OwOp) * n_ops, hipMemcpyHostToDevice, st));
-        owdev::k_apply_ops<<<dim3(ne), dim3(64), 0, st>>>(p->dK, p->d_nt, p->d_vrec, p->d_args, p->d_ops, e0);
+        // one block per engine THAT HAS OPS: the kernel holds the MLP weights in ~500 registers, and a block that only finds
+        // op_count == 0 still pays for that prologue (measured 8 ms per launch for 65 536 mostly idle engines)
+        uint32_t n_act = 0;
+        for (int k = 0; k < ne; ++k) if (p->h_args[e0 + k].op_count) p->h_op_engines[n_act++] = (uint32_t)(e0 + k);
+        HIP_OK(hipMemcpyAsync(p->d_op_engines, p->h_op_engines, sizeof(uint32_t) * n_act, hipMemcpyHostToDevice, st));
+        owdev::k_apply_ops<<<dim3(n_act), dim3(64), 0, st>>>(p->dK, p->d_nt, p->d_vrec, p->d_args, p->d_ops, p->d_op_engines);
+        HIP_OK(hipEventRecord(p->ev_ops, st));
+        HIP_OK(hipStreamWaitEvent(tt, p->ev_ops, 0));
+        launch_block_ahead();
     }
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[1], st));
     if (with_voices && (any_main || any_steal)) {
@@ -515,6 +532,7 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     HIP_OK(hipStreamCreateWithFlags(&p->stream_trem, hipStreamNonBlocking));
     for (auto& e : p->ev) HIP_OK(hipEventCreate(&e));
     for (auto& e : p->ev_trem) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&p->ev_ops, hipEventDisableTiming));
     HIP_OK(hipMalloc(&p->d_trem_backup, sizeof(double) * 18 * n_engines));
     HIP_OK(hipMalloc(&p->dK, sizeof(OwConsts)));
     HIP_OK(hipMalloc(&p->dK48, sizeof(OwConsts)));
@@ -525,6 +543,8 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     HIP_OK(hipMalloc(&p->d_eout, sizeof(OwEngineOut) * n_engines));
     HIP_OK(hipHostMalloc(&p->h_args, sizeof(OwEngineArgs) * n_engines));
     HIP_OK(hipHostMalloc(&p->h_eout, sizeof(OwEngineOut) * n_engines));
+    HIP_OK(hipMalloc(&p->d_op_engines, sizeof(uint32_t) * n_engines));
+    HIP_OK(hipHostMalloc(&p->h_op_engines, sizeof(uint32_t) * n_engines));
     std::memset(p->h_args, 0, sizeof(OwEngineArgs) * n_engines);
     std::memset(p->h_eout, 0, sizeof(OwEngineOut) * n_engines);
     HIP_OK(hipMemsetAsync(p->d_vrec, 0, sizeof(double) * n_engines * 2 * OW_VREC_DOUBLES, p->stream));
@@ -575,9 +595,12 @@ void pool_destroy(ow_pool* p) {
     hipFree(p->d_args); hipFree(p->d_eout);
     if (p->d_ops) hipFree(p->d_ops);
     if (p->h_ops) hipHostFree(p->h_ops);
+    if (p->d_op_engines) hipFree(p->d_op_engines);
+    if (p->h_op_engines) hipHostFree(p->h_op_engines);
     hipHostFree(p->h_args); hipHostFree(p->h_eout);
     for (auto& e : p->ev) if (e) hipEventDestroy(e);
     for (auto& e : p->ev_trem) if (e) hipEventDestroy(e);
+    if (p->ev_ops) hipEventDestroy(p->ev_ops);
     if (p->d_trem_backup) hipFree(p->d_trem_backup);
     if (p->stream_trem) hipStreamDestroy(p->stream_trem);
     if (p->stream) hipStreamDestroy(p->stream);

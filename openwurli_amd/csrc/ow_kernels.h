@@ -57,9 +57,10 @@ __device__ inline void mlp_raw_mfma(double* __restrict__ h, double in0, double i
 // Ops of one engine are applied in queue order per slot.  The wavefront advances in rounds: every lane takes its next
 // pending op; the note-ons of a round share ONE batched MLP evaluation on the f64 matrix cores (ow_mlp_mfma.h).
 __global__ __launch_bounds__(64) void k_apply_ops(const OwConsts* __restrict__ K, const double* __restrict__ nt, double* __restrict__ vrec,
-                                                  const OwEngineArgs* __restrict__ args, const OwOp* __restrict__ ops, int e0) {
+                                                  const OwEngineArgs* __restrict__ args, const OwOp* __restrict__ ops,
+                                                  const uint32_t* __restrict__ engines) {
     __shared__ double h[64 * 17];
-    const int e = e0 + blockIdx.x;
+    const int e = (int)engines[blockIdx.x];
     const int lane = threadIdx.x;
     const OwEngineArgs a = args[e];
     if (a.op_count == 0) return;
@@ -126,6 +127,13 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
     bool bad_voice = false, bad_sum = false;
     for (int base = 0; base < L; base += OW_VCHUNK) {
         const int cn = min(OW_VCHUNK, L - base);
+        // Steal pass: once every crossfade of this engine has run out (gain (fade - i)/len == 0 from here on, engine.rs:483-489)
+        // the rest of the block only adds voice x 0.0, and the voices are dropped after the block (steal_fade reaches 0): stop
+        // stepping them.  (The reference keeps rendering them; only a voice turning non-finite inside its last 5 ms would differ.)
+        if (pass && __all(!active || steal_fade <= (uint32_t)base)) {
+            for (int i = base + lane; i < L; i += 64) row[i] = 0.0;
+            break;
+        }
         for (int n = 0; n < cn; ++n) {
             double o = 0.0;
             if (active) {
