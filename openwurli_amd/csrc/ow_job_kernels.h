@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64) void k_job_voice(const OwConsts* __restrict__ K
     const int j = jb + lane;
     const bool active = j < n_jobs;
     double* rec = vrec + (size_t)blockIdx.x * OW_VREC_DOUBLES + lane;
-    __shared__ double ncoef[5 * 64];
+    __shared__ double lcoef[OW_LCOEF_ROWS * 64];
     VoiceRegs v;
     if (active) {
         const OwJobDev jd = jobs[j];
@@ -39,11 +39,11 @@ __global__ __launch_bounds__(64) void k_job_voice(const OwConsts* __restrict__ K
         const MlpOut corr = mlp_finish(note, raw, jd.mlp != 0);
         note_on_lane(rec, nt, K, note, vel, (uint32_t)jd.note * 2654435761u, corr);   // main.rs:404-405
         v.load(rec);
-        for (int i = 0; i < 5; ++i) ncoef[i * 64 + lane] = rec[(VF_NB0 + i) * 64];
+        lcoef_load(lcoef + lane, rec);
     }
     for (long long base = 0; base < n; base += OW_VCHUNK) {
         const int cn = (int)((n - base) < OW_VCHUNK ? (n - base) : OW_VCHUNK);
-        for (int s = 0; s < cn; ++s) tile[lane * (OW_VCHUNK + 1) + s] = active ? v.step<false>(rec, ncoef + lane) : 0.0;
+        for (int s = 0; s < cn; ++s) tile[lane * (OW_VCHUNK + 1) + s] = active ? v.step<false>(lcoef + lane) : 0.0;
         __syncthreads();
         // transposed, coalesced store: 2 job rows per pass (32 samples each)
         for (int r = (lane >> 5); r < 64; r += 2) {

@@ -112,12 +112,12 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
     double* rec = vrec + ((size_t)e * 2 + pass) * OW_VREC_DOUBLES + lane;
     double* row = sum + ((size_t)pass * I + e) * Lcap;
 
-    __shared__ double ncoef[5 * 64];
+    __shared__ double lcoef[OW_LCOEF_ROWS * 64];
     VoiceRegs v;
     uint32_t steal_fade = 0, steal_len = 1;
     if (active) {
         v.load(rec);
-        for (int i = 0; i < 5; ++i) ncoef[i * 64 + lane] = rec[(VF_NB0 + i) * 64];   // read back by this lane only
+        lcoef_load(lcoef + lane, rec);   // read back by this lane only
         if (pass) {
             const uint64_t sf = dbits(rec[VF_STEAL * 64]);
             steal_fade = (uint32_t)sf;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
         for (int n = 0; n < cn; ++n) {
             double o = 0.0;
             if (active) {
-                o = v.step<false>(rec, ncoef + lane);
+                o = v.step<false>(lcoef + lane);
                 if (pass) {  // 5 ms linear crossfade, engine.rs:483-489
                     const uint32_t i = (uint32_t)(base + n);
                     const uint32_t remaining = steal_fade > i ? steal_fade - i : 0u;

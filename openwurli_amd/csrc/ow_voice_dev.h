@@ -354,6 +354,13 @@ __device__ __noinline__ __attribute__((const)) double pickup_saturate_hi(double 
 }
 
 // ------------------------------------------------------------------ per-sample voice state in registers
+#define OW_LCOEF_ROWS 19
+// fills the lane's column of the phase-only coefficient table (see VoiceRegs::step)
+OW_DEV void lcoef_load(double* __restrict__ lcoef, const double* __restrict__ rec) {
+    for (int i = 0; i < 5; ++i) lcoef[i * 64] = rec[(VF_NB0 + i) * 64];
+    for (int i = 0; i < 7; ++i) { lcoef[(5 + i) * 64] = rec[(VF_DRATE + i) * 64]; lcoef[(12 + i) * 64] = rec[(VF_DMULT + i) * 64]; }
+}
+
 struct VoiceRegs {
     double s[7], c[7], env[7], drift[7], cos_inc[7], sin_inc[7], phase_inc[7], amp[7], decay[7];
     double onset_inc, onset_exp, dramp, dcount, q, ds, gain;
@@ -406,9 +413,11 @@ struct VoiceRegs {
     // the kernel is VALU-issue bound and the rotation / pickup are mul-add chains.  Fused results differ from the
     // unfused reference by <= 1e-12 of peak over the parity renders (tests/test_gpu_parity.py voice-sum tap).
     template <bool STEADY>
-    // ncoef: the lane's attack-noise BPF coefficients b0, b1, b2, a1, a2 at ncoef[i * 64] (an LDS copy of VF_NB0..VF_NA2: they are
-    // needed only during the first 15 ms of a note and would otherwise hold ten VGPRs for the whole kernel)
-    OW_DEV double step(const double* __restrict__ rec, const double* __restrict__ ncoef) {
+    // lcoef: LDS copy of the lane's phase-only coefficients, lcoef[i * 64]: i = 0..4 attack-noise BPF b0, b1, b2, a1, a2
+    // (VF_NB0..VF_NA2, first 15 ms of a note), i = 5..11 damper_rate, i = 12..18 damper_mult (VF_DRATE / VF_DMULT, while the key is
+    // released).  In registers they would cost 38 VGPRs for the whole kernel; read from the voice record in HBM they cost a
+    // dependent global load per mode per sample for as long as a released voice rings (measured: the played workload's bottleneck).
+    OW_DEV double step(const double* __restrict__ lcoef) {
 #ifndef OW_STRICT_FP
 #pragma clang fp contract(fast)
 #endif
@@ -422,14 +431,14 @@ struct VoiceRegs {
                     else {
 #pragma unroll
                         for (int m = 0; m < 7; ++m) {
-                            const double inst_rate = rec[(VF_DRATE + m) * 64] * t / dramp;
+                            const double inst_rate = lcoef[(5 + m) * 64] * t / dramp;
                             env[m] *= exp_neg(inst_rate);
                         }
                     }
                 }
                 if (flags & 2u) {
 #pragma unroll
-                    for (int m = 0; m < 7; ++m) env[m] *= rec[(VF_DMULT + m) * 64];
+                    for (int m = 0; m < 7; ++m) env[m] *= lcoef[(12 + m) * 64];
                 }
             }
             if (sample < onset_n) onset = onset_gain((double)sample, onset_inc, onset_exp);
@@ -479,9 +488,9 @@ struct VoiceRegs {
             }
             noise_rng = lcg(noise_rng);
             const double nz = (double)(int32_t)noise_rng / 2147483647.0;
-            const double y = ncoef[0] * nz + ns1;
-            ns1 = ncoef[64] * nz - ncoef[192] * y + ns2;
-            ns2 = ncoef[128] * nz - ncoef[256] * y;
+            const double y = lcoef[0] * nz + ns1;
+            ns1 = lcoef[64] * nz - lcoef[192] * y + ns2;
+            ns2 = lcoef[128] * nz - lcoef[256] * y;
             x += namp * e * y;
             namp *= ndecay;
             noise_rem -= 1u;
