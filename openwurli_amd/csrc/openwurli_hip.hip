@@ -149,6 +149,13 @@ struct ow_pool {
     OwEngineArgs* h_args = nullptr;   // pinned
     OwEngineOut* h_eout = nullptr;    // pinned
     OwOp* h_ops = nullptr;            // pinned
+    // Packed voice dispatch (ow_kernels.h): lane = sounding voice.  Three block lists of (engine << 6 | slot) entries, rebuilt when a
+    // mask, a pending op or a transient flag changed: steady slot voices, slot voices of engines in a transient phase, steal voices.
+    struct VoiceList { uint32_t* h = nullptr; uint32_t* d = nullptr; uint32_t n_blocks = 0; };
+    VoiceList vl_steady, vl_general, vl_steal;
+    std::vector<uint8_t> transient;   // per engine: device status after the previous block (OwEngineOut::transient)
+    bool lists_valid = false;
+    int lists_e0 = -1, lists_ne = -1;
     uint32_t* d_op_engines = nullptr; // engines that have pending ops this block (k_apply_ops runs one block per entry)
     uint32_t* h_op_engines = nullptr; // pinned, I entries
     std::vector<ow_engine*> engines;
@@ -282,6 +289,36 @@ static size_t effective_cpus() {
     return n;
 }
 
+// Deal the sounding voices of engines [e0, e0+ne) into wavefront-sized blocks (see ow_kernels.h, "Packed dispatch").
+// general = engines whose status after the previous block reported a transient phase, or that receive ops in this block (a note-on
+// starts an onset ramp and an attack-noise burst, a note-off a damper phase; nothing else starts one).
+void build_voice_lists(ow_pool* p, int e0, int ne) {
+    uint32_t fs = 0, fg = 0, fl = 0;   // entries written so far
+    uint32_t* S = p->vl_steady.h; uint32_t* G = p->vl_general.h; uint32_t* T = p->vl_steal.h;
+    auto pad = [](uint32_t* a, uint32_t& n) { while (n & 63u) a[n++] = 0xFFFFFFFFu; };
+    auto put = [&](uint32_t* a, uint32_t& n, uint32_t e, uint64_t mask, bool own_block) {
+        const uint32_t pc = (uint32_t)__builtin_popcountll(mask);
+        if (own_block || (n & 63u) + pc > 64u) pad(a, n);
+        for (uint64_t m = mask; m; m &= m - 1) a[n++] = (e << 6) | (uint32_t)__builtin_ctzll(m);
+    };
+    for (int k = 0; k < ne; ++k) {
+        const uint32_t e = (uint32_t)(e0 + k);
+        const OwEngineArgs& a = p->h_args[e];
+        if (a.main_mask) {
+            if (p->transient[e] || a.op_count) put(G, fg, e, a.main_mask, false);
+            else put(S, fs, e, a.main_mask, false);
+        }
+        if (a.steal_mask) put(T, fl, e, a.steal_mask, true);   // one engine per block: the crossfade early-out is per engine
+    }
+    pad(S, fs); pad(G, fg); pad(T, fl);
+    p->vl_steady.n_blocks = fs / 64; p->vl_general.n_blocks = fg / 64; p->vl_steal.n_blocks = fl / 64;
+    hipStream_t st = p->stream;
+    if (fs) HIP_OK(hipMemcpyAsync(p->vl_steady.d, S, sizeof(uint32_t) * fs, hipMemcpyHostToDevice, st));
+    if (fg) HIP_OK(hipMemcpyAsync(p->vl_general.d, G, sizeof(uint32_t) * fg, hipMemcpyHostToDevice, st));
+    if (fl) HIP_OK(hipMemcpyAsync(p->vl_steal.d, T, sizeof(uint32_t) * fl, hipMemcpyHostToDevice, st));
+    p->lists_e0 = e0; p->lists_ne = ne;
+}
+
 // One render of `len` samples for engines [e0, e0+ne).  with_voices=false skips the voice kernels
 // (warm-up of engines whose voices were just freed).
 void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
@@ -401,8 +438,15 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[1], st));
     if (with_voices && (any_main || any_steal)) {
         // steady-state engines take the lean kernel; k_voice picks up engines with voices in a transient phase and all steal voices
-        if (any_main) owdev::k_voice_steady<<<dim3(ne), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->d_args, p->d_sum, p->d_eout, I, L, Lcap, e0);
-        owdev::k_voice<<<dim3(ne, any_steal ? 2 : 1), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->d_args, p->d_sum, p->d_eout, I, L, Lcap, e0);
+        // the lists depend on masks, pending ops (any_dirty) and the transient flags of the previous block (post_render_host)
+        if (!p->lists_valid || any_dirty || p->lists_e0 != e0 || p->lists_ne != ne) build_voice_lists(p, e0, ne);
+        p->lists_valid = !any_dirty;     // engines with ops were classified "general" for this block only
+        if (p->vl_steady.n_blocks)
+            owdev::k_voice_steady<<<dim3(p->vl_steady.n_blocks), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_steady.d, p->d_sum, p->d_eout, I, L, Lcap);
+        if (p->vl_general.n_blocks)
+            owdev::k_voice<<<dim3(p->vl_general.n_blocks), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_general.d, p->d_sum, p->d_eout, I, L, Lcap, 0);
+        if (p->vl_steal.n_blocks)
+            owdev::k_voice<<<dim3(p->vl_steal.n_blocks), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_steal.d, p->d_sum, p->d_eout, I, L, Lcap, 1);
     }
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[2], st));
     HIP_OK(hipStreamWaitEvent(st, p->ev_trem[rb_now_idx], 0));
@@ -456,6 +500,9 @@ void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
     for (int k = 0; k < ne; ++k) {
         const OwEngineOut& o = p->h_eout[e0 + k];
         const OwEngineArgs& a = p->h_args[e0 + k];
+        if (o.transient == 2u) set_err("voice dispatch: an engine in a transient phase was sent to the steady kernel");
+        const uint8_t tr = o.transient != 0u;
+        if (tr != p->transient[e0 + k]) { p->transient[e0 + k] = tr; p->lists_valid = false; }
         // fast path on the contiguous status/args arrays: nothing to book-keep for this engine
         if (!a.steal_mask && !(o.silent_mask & a.main_mask) && !o.sum_nonfinite && !o.out_nonfinite) continue;
         engine_post_render(p->engines[e0 + k], l32, o);
@@ -543,6 +590,11 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     HIP_OK(hipMalloc(&p->d_eout, sizeof(OwEngineOut) * n_engines));
     HIP_OK(hipHostMalloc(&p->h_args, sizeof(OwEngineArgs) * n_engines));
     HIP_OK(hipHostMalloc(&p->h_eout, sizeof(OwEngineOut) * n_engines));
+    for (ow_pool::VoiceList* vl : {&p->vl_steady, &p->vl_general, &p->vl_steal}) {   // worst case: one block per engine
+        HIP_OK(hipMalloc(&vl->d, sizeof(uint32_t) * 64 * n_engines));
+        HIP_OK(hipHostMalloc(&vl->h, sizeof(uint32_t) * 64 * n_engines));
+    }
+    p->transient.assign(n_engines, 0);
     HIP_OK(hipMalloc(&p->d_op_engines, sizeof(uint32_t) * n_engines));
     HIP_OK(hipHostMalloc(&p->h_op_engines, sizeof(uint32_t) * n_engines));
     std::memset(p->h_args, 0, sizeof(OwEngineArgs) * n_engines);
@@ -595,6 +647,7 @@ void pool_destroy(ow_pool* p) {
     hipFree(p->d_args); hipFree(p->d_eout);
     if (p->d_ops) hipFree(p->d_ops);
     if (p->h_ops) hipHostFree(p->h_ops);
+    for (ow_pool::VoiceList* vl : {&p->vl_steady, &p->vl_general, &p->vl_steal}) { if (vl->d) hipFree(vl->d); if (vl->h) hipHostFree(vl->h); }
     if (p->d_op_engines) hipFree(p->d_op_engines);
     if (p->h_op_engines) hipHostFree(p->h_op_engines);
     hipHostFree(p->h_args); hipHostFree(p->h_eout);

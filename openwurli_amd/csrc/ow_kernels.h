@@ -26,7 +26,8 @@ struct OwEngineOut {
     uint64_t bad_steal;       // steal voices that produced a non-finite sample
     uint32_t sum_nonfinite;   // engine.rs:499 NaN guard condition (either pass)
     uint32_t out_nonfinite;   // engine.rs:450 output NaN guard fired this block
-    uint32_t steady_done;     // k_voice_steady rendered the slot pass of this engine (k_voice skips it)
+    uint32_t transient;       // after this block some slot voice is inside a damper / onset / attack-noise phase (host: general kernel
+                              // next block); 2 = a voice in such a phase was found by the steady kernel (host classification bug)
     uint32_t pad;
 };
 
@@ -98,21 +99,77 @@ __global__ __launch_bounds__(64) void k_apply_ops(const OwConsts* __restrict__ K
 }
 
 // ------------------------------------------------------------------ voices
+// Packed dispatch: lane = SOUNDING VOICE, not voice slot.  The host deals the sounding voices of consecutive engines into blocks of
+// up to 64 (an engine is never split), in (engine, slot) order; `entries[block * 64 + lane]` = (engine << 6) | slot or OW_NO_VOICE
+// behind the last one.  An engine that sounds 8 voices then costs an eighth of a wavefront instead of a whole one; with all 64 keys
+// down a block is one engine as before.  The ordered voice sum (engine.rs:469-479) is taken per engine over its lanes, which are in
+// slot order, so it is still the reference's sequential sum -- without the +0.0 terms of the silent slots.
 #define OW_VCHUNK 24   // 64 voices x 24 samples x f64 = 12.8 KB tile: 8 voice blocks + 4 tremolo blocks fit the 160 KB LDS of a CU
-__global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, double* __restrict__ vrec, const OwEngineArgs* __restrict__ args,
-                                              double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int L, int Lcap, int e0) {
-    __shared__ double tile[64 * (OW_VCHUNK + 1)];
-    const int e = e0 + blockIdx.x;
-    const int pass = blockIdx.y;
-    const int lane = threadIdx.x;
-    const uint64_t mask = pass ? args[e].steal_mask : args[e].main_mask;
-    if (mask == 0ull) return;  // chain kernels skip rows of empty passes
-    if (pass == 0 && eout[e].steady_done) return;  // k_voice_steady already rendered this engine's slot voices
-    const bool active = (mask >> lane) & 1ull;
-    double* rec = vrec + ((size_t)e * 2 + pass) * OW_VREC_DOUBLES + lane;
-    double* row = sum + ((size_t)pass * I + e) * Lcap;
+#define OW_NO_VOICE 0xFFFFFFFFu
 
+struct VoiceLanes {           // per-lane view of one packed block
+    int e, slot;
+    bool active;
+    uint64_t seg_end;         // bit l: lane l is the last voice of its engine in this block (wave-uniform)
+    int nvalid;               // entries are contiguous from lane 0
+};
+OW_DEV VoiceLanes voice_lanes(const uint32_t* __restrict__ entries, int* __restrict__ eng_l) {
+    const int lane = threadIdx.x;
+    const uint32_t ent = entries[(size_t)blockIdx.x * 64 + lane];
+    VoiceLanes w;
+    w.active = ent != OW_NO_VOICE;
+    w.e = w.active ? (int)(ent >> 6) : -1;
+    w.slot = (int)(ent & 63u);
+    eng_l[lane] = w.e;
+    const int e_next = __shfl_down(w.e, 1);
+    w.seg_end = __ballot(w.active && (lane == 63 || e_next != w.e));
+    w.nvalid = __popcll(__ballot(w.active));
+    return w;
+}
+// Sum the voices of each engine of the block in slot order for sample (base + lane) and write its row of sum[pass][engine][.].
+OW_DEV void voice_reduce(const double* __restrict__ tile, const int* __restrict__ eng_l, const VoiceLanes& w, int cn, int base, int pass,
+                         double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int Lcap) {
+    const int lane = threadIdx.x;
+    if (lane < cn) {
+        if (w.seg_end == (1ull << (w.nvalid - 1))) {   // one engine in the block (every block when all keys are down): no segment tests
+            double acc = 0.0;
+            if (w.nvalid == 64) {
+#pragma unroll 16
+                for (int l = 0; l < 64; ++l) acc += tile[l * (OW_VCHUNK + 1) + lane];
+            } else {
+#pragma unroll 4
+                for (int l = 0; l < w.nvalid; ++l) acc += tile[l * (OW_VCHUNK + 1) + lane];
+            }
+            const int e = eng_l[0];
+            if (!isfinite(acc)) atomicOr(&eout[e].sum_nonfinite, 1u);
+            sum[((size_t)pass * I + e) * Lcap + base + lane] = acc;
+            return;
+        }
+        double acc = 0.0;
+        for (int l = 0; l < w.nvalid; ++l) {
+            acc += tile[l * (OW_VCHUNK + 1) + lane];
+            if ((w.seg_end >> l) & 1ull) {
+                const int e = eng_l[l];
+                if (!isfinite(acc)) atomicOr(&eout[e].sum_nonfinite, 1u);
+                sum[((size_t)pass * I + e) * Lcap + base + lane] = acc;
+                acc = 0.0;
+            }
+        }
+    }
+}
+
+// General step (any phase).  pass 0 = slot voices of the engines the host classified as "in a transient phase", pass 1 = steal voices
+// (one engine per block there, so the crossfade early-out below is per engine).
+__global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, double* __restrict__ vrec, const uint32_t* __restrict__ entries,
+                                              double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int L, int Lcap, int pass) {
+    __shared__ double tile[64 * (OW_VCHUNK + 1)];
     __shared__ double lcoef[OW_LCOEF_ROWS * 64];
+    __shared__ int eng_l[64];
+    const int lane = threadIdx.x;
+    const VoiceLanes w = voice_lanes(entries, eng_l);
+    const bool active = w.active;
+    double* rec = vrec + ((size_t)(active ? w.e : 0) * 2 + pass) * OW_VREC_DOUBLES + w.slot;
+
     VoiceRegs v;
     uint32_t steal_fade = 0, steal_len = 1;
     if (active) {
@@ -124,13 +181,15 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
             steal_len = (uint32_t)(sf >> 32);
         }
     }
-    bool bad_voice = false, bad_sum = false;
+    __syncthreads();                     // eng_l
+    bool bad_voice = false;
     for (int base = 0; base < L; base += OW_VCHUNK) {
         const int cn = min(OW_VCHUNK, L - base);
         // Steal pass: once every crossfade of this engine has run out (gain (fade - i)/len == 0 from here on, engine.rs:483-489)
         // the rest of the block only adds voice x 0.0, and the voices are dropped after the block (steal_fade reaches 0): stop
         // stepping them.  (The reference keeps rendering them; only a voice turning non-finite inside its last 5 ms would differ.)
         if (pass && __all(!active || steal_fade <= (uint32_t)base)) {
+            double* row = sum + ((size_t)pass * I + eng_l[0]) * Lcap;
             for (int i = base + lane; i < L; i += 64) row[i] = 0.0;
             break;
         }
@@ -148,16 +207,9 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
         }
         if (active && !v.state_finite()) bad_voice = true;
         __syncthreads();
-        if (lane < cn) {  // sum the 64 slots in slot order (engine.rs:469-479)
-            double acc = 0.0;
-#pragma unroll 16
-            for (int s = 0; s < 64; ++s) acc += tile[s * (OW_VCHUNK + 1) + lane];
-            if (!isfinite(acc)) bad_sum = true;
-            row[base + lane] = acc;
-        }
+        voice_reduce(tile, eng_l, w, cn, base, pass, sum, eout, I, Lcap);
         __syncthreads();
     }
-    bool silent = false;
     if (active) {
         if (pass) {  // slot.steal_fade.saturating_sub(len) (engine.rs:490)
             const uint32_t l32 = (uint32_t)L;
@@ -165,15 +217,15 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
             rec[VF_STEAL * 64] = bitsd((uint64_t)steal_fade | ((uint64_t)steal_len << 32));
         }
         v.store(rec);
-        silent = v.is_silent(rec);
-    }
-    const uint64_t silent_mask = __ballot(active && silent);
-    const uint64_t bad_mask = __ballot(active && bad_voice);
-    const uint64_t bs = __ballot(bad_sum);
-    if (lane == 0) {
-        if (pass == 0) { eout[e].silent_mask = silent_mask; eout[e].bad_main = bad_mask; }
-        else eout[e].bad_steal = bad_mask;
-        if (bs) atomicOr(&eout[e].sum_nonfinite, 1u);
+        OwEngineOut* o = eout + w.e;
+        const unsigned long long bit = 1ull << w.slot;
+        if (pass == 0) {
+            if (v.is_silent(rec)) atomicOr((unsigned long long*)&o->silent_mask, bit);
+            if (bad_voice) atomicOr((unsigned long long*)&o->bad_main, bit);
+            if (v.in_transient()) o->transient = 1u;
+        } else if (bad_voice) {
+            atomicOr((unsigned long long*)&o->bad_steal, bit);
+        }
     }
 }
 
@@ -267,28 +319,23 @@ struct VoiceSteady {
     }
 };
 
-__global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict__ K, double* __restrict__ vrec, const OwEngineArgs* __restrict__ args,
-                                                     double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int L, int Lcap, int e0) {
+__global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict__ K, double* __restrict__ vrec, const uint32_t* __restrict__ entries,
+                                                     double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int L, int Lcap) {
     __shared__ double tile[64 * (OW_VCHUNK + 1)];
-    const int e = e0 + blockIdx.x;
+    __shared__ int eng_l[64];
     const int lane = threadIdx.x;
-    const uint64_t mask = args[e].main_mask;
-    if (mask == 0ull) return;
-    const bool active = (mask >> lane) & 1ull;
-    double* rec = vrec + ((size_t)e * 2) * OW_VREC_DOUBLES + lane;
-    bool transient = false;
-    uint32_t flags = 0;
-    if (active) {
-        flags = (uint32_t)dbits(rec[VF_FLAGS * 64]);
-        const uint64_t smp = dbits(rec[VF_SAMPLE * 64]), onset_n = dbits(rec[VF_ONSET_N * 64]);
-        const uint32_t noise_rem = (uint32_t)dbits(rec[VF_NCNT * 64]);
-        transient = (flags & 1u) || smp < onset_n || noise_rem > 0u;
-    }
-    if (__any(transient)) return;          // eout[e].steady_done stays 0: k_voice renders this engine
-    double* row = sum + (size_t)e * Lcap;  // pass 0 rows
+    const VoiceLanes w = voice_lanes(entries, eng_l);
+    const bool active = w.active;
+    double* rec = vrec + ((size_t)(active ? w.e : 0) * 2) * OW_VREC_DOUBLES + w.slot;
     VoiceSteady v;
     uint32_t noise_rng = 0;
     if (active) {
+        // The host sends an engine here only if its status after the previous block said "no transient phase" and no note event
+        // arrived since; those phases never start by themselves.  A voice found inside one means that bookkeeping is wrong.
+        const uint32_t flags = (uint32_t)dbits(rec[VF_FLAGS * 64]);
+        const uint64_t smp = dbits(rec[VF_SAMPLE * 64]), onset_n = dbits(rec[VF_ONSET_N * 64]);
+        const uint32_t noise_rem = (uint32_t)dbits(rec[VF_NCNT * 64]);
+        if ((flags & 1u) || smp < onset_n || noise_rem > 0u) eout[w.e].transient = 2u;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             v.s[i] = rec[(VF_S + i) * 64]; v.c[i] = rec[(VF_C + i) * 64]; v.env[i] = rec[(VF_ENV + i) * 64];
@@ -302,10 +349,7 @@ __global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict_
         v.jitter_state = (uint32_t)r; noise_rng = (uint32_t)(r >> 32);
         v.update_rotation();
     }
-    bool bad_sum = false;
-    if (!active) {   // rows of the tile belong to one lane each: idle slots contribute +0.0 to the ordered sum
-        for (int n = 0; n < OW_VCHUNK; ++n) tile[lane * (OW_VCHUNK + 1) + n] = 0.0;
-    }
+    __syncthreads();                     // eng_l
     for (int base = 0; base < L; base += OW_VCHUNK) {
         const int cn = min(OW_VCHUNK, L - base);
         if (active) {
@@ -321,16 +365,9 @@ __global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict_
             trow[cn - 1] = v.pickup(y);
         }
         __syncthreads();
-        if (lane < cn) {  // sum the 64 slots in slot order (engine.rs:469-479)
-            double acc = 0.0;
-#pragma unroll 16
-            for (int s = 0; s < 64; ++s) acc += tile[s * (OW_VCHUNK + 1) + lane];
-            if (!isfinite(acc)) bad_sum = true;
-            row[base + lane] = acc;
-        }
+        voice_reduce(tile, eng_l, w, cn, base, 0, sum, eout, I, Lcap);
         __syncthreads();
     }
-    bool silent = false, bad_voice = false;
     if (active) {
         bool fin = isfinite(v.q);
         bool all_quiet = true;
@@ -343,17 +380,9 @@ __global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict_
         rec[VF_Q * 64] = v.q;
         rec[VF_SAMPLE * 64] = bitsd(v.sample);
         rec[VF_RNG * 64] = bitsd((uint64_t)v.jitter_state | ((uint64_t)noise_rng << 32));
-        bad_voice = !fin;
-        silent = all_quiet;                // damper inactive here, so only the -80 dB test of Voice::is_silent applies
-    }
-    const uint64_t silent_mask = __ballot(active && silent);
-    const uint64_t bad_mask = __ballot(active && bad_voice);
-    const uint64_t bs = __ballot(bad_sum);
-    if (lane == 0) {
-        eout[e].silent_mask = silent_mask;
-        eout[e].bad_main = bad_mask;
-        eout[e].steady_done = 1u;
-        if (bs) atomicOr(&eout[e].sum_nonfinite, 1u);
+        const unsigned long long bit = 1ull << w.slot;
+        if (all_quiet) atomicOr((unsigned long long*)&eout[w.e].silent_mask, bit);   // damper inactive here: only the -80 dB test of Voice::is_silent
+        if (!fin) atomicOr((unsigned long long*)&eout[w.e].bad_main, bit);
     }
 }
 
