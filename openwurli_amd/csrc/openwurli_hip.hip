@@ -293,29 +293,51 @@ static size_t effective_cpus() {
 // general = engines whose status after the previous block reported a transient phase, or that receive ops in this block (a note-on
 // starts an onset ramp and an attack-noise burst, a note-off a damper phase; nothing else starts one).
 void build_voice_lists(ow_pool* p, int e0, int ne) {
-    uint32_t fs = 0, fg = 0, fl = 0;   // entries written so far
-    uint32_t* S = p->vl_steady.h; uint32_t* G = p->vl_general.h; uint32_t* T = p->vl_steal.h;
-    auto pad = [](uint32_t* a, uint32_t& n) { while (n & 63u) a[n++] = 0xFFFFFFFFu; };
-    auto put = [&](uint32_t* a, uint32_t& n, uint32_t e, uint64_t mask, bool own_block) {
-        const uint32_t pc = (uint32_t)__builtin_popcountll(mask);
-        if (own_block || (n & 63u) + pc > 64u) pad(a, n);
-        for (uint64_t m = mask; m; m &= m - 1) a[n++] = (e << 6) | (uint32_t)__builtin_ctzll(m);
-    };
-    for (int k = 0; k < ne; ++k) {
-        const uint32_t e = (uint32_t)(e0 + k);
-        const OwEngineArgs& a = p->h_args[e];
-        if (a.main_mask) {
-            if (p->transient[e] || a.op_count) put(G, fg, e, a.main_mask, false);
-            else put(S, fs, e, a.main_mask, false);
+    // Big ranges are cut into T engine slices that are packed independently (each slice starts on a block boundary, so at most
+    // T - 1 blocks are less full than they could be): pass 1 sizes the three lists of every slice, a prefix sum places them,
+    // pass 2 writes the entries.
+    const size_t T = ne >= 16384 ? std::min<size_t>(effective_cpus(), 32) : 1;
+    const int per = (int)((ne + T - 1) / T);
+    struct Fill { uint32_t s = 0, g = 0, t = 0; };
+    std::vector<Fill> size(T), start(T + 1);
+    auto pack = [&](size_t t, uint32_t* S, uint32_t* G, uint32_t* Tl, Fill& f) {   // S == nullptr: count only
+        auto pad = [](uint32_t* a, uint32_t& n) { while (n & 63u) { if (a) a[n] = 0xFFFFFFFFu; ++n; } };
+        auto put = [&](uint32_t* a, uint32_t& n, uint32_t e, uint64_t mask, bool own_block) {
+            const uint32_t pc = (uint32_t)__builtin_popcountll(mask);
+            if (own_block || (n & 63u) + pc > 64u) pad(a, n);
+            if (a) for (uint64_t m = mask; m; m &= m - 1) a[n++] = (e << 6) | (uint32_t)__builtin_ctzll(m);
+            else n += pc;
+        };
+        const int k1 = std::min(ne, (int)(t + 1) * per);
+        for (int k = (int)t * per; k < k1; ++k) {
+            const uint32_t e = (uint32_t)(e0 + k);
+            const OwEngineArgs& a = p->h_args[e];
+            if (a.main_mask) {
+                if (p->transient[e] || a.op_count) put(G, f.g, e, a.main_mask, false);
+                else put(S, f.s, e, a.main_mask, false);
+            }
+            if (a.steal_mask) put(Tl, f.t, e, a.steal_mask, true);   // one engine per block: the crossfade early-out is per engine
         }
-        if (a.steal_mask) put(T, fl, e, a.steal_mask, true);   // one engine per block: the crossfade early-out is per engine
-    }
-    pad(S, fs); pad(G, fg); pad(T, fl);
+        pad(S, f.s); pad(G, f.g); pad(Tl, f.t);
+    };
+    auto run = [&](auto&& fn) {
+        if (T == 1) { fn((size_t)0); return; }
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < T; ++t) th.emplace_back([&fn, t] { fn(t); });
+        for (auto& x : th) x.join();
+    };
+    run([&](size_t t) { pack(t, nullptr, nullptr, nullptr, size[t]); });
+    for (size_t t = 0; t < T; ++t) { start[t + 1].s = start[t].s + size[t].s; start[t + 1].g = start[t].g + size[t].g; start[t + 1].t = start[t].t + size[t].t; }
+    run([&](size_t t) {
+        Fill f;   // slice-local counters: the slice regions start on block boundaries, so padding decisions match pass 1
+        pack(t, p->vl_steady.h + start[t].s, p->vl_general.h + start[t].g, p->vl_steal.h + start[t].t, f);
+    });
+    const uint32_t fs = start[T].s, fg = start[T].g, fl = start[T].t;
     p->vl_steady.n_blocks = fs / 64; p->vl_general.n_blocks = fg / 64; p->vl_steal.n_blocks = fl / 64;
     hipStream_t st = p->stream;
-    if (fs) HIP_OK(hipMemcpyAsync(p->vl_steady.d, S, sizeof(uint32_t) * fs, hipMemcpyHostToDevice, st));
-    if (fg) HIP_OK(hipMemcpyAsync(p->vl_general.d, G, sizeof(uint32_t) * fg, hipMemcpyHostToDevice, st));
-    if (fl) HIP_OK(hipMemcpyAsync(p->vl_steal.d, T, sizeof(uint32_t) * fl, hipMemcpyHostToDevice, st));
+    if (fs) HIP_OK(hipMemcpyAsync(p->vl_steady.d, p->vl_steady.h, sizeof(uint32_t) * fs, hipMemcpyHostToDevice, st));
+    if (fg) HIP_OK(hipMemcpyAsync(p->vl_general.d, p->vl_general.h, sizeof(uint32_t) * fg, hipMemcpyHostToDevice, st));
+    if (fl) HIP_OK(hipMemcpyAsync(p->vl_steal.d, p->vl_steal.h, sizeof(uint32_t) * fl, hipMemcpyHostToDevice, st));
     p->lists_e0 = e0; p->lists_ne = ne;
 }
 

@@ -1,7 +1,7 @@
 // openwurli-hip: gfx950 kernels of the render path.
 //
 //   k_apply_ops   block = engine, lane = slot     note-on / damper / move-to-steal on voice records
-//   k_voice       block = (engine, pass), lane = slot   64 voices x L samples, ordered LDS reduction
+//   k_voice(_steady) lane = sounding voice (packed across engines by the host), ordered per-engine LDS reduction
 //   k_tremolo     lane = engine                    Twin-T oscillator + LDR -> R[n]
 //   k_preamp      lane = (engine, main|shadow)     half-band up + DK preamp (main - shadow)
 //   k_post        lane = engine                    power amp x2 -> half-band down -> speaker -> gain -> f32
