@@ -82,6 +82,10 @@ class _EngineHandle:
     def sustained_voice_count(self):
         return self.diag().sustained_voices
 
+    def slot_state(self, slot):
+        """VoiceSlot.state of one of the 64 slots (VoiceState value)."""
+        return self._lib.ow_engine_slot_state(self._h, int(slot))
+
     def count_voices_in_state(self, state):
         return sum(1 for s in range(64) if self._lib.ow_engine_slot_state(self._h, s) == int(state))
 

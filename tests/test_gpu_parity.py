@@ -289,6 +289,47 @@ def test_packed_dispatch_many_sparse_engines(hiplib, oracle):
     g.close()
 
 
+def test_played_random_script_against_oracle(hiplib, oracle):
+    """A played part per engine (random note-ons / note-offs / pedal at block boundaries, like tools/bench_midi.py) against one oracle
+    engine each: engines keep hopping between the steady and the general voice list, voices are stolen, freed and restruck, and
+    several engines share each wavefront.  Slot states and voice counts are compared after every block."""
+    import openwurli_amd as ow
+    from openwurli_amd import binding
+    sr, n, blocks, length = 48000.0, 7, 36, 256
+    g, cs = _both(ow, oracle, sr, n=n)
+    rng = np.random.default_rng(2024)
+    for k in range(n):
+        for e in (g[k], cs[k]):
+            e.set_tremolo_depth(0.15 * k); e.set_volume(0.4 + 0.05 * k)
+    held = [[] for _ in range(n)]
+    for b in range(blocks):
+        for k in range(n):
+            r = rng.random()
+            if r < 0.45 + 0.05 * k:                                   # busier engines get more notes; engine 6 fills up and steals
+                note, vel = int(rng.integers(33, 97)), float(rng.uniform(0.3, 1.0))
+                for e in (g[k], cs[k]):
+                    e.note_on(note, vel)
+                held[k].append(note)
+            if held[k] and rng.random() < 0.35:
+                note = held[k].pop(int(rng.integers(0, len(held[k]))))
+                for e in (g[k], cs[k]):
+                    e.note_off(note)
+            if rng.random() < 0.08:
+                on = bool(rng.integers(0, 2))
+                for e in (g[k], cs[k]):
+                    e.set_sustain(on)
+        go = g.render(length)
+        gv = g.voice_sum(length)
+        for k, c in enumerate(cs):
+            co, cv, _, _ = c.render_taps(length)
+            _check(oracle.parity_report(go[k], co, abs_floor=oracle.ABS_FLOOR_OUTPUT), ("played out", b, k))
+            _check(oracle.parity_report(gv[k], cv, rel=1e-11, floor_frac=1.0, abs_floor=1e-15), ("played voice_sum", b, k))
+            assert g[k].active_voice_count() == c.active_voice_count(), (b, k)
+            assert [g[k].slot_state(i) for i in range(64)] == [c.slot_state(i) for i in range(64)], (b, k)
+    assert "voice dispatch" not in binding.last_error(hiplib)
+    g.close()
+
+
 def test_config2_all_keys_restrike_against_oracle(hiplib, oracle):
     """BASELINE configs[1] event script: all 64 keys, 1.0 s re-strike, buffers of 512, 1.5 s."""
     import openwurli_amd as ow
