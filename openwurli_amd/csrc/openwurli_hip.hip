@@ -465,10 +465,15 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
         p->lists_valid = !any_dirty;     // engines with ops were classified "general" for this block only
         if (p->vl_steady.n_blocks)
             owdev::k_voice_steady<<<dim3(p->vl_steady.n_blocks), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_steady.d, p->d_sum, p->d_eout, I, L, Lcap);
-        if (p->vl_general.n_blocks)
-            owdev::k_voice<<<dim3(p->vl_general.n_blocks), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_general.d, p->d_sum, p->d_eout, I, L, Lcap, 0);
+        if (p->vl_general.n_blocks) {
+            // sparse general list (played input): tabulated phase gains; most engines in it (everything re-struck): plain variant
+            if ((size_t)p->vl_general.n_blocks * 4 < (size_t)ne)
+                owdev::k_voice<true><<<dim3(p->vl_general.n_blocks), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_general.d, p->d_sum, p->d_eout, I, L, Lcap, 0);
+            else
+                owdev::k_voice<false><<<dim3(p->vl_general.n_blocks), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_general.d, p->d_sum, p->d_eout, I, L, Lcap, 0);
+        }
         if (p->vl_steal.n_blocks)
-            owdev::k_voice<<<dim3(p->vl_steal.n_blocks), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_steal.d, p->d_sum, p->d_eout, I, L, Lcap, 1);
+            owdev::k_voice<false><<<dim3(p->vl_steal.n_blocks), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_steal.d, p->d_sum, p->d_eout, I, L, Lcap, 1);
     }
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[2], st));
     HIP_OK(hipStreamWaitEvent(st, p->ev_trem[rb_now_idx], 0));

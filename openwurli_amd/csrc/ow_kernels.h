@@ -106,6 +106,8 @@ __global__ __launch_bounds__(64) void k_apply_ops(const OwConsts* __restrict__ K
 // slot order, so it is still the reference's sequential sum -- without the +0.0 terms of the silent slots.
 #define OW_VCHUNK 24   // 64 voices x 24 samples x f64 = 12.8 KB tile: 8 voice blocks + 4 tremolo blocks fit the 160 KB LDS of a CU
 #define OW_NO_VOICE 0xFFFFFFFFu
+#define OW_GT_MAX 16      // lanes in an onset ramp / damper ramp up to which their gain curves are tabulated per chunk (k_voice)
+#define OW_DT_MAX 8
 
 struct VoiceLanes {           // per-lane view of one packed block
     int e, slot;
@@ -160,10 +162,15 @@ OW_DEV void voice_reduce(const double* __restrict__ tile, const int* __restrict_
 
 // General step (any phase).  pass 0 = slot voices of the engines the host classified as "in a transient phase", pass 1 = steal voices
 // (one engine per block there, so the crossfade early-out below is per engine).
+// TABS: tabulate phase gain curves per chunk (below).  The tables cost 14 KB of LDS (4 instead of 7 blocks per CU), so the host uses
+// this variant when the general list is sparse (played input) and the plain one when most engines are in it (a re-strike of everything).
+template <bool TABS>
 __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, double* __restrict__ vrec, const uint32_t* __restrict__ entries,
                                               double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int L, int Lcap, int pass) {
     __shared__ double tile[64 * (OW_VCHUNK + 1)];
     __shared__ double lcoef[OW_LCOEF_ROWS * 64];
+    __shared__ double gtab[TABS ? OW_GT_MAX * OW_VCHUNK : 1];       // onset gains of this chunk, one row per lane inside its onset ramp
+    __shared__ double dtab[TABS ? OW_DT_MAX * OW_VCHUNK * 7 : 1];   // damper-ramp factors of this chunk, [lane in its ramp][sample][mode]
     __shared__ int eng_l[64];
     const int lane = threadIdx.x;
     const VoiceLanes w = voice_lanes(entries, eng_l);
@@ -193,10 +200,42 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
             for (int i = base + lane; i < L; i += 64) row[i] = 0.0;
             break;
         }
+        // Phase gain curves of the chunk, lane-parallel over its samples.  The onset gain (cos, pow) and the damper-ramp factors
+        // (seven exp) depend on the voice's own sample counters only; evaluated inside the sample loop they cost every sample of
+        // the wavefront ~500 instructions as soon as ONE lane is in such a phase (a packed block mixes voices of many engines and
+        // phases).  Here each voice in a phase costs one pass of those functions per chunk, spread over the lanes.  With many lanes
+        // in the phase at once (a re-strike of all keys) the in-loop evaluation serves them all together and stays cheaper.
+        const uint64_t m_on = __ballot(active && v.sample < v.onset_n);
+        const uint64_t m_rp = __ballot(active && (v.flags & 1u) && !(v.flags & 2u));
+        const bool tab_on = TABS && m_on != 0ull && __popcll(m_on) <= OW_GT_MAX;
+        const bool tab_rp = TABS && m_rp != 0ull && __popcll(m_rp) <= OW_DT_MAX;
+        if (tab_on) {
+            int r = 0;
+            for (uint64_t m = m_on; m; m &= m - 1, ++r) {
+                const int l = __builtin_ctzll(m);
+                const unsigned long long s0 = __shfl((unsigned long long)v.sample, l), on = __shfl((unsigned long long)v.onset_n, l);
+                const double inc = __shfl(v.onset_inc, l), ex = __shfl(v.onset_exp, l);
+                if (lane < cn) gtab[r * OW_VCHUNK + lane] = (s0 + lane < on) ? onset_gain((double)(s0 + lane), inc, ex) : 1.0;
+            }
+        }
+        if (tab_rp) {
+            int r = 0;
+            for (uint64_t m = m_rp; m; m &= m - 1, ++r) {
+                const int l = __builtin_ctzll(m);
+                const double d0 = __shfl(v.dcount, l), dr = __shfl(v.dramp, l);
+                for (int q = lane; q < cn * 7; q += 64) {
+                    const int i = q / 7, md = q - 7 * i;
+                    const double t = d0 + (double)(i + 1);      // dcount after this sample's increment (exact: a sample count)
+                    dtab[(r * OW_VCHUNK + i) * 7 + md] = exp_neg(lcoef[(5 + md) * 64 + l] * t / dr);
+                }
+            }
+        }
+        const double* my_gt = (tab_on && ((m_on >> lane) & 1ull)) ? gtab + __popcll(m_on & ((1ull << lane) - 1ull)) * OW_VCHUNK : nullptr;
+        const double* my_dt = (tab_rp && ((m_rp >> lane) & 1ull)) ? dtab + __popcll(m_rp & ((1ull << lane) - 1ull)) * OW_VCHUNK * 7 : nullptr;
         for (int n = 0; n < cn; ++n) {
             double o = 0.0;
             if (active) {
-                o = v.step<false>(lcoef + lane);
+                o = v.step<false>(lcoef + lane, my_gt ? my_gt + n : nullptr, my_dt ? my_dt + 7 * n : nullptr);
                 if (pass) {  // 5 ms linear crossfade, engine.rs:483-489
                     const uint32_t i = (uint32_t)(base + n);
                     const uint32_t remaining = steal_fade > i ? steal_fade - i : 0u;

@@ -417,7 +417,10 @@ struct VoiceRegs {
     // (VF_NB0..VF_NA2, first 15 ms of a note), i = 5..11 damper_rate, i = 12..18 damper_mult (VF_DRATE / VF_DMULT, while the key is
     // released).  In registers they would cost 38 VGPRs for the whole kernel; read from the voice record in HBM they cost a
     // dependent global load per mode per sample for as long as a released voice rings (measured: the played workload's bottleneck).
-    OW_DEV double step(const double* __restrict__ lcoef) {
+    // onset_tab / damp_tab: this sample's onset gain / the seven damper-ramp factors exp(-rate t / ramp), evaluated ahead for the
+    // whole chunk by k_voice (lane-parallel over the samples), or nullptr to evaluate them here.
+    OW_DEV double step(const double* __restrict__ lcoef, const double* __restrict__ onset_tab = nullptr,
+                       const double* __restrict__ damp_tab = nullptr) {
 #ifndef OW_STRICT_FP
 #pragma clang fp contract(fast)
 #endif
@@ -428,7 +431,10 @@ struct VoiceRegs {
                 const double t = dcount;
                 if (!(flags & 2u)) {
                     if (t > dramp) flags |= 2u;
-                    else {
+                    else if (damp_tab) {
+#pragma unroll
+                        for (int m = 0; m < 7; ++m) env[m] *= damp_tab[m];
+                    } else {
 #pragma unroll
                         for (int m = 0; m < 7; ++m) {
                             const double inst_rate = lcoef[(5 + m) * 64] * t / dramp;
@@ -441,7 +447,7 @@ struct VoiceRegs {
                     for (int m = 0; m < 7; ++m) env[m] *= lcoef[(12 + m) * 64];
                 }
             }
-            if (sample < onset_n) onset = onset_gain((double)sample, onset_inc, onset_exp);
+            if (sample < onset_n) onset = onset_tab ? *onset_tab : onset_gain((double)sample, onset_inc, onset_exp);
         }
         const uint32_t lo = (uint32_t)sample;
         if ((lo & 15u) == 0u) {
