@@ -125,7 +125,6 @@ struct ow_pool {
     hipStream_t stream = nullptr;      // voices -> preamp -> output stage
     hipStream_t stream_trem = nullptr; // tremolo oscillator: no audio input (tremolo.rs:121), runs beside the voices
     hipEvent_t ev_trem[2] = {nullptr, nullptr};   // one per rbuf half
-    hipEvent_t ev_ops = nullptr;                  // k_apply_ops of the current block issued (gates the block-ahead tremolo)
     // The tremolo oscillator is produced one block ahead (speculating that the next block has the same length); the
     // tremolo rows of the chain state are backed up first so a mis-speculation can be rolled back.
     double* d_trem_backup = nullptr;   // [18][I]
@@ -346,6 +345,37 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
 void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
     const int I = (int)p->I;
     const int L = (int)len, Lcap = (int)p->Lcap;
+    hipStream_t st = p->stream, tt = p->stream_trem;
+    // ---- tremolo stream: CdS cell resistance of this block (already there if the block-ahead speculation hit)
+    const int n_os = L * (p->hc.oversample ? 2 : 1);
+    const size_t rb_half = (size_t)2 * p->Lcap * p->I;
+    const bool hit = p->spec.valid && p->spec.e0 == e0 && p->spec.ne == ne && p->spec.n_os == n_os;
+    if (p->spec.valid && !hit) {   // mis-speculated (different block length / engine range): roll the oscillator back
+        HIP_OK(hipMemcpyAsync(p->d_cs, p->d_trem_backup, sizeof(double) * 18 * p->I, hipMemcpyDeviceToDevice, tt));
+        p->spec.valid = false;
+    }
+    if (hit) {
+        p->rb_cur ^= 1;            // the half the speculation filled
+    } else {
+        owdev::k_tremolo<<<dim3((ne + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, p->d_rbuf + p->rb_cur * rb_half, I, n_os, e0, ne);
+        HIP_OK(hipEventRecord(p->ev_trem[p->rb_cur], tt));
+    }
+    const double* rb_now = p->d_rbuf + p->rb_cur * rb_half;
+    const int rb_now_idx = p->rb_cur;
+    // ---- next block, speculatively: back up the oscillator rows, then run ahead into the other half
+    auto launch_block_ahead = [&] {
+        const int nxt = p->rb_cur ^ 1;
+        HIP_OK(hipMemcpyAsync(p->d_trem_backup, p->d_cs, sizeof(double) * 18 * p->I, hipMemcpyDeviceToDevice, tt));
+        if (p->profiling) HIP_OK(hipEventRecord(p->ev[6], tt));
+        owdev::k_tremolo<<<dim3((ne + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, p->d_rbuf + nxt * rb_half, I, n_os, e0, ne);
+        if (p->profiling) HIP_OK(hipEventRecord(p->ev[7], tt));
+        HIP_OK(hipEventRecord(p->ev_trem[nxt], tt));
+        p->spec.valid = true; p->spec.e0 = e0; p->spec.ne = ne; p->spec.n_os = n_os;
+    };
+    // The oscillator goes first: it needs nothing from the host, so it runs while the host packs ops and voice lists, and its
+    // 1 024 wavefronts (one per SIMD) are resident before the voice kernel fills the rest.  (k_apply_ops is register-capped so that
+    // it fits beside them.)
+    launch_block_ahead();
     // ---- per-engine args + ops: only engines whose host state changed are touched (the rest keep their
     // uploaded args; a steady-state step of a large pool does no per-engine host work here)
     // Large pools split the range over host threads: slice t counts its pending ops, a prefix sum places the slices in h_ops,
@@ -407,55 +437,20 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
     }
     bool any_main = false, any_steal = false;
     for (int k = 0; k < ne; ++k) { any_main |= p->h_args[e0 + k].main_mask != 0; any_steal |= p->h_args[e0 + k].steal_mask != 0; }
-    hipStream_t st = p->stream, tt = p->stream_trem;
     // args carry one-shot fields (ops, setter targets): upload when anything changed, and once more afterwards to clear them
     if (any_dirty || p->args_stale) {
         HIP_OK(hipMemcpyAsync(p->d_args + e0, p->h_args + e0, sizeof(OwEngineArgs) * ne, hipMemcpyHostToDevice, st));
         p->args_stale = any_dirty;
     }
-    // ---- tremolo stream: CdS cell resistance of this block (already there if the block-ahead speculation hit)
-    const int n_os = L * (p->hc.oversample ? 2 : 1);
-    const size_t rb_half = (size_t)2 * p->Lcap * p->I;
-    const bool hit = p->spec.valid && p->spec.e0 == e0 && p->spec.ne == ne && p->spec.n_os == n_os;
-    if (p->spec.valid && !hit) {   // mis-speculated (different block length / engine range): roll the oscillator back
-        HIP_OK(hipMemcpyAsync(p->d_cs, p->d_trem_backup, sizeof(double) * 18 * p->I, hipMemcpyDeviceToDevice, tt));
-        p->spec.valid = false;
-    }
-    if (hit) {
-        p->rb_cur ^= 1;            // the half the speculation filled
-    } else {
-        owdev::k_tremolo<<<dim3((ne + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, p->d_rbuf + p->rb_cur * rb_half, I, n_os, e0, ne);
-        HIP_OK(hipEventRecord(p->ev_trem[p->rb_cur], tt));
-    }
-    const double* rb_now = p->d_rbuf + p->rb_cur * rb_half;
-    const int rb_now_idx = p->rb_cur;
-    // ---- next block, speculatively: back up the oscillator rows, then run ahead into the other half
-    auto launch_block_ahead = [&] {
-        const int nxt = p->rb_cur ^ 1;
-        HIP_OK(hipMemcpyAsync(p->d_trem_backup, p->d_cs, sizeof(double) * 18 * p->I, hipMemcpyDeviceToDevice, tt));
-        if (p->profiling) HIP_OK(hipEventRecord(p->ev[6], tt));
-        owdev::k_tremolo<<<dim3((ne + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, p->d_rbuf + nxt * rb_half, I, n_os, e0, ne);
-        if (p->profiling) HIP_OK(hipEventRecord(p->ev[7], tt));
-        HIP_OK(hipEventRecord(p->ev_trem[nxt], tt));
-        p->spec.valid = true; p->spec.e0 = e0; p->spec.ne = ne; p->spec.n_os = n_os;
-    };
-    // Without note events the oscillator goes first, so its 1 024 wavefronts (one per SIMD) are resident before the voice kernel
-    // fills the rest.  k_apply_ops keeps the MLP weights in ~500 registers per lane and cannot share a SIMD with a tremolo
-    // wavefront: with note events the oscillator starts after that (short) kernel instead of holding it up for a whole launch.
-    if (!n_ops) launch_block_ahead();
     HIP_OK(hipMemsetAsync(p->d_eout + e0, 0, sizeof(OwEngineOut) * ne, st));
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[0], st));
     if (n_ops) {
         HIP_OK(hipMemcpyAsync(p->d_ops, p->h_ops, sizeof(OwOp) * n_ops, hipMemcpyHostToDevice, st));
-        // one block per engine THAT HAS OPS: the kernel holds the MLP weights in ~500 registers, and a block that only finds
-        // op_count == 0 still pays for that prologue (measured 8 ms per launch for 65 536 mostly idle engines)
+        // one block per engine that has ops
         uint32_t n_act = 0;
         for (int k = 0; k < ne; ++k) if (p->h_args[e0 + k].op_count) p->h_op_engines[n_act++] = (uint32_t)(e0 + k);
         HIP_OK(hipMemcpyAsync(p->d_op_engines, p->h_op_engines, sizeof(uint32_t) * n_act, hipMemcpyHostToDevice, st));
         owdev::k_apply_ops<<<dim3(n_act), dim3(64), 0, st>>>(p->dK, p->d_nt, p->d_vrec, p->d_args, p->d_ops, p->d_op_engines);
-        HIP_OK(hipEventRecord(p->ev_ops, st));
-        HIP_OK(hipStreamWaitEvent(tt, p->ev_ops, 0));
-        launch_block_ahead();
     }
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[1], st));
     if (with_voices && (any_main || any_steal)) {
@@ -606,7 +601,6 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     HIP_OK(hipStreamCreateWithFlags(&p->stream_trem, hipStreamNonBlocking));
     for (auto& e : p->ev) HIP_OK(hipEventCreate(&e));
     for (auto& e : p->ev_trem) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags(&p->ev_ops, hipEventDisableTiming));
     HIP_OK(hipMalloc(&p->d_trem_backup, sizeof(double) * 18 * n_engines));
     HIP_OK(hipMalloc(&p->dK, sizeof(OwConsts)));
     HIP_OK(hipMalloc(&p->dK48, sizeof(OwConsts)));
@@ -680,7 +674,6 @@ void pool_destroy(ow_pool* p) {
     hipHostFree(p->h_args); hipHostFree(p->h_eout);
     for (auto& e : p->ev) if (e) hipEventDestroy(e);
     for (auto& e : p->ev_trem) if (e) hipEventDestroy(e);
-    if (p->ev_ops) hipEventDestroy(p->ev_ops);
     if (p->d_trem_backup) hipFree(p->d_trem_backup);
     if (p->stream_trem) hipStreamDestroy(p->stream_trem);
     if (p->stream) hipStreamDestroy(p->stream);

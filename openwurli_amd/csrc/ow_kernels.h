@@ -57,7 +57,9 @@ __device__ inline void mlp_raw_mfma(double* __restrict__ h, double in0, double i
 
 // Ops of one engine are applied in queue order per slot.  The wavefront advances in rounds: every lane takes its next
 // pending op; the note-ons of a round share ONE batched MLP evaluation on the f64 matrix cores (ow_mlp_mfma.h).
-__global__ __launch_bounds__(64) void k_apply_ops(const OwConsts* __restrict__ K, const double* __restrict__ nt, double* __restrict__ vrec,
+// Capped at 256 registers (it would take ~500 to keep the MLP weights resident): a wavefront of this kernel then fits beside a
+// tremolo wavefront on a SIMD, so the block-ahead oscillator can be launched before the host has prepared the ops.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_apply_ops(const OwConsts* __restrict__ K, const double* __restrict__ nt, double* __restrict__ vrec,
                                                   const OwEngineArgs* __restrict__ args, const OwOp* __restrict__ ops,
                                                   const uint32_t* __restrict__ engines) {
     __shared__ double h[64 * 17];
