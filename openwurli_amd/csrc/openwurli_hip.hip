@@ -454,7 +454,6 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
     }
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[1], st));
     if (with_voices && (any_main || any_steal)) {
-        // steady-state engines take the lean kernel; k_voice picks up engines with voices in a transient phase and all steal voices
         // the lists depend on masks, pending ops (any_dirty) and the transient flags of the previous block (post_render_host)
         if (!p->lists_valid || any_dirty || p->lists_e0 != e0 || p->lists_ne != ne) build_voice_lists(p, e0, ne);
         p->lists_valid = !any_dirty;     // engines with ops were classified "general" for this block only

@@ -1,7 +1,7 @@
 // openwurli-hip: device code for the voice layer (gfx950, wave64, f64).
 //
-//   lane = voice slot (64 slots = one wavefront, engine.rs:24), block = (engine, pass)
-//   pass 0 = slot voices, pass 1 = steal voices fading out (engine.rs:481-493)
+//   A voice record = one of the 64 slots of an engine (engine.rs:24), field-major [field][64 slots]; pass 0 = slot voices, pass 1 =
+//   steal voices fading out (engine.rs:481-493).  The voice kernels (ow_kernels.h) run one lane per SOUNDING voice, packed across engines.
 //
 // Mirrors (citations into /root/reference/crates/openwurli-dsp/src/):
 //   voice.rs:28-142   Voice::note_on            -> note_on_lane()
