@@ -11,7 +11,8 @@
  * Only constructors and the offline entry points report errors (NULL / negative return).
  *
  * A *pool* is the MI355X-native unit: I independent engines at one sample rate that render in
- * lock-step with lane-per-engine chain kernels.  An `ow_engine*` is one engine of a pool;
+ * lock-step: one lane per sounding voice (packed across engines) in the voice kernels, one lane
+ * per engine in the chain kernels.  An `ow_engine*` is one engine of a pool;
  * `ow_engine_new` creates a pool of one.
  */
 #ifndef OPENWURLI_HIP_H
@@ -62,7 +63,9 @@ void ow_pool_ensure_buffer_capacity(ow_pool*, size_t max_samples);
  * leave the block in HBM (see ow_pool_device_output).  Blocking; never fails. */
 void ow_pool_render(ow_pool*, float* out_host, size_t out_stride, size_t len);
 /* Sample-accurate MIDI for many engines in one call: the plugin's handle_event (plugin/src/lib.rs:49-62)
- * applied in array order.  type 0 = NoteOn(note, value=velocity 0..1), 1 = NoteOff(note), 2 = sustain (value >= 0.5 = held). */
+ * applied in array order.  type 0 = NoteOn(note, value=velocity 0..1), 1 = NoteOff(note), 2 = sustain (value >= 0.5 = held).
+ * Only the order of the events of one engine matters.  Large lists are applied by several host threads; a list grouped by engine
+ * (non-decreasing `engine`) is cut into per-thread slices, any other order makes every thread scan the whole list. */
 typedef struct ow_midi_event {
     uint32_t engine;
     uint8_t type;
