@@ -158,6 +158,10 @@ typedef struct ow_batch_cfg {
  * If out_is_device != 0, `out` is a device pointer and nothing is copied to the host.  Returns samples per job, <0 on error. */
 long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg* cfg, double* out, size_t stride, int out_is_device);
 
+/* Plain device buffers for chaining the offline entry points without a host round trip (out_is_device / audio_is_device). */
+void* ow_device_alloc(size_t bytes, int device);   /* NULL on failure */
+void ow_device_free(void* ptr, int device);
+
 /* ---- ML-pipeline stage after the batch render --------------------------------- */
 /* 24-bit PCM quantisers of the reference's two WAV writers.  OW_WAV_ROUND: preamp-bench write_wav_24bit
  * (tools/preamp-bench/src/main.rs:941-957): (sample * scale * (2^23-1)).round() as i32, clamped to +-(2^23-1); Rust round() is

@@ -1153,6 +1153,15 @@ long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg*
     } catch (const std::exception& ex) { set_err(std::string("ow_batch_render: ") + ex.what()); return -1; }
 }
 
+void* ow_device_alloc(size_t bytes, int device) {
+    void* ptr = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&ptr, bytes ? bytes : 1) != hipSuccess) { set_err("ow_device_alloc: hipMalloc failed"); return nullptr; }
+    return ptr;
+}
+void ow_device_free(void* ptr, int device) {
+    if (ptr && hipSetDevice(device) == hipSuccess) hipFree(ptr);
+}
+
 // ---- ML-pipeline stage after the batch render ---------------------------------------------------------------
 int ow_wav24_quantize(const double* samples, size_t n, double scale, int mode, int32_t* out) {
     if ((!samples || !out) && n) { set_err("ow_wav24_quantize: null argument"); return -1; }

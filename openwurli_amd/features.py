@@ -53,24 +53,30 @@ def write_wav_24bit(path, samples, sample_rate, scale=1.0, mode="round"):
 _WAV_MODES = {None: binding.WAV_NONE, "round": binding.WAV_ROUND, "truncate": binding.WAV_TRUNCATE}
 
 
-def extract_segments(audio, sample_rate, segments, search_pct=0.01, device=0, wav24=None):
+def extract_segments(audio, sample_rate, segments, search_pct=0.01, device=0, wav24=None, device_audio=None):
     """`extract_harmonics_fft` on many segments in one call.
 
     audio: float64 [rows, stride]; segments: iterable of (row, start, end, n_harmonics, f0).
     wav24: None analyses the samples as given; "round" / "truncate" analyses what a 24-bit WAV written with that quantiser
     reads back as (the reference script always goes through the file).
+    device_audio = (pointer, rows, stride): analyse f64 audio that is already in HBM (e.g. what batch_render left there) instead of
+    `audio` (which may then be None).
     Returns (amps [n, 8], freqs [n, 8], rms [n])."""
     lib = binding.load_library()
-    a = np.ascontiguousarray(audio, dtype=np.float64)
-    if a.ndim == 1:
-        a = a[None, :]
+    if device_audio is None:
+        a = np.ascontiguousarray(audio, dtype=np.float64)
+        if a.ndim == 1:
+            a = a[None, :]
+        ptr, rows, stride, on_dev = a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], 0
+    else:
+        ptr, rows, stride, on_dev = C.c_void_p(int(device_audio[0])), int(device_audio[1]), int(device_audio[2]), 1
     seg = np.array([tuple(s) for s in segments], dtype=np.dtype(binding.SEGMENT_DTYPE))
     n = seg.size
     amps = np.zeros((n, binding.MAX_HARMONICS)); freqs = np.zeros((n, binding.MAX_HARMONICS)); rms = np.zeros(n)
     if n == 0:
         return amps, freqs, rms
-    rc = lib.ow_extract_harmonics(a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], float(sample_rate),
-                                  seg.ctypes.data_as(C.c_void_p), n, float(search_pct), _WAV_MODES[wav24], int(device), 0,
+    rc = lib.ow_extract_harmonics(ptr, rows, stride, float(sample_rate),
+                                  seg.ctypes.data_as(C.c_void_p), n, float(search_pct), _WAV_MODES[wav24], int(device), on_dev,
                                   amps.ctypes.data_as(C.c_void_p), freqs.ctypes.data_as(C.c_void_p), rms.ctypes.data_as(C.c_void_p))
     if rc != 0:
         raise OwError(binding.last_error(lib))
@@ -102,18 +108,23 @@ def _note_segments(row, n_samples, sr, f0):
     return out
 
 
-def extract_model_features(audio, sr, pairs, device=0, wav24="round"):
+def extract_model_features(audio, sr, pairs, device=0, wav24="round", device_audio=None):
     """`extract_model_features(wav_paths, pairs)` (render_model_notes.py:118-237) on renders that are still in memory:
     audio[j] is the note of pairs[j] = (midi, velocity), starting at t = 0.  One GPU call for all notes.
-    wav24="round" (default) reproduces the script's WAV round trip (preamp-bench writes, soundfile reads) without the files."""
-    a = np.ascontiguousarray(audio, dtype=np.float64)
-    n_samples = a.shape[1]
+    wav24="round" (default) reproduces the script's WAV round trip (preamp-bench writes, soundfile reads) without the files.
+    device_audio = (pointer, rows, stride, n_samples): the renders are still in HBM (see render_and_extract)."""
+    if device_audio is None:
+        a = np.ascontiguousarray(audio, dtype=np.float64)
+        n_samples = a.shape[1]
+        dev = None
+    else:
+        a, n_samples, dev = None, int(device_audio[3]), device_audio[:3]
     plan, flat = [], []
     for j, (midi, _) in enumerate(pairs):
         segs = _note_segments(j, n_samples, sr, midi_to_freq(midi))
         plan.append([None if s is None else len(flat) + sum(1 for t in segs[:i] if t is not None) for i, s in enumerate(segs)])
         flat.extend(s for s in segs if s is not None)
-    amps, freqs, rms = extract_segments(a, sr, flat, 0.01, device, wav24)
+    amps, freqs, rms = extract_segments(a, sr, flat, 0.01, device, wav24, dev)
     features = {}
     for j, (midi, vel) in enumerate(pairs):
         idx = plan[j]
@@ -145,3 +156,22 @@ def extract_model_features(audio, sr, pairs, device=0, wav24="round"):
             feat[f"centroid_{name}"] = round(float(np.sum(fr[ok] * am[ok]) / np.sum(am[ok])), 1) if np.any(ok) else None
         features[(midi, vel)] = feat
     return features
+
+
+def render_and_extract(pairs, sample_rate=44100.0, duration_s=2.0, device=0, preamp_kind=0, wav24="round"):
+    """Stages 3 + 4 of ml/render_model_notes.py in one go, nothing leaving the GPU in between: `preamp-bench render` of every
+    (midi, velocity) pair (ow_batch_render into a device buffer) and `extract_model_features` on that buffer.
+    Returns the features dictionary."""
+    from .engine import batch_render
+    lib = binding.load_library()
+    pairs = list(pairs)
+    n = int(duration_s * sample_rate)
+    buf = lib.ow_device_alloc(8 * len(pairs) * n, int(device))
+    if not buf:
+        raise OwError(binding.last_error(lib))
+    try:
+        batch_render([{"note": m, "velocity": v} for m, v in pairs], sample_rate=sample_rate, duration_s=duration_s, device=device,
+                     preamp_kind=preamp_kind, out_device_ptr=buf, stride=n)
+        return extract_model_features(None, sample_rate, pairs, device, wav24, device_audio=(buf, len(pairs), n, n))
+    finally:
+        lib.ow_device_free(buf, int(device))

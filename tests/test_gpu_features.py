@@ -102,6 +102,18 @@ def test_extract_model_features_matches_oracle(hiplib):
             assert abs(f[f"centroid_{name}"] - ref[f"centroid_{name}"]) <= 0.101
 
 
+def test_render_and_extract_stays_on_the_device(hiplib):
+    """ow_batch_render(out_is_device) -> ow_extract_harmonics(audio_is_device): same dictionary as the two host-visible steps."""
+    import openwurli_amd as ow
+    from openwurli_amd import features
+    sr = 44100.0
+    pairs = [(40, 50), (60, 127), (79, 95), (93, 35)]
+    one = features.render_and_extract(pairs, sample_rate=sr, duration_s=1.0)
+    audio = ow.batch_render([{"note": n, "velocity": v} for n, v in pairs], sample_rate=sr, duration_s=1.0)
+    two = features.extract_model_features(audio, sr, pairs)
+    assert one == two and list(one) == pairs
+
+
 def test_features_full_size_properties(hiplib):
     """Config-4 sized call (512 notes x 11 segments) on synthetic audio: linearity in amplitude (amps scale, peak bins do not
     move) and agreement of a sample of segments with the oracle."""
