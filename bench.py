@@ -163,7 +163,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--instances", type=int, default=int(os.environ.get("OW_BENCH_INSTANCES", "65536")), help="engine instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-rate", type=float, default=48000.0,
+                    help="host sample rate: 48000 = BASELINE configs[1] (the metric's config, default); 96000 = configs[2] (no oversampling)")
     args = ap.parse_args()
+    global SR, EPOCH, FLOPS_TREMOLO, FLOPS_PREAMP, FLOPS_POST, FLOPS_PER_SAMPLE
+    if args.host_rate != SR:
+        SR = float(args.host_rate)
+        EPOCH = int(SR)                              # 1.0 s re-strike epochs at any rate
+        osr = 2 if SR < 88200.0 else 1               # engine.rs:195
+        FLOPS_TREMOLO = osr * (1000 + 25)
+        FLOPS_PREAMP = osr * 1400 + (24 if osr == 2 else 0)
+        FLOPS_POST = osr * 90 + (24 if osr == 2 else 0) + 45
+        FLOPS_PER_SAMPLE = FLOPS_VOICES + FLOPS_TREMOLO + FLOPS_PREAMP + FLOPS_POST
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -244,13 +255,15 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "audio samples/s, 64-voice full chain (x real-time @48 kHz = value / 48000)",
+            "metric": f"audio samples/s, 64-voice full chain (x real-time @{SR / 1000:.0f} kHz = value / {SR:.0f})",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": "cfg2: 64-voice all-keys-sustained (1.0 s re-strike), 48 kHz host / 96 kHz chain, full chain "
-                            "(tremolo+legacy DK preamp+behavioural power amp+speaker), MLP on, buffers of 512",
+                "workload": ("cfg2: 64-voice all-keys-sustained (1.0 s re-strike), 48 kHz host / 96 kHz chain, full chain "
+                             "(tremolo+legacy DK preamp+behavioural power amp+speaker), MLP on, buffers of 512") if SR == 48000.0 else
+                            (f"cfg3: 64-voice all-keys-sustained (1.0 s re-strike), {SR:.0f} Hz host"
+                             f"{' (no oversampling)' if SR >= 88200.0 else ' / 2x chain'}, full chain, MLP on, buffers of 512"),
                 "instances_per_gpu": n_inst, "buffer": BUF, "parallelism": f"{world} x independent pools (no data-path collective)",
             },
             "x_realtime_aggregate": value / SR,
