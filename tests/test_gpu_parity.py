@@ -405,6 +405,36 @@ def test_pool_midi_threaded_paths_agree(hiplib):
     assert "voice dispatch" not in binding.last_error(hiplib)
 
 
+@pytest.mark.parametrize("sr", [48000.0, 96000.0])
+def test_configs_2_and_3_in_full(hiplib, oracle, sr):
+    """configs 2 and 3 IN FULL -- 10 s, all 64 keys, re-strike every 1.0 s (ten epochs of release-steal + 5 ms crossfades),
+    buffers of 512, 48 kHz host / 96 kHz chain and 96 kHz host without oversampling; a second instance runs the speaker at
+    character 1.0 (polynomial + tanh + thermal path) with the per-instance velocity of config 5."""
+    import openwurli_amd as ow
+    g, cs = _both(ow, oracle, sr, n=2)
+    for k in range(2):
+        for e in (g[k], cs[k]):
+            e.set_volume(0.5); e.set_tremolo_depth(0.5); e.set_speaker_character(1.0 * k); e.set_mlp_enabled(True)
+    epoch, total, pos, worst = int(sr), int(10.0 * sr), 0, 0.0
+    while pos < total:
+        if pos % epoch == 0:
+            for k in range(2):
+                for e in (g[k], cs[k]):
+                    for n in range(33, 97):
+                        if pos:
+                            e.note_off(n)
+                        e.note_on(n, (40 + 37 * k % 88) / 127.0 if k else VEL)
+        length = min(512, epoch - pos % epoch, total - pos)
+        go = g.render(length)
+        for k in range(2):
+            rep = oracle.parity_report(go[k], cs[k].render(length), abs_floor=oracle.ABS_FLOOR_OUTPUT)
+            worst = max(worst, rep["worst_ratio"])
+            _check(rep, ("full config", sr, pos, k))
+        pos += length
+    assert worst < 1.0 and all(g[k].active_voice_count() == cs[k].active_voice_count() for k in range(2))
+    g.close()
+
+
 # ------------------------------------------------------------------ size-independent properties at full size
 def test_properties_full_size(hiplib):
     """64-voice instances at the bench size: determinism (two pools, same script -> bit-identical), volume linearity
