@@ -470,7 +470,7 @@ def test_batch_render_jobs(hiplib, oracle, sr):
     """16-job subset of config 4: notes {33,48,60,72,84,91,96,40} x velocities {50,127}, render_model_notes flags."""
     import openwurli_amd as ow
     jobs = [{"note": n, "velocity": v} for n in (33, 48, 60, 72, 84, 91, 96, 40) for v in (50, 127)]
-    dur = 0.75
+    dur = 5.0 if sr == 48000.0 else 0.75        # config 4 length (5 s) at 48 kHz; the reference's default rate gets a short run
     g = ow.batch_render(jobs, sample_rate=sr, duration_s=dur)
     assert g.shape == (16, int(dur * sr))
     for i, j in enumerate(jobs):
