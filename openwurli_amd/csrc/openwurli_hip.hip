@@ -532,6 +532,7 @@ void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
 
 void collect_profile(ow_pool* p) {
     if (!p->profiling) return;
+    hipEventSynchronize(p->ev[7]);   // in a small pool the block-ahead tremolo outlasts the audio stream; profiling waits for it, a normal render does not
     hipEventElapsedTime(&p->last_ms[0], p->ev[0], p->ev[1]);   // ops
     hipEventElapsedTime(&p->last_ms[1], p->ev[1], p->ev[2]);   // voices
     hipEventElapsedTime(&p->last_ms[2], p->ev[6], p->ev[7]);   // tremolo (own stream)
