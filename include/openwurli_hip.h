@@ -81,6 +81,8 @@ int ow_pool_read_voice_sum(ow_pool*, double* out_host, size_t out_stride, size_t
 /* Preamp output (main - shadow, before the power amp) of the last block at the chain rate: f64 [n_engines][n_os],
  * n_os = len * (oversampled ? 2 : 1). */
 int ow_pool_read_preamp_out(ow_pool*, double* out_host, size_t out_stride, size_t n_os);
+/* CdS-cell resistance R[n] the tremolo produced for the last block (before the depth divider), chain rate: f64 [n_engines][n_os]. */
+int ow_pool_read_tremolo_r(ow_pool*, double* out_host, size_t out_stride, size_t n_os);
 /* HIP stream the pool launches on (hipStream_t as void*), for event timing by the caller. */
 void* ow_pool_stream(ow_pool*);
 /* Time (ms, HIP events on the pool stream) each kernel of the last ow_pool_render took:

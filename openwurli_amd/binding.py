@@ -59,6 +59,7 @@ SYMBOLS = {
     "ow_pool_device_output": (_VP, [_VP, C.POINTER(C.c_size_t)]),
     "ow_pool_read_voice_sum": (C.c_int, [_VP, _VP, C.c_size_t, C.c_size_t]),
     "ow_pool_read_preamp_out": (C.c_int, [_VP, _VP, C.c_size_t, C.c_size_t]),
+    "ow_pool_read_tremolo_r": (C.c_int, [_VP, _VP, C.c_size_t, C.c_size_t]),
     "ow_pool_stream": (_VP, [_VP]),
     "ow_pool_set_profiling": (None, [_VP, C.c_int]),
     "ow_pool_last_kernel_ms": (None, [_VP, C.POINTER(C.c_float)]),

@@ -21,6 +21,7 @@
 #include "ow_mlp_mfma.h"
 #include "ow_melange_dev.h"
 #include "ow_features.h"
+#include "ow_trem_wide.h"
 #include <map>
 #include <mutex>
 
@@ -239,6 +240,12 @@ enum { INIT_NEW = 1, INIT_RATE = 2, INIT_RESET = 0 };
 
 // chain (re)initialisation of engines [e0, e0+ne): DC states on the device, then the Twin-T settle
 // (50 warm-up steps at the codegen matrices + 2 s at the pool rate), all in the product kernels.
+// Pools this small leave SIMDs idle, and the oscillator's serial latency is their block time: four lanes per engine (ow_trem_wide.h).
+// OW_TREM_WIDE=0/1 forces the choice (the parity test compares the two kernels bit for bit).
+static inline bool trem_wide(int ne) {
+    if (const char* env = std::getenv("OW_TREM_WIDE")) return env[0] == '1';
+    return ne <= 16384;
+}
 void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<double>& depth0) {
     invalidate_spec(p);
     HIP_OK(hipStreamSynchronize(p->stream));
@@ -254,9 +261,14 @@ void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<do
     if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)   // DkPreamp::new / reset of the melange adapter: settled state at the chain rate
         owdev::k_mel_init<<<dim3((2 * ne + 63) / 64), dim3(64), 0, p->stream>>>(p->d_cs, p->d_mel_settled, p->d_noise, I, e0, ne);
     const int blocks = (ne + 63) / 64;
-    owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, I, e0, ne, 50LL);
     const long long n_settle = (long long)owhip::sat_u32(p->hc.os_sr * 2.0);
-    owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, I, e0, ne, n_settle);
+    if (trem_wide(ne)) {   // small range: four lanes per engine (ow_trem_wide.h); the 2-second settle is pure serial latency
+        owdev::k_tremolo_wide<true><<<dim3((ne + 15) / 16), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, nullptr, I, 50LL, e0, ne);
+        owdev::k_tremolo_wide<true><<<dim3((ne + 15) / 16), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, nullptr, I, n_settle, e0, ne);
+    } else {
+        owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, I, e0, ne, 50LL);
+        owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, I, e0, ne, n_settle);
+    }
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(p->stream));   // the tremolo stream picks these rows up next (init-time sync)
 }
@@ -340,6 +352,12 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
     p->lists_e0 = e0; p->lists_ne = ne;
 }
 
+static void launch_tremolo(ow_pool* p, hipStream_t tt, double* rbuf, int n_os, int e0, int ne) {
+    const int I = (int)p->I;
+    if (trem_wide(ne)) owdev::k_tremolo_wide<false><<<dim3((ne + 15) / 16), dim3(64), 0, tt>>>(p->dK, p->d_cs, rbuf, I, (long long)n_os, e0, ne);
+    else owdev::k_tremolo<<<dim3((ne + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, rbuf, I, n_os, e0, ne);
+}
+
 // One render of `len` samples for engines [e0, e0+ne).  with_voices=false skips the voice kernels
 // (warm-up of engines whose voices were just freed).
 void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
@@ -357,7 +375,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
     if (hit) {
         p->rb_cur ^= 1;            // the half the speculation filled
     } else {
-        owdev::k_tremolo<<<dim3((ne + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, p->d_rbuf + p->rb_cur * rb_half, I, n_os, e0, ne);
+        launch_tremolo(p, tt, p->d_rbuf + p->rb_cur * rb_half, n_os, e0, ne);
         HIP_OK(hipEventRecord(p->ev_trem[p->rb_cur], tt));
     }
     const double* rb_now = p->d_rbuf + p->rb_cur * rb_half;
@@ -367,7 +385,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
         const int nxt = p->rb_cur ^ 1;
         HIP_OK(hipMemcpyAsync(p->d_trem_backup, p->d_cs, sizeof(double) * 18 * p->I, hipMemcpyDeviceToDevice, tt));
         if (p->profiling) HIP_OK(hipEventRecord(p->ev[6], tt));
-        owdev::k_tremolo<<<dim3((ne + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, p->d_rbuf + nxt * rb_half, I, n_os, e0, ne);
+        launch_tremolo(p, tt, p->d_rbuf + nxt * rb_half, n_os, e0, ne);
         if (p->profiling) HIP_OK(hipEventRecord(p->ev[7], tt));
         HIP_OK(hipEventRecord(p->ev_trem[nxt], tt));
         p->spec.valid = true; p->spec.e0 = e0; p->spec.ne = ne; p->spec.n_os = n_os;
@@ -798,6 +816,20 @@ int ow_pool_read_preamp_out(ow_pool* p, double* out_host, size_t out_stride, siz
             for (size_t n = 0; n < n_os; ++n) out_host[e * out_stride + n] = a[n * I + e];
         return 0;
     } catch (const std::exception& ex) { set_err(std::string("ow_pool_read_preamp_out: ") + ex.what()); return -1; }
+}
+
+int ow_pool_read_tremolo_r(ow_pool* p, double* out_host, size_t out_stride, size_t n_os) {
+    if (!p || !out_host || n_os > 2 * p->Lcap) return -1;
+    try {
+        HIP_OK(hipSetDevice(p->device));
+        const size_t I = p->I;
+        std::vector<double> a(I * n_os);
+        const double* src = p->d_rbuf + (size_t)p->rb_cur * (2 * p->Lcap * I);   // the half the last block consumed, [n_os][I]
+        HIP_OK(hipMemcpy(a.data(), src, sizeof(double) * I * n_os, hipMemcpyDeviceToHost));
+        for (size_t e = 0; e < I; ++e)
+            for (size_t n = 0; n < n_os; ++n) out_host[e * out_stride + n] = a[n * I + e];
+        return 0;
+    } catch (const std::exception& ex) { set_err(std::string("ow_pool_read_tremolo_r: ") + ex.what()); return -1; }
 }
 
 // ---- engines ------------------------------------------------------------------------------------

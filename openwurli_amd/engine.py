@@ -201,6 +201,13 @@ class EnginePool:
             raise OwError(binding.last_error(self._lib))
         return out
 
+    def tremolo_r(self, n_os):
+        """CdS-cell resistance stream of the last block, float64 [n, n_os]."""
+        out = np.zeros((self.n, int(n_os)), dtype=np.float64)
+        if self._lib.ow_pool_read_tremolo_r(self._h, out.ctypes.data_as(C.c_void_p), int(n_os), int(n_os)) != 0:
+            raise OwError(binding.last_error(self._lib))
+        return out
+
     def preamp_out(self, n_os):
         out = np.zeros((self.n, int(n_os)), dtype=np.float64)
         if self._lib.ow_pool_read_preamp_out(self._h, out.ctypes.data_as(C.c_void_p), int(n_os), int(n_os)) != 0:

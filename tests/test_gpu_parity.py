@@ -6,6 +6,8 @@ where ABS_FLOOR = 2e-9 is the reference algorithm's own indeterminacy measured b
 tests/test_oracle_sensitivity.py (Newton stop criterion 1e-9 V in the legacy preamp).  The f64 voice-sum tap is
 held to 1e-12 of peak (same arithmetic, different libm only in transient phases).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -236,6 +238,36 @@ def test_voices_keep_their_rate_constants_across_set_sample_rate(hiplib, oracle)
     g.set_sample_rate(96000.0); cs[0].set_sample_rate(96000.0)           # no oversampling from here
     _render_compare(oracle, g, cs, 2, 960, "second change")
     g.close()
+
+
+def test_tremolo_wide_is_bit_identical(hiplib, oracle):
+    """Small pools run the Twin-T oscillator with four lanes per engine (ow_trem_wide.h: rows / ports / elimination rows spread over a
+    quad); large pools with one lane per engine.  Both must produce the SAME bits: the settle of 50 + 2 sr steps at pool creation,
+    then R[n] over several blocks incl. a block-length change (speculation rollback), at two rates; and both match the oracle."""
+    import openwurli_amd as ow
+    for sr in (48000.0, 44100.0):
+        streams = {}
+        for wide in ("0", "1"):
+            os.environ["OW_TREM_WIDE"] = wide
+            try:
+                p = ow.EnginePool(sr, 3)
+                p.set_sample_rate(sr)
+                rs = []
+                for length in (512, 512, 100, 512, 37):
+                    p.render(length)
+                    rs.append(p.tremolo_r(2 * length)[1].copy())
+                p.close()
+            finally:
+                del os.environ["OW_TREM_WIDE"]
+            streams[wide] = np.concatenate(rs)
+        assert np.array_equal(streams["0"], streams["1"]), (sr, np.max(np.abs(streams["0"] - streams["1"])))
+        assert 1e3 < streams["1"].min() < streams["1"].max() <= 1e6
+        c = oracle.OracleEngine(sr)
+        c.set_sample_rate(sr)
+        ro = np.concatenate([c.render_taps(n)[3] for n in (512, 512, 100, 512, 37)])   # oracle tap = shunt impedance at depth 0.5
+        r = streams["1"]
+        shunt = 25000.0 * 18000.0 / (25000.0 + 18000.0) + 25000.0 * (680.0 + r) / (25000.0 + (680.0 + r))   # tremolo.rs:152-167
+        assert np.max(np.abs(shunt - ro) / ro) < 1e-9
 
 
 def test_pool_of_independent_engines(hiplib, oracle):
