@@ -197,6 +197,31 @@ typedef struct ow_segment {
 int ow_extract_harmonics(const double* audio, size_t n_rows, size_t stride, double sample_rate, const ow_segment* segs, size_t n_segs,
                          double search_pct, int wav24_mode, int device, int audio_is_device, double* amps, double* freqs, double* rms);
 
+/* ---- click-band alias audit (crates/openwurli-dsp/src/alias_audit.rs) ----------- */
+/* AliasAuditResult (alias_audit.rs:68-93), same fields in the same order. */
+#define OW_AUDIT_HARMONICS 12
+typedef struct ow_alias_audit_result {
+    double f0_hz;                               /* peak of the +-5 Hz / 0.1 Hz search around the nominal pitch */
+    double h1_dbfs;                             /* H1 magnitude, dB FS */
+    double harmonic_db[OW_AUDIT_HARMONICS];     /* H(i+1), dB FS */
+    double harmonic_dbc[OW_AUDIT_HARMONICS];    /* H(i+1) relative to H1, dB; [0] is 0.0 */
+    double max_step_up_db;                      /* largest harmonic_dbc[n+1] - harmonic_dbc[n], n over H6..H10 */
+    uint32_t max_step_up_from_harmonic;         /* 1-based harmonic the worst rise starts from */
+    uint32_t reserved;
+    double hf_band_dbc;                         /* RMS of the 5-18 kHz band relative to H1, dB */
+} ow_alias_audit_result;
+/* analyze (alias_audit.rs:163-211) of n_signals rows at once.  signals: f64 [n_signals][stride], the first `len` samples of a
+ * row are the render (device pointer if signals_is_device != 0); the last floor(sample_rate * 0.5) of them are analysed.
+ * nominal_f0: [n_signals].  Returns 0; <0 if len is shorter than the analysis window (the reference asserts) or on a device error. */
+int ow_alias_audit_analyze(const double* signals, size_t n_signals, size_t stride, size_t len, double sample_rate,
+                           const double* nominal_f0, int device, int signals_is_device, ow_alias_audit_result* out);
+/* run_with_note for n (note, velocity 0..127) pairs at once (alias_audit.rs:104-108; run_sweep :123-133 is the three
+ * STIMULUS_NOTES at velocity 120): one pool engine per pair renders the canonical stimulus (render_stimulus :135-160: 44.1 kHz,
+ * volume 0.5, tremolo depth 0, speaker 0, MLP on, noise off, six settling blocks of 1024, note-on, 1.5 s in blocks of 1024), the
+ * blocks stay in HBM and are analysed there.  signals_out: NULL or host f64 [n][signals_stride >= 66150] receiving the renders. */
+int ow_alias_audit_run(const uint8_t* notes, const uint8_t* velocities, size_t n, int device, int preamp_kind,
+                       ow_alias_audit_result* out, double* signals_out, size_t signals_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,12 @@ class OwBatchCfg(C.Structure):
     _fields_ = [("sample_rate", C.c_double), ("duration_s", C.c_double), ("device", C.c_int), ("preamp_kind", C.c_int)]
 
 
+class OwAliasAuditResult(C.Structure):
+    _fields_ = [("f0_hz", C.c_double), ("h1_dbfs", C.c_double), ("harmonic_db", C.c_double * 12), ("harmonic_dbc", C.c_double * 12),
+                ("max_step_up_db", C.c_double), ("max_step_up_from_harmonic", C.c_uint32), ("reserved", C.c_uint32),
+                ("hf_band_dbc", C.c_double)]
+
+
 # every symbol include/openwurli_hip.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 class OwSegment(C.Structure):
@@ -98,6 +104,8 @@ SYMBOLS = {
     "ow_wav24_write": (C.c_int, [C.c_char_p, _VP, C.c_size_t, C.c_uint32, C.c_double, C.c_int]),
     "ow_extract_harmonics": (C.c_int, [_VP, C.c_size_t, C.c_size_t, C.c_double, _VP, C.c_size_t, C.c_double, C.c_int, C.c_int, C.c_int,
                                        _VP, _VP, _VP]),
+    "ow_alias_audit_analyze": (C.c_int, [_VP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, _VP, C.c_int, C.c_int, _VP]),
+    "ow_alias_audit_run": (C.c_int, [_VP, _VP, C.c_size_t, C.c_int, C.c_int, _VP, _VP, C.c_size_t]),
 }
 
 

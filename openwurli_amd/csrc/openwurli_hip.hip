@@ -22,6 +22,7 @@
 #include "ow_melange_dev.h"
 #include "ow_features.h"
 #include "ow_trem_wide.h"
+#include "ow_audit.h"
 #include <map>
 #include <mutex>
 
@@ -1341,6 +1342,204 @@ int ow_extract_harmonics(const double* audio, size_t n_rows, size_t stride, doub
         hipStreamDestroy(st);
         return 0;
     } catch (const std::exception& ex) { set_err(std::string("ow_extract_harmonics: ") + ex.what()); return -1; }
+}
+
+}  // extern "C"
+
+// ---- click-band alias audit (alias_audit.rs) -----------------------------------------------------
+namespace {
+struct DevMem {   // device buffer released on every exit path
+    void* p = nullptr;
+    DevMem() = default;
+    DevMem(const DevMem&) = delete;
+    DevMem& operator=(const DevMem&) = delete;
+    ~DevMem() { if (p) hipFree(p); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+    void alloc(size_t bytes) { HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 8))); }
+};
+struct StreamOwner {
+    hipStream_t s = nullptr;
+    ~StreamOwner() { if (s) hipStreamDestroy(s); }
+};
+constexpr double AUDIT_SR = 44100.0, AUDIT_RENDER_S = 1.5, AUDIT_ANALYZE_S = 0.5;   // alias_audit.rs:47-53
+constexpr uint32_t AUDIT_PROBES = 112;   // nominal + the 0.1 Hz walk over +-5 Hz (101 or 102 points), rounded up
+inline double audit_db(double mag) { return mag > 0.0 ? 20.0 * std::log10(mag) : -200.0; }   // mag_to_db :242-248
+owdev::OwAuditBq audit_biquad(bool highpass, double fc, double q, double sr) {   // filters.rs:24-38 (RBJ), host libm like the reference
+    const double w0 = 2.0 * 3.14159265358979323846 * fc / sr;
+    const double cw = std::cos(w0), sw = std::sin(w0);
+    const double alpha = sw / (2.0 * q), a0 = 1.0 + alpha;
+    owdev::OwAuditBq c;
+    if (highpass) { c.b0 = ((1.0 + cw) / 2.0) / a0; c.b1 = (-(1.0 + cw)) / a0; c.b2 = ((1.0 + cw) / 2.0) / a0; }
+    else          { c.b0 = ((1.0 - cw) / 2.0) / a0; c.b1 = (1.0 - cw) / a0;    c.b2 = ((1.0 - cw) / 2.0) / a0; }
+    c.a1 = (-2.0 * cw) / a0;
+    c.a2 = (1.0 - alpha) / a0;
+    return c;
+}
+
+void alias_audit_analyze_device(const double* d_sig, size_t n_sig, size_t stride, size_t len, double sr, const double* nominal_f0,
+                                hipStream_t st, ow_alias_audit_result* out) {
+    const size_t analyze_n = (size_t)(sr * AUDIT_ANALYZE_S);   // alias_audit.rs:166
+    if (len < analyze_n)
+        throw std::runtime_error("alias_audit signal too short: " + std::to_string(len) + " samples for " + std::to_string(analyze_n) + " analysis window");
+    if (analyze_n == 0 || analyze_n > 0xffffffffull || n_sig > 65535) throw std::runtime_error("analysis window or signal count out of range");
+    const size_t tail_off = len - analyze_n;
+    const double nn = (double)analyze_n;
+    const double two_pi = 2.0 * 3.14159265358979323846;
+    auto magnitude = [&](double2 v) { const double a = v.x / nn, b = v.y / nn; return 2.0 * std::sqrt(a * a + b * b); };   // :239
+
+    // refine_f0 (:252-265): the probe list is the reference's own loop (nominal first, then f += 0.1 while f <= nominal + 5)
+    std::vector<double> freq(n_sig * AUDIT_PROBES, 0.0), omega(n_sig * AUDIT_PROBES, 0.0);
+    std::vector<uint32_t> count(n_sig, 0);
+    for (size_t s = 0; s < n_sig; ++s) {
+        const double nominal = nominal_f0[s];
+        uint32_t k = 0;
+        freq[s * AUDIT_PROBES + k++] = nominal;
+        double f = nominal - 5.0;
+        while (f <= nominal + 5.0) {
+            if (k >= AUDIT_PROBES) throw std::runtime_error("refine_f0 grid larger than expected");
+            freq[s * AUDIT_PROBES + k++] = f;
+            f += 0.1;
+        }
+        count[s] = k;
+        for (uint32_t j = 0; j < k; ++j) omega[s * AUDIT_PROBES + j] = two_pi * freq[s * AUDIT_PROBES + j] / sr;   // :233
+    }
+    DevMem d_omega, d_count, d_out, d_ss;
+    d_omega.alloc(sizeof(double) * omega.size());
+    d_count.alloc(sizeof(uint32_t) * n_sig);
+    d_out.alloc(sizeof(double2) * omega.size());
+    d_ss.alloc(sizeof(double) * n_sig);
+    HIP_OK(hipMemcpyAsync(d_omega.p, omega.data(), sizeof(double) * omega.size(), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_count.p, count.data(), sizeof(uint32_t) * n_sig, hipMemcpyHostToDevice, st));
+    owdev::k_audit_dft<<<dim3(AUDIT_PROBES, (unsigned)n_sig), dim3(256), 0, st>>>(d_sig, stride, tail_off, (uint32_t)analyze_n, d_omega.as<double>(),
+                                                                                 d_count.as<uint32_t>(), AUDIT_PROBES, d_out.as<double2>());
+    // bandpass_rms (:270-282) has no dependence on f0: same stream, behind the first DFT pass
+    owdev::OwAuditBand band;
+    band.hp = audit_biquad(true, 5000.0, 0.70710678118654752440, sr);     // HF_BAND_LO_HZ :62
+    band.lp = audit_biquad(false, 18000.0, 0.70710678118654752440, sr);   // HF_BAND_HI_HZ :64
+    owdev::k_audit_bandpass<<<dim3((unsigned)((n_sig + 63) / 64)), dim3(64), 0, st>>>(d_sig, stride, tail_off, (uint32_t)analyze_n, (uint32_t)n_sig, band,
+                                                                                      d_ss.as<double>());
+    std::vector<double2> spec(omega.size());
+    HIP_OK(hipMemcpyAsync(spec.data(), d_out.p, sizeof(double2) * spec.size(), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(st));
+    std::vector<double> f0(n_sig);
+    for (size_t s = 0; s < n_sig; ++s) {
+        double best_f = freq[s * AUDIT_PROBES], best = magnitude(spec[s * AUDIT_PROBES]);
+        for (uint32_t j = 1; j < count[s]; ++j) {
+            const double m = magnitude(spec[s * AUDIT_PROBES + j]);
+            if (m > best) { best = m; best_f = freq[s * AUDIT_PROBES + j]; }
+        }
+        f0[s] = best_f;
+        for (uint32_t k = 0; k < OW_AUDIT_HARMONICS; ++k) omega[s * AUDIT_PROBES + k] = two_pi * ((double)(k + 1) * best_f) / sr;   // :180
+        count[s] = OW_AUDIT_HARMONICS;
+    }
+    HIP_OK(hipMemcpyAsync(d_omega.p, omega.data(), sizeof(double) * omega.size(), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_count.p, count.data(), sizeof(uint32_t) * n_sig, hipMemcpyHostToDevice, st));
+    owdev::k_audit_dft<<<dim3(OW_AUDIT_HARMONICS, (unsigned)n_sig), dim3(256), 0, st>>>(d_sig, stride, tail_off, (uint32_t)analyze_n, d_omega.as<double>(),
+                                                                                       d_count.as<uint32_t>(), AUDIT_PROBES, d_out.as<double2>());
+    std::vector<double> ss(n_sig);
+    HIP_OK(hipMemcpyAsync(spec.data(), d_out.p, sizeof(double2) * spec.size(), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(ss.data(), d_ss.p, sizeof(double) * n_sig, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(st));
+    for (size_t s = 0; s < n_sig; ++s) {
+        ow_alias_audit_result& r = out[s];
+        std::memset(&r, 0, sizeof r);
+        const double h1 = magnitude(spec[s * AUDIT_PROBES]);   // dft_magnitude(tail, f0) :178 == the k = 0 probe
+        for (uint32_t k = 0; k < OW_AUDIT_HARMONICS; ++k) {
+            const double mag = magnitude(spec[s * AUDIT_PROBES + k]);
+            r.harmonic_db[k] = audit_db(mag);
+            r.harmonic_dbc[k] = h1 > 0.0 ? 20.0 * std::log10(mag / h1) : -200.0;
+        }
+        r.harmonic_dbc[0] = 0.0;
+        double worst = -INFINITY;
+        uint32_t worst_from = 6;                              // plateau_metric :213-227, PLATEAU_FIRST..LAST_HARMONIC = 6..11
+        for (uint32_t i = 5; i < 10; ++i) {
+            const double delta = r.harmonic_dbc[i + 1] - r.harmonic_dbc[i];
+            if (delta > worst) { worst = delta; worst_from = i + 1; }
+        }
+        r.f0_hz = f0[s];
+        r.h1_dbfs = audit_db(h1);
+        r.max_step_up_db = worst;
+        r.max_step_up_from_harmonic = worst_from;
+        const double hf_rms = std::sqrt(ss[s] / nn);
+        r.hf_band_dbc = h1 > 0.0 ? 20.0 * std::log10(hf_rms / h1) : -200.0;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int ow_alias_audit_analyze(const double* signals, size_t n_signals, size_t stride, size_t len, double sample_rate,
+                           const double* nominal_f0, int device, int signals_is_device, ow_alias_audit_result* out) {
+    try {
+        if (!signals || !nominal_f0 || !out) throw std::runtime_error("null argument");
+        if (!(sample_rate > 0.0) || len > stride) throw std::runtime_error("invalid sample rate or row length");
+        if (n_signals == 0) return 0;
+        HIP_OK(hipSetDevice(device));
+        StreamOwner so;
+        HIP_OK(hipStreamCreateWithFlags(&so.s, hipStreamNonBlocking));
+        DevMem d_sig;
+        const double* src = signals;
+        if (!signals_is_device) {
+            d_sig.alloc(sizeof(double) * n_signals * stride);
+            HIP_OK(hipMemcpyAsync(d_sig.p, signals, sizeof(double) * n_signals * stride, hipMemcpyHostToDevice, so.s));
+            src = d_sig.as<double>();
+        }
+        alias_audit_analyze_device(src, n_signals, stride, len, sample_rate, nominal_f0, so.s, out);
+        return 0;
+    } catch (const std::exception& ex) { set_err(std::string("ow_alias_audit_analyze: ") + ex.what()); return -1; }
+}
+
+int ow_alias_audit_run(const uint8_t* notes, const uint8_t* velocities, size_t n, int device, int preamp_kind,
+                       ow_alias_audit_result* out, double* signals_out, size_t signals_stride) {
+    ow_pool* pool = nullptr;
+    try {
+        if (!notes || !velocities || !out) throw std::runtime_error("null argument");
+        if (n == 0) return 0;
+        const size_t total = (size_t)(AUDIT_SR * AUDIT_RENDER_S);   // :151
+        if (signals_out && signals_stride < total) throw std::runtime_error("signals_stride shorter than the render");
+        g_err.clear();
+        pool = ow_pool_new(AUDIT_SR, n, device, preamp_kind);       // WurliEngine::new(sr) per stimulus, :137
+        if (!pool) throw std::runtime_error(g_err.empty() ? "pool creation failed" : g_err);
+        ow_pool_ensure_buffer_capacity(pool, 1024);                 // :138
+        for (size_t k = 0; k < n; ++k) {                            // :139-143
+            ow_engine* e = pool->engines[k];
+            ow_engine_set_volume(e, 0.5);
+            ow_engine_set_tremolo_depth(e, 0.0);
+            ow_engine_set_speaker_character(e, 0.0);
+            ow_engine_set_mlp_enabled(e, 1);
+            ow_engine_set_noise_enabled(e, 0);
+        }
+        for (int k = 0; k < 6; ++k) ow_pool_render(pool, nullptr, 0, 1024);   // smoother settle, :147-150
+        std::vector<double> nominal(n);
+        for (size_t k = 0; k < n; ++k) {
+            ow_engine_note_on(pool->engines[k], notes[k], (float)velocities[k] / 127.0f);   // :152
+            nominal[k] = 440.0 * std::pow(2.0, ((double)notes[k] - 69.0) / 12.0);            // midi_note_hz :284-287
+        }
+        DevMem d_sig;
+        d_sig.alloc(sizeof(double) * n * total);
+        size_t pos = 0;
+        while (pos < total) {                                       // :154-165
+            const size_t len = std::min<size_t>(1024, total - pos);
+            ow_pool_render(pool, nullptr, 0, len);
+            owdev::k_audit_gather<<<dim3((unsigned)((len + 255) / 256), (unsigned)n), dim3(256), 0, pool->stream>>>(
+                pool->d_out, pool->Lcap, d_sig.as<double>(), total, pos, (uint32_t)len);
+            pos += len;
+        }
+        HIP_OK(hipGetLastError());
+        if (!g_err.empty()) throw std::runtime_error(g_err);
+        if (signals_out)
+            HIP_OK(hipMemcpy2DAsync(signals_out, signals_stride * sizeof(double), d_sig.p, total * sizeof(double), total * sizeof(double), n,
+                                    hipMemcpyDeviceToHost, pool->stream));
+        alias_audit_analyze_device(d_sig.as<double>(), n, total, total, AUDIT_SR, nominal.data(), pool->stream, out);
+        pool_destroy(pool);
+        return 0;
+    } catch (const std::exception& ex) {
+        if (pool) pool_destroy(pool);
+        set_err(std::string("ow_alias_audit_run: ") + ex.what());
+        return -1;
+    }
 }
 
 }  // extern "C"

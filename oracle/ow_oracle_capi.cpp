@@ -10,6 +10,7 @@
 // reference's only golden numeric fixture (tests/golden/alias_audit_v0_5_1.json).
 // The melange-primitives Biquad boundary stays "parity unpinned" (see ow_voice.hpp).
 #include "ow_engine.hpp"
+#include "ow_alias_audit.hpp"
 #include <cstdio>
 
 using namespace owo;
@@ -274,5 +275,25 @@ void owo_oversampler_roundtrip(const double* x, double* up, double* y, size_t n)
     os.upsample_2x(x, n, up);
     os.downsample_2x(up, y, n);
 }
+
+// ---- alias_audit.rs (click-band alias detector) ----
+size_t owo_alias_audit_result_size() { return sizeof(AliasAuditResult); }
+int owo_alias_audit_analyze(const double* signal, size_t len, double sr, double nominal_f0, void* result) {
+    return audit_analyze(signal, len, sr, nominal_f0, (AliasAuditResult*)result) ? 0 : -1;
+}
+// render_stimulus (alias_audit.rs:127-160): returns the sample count, writes min(cap, count) samples
+size_t owo_alias_audit_render_stimulus(int note, int velocity, int preamp_kind, double* out, size_t cap) {
+    std::vector<double> v = audit_render_stimulus(note, velocity, preamp_kind);
+    const size_t n = std::min(cap, v.size());
+    for (size_t i = 0; i < n; ++i) out[i] = v[i];
+    return v.size();
+}
+int owo_alias_audit_run(int note, int velocity, int preamp_kind, void* result) {   // run_with_note, alias_audit.rs:104-108
+    std::vector<double> v = audit_render_stimulus(note, velocity, preamp_kind);
+    return audit_analyze(v.data(), v.size(), AUDIT_SAMPLE_RATE, audit_midi_note_hz(note), (AliasAuditResult*)result) ? 0 : -1;
+}
+double owo_alias_dft_magnitude(const double* s, size_t len, double freq, double sr) { return audit_dft_magnitude(s, len, freq, sr); }
+double owo_alias_bandpass_rms(const double* s, size_t len, double sr, double lo, double hi) { return audit_bandpass_rms(s, len, sr, lo, hi); }
+double owo_alias_plateau_metric(const double* dbc12, unsigned* from) { double w; uint32_t f; audit_plateau_metric(dbc12, &w, &f); *from = f; return w; }
 
 }  // extern "C"

@@ -27,12 +27,15 @@ def _configure(L):
         for name in ("owo_midi_to_freq", "owo_tip_mass_ratio", "owo_reed_length_mm", "owo_pickup_displacement_scale",
                      "owo_fundamental_decay_rate", "owo_output_scale", "owo_velocity_exponent", "owo_velocity_scurve",
                      "owo_register_trim_db", "owo_pickup_rms_proxy", "owo_freq_detune", "owo_dwell_time", "owo_onset_ramp_time",
-                     "owo_pickup_soft_saturate", "owo_fast_exp", "owo_power_amp"):
+                     "owo_pickup_soft_saturate", "owo_fast_exp", "owo_power_amp", "owo_alias_dft_magnitude", "owo_alias_bandpass_rms",
+                     "owo_alias_plateau_metric"):
             getattr(L, name).restype = C.c_double
         L.owo_render_note.restype = C.c_size_t
         L.owo_batch_render_job.restype = C.c_size_t
         L.owo_batch_render_job_kind.restype = C.c_size_t
         L.owo_engine_nan_guard_fires.restype = C.c_ulonglong
+        L.owo_alias_audit_render_stimulus.restype = C.c_size_t
+        L.owo_alias_audit_result_size.restype = C.c_size_t
     return L
 
 
@@ -131,6 +134,35 @@ def batch_render_job(note, vel_u8, dur, sr, volume=1.0, speaker=0.0, r_ldr=1e6, 
     return out[:got]
 
 
+class AliasAuditResult(C.Structure):
+    """alias_audit.rs:68-93 (same field order as include/openwurli_hip.h ow_alias_audit_result)."""
+    _fields_ = [("f0_hz", C.c_double), ("h1_dbfs", C.c_double), ("harmonic_db", C.c_double * 12), ("harmonic_dbc", C.c_double * 12),
+                ("max_step_up_db", C.c_double), ("max_step_up_from_harmonic", C.c_uint32), ("pad", C.c_uint32), ("hf_band_dbc", C.c_double)]
+
+
+def alias_audit_render_stimulus(note, velocity, preamp_kind=0, perturbed=False):
+    out = np.zeros(int(44100.0 * 1.5))
+    got = (lib_perturbed() if perturbed else lib()).owo_alias_audit_render_stimulus(int(note), int(velocity), int(preamp_kind), _p(out), C.c_size_t(out.size))
+    assert got == out.size
+    return out
+
+
+def alias_audit_analyze(signal, sr, nominal_f0):
+    assert lib().owo_alias_audit_result_size() == C.sizeof(AliasAuditResult)
+    signal = np.ascontiguousarray(signal, dtype=np.float64)
+    r = AliasAuditResult()
+    rc = lib().owo_alias_audit_analyze(_p(signal), C.c_size_t(signal.size), C.c_double(sr), C.c_double(nominal_f0), C.byref(r))
+    if rc != 0:
+        raise ValueError("alias_audit signal too short")
+    return r
+
+
+def alias_audit_run(note, velocity, preamp_kind=0):
+    r = AliasAuditResult()
+    assert lib().owo_alias_audit_run(int(note), int(velocity), int(preamp_kind), C.byref(r)) == 0
+    return r
+
+
 # Absolute indeterminacy of the REFERENCE ALGORITHM itself at the f32 output: the legacy preamp's Newton loop
 # stops at |f| < 1e-9 V (dk_preamp_legacy.rs:500), so a libm whose exp() differs in the last bit moves the preamp
 # node by ~5e-10 V and the output by ~5e-10 (tests/test_oracle_sensitivity.py measures it on the CPU oracle alone).
@@ -139,6 +171,9 @@ ABS_FLOOR_PREAMP = 2e-9
 # batch jobs (`preamp-bench render`): output = preamp x volume^2 x 7.5 with a static LDR, so the same indeterminacy
 # shows up ~10x larger (measured ~1.1e-8 by test_oracle_sensitivity.py)
 ABS_FLOOR_BATCH = 3e-8
+# alias-audit stimulus (tremolo depth 0, i.e. the LDR dark and the preamp at its lowest loop gain): the same one-ulp experiment
+# moves quiet samples by up to 2.5e-9 (tests/test_oracle_sensitivity.py::test_alias_audit_stimulus_floor)
+ABS_FLOOR_AUDIT = 4e-9
 # melange 12-node solver.  The reference (and the oracle) re-invert the 12x12 MNA matrix by LU for every sample whose R_ldr
 # moved; the GPU applies the mathematically identical rank-one (Sherman-Morrison) update of the inverse at the nominal pot.
 # While R_ldr is steady the two agree to 4-7e-10 at the preamp node.  While R_ldr moves fast (depth-knob ramp, tremolo trough)

@@ -437,6 +437,52 @@ def test_golden_spectral_baseline(oracle):
     assert max(shifts) - min(shifts) < 0.1, shifts
 
 
+# ---------------------------------------------------------------- alias_audit.rs:293-361 unit tests + the gate of alias_audit_regression.rs
+def test_alias_audit_plateau_metric_kats(oracle):
+    L = oracle.lib()
+    frm = C.c_uint()
+
+    def plateau(h):
+        a = np.array(h, dtype=np.float64)
+        return L.owo_alias_plateau_metric(_p(a), C.byref(frm)), frm.value
+    d, _ = plateau([-50.0 - 5.0 * i for i in range(12)])                       # :294-305 monotonic descent
+    assert d == -5.0
+    d, f = plateau([0, -10, -20, -30, -50, -67, -63, -58, -58, -58, -61, -70])  # :308-327 pre-fix signature
+    assert abs(d - 5.0) < 0.001 and f == 7                                     # first maximum wins (strict >): H7 -> H8
+    d, f = plateau([0, -10, -20, -30, -50, -74, -72, -71, -70, -84, -79, -90])  # :330-345 post-fix fixture
+    assert d == 5.0 and f == 10
+
+
+def test_alias_audit_dft_magnitude_recovers_known_sinusoid(oracle):           # :348-361
+    sr, f, amp = 44100.0, 1000.0, 0.7
+    n = int(sr * 0.5)
+    x = amp * np.sin(2.0 * np.pi * f * np.arange(n) / sr)
+    mag = oracle.lib().owo_alias_dft_magnitude(_p(x), C.c_size_t(n), C.c_double(f), C.c_double(sr))
+    assert abs(mag - amp) < 0.01
+    assert abs(mag - _dft_mag(x, f, sr)) < 1e-12
+
+
+def test_alias_audit_sweep_passes_the_reference_gate(oracle):
+    """alias_audit_regression.rs:59-127: run_sweep() against the v0.5.1 baseline with the reference's one-sided tolerances
+    (MAX_STEP_UP_TOLERANCE_DB = 1.5, HF_BAND_TOLERANCE_DB = 2.0), plus f0 on the 0.1 Hz search grid."""
+    base = json.load(open(os.path.join(HERE, "golden", "alias_audit_v0_5_1.json")))
+    assert [e["note"] for e in base["entries"]] == [72, 84, 91]               # STIMULUS_NOTES, alias_audit.rs:45
+    for ent in base["entries"]:
+        r = oracle.alias_audit_run(ent["note"], base["stimulus_velocity"])
+        assert abs(r.f0_hz - ent["f0_hz"]) < 0.051
+        assert r.max_step_up_db - ent["max_step_up_db"] <= 1.5
+        assert r.hf_band_dbc - ent["hf_band_dbc"] <= 2.0
+        assert r.harmonic_dbc[0] == 0.0 and abs(r.harmonic_db[0] - r.h1_dbfs) == 0.0
+        assert abs(r.harmonic_dbc[1] - ent["harmonic_dbc"][1]) < 1.0
+        # numpy cross-check of the restated analysis on the same stimulus
+        sig = oracle.alias_audit_render_stimulus(ent["note"], base["stimulus_velocity"])
+        tail = sig[-int(44100.0 * 0.5):]
+        assert abs(20 * np.log10(_dft_mag(tail, r.f0_hz, 44100.0)) - r.h1_dbfs) < 1e-9
+    short = np.zeros(1000)
+    with pytest.raises(ValueError):                                            # alias_audit.rs:167-171 assert
+        oracle.alias_audit_analyze(short, 44100.0, 440.0)
+
+
 # ---------------------------------------------------------------- tools/reed-renderer/tests/integration.rs:23-164
 def test_reed_renderer_properties(oracle):
     x = oracle.render_note(60, 100 / 127.0, 0.5, 44100.0)

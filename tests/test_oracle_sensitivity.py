@@ -57,3 +57,20 @@ def test_melange_floor(oracle):
     o1, p1 = run(True)
     assert np.max(np.abs(p1 - p0)) < 5e-9 < oracle.ABS_FLOOR_MELANGE_PREAMP
     assert np.max(np.abs(o1 - o0)) < 2e-8          # f32 rounding flips at |x| ~ 0.1 are 7.5e-9
+
+
+def test_alias_audit_stimulus_floor(oracle):
+    """The audit stimulus (alias_audit.rs:135-160) under the same one-ulp exp() experiment: quiet samples move by up to 2.5e-9,
+    and the audit's dB figures (harmonics 70-110 dB below H1) by up to a few 1e-3 dB -- the tolerances of tests/test_gpu_alias_audit.py."""
+    worst_quiet, worst_db = 0.0, 0.0
+    for note in (72, 84, 91):
+        a = oracle.alias_audit_render_stimulus(note, 120)
+        b = oracle.alias_audit_render_stimulus(note, 120, perturbed=True)
+        quiet = np.abs(a) < 1e-3 * np.max(np.abs(a))
+        worst_quiet = max(worst_quiet, float(np.max(np.abs(a - b)[quiet])))
+        ra = oracle.alias_audit_analyze(a, 44100.0, 440.0 * 2 ** ((note - 69) / 12))
+        rb = oracle.alias_audit_analyze(b, 44100.0, 440.0 * 2 ** ((note - 69) / 12))
+        assert ra.f0_hz == rb.f0_hz
+        worst_db = max(worst_db, max(abs(x - y) for x, y in zip(ra.harmonic_db, rb.harmonic_db)), abs(ra.hf_band_dbc - rb.hf_band_dbc))
+    assert 1e-10 < worst_quiet < oracle.ABS_FLOOR_AUDIT, worst_quiet
+    assert worst_db < 2e-2, worst_db
