@@ -222,6 +222,38 @@ int ow_alias_audit_analyze(const double* signals, size_t n_signals, size_t strid
 int ow_alias_audit_run(const uint8_t* notes, const uint8_t* velocities, size_t n, int device, int preamp_kind,
                        ow_alias_audit_result* out, double* signals_out, size_t signals_stride);
 
+/* ---- MIDI-file render (`preamp-bench render-midi`, tools/preamp-bench/src/main.rs:1603-1923) ---- */
+/* One timed event of the command's internal list (main.rs:1639-1649). */
+typedef struct ow_timed_event {
+    double time_s;
+    uint8_t type;        /* 0 NoteOn(note, value = velocity 1..127)  1 NoteOff(note)  2 Pedal(value != 0 = down) */
+    uint8_t note;
+    uint8_t value;
+    uint8_t reserved[5];
+} ow_timed_event;
+/* The part of midly 0.5.3 (Cargo.lock) the command uses: Standard MIDI File -> events with absolute times in seconds, in file
+ * order (main.rs:1627-1708): metrical timing only, tempo meta events applied per track (every track starts at 500 000 us per
+ * beat), note-on with velocity 0 = note-off, controller 64 >= 64 = pedal down.  track_filter < 0: all tracks (`--track N`
+ * otherwise).  Returns the event count (writes min(cap, count) events; out may be NULL with cap 0), <0 on malformed data. */
+long long ow_smf_parse(const uint8_t* data, size_t len, int track_filter, ow_timed_event* out, size_t cap);
+typedef struct ow_midi_render_cfg {
+    double volume;       /* --volume, default 0.60 (applied squared)       */
+    double speaker;      /* --speaker, default 1.0                         */
+    double tail_s;       /* --tail, default 2.0                            */
+    int no_poweramp;     /* --no-poweramp                                  */
+    int device;
+    int preamp_kind;     /* OW_PREAMP_LEGACY8 only (`--model dk` of the default build) */
+    int reserved;
+} ow_midi_render_cfg;
+typedef struct ow_midi_render_stats { uint64_t n_samples, note_ons, peak_polyphony; } ow_midi_render_stats;
+/* cmd_render_midi's render loop (main.rs:1711-1891) for n_jobs event lists at once, 44.1 kHz (BASE_SR, main.rs:27).
+ * Job j owns events[job_offsets[j] .. job_offsets[j+1]); they are stably sorted by time like the command does.  Its output is
+ * floor((last event time + tail_s) * 44100) samples (0 for an empty list, where the command prints and returns).
+ * out: host f64 [n_jobs][stride], rows zero-padded behind their job's samples; NULL only fills stats (to size the buffer).
+ * Returns the longest job's sample count, <0 on error (e.g. stride too small, NaN times). */
+long long ow_render_midi(const ow_timed_event* events, const size_t* job_offsets, size_t n_jobs, const ow_midi_render_cfg* cfg,
+                         double* out, size_t stride, ow_midi_render_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

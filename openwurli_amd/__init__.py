@@ -10,5 +10,6 @@ from .binding import load_library, library_path, OwError  # noqa: F401
 from .engine import WurliEngine, EnginePool, VoiceState, render_note, batch_render  # noqa: F401
 from . import features  # noqa: F401
 from . import alias_audit  # noqa: F401
+from . import midi_render  # noqa: F401
 
-__all__ = ["load_library", "library_path", "OwError", "WurliEngine", "EnginePool", "VoiceState", "render_note", "batch_render", "features", "alias_audit"]
+__all__ = ["load_library", "library_path", "OwError", "WurliEngine", "EnginePool", "VoiceState", "render_note", "batch_render", "features", "alias_audit", "midi_render"]

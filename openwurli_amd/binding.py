@@ -41,6 +41,22 @@ class OwAliasAuditResult(C.Structure):
                 ("hf_band_dbc", C.c_double)]
 
 
+class OwTimedEvent(C.Structure):
+    _fields_ = [("time_s", C.c_double), ("type", C.c_uint8), ("note", C.c_uint8), ("value", C.c_uint8), ("reserved", C.c_uint8 * 5)]
+
+
+TIMED_EVENT_DTYPE = [("time_s", "<f8"), ("type", "u1"), ("note", "u1"), ("value", "u1"), ("reserved", "u1", (5,))]
+
+
+class OwMidiRenderCfg(C.Structure):
+    _fields_ = [("volume", C.c_double), ("speaker", C.c_double), ("tail_s", C.c_double), ("no_poweramp", C.c_int), ("device", C.c_int),
+                ("preamp_kind", C.c_int), ("reserved", C.c_int)]
+
+
+class OwMidiRenderStats(C.Structure):
+    _fields_ = [("n_samples", C.c_uint64), ("note_ons", C.c_uint64), ("peak_polyphony", C.c_uint64)]
+
+
 # every symbol include/openwurli_hip.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 class OwSegment(C.Structure):
@@ -106,6 +122,8 @@ SYMBOLS = {
                                        _VP, _VP, _VP]),
     "ow_alias_audit_analyze": (C.c_int, [_VP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, _VP, C.c_int, C.c_int, _VP]),
     "ow_alias_audit_run": (C.c_int, [_VP, _VP, C.c_size_t, C.c_int, C.c_int, _VP, _VP, C.c_size_t]),
+    "ow_smf_parse": (C.c_longlong, [_VP, C.c_size_t, C.c_int, _VP, C.c_size_t]),
+    "ow_render_midi": (C.c_longlong, [_VP, _VP, C.c_size_t, _VP, _VP, C.c_size_t, _VP]),
 }
 
 

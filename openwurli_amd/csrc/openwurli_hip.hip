@@ -23,6 +23,7 @@
 #include "ow_features.h"
 #include "ow_trem_wide.h"
 #include "ow_audit.h"
+#include "ow_midi_kernels.h"
 #include <map>
 #include <mutex>
 
@@ -1540,6 +1541,191 @@ int ow_alias_audit_run(const uint8_t* notes, const uint8_t* velocities, size_t n
         set_err(std::string("ow_alias_audit_run: ") + ex.what());
         return -1;
     }
+}
+
+}  // extern "C"
+
+// ---- `preamp-bench render-midi` ---------------------------------------------------------------------
+namespace {
+struct SmfReader {   // the subset of the SMF grammar cmd_render_midi consumes through midly (main.rs:1627-1708)
+    const uint8_t* d; size_t n;
+    uint32_t be32(size_t p) const { return ((uint32_t)d[p] << 24) | ((uint32_t)d[p + 1] << 16) | ((uint32_t)d[p + 2] << 8) | (uint32_t)d[p + 3]; }
+    static uint32_t vlq(const uint8_t* d, size_t& p, size_t end) {
+        uint32_t v = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (p >= end) throw std::runtime_error("truncated track");
+            const uint8_t b = d[p++];
+            v = (v << 7) | (uint32_t)(b & 0x7F);
+            if (!(b & 0x80)) return v;
+        }
+        throw std::runtime_error("variable-length quantity longer than four bytes");
+    }
+    std::vector<ow_timed_event> events(int track_filter) const {
+        if (n < 14 || std::memcmp(d, "MThd", 4) != 0) throw std::runtime_error("not a Standard MIDI File");
+        const uint32_t hlen = be32(4);
+        if (hlen < 6 || 8 + (size_t)hlen > n) throw std::runtime_error("bad MThd chunk");
+        const uint32_t division = ((uint32_t)d[12] << 8) | d[13];
+        if (division & 0x8000u) throw std::runtime_error("Only metrical (ticks per beat) MIDI timing is supported");   // main.rs:1630-1636
+        const double ticks_per_beat = (double)division;
+        std::vector<ow_timed_event> out;
+        int track_idx = 0;
+        for (size_t pos = 8 + hlen; pos + 8 <= n;) {
+            const bool is_track = std::memcmp(d + pos, "MTrk", 4) == 0;
+            const size_t len = be32(pos + 4);
+            pos += 8;
+            if (pos + len > n) throw std::runtime_error("truncated chunk");
+            if (is_track) {
+                track(pos, pos + len, ticks_per_beat, track_filter < 0 || track_filter == track_idx, out);
+                ++track_idx;
+            }
+            pos += len;
+        }
+        return out;
+    }
+    void track(size_t p, size_t end, double ticks_per_beat, bool emit_notes, std::vector<ow_timed_event>& out) const {
+        double tempo = 500000.0, time_s = 0.0;   // per track: 120 BPM until this track's own tempo events (main.rs:1653-1654)
+        uint8_t running = 0;
+        while (p < end) {
+            const uint64_t delta_ticks = vlq(d, p, end);
+            time_s += ((double)delta_ticks / ticks_per_beat) * (tempo / 1000000.0);   // main.rs:1661-1663
+            if (p >= end) throw std::runtime_error("truncated track");
+            uint8_t status = d[p];
+            if (status & 0x80) ++p;
+            else if (running) status = running;
+            else throw std::runtime_error("data byte without running status");
+            if (status == 0xFF) {
+                if (p >= end) throw std::runtime_error("truncated track");
+                const uint8_t type = d[p++];
+                const uint32_t l = vlq(d, p, end);
+                if (p + l > end) throw std::runtime_error("truncated track");
+                if (type == 0x51 && l == 3) tempo = (double)(((uint32_t)d[p] << 16) | ((uint32_t)d[p + 1] << 8) | (uint32_t)d[p + 2]);
+                p += l;
+                running = 0;
+            } else if (status == 0xF0 || status == 0xF7) {
+                const uint32_t l = vlq(d, p, end);
+                if (p + l > end) throw std::runtime_error("truncated track");
+                p += l;
+                running = 0;
+            } else if (status >= 0xF0) {
+                throw std::runtime_error("system message inside a track");
+            } else {
+                running = status;
+                const uint8_t kind = status & 0xF0;
+                const size_t nd = (kind == 0xC0 || kind == 0xD0) ? 1 : 2;
+                if (p + nd > end) throw std::runtime_error("truncated track");
+                const uint8_t a = d[p] & 0x7F, b = nd == 2 ? (uint8_t)(d[p + 1] & 0x7F) : (uint8_t)0;
+                p += nd;
+                if (!emit_notes) continue;
+                ow_timed_event e{};
+                e.time_s = time_s;
+                if (kind == 0x90)      { e.type = b == 0 ? 1 : 0; e.note = a; e.value = b; }       // velocity 0 = note-off (main.rs:1671-1678)
+                else if (kind == 0x80) { e.type = 1; e.note = a; }
+                else if (kind == 0xB0 && a == 64) { e.type = 2; e.value = b >= 64 ? 1 : 0; }      // sustain pedal (main.rs:1693-1703)
+                else continue;
+                out.push_back(e);
+            }
+        }
+    }
+};
+}  // namespace
+
+extern "C" {
+
+long long ow_smf_parse(const uint8_t* data, size_t len, int track_filter, ow_timed_event* out, size_t cap) {
+    try {
+        if (!data || (!out && cap)) throw std::runtime_error("null argument");
+        const std::vector<ow_timed_event> ev = SmfReader{data, len}.events(track_filter);
+        for (size_t i = 0; i < std::min(cap, ev.size()); ++i) out[i] = ev[i];
+        return (long long)ev.size();
+    } catch (const std::exception& ex) { set_err(std::string("ow_smf_parse: ") + ex.what()); return -1; }
+}
+
+long long ow_render_midi(const ow_timed_event* events, const size_t* job_offsets, size_t n_jobs, const ow_midi_render_cfg* cfg,
+                         double* out, size_t stride, ow_midi_render_stats* stats) {
+    try {
+        if (!job_offsets || !cfg || (!out && !stats)) throw std::runtime_error("null argument");
+        if (cfg->preamp_kind != OW_PREAMP_LEGACY8) throw std::runtime_error("render-midi is built for the legacy preamp (--model dk of the default build)");
+        if (n_jobs == 0) return 0;
+        const double SR = 44100.0;                       // BASE_SR, main.rs:27
+        const size_t n_ev = job_offsets[n_jobs];
+        if (n_ev && !events) throw std::runtime_error("null argument");
+        std::vector<owdev::OwMidiEvDev> hev(std::max<size_t>(n_ev, 1));
+        std::vector<owdev::OwMidiJobDev> hj(n_jobs);
+        size_t longest = 0;
+        for (size_t j = 0; j < n_jobs; ++j) {
+            const size_t b = job_offsets[j], e = job_offsets[j + 1];
+            if (e < b || e > n_ev) throw std::runtime_error("job_offsets not monotonic");
+            std::vector<ow_timed_event> ev(events + b, events + e);
+            for (const ow_timed_event& x : ev)
+                if (!(x.time_s == x.time_s) || x.type > 2) throw std::runtime_error("event with NaN time or unknown type");   // partial_cmp().unwrap() panics
+            std::stable_sort(ev.begin(), ev.end(), [](const ow_timed_event& a, const ow_timed_event& c) { return a.time_s < c.time_s; });   // :1712
+            size_t total = 0;
+            if (!ev.empty()) {
+                const double x = (ev.back().time_s + cfg->tail_s) * SR;                                                     // :1719-1721
+                total = (!(x == x) || x <= 0.0) ? 0 : (x >= 1.8446744073709552e19 ? SIZE_MAX : (size_t)x);
+                if (total > (size_t)1 << 36) throw std::runtime_error("render longer than 2^36 samples");
+            }
+            for (size_t i = 0; i < ev.size(); ++i) {
+                // the chunk at sample_pos fires every event with time_s <= sample_pos / SR (:1778-1781)
+                const double t = ev[i].time_s;
+                uint64_t c = t > 0.0 ? (uint64_t)(t * SR / 64.0) : 0;
+                while (c > 0 && (double)(64 * (c - 1)) / SR >= t) --c;
+                while ((double)(64 * c) / SR < t) ++c;
+                owdev::OwMidiEvDev& dv = hev[b + i];
+                dv.chunk = (uint32_t)std::min<uint64_t>(c, 0xFFFFFFFFull);
+                dv.type = ev[i].type; dv.note = ev[i].note; dv.value = ev[i].value; dv.pad = 0;
+            }
+            hj[j].ev_begin = b; hj[j].n_events = (uint32_t)ev.size(); hj[j].pad = 0; hj[j].total_samples = total;
+            if (stats) { stats[j].n_samples = total; stats[j].note_ons = 0; stats[j].peak_polyphony = 0; }
+            longest = std::max(longest, total);
+        }
+        if (!out || longest == 0) return (long long)longest;
+        if (stride < longest) throw std::runtime_error("stride smaller than the longest job");
+        int ndev = 0;
+        HIP_OK(hipGetDeviceCount(&ndev));
+        if (ndev <= 0) throw std::runtime_error("no HIP device: openwurli-hip has no CPU fallback");
+        HIP_OK(hipSetDevice(cfg->device));
+        OwConsts hc;
+        owhip::build_consts(hc, SR, OW_PREAMP_LEGACY8);
+        std::vector<owdev::OwJobDev> hjob(n_jobs);       // chain parameters: Speaker(speaker), static 1 Mohm LDR, volume, power amp
+        for (auto& q : hjob) { q.note = 60; q.velocity = 0; q.mlp = 1; q.poweramp = cfg->no_poweramp ? 0 : 1; q.pad = 0; q.volume = cfg->volume; q.speaker = cfg->speaker; q.r_ldr = 1000000.0; }
+        StreamOwner so;
+        HIP_OK(hipStreamCreateWithFlags(&so.s, hipStreamNonBlocking));
+        hipStream_t st = so.s;
+        DevMem dK, d_nt, d_vrec, d_jobs, d_ev, d_held, d_sum, d_out, d_chain, d_stats;
+        dK.alloc(sizeof(OwConsts));
+        d_nt.alloc(sizeof(double) * NT_COUNT * 64);
+        d_vrec.alloc(sizeof(double) * n_jobs * OW_VREC_DOUBLES);
+        d_jobs.alloc(sizeof(owdev::OwMidiJobDev) * n_jobs);
+        d_ev.alloc(sizeof(owdev::OwMidiEvDev) * hev.size());
+        d_held.alloc(sizeof(uint32_t) * hev.size());
+        d_sum.alloc(sizeof(double) * n_jobs * longest);
+        d_out.alloc(sizeof(double) * n_jobs * longest);
+        d_chain.alloc(sizeof(owdev::OwJobDev) * n_jobs);
+        d_stats.alloc(sizeof(owdev::OwMidiStatsDev) * n_jobs);
+        HIP_OK(hipMemcpyAsync(dK.p, &hc, sizeof(OwConsts), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(d_jobs.p, hj.data(), sizeof(owdev::OwMidiJobDev) * n_jobs, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(d_ev.p, hev.data(), sizeof(owdev::OwMidiEvDev) * hev.size(), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(d_chain.p, hjob.data(), sizeof(owdev::OwJobDev) * n_jobs, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemsetAsync(d_sum.p, 0, sizeof(double) * n_jobs * longest, st));   // rows behind a shorter job's end feed the chain zeros
+        owdev::k_note_table<<<dim3(1), dim3(64), 0, st>>>(d_nt.as<double>());
+        owdev::k_midi_voices<<<dim3((unsigned)n_jobs), dim3(64), 0, st>>>(dK.as<OwConsts>(), d_nt.as<double>(), d_vrec.as<double>(), d_jobs.as<owdev::OwMidiJobDev>(),
+                                                                         d_ev.as<owdev::OwMidiEvDev>(), d_held.as<uint32_t>(), d_sum.as<double>(), (long long)longest,
+                                                                         d_stats.as<owdev::OwMidiStatsDev>());
+        owdev::k_job_chain<false><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK.as<OwConsts>(), d_chain.as<owdev::OwJobDev>(), d_sum.as<double>(),
+                                                                                             d_out.as<double>(), nullptr, (int)n_jobs, (long long)longest, (long long)longest);
+        HIP_OK(hipGetLastError());
+        std::vector<owdev::OwMidiStatsDev> hs(n_jobs);
+        HIP_OK(hipMemcpy2DAsync(out, stride * sizeof(double), d_out.p, longest * sizeof(double), longest * sizeof(double), n_jobs, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(hs.data(), d_stats.p, sizeof(owdev::OwMidiStatsDev) * n_jobs, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        for (size_t j = 0; j < n_jobs; ++j) {
+            // the chain kernel ran every row to the longest job's length: what lies behind a job's own end is not part of its render
+            for (size_t i = hj[j].total_samples; i < std::min(stride, longest); ++i) out[j * stride + i] = 0.0;
+            if (stats) { stats[j].note_ons = hs[j].note_ons; stats[j].peak_polyphony = hs[j].peak_polyphony; }
+        }
+        return (long long)longest;
+    } catch (const std::exception& ex) { set_err(std::string("ow_render_midi: ") + ex.what()); return -1; }
 }
 
 }  // extern "C"

@@ -11,6 +11,7 @@
 // The melange-primitives Biquad boundary stays "parity unpinned" (see ow_voice.hpp).
 #include "ow_engine.hpp"
 #include "ow_alias_audit.hpp"
+#include "ow_render_midi.hpp"
 #include <cstdio>
 
 using namespace owo;
@@ -295,5 +296,26 @@ int owo_alias_audit_run(int note, int velocity, int preamp_kind, void* result) {
 double owo_alias_dft_magnitude(const double* s, size_t len, double freq, double sr) { return audit_dft_magnitude(s, len, freq, sr); }
 double owo_alias_bandpass_rms(const double* s, size_t len, double sr, double lo, double hi) { return audit_bandpass_rms(s, len, sr, lo, hi); }
 double owo_alias_plateau_metric(const double* dbc12, unsigned* from) { double w; uint32_t f; audit_plateau_metric(dbc12, &w, &f); *from = f; return w; }
+
+// ---- preamp-bench render-midi (tools/preamp-bench/src/main.rs:1603-1923) ----
+// events as parallel arrays; returns the event count (writes min(cap, count)), -1 on a parse error
+long long owo_smf_parse(const uint8_t* data, size_t len, int track_filter, double* time_s, uint8_t* type, uint8_t* note, uint8_t* value, size_t cap) {
+    try {
+        std::vector<TimedEvent> ev = smf_events(data, len, track_filter);
+        for (size_t i = 0; i < std::min(cap, ev.size()); ++i) { time_s[i] = ev[i].time_s; type[i] = ev[i].type; note[i] = ev[i].note; value[i] = ev[i].value; }
+        return (long long)ev.size();
+    } catch (const std::exception&) { return -1; }
+}
+// returns the sample count (writes min(cap, count)); stats2 = {note-ons, peak polyphony}
+size_t owo_render_midi(const double* time_s, const uint8_t* type, const uint8_t* note, const uint8_t* value, size_t n, double volume,
+                       double speaker_char, int no_poweramp, double tail_s, double* out, size_t cap, unsigned long long* stats2) {
+    std::vector<TimedEvent> ev(n);
+    for (size_t i = 0; i < n; ++i) ev[i] = TimedEvent{time_s[i], type[i], note[i], value[i]};
+    MidiRenderStats st;
+    std::vector<double> v = render_midi(ev, volume, speaker_char, no_poweramp != 0, tail_s, &st);
+    for (size_t i = 0; i < std::min(cap, v.size()); ++i) out[i] = v[i];
+    if (stats2) { stats2[0] = st.note_ons; stats2[1] = st.peak_polyphony; }
+    return v.size();
+}
 
 }  // extern "C"
