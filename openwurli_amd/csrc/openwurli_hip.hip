@@ -664,6 +664,10 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
         en->index = i;
         en->dirty = &p->dirty[i];
         en->sr = sample_rate;
+        // Room for a whole-keyboard re-strike (damper + move-to-steal + note-on per key) from the start: growing 65 536 op lists
+        // from 64 to 192 entries inside the first re-strike cost 180 ms of reallocation and page faults on the MIDI threads
+        // (later ones take 8 ms).  Same reason as ensure_buffer_capacity: no allocation where the events arrive.
+        en->ops.reserve(3 * OW_MAX_VOICES);
         p->engines[i] = en;
     }
     // WurliEngine::new for engine 0 on the device, then replicate (every engine of a fresh pool is identical)
