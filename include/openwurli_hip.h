@@ -134,6 +134,10 @@ uint64_t ow_test_engine_masks(const ow_engine*, int which /* 0 = slot voices, 1 
  * out[n][11].  use_mfma = 1 runs the wavefront-batched v_mfma_f64_16x16x4_f64 path that k_apply_ops uses,
  * 0 the scalar lane path (batch jobs).  Returns 0, <0 on device error. */
 int ow_debug_mlp_raw(const uint8_t* notes, const double* velocities, size_t n, double* out, int use_mfma, int device);
+/* The kernels' division routine (ow_voice_dev.h, ow_div: the compiler's IEEE f64 division sequence without the operand
+ * pre-scaling that only extreme exponents need) next to the compiler's own `a / b`, element-wise on the device:
+ * fast[i], ieee[i] for n operand pairs.  Returns 0, <0 on device error. */
+int ow_debug_div(const double* a, const double* b, size_t n, double* fast, double* ieee, int device);
 
 /* ---- offline / batch ---------------------------------------------------------------------- */
 /* Voice::render_note (voice.rs:191-221): one voice, no chain, f64.  Returns the number of samples

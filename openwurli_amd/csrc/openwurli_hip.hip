@@ -51,6 +51,20 @@ uint64_t process_noise_seed() {
         if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
+struct DevMem {   // device buffer released on every exit path
+    void* p = nullptr;
+    DevMem() = default;
+    DevMem(const DevMem&) = delete;
+    DevMem& operator=(const DevMem&) = delete;
+    ~DevMem() { if (p) hipFree(p); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+    void alloc(size_t bytes) { HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 8))); }
+};
+struct StreamOwner {
+    hipStream_t s = nullptr;
+    ~StreamOwner() { if (s) hipStreamDestroy(s); }
+};
+
 struct Slot {  // VoiceSlot, engine.rs:39-62 (the Voice objects themselves live in HBM); state and note live in ow_engine's
                // st_mask[] / midi_of[] so the per-event searches are mask operations, not 64-slot walks
     uint64_t age = 0;
@@ -1109,6 +1123,23 @@ int ow_debug_mlp_raw(const uint8_t* notes, const double* velocities, size_t n, d
     } catch (const std::exception& ex) { set_err(std::string("ow_debug_mlp_raw: ") + ex.what()); return -1; }
 }
 
+int ow_debug_div(const double* a, const double* b, size_t n, double* fast, double* ieee, int device) {
+    try {
+        if (!a || !b || !fast || !ieee) throw std::runtime_error("null argument");
+        if (n == 0) return 0;
+        HIP_OK(hipSetDevice(device));
+        DevMem da, db, df, di;
+        da.alloc(n * sizeof(double)); db.alloc(n * sizeof(double)); df.alloc(n * sizeof(double)); di.alloc(n * sizeof(double));
+        HIP_OK(hipMemcpy(da.p, a, n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(db.p, b, n * sizeof(double), hipMemcpyHostToDevice));
+        owdev::k_debug_div<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(da.as<double>(), db.as<double>(), n, df.as<double>(), di.as<double>());
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpy(fast, df.p, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(ieee, di.p, n * sizeof(double), hipMemcpyDeviceToHost));
+        return 0;
+    } catch (const std::exception& ex) { set_err(std::string("ow_debug_div: ") + ex.what()); return -1; }
+}
+
 // ---- offline ------------------------------------------------------------------------------------
 long long ow_render_note(uint8_t midi, double velocity, double dur_s, double sample_rate, int device, double* out, size_t cap) {
     try {
@@ -1353,19 +1384,6 @@ int ow_extract_harmonics(const double* audio, size_t n_rows, size_t stride, doub
 
 // ---- click-band alias audit (alias_audit.rs) -----------------------------------------------------
 namespace {
-struct DevMem {   // device buffer released on every exit path
-    void* p = nullptr;
-    DevMem() = default;
-    DevMem(const DevMem&) = delete;
-    DevMem& operator=(const DevMem&) = delete;
-    ~DevMem() { if (p) hipFree(p); }
-    template <class T> T* as() const { return static_cast<T*>(p); }
-    void alloc(size_t bytes) { HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 8))); }
-};
-struct StreamOwner {
-    hipStream_t s = nullptr;
-    ~StreamOwner() { if (s) hipStreamDestroy(s); }
-};
 constexpr double AUDIT_SR = 44100.0, AUDIT_RENDER_S = 1.5, AUDIT_ANALYZE_S = 0.5;   // alias_audit.rs:47-53
 constexpr uint32_t AUDIT_PROBES = 112;   // nominal + the 0.1 Hz walk over +-5 Hz (101 or 102 points), rounded up
 inline double audit_db(double mag) { return mag > 0.0 ? 20.0 * std::log10(mag) : -200.0; }   // mag_to_db :242-248

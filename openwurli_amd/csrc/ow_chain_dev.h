@@ -54,8 +54,8 @@ OW_DEV Bjt bjt_eval(double vbe, double vbc) {  // gen_tremolo.rs:1546-1633 (Eber
     const double is = OW_T_IS, vt = OW_T_VT, nf = 1.0, nr = 1.0, beta_f = OW_T_BF, beta_r = OW_T_BR, sign = 1.0;
     const double vbe_eff = sign * vbe, vbc_eff = sign * vbc;
     const double nf_vt = nf * vt, nr_vt = nr * vt;
-    const double exp_be = fast_exp(vbe_eff / nf_vt);
-    const double exp_bc = fast_exp(vbc_eff / nr_vt);
+    const double exp_be = fast_exp(ow_div(vbe_eff, nf_vt));
+    const double exp_bc = fast_exp(ow_div(vbc_eff, nr_vt));
     const double i_cc = is * (exp_be - exp_bc);
     const double ib_fwd = is / beta_f * (exp_be - 1.0);
     const double ib_rev = is / beta_r * (exp_bc - 1.0);
@@ -104,7 +104,7 @@ OW_DEV bool solve4(double a[4][4], double b[4]) {
             const double pivot = a[col][col];
 #pragma unroll
             for (int row = col + 1; row < 4; ++row) {
-                const double factor = a[row][col] / pivot;
+                const double factor = ow_div(a[row][col], pivot);
 #pragma unroll
                 for (int j = col + 1; j < 4; ++j) a[row][j] -= factor * a[col][j];
                 b[row] -= factor * b[col];
@@ -118,7 +118,7 @@ OW_DEV bool solve4(double a[4][4], double b[4]) {
 #pragma unroll
             for (int j = i + 1; j < 4; ++j) sum -= a[i][j] * b[j];
             if (!singular && fabs(a[i][i]) < 1e-15) singular = true;
-            if (!singular) b[i] = sum / a[i][i];
+            if (!singular) b[i] = ow_div(sum, a[i][i]);
         }
     }
     return !singular;
@@ -198,12 +198,12 @@ __device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk
                 for (int q = 0; q < 4; ++q) {
                     const double dv_lim = v_lim[q] - vd[q];
                     if (fabs(dv_trial[q]) > 1e-15) {
-                        const double r = (dv_trial[q] * dv_lim < 0.0) ? 0.0 : clampd(dv_lim / dv_trial[q], 0.0, 1.0);
+                        const double r = (dv_trial[q] * dv_lim < 0.0) ? 0.0 : clampd(ow_div(dv_lim, dv_trial[q]), 0.0, 1.0);
                         if (r < ga) { ga = r; any_limited = true; }
                     }
                 }
                 const double max_dv = fmax(fmax(fmax(fabs(dv_trial[0] * ga), fabs(dv_trial[1] * ga)), fabs(dv_trial[2] * ga)), fabs(dv_trial[3] * ga));
-                if (max_dv > 3.5) { ga *= fmax(3.5 / max_dv, 0.1); any_limited = true; }
+                if (max_dv > 3.5) { ga *= fmax(ow_div(3.5, max_dv), 0.1); any_limited = true; }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) i_nl[q] -= ga * b[q];
                 if (!any_limited) {
@@ -225,7 +225,7 @@ __device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk
                 for (int q = 0; q < 4; ++q) {
                     if (fabs(dv[q]) > 1e-4) {
                         const double vl = pnjlim(vd[q] + dv[q], vd[q], OW_T_VT, OW_T_VCRIT);
-                        const double ratio = fmax((vl - vd[q]) / dv[q], 0.01);
+                        const double ratio = fmax(ow_div(vl - vd[q], dv[q]), 0.01);
                         if (ratio < al[q]) { al[q] = ratio; if (ratio < 1.0) any_limited = true; }
                     }
                 }
@@ -233,7 +233,7 @@ __device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk
                 { const double m = fmin(al[2], al[3]); al[2] = m; al[3] = m; }
                 const double max_dv = fmax(fmax(fmax(fabs(dv[0] * al[0]), fabs(dv[1] * al[1])), fabs(dv[2] * al[2])), fabs(dv[3] * al[3]));
                 if (max_dv > 3.5) {
-                    const double fct = fmax(3.5 / max_dv, 0.1);
+                    const double fct = fmax(ow_div(3.5, max_dv), 0.1);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) al[q] *= fct;
                 }
@@ -403,7 +403,7 @@ __device__ inline double trem_osc_step(TremState& st, TremPark* __restrict__ P0,
 // It has no audio input and no dependence on the depth knob, so it is produced a block ahead (k_tremolo).
 __device__ inline double trem_cell_r(TremState& st, TremPark* __restrict__ P, const OwConsts* __restrict__ K, const TremMats* __restrict__ M) {
     const double v_out = trem_osc_step(st, P, K, M);
-    const double led = clampd((10.95 - v_out) / (10.95 - 0.70), 0.0, 1.0);
+    const double led = clampd(ow_div(10.95 - v_out, 10.95 - 0.70), 0.0, 1.0);
     const double coeff = led > st.env ? K->ldr_attack : K->ldr_release;
     st.env = led + coeff * (st.env - led);
     const double drive = clampd(st.env, 0.0, 1.0);
@@ -415,9 +415,9 @@ __device__ inline double trem_cell_r(TremState& st, TremPark* __restrict__ P, co
 OW_DEV double trem_shunt(double depth, double r_ldr) {
     const double r_upper = 50000.0 * (1.0 - depth);
     const double r_lower = 50000.0 * depth;
-    const double top = r_upper > 0.0 ? r_upper * 18000.0 / (r_upper + 18000.0) : 0.0;
+    const double top = r_upper > 0.0 ? ow_div(r_upper * 18000.0, r_upper + 18000.0) : 0.0;
     const double branch = 680.0 + r_ldr;
-    const double low = r_lower > 0.0 ? r_lower * branch / (r_lower + branch) : 0.0;
+    const double low = r_lower > 0.0 ? ow_div(r_lower * branch, r_lower + branch) : 0.0;
     return top + low;
 }
 
@@ -448,10 +448,10 @@ struct Smoother {
 struct DkSt { double j_cin, cin_prev, v[8], i_nl[2], v_nl[2]; };
 
 OW_DEV double dk_ic(double vbe) {  // dk_preamp_legacy.rs:663-666
-    return OW_P_IS * (exp(clampd(vbe, -1.0, 0.85) / OW_P_VT) - 1.0);
+    return OW_P_IS * (exp(ow_div(clampd(vbe, -1.0, 0.85), OW_P_VT)) - 1.0);
 }
 OW_DEV void dk_ic_gm(double vbe, double& ic, double& gm) {  // :686-690
-    const double e = exp(clampd(vbe, -1.0, 0.85) / OW_P_VT);
+    const double e = exp(ow_div(clampd(vbe, -1.0, 0.85), OW_P_VT));
     ic = OW_P_IS * (e - 1.0);
     gm = (OW_P_IS / OW_P_VT) * e;
 }
@@ -512,7 +512,7 @@ __device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_
         }
     }
     K = k_reload(K0);
-    const double sm_k = g_ldr / (1.0 + K->p_s_fb_fb * g_ldr);
+    const double sm_k = ow_div(g_ldr, 1.0 + K->p_s_fb_fb * g_ldr);
     const double sm_vpred = sm_k * vpb[7];
     double v_pred[8];
 #pragma unroll
@@ -533,7 +533,7 @@ __device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_
         const double j00 = 1.0 - k00 * gm0, j01 = -k01 * gm1, j10 = -k10 * gm0, j11 = 1.0 - k11 * gm1;
         const double det = j00 * j11 - j01 * j10;
         if (fabs(det) < 1e-30) break;
-        const double inv_det = 1.0 / det;
+        const double inv_det = ow_div(1.0, det);
         vn0 -= inv_det * (j11 * f0 - j01 * f1);
         vn1 -= inv_det * (j00 * f1 - j10 * f0);
     }
@@ -656,21 +656,21 @@ __device__ inline double power_amp(double input) {
         const double v = A * error;
         const double v_sq = v * v;
         const double vt_sq = 0.013 * 0.013;
-        const double exp_term = exp(-v_sq / vt_sq);
+        const double exp_term = exp(ow_div(-v_sq, vt_sq));
         const double q = 0.1;
         const double cross_gain = q + (1.0 - q) * (1.0 - exp_term);
         const double v_cross = v * cross_gain;
-        const double dcross_dv = cross_gain + v * (1.0 - q) * (2.0 * v / vt_sq) * exp_term;
-        const double tanh_val = tanh(v_cross / H);
+        const double dcross_dv = cross_gain + v * (1.0 - q) * ow_div(2.0 * v, vt_sq) * exp_term;
+        const double tanh_val = tanh(ow_div(v_cross, H));
         const double f_val = H * tanh_val;
         const double f_deriv = (1.0 - tanh_val * tanh_val) * dcross_dv;
         const double residual = y - f_val;
         const double jac = 1.0 + A * beta * f_deriv;
-        const double delta = residual / jac;
+        const double delta = ow_div(residual, jac);
         y -= delta;
         if (fabs(delta) < TOL) break;
     }
-    return y / H;
+    return ow_div(y, H);
 }
 
 // ------------------------------------------------------------------ speaker (speaker.rs:81-132)
@@ -710,10 +710,10 @@ OW_DEV void speaker_set_character(SpeakerSt& s, double ch, double sr) {  // spea
 OW_DEV double speaker_process(SpeakerSt& s, double input, double thermal_alpha) {  // speaker.rs:105-132
     const double x2 = input * input;
     const double x3 = x2 * input;
-    const double shaped = (input + s.a2 * x2 + s.a3 * x3) / (1.0 + s.a2 + s.a3);
+    const double shaped = ow_div(input + s.a2 * x2 + s.a3 * x3, 1.0 + s.a2 + s.a3);
     const double limited = s.character < 0.001 ? shaped : tanh(shaped);
     s.ts += (x2 - s.ts) * thermal_alpha;
-    const double tg = 1.0 / (1.0 + s.tc * sqrt(s.ts));
+    const double tg = ow_div(1.0, 1.0 + s.tc * sqrt(s.ts));
     const double filtered = bq_process(s.hpf, limited * tg);
     return bq_process(s.lpf, filtered);
 }

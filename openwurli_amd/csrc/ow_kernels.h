@@ -354,7 +354,7 @@ struct VoiceSteady {
 #endif
         const double omy = 1.0 - y;
         const double alpha = beta * omy;
-        const double q_next = (q * (1.0 - alpha) + 2.0 * beta) / (1.0 + alpha);
+        const double q_next = ow_div(q * (1.0 - alpha) + 2.0 * beta, 1.0 + alpha);
         q = q_next;
         return ((q_next * omy - 1.0) * 1.8375) * gain;
     }
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
             for (int j = 0; j < osr; ++j) {
                 const size_t idx = (size_t)((base + n) * osr + j);
                 const double r_new = fmax(trem_shunt(depth, rc[j]), 1000.0);   // tremolo.rs:152-167; set_ldr_resistance, :620-626
-                if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = 1.0 / r_new; }
+                if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = ow_div(1.0, r_new); }
                 const double o = dk_step(st, in[j], g_ldr, g_prev, K);
                 g_prev = g_ldr;                                                   // :604
                 const double other = __shfl_xor(o, 32);

@@ -83,4 +83,11 @@ __global__ __launch_bounds__(64) void k_debug_mlp(const uint8_t* __restrict__ no
         for (int i = 0; i < 11; ++i) out[(size_t)idx * 11 + i] = raw[i];
 }
 
+// ow_div against the compiler's division (tests/test_gpu_division.py)
+__global__ __launch_bounds__(256) void k_debug_div(const double* __restrict__ a, const double* __restrict__ b, size_t n, double* __restrict__ fast,
+                                                   double* __restrict__ ieee) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { fast[i] = ow_div(a[i], b[i]); ieee[i] = a[i] / b[i]; }
+}
+
 }  // namespace owdev

@@ -100,7 +100,7 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
         if (q != 2) vd = vd + kq2 * i_nl[2];
         if (q != 1) vd = vd + kq3 * i_nl[3];
         // junction exponentials: lane 0 exp_be(Q1), 1 exp_bc(Q1), 2 exp_be(Q2), 3 exp_bc(Q2)   (bjt_eval: sign = nf = nr = 1)
-        const double e_me = fast_exp((1.0 * vd) / (1.0 * OW_T_VT));
+        const double e_me = fast_exp(ow_div(1.0 * vd, 1.0 * OW_T_VT));
         const double e_ot = qswap1(e_me);
         const double exp_be = (q & 1) ? e_ot : e_me, exp_bc = (q & 1) ? e_me : e_ot;
         const double is = OW_T_IS, vt = OW_T_VT, beta_f = OW_T_BF, beta_r = OW_T_BR;
@@ -150,7 +150,7 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
 #pragma unroll
                 for (int j = 0; j < 4; ++j) prow[j] = qget<col>(ar[j]);
                 if (q > col) {
-                    const double factor = ar[col] / pivot;
+                    const double factor = ow_div(ar[col], pivot);
 #pragma unroll
                     for (int j = col + 1; j < 4; ++j) ar[j] -= factor * prow[j];
                     br -= factor * pb;
@@ -166,7 +166,7 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
                 for (int j = i + 1; j < 4; ++j) sum -= ar[j] * b[j];
                 const double diag = qget<i>(ar[i]);
                 if (!singular && fabs(diag) < 1e-15) singular = true;
-                if (!singular) b[i] = qget<i>(sum / ar[i]);
+                if (!singular) b[i] = qget<i>(ow_div(sum, ar[i]));
                 else b[i] = qget<i>(br);      // the scalar code leaves b[i] unreduced once singular; its value is not used afterwards
             });
         }
@@ -182,7 +182,7 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
             const double v_lim = (fabs(dv_trial) > 1e-4) ? pnjlim(v_trial, vd, OW_T_VT, OW_T_VCRIT) : v_trial;
             const double dv_lim = v_lim - vd;
             double r_me = 1.0;           // ports that do not take part leave ga alone
-            if (fabs(dv_trial) > 1e-15) r_me = (dv_trial * dv_lim < 0.0) ? 0.0 : clampd(dv_lim / dv_trial, 0.0, 1.0);
+            if (fabs(dv_trial) > 1e-15) r_me = (dv_trial * dv_lim < 0.0) ? 0.0 : clampd(ow_div(dv_lim, dv_trial), 0.0, 1.0);
             // ga = min over the ports in port order with a strict "<" (a NaN ratio never wins, as in the scalar loop)
             double ga = 1.0;
             bool any_limited = false;
@@ -193,7 +193,7 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
             const double adv = fabs(dv_trial * ga);
             double max_dv = qget<0>(adv);
             max_dv = fmax(max_dv, qget<1>(adv)); max_dv = fmax(max_dv, qget<2>(adv)); max_dv = fmax(max_dv, qget<3>(adv));
-            if (max_dv > 3.5) { ga *= fmax(3.5 / max_dv, 0.1); any_limited = true; }
+            if (max_dv > 3.5) { ga *= fmax(ow_div(3.5, max_dv), 0.1); any_limited = true; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) i_nl[j] -= ga * b[j];
             if (!any_limited) {
@@ -245,7 +245,7 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
 // so the kernel applies it afterwards with the quad's four lanes working on four different samples.
 __device__ inline double trem_cell_drive_wide(TremWide& st, const OwConsts* __restrict__ K, const TremMats* __restrict__ M) {
     const double v_out = trem_osc_step_wide(st, K, M);
-    const double led = clampd((10.95 - v_out) / (10.95 - 0.70), 0.0, 1.0);
+    const double led = clampd(ow_div(10.95 - v_out, 10.95 - 0.70), 0.0, 1.0);
     const double coeff = led > st.env ? K->ldr_attack : K->ldr_release;
     st.env = led + coeff * (st.env - led);
     return clampd(st.env, 0.0, 1.0);
