@@ -138,6 +138,10 @@ int ow_debug_mlp_raw(const uint8_t* notes, const double* velocities, size_t n, d
  * pre-scaling that only extreme exponents need) next to the compiler's own `a / b`, element-wise on the device:
  * fast[i], ieee[i] for n operand pairs.  Returns 0, <0 on device error. */
 int ow_debug_div(const double* a, const double* b, size_t n, double* fast, double* ieee, int device);
+/* The same for the constant-divisor form (OW_DIV_C): which = 0 jitter draw 2147483647.5, 1 Twin-T V_T, 2 LED span 10.25,
+ * 3 preamp V_T 0.026, 4 power-amp 0.013^2, 5 power-amp headroom 22.  a == NULL runs every numerator of the jitter draw
+ * (all 2^31 integers) on the device and stores the number of quotients that differ from `a / B` in *mismatches. */
+int ow_debug_div_const(int which, const double* a, size_t n, double* fast, double* ieee, uint64_t* mismatches, int device);
 
 /* ---- offline / batch ---------------------------------------------------------------------- */
 /* Voice::render_note (voice.rs:191-221): one voice, no chain, f64.  Returns the number of samples

@@ -1140,6 +1140,35 @@ int ow_debug_div(const double* a, const double* b, size_t n, double* fast, doubl
     } catch (const std::exception& ex) { set_err(std::string("ow_debug_div: ") + ex.what()); return -1; }
 }
 
+int ow_debug_div_const(int which, const double* a, size_t n, double* fast, double* ieee, uint64_t* mismatches, int device) {
+    try {
+        if (which < 0 || which > 5) throw std::runtime_error("unknown constant");
+        HIP_OK(hipSetDevice(device));
+        if (!a) {
+            if (!mismatches) throw std::runtime_error("null argument");
+            DevMem dm;
+            dm.alloc(sizeof(unsigned long long));
+            HIP_OK(hipMemset(dm.p, 0, sizeof(unsigned long long)));
+            owdev::k_debug_div_jitter_all<<<dim3(4096), dim3(256)>>>(dm.as<unsigned long long>());
+            HIP_OK(hipGetLastError());
+            unsigned long long h = 0;
+            HIP_OK(hipMemcpy(&h, dm.p, sizeof h, hipMemcpyDeviceToHost));
+            *mismatches = h;
+            return 0;
+        }
+        if (!fast || !ieee) throw std::runtime_error("null argument");
+        if (n == 0) return 0;
+        DevMem da, df, di;
+        da.alloc(n * sizeof(double)); df.alloc(n * sizeof(double)); di.alloc(n * sizeof(double));
+        HIP_OK(hipMemcpy(da.p, a, n * sizeof(double), hipMemcpyHostToDevice));
+        owdev::k_debug_div_const<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(which, da.as<double>(), n, df.as<double>(), di.as<double>());
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpy(fast, df.p, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(ieee, di.p, n * sizeof(double), hipMemcpyDeviceToHost));
+        return 0;
+    } catch (const std::exception& ex) { set_err(std::string("ow_debug_div_const: ") + ex.what()); return -1; }
+}
+
 // ---- offline ------------------------------------------------------------------------------------
 long long ow_render_note(uint8_t midi, double velocity, double dur_s, double sample_rate, int device, double* out, size_t cap) {
     try {

@@ -54,8 +54,8 @@ OW_DEV Bjt bjt_eval(double vbe, double vbc) {  // gen_tremolo.rs:1546-1633 (Eber
     const double is = OW_T_IS, vt = OW_T_VT, nf = 1.0, nr = 1.0, beta_f = OW_T_BF, beta_r = OW_T_BR, sign = 1.0;
     const double vbe_eff = sign * vbe, vbc_eff = sign * vbc;
     const double nf_vt = nf * vt, nr_vt = nr * vt;
-    const double exp_be = fast_exp(ow_div(vbe_eff, nf_vt));
-    const double exp_bc = fast_exp(ow_div(vbc_eff, nr_vt));
+    const double exp_be = fast_exp(OW_DIV_C(vbe_eff, 1.0 * OW_T_VT));   // nf_vt, nr_vt are this constant
+    const double exp_bc = fast_exp(OW_DIV_C(vbc_eff, 1.0 * OW_T_VT));
     const double i_cc = is * (exp_be - exp_bc);
     const double ib_fwd = is / beta_f * (exp_be - 1.0);
     const double ib_rev = is / beta_r * (exp_bc - 1.0);
@@ -403,7 +403,7 @@ __device__ inline double trem_osc_step(TremState& st, TremPark* __restrict__ P0,
 // It has no audio input and no dependence on the depth knob, so it is produced a block ahead (k_tremolo).
 __device__ inline double trem_cell_r(TremState& st, TremPark* __restrict__ P, const OwConsts* __restrict__ K, const TremMats* __restrict__ M) {
     const double v_out = trem_osc_step(st, P, K, M);
-    const double led = clampd(ow_div(10.95 - v_out, 10.95 - 0.70), 0.0, 1.0);
+    const double led = clampd(OW_DIV_C(10.95 - v_out, 10.95 - 0.70), 0.0, 1.0);
     const double coeff = led > st.env ? K->ldr_attack : K->ldr_release;
     st.env = led + coeff * (st.env - led);
     const double drive = clampd(st.env, 0.0, 1.0);
@@ -448,10 +448,10 @@ struct Smoother {
 struct DkSt { double j_cin, cin_prev, v[8], i_nl[2], v_nl[2]; };
 
 OW_DEV double dk_ic(double vbe) {  // dk_preamp_legacy.rs:663-666
-    return OW_P_IS * (exp(ow_div(clampd(vbe, -1.0, 0.85), OW_P_VT)) - 1.0);
+    return OW_P_IS * (exp(OW_DIV_C(clampd(vbe, -1.0, 0.85), OW_P_VT)) - 1.0);
 }
 OW_DEV void dk_ic_gm(double vbe, double& ic, double& gm) {  // :686-690
-    const double e = exp(ow_div(clampd(vbe, -1.0, 0.85), OW_P_VT));
+    const double e = exp(OW_DIV_C(clampd(vbe, -1.0, 0.85), OW_P_VT));
     ic = OW_P_IS * (e - 1.0);
     gm = (OW_P_IS / OW_P_VT) * e;
 }
@@ -656,12 +656,12 @@ __device__ inline double power_amp(double input) {
         const double v = A * error;
         const double v_sq = v * v;
         const double vt_sq = 0.013 * 0.013;
-        const double exp_term = exp(ow_div(-v_sq, vt_sq));
+        const double exp_term = exp(OW_DIV_C(-v_sq, 0.013 * 0.013));
         const double q = 0.1;
         const double cross_gain = q + (1.0 - q) * (1.0 - exp_term);
         const double v_cross = v * cross_gain;
-        const double dcross_dv = cross_gain + v * (1.0 - q) * ow_div(2.0 * v, vt_sq) * exp_term;
-        const double tanh_val = tanh(ow_div(v_cross, H));
+        const double dcross_dv = cross_gain + v * (1.0 - q) * OW_DIV_C(2.0 * v, 0.013 * 0.013) * exp_term;
+        const double tanh_val = tanh(OW_DIV_C(v_cross, 22.0));
         const double f_val = H * tanh_val;
         const double f_deriv = (1.0 - tanh_val * tanh_val) * dcross_dv;
         const double residual = y - f_val;
@@ -670,7 +670,7 @@ __device__ inline double power_amp(double input) {
         y -= delta;
         if (fabs(delta) < TOL) break;
     }
-    return ow_div(y, H);
+    return OW_DIV_C(y, 22.0);
 }
 
 // ------------------------------------------------------------------ speaker (speaker.rs:81-132)

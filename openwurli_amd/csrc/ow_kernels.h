@@ -310,7 +310,7 @@ struct VoiceSteady {
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
                 jitter_state = lcg(jitter_state);
-                const double u = ow_div((double)(jitter_state >> 1), 2147483647.5);
+                const double u = OW_DIV_C((double)(jitter_state >> 1), OW_JITTER_DIV);
                 const double noise = (u * 2.0 - 1.0) * 1.7320508080;
                 drift[m] = revert * drift[m] + diffusion * noise;
             }

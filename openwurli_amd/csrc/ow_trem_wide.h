@@ -100,7 +100,7 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
         if (q != 2) vd = vd + kq2 * i_nl[2];
         if (q != 1) vd = vd + kq3 * i_nl[3];
         // junction exponentials: lane 0 exp_be(Q1), 1 exp_bc(Q1), 2 exp_be(Q2), 3 exp_bc(Q2)   (bjt_eval: sign = nf = nr = 1)
-        const double e_me = fast_exp(ow_div(1.0 * vd, 1.0 * OW_T_VT));
+        const double e_me = fast_exp(OW_DIV_C(1.0 * vd, 1.0 * OW_T_VT));
         const double e_ot = qswap1(e_me);
         const double exp_be = (q & 1) ? e_ot : e_me, exp_bc = (q & 1) ? e_me : e_ot;
         const double is = OW_T_IS, vt = OW_T_VT, beta_f = OW_T_BF, beta_r = OW_T_BR;
@@ -245,7 +245,7 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
 // so the kernel applies it afterwards with the quad's four lanes working on four different samples.
 __device__ inline double trem_cell_drive_wide(TremWide& st, const OwConsts* __restrict__ K, const TremMats* __restrict__ M) {
     const double v_out = trem_osc_step_wide(st, K, M);
-    const double led = clampd(ow_div(10.95 - v_out, 10.95 - 0.70), 0.0, 1.0);
+    const double led = clampd(OW_DIV_C(10.95 - v_out, 10.95 - 0.70), 0.0, 1.0);
     const double coeff = led > st.env ? K->ldr_attack : K->ldr_release;
     st.env = led + coeff * (st.env - led);
     return clampd(st.env, 0.0, 1.0);

@@ -40,6 +40,21 @@ OW_DEV double ow_div(double a, double b) {
     return __builtin_amdgcn_div_fixup(__builtin_fma(r, y, q), b, a);
 #endif
 }
+// Division by a compile-time constant: y = 1.0 / B is folded by the compiler (correctly rounded), which leaves q = a*y, the exact
+// residual and the final correction of the sequence above -- the quotient is again the correctly rounded a / B (Markstein's
+// correction step with a correctly rounded reciprocal); v_div_fixup keeps zero / infinite / NaN numerators IEEE.  Checked on the
+// device against `a / B` for every constant the kernels use (tests/test_gpu_division.py; all 2^31 numerators of the jitter draw).
+OW_DEV double ow_div_const(double a, const double b, const double y) {
+#ifdef OW_IEEE_DIV
+    return a / b;
+#else
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_amdgcn_div_fixup(__builtin_fma(r, y, q), b, a);
+#endif
+}
+#define OW_DIV_C(a, B) ow_div_const((a), (B), 1.0 / (B))
+#define OW_JITTER_DIV 2147483647.5            // reed.rs:267-272
 OW_DEV double clampd(double x, double lo, double hi) {  // Rust f64::clamp (NaN propagates)
     return x < lo ? lo : (x > hi ? hi : x);
 }
@@ -476,7 +491,7 @@ struct VoiceRegs {
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
                 jitter_state = lcg(jitter_state);
-                const double u = ow_div((double)(jitter_state >> 1), 2147483647.5);
+                const double u = OW_DIV_C((double)(jitter_state >> 1), OW_JITTER_DIV);
                 const double noise = (u * 2.0 - 1.0) * 1.7320508080;
                 drift[m] = revert * drift[m] + diffusion * noise;
             }

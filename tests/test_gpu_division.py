@@ -70,3 +70,32 @@ def test_outside_the_promise_is_reported_not_hidden(hiplib):
     fast, ieee = _div(hiplib, a, b)
     ulp = 2.0 ** -1074
     assert np.max(np.abs(fast - ieee)) <= ulp
+
+
+CONSTANTS = [2147483647.5, 1.0 * 2.58519910000000012e-2, 10.95 - 0.70, 0.026, 0.013 * 0.013, 22.0]
+
+
+@pytest.mark.parametrize("which", range(6))
+def test_constant_divisors_bit_identical(hiplib, which):
+    """OW_DIV_C(a, B): reciprocal folded at compile time, product, exact residual, one correction.  Numerators: what the call site
+    can produce and several decades around it, rounding-boundary neighbours of multiples of B, zeros, infinities, NaN."""
+    rng = np.random.default_rng(100 + which)
+    B = CONSTANTS[which]
+    n = 1 << 23
+    a = np.concatenate([_rand(rng, n, -60, 40), rng.uniform(-40.0, 40.0, n), B * rng.integers(-1 << 20, 1 << 20, n).astype(np.float64),
+                        np.nextafter(B * rng.integers(1, 1 << 20, n).astype(np.float64), np.inf),
+                        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, B, -B, 1.0, 2.0 ** -1060])])
+    f = np.zeros_like(a); i = np.zeros_like(a)
+    assert hiplib.ow_debug_div_const(which, a.ctypes.data_as(C.c_void_p), a.size, f.ctypes.data_as(C.c_void_p), i.ctypes.data_as(C.c_void_p), None, 0) == 0
+    with np.errstate(all="ignore"):
+        want = a / B
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(f), nan) and np.array_equal(np.isnan(i), nan)
+    assert _same_bits(f[~nan], want[~nan]) and _same_bits(i[~nan], want[~nan])
+
+
+def test_jitter_draw_exhaustive(hiplib):
+    """u = (jitter_state >> 1) / 2147483647.5 (reed.rs:267-272): every one of the 2^31 possible numerators, on the device."""
+    bad = C.c_uint64(123)
+    assert hiplib.ow_debug_div_const(0, None, 0, None, None, C.byref(bad), 0) == 0
+    assert bad.value == 0
