@@ -552,15 +552,43 @@ void engine_post_render(ow_engine* en, uint32_t l32, const OwEngineOut& o) {
 // host bookkeeping after the block has been rendered (needs h_eout; call after stream sync)
 void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
     const uint32_t l32 = (uint32_t)std::min<size_t>(len, 0xFFFFFFFFull);
-    for (int k = 0; k < ne; ++k) {
-        const OwEngineOut& o = p->h_eout[e0 + k];
-        const OwEngineArgs& a = p->h_args[e0 + k];
-        if (o.transient == 2u) set_err("voice dispatch: an engine in a transient phase was sent to the steady kernel");
-        const uint8_t tr = o.transient != 0u;
-        if (tr != p->transient[e0 + k]) { p->transient[e0 + k] = tr; p->lists_valid = false; }
-        // fast path on the contiguous status/args arrays: nothing to book-keep for this engine
-        if (!a.steal_mask && !(o.silent_mask & a.main_mask) && !o.sum_nonfinite && !o.out_nonfinite) continue;
-        engine_post_render(p->engines[e0 + k], l32, o);
+    // engines are independent: after a whole-pool re-strike every engine has 64 steal fades to count down and 64 masks to
+    // update (40 ms on one thread for 65 536 engines), so large ranges are cut into slices like the MIDI and op packing are
+    const size_t T = ne >= 16384 ? std::min<size_t>(effective_cpus(), 32) : 1;
+    const int per = (int)((ne + T - 1) / T);
+    std::vector<uint8_t> lists_changed(T, 0), misdispatch(T, 0);
+    auto slice = [&](size_t t) {
+        const int k1 = std::min(ne, (int)(t + 1) * per);
+        uint8_t changed = 0, bad = 0;
+        for (int k = (int)t * per; k < k1; ++k) {
+            const OwEngineOut& o = p->h_eout[e0 + k];
+            const OwEngineArgs& a = p->h_args[e0 + k];
+            if (o.transient == 2u) bad = 1;
+            const uint8_t tr = o.transient != 0u;
+            if (tr != p->transient[e0 + k]) { p->transient[e0 + k] = tr; changed = 1; }
+            // fast path on the contiguous status/args arrays: nothing to book-keep for this engine
+            if (!a.steal_mask && !(o.silent_mask & a.main_mask) && !o.sum_nonfinite && !o.out_nonfinite) continue;
+            engine_post_render(p->engines[e0 + k], l32, o);
+        }
+        lists_changed[t] = changed; misdispatch[t] = bad;
+    };
+    // a steady block of a big pool has (almost) nothing to do per engine, which is not worth starting threads for (~0.1 ms): estimate
+    // the engines with steal fades / silent voices from every 64th one and go parallel from ~8 000 of them
+    long need = 0;
+    if (T > 1)
+        for (int k = 0; k < ne; k += 64)
+            need += p->h_args[e0 + k].steal_mask != 0 || (p->h_eout[e0 + k].silent_mask & p->h_args[e0 + k].main_mask) != 0;
+    const bool busy = need * 64 > 8192;
+    if (T == 1 || !busy) {
+        for (size_t t = 0; t < T; ++t) slice(t);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < T; ++t) th.emplace_back([&slice, t] { slice(t); });
+        for (auto& x : th) x.join();
+    }
+    for (size_t t = 0; t < T; ++t) {
+        if (lists_changed[t]) p->lists_valid = false;
+        if (misdispatch[t]) set_err("voice dispatch: an engine in a transient phase was sent to the steady kernel");
     }
 }
 
@@ -784,13 +812,25 @@ void ow_pool_render(ow_pool* p, float* out_host, size_t out_stride, size_t len) 
     guarded("ow_pool_render", [&] {
         HIP_OK(hipSetDevice(p->device));
         if (len > p->Lcap) { HIP_OK(hipStreamSynchronize(p->stream)); alloc_stream_buffers(p, len); }  // auto-grow, engine.rs:430
+        static const bool hostprof = std::getenv("OW_HOST_PROFILE") != nullptr;
+        static double acc[4] = {0, 0, 0, 0}; static long cnt = 0;
+        auto t0 = std::chrono::steady_clock::now();
         render_range(p, 0, (int)p->I, len, true);
         if (out_host)
             HIP_OK(hipMemcpy2DAsync(out_host, out_stride * sizeof(float), p->d_out, p->Lcap * sizeof(float), len * sizeof(float), p->I,
                                     hipMemcpyDeviceToHost, p->stream));
+        auto t1 = std::chrono::steady_clock::now();
         HIP_OK(hipStreamSynchronize(p->stream));
+        auto t2 = std::chrono::steady_clock::now();
         post_render_host(p, 0, (int)p->I, len);
+        auto t3 = std::chrono::steady_clock::now();
         collect_profile(p);
+        auto t4 = std::chrono::steady_clock::now();
+        if (hostprof) {
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            acc[0] += ms(t0, t1); acc[1] += ms(t1, t2); acc[2] += ms(t2, t3); acc[3] += ms(t3, t4);
+            if (++cnt % 50 == 0) { std::fprintf(stderr, "hostprof I=%zu: launch %.3f wait %.3f post %.3f profile %.3f ms (mean of 50)\n", p->I, acc[0] / 50, acc[1] / 50, acc[2] / 50, acc[3] / 50); acc[0] = acc[1] = acc[2] = acc[3] = 0; }
+        }
         p->last_len = len;
     });
     if (!g_err.empty() && out_host) { /* degrade to silence on device failure */ }
