@@ -24,6 +24,7 @@
 #include "ow_trem_wide.h"
 #include "ow_audit.h"
 #include "ow_midi_kernels.h"
+#include "ow_chain_wide.h"
 #include <map>
 #include <mutex>
 
@@ -253,6 +254,21 @@ void mel_settled_to_device(int device, double* d_dst, hipStream_t st) {
 }
 
 enum { INIT_NEW = 1, INIT_RATE = 2, INIT_RESET = 0 };
+
+// Job paths (batch render, render-midi): a quad of lanes per preamp state (ow_chain_wide.h) while the jobs are too few to fill the
+// chip with one lane pair each -- their run time is then the chain's serial latency.  OW_CHAIN_WIDE=0/1 forces the choice (the
+// parity test compares the two kernels bit for bit).
+static inline bool chain_wide(size_t n_jobs) {
+    if (const char* env = std::getenv("OW_CHAIN_WIDE")) return env[0] == '1';
+    return n_jobs <= 8192;
+}
+static void launch_job_chain_legacy(const OwConsts* dK, const owdev::OwJobDev* d_jobs, const double* d_in, double* d_out, size_t n_jobs, long long n,
+                                    long long stride, hipStream_t st) {
+    if (chain_wide(n_jobs))
+        owdev::k_job_chain_wide<<<dim3((unsigned)((n_jobs + 7) / 8)), dim3(64), 0, st>>>(dK, d_jobs, d_in, d_out, (int)n_jobs, n, stride);
+    else
+        owdev::k_job_chain<false><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_in, d_out, nullptr, (int)n_jobs, n, stride);
+}
 
 // chain (re)initialisation of engines [e0, e0+ne): DC states on the device, then the Twin-T settle
 // (50 warm-up steps at the codegen matrices + 2 s at the pool rate), all in the product kernels.
@@ -1278,8 +1294,7 @@ long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg*
             owdev::k_job_chain<true><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_reed, d_out, d_settled, (int)n_jobs, (long long)n,
                                                                                                 (long long)stride);
         } else {
-            owdev::k_job_chain<false><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_reed, d_out, nullptr, (int)n_jobs, (long long)n,
-                                                                                                 (long long)stride);
+            launch_job_chain_legacy(dK, d_jobs, d_reed, d_out, n_jobs, (long long)n, (long long)stride, st);
         }
         HIP_OK(hipGetLastError());
         if (!out_is_device) HIP_OK(hipMemcpyAsync(out, d_out, sizeof(double) * n_jobs * stride, hipMemcpyDeviceToHost, st));
@@ -1803,8 +1818,8 @@ long long ow_render_midi(const ow_timed_event* events, const size_t* job_offsets
         owdev::k_midi_voices<<<dim3((unsigned)n_jobs), dim3(64), 0, st>>>(dK.as<OwConsts>(), d_nt.as<double>(), d_vrec.as<double>(), d_jobs.as<owdev::OwMidiJobDev>(),
                                                                          d_ev.as<owdev::OwMidiEvDev>(), d_held.as<uint32_t>(), d_sum.as<double>(), (long long)longest,
                                                                          d_stats.as<owdev::OwMidiStatsDev>());
-        owdev::k_job_chain<false><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK.as<OwConsts>(), d_chain.as<owdev::OwJobDev>(), d_sum.as<double>(),
-                                                                                             d_out.as<double>(), nullptr, (int)n_jobs, (long long)longest, (long long)longest);
+        launch_job_chain_legacy(dK.as<OwConsts>(), d_chain.as<owdev::OwJobDev>(), d_sum.as<double>(), d_out.as<double>(), n_jobs, (long long)longest,
+                                (long long)longest, st);
         HIP_OK(hipGetLastError());
         std::vector<owdev::OwMidiStatsDev> hs(n_jobs);
         HIP_OK(hipMemcpy2DAsync(out, stride * sizeof(double), d_out.p, longest * sizeof(double), longest * sizeof(double), n_jobs, hipMemcpyDeviceToHost, st));

@@ -1,0 +1,205 @@
+// openwurli-hip: legacy DK preamp step with FOUR LANES PER SOLVER STATE, for the job paths (batch render, render-midi) whose
+// few hundred jobs leave the chip idle and whose run time is the serial latency of dk_step (ow_chain_dev.h): ~840 dependent-ish
+// instructions per 96 kHz sample for a lone wavefront.
+//
+// The four lanes of a quad hold the same state.  What is split is the dense part of the step:
+//   * v_pred_base = S * rhs (8x8): lane q forms rows q and q + 4 (its two rows of S live in its own registers) and the quad
+//     all-gathers the eight sums with DPP quad moves;
+//   * the two junction exponentials of every Newton iteration (and of the final current evaluation): even lanes take Q1, odd
+//     lanes Q2, one exchange.
+// Everything else (the sparse A_neg product, Sherman-Morrison scalars, the 2x2 Newton update, the state update) is cheap and stays
+// replicated, statement for statement as in dk_step.  Every number is produced by the same operations in the same order, so the
+// result is bit-identical to dk_step's (tests/test_gpu_parity.py::test_chain_wide_is_bit_identical).
+#pragma once
+#include "ow_trem_wide.h"
+
+namespace owdev {
+
+struct DkWideRows { double s_lo[8], s_hi[8]; };   // rows q and q + 4 of S (lane q of the quad), loop-invariant
+
+__device__ inline void dk_wide_rows_load(DkWideRows& R, const OwConsts* __restrict__ K, int q) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { R.s_lo[j] = K->p_s[q][j]; R.s_hi[j] = K->p_s[q + 4][j]; }
+}
+
+// ic, gm of both junctions with one exponential per lane: even lanes of the quad evaluate vn0, odd lanes vn1 (dk_ic_gm, :686-690)
+OW_DEV void dk_ic_gm_pair(int q, double vn0, double vn1, double& ic0, double& gm0, double& ic1, double& gm1) {
+    double ic, gm;
+    dk_ic_gm((q & 1) ? vn1 : vn0, ic, gm);
+    ic0 = qperm<0xA0>(ic); gm0 = qperm<0xA0>(gm);   // lanes (0,1,2,3) read lanes (0,0,2,2)
+    ic1 = qperm<0xF5>(ic); gm1 = qperm<0xF5>(gm);   // lanes (0,1,2,3) read lanes (1,1,3,3)
+}
+OW_DEV void dk_ic_pair(int q, double vn0, double vn1, double& ic0, double& ic1) {
+    const double ic = dk_ic((q & 1) ? vn1 : vn0);
+    ic0 = qperm<0xA0>(ic);
+    ic1 = qperm<0xF5>(ic);
+}
+
+// dk_step (dk_preamp_legacy.rs:447-554), quad-parallel.  `st` is replicated in the four lanes.
+__device__ inline double dk_step_wide(DkSt& st, const DkWideRows& R, int q, double input, double g_ldr, double g_ldr_prev,
+                                      const OwConsts* __restrict__ K0) {
+    const OwConsts* __restrict__ K = k_reload(K0);
+    const double (*__restrict__ an)[8] = K->p_a_neg;
+    const double* v = st.v;
+    double rhs[8];
+    rhs[0] = 0.0 + an[0][0] * v[0] + an[0][2] * v[2];
+    rhs[1] = 0.0 + an[1][1] * v[1] + an[1][7] * v[7];
+    rhs[2] = 0.0 + an[2][0] * v[0] + an[2][2] * v[2] + an[2][5] * v[5];
+    rhs[3] = 0.0 + an[3][3] * v[3] + an[3][4] * v[4];
+    rhs[4] = 0.0 + an[4][3] * v[3] + an[4][4] * v[4];
+    rhs[5] = 0.0 + an[5][2] * v[2] + an[5][5] * v[5] + an[5][6] * v[6];
+    rhs[6] = 0.0 + an[6][5] * v[5] + an[6][6] * v[6] + an[6][7] * v[7];
+    rhs[7] = 0.0 + an[7][1] * v[1] + an[7][6] * v[6] + an[7][7] * v[7];
+    rhs[7] -= g_ldr_prev * st.v[7];
+    const double cin_now = K->p_g_cin * input + st.j_cin;
+    rhs[0] += cin_now + st.cin_prev;
+    rhs[1] += st.i_nl[0];
+    rhs[2] -= st.i_nl[0];
+    rhs[3] += st.i_nl[1];
+    rhs[5] -= st.i_nl[1];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rhs[i] += K->p_two_w[i];
+    // v_pred_base = S rhs: this lane's two rows, then the quad's eight
+    double lo = 0.0, hi = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { lo += R.s_lo[j] * rhs[j]; hi += R.s_hi[j] * rhs[j]; }
+    double vpb[8];
+    static_for<0, 4>([&](auto i) { vpb[i] = qget<i>(lo); vpb[i + 4] = qget<i>(hi); });
+    K = k_reload(K0);
+    const double sm_k = ow_div(g_ldr, 1.0 + K->p_s_fb_fb * g_ldr);
+    const double sm_vpred = sm_k * vpb[7];
+    double v_pred[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v_pred[i] = vpb[i] - sm_vpred * K->p_s_fb_col[i];
+    const double p0 = v_pred[0] - v_pred[1], p1 = v_pred[2] - v_pred[3];
+    const double k00 = K->p_k[0][0] - sm_k * K->p_nv_sfb[0] * K->p_sfb_ni[0];
+    const double k01 = K->p_k[0][1] - sm_k * K->p_nv_sfb[0] * K->p_sfb_ni[1];
+    const double k10 = K->p_k[1][0] - sm_k * K->p_nv_sfb[1] * K->p_sfb_ni[0];
+    const double k11 = K->p_k[1][1] - sm_k * K->p_nv_sfb[1] * K->p_sfb_ni[1];
+    double vn0 = st.v_nl[0], vn1 = st.v_nl[1];
+    // The trip count is the same in the four lanes of a quad (replicated values), so the quad moves inside the loop always find
+    // their source lanes active.
+    for (int iter = 0; iter < 6; ++iter) {
+        double ic0, gm0, ic1, gm1;
+        dk_ic_gm_pair(q, vn0, vn1, ic0, gm0, ic1, gm1);
+        const double f0 = vn0 - p0 - k00 * ic0 - k01 * ic1;
+        const double f1 = vn1 - p1 - k10 * ic0 - k11 * ic1;
+        if (fabs(f0) < 1e-9 && fabs(f1) < 1e-9) break;
+        const double j00 = 1.0 - k00 * gm0, j01 = -k01 * gm1, j10 = -k10 * gm0, j11 = 1.0 - k11 * gm1;
+        const double det = j00 * j11 - j01 * j10;
+        if (fabs(det) < 1e-30) break;
+        const double inv_det = ow_div(1.0, det);
+        vn0 -= inv_det * (j11 * f0 - j01 * f1);
+        vn1 -= inv_det * (j00 * f1 - j10 * f0);
+    }
+    double ic0, ic1;
+    dk_ic_pair(q, vn0, vn1, ic0, ic1);
+    K = k_reload(K0);
+    const double dot = K->p_sfb_ni[0] * ic0 + K->p_sfb_ni[1] * ic1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double s_ni_i = ic0 * (K->p_s[i][1] - K->p_s[i][2]) + ic1 * (K->p_s[i][3] - K->p_s[i][5]);
+        st.v[i] = v_pred[i] + s_ni_i - sm_k * dot * K->p_s_fb_col[i];
+    }
+    st.cin_prev = cin_now;
+    const double dv_cin = input - st.v[0];
+    st.j_cin = -K->p_gc_1pc * dv_cin - K->p_c_cin * st.j_cin;
+    st.i_nl[0] = ic0; st.i_nl[1] = ic1;
+    st.v_nl[0] = vn0; st.v_nl[1] = vn1;
+    return st.v[6];
+}
+
+// Value of lane ^ 32 (main <-> shadow) without the LDS crossbar: v_permlane32_swap exchanges the upper half of its first operand
+// with the lower half of its second; with both = x the first result holds x[lane - 32] in lanes 32-63 and the second x[lane + 32]
+// in lanes 0-31.
+OW_DEV double xor32(double x) {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const bool low_half = threadIdx.x < 32;
+    return __hiloint2double(low_half ? b[1] : b[0], low_half ? a[1] : a[0]);
+}
+
+// k_job_chain<false> with a quad per solver state: 8 jobs per wavefront (main quads in lanes 0-31, shadow quads in lanes 32-63).
+#define OW_WCHUNK 64
+__global__ __launch_bounds__(64) void k_job_chain_wide(const OwConsts* __restrict__ K, const OwJobDev* __restrict__ jobs, const double* __restrict__ reed,
+                                                       double* __restrict__ out, int n_jobs, long long n, long long stride) {
+    __shared__ double tin[8 * (OW_WCHUNK + 1)];
+    __shared__ double tout[8 * (OW_WCHUNK + 1)];
+    const int lane = threadIdx.x;
+    const int q = lane & 3, jl = (lane & 31) >> 2, role = lane >> 5;
+    const int jb = blockIdx.x * 8;
+    const int j = jb + jl;
+    const bool valid = j < n_jobs;
+    const OwJobDev jd = jobs[valid ? j : n_jobs - 1];
+    const int osr = K->oversample ? 2 : 1;
+    const double sr = K->sr;
+    DkWideRows R;
+    dk_wide_rows_load(R, K, q);
+
+    // DkPreamp::new(preamp_sr); preamp.reset(); preamp.set_ldr_resistance(r_ldr)  (main.rs:432-441)
+    DkSt st;
+    double r_ldr = 1000000.0;
+    double g_ldr = 1.0 / r_ldr, g_prev = g_ldr;
+    dk_dc_reset(K, r_ldr, st);
+    {
+        const double r_new = fmax(jd.r_ldr, 1000.0);
+        if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = 1.0 / r_new; }
+    }
+    auto preamp_step = [&](double x) -> double {
+        const double o = dk_step_wide(st, R, q, x, g_ldr, g_prev, K);
+        g_prev = g_ldr;
+        const double other = xor32(o);
+        double res = role ? (other - o) : (o - other);
+        if (!isfinite(res)) {
+            dk_dc_reset(K, r_ldr, st); g_ldr = 1.0 / r_ldr; g_prev = g_ldr;
+            res = 0.0;
+        }
+        return res;
+    };
+    double ua[3] = {0, 0, 0}, ub[3] = {0, 0, 0}, da[3] = {0, 0, 0}, db[3] = {0, 0, 0}, dd = 0.0;
+    SpeakerSt sp;                                      // Speaker::new(sr); set_character(c)  (main.rs:483-484)
+    sp.character = 1.0; sp.ts = 0.0;
+    sp.hpf.s1 = sp.hpf.s2 = sp.lpf.s1 = sp.lpf.s2 = 0.0;
+    speaker_update(sp, sr);
+    speaker_set_character(sp, jd.speaker, sr);
+    const double vol2_a = jd.volume;
+
+    for (long long base = 0; base < n; base += OW_WCHUNK) {
+        const int cn = (int)((n - base) < OW_WCHUNK ? (n - base) : OW_WCHUNK);
+        for (int r = 0; r < 8; ++r) {
+            double x = 0.0;
+            if (jb + r < n_jobs && lane < cn) x = reed[(size_t)(jb + r) * stride + base + lane];
+            tin[r * (OW_WCHUNK + 1) + lane] = x;
+        }
+        __syncthreads();
+        for (int s = 0; s < cn; ++s) {
+            const double x = tin[jl * (OW_WCHUNK + 1) + s];
+            double pre;
+            if (osr == 2) {                            // main.rs:445-466: per-sample up(1) -> 2x process -> down(1)
+                const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, ua, x);
+                const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, ub, x);
+                double p[2];
+                const double in[2] = {role ? 0.0 : a, role ? 0.0 : b};
+                for (int k = 0; k < 2; ++k) p[k] = preamp_step(in[k]);
+                const double fa = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, p[0]);
+                const double fb = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, p[1]);
+                pre = (fa + dd) * 0.5;
+                dd = fb;
+            } else {
+                pre = preamp_step(role ? 0.0 : x);
+            }
+            // main.rs:487-496: volume^2 (audio taper) -> optional power amp at base rate -> speaker -> PSG
+            const double att = pre * vol2_a * vol2_a;
+            const double amp = jd.poweramp ? power_amp(att) : att;
+            const double y = speaker_process(sp, amp, K->spk_thermal_alpha) * 7.498942093324558;
+            if (role == 0 && q == 0) tout[jl * (OW_WCHUNK + 1) + s] = y;
+        }
+        __syncthreads();
+        for (int r = 0; r < 8; ++r)
+            if (jb + r < n_jobs && lane < cn) out[(size_t)(jb + r) * stride + base + lane] = tout[r * (OW_WCHUNK + 1) + lane];
+        __syncthreads();
+    }
+}
+
+}  // namespace owdev

@@ -270,6 +270,33 @@ def test_tremolo_wide_is_bit_identical(hiplib, oracle):
         assert np.max(np.abs(shunt - ro) / ro) < 1e-9
 
 
+def test_chain_wide_is_bit_identical(hiplib, oracle):
+    """Job paths run the legacy preamp with a quad of lanes per solver state while jobs are few (ow_chain_wide.h: the rows of S and the
+    two junction exponentials spread over the quad); with many jobs a lane pair per job.  Both must produce the SAME bits, at
+    both rates (with and without oversampling), with and without power amp / speaker character, and both match the oracle.
+    (Static LDR values stay inside the cell's range, >= 2e4 ohm: at a few kilohm the preamp leaves its operating region, output peaks
+    of 1e4, and neither side is a reference for the other any more.)"""
+    import openwurli_amd as ow
+    jobs = [dict(note=n, velocity=v, mlp=bool(k & 1), poweramp=bool(k & 2), volume=1.0 - 0.1 * (k % 4), speaker=0.25 * (k % 5), r_ldr=r)
+            for k, (n, v, r) in enumerate([(33, 127, 1e6), (48, 50, 1e6), (60, 100, 2.5e4), (72, 20, 1e6), (84, 127, 4e4), (91, 64, 1e6), (96, 110, 1e5),
+                                           (40, 90, 1e6), (55, 35, 7e5), (67, 80, 1e6), (79, 127, 1e6)])]
+    for sr in (44100.0, 96000.0):
+        outs = {}
+        for wide in ("0", "1"):
+            os.environ["OW_CHAIN_WIDE"] = wide
+            try:
+                outs[wide] = ow.batch_render(jobs, sr, 0.35)
+            finally:
+                del os.environ["OW_CHAIN_WIDE"]
+        assert np.array_equal(outs["0"], outs["1"]), (sr, np.max(np.abs(outs["0"] - outs["1"])))
+        for k in (0, 2, 4, 10):
+            j = jobs[k]
+            c = oracle.batch_render_job(j["note"], j["velocity"], 0.35, sr, volume=j["volume"], speaker=j["speaker"], r_ldr=j["r_ldr"],
+                                        mlp=j["mlp"], poweramp=j["poweramp"])
+            rep = oracle.parity_report(outs["1"][k][:c.size], c, abs_floor=oracle.ABS_FLOOR_BATCH)
+            assert rep["n_bad"] == 0, (sr, k, rep)
+
+
 def test_pool_of_independent_engines(hiplib, oracle):
     """Lane = engine kernels: 5 engines with different scripts in one pool vs 5 separate oracle engines."""
     import openwurli_amd as ow
