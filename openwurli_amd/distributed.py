@@ -64,6 +64,44 @@ def batch_render_sharded(jobs, sample_rate, duration_s, render_fn=None, device=N
     return unshard([g.cpu().numpy() for g in gathered], n_jobs, world)
 
 
+def render_midi_sharded(event_lists, render_fn=None, device=None, group=None, **render_kw):
+    """``midi_render.render_midi`` across the ranks: event list j -> rank j mod G, every rank renders its shard, the rows are padded
+    to the longest render of the whole job set (one MAX all-reduce of a scalar) and ONE gather brings the f32 slabs to rank 0, which
+    returns the list of renders at their own lengths (others None).  ``render_fn(local_lists) -> list of 1-D arrays`` defaults to
+    the HIP renderer; the CPU tests inject a stand-in."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    event_lists = list(event_lists)
+    n_jobs = len(event_lists)
+    mine = shard_indices(n_jobs, rank, world)
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", device if device is not None else torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    if render_fn is None:
+        if not on_gpu:
+            raise RuntimeError("the HIP renderer needs the nccl backend (a GPU per rank); pass render_fn for CPU tests")
+        from . import midi_render
+
+        def render_fn(lists):
+            return midi_render.render_midi(lists, device=dev.index, **render_kw)
+    local = [np.asarray(x, dtype=np.float32) for x in render_fn([event_lists[i] for i in mine])] if mine else []
+    lengths = torch.zeros(max(n_jobs, 1), dtype=torch.int64, device=dev)
+    for i, x in zip(mine, local):
+        lengths[i] = x.size
+    dist.all_reduce(lengths, op=dist.ReduceOp.MAX, group=group)          # every rank learns every job's length (and the longest)
+    longest = int(lengths.max().item())
+    n_pad = (n_jobs + world - 1) // world
+    slab = torch.zeros((n_pad, max(longest, 1)), dtype=torch.float32, device=dev)
+    for k, x in enumerate(local):
+        slab[k, :x.size] = torch.from_numpy(x).to(dev)
+    gathered = [torch.zeros_like(slab) for _ in range(world)] if rank == 0 else None
+    dist.gather(slab, gathered, dst=0, group=group)                      # the one exchange step of the data path
+    if rank != 0:
+        return None
+    full = unshard([g.cpu().numpy() for g in gathered], n_jobs, world)
+    return [full[j, :int(lengths[j].item())].copy() for j in range(n_jobs)]
+
+
 def model_notes_job_list(notes=range(33, 97), velocities=(20, 35, 50, 65, 80, 95, 110, 127)):
     """The job grid of ml/render_model_notes.py:26,106-114 (64 notes x 8 velocity buckets)."""
     return [{"note": n, "velocity": v, "mlp": False, "poweramp": False, "volume": 1.0, "speaker": 0.0, "r_ldr": 1e6}
