@@ -270,6 +270,25 @@ def test_tremolo_wide_is_bit_identical(hiplib, oracle):
         assert np.max(np.abs(shunt - ro) / ro) < 1e-9
 
 
+@pytest.mark.parametrize("sr", [64000.0, 88199.0, 88200.0, 176400.0, 192000.0])
+def test_unusual_host_rates(hiplib, oracle, sr):
+    """Host rates around the oversampling switch (engine.rs:195: 2x chain below 88.2 kHz, none from 88.2 kHz on) and far from the
+    usual ones: rate-dependent constants (matrices, ramps, decay multipliers, steal fade length) all come from the pool's rate.
+    (Below 40 kHz the speaker's 20 kHz low-pass lies above Nyquist and the reference algorithm itself blows up -- 32 kHz reaches
+    1e38 on both sides -- so there is nothing to compare there.)"""
+    import openwurli_amd as ow
+    g, cs = _both(ow, oracle, sr)
+    for e in (g[0], cs[0]):
+        e.set_tremolo_depth(0.7)
+        for n, v in ((40, 0.9), (64, 0.5), (88, 1.0)):
+            e.note_on(n, v)
+    _render_compare(oracle, g, cs, 3, 400, ("rate", sr))
+    for e in (g[0], cs[0]):
+        e.note_off(64); e.note_on(64, 0.8); e.set_sustain(True); e.note_off(40)
+    _render_compare(oracle, g, cs, 3, 333, ("rate-2", sr))
+    g.close()
+
+
 def test_chain_wide_is_bit_identical(hiplib, oracle):
     """Job paths run the legacy preamp with a quad of lanes per solver state while jobs are few (ow_chain_wide.h: the rows of S and the
     two junction exponentials spread over the quad); with many jobs a lane pair per job.  Both must produce the SAME bits, at
