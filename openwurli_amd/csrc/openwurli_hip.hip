@@ -223,6 +223,7 @@ void ensure_ops_capacity(ow_pool* p, size_t n) {
     size_t cap = std::max<size_t>(3 * n, std::max<size_t>(p->ops_cap * 2, 256));
     if (p->d_ops) hipFree(p->d_ops);
     if (p->h_ops) hipHostFree(p->h_ops);
+    p->d_ops = nullptr; p->h_ops = nullptr; p->ops_cap = 0;   // a failed allocation below must not leave freed pointers behind
     HIP_OK(hipMalloc(&p->d_ops, sizeof(OwOp) * cap));
     HIP_OK(hipHostMalloc(&p->h_ops, sizeof(OwOp) * cap));
     p->ops_cap = cap;
@@ -1167,14 +1168,13 @@ int ow_debug_mlp_raw(const uint8_t* notes, const double* velocities, size_t n, d
     try {
         if (!notes || !velocities || !out || n == 0) throw std::runtime_error("null argument");
         HIP_OK(hipSetDevice(device));
-        uint8_t* dn = nullptr; double* dv = nullptr; double* dout = nullptr;
-        HIP_OK(hipMalloc(&dn, n)); HIP_OK(hipMalloc(&dv, n * sizeof(double))); HIP_OK(hipMalloc(&dout, n * 11 * sizeof(double)));
-        HIP_OK(hipMemcpy(dn, notes, n, hipMemcpyHostToDevice));
-        HIP_OK(hipMemcpy(dv, velocities, n * sizeof(double), hipMemcpyHostToDevice));
-        owdev::k_debug_mlp<<<dim3((unsigned)((n + 63) / 64)), dim3(64)>>>(dn, dv, (int)n, dout, use_mfma);
+        DevMem dn, dv, dout;
+        dn.alloc(n); dv.alloc(n * sizeof(double)); dout.alloc(n * 11 * sizeof(double));
+        HIP_OK(hipMemcpy(dn.p, notes, n, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(dv.p, velocities, n * sizeof(double), hipMemcpyHostToDevice));
+        owdev::k_debug_mlp<<<dim3((unsigned)((n + 63) / 64)), dim3(64)>>>(dn.as<uint8_t>(), dv.as<double>(), (int)n, dout.as<double>(), use_mfma);
         HIP_OK(hipGetLastError());
-        HIP_OK(hipMemcpy(out, dout, n * 11 * sizeof(double), hipMemcpyDeviceToHost));
-        hipFree(dn); hipFree(dv); hipFree(dout);
+        HIP_OK(hipMemcpy(out, dout.p, n * 11 * sizeof(double), hipMemcpyDeviceToHost));
         return 0;
     } catch (const std::exception& ex) { set_err(std::string("ow_debug_mlp_raw: ") + ex.what()); return -1; }
 }
@@ -1272,37 +1272,35 @@ long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg*
             hj[i].note = jobs[i].note; hj[i].velocity = jobs[i].velocity; hj[i].mlp = jobs[i].mlp; hj[i].poweramp = jobs[i].poweramp;
             hj[i].pad = 0; hj[i].volume = jobs[i].volume; hj[i].speaker = jobs[i].speaker; hj[i].r_ldr = jobs[i].r_ldr;
         }
-        OwConsts* dK = nullptr; double* d_nt = nullptr; double* d_vrec = nullptr; owdev::OwJobDev* d_jobs = nullptr;
-        double* d_reed = nullptr; double* d_out = nullptr;
         const size_t vblocks = (n_jobs + 63) / 64;
-        hipStream_t st;
-        HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        HIP_OK(hipMalloc(&dK, sizeof(OwConsts)));
-        HIP_OK(hipMalloc(&d_nt, sizeof(double) * NT_COUNT * 64));
-        HIP_OK(hipMalloc(&d_vrec, sizeof(double) * vblocks * OW_VREC_DOUBLES));
-        HIP_OK(hipMalloc(&d_jobs, sizeof(owdev::OwJobDev) * n_jobs));
-        HIP_OK(hipMalloc(&d_reed, sizeof(double) * n_jobs * n));
-        if (out_is_device) d_out = out; else HIP_OK(hipMalloc(&d_out, sizeof(double) * n_jobs * stride));
+        StreamOwner so;
+        HIP_OK(hipStreamCreateWithFlags(&so.s, hipStreamNonBlocking));
+        hipStream_t st = so.s;
+        DevMem m_K, m_nt, m_vrec, m_jobs, m_reed, m_out, m_settled;   // released on every exit path
+        m_K.alloc(sizeof(OwConsts));
+        m_nt.alloc(sizeof(double) * NT_COUNT * 64);
+        m_vrec.alloc(sizeof(double) * vblocks * OW_VREC_DOUBLES);
+        m_jobs.alloc(sizeof(owdev::OwJobDev) * n_jobs);
+        m_reed.alloc(sizeof(double) * n_jobs * n);
+        if (!out_is_device) m_out.alloc(sizeof(double) * n_jobs * stride);
+        OwConsts* dK = m_K.as<OwConsts>(); double* d_nt = m_nt.as<double>(); double* d_vrec = m_vrec.as<double>();
+        owdev::OwJobDev* d_jobs = m_jobs.as<owdev::OwJobDev>(); double* d_reed = m_reed.as<double>();
+        double* d_out = out_is_device ? out : m_out.as<double>();
         HIP_OK(hipMemcpyAsync(dK, &hc, sizeof(OwConsts), hipMemcpyHostToDevice, st));
         HIP_OK(hipMemcpyAsync(d_jobs, hj.data(), sizeof(owdev::OwJobDev) * n_jobs, hipMemcpyHostToDevice, st));
         owdev::k_note_table<<<dim3(1), dim3(64), 0, st>>>(d_nt);
         owdev::k_job_voice<<<dim3((unsigned)vblocks), dim3(64), 0, st>>>(dK, d_nt, d_vrec, d_jobs, d_reed, (int)n_jobs, (long long)n, (long long)n);
-        double* d_settled = nullptr;
         if (cfg->preamp_kind == OW_PREAMP_MELANGE12) {
-            HIP_OK(hipMalloc(&d_settled, sizeof(double) * 18));
-            mel_settled_to_device(cfg->device, d_settled, st);
-            owdev::k_job_chain<true><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_reed, d_out, d_settled, (int)n_jobs, (long long)n,
-                                                                                                (long long)stride);
+            m_settled.alloc(sizeof(double) * 18);
+            mel_settled_to_device(cfg->device, m_settled.as<double>(), st);
+            owdev::k_job_chain<true><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_reed, d_out, m_settled.as<double>(), (int)n_jobs,
+                                                                                                (long long)n, (long long)stride);
         } else {
             launch_job_chain_legacy(dK, d_jobs, d_reed, d_out, n_jobs, (long long)n, (long long)stride, st);
         }
         HIP_OK(hipGetLastError());
         if (!out_is_device) HIP_OK(hipMemcpyAsync(out, d_out, sizeof(double) * n_jobs * stride, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
-        hipFree(dK); hipFree(d_nt); hipFree(d_vrec); hipFree(d_jobs); hipFree(d_reed);
-        if (d_settled) hipFree(d_settled);
-        if (!out_is_device) hipFree(d_out);
-        hipStreamDestroy(st);
         return (long long)n;
     } catch (const std::exception& ex) { set_err(std::string("ow_batch_render: ") + ex.what()); return -1; }
 }
@@ -1412,27 +1410,30 @@ int ow_extract_harmonics(const double* audio, size_t n_rows, size_t stride, doub
             }
         }
         HIP_OK(hipSetDevice(device));
-        hipStream_t st;
-        HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        double* d_audio = nullptr; double* d_xw = nullptr; double* d_ss = nullptr;
-        owdev::OwSegDev* d_segs = nullptr; owdev::OwBinsDev* d_bins = nullptr; owdev::OwPeakDev* d_peaks = nullptr;
-        if (audio_is_device) d_audio = const_cast<double*>(audio);
-        else {
-            HIP_OK(hipMalloc(&d_audio, sizeof(double) * n_rows * stride));
-            HIP_OK(hipMemcpyAsync(d_audio, audio, sizeof(double) * n_rows * stride, hipMemcpyHostToDevice, st));
+        StreamOwner so;
+        HIP_OK(hipStreamCreateWithFlags(&so.s, hipStreamNonBlocking));
+        hipStream_t st = so.s;
+        DevMem own_audio, m_xw, m_ss, m_segs, m_bins, m_peaks;   // released on every exit path
+        const double* d_audio = audio;
+        if (!audio_is_device) {
+            own_audio.alloc(sizeof(double) * n_rows * stride);
+            HIP_OK(hipMemcpyAsync(own_audio.p, audio, sizeof(double) * n_rows * stride, hipMemcpyHostToDevice, st));
+            d_audio = own_audio.as<double>();
         }
-        HIP_OK(hipMalloc(&d_xw, sizeof(double) * std::max<uint64_t>(off, 1)));
-        HIP_OK(hipMalloc(&d_ss, sizeof(double) * n_segs));
-        HIP_OK(hipMalloc(&d_segs, sizeof(owdev::OwSegDev) * n_segs));
+        m_xw.alloc(sizeof(double) * std::max<uint64_t>(off, 1));
+        m_ss.alloc(sizeof(double) * n_segs);
+        m_segs.alloc(sizeof(owdev::OwSegDev) * n_segs);
+        double* d_xw = m_xw.as<double>(); double* d_ss = m_ss.as<double>();
+        owdev::OwSegDev* d_segs = m_segs.as<owdev::OwSegDev>();
         HIP_OK(hipMemcpyAsync(d_segs, hs.data(), sizeof(owdev::OwSegDev) * n_segs, hipMemcpyHostToDevice, st));
         owdev::k_feat_window<<<dim3((unsigned)n_segs), dim3(256), 0, st>>>(d_audio, stride, d_segs, d_xw, d_ss, wav24_mode);
         std::vector<owdev::OwPeakDev> peaks(hb.size());
         if (!hb.empty()) {
-            HIP_OK(hipMalloc(&d_bins, sizeof(owdev::OwBinsDev) * hb.size()));
-            HIP_OK(hipMalloc(&d_peaks, sizeof(owdev::OwPeakDev) * hb.size()));
-            HIP_OK(hipMemcpyAsync(d_bins, hb.data(), sizeof(owdev::OwBinsDev) * hb.size(), hipMemcpyHostToDevice, st));
-            owdev::k_feat_peaks<<<dim3((unsigned)hb.size()), dim3(256), 0, st>>>(d_segs, d_bins, d_xw, d_peaks);
-            HIP_OK(hipMemcpyAsync(peaks.data(), d_peaks, sizeof(owdev::OwPeakDev) * hb.size(), hipMemcpyDeviceToHost, st));
+            m_bins.alloc(sizeof(owdev::OwBinsDev) * hb.size());
+            m_peaks.alloc(sizeof(owdev::OwPeakDev) * hb.size());
+            HIP_OK(hipMemcpyAsync(m_bins.p, hb.data(), sizeof(owdev::OwBinsDev) * hb.size(), hipMemcpyHostToDevice, st));
+            owdev::k_feat_peaks<<<dim3((unsigned)hb.size()), dim3(256), 0, st>>>(d_segs, m_bins.as<owdev::OwBinsDev>(), d_xw, m_peaks.as<owdev::OwPeakDev>());
+            HIP_OK(hipMemcpyAsync(peaks.data(), m_peaks.p, sizeof(owdev::OwPeakDev) * hb.size(), hipMemcpyDeviceToHost, st));
         }
         std::vector<double> ss(n_segs);
         HIP_OK(hipMemcpyAsync(ss.data(), d_ss, sizeof(double) * n_segs, hipMemcpyDeviceToHost, st));
@@ -1455,11 +1456,6 @@ int ow_extract_harmonics(const double* audio, size_t n_rows, size_t stride, doub
             }
             if (rms) rms[i] = std::max(std::sqrt(ss[i] / N), 1e-20);
         }
-        if (!audio_is_device) hipFree(d_audio);
-        hipFree(d_xw); hipFree(d_ss); hipFree(d_segs);
-        if (d_bins) hipFree(d_bins);
-        if (d_peaks) hipFree(d_peaks);
-        hipStreamDestroy(st);
         return 0;
     } catch (const std::exception& ex) { set_err(std::string("ow_extract_harmonics: ") + ex.what()); return -1; }
 }
