@@ -447,11 +447,36 @@ struct Smoother {
 #define OW_P_VT 0.026
 struct DkSt { double j_cin, cin_prev, v[8], i_nl[2], v_nl[2]; };
 
+// exp() for the junction laws below, whose argument is clamped to [-1 V, 0.85 V] / V_T = [-38.5, 32.7]: the device library's f64 exp
+// (x * log2(e) rounded to n, two-step reduction by ln 2, degree-11 polynomial, ldexp) without its overflow / underflow selects
+// (two compares, three v_cndmask), which cannot fire here.  Same constants, same operations: bit-identical to exp() on the whole
+// clamp range (tests/test_gpu_division.py::test_bounded_exp_is_the_library_exp).
+OW_DEV double exp_bounded(double x) {
+#ifdef OW_LIB_EXP
+    return exp(x);
+#else
+    const double n = rint(x * __longlong_as_double(0x3ff71547652b82feLL));
+    double r = __builtin_fma(__longlong_as_double((long long)0xbfe62e42fefa39efULL), n, x);
+    r = __builtin_fma(__longlong_as_double((long long)0xbc7abc9e3b39803fULL), n, r);
+    double p = __builtin_fma(__longlong_as_double(0x3e5ade156a5dcb37LL), r, __longlong_as_double(0x3e928af3fca7ab0cLL));
+    p = __builtin_fma(r, p, __longlong_as_double(0x3ec71dee623fde64LL));
+    p = __builtin_fma(r, p, __longlong_as_double(0x3efa01997c89e6b0LL));
+    p = __builtin_fma(r, p, __longlong_as_double(0x3f2a01a014761f6eLL));
+    p = __builtin_fma(r, p, __longlong_as_double(0x3f56c16c1852b7b0LL));
+    p = __builtin_fma(r, p, __longlong_as_double(0x3f81111111122322LL));
+    p = __builtin_fma(r, p, __longlong_as_double(0x3fa55555555502a1LL));
+    p = __builtin_fma(r, p, __longlong_as_double(0x3fc5555555555511LL));
+    p = __builtin_fma(r, p, __longlong_as_double(0x3fe000000000000bLL));
+    p = __builtin_fma(r, p, 1.0);
+    p = __builtin_fma(r, p, 1.0);
+    return ldexp(p, (int)n);
+#endif
+}
 OW_DEV double dk_ic(double vbe) {  // dk_preamp_legacy.rs:663-666
-    return OW_P_IS * (exp(OW_DIV_C(clampd(vbe, -1.0, 0.85), OW_P_VT)) - 1.0);
+    return OW_P_IS * (exp_bounded(OW_DIV_C(clampd(vbe, -1.0, 0.85), OW_P_VT)) - 1.0);
 }
 OW_DEV void dk_ic_gm(double vbe, double& ic, double& gm) {  // :686-690
-    const double e = exp(OW_DIV_C(clampd(vbe, -1.0, 0.85), OW_P_VT));
+    const double e = exp_bounded(OW_DIV_C(clampd(vbe, -1.0, 0.85), OW_P_VT));
     ic = OW_P_IS * (e - 1.0);
     gm = (OW_P_IS / OW_P_VT) * e;
 }

@@ -106,6 +106,12 @@ __global__ __launch_bounds__(256) void k_debug_div_jitter_all(unsigned long long
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// exp_bounded against the library's exp (tests/test_gpu_division.py)
+__global__ __launch_bounds__(256) void k_debug_exp(const double* __restrict__ x, size_t n, double* __restrict__ fast, double* __restrict__ lib) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { fast[i] = exp_bounded(x[i]); lib[i] = exp(x[i]); }
+}
+
 // ow_div against the compiler's division (tests/test_gpu_division.py)
 __global__ __launch_bounds__(256) void k_debug_div(const double* __restrict__ a, const double* __restrict__ b, size_t n, double* __restrict__ fast,
                                                    double* __restrict__ ieee) {

@@ -99,3 +99,17 @@ def test_jitter_draw_exhaustive(hiplib):
     bad = C.c_uint64(123)
     assert hiplib.ow_debug_div_const(0, None, 0, None, None, C.byref(bad), 0) == 0
     assert bad.value == 0
+
+
+def test_bounded_exp_is_the_library_exp(hiplib):
+    """exp_bounded (the junction law's exponential: library algorithm without its overflow / underflow selects) on the whole clamp
+    range [-1 V, 0.85 V] / 0.026 V and a margin around it: bit-identical to the device library's exp(), and within one unit in the
+    last place of numpy's."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-38.5, 32.7, 1 << 24), rng.uniform(-60.0, 60.0, 1 << 22), np.linspace(-38.5, 32.7, 100001),
+                        np.array([0.0, -0.0, -1.0 / 0.026, 0.85 / 0.026, 1e-300, -1e-300, 1e-17])])
+    f = np.zeros_like(x); l = np.zeros_like(x)
+    assert hiplib.ow_debug_exp(x.ctypes.data_as(C.c_void_p), x.size, f.ctypes.data_as(C.c_void_p), l.ctypes.data_as(C.c_void_p), 0) == 0
+    assert _same_bits(f, l)
+    ref = np.exp(x)
+    assert np.max(np.abs(f - ref) / np.spacing(ref)) <= 1.0
