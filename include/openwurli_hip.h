@@ -142,9 +142,10 @@ int ow_debug_div(const double* a, const double* b, size_t n, double* fast, doubl
  * 3 preamp V_T 0.026, 4 power-amp 0.013^2, 5 power-amp headroom 22.  a == NULL runs every numerator of the jitter draw
  * (all 2^31 integers) on the device and stores the number of quotients that differ from `a / B` in *mismatches. */
 int ow_debug_div_const(int which, const double* a, size_t n, double* fast, double* ieee, uint64_t* mismatches, int device);
-/* The preamp's junction exponential (exp without the overflow / underflow selects, for arguments inside the junction clamp)
- * next to the device library's exp(), element-wise. */
-int ow_debug_exp(const double* x, size_t n, double* fast, double* lib, int device);
+/* Element-wise, the kernels' own elementary functions next to the device library's: which = 0 the preamp's junction exponential
+ * (exp without the overflow / underflow selects, for arguments inside the junction clamp) and exp(); 1 the power amp's / speaker's
+ * tanh (expm1-based, <= 2 ulp) and tanh(). */
+int ow_debug_unary(int which, const double* x, size_t n, double* fast, double* lib, int device);
 
 /* ---- offline / batch ---------------------------------------------------------------------- */
 /* Voice::render_note (voice.rs:191-221): one voice, no chain, f64.  Returns the number of samples

@@ -124,7 +124,7 @@ SYMBOLS = {
     "ow_alias_audit_run": (C.c_int, [_VP, _VP, C.c_size_t, C.c_int, C.c_int, _VP, _VP, C.c_size_t]),
     "ow_debug_div": (C.c_int, [_VP, _VP, C.c_size_t, _VP, _VP, C.c_int]),
     "ow_debug_div_const": (C.c_int, [C.c_int, _VP, C.c_size_t, _VP, _VP, _VP, C.c_int]),
-    "ow_debug_exp": (C.c_int, [_VP, C.c_size_t, _VP, _VP, C.c_int]),
+    "ow_debug_unary": (C.c_int, [C.c_int, _VP, C.c_size_t, _VP, _VP, C.c_int]),
     "ow_smf_parse": (C.c_longlong, [_VP, C.c_size_t, C.c_int, _VP, C.c_size_t]),
     "ow_render_midi": (C.c_longlong, [_VP, _VP, C.c_size_t, _VP, _VP, C.c_size_t, _VP]),
 }

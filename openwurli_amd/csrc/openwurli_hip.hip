@@ -1225,20 +1225,20 @@ int ow_debug_div_const(int which, const double* a, size_t n, double* fast, doubl
     } catch (const std::exception& ex) { set_err(std::string("ow_debug_div_const: ") + ex.what()); return -1; }
 }
 
-int ow_debug_exp(const double* x, size_t n, double* fast, double* lib, int device) {
+int ow_debug_unary(int which, const double* x, size_t n, double* fast, double* lib, int device) {
     try {
-        if (!x || !fast || !lib) throw std::runtime_error("null argument");
+        if (!x || !fast || !lib || which < 0 || which > 1) throw std::runtime_error("null argument or unknown function");
         if (n == 0) return 0;
         HIP_OK(hipSetDevice(device));
         DevMem dx, df, dl;
         dx.alloc(n * sizeof(double)); df.alloc(n * sizeof(double)); dl.alloc(n * sizeof(double));
         HIP_OK(hipMemcpy(dx.p, x, n * sizeof(double), hipMemcpyHostToDevice));
-        owdev::k_debug_exp<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(dx.as<double>(), n, df.as<double>(), dl.as<double>());
+        owdev::k_debug_exp<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(which, dx.as<double>(), n, df.as<double>(), dl.as<double>());
         HIP_OK(hipGetLastError());
         HIP_OK(hipMemcpy(fast, df.p, n * sizeof(double), hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(lib, dl.p, n * sizeof(double), hipMemcpyDeviceToHost));
         return 0;
-    } catch (const std::exception& ex) { set_err(std::string("ow_debug_exp: ") + ex.what()); return -1; }
+    } catch (const std::exception& ex) { set_err(std::string("ow_debug_unary: ") + ex.what()); return -1; }
 }
 
 // ---- offline ------------------------------------------------------------------------------------

@@ -107,9 +107,11 @@ __global__ __launch_bounds__(256) void k_debug_div_jitter_all(unsigned long long
 }
 
 // exp_bounded against the library's exp (tests/test_gpu_division.py)
-__global__ __launch_bounds__(256) void k_debug_exp(const double* __restrict__ x, size_t n, double* __restrict__ fast, double* __restrict__ lib) {
+__global__ __launch_bounds__(256) void k_debug_exp(int which, const double* __restrict__ x, size_t n, double* __restrict__ fast, double* __restrict__ lib) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) { fast[i] = exp_bounded(x[i]); lib[i] = exp(x[i]); }
+    if (i >= n) return;
+    if (which == 0) { fast[i] = exp_bounded(x[i]); lib[i] = exp(x[i]); }
+    else            { fast[i] = tanh_fast(x[i]);   lib[i] = tanh(x[i]); }
 }
 
 // ow_div against the compiler's division (tests/test_gpu_division.py)

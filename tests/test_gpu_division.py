@@ -109,7 +109,30 @@ def test_bounded_exp_is_the_library_exp(hiplib):
     x = np.concatenate([rng.uniform(-38.5, 32.7, 1 << 24), rng.uniform(-60.0, 60.0, 1 << 22), np.linspace(-38.5, 32.7, 100001),
                         np.array([0.0, -0.0, -1.0 / 0.026, 0.85 / 0.026, 1e-300, -1e-300, 1e-17])])
     f = np.zeros_like(x); l = np.zeros_like(x)
-    assert hiplib.ow_debug_exp(x.ctypes.data_as(C.c_void_p), x.size, f.ctypes.data_as(C.c_void_p), l.ctypes.data_as(C.c_void_p), 0) == 0
+    assert hiplib.ow_debug_unary(0, x.ctypes.data_as(C.c_void_p), x.size, f.ctypes.data_as(C.c_void_p), l.ctypes.data_as(C.c_void_p), 0) == 0
     assert _same_bits(f, l)
     ref = np.exp(x)
     assert np.max(np.abs(f - ref) / np.spacing(ref)) <= 1.0
+
+
+def test_tanh_fast_accuracy(hiplib):
+    """tanh_fast (power amp, speaker): expm1-based, against numpy's tanh over the whole domain -- tiny arguments (the power amp's
+    usual regime, where 1 - 2/(e^2x + 1) would cancel), the reduction boundaries, saturation, signs, specials."""
+    rng = np.random.default_rng(6)
+    x = np.concatenate([rng.uniform(-1.0, 1.0, 1 << 23), rng.uniform(-25.0, 25.0, 1 << 22), _rand(rng, 1 << 22, -60, 2),
+                        np.ldexp(1.0, np.arange(-1074, 12)), 0.5 * np.log(2.0) * (np.arange(-60, 61) + 0.5) / 2.0,
+                        np.array([0.0, -0.0, 19.0, 20.0, 20.0000001, 700.0, -700.0, 1e300, np.inf, -np.inf])])
+    f = np.zeros_like(x); l = np.zeros_like(x)
+    assert hiplib.ow_debug_unary(1, x.ctypes.data_as(C.c_void_p), x.size, f.ctypes.data_as(C.c_void_p), l.ctypes.data_as(C.c_void_p), 0) == 0
+    with np.errstate(all="ignore"):
+        ref = np.tanh(x.astype(np.longdouble))                                             # x87 extended precision: 64-bit significand
+        sp = np.spacing(np.abs(ref.astype(np.float64)) + (ref == 0))
+
+        def ulps(y):
+            return np.max(np.abs(y.astype(np.longdouble) - ref).astype(np.float64) / sp)
+        assert ulps(f) <= 2.0, ulps(f)
+        assert ulps(l) <= 1.0 and ulps(np.tanh(x)) <= 2.0                                  # the device library and glibc on the same yardstick
+    assert np.array_equal(np.signbit(f), np.signbit(x)) and np.all(np.abs(f) <= 1.0)
+    nan = np.array([np.nan]); fn = np.zeros(1); ln = np.zeros(1)
+    assert hiplib.ow_debug_unary(1, nan.ctypes.data_as(C.c_void_p), 1, fn.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p), 0) == 0
+    assert np.isnan(fn[0]) and np.isnan(ln[0])
