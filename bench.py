@@ -115,7 +115,7 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(seconds_audio=1.0):
+def cpu_baseline(seconds_audio=1.0, preamp_kind=0):
     """Oracle (CPU restatement, kind 'port') on the host cores: one cfg-2 instance per thread."""
     import oracle_binding as ob
     ob.lib()
@@ -123,7 +123,7 @@ def cpu_baseline(seconds_audio=1.0):
     n = int(SR * seconds_audio)
 
     def work(k, out):
-        e = ob.OracleEngine(SR)
+        e = ob.OracleEngine(SR, preamp_kind=preamp_kind)
         e.set_volume(0.5); e.set_tremolo_depth(0.5); e.set_speaker_character(0.0); e.set_mlp_enabled(True)
         for nn in NOTES:
             e.note_on(nn, instance_velocity(k))
@@ -163,6 +163,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--instances", type=int, default=int(os.environ.get("OW_BENCH_INSTANCES", "65536")), help="engine instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preamp", choices=["legacy", "melange"], default="legacy",
+                    help="legacy = the 8-node DK solver of the reference's default build (the metric's config); melange = the generated "
+                         "12-node solver of its `--features melange-preamp` build")
     ap.add_argument("--host-rate", type=float, default=48000.0,
                     help="host sample rate: 48000 = BASELINE configs[1] (the metric's config, default); 96000 = configs[2] (no oversampling)")
     args = ap.parse_args()
@@ -190,7 +193,11 @@ def main():
 
     import openwurli_amd as ow
     n_inst = args.instances
-    pool = ow.EnginePool(SR, n_inst, device=local_rank)
+    preamp_kind = 1 if args.preamp == "melange" else 0
+    if preamp_kind:                   # +~12 kflop per output sample (two states x 2 OS samples x 12-node solve)
+        FLOPS_PREAMP += 12000
+        FLOPS_PER_SAMPLE += 12000
+    pool = ow.EnginePool(SR, n_inst, device=local_rank, preamp_kind=preamp_kind)
     pool.set_sample_rate(SR)          # the plugin's initialize(): chain build + 0.6 s warm-up (not timed)
     pool.ensure_buffer_capacity(BUF)
     # volume 0.5 / tremolo depth 0.5 / speaker character 0.0 / MLP on are the engine defaults (engine.rs:221-224)
@@ -223,7 +230,7 @@ def main():
     single = None
     cpu = None
     if rank == 0:
-        one = ow.EnginePool(SR, 1, device=local_rank)
+        one = ow.EnginePool(SR, 1, device=local_rank, preamp_kind=preamp_kind)
         one.set_sample_rate(SR)
         s1 = Script(one, 1)
         for _ in range(3):
@@ -234,7 +241,7 @@ def main():
         single = 20 * BUF / (time.perf_counter() - t1)
         one.close()
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline()
+            cpu = cpu_baseline(preamp_kind=preamp_kind)
 
     if rank == 0:
         total_samples = args.steps * BUF * n_inst * world
@@ -261,7 +268,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": ("cfg2: 64-voice all-keys-sustained (1.0 s re-strike), 48 kHz host / 96 kHz chain, full chain "
-                             "(tremolo+legacy DK preamp+behavioural power amp+speaker), MLP on, buffers of 512") if SR == 48000.0 else
+                             "(tremolo+legacy DK preamp+behavioural power amp+speaker), MLP on, buffers of 512").replace("legacy DK", "melange 12-node DK" if preamp_kind else "legacy DK") if SR == 48000.0 else
                             (f"cfg3: 64-voice all-keys-sustained (1.0 s re-strike), {SR:.0f} Hz host"
                              f"{' (no oversampling)' if SR >= 88200.0 else ' / 2x chain'}, full chain, MLP on, buffers of 512"),
                 "instances_per_gpu": n_inst, "buffer": BUF, "parallelism": f"{world} x independent pools (no data-path collective)",
@@ -270,7 +277,7 @@ def main():
             "host_midi_s": script.t_midi, "render_calls_s": script.t_render, "elapsed_s": elapsed,
             "single_instance_samples_per_s": single,
             "roofline": {
-                "bound": "valu_f64", "kernel": KERNEL_OF[dom], "achieved": achieved,
+                "bound": "valu_f64", "kernel": KERNEL_OF[dom] + ("_mel" if preamp_kind and dom == "preamp" else ""), "achieved": achieved,
                 "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
                 "kernel_ms_per_step": {n: float(k) for n, k in zip(names, kms)},
                 "whole_chain_frac": FLOPS_PER_SAMPLE * value / world / 1e12 / PEAK_FP64_VALU_TFLOPS,

@@ -49,12 +49,12 @@ __device__ inline uint32_t mel_solve_nl(const double p[3], const double kk[3][3]
         const double nvt0 = PRE_DEVICE_0_N_VT;
         const double vcl = clampd(vd[0], -40.0 * nvt0, 40.0 * nvt0);
         double idev[3], jdev[3];
-        idev[0] = PRE_DEVICE_0_IS * (fast_exp(vcl / nvt0) - 1.0);
-        jdev[0] = (PRE_DEVICE_0_IS / nvt0) * fast_exp(vcl / nvt0);
-        const double e1 = fast_exp((vd[1] * 1.0) / (PRE_DEVICE_1_NF * PRE_DEVICE_1_VT));
+        idev[0] = PRE_DEVICE_0_IS * (fast_exp(OW_DIV_C(vcl, PRE_DEVICE_0_N_VT)) - 1.0);
+        jdev[0] = (PRE_DEVICE_0_IS / nvt0) * fast_exp(OW_DIV_C(vcl, PRE_DEVICE_0_N_VT));
+        const double e1 = fast_exp(OW_DIV_C(vd[1] * 1.0, PRE_DEVICE_1_NF * PRE_DEVICE_1_VT));
         idev[1] = PRE_DEVICE_1_IS * (e1 - 1.0) * 1.0;
         jdev[1] = PRE_DEVICE_1_IS / (PRE_DEVICE_1_NF * PRE_DEVICE_1_VT) * e1;
-        const double e2 = fast_exp((vd[2] * 1.0) / (PRE_DEVICE_2_NF * PRE_DEVICE_2_VT));
+        const double e2 = fast_exp(OW_DIV_C(vd[2] * 1.0, PRE_DEVICE_2_NF * PRE_DEVICE_2_VT));
         idev[2] = PRE_DEVICE_2_IS * (e2 - 1.0) * 1.0;
         jdev[2] = PRE_DEVICE_2_IS / (PRE_DEVICE_2_NF * PRE_DEVICE_2_VT) * e2;
         const double f[3] = {i_nl[0] - idev[0], i_nl[1] - idev[1], i_nl[2] - idev[2]};
@@ -91,7 +91,7 @@ __device__ inline uint32_t mel_solve_nl(const double p[3], const double kk[3][3]
                 const double pivot = a[col][col];
 #pragma unroll
                 for (int row = col + 1; row < 3; ++row) {
-                    const double factor = a[row][col] / pivot;
+                    const double factor = ow_div(a[row][col], pivot);
 #pragma unroll
                     for (int j = col + 1; j < 3; ++j) a[row][j] -= factor * a[col][j];
                     b[row] -= factor * b[col];
@@ -105,7 +105,7 @@ __device__ inline uint32_t mel_solve_nl(const double p[3], const double kk[3][3]
 #pragma unroll
                 for (int j = i + 1; j < 3; ++j) sum -= a[i][j] * b[j];
                 if (!singular && fabs(a[i][i]) < 1e-15) singular = true;
-                if (!singular) b[i] = sum / a[i][i];
+                if (!singular) b[i] = ow_div(sum, a[i][i]);
             }
         }
         if (!singular) {
@@ -119,14 +119,14 @@ __device__ inline uint32_t mel_solve_nl(const double p[3], const double kk[3][3]
             for (int q = 0; q < 3; ++q) {
                 if (fabs(dv[q]) > 1e-4) {
                     const double v_lim = pnjlim(vd[q] + dv[q], vd[q], vts[q], vcr[q]);
-                    const double ratio = fmax((v_lim - vd[q]) / dv[q], 0.01);
+                    const double ratio = fmax(ow_div(v_lim - vd[q], dv[q]), 0.01);
                     if (ratio < al[q]) { al[q] = ratio; if (ratio < 1.0) any_limited = true; }
                 }
             }
             double as = fmin(al[0], fmin(al[1], al[2]));
             if (as < 1.0) any_limited = true;
             const double max_di = fmax(fmax(fabs(b[0]), fabs(b[1])), fabs(b[2]));
-            if (max_di * as > 0.1) as = fmin(fmax(0.1 / max_di, 0.01), as);
+            if (max_di * as > 0.1) as = fmin(fmax(ow_div(0.1, max_di), 0.01), as);
 #pragma unroll
             for (int q = 0; q < 3; ++q) i_nl[q] -= as * b[q];
             bool conv = true;
@@ -288,8 +288,8 @@ __device__ __noinline__ uint32_t mel_be_fallback(const MelSt& st, double input, 
 __device__ inline double mel_process(MelSt& st, double input_in, const MelMats* __restrict__ M, const double* nz = nullptr, int nz_stride = 0) {
     const double input = isfinite(input_in) ? clampd(input_in, -100.0, 100.0) : 0.0;
     // rank-one factor of the current R_ldr (replaces the lazy rebuild_matrices of the reference)
-    const double dg = 1.0 / st.pot - M->g_nom;
-    const double c = dg / (1.0 + dg * M->s66);
+    const double dg = ow_div(1.0, st.pot) - M->g_nom;
+    const double c = ow_div(dg, 1.0 + dg * M->s66);
 #pragma unroll
     for (int i = 0; i < 12; ++i) st.v[i] = st.v[i] + 1e-25 - 1e-25;
 #pragma unroll
@@ -369,7 +369,7 @@ __device__ inline double mel_process(MelSt& st, double input_in, const MelMats* 
         for (int i = 0; i < 11; ++i) { const double a = fabs(PRE_DC_OP[i]); if (a > max_dc) max_dc = a; }
         const double thr = fma(max_dc, 0.05, 2.0);
         if (max_delta > thr) {
-            const double damp = fmax(thr / max_delta, 0.01);
+            const double damp = fmax(ow_div(thr, max_delta), 0.01);
 #pragma unroll
             for (int i = 0; i < 12; ++i) vn[i] = st.v[i] + damp * (vn[i] - st.v[i]);
 #pragma unroll
