@@ -246,8 +246,11 @@ __device__ inline void nz_stamp(double rhs[12], const double* nz, int stride) {
 
 // Backward-Euler fallback (gen_preamp.rs:3483-3572) with the never-rebuilt 48 kHz / 100 kOhm codegen tables.
 // nz != nullptr: replay of this sample's thermal stamp (:3522-3535).
-__device__ __noinline__ uint32_t mel_be_fallback(const MelSt& st, double input, double vn[12], double i_nl[3], const double* nz, int nz_stride) {
+// Inlined behind __builtin_expect (cold): out of line it pinned the caller's register budget (a callee cannot be capped) and the kernel
+// to one wavefront per SIMD.  Rolled loops: this path runs once in thousands of samples.
+__device__ inline uint32_t mel_be_fallback(const MelSt& st, double input, double vn[12], double i_nl[3], const double* nz, int nz_stride) {
     double rhs[12], vp[12], p[3];
+#pragma unroll 1
     for (int i = 0; i < 12; ++i) {
         double sum = PRE_RHS_CONST_BE[i];
         for (int j = 0; j < 12; ++j) sum += PRE_A_NEG_BE_DEFAULT[i][j] * st.v[j];
@@ -262,11 +265,13 @@ __device__ __noinline__ uint32_t mel_be_fallback(const MelSt& st, double input, 
             if (ni > 0) rhs[ni - 1] += i_n;
             if (nj > 0) rhs[nj - 1] -= i_n;
         }
+#pragma unroll 1
     for (int i = 0; i < 12; ++i) {
         double sum = 0.0;
         for (int j = 0; j < 12; ++j) sum += PRE_S_BE_DEFAULT[i][j] * rhs[j];
         vp[i] = sum;
     }
+#pragma unroll 1
     for (int i = 0; i < 3; ++i) {
         double sum = 0.0;
         for (int j = 0; j < 12; ++j) sum += PRE_N_V[i][j] * vp[j];
@@ -275,6 +280,7 @@ __device__ __noinline__ uint32_t mel_be_fallback(const MelSt& st, double input, 
     double kb[3][3];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) kb[i][j] = PRE_K_BE_DEFAULT[i][j];
     const uint32_t it = mel_solve_nl(p, kb, st.ip, st.ipp, i_nl);
+#pragma unroll 1
     for (int i = 0; i < 12; ++i) {
         double x = vp[i];
         for (int j = 0; j < 3; ++j) x += PRE_S_NI_BE_DEFAULT[i][j] * i_nl[j];
@@ -355,10 +361,18 @@ __device__ inline double mel_process(MelSt& st, double input_in, const MelMats* 
     bool ringing = false;
 #pragma unroll
     for (int i = 0; i < 11; ++i) ringing = ringing || (fabs(vn[i]) > 55.0);
-    if (nr_failed || ringing || force_be) {
+    if (__builtin_expect(nr_failed || ringing || force_be, 0)) {
         if (ringing || nr_failed) st.be_cooldown = 64u;
         st.be_fallbacks += 1u;
-        last_it = mel_be_fallback(st, input, vn, i_nl, nz, nz_stride);
+        // The out-of-line retry takes its operands by address: hand it copies, so that the solver state and the candidate solution
+        // of the common path are never address-taken (they would live in scratch / spilled registers for every sample otherwise).
+        MelSt tmp = st;
+        double vn2[12], inl2[3];
+        last_it = mel_be_fallback(tmp, input, vn2, inl2, nz, nz_stride);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) vn[i] = vn2[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) i_nl[i] = inl2[i];
     }
     {   // voltage-damp net (gen_preamp.rs:3576-3613); threshold = fma(max|DC_OP|, 0.05, 2.0), the path's one explicit mul_add
         double max_delta = 0.0;
