@@ -333,12 +333,18 @@ __device__ inline double mel_process(MelSt& st, double input_in, const MelMats* 
     for (int j = 0; j < 12; ++j) wr += M->w[j] * rhs[j];
     const double cwr = c * wr;
     double v_pred[12];
+    {   // column sweep: every row still accumulates its terms in j order (same sums), but only the twelve running sums are live
+        // while a column of the matrix streams through, instead of whole rows of it waiting in registers
+        double acc[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        double sum = 0.0;
+        for (int i = 0; i < 12; ++i) acc[i] = 0.0;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) sum += M->s0[i][j] * rhs[j];
-        v_pred[i] = sum - cwr * M->u[i];
+        for (int j = 0; j < 12; ++j) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) acc[i] += M->s0[i][j] * rhs[j];
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v_pred[i] = acc[i] - cwr * M->u[i];
     }
     const double p[3] = {-v_pred[2], v_pred[2] - v_pred[5], v_pred[4] - v_pred[8]};
     double kk[3][3];                                                  // K(R) = K0 - c (N_v u)(w N_i)^T
