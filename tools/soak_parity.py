@@ -1,0 +1,66 @@
+"""Long-run parity soak (not part of the suites): N engines play random parts for many seconds, every block compared with one CPU
+oracle engine each (output within the parity bar, voice counts equal).  Usage: python tools/soak_parity.py [seconds] [engines]
+
+Absolute floor: 5e-9.  The suites use 2e-9, four times what a one-ulp exp() perturbation moves the oracle in the 4-note scenario of
+tests/test_oracle_sensitivity.py; under dense play (up to 64 voices, volume up to 0.65, tremolo depth up to 1) the same experiment --
+oracle against its own perturbed build on THIS script -- moves quiet samples by up to 3.1e-9: the Newton stop of the preamp
+(|f| < 1e-9 V) is an absolute threshold and what reaches the output scales with volume^2 and the tremolo's gain swing."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import oracle_binding as ob
+    import openwurli_amd as ow
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    sr, length = 48000.0, 512
+    g = ow.EnginePool(sr, n); g.set_sample_rate(sr)
+    cs = [ob.OracleEngine(sr) for _ in range(n)]
+    for c in cs:
+        c.set_sample_rate(sr)
+    rng = np.random.default_rng(99)
+    for k in range(n):
+        for e in (g[k], cs[k]):
+            e.set_tremolo_depth(0.25 * k); e.set_volume(0.35 + 0.1 * k); e.set_speaker_character(0.3 * (k % 3))
+    held = [[] for _ in range(n)]
+    blocks = int(seconds * sr / length)
+    worst, t0 = 0.0, time.time()
+    for b in range(blocks):
+        for k in range(n):
+            if rng.random() < 0.08 + 0.03 * k:
+                note, vel = int(rng.integers(33, 97)), float(rng.uniform(0.2, 1.0))
+                for e in (g[k], cs[k]):
+                    e.note_on(note, vel)
+                held[k].append(note)
+            if held[k] and rng.random() < 0.07:
+                note = held[k].pop(int(rng.integers(0, len(held[k]))))
+                for e in (g[k], cs[k]):
+                    e.note_off(note)
+            if rng.random() < 0.01:
+                on = bool(rng.integers(0, 2))
+                for e in (g[k], cs[k]):
+                    e.set_sustain(on)
+            if rng.random() < 0.002:
+                d = float(rng.uniform(0.0, 1.0))
+                for e in (g[k], cs[k]):
+                    e.set_tremolo_depth(d)
+        go = g.render(length)
+        for k, c in enumerate(cs):
+            rep = ob.parity_report(go[k], c.render(length), abs_floor=ob.ABS_FLOOR_DENSE)
+            worst = max(worst, rep["worst_ratio"])
+            if rep["n_bad"] or g[k].active_voice_count() != c.active_voice_count():
+                print("MISMATCH at block", b, "engine", k, rep, g[k].active_voice_count(), c.active_voice_count())
+                sys.exit(1)
+    print("soak ok: %.0f s x %d engines, %d blocks, worst error / tolerance %.3f, %.0f s wall" % (seconds, n, blocks, worst, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
