@@ -319,6 +319,7 @@ void upload_consts(ow_pool* p, double sr, int preamp_kind) {
 // Host threads worth starting: the CPU count capped by the cgroup CPU quota (cpu.max "quota period").  A container limited
 // to 16 CPUs on a 256-thread host gets throttled for whole scheduler periods when 64 threads burst at once.
 static size_t effective_cpus() {
+    static const size_t cached = [] {
     size_t n = std::thread::hardware_concurrency();
     if (n == 0) n = 1;
     if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
@@ -330,7 +331,13 @@ static size_t effective_cpus() {
         }
         std::fclose(f);
     }
+    // one process per GPU (torchrun sets LOCAL_WORLD_SIZE): the ranks of a node share the quota, so each takes its share of the
+    // threads -- eight ranks bursting 16 threads each into a 16-CPU quota get throttled for whole scheduler periods
+    if (const char* lws = std::getenv("LOCAL_WORLD_SIZE")) { const long w = std::atol(lws); if (w > 1) n = std::max<size_t>(1, n / (size_t)w); }
+    if (const char* env = std::getenv("OW_HOST_THREADS")) { const long v = std::atol(env); if (v >= 1 && v <= 256) n = (size_t)v; }
     return n;
+    }();
+    return cached;
 }
 
 // Deal the sounding voices of engines [e0, e0+ne) into wavefront-sized blocks (see ow_kernels.h, "Packed dispatch").
