@@ -43,8 +43,11 @@ typedef struct ow_diag {
     uint64_t output_nan_resets;      /* engine.rs:450-458 */
 } ow_diag;
 
-/* Last error message of the calling thread ("" if none). */
+/* Last error message of the calling thread ("" if none).  The realtime calls return void and never fail (the reference's contract,
+ * SURVEY.md 8b): when one of them had to degrade (silence, dropped request) the reason is left here; it stays until the next
+ * error replaces it or ow_clear_error() is called. */
 const char* ow_last_error(void);
+void ow_clear_error(void);
 
 /* ---- pools ------------------------------------------------------------------------------ */
 /* n_engines >= 1 engines at `sample_rate` on HIP device `device`.  Like WurliEngine::new
@@ -54,6 +57,7 @@ ow_pool* ow_pool_new(double sample_rate, size_t n_engines, int device, int pream
 void ow_pool_free(ow_pool*);
 size_t ow_pool_size(const ow_pool*);
 ow_engine* ow_pool_engine(ow_pool*, size_t index);
+ow_pool* ow_engine_pool(ow_engine*);              /* the pool an engine belongs to (a pool of one for ow_engine_new) */
 /* WurliEngine::set_sample_rate for every engine of the pool (engine.rs:272-286): rebuilds the chain, 0.6 s warm-up. */
 int ow_pool_set_sample_rate(ow_pool*, double sample_rate);
 /* WurliEngine::reset for every engine (engine.rs:231-251). */
@@ -116,36 +120,6 @@ void ow_engine_get_diag(const ow_engine*, ow_diag* out);
 int ow_engine_slot_state(const ow_engine*, int slot);                             /* VoiceSlot.state              */
 int ow_engine_slot_note(const ow_engine*, int slot);                              /* VoiceSlot.midi_note          */
 int ow_engine_has_steal_voice_for(const ow_engine*, uint8_t note);                /* has_steal_voice_for     :627 */
-
-/* ---- host-logic test hooks ------------------------------------------------------------------ */
-/* A detached engine: the host voice-pool / MIDI state machine (engine.rs:299-374,569-602) without a pool or a device.
- * note_on / note_off / set_sustain / get_diag / slot_* work on it; the slot ops it would send to the GPU can be taken
- * out, and the post-render bookkeeping can be driven with an explicit "silent" mask.  Used by the CPU-only tests. */
-ow_engine* ow_test_engine_new(double sample_rate);
-void ow_test_engine_free(ow_engine*);
-/* Copies up to cap pending ops (type 1 = note-on, 2 = damper, 3 = move-to-steal; seed = fade length for type 3), clears the queue,
- * returns the number that were pending. */
-size_t ow_test_engine_take_ops(ow_engine*, uint8_t* type, uint8_t* slot, uint8_t* note, uint32_t* seed, double* velocity, size_t cap);
-void ow_test_engine_after_render(ow_engine*, size_t len, uint64_t silent_mask);
-uint64_t ow_test_engine_masks(const ow_engine*, int which /* 0 = slot voices, 1 = steal voices */);
-
-/* ---- diagnostics ------------------------------------------------------------------------- */
-/* Raw (pre-fade, pre-clamp) outputs of the note-on MLP (mlp_correction.rs:86-116) for n (note, velocity) pairs:
- * out[n][11].  use_mfma = 1 runs the wavefront-batched v_mfma_f64_16x16x4_f64 path that k_apply_ops uses,
- * 0 the scalar lane path (batch jobs).  Returns 0, <0 on device error. */
-int ow_debug_mlp_raw(const uint8_t* notes, const double* velocities, size_t n, double* out, int use_mfma, int device);
-/* The kernels' division routine (ow_voice_dev.h, ow_div: the compiler's IEEE f64 division sequence without the operand
- * pre-scaling that only extreme exponents need) next to the compiler's own `a / b`, element-wise on the device:
- * fast[i], ieee[i] for n operand pairs.  Returns 0, <0 on device error. */
-int ow_debug_div(const double* a, const double* b, size_t n, double* fast, double* ieee, int device);
-/* The same for the constant-divisor form (OW_DIV_C): which = 0 jitter draw 2147483647.5, 1 Twin-T V_T, 2 LED span 10.25,
- * 3 preamp V_T 0.026, 4 power-amp 0.013^2, 5 power-amp headroom 22.  a == NULL runs every numerator of the jitter draw
- * (all 2^31 integers) on the device and stores the number of quotients that differ from `a / B` in *mismatches. */
-int ow_debug_div_const(int which, const double* a, size_t n, double* fast, double* ieee, uint64_t* mismatches, int device);
-/* Element-wise, the kernels' own elementary functions next to the device library's: which = 0 the preamp's junction exponential
- * (exp without the overflow / underflow selects, for arguments inside the junction clamp) and exp(); 1 the power amp's / speaker's
- * tanh (expm1-based, <= 2 ulp) and tanh(). */
-int ow_debug_unary(int which, const double* x, size_t n, double* fast, double* lib, int device);
 
 /* ---- offline / batch ---------------------------------------------------------------------- */
 /* Voice::render_note (voice.rs:191-221): one voice, no chain, f64.  Returns the number of samples

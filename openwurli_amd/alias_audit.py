@@ -8,7 +8,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-from .binding import OwAliasAuditResult, OwError, load_library
+from .binding import OwAliasAuditResult, OwError, load_library, take_error
 
 STIMULUS_NOTE = 84                      # alias_audit.rs:28
 STIMULUS_VELOCITY = 120                 # :30
@@ -49,7 +49,7 @@ def _unpack(r):
 
 def _check(L, rc):
     if rc != 0:
-        raise OwError((L.ow_last_error() or b"").decode())
+        raise OwError(take_error(L))
 
 
 def midi_note_hz(note):                 # alias_audit.rs:284-287

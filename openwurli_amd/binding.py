@@ -69,10 +69,12 @@ WAV_NONE, WAV_ROUND, WAV_TRUNCATE = -1, 0, 1
 
 SYMBOLS = {
     "ow_last_error": (C.c_char_p, []),
+    "ow_clear_error": (None, []),
     "ow_pool_new": (_VP, [C.c_double, C.c_size_t, C.c_int, C.c_int]),
     "ow_pool_free": (None, [_VP]),
     "ow_pool_size": (C.c_size_t, [_VP]),
     "ow_pool_engine": (_VP, [_VP, C.c_size_t]),
+    "ow_engine_pool": (_VP, [_VP]),
     "ow_pool_set_sample_rate": (C.c_int, [_VP, C.c_double]),
     "ow_pool_reset": (None, [_VP]),
     "ow_pool_ensure_buffer_capacity": (None, [_VP, C.c_size_t]),
@@ -106,12 +108,6 @@ SYMBOLS = {
     "ow_engine_slot_state": (C.c_int, [_VP, C.c_int]),
     "ow_engine_slot_note": (C.c_int, [_VP, C.c_int]),
     "ow_engine_has_steal_voice_for": (C.c_int, [_VP, C.c_uint8]),
-    "ow_test_engine_new": (_VP, [C.c_double]),
-    "ow_test_engine_free": (None, [_VP]),
-    "ow_test_engine_take_ops": (C.c_size_t, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t]),
-    "ow_test_engine_after_render": (None, [_VP, C.c_size_t, C.c_uint64]),
-    "ow_test_engine_masks": (C.c_uint64, [_VP, C.c_int]),
-    "ow_debug_mlp_raw": (C.c_int, [_VP, _VP, C.c_size_t, _VP, C.c_int, C.c_int]),
     "ow_render_note": (C.c_longlong, [C.c_uint8, C.c_double, C.c_double, C.c_double, C.c_int, _VP, C.c_size_t]),
     "ow_batch_render": (C.c_longlong, [C.POINTER(OwJob), C.c_size_t, C.POINTER(OwBatchCfg), _VP, C.c_size_t, C.c_int]),
     "ow_device_alloc": (_VP, [C.c_size_t, C.c_int]),
@@ -122,11 +118,23 @@ SYMBOLS = {
                                        _VP, _VP, _VP]),
     "ow_alias_audit_analyze": (C.c_int, [_VP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, _VP, C.c_int, C.c_int, _VP]),
     "ow_alias_audit_run": (C.c_int, [_VP, _VP, C.c_size_t, C.c_int, C.c_int, _VP, _VP, C.c_size_t]),
+    "ow_smf_parse": (C.c_longlong, [_VP, C.c_size_t, C.c_int, _VP, C.c_size_t]),
+    "ow_render_midi": (C.c_longlong, [_VP, _VP, C.c_size_t, _VP, _VP, C.c_size_t, _VP]),
+}
+
+
+# include/openwurli_hip_test.h: test and debug hooks (not part of the drop-in boundary; bound for tests/ only)
+TEST_SYMBOLS = {
+    "ow_test_engine_new": (_VP, [C.c_double]),
+    "ow_test_engine_free": (None, [_VP]),
+    "ow_test_engine_take_ops": (C.c_size_t, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t]),
+    "ow_test_engine_after_render": (None, [_VP, C.c_size_t, C.c_uint64]),
+    "ow_test_engine_masks": (C.c_uint64, [_VP, C.c_int]),
+    "ow_debug_mlp_raw": (C.c_int, [_VP, _VP, C.c_size_t, _VP, C.c_int, C.c_int]),
     "ow_debug_div": (C.c_int, [_VP, _VP, C.c_size_t, _VP, _VP, C.c_int]),
     "ow_debug_div_const": (C.c_int, [C.c_int, _VP, C.c_size_t, _VP, _VP, _VP, C.c_int]),
     "ow_debug_unary": (C.c_int, [C.c_int, _VP, C.c_size_t, _VP, _VP, C.c_int]),
-    "ow_smf_parse": (C.c_longlong, [_VP, C.c_size_t, C.c_int, _VP, C.c_size_t]),
-    "ow_render_midi": (C.c_longlong, [_VP, _VP, C.c_size_t, _VP, _VP, C.c_size_t, _VP]),
+    "ow_test_inject_render_faults": (None, [_VP, C.c_int]),
 }
 
 
@@ -144,7 +152,7 @@ def load_library():
         raise OwError(f"{path} not found: build it with ./build.sh (hipcc --offload-arch=gfx950); "
                       "openwurli-hip has no CPU fallback")
     lib = C.CDLL(path)
-    for name, (res, args) in SYMBOLS.items():
+    for name, (res, args) in list(SYMBOLS.items()) + list(TEST_SYMBOLS.items()):
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
@@ -156,3 +164,21 @@ def last_error(lib=None):
     lib = lib or load_library()
     msg = lib.ow_last_error()
     return msg.decode() if msg else ""
+
+
+def take_error(lib=None):
+    """The recorded error message, cleared (so that a later raise_if_error does not report it again)."""
+    lib = lib or load_library()
+    msg = last_error(lib)
+    lib.ow_clear_error()
+    return msg
+
+
+def raise_if_error(lib=None):
+    """The realtime C entry points return void and degrade to silence; the Python mirror turns the recorded reason into an exception
+    (the block it returns alongside is the silence the C contract promises)."""
+    lib = lib or load_library()
+    msg = last_error(lib)
+    if msg:
+        lib.ow_clear_error()
+        raise OwError(msg)

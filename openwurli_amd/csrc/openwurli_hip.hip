@@ -4,6 +4,7 @@
 // everything that touches audio samples runs in the gfx950 kernels of ow_kernels.h.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -15,6 +16,7 @@
 #include <vector>
 
 #include "../../include/openwurli_hip.h"
+#include "../../include/openwurli_hip_test.h"
 #include "ow_consts_host.hpp"
 #include "ow_kernels.h"
 #include "ow_job_kernels.h"
@@ -25,6 +27,7 @@
 #include "ow_audit.h"
 #include "ow_midi_kernels.h"
 #include "ow_chain_wide.h"
+#include <condition_variable>
 #include <map>
 #include <mutex>
 
@@ -65,6 +68,77 @@ struct StreamOwner {
     hipStream_t s = nullptr;
     ~StreamOwner() { if (s) hipStreamDestroy(s); }
 };
+
+// Persistent host worker threads.  The realtime entry points (ow_pool_render, ow_pool_midi) must not allocate once capacity is
+// ensured (nih-plug's assert_process_allocs; engine.rs:288-297), and starting a std::thread allocates its state
+// block and a stack: big pools therefore cut their per-engine host work into slices that run on these threads, started once
+// per process and parked on a condition variable in between.  run() hands out slice indices from an atomic counter; the
+// caller works too.  No std::function, no heap: the job is a function pointer + context pointer.
+class Workers {
+  public:
+    static Workers& get() { static Workers w; return w; }
+    // fn(ctx, t) for t in [0, T); returns when all slices are done.  One dispatch at a time (callers of different pools serialise).
+    void run(size_t T, void (*fn)(void*, size_t), void* ctx) {
+        if (T <= 1 || th_.empty()) { for (size_t t = 0; t < T; ++t) fn(ctx, t); return; }
+        std::lock_guard<std::mutex> one(dispatch_mu_);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = fn; ctx_ = ctx; total_ = T; next_.store(0); done_ = 0; ++gen_;
+        }
+        cv_.notify_all();
+        size_t mine = 0;
+        for (size_t t; (t = next_.fetch_add(1)) < T; ++mine) fn(ctx, t);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_ += mine;
+        cv_done_.wait(lk, [&] { return done_ == total_ && active_ == 0; });
+        fn_ = nullptr;
+    }
+    template <class F> void each(size_t T, F& f) { run(T, [](void* c, size_t t) { (*static_cast<F*>(c))(t); }, &f); }
+    size_t threads() const { return th_.size() + 1; }
+
+  private:
+    Workers() {
+        size_t n = host_threads();
+        for (size_t i = 1; i < n; ++i) th_.emplace_back([this] { loop(); });
+    }
+    ~Workers() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    static size_t host_threads();
+    void loop() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+            if (stop_) return;
+            seen = gen_;
+            void (*fn)(void*, size_t) = fn_;
+            void* ctx = ctx_;
+            const size_t T = total_;
+            if (!fn) continue;
+            ++active_;
+            lk.unlock();
+            size_t mine = 0;
+            for (size_t t; (t = next_.fetch_add(1)) < T; ++mine) fn(ctx, t);
+            lk.lock();
+            done_ += mine;
+            --active_;
+            if (done_ == total_ && active_ == 0) cv_done_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_, dispatch_mu_;
+    std::condition_variable cv_, cv_done_;
+    void (*fn_)(void*, size_t) = nullptr;
+    void* ctx_ = nullptr;
+    size_t total_ = 0, done_ = 0, active_ = 0;
+    std::atomic<size_t> next_{0};
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+#define OW_MAX_SLICES 64   // upper bound of the slices one dispatch is cut into (scratch arrays live on the stack)
 
 struct Slot {  // VoiceSlot, engine.rs:39-62 (the Voice objects themselves live in HBM); state and note live in ow_engine's
                // st_mask[] / midi_of[] so the per-event searches are mask operations, not 64-slot walks
@@ -178,6 +252,11 @@ struct ow_pool {
     std::vector<ow_engine*> engines;
     std::vector<uint8_t> dirty;       // per engine: host state changed since the args were last uploaded
     bool args_stale = true;           // device args still hold one-shot fields of the previous block
+    double* d_snap = nullptr;         // [3][I] smoother targets (depth, speaker, volume) handed to k_chain_init on reset
+    double* h_snap = nullptr;         // pinned
+    int inject_faults = 0;            // test hook (openwurli_hip_test.h): the next n renders fail before their first launch
+    double hostprof_acc[4] = {0, 0, 0, 0};
+    long hostprof_cnt = 0;
     bool profiling = false;
     hipEvent_t ev[8] = {};
     float last_ms[5] = {0, 0, 0, 0, 0};
@@ -216,11 +295,12 @@ void alloc_stream_buffers(ow_pool* p, size_t cap) {
     p->Lcap = cap;
 }
 
+// Op staging (pinned + device).  pool_create sizes it for a whole-keyboard re-strike of EVERY engine in one block (damper +
+// move-to-steal + note-on per key = 192 ops of 16 B per engine), so ow_pool_render never gets here with n > ops_cap unless more
+// than that was queued between two renders -- the only case in which a render allocates (like the reference's buffer auto-grow).
 void ensure_ops_capacity(ow_pool* p, size_t n) {
     if (n <= p->ops_cap) return;
-    // A re-strike queues 3 ops per key (damper, move-to-steal, note-on) where the first strike queued 1: growing to exactly n would
-    // re-allocate ~200 MB of pinned + device memory (tens of ms) on the first re-strike of a big pool, so leave that headroom at once.
-    size_t cap = std::max<size_t>(3 * n, std::max<size_t>(p->ops_cap * 2, 256));
+    size_t cap = std::max<size_t>(n, std::max<size_t>(p->ops_cap * 2, 256));
     if (p->d_ops) hipFree(p->d_ops);
     if (p->h_ops) hipHostFree(p->h_ops);
     p->d_ops = nullptr; p->h_ops = nullptr; p->ops_cap = 0;   // a failed allocation below must not leave freed pointers behind
@@ -283,12 +363,23 @@ void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<do
     invalidate_spec(p);
     HIP_OK(hipStreamSynchronize(p->stream));
     const int I = (int)p->I;
+    if (mode == INIT_RESET) {
+        // reset() snaps every smoother to ITS target (engine.rs:245-249), and LinearSmoother::set_target stores the target at once
+        // (engine.rs:86-99) -- also for a setter call the device has not seen yet because no block was rendered since.  Hand the
+        // host targets to the kernel; the retarget requests themselves are dropped by engine_host_reset.
+        for (int k = 0; k < ne; ++k) {
+            const ow_engine* en = p->engines[e0 + k];
+            p->h_snap[0 * p->I + e0 + k] = en->depth.target; p->h_snap[1 * p->I + e0 + k] = en->spk.target; p->h_snap[2 * p->I + e0 + k] = en->volume.target;
+        }
+        for (int r = 0; r < 3; ++r)
+            HIP_OK(hipMemcpyAsync(p->d_snap + (size_t)r * p->I + e0, p->h_snap + (size_t)r * p->I + e0, sizeof(double) * ne, hipMemcpyHostToDevice, p->stream));
+    }
     // depth0: one value per engine of the range (Tremolo::new(depth)); the kernel takes a scalar, so group equal values
     int i = 0;
     while (i < ne) {
         int j = i + 1;
         while (j < ne && depth0[j] == depth0[i]) ++j;
-        owdev::k_chain_init<<<dim3((j - i + 63) / 64), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, I, e0 + i, j - i, mode, depth0[i]);
+        owdev::k_chain_init<<<dim3((j - i + 63) / 64), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, p->d_snap, I, e0 + i, j - i, mode, depth0[i]);
         i = j;
     }
     if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)   // DkPreamp::new / reset of the melange adapter: settled state at the chain rate
@@ -339,6 +430,7 @@ static size_t effective_cpus() {
     }();
     return cached;
 }
+size_t Workers::host_threads() { return std::min<size_t>(effective_cpus(), OW_MAX_SLICES); }
 
 // Deal the sounding voices of engines [e0, e0+ne) into wavefront-sized blocks (see ow_kernels.h, "Packed dispatch").
 // general = engines whose status after the previous block reported a transient phase, or that receive ops in this block (a note-on
@@ -350,7 +442,7 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
     const size_t T = ne >= 16384 ? std::min<size_t>(effective_cpus(), 32) : 1;
     const int per = (int)((ne + T - 1) / T);
     struct Fill { uint32_t s = 0, g = 0, t = 0; };
-    std::vector<Fill> size(T), start(T + 1);
+    Fill size[OW_MAX_SLICES], start[OW_MAX_SLICES + 1];      // T <= 32: on the stack, no allocation in the render path
     auto pack = [&](size_t t, uint32_t* S, uint32_t* G, uint32_t* Tl, Fill& f) {   // S == nullptr: count only
         auto pad = [](uint32_t* a, uint32_t& n) { while (n & 63u) { if (a) a[n] = 0xFFFFFFFFu; ++n; } };
         auto put = [&](uint32_t* a, uint32_t& n, uint32_t e, uint64_t mask, bool own_block) {
@@ -371,18 +463,14 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
         }
         pad(S, f.s); pad(G, f.g); pad(Tl, f.t);
     };
-    auto run = [&](auto&& fn) {
-        if (T == 1) { fn((size_t)0); return; }
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < T; ++t) th.emplace_back([&fn, t] { fn(t); });
-        for (auto& x : th) x.join();
-    };
-    run([&](size_t t) { pack(t, nullptr, nullptr, nullptr, size[t]); });
+    auto pass1 = [&](size_t t) { pack(t, nullptr, nullptr, nullptr, size[t]); };
+    Workers::get().each(T, pass1);
     for (size_t t = 0; t < T; ++t) { start[t + 1].s = start[t].s + size[t].s; start[t + 1].g = start[t].g + size[t].g; start[t + 1].t = start[t].t + size[t].t; }
-    run([&](size_t t) {
+    auto pass2 = [&](size_t t) {
         Fill f;   // slice-local counters: the slice regions start on block boundaries, so padding decisions match pass 1
         pack(t, p->vl_steady.h + start[t].s, p->vl_general.h + start[t].g, p->vl_steal.h + start[t].t, f);
-    });
+    };
+    Workers::get().each(T, pass2);
     const uint32_t fs = start[T].s, fg = start[T].g, fl = start[T].t;
     p->vl_steady.n_blocks = fs / 64; p->vl_general.n_blocks = fg / 64; p->vl_steal.n_blocks = fl / 64;
     hipStream_t st = p->stream;
@@ -442,8 +530,8 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
     for (int k = 0; k < ne; ++k) n_dirty += p->dirty[e0 + k];     // dirty[] holds 0/1
     size_t T = (n_dirty >= 4096) ? std::min<size_t>(effective_cpus(), 32) : 1;
     const int per = (int)((ne + T - 1) / T);
-    std::vector<size_t> cnt(T + 1, 0);
-    std::vector<uint8_t> dirty_t(T, 0);
+    size_t cnt[OW_MAX_SLICES + 1] = {0};
+    uint8_t dirty_t[OW_MAX_SLICES] = {0};
     auto count_slice = [&](size_t t) {
         size_t c = 0; uint8_t d = 0;
         const int k1 = std::min(ne, (int)(t + 1) * per);
@@ -454,13 +542,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
         }
         cnt[t + 1] = c; dirty_t[t] = d;
     };
-    auto run_slices = [&](auto&& fn) {
-        if (T == 1) { fn((size_t)0); return; }
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < T; ++t) th.emplace_back([&fn, t] { fn(t); });
-        for (auto& x : th) x.join();
-    };
-    run_slices(count_slice);
+    Workers::get().each(T, count_slice);
     bool any_dirty = false;
     for (size_t t = 0; t < T; ++t) { any_dirty = any_dirty || dirty_t[t]; cnt[t + 1] += cnt[t]; }
     const size_t n_ops = cnt[T];
@@ -491,7 +573,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
                 p->dirty[e0 + k] = 0;
             }
         };
-        run_slices(pack_slice);
+        Workers::get().each(T, pack_slice);
     }
     bool any_main = false, any_steal = false;
     for (int k = 0; k < ne; ++k) { any_main |= p->h_args[e0 + k].main_mask != 0; any_steal |= p->h_args[e0 + k].steal_mask != 0; }
@@ -580,7 +662,7 @@ void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
     // update (40 ms on one thread for 65 536 engines), so large ranges are cut into slices like the MIDI and op packing are
     const size_t T = ne >= 16384 ? std::min<size_t>(effective_cpus(), 32) : 1;
     const int per = (int)((ne + T - 1) / T);
-    std::vector<uint8_t> lists_changed(T, 0), misdispatch(T, 0);
+    uint8_t lists_changed[OW_MAX_SLICES] = {0}, misdispatch[OW_MAX_SLICES] = {0};
     auto slice = [&](size_t t) {
         const int k1 = std::min(ne, (int)(t + 1) * per);
         uint8_t changed = 0, bad = 0;
@@ -606,9 +688,7 @@ void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
     if (T == 1 || !busy) {
         for (size_t t = 0; t < T; ++t) slice(t);
     } else {
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < T; ++t) th.emplace_back([&slice, t] { slice(t); });
-        for (auto& x : th) x.join();
+        Workers::get().each(T, slice);
     }
     for (size_t t = 0; t < T; ++t) {
         if (lists_changed[t]) p->lists_valid = false;
@@ -702,6 +782,10 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
         HIP_OK(hipHostMalloc(&vl->h, sizeof(uint32_t) * 64 * n_engines));
     }
     p->transient.assign(n_engines, 0);
+    HIP_OK(hipMalloc(&p->d_snap, sizeof(double) * 3 * n_engines));
+    HIP_OK(hipHostMalloc(&p->h_snap, sizeof(double) * 3 * n_engines));
+    ensure_ops_capacity(p, (size_t)3 * OW_MAX_VOICES * n_engines);   // a whole-keyboard re-strike of every engine: no allocation in render
+    Workers::get();                                                  // start the host worker threads now, not inside the first render
     HIP_OK(hipMalloc(&p->d_op_engines, sizeof(uint32_t) * n_engines));
     HIP_OK(hipHostMalloc(&p->h_op_engines, sizeof(uint32_t) * n_engines));
     std::memset(p->h_args, 0, sizeof(OwEngineArgs) * n_engines);
@@ -761,6 +845,8 @@ void pool_destroy(ow_pool* p) {
     for (ow_pool::VoiceList* vl : {&p->vl_steady, &p->vl_general, &p->vl_steal}) { if (vl->d) hipFree(vl->d); if (vl->h) hipHostFree(vl->h); }
     if (p->d_op_engines) hipFree(p->d_op_engines);
     if (p->h_op_engines) hipHostFree(p->h_op_engines);
+    if (p->d_snap) hipFree(p->d_snap);
+    if (p->h_snap) hipHostFree(p->h_snap);
     hipHostFree(p->h_args); hipHostFree(p->h_eout);
     for (auto& e : p->ev) if (e) hipEventDestroy(e);
     for (auto& e : p->ev_trem) if (e) hipEventDestroy(e);
@@ -772,8 +858,9 @@ void pool_destroy(ow_pool* p) {
 }
 
 template <typename F>
-void guarded(const char* what, F&& f) {  // realtime entry points never fail: record the error, degrade
-    try { f(); } catch (const std::exception& ex) { set_err(std::string(what) + ": " + ex.what()); std::fprintf(stderr, "openwurli-hip: %s: %s\n", what, ex.what()); }
+bool guarded(const char* what, F&& f) {  // realtime entry points never fail: record the error, degrade; false = it failed
+    try { f(); return true; }
+    catch (const std::exception& ex) { set_err(std::string(what) + ": " + ex.what()); std::fprintf(stderr, "openwurli-hip: %s: %s\n", what, ex.what()); return false; }
 }
 
 }  // namespace
@@ -781,6 +868,7 @@ void guarded(const char* what, F&& f) {  // realtime entry points never fail: re
 extern "C" {
 
 const char* ow_last_error(void) { return g_err.c_str(); }
+void ow_clear_error(void) { g_err.clear(); }
 
 ow_pool* ow_pool_new(double sample_rate, size_t n_engines, int device, int preamp_kind) {
     try { return pool_create(sample_rate, n_engines, device, preamp_kind); }
@@ -789,6 +877,7 @@ ow_pool* ow_pool_new(double sample_rate, size_t n_engines, int device, int pream
 void ow_pool_free(ow_pool* p) { pool_destroy(p); }
 size_t ow_pool_size(const ow_pool* p) { return p ? p->I : 0; }
 ow_engine* ow_pool_engine(ow_pool* p, size_t i) { return (p && i < p->I) ? p->engines[i] : nullptr; }
+ow_pool* ow_engine_pool(ow_engine* e) { return e ? e->pool : nullptr; }
 void* ow_pool_stream(ow_pool* p) { return p ? (void*)p->stream : nullptr; }
 void ow_pool_set_profiling(ow_pool* p, int on) { if (p) p->profiling = on != 0; }
 void ow_pool_last_kernel_ms(const ow_pool* p, float ms[5]) { for (int i = 0; i < 5; ++i) ms[i] = p ? p->last_ms[i] : 0.f; }
@@ -833,11 +922,11 @@ void ow_pool_ensure_buffer_capacity(ow_pool* p, size_t n) {
 
 void ow_pool_render(ow_pool* p, float* out_host, size_t out_stride, size_t len) {
     if (!p || len == 0) return;
-    guarded("ow_pool_render", [&] {
+    const bool ok = guarded("ow_pool_render", [&] {
         HIP_OK(hipSetDevice(p->device));
+        if (p->inject_faults > 0) { --p->inject_faults; throw std::runtime_error("injected fault (ow_test_inject_render_faults)"); }
         if (len > p->Lcap) { HIP_OK(hipStreamSynchronize(p->stream)); alloc_stream_buffers(p, len); }  // auto-grow, engine.rs:430
         static const bool hostprof = std::getenv("OW_HOST_PROFILE") != nullptr;
-        static double acc[4] = {0, 0, 0, 0}; static long cnt = 0;
         auto t0 = std::chrono::steady_clock::now();
         render_range(p, 0, (int)p->I, len, true);
         if (out_host)
@@ -852,12 +941,20 @@ void ow_pool_render(ow_pool* p, float* out_host, size_t out_stride, size_t len) 
         auto t4 = std::chrono::steady_clock::now();
         if (hostprof) {
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            double* acc = p->hostprof_acc;
             acc[0] += ms(t0, t1); acc[1] += ms(t1, t2); acc[2] += ms(t2, t3); acc[3] += ms(t3, t4);
-            if (++cnt % 50 == 0) { std::fprintf(stderr, "hostprof I=%zu: launch %.3f wait %.3f post %.3f profile %.3f ms (mean of 50)\n", p->I, acc[0] / 50, acc[1] / 50, acc[2] / 50, acc[3] / 50); acc[0] = acc[1] = acc[2] = acc[3] = 0; }
+            if (++p->hostprof_cnt % 50 == 0) { std::fprintf(stderr, "hostprof I=%zu: launch %.3f wait %.3f post %.3f profile %.3f ms (mean of 50)\n", p->I, acc[0] / 50, acc[1] / 50, acc[2] / 50, acc[3] / 50); acc[0] = acc[1] = acc[2] = acc[3] = 0; }
         }
         p->last_len = len;
     });
-    if (!g_err.empty() && out_host) { /* degrade to silence on device failure */ }
+    if (!ok) {
+        // "never fails, degrades to silence" (engine.rs:450-458 does the same for numeric failure): every row of the
+        // caller's block is written.  Drain the stream first so that an output copy already queued cannot land after the zeros.
+        hipStreamSynchronize(p->stream);
+        if (out_host && out_stride >= len)
+            for (size_t e = 0; e < p->I; ++e) std::memset(out_host + e * out_stride, 0, len * sizeof(float));
+        if (p->d_out && len <= p->Lcap) hipMemset2D(p->d_out, p->Lcap * sizeof(float), 0, len * sizeof(float), p->I);   // the HBM copy of the block too
+    }
 }
 
 const float* ow_pool_device_output(const ow_pool* p, size_t* stride) {
@@ -1040,9 +1137,7 @@ void ow_engine_set_noise_seed(ow_engine* e, uint64_t seed) {
 void ow_engine_render(ow_engine* e, float* out, size_t len) {
     if (!e || !out || len == 0) return;
     if (e->pool->I != 1) { set_err("ow_engine_render: engine belongs to a multi-engine pool; use ow_pool_render"); std::memset(out, 0, len * sizeof(float)); return; }
-    g_err.clear();
-    ow_pool_render(e->pool, out, len, len);
-    if (!g_err.empty()) std::memset(out, 0, len * sizeof(float));
+    ow_pool_render(e->pool, out, len, len);      // writes silence itself when the render fails
 }
 
 void ow_engine_get_diag(const ow_engine* e, ow_diag* d) {
@@ -1090,34 +1185,30 @@ static void midi_apply_one(ow_pool* p, const ow_midi_event& ev) {
 
 void ow_pool_midi(ow_pool* p, const ow_midi_event* ev, size_t n) {
     if (!p || !ev) return;
-    // Engines are independent state machines: large event lists are applied by several host threads, each owning a
-    // contiguous range of engines and walking the list in array order (per-engine order is what matters).
-    size_t T = std::min<size_t>(effective_cpus(), 64);
-    if (const char* env = std::getenv("OW_MIDI_THREADS")) { const long v = std::atol(env); if (v >= 1 && v <= 256) T = (size_t)v; }
+    // Engines are independent state machines: large event lists are applied by the persistent host workers, each slice owning a
+    // contiguous range of engines and walking the list in array order (per-engine order is what matters).  No allocation here.
+    size_t T = std::min<size_t>(effective_cpus(), OW_MAX_SLICES);
+    if (const char* env = std::getenv("OW_MIDI_THREADS")) { const long v = std::atol(env); if (v >= 1 && v <= OW_MAX_SLICES) T = (size_t)v; }
     if (n < 4096 || p->I < 2 * T) T = 1;
     if (T == 1) {
         for (size_t i = 0; i < n; ++i) if (ev[i].engine < p->I) midi_apply_one(p, ev[i]);
         return;
     }
     // Fast path: a list grouped by engine (non-decreasing engine index, the usual layout of a batched script) is cut into T
-    // contiguous slices at engine boundaries, so each thread touches only its own events.  The grouping is verified first, in
-    // parallel; an ungrouped list falls back to every thread scanning the whole list for its engine range.
-    std::vector<std::thread> th;
-    std::vector<uint8_t> ok(T, 1);
-    for (size_t t = 0; t < T; ++t) {
+    // contiguous slices at engine boundaries, so each slice touches only its own events.  The grouping is verified first, in
+    // parallel; an ungrouped list falls back to every slice scanning the whole list for its engine range.
+    uint8_t ok[OW_MAX_SLICES];
+    auto verify = [&](size_t t) {
         const size_t i0 = std::max<size_t>(n * t / T, 1), i1 = n * (t + 1) / T;
-        th.emplace_back([=, &ok] {
-            uint8_t good = 1;
-            for (size_t i = i0; i < i1; ++i) good &= (uint8_t)(ev[i].engine >= ev[i - 1].engine);
-            ok[t] = good;
-        });
-    }
-    for (auto& x : th) x.join();
-    th.clear();
+        uint8_t good = 1;
+        for (size_t i = i0; i < i1; ++i) good &= (uint8_t)(ev[i].engine >= ev[i - 1].engine);
+        ok[t] = good;
+    };
+    Workers::get().each(T, verify);
     bool grouped = true;
     for (size_t t = 0; t < T; ++t) grouped = grouped && ok[t];
     if (grouped) {
-        std::vector<size_t> cut(T + 1);
+        size_t cut[OW_MAX_SLICES + 1];
         cut[0] = 0; cut[T] = n;
         for (size_t t = 1; t < T; ++t) {   // first event of the engine that owns position n*t/T belongs to the slice on the right
             size_t i = n * t / T;
@@ -1125,23 +1216,18 @@ void ow_pool_midi(ow_pool* p, const ow_midi_event* ev, size_t n) {
             i = (size_t)(std::lower_bound(ev, ev + i, eng, [](const ow_midi_event& a, uint32_t b) { return a.engine < b; }) - ev);
             cut[t] = std::max(i, cut[t - 1]);
         }
-        for (size_t t = 0; t < T; ++t) {
-            const size_t i0 = cut[t], i1 = cut[t + 1];
-            if (i0 >= i1) continue;
-            th.emplace_back([=] {
-                for (size_t i = i0; i < i1; ++i) if (ev[i].engine < p->I) midi_apply_one(p, ev[i]);
-            });
-        }
+        auto apply = [&](size_t t) {
+            for (size_t i = cut[t]; i < cut[t + 1]; ++i) if (ev[i].engine < p->I) midi_apply_one(p, ev[i]);
+        };
+        Workers::get().each(T, apply);
     } else {
         const size_t per = (p->I + T - 1) / T;
-        for (size_t t = 0; t < T; ++t) {
+        auto apply = [&](size_t t) {
             const uint32_t lo = (uint32_t)(t * per), hi = (uint32_t)std::min(p->I, (t + 1) * per);
-            th.emplace_back([=] {
-                for (size_t i = 0; i < n; ++i) if (ev[i].engine >= lo && ev[i].engine < hi) midi_apply_one(p, ev[i]);
-            });
-        }
+            for (size_t i = 0; i < n; ++i) if (ev[i].engine >= lo && ev[i].engine < hi) midi_apply_one(p, ev[i]);
+        };
+        Workers::get().each(T, apply);
     }
-    for (auto& x : th) x.join();
 }
 
 // ---- host-logic test hooks (no device) -----------------------------------------------------------
@@ -1169,6 +1255,7 @@ void ow_test_engine_after_render(ow_engine* e, size_t len, uint64_t silent_mask)
     engine_post_render(e, (uint32_t)std::min<size_t>(len, 0xFFFFFFFFull), o);
 }
 uint64_t ow_test_engine_masks(const ow_engine* e, int which) { return e ? (which ? e->steal_mask : e->main_mask) : 0; }
+void ow_test_inject_render_faults(ow_pool* p, int n_renders) { if (p) p->inject_faults = n_renders > 0 ? n_renders : 0; }
 
 // ---- diagnostics ---------------------------------------------------------------------------------
 int ow_debug_mlp_raw(const uint8_t* notes, const double* velocities, size_t n, double* out, int use_mfma, int device) {
@@ -1251,7 +1338,8 @@ int ow_debug_unary(int which, const double* x, size_t n, double* fast, double* l
 // ---- offline ------------------------------------------------------------------------------------
 long long ow_render_note(uint8_t midi, double velocity, double dur_s, double sample_rate, int device, double* out, size_t cap) {
     try {
-        ow_pool* p = pool_create(sample_rate, 1, device, OW_PREAMP_LEGACY8);
+        struct PoolGuard { ow_pool* p; ~PoolGuard() { pool_destroy(p); } } guard{pool_create(sample_rate, 1, device, OW_PREAMP_LEGACY8)};
+        ow_pool* p = guard.p;
         ow_engine* e = p->engines[0];
         // Voice::render_note: seed = midi * 2654435761, MLP off, no note clamping beyond the table range (voice.rs:206-207)
         const uint8_t note = std::min<uint8_t>(std::max<uint8_t>(midi, OW_MIDI_LO), OW_MIDI_HI);
@@ -1271,8 +1359,7 @@ long long ow_render_note(uint8_t midi, double velocity, double dur_s, double sam
             for (size_t i = 0; i < len && done + i < cap; ++i) out[done + i] = chunk[i];
             done += len;
         }
-        pool_destroy(p);
-        return (long long)n;
+        return (long long)n;      // the note's length; min(n, cap) samples were written (header contract)
     } catch (const std::exception& ex) { set_err(std::string("ow_render_note: ") + ex.what()); return -1; }
 }
 

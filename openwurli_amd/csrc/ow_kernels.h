@@ -476,7 +476,10 @@ OW_DEV void dk_store(const DkSt& s, double* __restrict__ cs, int I, int e, int b
 //   mode 0  reset (engine.rs:231-251): preamp.reset() at the current R_ldr, tremolo rebuilt, oversampler and
 //           speaker state cleared, smoothers snapped to their targets
 // The Twin-T oscillator is left at CircuitState DC_OP; k_trem_settle then runs the 50 + 2*sr settle.
-__global__ __launch_bounds__(64) void k_chain_init(const OwConsts* __restrict__ K, double* __restrict__ cs, int I, int e0, int ne, int mode, double depth0) {
+// snap (mode 0): [3][I] host-side smoother targets (depth, speaker, volume): LinearSmoother::set_target stores its target when it is
+// called (engine.rs:86-99), the device only learns it with the next block, and reset() must snap to the NEW target (engine.rs:245-249).
+__global__ __launch_bounds__(64) void k_chain_init(const OwConsts* __restrict__ K, double* __restrict__ cs, const double* __restrict__ snap, int I, int e0, int ne,
+                                                   int mode, double depth0) {
     const int e = e0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= e0 + ne) return;
     const double dc[7] = {4.26480458363572357e0, 0.0, 1.24642300965575981e0, 2.75561285973736503e0, 6.66518981651571640e-1, 1.5e1, -2.28408414614134341e-3};
@@ -516,7 +519,10 @@ __global__ __launch_bounds__(64) void k_chain_init(const OwConsts* __restrict__ 
         CSF(CS_SPK_CHAR) = sp.character; CSF(CS_SPK_A2) = sp.a2; CSF(CS_SPK_A3) = sp.a3; CSF(CS_SPK_TC) = sp.tc; CSF(CS_SPK_TS) = 0.0;
     } else {
         r_ldr = CSF(CS_P_RLDR);
-        for (int f = CS_SM_DEPTH; f <= CS_SM_VOL; f += 4) { CSF(f) = CSF(f + 1); CSF(f + 2) = 0.0; CSF(f + 3) = bitsd(0ull); }  // snap_to(target)
+        for (int f = CS_SM_DEPTH, r = 0; f <= CS_SM_VOL; f += 4, ++r) {   // snap_to(target)
+            const double t = snap[(size_t)r * I + e];
+            CSF(f) = t; CSF(f + 1) = t; CSF(f + 2) = 0.0; CSF(f + 3) = bitsd(0ull);
+        }
         CSF(CS_SPK_HPF + 5) = 0.0; CSF(CS_SPK_HPF + 6) = 0.0; CSF(CS_SPK_LPF + 5) = 0.0; CSF(CS_SPK_LPF + 6) = 0.0;
         CSF(CS_SPK_TS) = 0.0;
     }

@@ -63,9 +63,11 @@ class _EngineHandle:
 
     def reset(self):
         self._lib.ow_engine_reset(self._h)
+        binding.raise_if_error(self._lib)
 
     def warm_up(self):
         self._lib.ow_engine_warm_up(self._h)
+        binding.raise_if_error(self._lib)
 
     # ---- introspection (engine.rs:606-675)
     def diag(self):
@@ -111,7 +113,7 @@ class WurliEngine(_EngineHandle):
         lib = binding.load_library()
         h = lib.ow_engine_new(float(sample_rate), int(device), int(preamp_kind))
         if not h:
-            raise OwError(binding.last_error(lib))
+            raise OwError(binding.take_error(lib))
         super().__init__(lib, h)
 
     def close(self):
@@ -127,9 +129,11 @@ class WurliEngine(_EngineHandle):
 
     def set_sample_rate(self, sr):
         self._lib.ow_engine_set_sample_rate(self._h, float(sr))
+        binding.raise_if_error(self._lib)
 
     def ensure_buffer_capacity(self, n):
         self._lib.ow_engine_ensure_buffer_capacity(self._h, int(n))
+        binding.raise_if_error(self._lib)
 
     def render(self, out):
         """``engine.render(&mut out)``: ``out`` is a writable 1-D float32 numpy array, or a length."""
@@ -137,6 +141,7 @@ class WurliEngine(_EngineHandle):
             out = np.zeros(int(out), dtype=np.float32)
         assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"]
         self._lib.ow_engine_render(self._h, out.ctypes.data_as(C.c_void_p), out.size)
+        binding.raise_if_error(self._lib)          # `out` holds silence in that case (the C contract)
         return out
 
 
@@ -147,7 +152,7 @@ class EnginePool:
         self._lib = binding.load_library()
         h = self._lib.ow_pool_new(float(sample_rate), int(n_engines), int(device), int(preamp_kind))
         if not h:
-            raise OwError(binding.last_error(self._lib))
+            raise OwError(binding.take_error(self._lib))
         self._h = C.c_void_p(h)
         self.n = int(n_engines)
         self._engines = {}
@@ -173,21 +178,25 @@ class EnginePool:
 
     def set_sample_rate(self, sr):
         if self._lib.ow_pool_set_sample_rate(self._h, float(sr)) != 0:
-            raise OwError(binding.last_error(self._lib))
+            raise OwError(binding.take_error(self._lib))
 
     def reset(self):
         self._lib.ow_pool_reset(self._h)
+        binding.raise_if_error(self._lib)
 
     def ensure_buffer_capacity(self, n):
         self._lib.ow_pool_ensure_buffer_capacity(self._h, int(n))
+        binding.raise_if_error(self._lib)
 
     def render(self, length, to_host=True):
         """Render ``length`` samples on every engine; returns float32 [n, length] (or None if left in HBM)."""
         if to_host:
             out = np.zeros((self.n, int(length)), dtype=np.float32)
             self._lib.ow_pool_render(self._h, out.ctypes.data_as(C.c_void_p), int(length), int(length))
+            binding.raise_if_error(self._lib)
             return out
         self._lib.ow_pool_render(self._h, None, 0, int(length))
+        binding.raise_if_error(self._lib)
         return None
 
     def midi(self, events):
@@ -198,20 +207,20 @@ class EnginePool:
     def voice_sum(self, length):
         out = np.zeros((self.n, int(length)), dtype=np.float64)
         if self._lib.ow_pool_read_voice_sum(self._h, out.ctypes.data_as(C.c_void_p), int(length), int(length)) != 0:
-            raise OwError(binding.last_error(self._lib))
+            raise OwError(binding.take_error(self._lib))
         return out
 
     def tremolo_r(self, n_os):
         """CdS-cell resistance stream of the last block, float64 [n, n_os]."""
         out = np.zeros((self.n, int(n_os)), dtype=np.float64)
         if self._lib.ow_pool_read_tremolo_r(self._h, out.ctypes.data_as(C.c_void_p), int(n_os), int(n_os)) != 0:
-            raise OwError(binding.last_error(self._lib))
+            raise OwError(binding.take_error(self._lib))
         return out
 
     def preamp_out(self, n_os):
         out = np.zeros((self.n, int(n_os)), dtype=np.float64)
         if self._lib.ow_pool_read_preamp_out(self._h, out.ctypes.data_as(C.c_void_p), int(n_os), int(n_os)) != 0:
-            raise OwError(binding.last_error(self._lib))
+            raise OwError(binding.take_error(self._lib))
         return out
 
     def set_profiling(self, on):
@@ -236,7 +245,7 @@ def render_note(midi_note, velocity, duration_secs, sample_rate, device=0):
     got = lib.ow_render_note(int(midi_note) & 0xFF, float(velocity), float(duration_secs), float(sample_rate), int(device),
                              out.ctypes.data_as(C.c_void_p), out.size)
     if got < 0:
-        raise OwError(binding.last_error(lib))
+        raise OwError(binding.take_error(lib))
     return out[:got]
 
 
@@ -261,10 +270,10 @@ def batch_render(jobs, sample_rate=44100.0, duration_s=2.0, device=0, preamp_kin
     if out_device_ptr is not None:
         got = lib.ow_batch_render(arr, len(jobs), C.byref(cfg), C.c_void_p(out_device_ptr), stride, 1)
         if got < 0:
-            raise OwError(binding.last_error(lib))
+            raise OwError(binding.take_error(lib))
         return None
     out = np.zeros((len(jobs), stride), dtype=np.float64)
     got = lib.ow_batch_render(arr, len(jobs), C.byref(cfg), out.ctypes.data_as(C.c_void_p), stride, 0)
     if got < 0:
-        raise OwError(binding.last_error(lib))
+        raise OwError(binding.take_error(lib))
     return out[:, :got]

@@ -37,7 +37,7 @@ def quantize_24bit(samples, scale=1.0, mode="round"):
     out = np.zeros(x.size, dtype=np.int32)
     m = binding.WAV_ROUND if mode == "round" else binding.WAV_TRUNCATE
     if lib.ow_wav24_quantize(x.ctypes.data_as(C.c_void_p), x.size, float(scale), m, out.ctypes.data_as(C.c_void_p)) != 0:
-        raise OwError(binding.last_error(lib))
+        raise OwError(binding.take_error(lib))
     return out.reshape(x.shape)
 
 
@@ -47,7 +47,7 @@ def write_wav_24bit(path, samples, sample_rate, scale=1.0, mode="round"):
     x = np.ascontiguousarray(samples, dtype=np.float64)
     m = binding.WAV_ROUND if mode == "round" else binding.WAV_TRUNCATE
     if lib.ow_wav24_write(str(path).encode(), x.ctypes.data_as(C.c_void_p), x.size, int(sample_rate), float(scale), m) != 0:
-        raise OwError(binding.last_error(lib))
+        raise OwError(binding.take_error(lib))
 
 
 _WAV_MODES = {None: binding.WAV_NONE, "round": binding.WAV_ROUND, "truncate": binding.WAV_TRUNCATE}
@@ -79,7 +79,7 @@ def extract_segments(audio, sample_rate, segments, search_pct=0.01, device=0, wa
                                   seg.ctypes.data_as(C.c_void_p), n, float(search_pct), _WAV_MODES[wav24], int(device), on_dev,
                                   amps.ctypes.data_as(C.c_void_p), freqs.ctypes.data_as(C.c_void_p), rms.ctypes.data_as(C.c_void_p))
     if rc != 0:
-        raise OwError(binding.last_error(lib))
+        raise OwError(binding.take_error(lib))
     return amps, freqs, rms
 
 
@@ -168,7 +168,7 @@ def render_and_extract(pairs, sample_rate=44100.0, duration_s=2.0, device=0, pre
     n = int(duration_s * sample_rate)
     buf = lib.ow_device_alloc(8 * len(pairs) * n, int(device))
     if not buf:
-        raise OwError(binding.last_error(lib))
+        raise OwError(binding.take_error(lib))
     try:
         batch_render([{"note": m, "velocity": v} for m, v in pairs], sample_rate=sample_rate, duration_s=duration_s, device=device,
                      preamp_kind=preamp_kind, out_device_ptr=buf, stride=n)

@@ -6,14 +6,14 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-from .binding import OwError, OwMidiRenderCfg, OwMidiRenderStats, TIMED_EVENT_DTYPE, load_library
+from .binding import OwError, OwMidiRenderCfg, OwMidiRenderStats, TIMED_EVENT_DTYPE, load_library, take_error
 
 BASE_SR = 44100.0        # main.rs:27
 NOTE_ON, NOTE_OFF, PEDAL = 0, 1, 2
 
 
 def _err(L):
-    return OwError((L.ow_last_error() or b"").decode())
+    return OwError(take_error(L))
 
 
 def parse_smf(data: bytes, track: Optional[int] = None) -> np.ndarray:

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
-    src = open(os.path.join(ROOT, "include", "openwurli_hip.h")).read()
+def _header_functions(name="openwurli_hip.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(ow_[a-z0-9_]+)\s*\(", src)))
 
@@ -18,14 +18,22 @@ def _header_functions():
 def test_header_and_binding_agree():
     from openwurli_amd import binding
     assert _header_functions() == sorted(binding.SYMBOLS)
+    assert _header_functions("openwurli_hip_test.h") == sorted(binding.TEST_SYMBOLS)
+    # the drop-in header carries no test or debug hook
+    assert not [f for f in _header_functions() if f.startswith(("ow_test_", "ow_debug_"))]
 
 
 def test_library_exports_every_declared_symbol(hiplib):
-    for name in _header_functions():
+    for name in _header_functions() + _header_functions("openwurli_hip_test.h"):
         assert getattr(hiplib, name) is not None
     out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "openwurli_amd", "lib", "libopenwurli_hip.so")], text=True)
     exported = set(re.findall(r" T (ow_[a-z0-9_]+)", out))
-    assert set(_header_functions()) <= exported
+    assert set(_header_functions()) | set(_header_functions("openwurli_hip_test.h")) <= exported
+
+
+def test_headers_compile_as_c99():
+    for h in ("openwurli_hip.h", "openwurli_hip_test.h"):
+        subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", h)])
 
 
 def test_library_contains_gfx950_code_object():
