@@ -44,6 +44,15 @@ int ow_debug_div_const(int which, const double* a, size_t n, double* fast, doubl
  * tanh (expm1-based, <= 2 ulp) and tanh(). */
 int ow_debug_unary(int which, const double* x, size_t n, double* fast, double* lib, int device);
 
+/* ---- tremolo phase groups -------------------------------------------------------------------- */
+/* Engines whose tremolo oscillators are bit-identical share one oscillator (a fresh pool is one group).  This hook cuts the pool into
+ * n_groups groups {g, g + n_groups, ...} and runs group g ahead by g * (one oscillator period / n_groups) samples: decorrelated
+ * tremolo phases, as instances that were reset at different times would have -- what the bench uses to price the per-engine path.
+ * Returns 0, <0 on error. */
+int ow_test_pool_stagger_tremolo(ow_pool*, size_t n_groups);
+/* Number of tremolo phase groups of the pool (1 for a fresh pool, +1 for every engine reset / warmed up on its own). */
+size_t ow_test_pool_tremolo_groups(const ow_pool*);
+
 /* ---- fault injection ------------------------------------------------------------------------ */
 /* The next n_renders calls of ow_pool_render / ow_engine_render on this pool fail before their first launch, exactly as a HIP
  * error would (exception inside the guarded region): the caller's block must come back as silence in every row, ow_last_error

@@ -135,6 +135,8 @@ TEST_SYMBOLS = {
     "ow_debug_div_const": (C.c_int, [C.c_int, _VP, C.c_size_t, _VP, _VP, _VP, C.c_int]),
     "ow_debug_unary": (C.c_int, [C.c_int, _VP, C.c_size_t, _VP, _VP, C.c_int]),
     "ow_test_inject_render_faults": (None, [_VP, C.c_int]),
+    "ow_test_pool_stagger_tremolo": (C.c_int, [_VP, C.c_size_t]),
+    "ow_test_pool_tremolo_groups": (C.c_size_t, [_VP]),
 }
 
 

@@ -252,6 +252,20 @@ struct ow_pool {
     std::vector<ow_engine*> engines;
     std::vector<uint8_t> dirty;       // per engine: host state changed since the args were last uploaded
     bool args_stale = true;           // device args still hold one-shot fields of the previous block
+    // Tremolo phase groups: engines whose Twin-T / CdS state is bit-identical (everything since their last chain init happened in
+    // lock-step) share ONE oscillator: the group's leader (its lowest engine index) carries the 18 tremolo rows of the chain state and
+    // owns a column of rbuf, the other members read that column.  A fresh pool is one group; ow_engine_reset / ow_engine_warm_up of a
+    // single engine split it off (per-engine fallback), a whole-pool reset / rate change merges everything again.
+    uint32_t* h_lead = nullptr;       // pinned [I]: leader engine of every engine
+    uint32_t* d_lead = nullptr;
+    uint32_t* h_leaders = nullptr;    // pinned [I]: compact list of the leaders inside the range being rendered
+    uint32_t* d_leaders = nullptr;
+    uint32_t* h_copy = nullptr;       // pinned [2][I]: (src, dst) pairs for k_trem_copy_rows
+    uint32_t* d_copy = nullptr;
+    std::vector<uint32_t> grp_in, grp_out;   // scratch of trem_split_at_range (first member inside / outside the range, per leader)
+    int n_lead = 0, lead_e0 = -1, lead_ne = -1;
+    bool lead_list_valid = false;     // d_leaders matches (lead_e0, lead_ne) and the current groups
+    int split_e0 = -1, split_ne = -1; // range for which "no group straddles the range boundary" is known to hold
     double* d_snap = nullptr;         // [3][I] smoother targets (depth, speaker, volume) handed to k_chain_init on reset
     double* h_snap = nullptr;         // pinned
     int inject_faults = 0;            // test hook (openwurli_hip_test.h): the next n renders fail before their first launch
@@ -359,10 +373,73 @@ static inline bool trem_wide(int ne) {
     if (const char* env = std::getenv("OW_TREM_WIDE")) return env[0] == '1';
     return ne <= 16384;
 }
+// ---- tremolo phase groups (see ow_pool) ---------------------------------------------------------------------------------
+void trem_groups_changed(ow_pool* p) {
+    HIP_OK(hipMemcpyAsync(p->d_lead, p->h_lead, sizeof(uint32_t) * p->I, hipMemcpyHostToDevice, p->stream));
+    p->lead_list_valid = false;
+    p->split_e0 = p->split_ne = -1;
+}
+// After this no group has members on both sides of the boundary of [e0, e0+ne): a straddling group is cut in two, the part that
+// loses the leader gets its lowest member as the new leader together with a copy of the 18 tremolo rows.  Init / reset / warm-up of
+// a sub-range then only touch groups that lie wholly inside it.  O(I) host work, on reset-class calls only.
+void trem_split_at_range(ow_pool* p, int e0, int ne) {
+    const uint32_t I = (uint32_t)p->I, lo = (uint32_t)e0, hi = (uint32_t)(e0 + ne);
+    if (ne >= (int)I || (p->split_e0 == e0 && p->split_ne == ne)) return;
+    const uint32_t NONE = 0xFFFFFFFFu;
+    bool straddle = false;
+    std::fill(p->grp_in.begin(), p->grp_in.end(), NONE);
+    std::fill(p->grp_out.begin(), p->grp_out.end(), NONE);
+    for (uint32_t e = 0; e < I; ++e) {
+        const uint32_t x = p->h_lead[e];
+        uint32_t& slot = (e >= lo && e < hi) ? p->grp_in[x] : p->grp_out[x];
+        if (slot == NONE) slot = e;                    // ascending scan: the first one found is the lowest
+    }
+    size_t n_copy = 0;
+    for (uint32_t x = 0; x < I; ++x) {
+        if (p->grp_in[x] == NONE || p->grp_out[x] == NONE) continue;
+        straddle = true;
+        const bool x_inside = x >= lo && x < hi;
+        const uint32_t fresh = x_inside ? p->grp_out[x] : p->grp_in[x];     // leader of the part that loses x
+        p->h_copy[n_copy] = x; p->h_copy[I + n_copy] = fresh; ++n_copy;
+    }
+    if (straddle) {
+        invalidate_spec(p);                             // the oscillator rows must be the committed ones before they are copied
+        HIP_OK(hipStreamSynchronize(p->stream));
+        for (uint32_t e = 0; e < I; ++e) {
+            const uint32_t x = p->h_lead[e];
+            if (p->grp_in[x] == NONE || p->grp_out[x] == NONE) continue;
+            const bool e_inside = e >= lo && e < hi, x_inside = x >= lo && x < hi;
+            if (e_inside != x_inside) p->h_lead[e] = x_inside ? p->grp_out[x] : p->grp_in[x];
+        }
+        HIP_OK(hipMemcpyAsync(p->d_copy, p->h_copy, sizeof(uint32_t) * n_copy, hipMemcpyHostToDevice, p->stream));
+        HIP_OK(hipMemcpyAsync(p->d_copy + I, p->h_copy + I, sizeof(uint32_t) * n_copy, hipMemcpyHostToDevice, p->stream));
+        owdev::k_trem_copy_rows<<<dim3((unsigned)((n_copy + 63) / 64)), dim3(64), 0, p->stream>>>(p->d_cs, (int)I, p->d_copy, p->d_copy + I, (int)n_copy);
+        trem_groups_changed(p);
+        HIP_OK(hipStreamSynchronize(p->stream));
+    }
+    p->split_e0 = e0; p->split_ne = ne;
+}
+// Compact list of the group leaders inside [e0, e0+ne) (groups do not straddle the range: trem_split_at_range) -> d_leaders.
+void trem_leader_list(ow_pool* p, int e0, int ne) {
+    if (p->lead_list_valid && p->lead_e0 == e0 && p->lead_ne == ne) return;
+    if (p->stream_trem) HIP_OK(hipStreamSynchronize(p->stream_trem));   // a kernel still reading the old list (rare path: groups or range changed)
+    int n = 0;
+    for (int k = 0; k < ne; ++k) if (p->h_lead[e0 + k] == (uint32_t)(e0 + k)) p->h_leaders[n++] = (uint32_t)(e0 + k);
+    HIP_OK(hipMemcpy(p->d_leaders, p->h_leaders, sizeof(uint32_t) * std::max(n, 1), hipMemcpyHostToDevice));
+    p->n_lead = n; p->lead_e0 = e0; p->lead_ne = ne; p->lead_list_valid = true;
+}
+
 void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<double>& depth0) {
     invalidate_spec(p);
     HIP_OK(hipStreamSynchronize(p->stream));
     const int I = (int)p->I;
+    // the range's engines get identical fresh tremolo states below: cut them out of the groups they shared with engines outside the
+    // range (those keep their oscillator), then make the range one group led by its first engine
+    trem_split_at_range(p, e0, ne);
+    for (int k = 0; k < ne; ++k) p->h_lead[e0 + k] = (uint32_t)e0;
+    trem_groups_changed(p);
+    p->split_e0 = e0; p->split_ne = ne;
+    trem_leader_list(p, e0, ne);
     if (mode == INIT_RESET) {
         // reset() snaps every smoother to ITS target (engine.rs:245-249), and LinearSmoother::set_target stores the target at once
         // (engine.rs:86-99) -- also for a setter call the device has not seen yet because no block was rendered since.  Hand the
@@ -384,14 +461,15 @@ void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<do
     }
     if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)   // DkPreamp::new / reset of the melange adapter: settled state at the chain rate
         owdev::k_mel_init<<<dim3((2 * ne + 63) / 64), dim3(64), 0, p->stream>>>(p->d_cs, p->d_mel_settled, p->d_noise, I, e0, ne);
-    const int blocks = (ne + 63) / 64;
+    const int nl = p->n_lead;          // == 1: the range is one phase group
+    const int blocks = (nl + 63) / 64;
     const long long n_settle = (long long)owhip::sat_u32(p->hc.os_sr * 2.0);
-    if (trem_wide(ne)) {   // small range: four lanes per engine (ow_trem_wide.h); the 2-second settle is pure serial latency
-        owdev::k_tremolo_wide<true><<<dim3((ne + 15) / 16), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, nullptr, I, 50LL, e0, ne);
-        owdev::k_tremolo_wide<true><<<dim3((ne + 15) / 16), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, nullptr, I, n_settle, e0, ne);
+    if (trem_wide(nl)) {   // few oscillators: four lanes per engine (ow_trem_wide.h); the 2-second settle is pure serial latency
+        owdev::k_tremolo_wide<true><<<dim3((nl + 15) / 16), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, nullptr, I, 50LL, p->d_leaders, nl);
+        owdev::k_tremolo_wide<true><<<dim3((nl + 15) / 16), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, nullptr, I, n_settle, p->d_leaders, nl);
     } else {
-        owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, I, e0, ne, 50LL);
-        owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, I, e0, ne, n_settle);
+        owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, I, p->d_leaders, nl, 50LL);
+        owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, I, p->d_leaders, nl, n_settle);
     }
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(p->stream));   // the tremolo stream picks these rows up next (init-time sync)
@@ -480,10 +558,11 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
     p->lists_e0 = e0; p->lists_ne = ne;
 }
 
-static void launch_tremolo(ow_pool* p, hipStream_t tt, double* rbuf, int n_os, int e0, int ne) {
-    const int I = (int)p->I;
-    if (trem_wide(ne)) owdev::k_tremolo_wide<false><<<dim3((ne + 15) / 16), dim3(64), 0, tt>>>(p->dK, p->d_cs, rbuf, I, (long long)n_os, e0, ne);
-    else owdev::k_tremolo<<<dim3((ne + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, rbuf, I, n_os, e0, ne);
+// one oscillator per phase group of the range (p->d_leaders, trem_leader_list)
+static void launch_tremolo(ow_pool* p, hipStream_t tt, double* rbuf, int n_os) {
+    const int I = (int)p->I, nl = p->n_lead;
+    if (trem_wide(nl)) owdev::k_tremolo_wide<false><<<dim3((nl + 15) / 16), dim3(64), 0, tt>>>(p->dK, p->d_cs, rbuf, I, (long long)n_os, p->d_leaders, nl);
+    else owdev::k_tremolo<<<dim3((nl + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, rbuf, I, n_os, p->d_leaders, nl);
 }
 
 // One render of `len` samples for engines [e0, e0+ne).  with_voices=false skips the voice kernels
@@ -500,10 +579,14 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
         HIP_OK(hipMemcpyAsync(p->d_cs, p->d_trem_backup, sizeof(double) * 18 * p->I, hipMemcpyDeviceToDevice, tt));
         p->spec.valid = false;
     }
+    // a sub-range advances on its own: its engines leave the phase groups they share with engines outside it (no-op for the whole pool
+    // and for a range that was just initialised); then the oscillators to run are the group leaders inside the range
+    trem_split_at_range(p, e0, ne);
+    trem_leader_list(p, e0, ne);
     if (hit) {
         p->rb_cur ^= 1;            // the half the speculation filled
     } else {
-        launch_tremolo(p, tt, p->d_rbuf + p->rb_cur * rb_half, n_os, e0, ne);
+        launch_tremolo(p, tt, p->d_rbuf + p->rb_cur * rb_half, n_os);
         HIP_OK(hipEventRecord(p->ev_trem[p->rb_cur], tt));
     }
     const double* rb_now = p->d_rbuf + p->rb_cur * rb_half;
@@ -513,7 +596,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
         const int nxt = p->rb_cur ^ 1;
         HIP_OK(hipMemcpyAsync(p->d_trem_backup, p->d_cs, sizeof(double) * 18 * p->I, hipMemcpyDeviceToDevice, tt));
         if (p->profiling) HIP_OK(hipEventRecord(p->ev[6], tt));
-        launch_tremolo(p, tt, p->d_rbuf + nxt * rb_half, n_os, e0, ne);
+        launch_tremolo(p, tt, p->d_rbuf + nxt * rb_half, n_os);
         if (p->profiling) HIP_OK(hipEventRecord(p->ev[7], tt));
         HIP_OK(hipEventRecord(p->ev_trem[nxt], tt));
         p->spec.valid = true; p->spec.e0 = e0; p->spec.ne = ne; p->spec.n_os = n_os;
@@ -614,9 +697,9 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[3], st));
     if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)
         owdev::k_preamp_mel<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
-                                                                      p->d_pre, p->d_noise, I, L, Lcap, e0, ne);
+                                                                      p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, e0, ne);
     else
-        owdev::k_preamp<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, rb_now, p->d_pre, I, L, Lcap, e0, ne);
+        owdev::k_preamp<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, rb_now, p->d_lead, p->d_pre, I, L, Lcap, e0, ne);
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[4], st));
     if (p->hc.oversample)
         owdev::k_post<true><<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, Lcap, e0, ne);
@@ -782,6 +865,14 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
         HIP_OK(hipHostMalloc(&vl->h, sizeof(uint32_t) * 64 * n_engines));
     }
     p->transient.assign(n_engines, 0);
+    HIP_OK(hipMalloc(&p->d_lead, sizeof(uint32_t) * n_engines));
+    HIP_OK(hipHostMalloc(&p->h_lead, sizeof(uint32_t) * n_engines));
+    HIP_OK(hipMalloc(&p->d_leaders, sizeof(uint32_t) * n_engines));
+    HIP_OK(hipHostMalloc(&p->h_leaders, sizeof(uint32_t) * n_engines));
+    HIP_OK(hipMalloc(&p->d_copy, sizeof(uint32_t) * 2 * n_engines));
+    HIP_OK(hipHostMalloc(&p->h_copy, sizeof(uint32_t) * 2 * n_engines));
+    p->grp_in.assign(n_engines, 0); p->grp_out.assign(n_engines, 0);
+    for (size_t i = 0; i < n_engines; ++i) p->h_lead[i] = (uint32_t)i;   // singletons until the chain state is replicated below
     HIP_OK(hipMalloc(&p->d_snap, sizeof(double) * 3 * n_engines));
     HIP_OK(hipHostMalloc(&p->h_snap, sizeof(double) * 3 * n_engines));
     ensure_ops_capacity(p, (size_t)3 * OW_MAX_VOICES * n_engines);   // a whole-keyboard re-strike of every engine: no allocation in render
@@ -824,6 +915,8 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     chain_init_range(p, 0, 1, INIT_NEW, std::vector<double>(1, 0.5));
     if (n_engines > 1)
         owdev::k_chain_replicate<<<dim3((unsigned)((n_engines + 63) / 64)), dim3(64), 0, p->stream>>>(p->d_cs, (int)n_engines, 0, 0, (int)n_engines);
+    for (size_t i = 0; i < n_engines; ++i) p->h_lead[i] = 0u;             // identical oscillators: one tremolo phase group led by engine 0
+    trem_groups_changed(p);
     if (p->d_noise)   // the replicated chain state does not carry the noise columns: seed every engine's streams
         owdev::k_mel_noise_seed<<<dim3((unsigned)((n_engines + 63) / 64)), dim3(64), 0, p->stream>>>(p->d_noise, (int)n_engines, 0, (int)n_engines);
     HIP_OK(hipGetLastError());
@@ -845,6 +938,12 @@ void pool_destroy(ow_pool* p) {
     for (ow_pool::VoiceList* vl : {&p->vl_steady, &p->vl_general, &p->vl_steal}) { if (vl->d) hipFree(vl->d); if (vl->h) hipHostFree(vl->h); }
     if (p->d_op_engines) hipFree(p->d_op_engines);
     if (p->h_op_engines) hipHostFree(p->h_op_engines);
+    if (p->d_lead) hipFree(p->d_lead);
+    if (p->h_lead) hipHostFree(p->h_lead);
+    if (p->d_leaders) hipFree(p->d_leaders);
+    if (p->h_leaders) hipHostFree(p->h_leaders);
+    if (p->d_copy) hipFree(p->d_copy);
+    if (p->h_copy) hipHostFree(p->h_copy);
     if (p->d_snap) hipFree(p->d_snap);
     if (p->h_snap) hipHostFree(p->h_snap);
     hipHostFree(p->h_args); hipHostFree(p->h_eout);
@@ -1008,7 +1107,7 @@ int ow_pool_read_tremolo_r(ow_pool* p, double* out_host, size_t out_stride, size
         const double* src = p->d_rbuf + (size_t)p->rb_cur * (2 * p->Lcap * I);   // the half the last block consumed, [n_os][I]
         HIP_OK(hipMemcpy(a.data(), src, sizeof(double) * I * n_os, hipMemcpyDeviceToHost));
         for (size_t e = 0; e < I; ++e)
-            for (size_t n = 0; n < n_os; ++n) out_host[e * out_stride + n] = a[n * I + e];
+            for (size_t n = 0; n < n_os; ++n) out_host[e * out_stride + n] = a[n * I + p->h_lead[e]];   // the column of the engine's phase group
         return 0;
     } catch (const std::exception& ex) { set_err(std::string("ow_pool_read_tremolo_r: ") + ex.what()); return -1; }
 }
@@ -1159,7 +1258,7 @@ void ow_engine_get_diag(const ow_engine* e, ow_diag* d) {
         std::memcpy(&bits, &diag, 8);
         d->preamp_nan_resets = (uint32_t)(bits >> 32);
         double be = 0.0;   // counts the block-ahead samples too
-        if (hipMemcpy(&be, p->d_cs + (size_t)CS_T_BE * p->I + e->index, sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
+        if (hipMemcpy(&be, p->d_cs + (size_t)CS_T_BE * p->I + p->h_lead[e->index], sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
             std::memcpy(&bits, &be, 8);
             d->tremolo_be_fallbacks = bits;
         }
@@ -1255,6 +1354,39 @@ void ow_test_engine_after_render(ow_engine* e, size_t len, uint64_t silent_mask)
     engine_post_render(e, (uint32_t)std::min<size_t>(len, 0xFFFFFFFFull), o);
 }
 uint64_t ow_test_engine_masks(const ow_engine* e, int which) { return e ? (which ? e->steal_mask : e->main_mask) : 0; }
+int ow_test_pool_stagger_tremolo(ow_pool* p, size_t n_groups) {
+    if (!p || n_groups == 0 || n_groups > p->I) return -1;
+    try {
+        HIP_OK(hipSetDevice(p->device));
+        invalidate_spec(p);
+        HIP_OK(hipStreamSynchronize(p->stream));
+        const uint32_t I = (uint32_t)p->I, G = (uint32_t)n_groups;
+        // every engine takes the oscillator state of its current leader, then group g = {g, g + G, ...} is led by engine g
+        size_t n_copy = 0;
+        for (uint32_t g = 0; g < G; ++g) { p->h_copy[n_copy] = p->h_lead[g]; p->h_copy[I + n_copy] = g; ++n_copy; }
+        HIP_OK(hipMemcpyAsync(p->d_copy, p->h_copy, sizeof(uint32_t) * n_copy, hipMemcpyHostToDevice, p->stream));
+        HIP_OK(hipMemcpyAsync(p->d_copy + I, p->h_copy + I, sizeof(uint32_t) * n_copy, hipMemcpyHostToDevice, p->stream));
+        // leaders of the old groups are among the sources: copy through the backup buffer so that no source row is overwritten first
+        HIP_OK(hipMemcpyAsync(p->d_trem_backup, p->d_cs, sizeof(double) * 18 * p->I, hipMemcpyDeviceToDevice, p->stream));
+        owdev::k_trem_copy_rows_from<<<dim3((unsigned)((n_copy + 63) / 64)), dim3(64), 0, p->stream>>>(p->d_cs, p->d_trem_backup, (int)I, p->d_copy, p->d_copy + I, (int)n_copy);
+        for (uint32_t e = 0; e < I; ++e) p->h_lead[e] = e % G;
+        trem_groups_changed(p);
+        trem_leader_list(p, 0, (int)I);
+        // group g runs g * step samples ahead of group 0; the steps cover one period of the ~5.6 Hz oscillator
+        const long long period = (long long)(p->hc.os_sr / 5.6);
+        const long long step = std::max<long long>(1, period / (long long)G);
+        owdev::k_trem_settle<<<dim3((p->n_lead + 63) / 64), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, (int)I, p->d_leaders, p->n_lead, 0LL, step);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(p->stream));
+        return 0;
+    } catch (const std::exception& ex) { set_err(std::string("ow_test_pool_stagger_tremolo: ") + ex.what()); return -1; }
+}
+size_t ow_test_pool_tremolo_groups(const ow_pool* p) {
+    if (!p) return 0;
+    size_t n = 0;
+    for (size_t e = 0; e < p->I; ++e) n += p->h_lead[e] == (uint32_t)e;
+    return n;
+}
 void ow_test_inject_render_faults(ow_pool* p, int n_renders) { if (p) p->inject_faults = n_renders > 0 ? n_renders : 0; }
 
 // ---- diagnostics ---------------------------------------------------------------------------------

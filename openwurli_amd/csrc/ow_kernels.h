@@ -537,13 +537,17 @@ __global__ __launch_bounds__(64) void k_chain_init(const OwConsts* __restrict__ 
 
 // n oscillator steps with the matrices of `K` (Tremolo::new settle loop tremolo.rs:97-100; CircuitState::warmup
 // gen_tremolo.rs:2071-2075 when K holds the 48 kHz codegen matrices).
-__global__ __launch_bounds__(64) void k_trem_settle(const OwConsts* __restrict__ K, double* __restrict__ cs, int I, int e0, int ne, long long n) {
+// stagger: leader idx runs idx * stagger additional steps (test hook: decorrelated tremolo phases across the groups of a pool).
+__global__ __launch_bounds__(64) void k_trem_settle(const OwConsts* __restrict__ K, double* __restrict__ cs, int I, const uint32_t* __restrict__ leaders,
+                                                    int n_lead, long long n0, long long stagger = 0) {
     __shared__ TremMats M;
     __shared__ TremPark P;   // oscillator state of this wavefront (LDS-resident, see ow_chain_dev.h)
     trem_mats_load(&M, K, threadIdx.x, blockDim.x);
     __syncthreads();
-    const int e = e0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= e0 + ne) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_lead) return;
+    const int e = (int)leaders[idx];
+    const long long n = n0 + stagger * idx;
     TremState t;
     trem_load(t, &P, cs, I, e);
     for (long long i = 0; i < n; ++i) {
@@ -561,16 +565,32 @@ __global__ void k_chain_replicate(double* __restrict__ cs, int I, int src, int e
     for (int f = 0; f < CS_COUNT; ++f) cs[(size_t)f * I + e] = cs[(size_t)f * I + src];
 }
 
+// copy the 18 tremolo rows of engine src[i] to engine dst[i] (a phase group changes its leader / a part of it is split off)
+__global__ void k_trem_copy_rows(double* __restrict__ cs, int I, const uint32_t* __restrict__ src, const uint32_t* __restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || src[i] == dst[i]) return;
+    for (int f = 0; f <= CS_T_BE; ++f) cs[(size_t)f * I + dst[i]] = cs[(size_t)f * I + src[i]];
+}
+
+__global__ void k_trem_copy_rows_from(double* __restrict__ cs, const double* __restrict__ from, int I, const uint32_t* __restrict__ src,
+                                      const uint32_t* __restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int f = 0; f <= CS_T_BE; ++f) cs[(size_t)f * I + dst[i]] = from[(size_t)f * I + src[i]];
+}
+
 // ------------------------------------------------------------------ tremolo stream
 // CdS cell resistance for n_os chain-rate samples (no audio input, no depth dependence): runs a block ahead of the audio.
+// lane = tremolo phase group (its leader engine); engines of one group share one R stream (column of the leader).
 __global__ __launch_bounds__(64) void k_tremolo(const OwConsts* __restrict__ K, double* __restrict__ cs, double* __restrict__ rbuf, int I, int n_os,
-                                                int e0, int ne) {
+                                                const uint32_t* __restrict__ leaders, int n_lead) {
     __shared__ TremMats M;
     __shared__ TremPark P;   // oscillator state of this wavefront (LDS-resident, see ow_chain_dev.h)
     trem_mats_load(&M, K, threadIdx.x, 64);
     __syncthreads();
-    const int e = e0 + blockIdx.x * 64 + threadIdx.x;
-    if (e >= e0 + ne) return;
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= n_lead) return;
+    const int e = (int)leaders[idx];
     TremState t;
     trem_load(t, &P, cs, I, e);
     for (int i = 0; i < n_os; ++i) {
@@ -585,7 +605,7 @@ __global__ __launch_bounds__(64) void k_tremolo(const OwConsts* __restrict__ K, 
 #define OW_PCHUNK 64
 __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args,
                                                const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const double* __restrict__ rbuf,
-                                               double* __restrict__ pre, int I, int L, int Lcap, int e0, int ne) {
+                                               const uint32_t* __restrict__ trem_lead, double* __restrict__ pre, int I, int L, int Lcap, int e0, int ne) {
     __shared__ double tile[32 * (OW_PCHUNK + 1)];
     const int lane = threadIdx.x;
     const int el = lane & 31, role = lane >> 5;
@@ -624,9 +644,10 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
     }
     const int e_last = e0 + ne - 1;
     // R[n] is read one host sample ahead (registers), so its global-load latency is hidden behind the previous sample's solve
+    const int er = (int)trem_lead[ec];     // column of this engine's tremolo phase group (one column for a whole fresh pool: a broadcast load)
     double rn[2];
-    rn[0] = rbuf[(size_t)0 * I + ec];
-    rn[1] = osr == 2 ? rbuf[(size_t)1 * I + ec] : 0.0;
+    rn[0] = rbuf[(size_t)0 * I + er];
+    rn[1] = osr == 2 ? rbuf[(size_t)1 * I + er] : 0.0;
     for (int base = 0; base < L; base += OW_PCHUNK) {
         const int cn = min(OW_PCHUNK, L - base);
         // stage 32 engine rows x 64 samples of the voice sum (slot pass + steal pass) through LDS
@@ -647,8 +668,8 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
             const double rc[2] = {rn[0], rn[1]};
             {
                 const size_t nx = (size_t)min(base + n + 1, L - 1) * osr;
-                rn[0] = rbuf[nx * I + ec];
-                if (osr == 2) rn[1] = rbuf[(nx + 1) * I + ec];
+                rn[0] = rbuf[nx * I + er];
+                if (osr == 2) rn[1] = rbuf[(nx + 1) * I + er];
             }
             const double depth = clampd(sd.next(), 0.0, 1.0);   // engine.rs:533-534, tremolo.rs:117-119
             double in[2];

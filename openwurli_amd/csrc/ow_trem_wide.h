@@ -274,15 +274,17 @@ OW_DEV void trem_wide_store(const TremWide& t, double* __restrict__ cs, int I, i
 
 // 16 engines per wavefront.  settle_only: n oscillator steps without the LDR law (k_trem_settle); otherwise R[n] for n_os samples.
 template <bool SETTLE>
+// leaders[0..n_lead): the engines that own a tremolo phase group (see "Tremolo phase groups", openwurli_hip.hip); column e of rbuf is
+// written for those engines only, every other engine of a group reads its leader's column.
 __global__ __launch_bounds__(64) void k_tremolo_wide(const OwConsts* __restrict__ K, double* __restrict__ cs, double* __restrict__ rbuf, int I,
-                                                     long long n, int e0, int ne) {
+                                                     long long n, const uint32_t* __restrict__ leaders, int n_lead) {
     __shared__ TremMats M;
     trem_mats_load(&M, K, threadIdx.x, 64);
     __syncthreads();
     const int el = threadIdx.x >> 2, q = threadIdx.x & 3;
-    const int e_raw = e0 + blockIdx.x * 16 + el;
-    const bool valid = e_raw < e0 + ne;
-    const int e = valid ? e_raw : e0 + ne - 1;      // idle quads shadow the last engine (no divergence), and store nothing
+    const int idx = blockIdx.x * 16 + el;
+    const bool valid = idx < n_lead;
+    const int e = (int)leaders[valid ? idx : n_lead - 1];      // idle quads shadow the last engine (no divergence), and store nothing
     TremWide t;
     trem_wide_load(t, cs, I, e);
     double drive = 0.0;

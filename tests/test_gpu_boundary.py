@@ -62,7 +62,7 @@ def test_render_failure_is_silence_and_is_reported(hiplib):
     p = ow.EnginePool(48000.0, 5)
     for k in range(5):
         p[k].note_on(50 + k, 0.9)
-    a = p.render(256)
+    a = np.concatenate([p.render(256) for _ in range(6)], axis=1)              # past the onset ramp
     assert np.max(np.abs(a)) > 1e-3
     hiplib.ow_test_inject_render_faults(p._h, 2)
     out = np.full((5, 256), 7.0, dtype=np.float32)
