@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput bench of the OpenWurli DSP hot path on MI355X.
 
-Workload (BASELINE.json configs[1], SURVEY.md 8d config 2, scaled out per configs[4]):
+Default workload (BASELINE.json configs[1], SURVEY.md 8d config 2, scaled out per configs[4]):
   I independent engine instances per GPU, each 64 voices (all keys 33..96 struck at t=0,
   note_off+note_on re-strike of all 64 every 1.0 s so that 64 voices stay alive), 48 kHz host
   rate (2x oversampled chain at 96 kHz), full chain: tremolo + legacy DK preamp + behavioural
@@ -12,13 +12,25 @@ Workload (BASELINE.json configs[1], SURVEY.md 8d config 2, scaled out per config
 One "step" = one 512-sample buffer rendered by every instance of every rank.  `value` =
 output samples per second over all instances of all ranks (weak scaling: I per GPU fixed).
 The rendered audio stays in HBM (inputs resident, no PCIe in the timed region except the
-per-step event list and the 32-byte-per-engine status block the host state machine needs).
+per-step event list and the 40-byte-per-engine status block the host state machine needs);
+`pcie_inclusive` repeats the run with every block copied to pinned host memory.
+
+`--workload batch` makes BASELINE configs[3] (ml/render_model_notes.py: 64 notes x 8 velocities x 5 s,
+`preamp-bench render` semantics) the headline instead: jobs dealt round-robin over the ranks, ONE
+RCCL gather of the f32 slabs to rank 0, timed separately.  Every run (any workload, any N) also
+carries a `batch` object with that literal grid and a grid scaled to 8 192 jobs per GPU, so the
+driver's 1/2/4/8-GPU runs show the batch path at both sizes.
+
+`--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself, before this process
+touches the GPU; under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.
 
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the roofline arithmetic.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -36,12 +48,15 @@ NOTES = list(range(33, 97))
 
 # Algorithmic f64 flops per OUTPUT sample of one 64-voice engine (restated in DESIGN.md):
 FLOPS_VOICES = 64 * 130            # 7 modes x 16 + jitter 3 + pickup 13 + gain/sum 2 per voice-sample
-FLOPS_TREMOLO = 2 * (1000 + 25)    # Twin-T NR step + LDR law per OS sample, 2 OS samples
+FLOPS_TREMOLO = 2 * (1000 + 25)    # Twin-T NR step + LDR law per OS sample, 2 OS samples -- per tremolo PHASE GROUP, not per engine
 FLOPS_PREAMP = 2 * 1400 + 24       # main+shadow dk_step per OS sample + half-band up
+# melange 12-node preamp as the kernel EXECUTES it (rank-one update of the inverse, no per-sample LU): per state and chain-rate
+# sample build_rhs ~120 + S.rhs 288 + Sherman-Morrison correction ~50 + 3 Newton sweeps x ~150 + S_NI.i 72 + damp net ~50 = ~1050
+FLOPS_PREAMP_MELANGE = 2 * 2 * 1050 + 24
 FLOPS_POST = 2 * 90 + 24 + 45      # power amp x2 + half-band down + speaker/gain
-FLOPS_PER_SAMPLE = FLOPS_VOICES + FLOPS_TREMOLO + FLOPS_PREAMP + FLOPS_POST
 KERNEL_OF = {"ops": "k_apply_ops", "voices": "k_voice_steady", "tremolo": "k_tremolo", "preamp": "k_preamp", "post": "k_post"}
 PEAK_FP64_VALU_TFLOPS = 78.6       # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (MI355X FP64 vector)
+FLOPS_BATCH_JOB = 3000             # config-4 job: 1 voice 129 + half-band 48 + 2 x 1400 legacy preamp + speaker 30
 
 
 def instance_velocity(k):
@@ -70,11 +85,13 @@ def build_events(n_inst, kind):
 
 
 class Script:
-    """Sample-accurate event script: renders one 512-sample step, splitting at epoch boundaries."""
+    """Sample-accurate event script: renders one buffer per step, splitting at epoch boundaries."""
 
-    def __init__(self, pool, n_inst):
+    def __init__(self, pool, n_inst, buf=BUF, host_out=None):
         self.pool = pool
         self.pos = 0
+        self.buf = buf
+        self.host_out = host_out          # (pointer, stride) of a pinned host block, or None = audio stays in HBM
         self.ev_strike = build_events(n_inst, "strike")
         self.ev_restrike = build_events(n_inst, "restrike")
         self.kernel_ms = np.zeros(5)
@@ -84,18 +101,21 @@ class Script:
 
     def step(self, profile=False):
         done = 0
-        while done < BUF:
+        while done < self.buf:
             t0 = time.perf_counter()
             if self.pos % EPOCH == 0:
                 self.pool.midi(self.ev_strike if self.pos == 0 else self.ev_restrike)
             t1 = time.perf_counter()
-            nxt = min(BUF - done, EPOCH - (self.pos % EPOCH))
-            self.pool.render(nxt, to_host=False)
+            nxt = min(self.buf - done, EPOCH - (self.pos % EPOCH))
+            if self.host_out is None:
+                self.pool.render(nxt, to_host=False)
+            else:
+                self.pool.render_into(self.host_out[0], self.host_out[1], nxt)
             self.t_midi += t1 - t0
             self.t_render += time.perf_counter() - t1
             if profile:
                 ms = self.pool.last_kernel_ms()
-                self.kernel_ms += np.array([ms["ops"], ms["voices"], ms["tremolo"], ms["preamp"], ms["post"]]) * (nxt / BUF)
+                self.kernel_ms += np.array([ms["ops"], ms["voices"], ms["tremolo"], ms["preamp"], ms["post"]]) * (nxt / self.buf)
             self.pos += nxt
             done += nxt
         if profile:
@@ -113,6 +133,16 @@ def effective_cpus():
     except (OSError, ValueError):
         pass
     return n
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(seconds_audio=1.0, preamp_kind=0):
@@ -149,27 +179,121 @@ def cpu_baseline(seconds_audio=1.0, preamp_kind=0):
     wall = time.perf_counter() - t0
     total = sum(v[0] for v in res.values())
     return {
-        "value": total / wall, "unit": "samples/s", "cores": cores, "kind": "port",
+        "value": total / wall, "unit": "samples/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
         "sample": f"{cores} threads (= usable CPUs: affinity capped by the cgroup quota) x 1 cfg-2 instance (64 voices, full chain) x {seconds_audio:.1f} s audio, buffers of {BUF}; "
                   f"oracle = C++ f64 restatement (reference Rust is not buildable in this image)",
         "single_thread_value": single,
     }
 
 
-def main():
+# ---------------------------------------------------------------------------------------------------------------- launcher
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (one per GPU) before anything in this process
+    touches the GPU, relay rank 0's line, exit non-zero when any rank fails.  Never re-execs."""
+    if os.environ.get("OW_BENCH_DRYRUN_BACKEND") is None:
+        import torch                                   # device_count() does not initialise the GPU on this image
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for ln in (out0 or "").splitlines():           # rank 0's JSON line goes to stdout; library chatter (gloo / RCCL banners) to stderr
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------- batch path
+def batch_pass(jobs, sr, dur, dist, world, render_fn=None):
+    """One pass of the sharded batch render: (elapsed_s over render + gather, max over ranks; per-phase maxima; ranks the collective saw)."""
+    import torch
+    from openwurli_amd import distributed as owd
+    tm = {}
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    res = owd.batch_render_sharded(jobs, sr, dur, render_fn=render_fn, timings=tm, to_host=False)
+    el = time.perf_counter() - t0
+    vals = [el, tm["render_s"], tm["gather_s"]]
+    if dist is not None:
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        vals = [float(x) for x in t.tolist()]
+    del res
+    return vals[0], vals[1], vals[2], tm["world_seen"]
+
+
+def batch_bench(dist, world, steps, warmup, scaled_jobs_per_gpu=8192, scaled_dur=1.0, render_fn=None, literal_dur=5.0):
+    """configs[3] literal (512 jobs x 5 s: 8 + 64 wavefronts, latency-bound, cannot scale) and a grid scaled until every GPU holds
+    `scaled_jobs_per_gpu` jobs (the regime in which >= 6x at 8 GPUs is reachable)."""
+    from openwurli_amd.distributed import model_notes_job_list
+    out = {}
+    base = model_notes_job_list()
+    grids = {"literal": (base, literal_dur),
+             "scaled": ([base[i % len(base)] for i in range(scaled_jobs_per_gpu * world)], scaled_dur)}
+    for name, (jobs, dur) in grids.items():
+        n = int(dur * SR)
+        for _ in range(warmup):
+            batch_pass(jobs, SR, dur, dist, world, render_fn)
+        el = rs = gs = 0.0
+        seen = world
+        for _ in range(steps):
+            e, r, g, seen = batch_pass(jobs, SR, dur, dist, world, render_fn)
+            el += e; rs += r; gs += g
+        samples = len(jobs) * n * steps
+        out[name] = {"jobs": len(jobs), "seconds_per_job": dur, "samples_per_s": samples / el, "x_realtime": samples / el / SR,
+                     "render_ms": 1e3 * rs / steps, "gather_ms": 1e3 * gs / steps, "pass_ms": 1e3 * el / steps, "ranks_seen_by_collective": seen,
+                     "scaling": "strong" if name == "literal" else "weak",
+                     "valu_frac": FLOPS_BATCH_JOB * samples / el / world / 1e12 / PEAK_FP64_VALU_TFLOPS}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- main
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["engines", "batch"], default="engines",
+                    help="engines = configs[1] replicated per configs[4] (the metric's config); batch = configs[3] sharded over the ranks")
     ap.add_argument("--instances", type=int, default=int(os.environ.get("OW_BENCH_INSTANCES", "65536")), help="engine instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip pcie_inclusive / config4_literal / single_instance / batch objects")
     ap.add_argument("--preamp", choices=["legacy", "melange"], default="legacy",
                     help="legacy = the 8-node DK solver of the reference's default build (the metric's config); melange = the generated "
                          "12-node solver of its `--features melange-preamp` build")
     ap.add_argument("--host-rate", type=float, default=48000.0,
                     help="host sample rate: 48000 = BASELINE configs[1] (the metric's config, default); 96000 = configs[2] (no oversampling)")
-    args = ap.parse_args()
-    global SR, EPOCH, FLOPS_TREMOLO, FLOPS_PREAMP, FLOPS_POST, FLOPS_PER_SAMPLE
+    ap.add_argument("--tremolo-groups", type=int, default=1,
+                    help="1 = a fresh pool: every instance was built at the same sample, so all share one tremolo phase (one oscillator "
+                         "per pool); G > 1 staggers the pool into G phase groups (test hook), G = instances prices the fully per-engine path")
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = 100 if args.workload == "engines" else 3
+    if args.warmup is None:
+        args.warmup = 5 if args.workload == "engines" else 1
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus, argv)
+
+    global SR, EPOCH, FLOPS_TREMOLO, FLOPS_PREAMP, FLOPS_POST
     if args.host_rate != SR:
         SR = float(args.host_rate)
         EPOCH = int(SR)                              # 1.0 s re-strike epochs at any rate (SURVEY 8d config 3)
@@ -177,127 +301,226 @@ def main():
         FLOPS_TREMOLO = osr * (1000 + 25)
         FLOPS_PREAMP = osr * 1400 + (24 if osr == 2 else 0)
         FLOPS_POST = osr * 90 + (24 if osr == 2 else 0) + 45
-        FLOPS_PER_SAMPLE = FLOPS_VOICES + FLOPS_TREMOLO + FLOPS_PREAMP + FLOPS_POST
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher decides; reporting n_gpus={world}", file=sys.stderr)
     import torch
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # OW_BENCH_DRYRUN_BACKEND=gloo: launcher / sharding / gather / JSON-contract dry run on CPU (tests/test_bench_launcher.py): the ranks
+    # rendezvous over gloo and the batch render is a deterministic stand-in.  Nothing is measured in that mode and the line says so.
+    dryrun = os.environ.get("OW_BENCH_DRYRUN_BACKEND")
+    if dryrun:
+        if args.workload != "batch":
+            print("bench.py: the dry run covers --workload batch only", file=sys.stderr)
+            return 2
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group(dryrun, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import openwurli_amd as ow
-    n_inst = args.instances
-    preamp_kind = 1 if args.preamp == "melange" else 0
-    if preamp_kind:                   # +~12 kflop per output sample (two states x 2 OS samples x 12-node solve)
-        FLOPS_PREAMP += 12000
-        FLOPS_PER_SAMPLE += 12000
-    pool = ow.EnginePool(SR, n_inst, device=local_rank, preamp_kind=preamp_kind)
-    pool.set_sample_rate(SR)          # the plugin's initialize(): chain build + 0.6 s warm-up (not timed)
-    pool.ensure_buffer_capacity(BUF)
-    # volume 0.5 / tremolo depth 0.5 / speaker character 0.0 / MLP on are the engine defaults (engine.rs:221-224)
-    for k in range(min(n_inst, 4096)):
-        e = pool[k]
-        e.set_volume(0.5); e.set_tremolo_depth(0.5); e.set_speaker_character(0.0); e.set_mlp_enabled(True)
-    script = Script(pool, n_inst)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dryrun:
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        script.step()
-    pool.set_profiling(True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        script.step(profile=True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    pool.set_profiling(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    preamp_kind = 1 if args.preamp == "melange" else 0
+    flops_preamp = FLOPS_PREAMP_MELANGE if preamp_kind else FLOPS_PREAMP
+    n_inst = args.instances
+    line = None
 
-    # single-instance latency figure (what one plugin instance would see), rank 0 only, not part of `value`
-    single = None
-    cpu = None
-    if rank == 0:
-        one = ow.EnginePool(SR, 1, device=local_rank, preamp_kind=preamp_kind)
-        one.set_sample_rate(SR)
-        s1 = Script(one, 1)
-        for _ in range(3):
-            s1.step()
-        t1 = time.perf_counter()
-        for _ in range(20):
-            s1.step()
-        single = 20 * BUF / (time.perf_counter() - t1)
-        one.close()
-        if world == 1 and not args.no_cpu_baseline:
+    if args.workload == "batch":
+        barrier()
+        fake = None
+        if dryrun:
+            def fake(jobs, n=int(0.01 * SR)):
+                return np.stack([np.full(n, j["note"] * 1000 + j["velocity"], dtype=np.float32) for j in jobs])
+        b = batch_bench(dist, world, args.steps, args.warmup, render_fn=fake, **({"scaled_jobs_per_gpu": 64, "scaled_dur": 0.01, "literal_dur": 0.01} if dryrun else {}))
+        if rank == 0:
+            lit = b["literal"]
+            line = {
+                "metric": "audio samples/s, batch-render path (ml/render_model_notes.py grid, preamp-bench render semantics)",
+                "value": lit["samples_per_s"], "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": lit["pass_ms"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic" if not dryrun else "DRY RUN (gloo, stand-in renderer): launcher and gather plumbing only, nothing measured",
+                "config": {"workload": "cfg4: 512 jobs (64 notes x 8 velocities) x 5 s at 48 kHz, job j -> rank j mod G, one RCCL gather of f32 slabs to rank 0",
+                           "parallelism": f"{world} rank(s), static job deal, no data-path collective besides the final gather"},
+                "batch": b,
+                "dry_run": bool(dryrun),
+                "roofline": {"bound": "valu_f64", "kernel": "k_job_chain_wide", "achieved": lit["valu_frac"] * PEAK_FP64_VALU_TFLOPS, "peak": PEAK_FP64_VALU_TFLOPS,
+                             "unit": "TFLOP/s", "frac": lit["valu_frac"], "traffic": None,
+                             "note": "512 jobs = 64 quad-lane wavefronts on 1 024 SIMDs: bounded by the serial latency of one preamp stream, not by issue or HBM"},
+                "cpu_baseline": None,
+            }
+    else:
+        pool = ow.EnginePool(SR, n_inst, device=local_rank, preamp_kind=preamp_kind)
+        pool.set_sample_rate(SR)          # the plugin's initialize(): chain build + 0.6 s warm-up (not timed)
+        pool.ensure_buffer_capacity(BUF)
+        groups = max(1, min(args.tremolo_groups, n_inst))
+        if groups > 1:
+            pool.stagger_tremolo(groups)
+        # volume 0.5 / tremolo depth 0.5 / speaker character 0.0 / MLP on are the engine defaults (engine.rs:221-224)
+        for k in range(min(n_inst, 4096)):
+            e = pool[k]
+            e.set_volume(0.5); e.set_tremolo_depth(0.5); e.set_speaker_character(0.0); e.set_mlp_enabled(True)
+        script = Script(pool, n_inst)
+        for _ in range(args.warmup):
+            script.step()
+        pool.set_profiling(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            script.step(profile=True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        pool.set_profiling(False)
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        extras = {}
+        if not args.no_extras:
+            # (a) PCIe-inclusive: the same steps with every block copied into a pinned host buffer (what render(&mut [f32]) hands back)
+            host = pool.alloc_host_block(BUF)
+            sp = Script(pool, n_inst, host_out=host)
+            sp.pos = script.pos
+            k_steps = max(5, min(args.steps, 20))
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(k_steps):
+                sp.step()
+            barrier()
+            el = time.perf_counter() - t1
+            if dist is not None:
+                t = torch.tensor([el], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            extras["pcie_inclusive"] = {"value": k_steps * BUF * n_inst * world / el, "unit": "samples/s", "ms_per_step": 1e3 * el / k_steps, "steps": k_steps,
+                                        "bytes_per_step_per_gpu": 4 * BUF * n_inst, "host_memory": "pinned (ow_host_alloc)"}
+            pool.free_host_block(host)
+        pool.close()
+
+        single = None
+        cpu = None
+        if rank == 0 and not args.no_extras:
+            # (b) configs[4] taken literally: ONE pool of 256 instances on this GPU
+            p256 = ow.EnginePool(SR, 256, device=local_rank, preamp_kind=preamp_kind)
+            p256.set_sample_rate(SR)
+            p256.ensure_buffer_capacity(BUF)
+            s256 = Script(p256, 256)
+            for _ in range(3):
+                s256.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(30):
+                s256.step()
+            el = time.perf_counter() - t1
+            extras["config4_literal"] = {"instances": 256, "value": 30 * BUF * 256 / el, "unit": "samples/s", "x_realtime_aggregate": 30 * BUF * 256 / el / SR,
+                                         "ms_per_step": 1e3 * el / 30}
+            p256.close()
+            # (c) one instance (what one plugin instance sees): per-buffer latency at the usual host buffer sizes, audio copied to the host
+            table = []
+            for buf in (64, 128, 256, 512):
+                one = ow.EnginePool(SR, 1, device=local_rank, preamp_kind=preamp_kind)
+                one.set_sample_rate(SR)
+                one.ensure_buffer_capacity(buf)
+                s1 = Script(one, 1, buf=buf)
+                host1 = np.zeros((1, buf), dtype=np.float32)
+                lat = []
+                for i in range(8 + 60):
+                    ta = time.perf_counter()
+                    if s1.pos % EPOCH == 0:
+                        one.midi(s1.ev_strike if s1.pos == 0 else s1.ev_restrike)
+                    one.render_into(host1.ctypes.data, buf, buf)
+                    s1.pos += buf
+                    if i >= 8:
+                        lat.append(time.perf_counter() - ta)
+                lat = np.array(lat) * 1e6
+                table.append({"buffer": buf, "latency_us_mean": float(lat.mean()), "latency_us_p50": float(np.median(lat)), "latency_us_max": float(lat.max()),
+                              "samples_per_s": buf / (lat.mean() * 1e-6), "x_realtime": buf / (lat.mean() * 1e-6) / SR,
+                              "buffer_period_us": 1e6 * buf / SR})
+                one.close()
+            extras["single_instance"] = table
+            single = table[-1]["samples_per_s"]
+        if not args.no_extras:
+            barrier()
+            extras["batch"] = batch_bench(dist, world, steps=2, warmup=1)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(preamp_kind=preamp_kind)
 
-    if rank == 0:
-        total_samples = args.steps * BUF * n_inst * world
-        value = total_samples / elapsed
-        kms = script.kernel_ms / max(script.kernel_launches, 1)     # average ms per step, per kernel
-        names = ["ops", "voices", "tremolo", "preamp", "post"]
-        flops = {"ops": 0.0, "voices": FLOPS_VOICES, "tremolo": FLOPS_TREMOLO, "preamp": FLOPS_PREAMP, "post": FLOPS_POST}
-        dom = names[int(np.argmax(kms))]
-        dom_ms = float(kms[names.index(dom)])
-        achieved = flops[dom] * BUF * n_inst / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tp):
-            try:
-                tj = json.load(open(tp))      # PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) measured per engine
-                per_engine = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_engine_launch")
-                traffic = per_engine * n_inst if per_engine is not None else None
-            except Exception:
-                traffic = None
-        line = {
-            "metric": f"audio samples/s, 64-voice full chain (x real-time @{SR / 1000:.0f} kHz = value / {SR:.0f})",
-            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {
-                "workload": ("cfg2: 64-voice all-keys-sustained (1.0 s re-strike), 48 kHz host / 96 kHz chain, full chain "
-                             "(tremolo+legacy DK preamp+behavioural power amp+speaker), MLP on, buffers of 512").replace("legacy DK", "melange 12-node DK" if preamp_kind else "legacy DK") if SR == 48000.0 else
-                            (f"cfg3: 64-voice all-keys-sustained (1.0 s re-strike), {SR:.0f} Hz host"
-                             f"{' (no oversampling)' if SR >= 88200.0 else ' / 2x chain'}, full chain, MLP on, buffers of 512"),
-                "instances_per_gpu": n_inst, "buffer": BUF, "parallelism": f"{world} x independent pools (no data-path collective)",
-            },
-            "x_realtime_aggregate": value / SR,
-            "host_midi_s": script.t_midi, "render_calls_s": script.t_render, "elapsed_s": elapsed,
-            "single_instance_samples_per_s": single,
-            "roofline": {
-                "bound": "valu_f64", "kernel": KERNEL_OF[dom] + ("_mel" if preamp_kind and dom == "preamp" else ""), "achieved": achieved,
-                "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
-                "kernel_ms_per_step": {n: float(k) for n, k in zip(names, kms)},
-                "whole_chain_frac": FLOPS_PER_SAMPLE * value / world / 1e12 / PEAK_FP64_VALU_TFLOPS,
-                # k_tremolo (block ahead, own stream) runs INSIDE the voice kernel's interval and shares its SIMDs, so the interval's
-                # arithmetic is voices + tremolo; `frac` above charges the whole interval to the voice kernel alone
-                "voices_plus_tremolo_frac": ((FLOPS_VOICES + FLOPS_TREMOLO) * BUF * n_inst / (float(kms[1]) * 1e-3) / 1e12
-                                             / PEAK_FP64_VALU_TFLOPS if kms[1] > 0 else None),
-                # the contract's own vocabulary, for reference: PMC HBM bytes of the dominant kernel / its duration against 8 TB/s
-                "hbm": ({"achieved": traffic / (dom_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                         "frac": traffic / (dom_ms * 1e-3) / 1e9 / 8000.0} if traffic and dom_ms > 0 else None),
-                "note": "path is FP64-VALU/latency bound (not HBM, not MFMA); achieved = algorithmic f64 flops of the dominant "
-                        "kernel per launch / its HIP-event duration",
-            },
-            "cpu_baseline": cpu,
-        }
+        if rank == 0:
+            total_samples = args.steps * BUF * n_inst * world
+            value = total_samples / elapsed
+            kms = script.kernel_ms / max(script.kernel_launches, 1)     # average ms per step, per kernel
+            names = ["ops", "voices", "tremolo", "preamp", "post"]
+            trem_per_engine = FLOPS_TREMOLO * groups / n_inst            # one oscillator per phase group
+            flops = {"ops": 0.0, "voices": FLOPS_VOICES, "tremolo": trem_per_engine, "preamp": flops_preamp, "post": FLOPS_POST}
+            per_sample = FLOPS_VOICES + trem_per_engine + flops_preamp + FLOPS_POST
+            audio = ["voices", "preamp", "post"] + (["tremolo"] if groups * 4 >= n_inst else [])   # the shared oscillator is not a pool-sized kernel
+            dom = max(audio, key=lambda k: kms[names.index(k)])
+            dom_ms = float(kms[names.index(dom)])
+            achieved = flops[dom] * BUF * n_inst / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tp):
+                try:
+                    tj = json.load(open(tp))      # PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) measured per engine
+                    per_engine = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_engine_launch")
+                    traffic = per_engine * n_inst if per_engine is not None else None
+                except Exception:
+                    traffic = None
+            solver = "melange 12-node DK" if preamp_kind else "legacy DK"
+            line = {
+                "metric": f"audio samples/s, 64-voice full chain (x real-time @{SR / 1000:.0f} kHz = value / {SR:.0f})",
+                "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {
+                    "workload": (f"cfg2: 64-voice all-keys-sustained (1.0 s re-strike), 48 kHz host / 96 kHz chain, full chain "
+                                 f"(tremolo+{solver} preamp+behavioural power amp+speaker), MLP on, buffers of 512") if SR == 48000.0 else
+                                (f"cfg3: 64-voice all-keys-sustained (1.0 s re-strike), {SR:.0f} Hz host"
+                                 f"{' (no oversampling)' if SR >= 88200.0 else ' / 2x chain'}, full chain, MLP on, buffers of 512"),
+                    "instances_per_gpu": n_inst, "buffer": BUF, "parallelism": f"{world} x independent pools (no data-path collective)",
+                    "tremolo_phase_groups": groups,
+                    "tremolo_note": ("all instances of a pool were built at the same sample, so their Twin-T oscillators are bit-identical and ONE is computed "
+                                     "per pool (its flops are not in the roofline numerator)") if groups == 1 else
+                                    f"pool staggered into {groups} tremolo phase groups (one oscillator each)",
+                },
+                "x_realtime_aggregate": value / SR,
+                "host_midi_s": script.t_midi, "render_calls_s": script.t_render, "elapsed_s": elapsed,
+                "single_instance_samples_per_s": single,
+                "roofline": {
+                    "bound": "valu_f64", "kernel": KERNEL_OF[dom] + ("_mel" if preamp_kind and dom == "preamp" else ""), "achieved": achieved,
+                    "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
+                    "kernel_ms_per_step": {n: float(k) for n, k in zip(names, kms)},
+                    "flops_per_output_sample": {"voices": FLOPS_VOICES, "tremolo": trem_per_engine, "preamp": flops_preamp, "post": FLOPS_POST},
+                    "whole_chain_frac": per_sample * value / world / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                    # the contract's own vocabulary, for reference: PMC HBM bytes of the dominant kernel / its duration against 8 TB/s
+                    "hbm": ({"achieved": traffic / (dom_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                             "frac": traffic / (dom_ms * 1e-3) / 1e9 / 8000.0} if traffic and dom_ms > 0 else None),
+                    "note": "path is FP64-VALU/latency bound (not HBM, not MFMA); achieved = algorithmic f64 flops of the dominant "
+                            "kernel per launch / its HIP-event duration",
+                },
+                "cpu_baseline": cpu,
+            }
+            line.update(extras)
+    if rank == 0 and line is not None:
         print(json.dumps(line))
-    pool.close()
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -149,6 +149,10 @@ long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg*
 /* Plain device buffers for chaining the offline entry points without a host round trip (out_is_device / audio_is_device). */
 void* ow_device_alloc(size_t bytes, int device);   /* NULL on failure */
 void ow_device_free(void* ptr, int device);
+/* Page-locked host memory for `out_host` of ow_pool_render: the block copy of a big pool then runs at PCIe rate instead of through
+ * the runtime's staging of pageable memory.  (A pool of one copies 2 KB per block; it does not need this.) */
+void* ow_host_alloc(size_t bytes, int device);     /* NULL on failure */
+void ow_host_free(void* ptr, int device);
 
 /* ---- ML-pipeline stage after the batch render --------------------------------- */
 /* 24-bit PCM quantisers of the reference's two WAV writers.  OW_WAV_ROUND: preamp-bench write_wav_24bit

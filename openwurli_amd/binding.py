@@ -112,6 +112,8 @@ SYMBOLS = {
     "ow_batch_render": (C.c_longlong, [C.POINTER(OwJob), C.c_size_t, C.POINTER(OwBatchCfg), _VP, C.c_size_t, C.c_int]),
     "ow_device_alloc": (_VP, [C.c_size_t, C.c_int]),
     "ow_device_free": (None, [_VP, C.c_int]),
+    "ow_host_alloc": (_VP, [C.c_size_t, C.c_int]),
+    "ow_host_free": (None, [_VP, C.c_int]),
     "ow_wav24_quantize": (C.c_int, [_VP, C.c_size_t, C.c_double, C.c_int, _VP]),
     "ow_wav24_write": (C.c_int, [C.c_char_p, _VP, C.c_size_t, C.c_uint32, C.c_double, C.c_int]),
     "ow_extract_harmonics": (C.c_int, [_VP, C.c_size_t, C.c_size_t, C.c_double, _VP, C.c_size_t, C.c_double, C.c_int, C.c_int, C.c_int,

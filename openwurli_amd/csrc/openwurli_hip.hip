@@ -1556,6 +1556,15 @@ void ow_device_free(void* ptr, int device) {
     if (ptr && hipSetDevice(device) == hipSuccess) hipFree(ptr);
 }
 
+void* ow_host_alloc(size_t bytes, int device) {
+    void* ptr = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&ptr, bytes ? bytes : 1) != hipSuccess) { set_err("ow_host_alloc: hipHostMalloc failed"); return nullptr; }
+    return ptr;
+}
+void ow_host_free(void* ptr, int device) {
+    if (ptr && hipSetDevice(device) == hipSuccess) hipHostFree(ptr);
+}
+
 // ---- ML-pipeline stage after the batch render ---------------------------------------------------------------
 int ow_wav24_quantize(const double* samples, size_t n, double scale, int mode, int32_t* out) {
     if ((!samples || !out) && n) { set_err("ow_wav24_quantize: null argument"); return -1; }

@@ -537,7 +537,9 @@ __global__ __launch_bounds__(64) void k_chain_init(const OwConsts* __restrict__ 
 
 // n oscillator steps with the matrices of `K` (Tremolo::new settle loop tremolo.rs:97-100; CircuitState::warmup
 // gen_tremolo.rs:2071-2075 when K holds the 48 kHz codegen matrices).
-// stagger: leader idx runs idx * stagger additional steps (test hook: decorrelated tremolo phases across the groups of a pool).
+// stagger: leader idx runs idx * stagger additional steps of the WHOLE cell (oscillator + LED + CdS envelope, Tremolo::process) -- the
+// test hook that decorrelates the tremolo phases of a pool's groups; the settle proper (Tremolo::new, tremolo.rs:97-100) steps the
+// oscillator only.
 __global__ __launch_bounds__(64) void k_trem_settle(const OwConsts* __restrict__ K, double* __restrict__ cs, int I, const uint32_t* __restrict__ leaders,
                                                     int n_lead, long long n0, long long stagger = 0) {
     __shared__ TremMats M;
@@ -553,7 +555,8 @@ __global__ __launch_bounds__(64) void k_trem_settle(const OwConsts* __restrict__
     for (long long i = 0; i < n; ++i) {
         int z = 0;
         asm volatile("" : "+v"(z));        // opaque zero: keeps the LDS reads inside the loop (no hoist into 200 live VGPRs)
-        trem_osc_step(t, &P, K, &M + z);
+        if (stagger) trem_cell_r(t, &P, K, &M + z);
+        else trem_osc_step(t, &P, K, &M + z);
     }
     trem_store(t, &P, cs, I, e);
 }

@@ -25,42 +25,72 @@ def unshard(slabs, n_jobs, world):
     return out
 
 
-def batch_render_sharded(jobs, sample_rate, duration_s, render_fn=None, device=None, group=None):
+def batch_render_sharded(jobs, sample_rate, duration_s, render_fn=None, device=None, group=None, timings=None, to_host=True):
     """Render ``jobs`` across the ranks of the default process group; rank 0 returns float32 [n_jobs, n], others None.
 
     ``render_fn(local_jobs) -> array [n_local, n]`` defaults to the HIP batch renderer; tests inject a CPU stand-in
-    to exercise the sharding + gather logic under gloo.
+    to exercise the sharding + gather logic under gloo.  Without an initialised process group this is a world of one
+    (no collective).  ``timings`` (dict) receives ``render_s`` and ``gather_s`` of this rank (device-synchronised);
+    ``to_host=False`` leaves the gathered slabs on rank 0's device and returns the list of per-rank slabs instead
+    (benchmarks: the host-side reassembly of a multi-GB result is not part of the render).
     """
+    import time
     import torch
     import torch.distributed as dist
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    distributed = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if distributed else (0, 1)
     jobs = list(jobs)
     n_jobs = len(jobs)
     n = int(duration_s * sample_rate)
     mine = shard_indices(n_jobs, rank, world)
     n_pad = (n_jobs + world - 1) // world          # equal-sized slabs so one gather suffices
-    backend = dist.get_backend(group)
-    on_gpu = backend == "nccl"
+    on_gpu = (dist.get_backend(group) == "nccl") if distributed else (render_fn is None)
     dev = torch.device("cuda", device if device is not None else torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize(dev)
     slab = torch.zeros((n_pad, n), dtype=torch.float32, device=dev)
+    sync()
+    t0 = time.perf_counter()
     if mine:
         if render_fn is None:
             from . import engine
             if on_gpu:
-                # render straight into a torch-owned HBM buffer (f64), then narrow to the f32 slab: no host round trip
+                # render straight into a torch-owned HBM buffer (f64), then narrow to the f32 slab: no host round trip.
+                # The library writes on its own stream: drain torch's stream first (a recycled block of the caching allocator may
+                # still have torch work pending on it), and synchronise afterwards before torch reads the result.
                 tmp = torch.empty((len(mine), n), dtype=torch.float64, device=dev)
+                torch.cuda.current_stream(dev).synchronize()
                 engine.batch_render([jobs[i] for i in mine], sample_rate, duration_s, device=dev.index, out_device_ptr=tmp.data_ptr(), stride=n)
                 torch.cuda.synchronize(dev)
                 slab[:len(mine)] = tmp.to(torch.float32)
+                del tmp
             else:
                 raise RuntimeError("the HIP renderer needs the nccl backend (a GPU per rank); pass render_fn for CPU tests")
         else:
             local = np.asarray(render_fn([jobs[i] for i in mine]), dtype=np.float32)
             slab[:len(mine)] = torch.from_numpy(local).to(dev)
-    gathered = [torch.zeros_like(slab) for _ in range(world)] if rank == 0 else None
-    dist.gather(slab, gathered, dst=0, group=group)     # the one exchange step
+    sync()
+    t1 = time.perf_counter()
+    if distributed:
+        gathered = [torch.zeros_like(slab) for _ in range(world)] if rank == 0 else None
+        sync()                                      # receive buffers allocated and zeroed before the gather clock starts
+        t2 = time.perf_counter()
+        dist.gather(slab, gathered, dst=0, group=group)     # the one exchange step
+        sync()
+    else:
+        gathered = [slab]
+        t2 = time.perf_counter()
+    t3 = time.perf_counter()
+    if timings is not None:
+        timings["render_s"] = t1 - t0
+        timings["gather_s"] = t3 - t2
+        timings["world_seen"] = world
     if rank != 0:
         return None
+    if not to_host:
+        return gathered
     return unshard([g.cpu().numpy() for g in gathered], n_jobs, world)
 
 

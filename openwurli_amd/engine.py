@@ -199,6 +199,29 @@ class EnginePool:
         binding.raise_if_error(self._lib)
         return None
 
+    def render_into(self, host_ptr, stride, length):
+        """``ow_pool_render`` into caller memory: float32 [n, stride] at address ``host_ptr`` (e.g. a block from ``alloc_host_block``)."""
+        self._lib.ow_pool_render(self._h, C.c_void_p(int(host_ptr)), int(stride), int(length))
+        binding.raise_if_error(self._lib)
+
+    def alloc_host_block(self, length, device=0):
+        """Page-locked float32 [n, length] block for ``render_into`` -> (address, stride)."""
+        ptr = self._lib.ow_host_alloc(4 * self.n * int(length), int(device))
+        if not ptr:
+            raise OwError(binding.take_error(self._lib))
+        return (ptr, int(length))
+
+    def free_host_block(self, block, device=0):
+        self._lib.ow_host_free(C.c_void_p(block[0]), int(device))
+
+    def stagger_tremolo(self, n_groups):
+        """Test / bench hook (openwurli_hip_test.h): cut the pool into ``n_groups`` tremolo phase groups with decorrelated phases."""
+        if self._lib.ow_test_pool_stagger_tremolo(self._h, int(n_groups)) != 0:
+            raise OwError(binding.take_error(self._lib))
+
+    def tremolo_groups(self):
+        return int(self._lib.ow_test_pool_tremolo_groups(self._h))
+
     def midi(self, events):
         """Apply a numpy structured array of events (dtype binding.MIDI_DTYPE) in order."""
         ev = np.ascontiguousarray(events, dtype=np.dtype(binding.MIDI_DTYPE))
