@@ -138,6 +138,7 @@ class Workers {
     uint64_t gen_ = 0;
     bool stop_ = false;
 };
+#define OW_MAX_STAGES 8
 #define OW_MAX_SLICES 64   // upper bound of the slices one dispatch is cut into (scratch arrays live on the stack)
 
 struct Slot {  // VoiceSlot, engine.rs:39-62 (the Voice objects themselves live in HBM); state and note live in ow_engine's
@@ -247,6 +248,15 @@ struct ow_pool {
     std::vector<uint8_t> transient;   // per engine: device status after the previous block (OwEngineOut::transient)
     bool lists_valid = false;
     int lists_e0 = -1, lists_ne = -1;
+    // Staged render (render_range): the range is cut into NP engine stages, each on its own stream; the voice kernel of stage k
+    // starts when the voice kernel of stage k-1 has finished, so the latency-bound chain kernels (and the output copy) of stage k-1
+    // run beside the issue-bound voice kernel of stage k.  Stage boundaries are slice boundaries of the packed voice lists.
+    int slice_T = 1, slice_per = 0;                             // slices the lists were packed in, engines per slice
+    struct SliceStart { uint32_t s = 0, g = 0, t = 0; } slice_start[OW_MAX_SLICES + 1];   // entry offsets of every slice in the three lists
+    hipStream_t pipe_stream[OW_MAX_STAGES] = {};               // [0] == stream
+    hipEvent_t ev_ready = nullptr, ev_voice_done[OW_MAX_STAGES] = {}, ev_stage_done[OW_MAX_STAGES] = {};
+    hipEvent_t ev_stage[OW_MAX_STAGES][5] = {};                // profiling: before voices, after voices, before preamp, after preamp, after post
+    int last_np = 1;
     uint32_t* d_op_engines = nullptr; // engines that have pending ops this block (k_apply_ops runs one block per entry)
     uint32_t* h_op_engines = nullptr; // pinned, I entries
     std::vector<ow_engine*> engines;
@@ -510,6 +520,15 @@ static size_t effective_cpus() {
 }
 size_t Workers::host_threads() { return std::min<size_t>(effective_cpus(), OW_MAX_SLICES); }
 
+// Stages of the staged render: big ranges only (a stage must still fill the chip: 16 384 engines = 8 voice wavefronts per SIMD slot).
+// OW_PIPE=n forces the count (1 = one stream, the round-1 behaviour).
+static inline int pipeline_stages(int ne) {
+    static const int forced = [] { const char* env = std::getenv("OW_PIPE"); const int v = env ? std::atoi(env) : 0; return (v >= 1 && v <= OW_MAX_STAGES) ? v : 0; }();
+    if (ne < 16384) return 1;
+    if (forced) return forced;
+    return ne >= 65536 ? 4 : 2;
+}
+
 // Deal the sounding voices of engines [e0, e0+ne) into wavefront-sized blocks (see ow_kernels.h, "Packed dispatch").
 // general = engines whose status after the previous block reported a transient phase, or that receive ops in this block (a note-on
 // starts an onset ramp and an attack-noise burst, a note-off a damper phase; nothing else starts one).
@@ -517,10 +536,15 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
     // Big ranges are cut into T engine slices that are packed independently (each slice starts on a block boundary, so at most
     // T - 1 blocks are less full than they could be): pass 1 sizes the three lists of every slice, a prefix sum places them,
     // pass 2 writes the entries.
-    const size_t T = ne >= 16384 ? std::min<size_t>(effective_cpus(), 32) : 1;
+    const int NP = pipeline_stages(ne);
+    size_t T = ne >= 16384 ? std::min<size_t>(effective_cpus(), 32) : 1;
+    if (NP > 1) T = std::max<size_t>(NP, T - T % (size_t)NP);   // stages are whole numbers of slices
     const int per = (int)((ne + T - 1) / T);
-    struct Fill { uint32_t s = 0, g = 0, t = 0; };
-    Fill size[OW_MAX_SLICES], start[OW_MAX_SLICES + 1];      // T <= 32: on the stack, no allocation in the render path
+    using Fill = ow_pool::SliceStart;
+    Fill size[OW_MAX_SLICES];
+    Fill* start = p->slice_start;                              // T <= 32; kept: stage k launches the blocks of its slices
+    start[0] = Fill();
+    p->slice_T = (int)T; p->slice_per = per;
     auto pack = [&](size_t t, uint32_t* S, uint32_t* G, uint32_t* Tl, Fill& f) {   // S == nullptr: count only
         auto pad = [](uint32_t* a, uint32_t& n) { while (n & 63u) { if (a) a[n] = 0xFFFFFFFFu; ++n; } };
         auto put = [&](uint32_t* a, uint32_t& n, uint32_t e, uint64_t mask, bool own_block) {
@@ -567,7 +591,8 @@ static void launch_tremolo(ow_pool* p, hipStream_t tt, double* rbuf, int n_os) {
 
 // One render of `len` samples for engines [e0, e0+ne).  with_voices=false skips the voice kernels
 // (warm-up of engines whose voices were just freed).
-void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
+// out_host != nullptr: rows [e0, e0+ne) of the block are copied to out_host[(e - e0) * out_stride] as their stages finish.
+void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, float* out_host = nullptr, size_t out_stride = 0) {
     const int I = (int)p->I;
     const int L = (int)len, Lcap = (int)p->Lcap;
     hipStream_t st = p->stream, tt = p->stream_trem;
@@ -676,36 +701,66 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices) {
         owdev::k_apply_ops<<<dim3(n_act), dim3(64), 0, st>>>(p->dK, p->d_nt, p->d_vrec, p->d_args, p->d_ops, p->d_op_engines);
     }
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[1], st));
-    if (with_voices && (any_main || any_steal)) {
+    const bool voices = with_voices && (any_main || any_steal);
+    if (voices) {
         // the lists depend on masks, pending ops (any_dirty) and the transient flags of the previous block (post_render_host)
         if (!p->lists_valid || any_dirty || p->lists_e0 != e0 || p->lists_ne != ne) build_voice_lists(p, e0, ne);
         p->lists_valid = !any_dirty;     // engines with ops were classified "general" for this block only
-        if (p->vl_steady.n_blocks)
-            owdev::k_voice_steady<<<dim3(p->vl_steady.n_blocks), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_steady.d, p->d_sum, p->d_eout, I, L, Lcap);
-        if (p->vl_general.n_blocks) {
-            // sparse general list (played input): tabulated phase gains; most engines in it (everything re-struck): plain variant
-            if ((size_t)p->vl_general.n_blocks * 4 < (size_t)ne)
-                owdev::k_voice<true><<<dim3(p->vl_general.n_blocks), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_general.d, p->d_sum, p->d_eout, I, L, Lcap, 0);
-            else
-                owdev::k_voice<false><<<dim3(p->vl_general.n_blocks), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_general.d, p->d_sum, p->d_eout, I, L, Lcap, 0);
-        }
-        if (p->vl_steal.n_blocks)
-            owdev::k_voice<false><<<dim3(p->vl_steal.n_blocks), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_steal.d, p->d_sum, p->d_eout, I, L, Lcap, 1);
     }
-    if (p->profiling) HIP_OK(hipEventRecord(p->ev[2], st));
-    HIP_OK(hipStreamWaitEvent(st, p->ev_trem[rb_now_idx], 0));
-    if (p->profiling) HIP_OK(hipEventRecord(p->ev[3], st));
-    if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)
-        owdev::k_preamp_mel<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
-                                                                      p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, e0, ne);
-    else
-        owdev::k_preamp<<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, rb_now, p->d_lead, p->d_pre, I, L, Lcap, e0, ne);
-    if (p->profiling) HIP_OK(hipEventRecord(p->ev[4], st));
-    if (p->hc.oversample)
-        owdev::k_post<true><<<dim3((ne + 31) / 32), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, Lcap, e0, ne);
-    else
-        owdev::k_post<false><<<dim3((ne + 63) / 64), dim3(64), 0, st>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, Lcap, e0, ne);
-    if (p->profiling) HIP_OK(hipEventRecord(p->ev[5], st));
+    // ---- stages (see ow_pool::slice_start).  Without voices the lists are not built: one stage.
+    const int NP = voices ? std::min(pipeline_stages(ne), p->slice_T) : 1;
+    p->last_np = NP;
+    if (NP > 1) HIP_OK(hipEventRecord(p->ev_ready, st));      // args, ops and voice lists are in place
+    const bool tabs = (size_t)p->vl_general.n_blocks * 4 < (size_t)ne;   // sparse general list (played input): tabulated phase gains
+    for (int k = 0; k < NP; ++k) {
+        hipStream_t s = p->pipe_stream[k];                    // [0] == st
+        const int t0 = k * p->slice_T / NP, t1 = (k + 1) * p->slice_T / NP;
+        const int se0 = NP == 1 ? e0 : e0 + std::min(ne, t0 * p->slice_per);
+        const int se1 = NP == 1 ? e0 + ne : e0 + std::min(ne, t1 * p->slice_per);
+        const int sne = se1 - se0;
+        if (k > 0) {
+            HIP_OK(hipStreamWaitEvent(s, p->ev_ready, 0));
+            HIP_OK(hipStreamWaitEvent(s, p->ev_voice_done[k - 1], 0));   // voice kernels run one stage after the other ...
+        }
+        if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][0], s));
+        if (voices) {
+            const ow_pool::SliceStart& a0 = p->slice_start[NP == 1 ? 0 : t0];
+            const ow_pool::SliceStart& a1 = p->slice_start[NP == 1 ? p->slice_T : t1];
+            const unsigned bs = (a1.s - a0.s) / 64, bg = (a1.g - a0.g) / 64, bt = (a1.t - a0.t) / 64;
+            if (bs)
+                owdev::k_voice_steady<<<dim3(bs), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_steady.d + a0.s, p->d_sum, p->d_eout, I, L, Lcap);
+            if (bg) {
+                if (tabs) owdev::k_voice<true><<<dim3(bg), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_general.d + a0.g, p->d_sum, p->d_eout, I, L, Lcap, 0);
+                else owdev::k_voice<false><<<dim3(bg), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_general.d + a0.g, p->d_sum, p->d_eout, I, L, Lcap, 0);
+            }
+            if (bt)
+                owdev::k_voice<false><<<dim3(bt), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_steal.d + a0.t, p->d_sum, p->d_eout, I, L, Lcap, 1);
+        }
+        if (NP > 1 && k + 1 < NP) HIP_OK(hipEventRecord(p->ev_voice_done[k], s));   // ... so that this stage's chain runs beside the next stage's voices
+        if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][1], s));
+        HIP_OK(hipStreamWaitEvent(s, p->ev_trem[rb_now_idx], 0));
+        if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][2], s));
+        if (sne > 0) {
+            if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)
+                owdev::k_preamp_mel<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
+                                                                             p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne);
+            else
+                owdev::k_preamp<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, rb_now, p->d_lead, p->d_pre, I, L, Lcap, se0, sne);
+        }
+        if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][3], s));
+        if (sne > 0) {
+            if (p->hc.oversample)
+                owdev::k_post<true><<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, Lcap, se0, sne);
+            else
+                owdev::k_post<false><<<dim3((sne + 63) / 64), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, Lcap, se0, sne);
+        }
+        if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][4], s));
+        if (out_host && sne > 0)          // the stage's rows go out while the later stages still compute
+            HIP_OK(hipMemcpy2DAsync(out_host + (size_t)(se0 - e0) * out_stride, out_stride * sizeof(float), p->d_out + (size_t)se0 * p->Lcap,
+                                    p->Lcap * sizeof(float), len * sizeof(float), (size_t)sne, hipMemcpyDeviceToHost, s));
+        if (k > 0) HIP_OK(hipEventRecord(p->ev_stage_done[k], s));
+    }
+    for (int k = 1; k < NP; ++k) HIP_OK(hipStreamWaitEvent(st, p->ev_stage_done[k], 0));
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(p->h_eout + e0, p->d_eout + e0, sizeof(OwEngineOut) * ne, hipMemcpyDeviceToHost, st));
 }
@@ -783,10 +838,16 @@ void collect_profile(ow_pool* p) {
     if (!p->profiling) return;
     hipEventSynchronize(p->ev[7]);   // in a small pool the block-ahead tremolo outlasts the audio stream; profiling waits for it, a normal render does not
     hipEventElapsedTime(&p->last_ms[0], p->ev[0], p->ev[1]);   // ops
-    hipEventElapsedTime(&p->last_ms[1], p->ev[1], p->ev[2]);   // voices
     hipEventElapsedTime(&p->last_ms[2], p->ev[6], p->ev[7]);   // tremolo (own stream)
-    hipEventElapsedTime(&p->last_ms[3], p->ev[3], p->ev[4]);   // preamp
-    hipEventElapsedTime(&p->last_ms[4], p->ev[4], p->ev[5]);   // post
+    // per-stage intervals on the stage streams, summed: voices run one stage after the other (the sum is the voice kernels' time, with
+    // the previous stage's chain kernels running beside them); preamp / post of a stage overlap the next stage's voices
+    float v = 0.f, pr = 0.f, po = 0.f, x = 0.f;
+    for (int k = 0; k < p->last_np; ++k) {
+        hipEventElapsedTime(&x, p->ev_stage[k][0], p->ev_stage[k][1]); v += x;
+        hipEventElapsedTime(&x, p->ev_stage[k][2], p->ev_stage[k][3]); pr += x;
+        hipEventElapsedTime(&x, p->ev_stage[k][3], p->ev_stage[k][4]); po += x;
+    }
+    p->last_ms[1] = v; p->last_ms[3] = pr; p->last_ms[4] = po;
 }
 
 // WurliEngine::warm_up (engine.rs:261-270): 0.6 s of render() in 512-sample blocks
@@ -849,6 +910,14 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&p->stream_trem, hipStreamNonBlocking));
     for (auto& e : p->ev) HIP_OK(hipEventCreate(&e));
+    p->pipe_stream[0] = p->stream;
+    for (int k = 1; k < OW_MAX_STAGES; ++k) HIP_OK(hipStreamCreateWithFlags(&p->pipe_stream[k], hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming));
+    for (int k = 0; k < OW_MAX_STAGES; ++k) {
+        HIP_OK(hipEventCreateWithFlags(&p->ev_voice_done[k], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&p->ev_stage_done[k], hipEventDisableTiming));
+        for (auto& e : p->ev_stage[k]) HIP_OK(hipEventCreate(&e));
+    }
     for (auto& e : p->ev_trem) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_OK(hipMalloc(&p->d_trem_backup, sizeof(double) * 18 * n_engines));
     HIP_OK(hipMalloc(&p->dK, sizeof(OwConsts)));
@@ -948,6 +1017,13 @@ void pool_destroy(ow_pool* p) {
     if (p->h_snap) hipHostFree(p->h_snap);
     hipHostFree(p->h_args); hipHostFree(p->h_eout);
     for (auto& e : p->ev) if (e) hipEventDestroy(e);
+    for (int k = 1; k < OW_MAX_STAGES; ++k) if (p->pipe_stream[k]) { hipStreamSynchronize(p->pipe_stream[k]); hipStreamDestroy(p->pipe_stream[k]); }
+    if (p->ev_ready) hipEventDestroy(p->ev_ready);
+    for (int k = 0; k < OW_MAX_STAGES; ++k) {
+        if (p->ev_voice_done[k]) hipEventDestroy(p->ev_voice_done[k]);
+        if (p->ev_stage_done[k]) hipEventDestroy(p->ev_stage_done[k]);
+        for (auto& e : p->ev_stage[k]) if (e) hipEventDestroy(e);
+    }
     for (auto& e : p->ev_trem) if (e) hipEventDestroy(e);
     if (p->d_trem_backup) hipFree(p->d_trem_backup);
     if (p->stream_trem) hipStreamDestroy(p->stream_trem);
@@ -1027,10 +1103,7 @@ void ow_pool_render(ow_pool* p, float* out_host, size_t out_stride, size_t len) 
         if (len > p->Lcap) { HIP_OK(hipStreamSynchronize(p->stream)); alloc_stream_buffers(p, len); }  // auto-grow, engine.rs:430
         static const bool hostprof = std::getenv("OW_HOST_PROFILE") != nullptr;
         auto t0 = std::chrono::steady_clock::now();
-        render_range(p, 0, (int)p->I, len, true);
-        if (out_host)
-            HIP_OK(hipMemcpy2DAsync(out_host, out_stride * sizeof(float), p->d_out, p->Lcap * sizeof(float), len * sizeof(float), p->I,
-                                    hipMemcpyDeviceToHost, p->stream));
+        render_range(p, 0, (int)p->I, len, true, out_host, out_stride);
         auto t1 = std::chrono::steady_clock::now();
         HIP_OK(hipStreamSynchronize(p->stream));
         auto t2 = std::chrono::steady_clock::now();
@@ -1049,7 +1122,7 @@ void ow_pool_render(ow_pool* p, float* out_host, size_t out_stride, size_t len) 
     if (!ok) {
         // "never fails, degrades to silence" (engine.rs:450-458 does the same for numeric failure): every row of the
         // caller's block is written.  Drain the stream first so that an output copy already queued cannot land after the zeros.
-        hipStreamSynchronize(p->stream);
+        for (int k = 0; k < OW_MAX_STAGES; ++k) if (p->pipe_stream[k]) hipStreamSynchronize(p->pipe_stream[k]);
         if (out_host && out_stride >= len)
             for (size_t e = 0; e < p->I; ++e) std::memset(out_host + e * out_stride, 0, len * sizeof(float));
         if (p->d_out && len <= p->Lcap) hipMemset2D(p->d_out, p->Lcap * sizeof(float), 0, len * sizeof(float), p->I);   // the HBM copy of the block too
