@@ -248,9 +248,9 @@ struct ow_pool {
     std::vector<uint8_t> transient;   // per engine: device status after the previous block (OwEngineOut::transient)
     bool lists_valid = false;
     int lists_e0 = -1, lists_ne = -1;
-    // Staged render (render_range): the range is cut into NP engine stages, each on its own stream; the voice kernel of stage k
-    // starts when the voice kernel of stage k-1 has finished, so the latency-bound chain kernels (and the output copy) of stage k-1
-    // run beside the issue-bound voice kernel of stage k.  Stage boundaries are slice boundaries of the packed voice lists.
+    // Staged render (render_range), used when a big pool's block is copied to the host: the range is cut into NP engine stages, each
+    // on its own stream; the kernels of stage k start when those of stage k-1 have finished, so the device-to-host copy of stage k-1
+    // (copy engine) runs beside the kernels of stage k.  Stage boundaries are slice boundaries of the packed voice lists.
     int slice_T = 1, slice_per = 0;                             // slices the lists were packed in, engines per slice
     struct SliceStart { uint32_t s = 0, g = 0, t = 0; } slice_start[OW_MAX_SLICES + 1];   // entry offsets of every slice in the three lists
     hipStream_t pipe_stream[OW_MAX_STAGES] = {};               // [0] == stream
@@ -520,13 +520,20 @@ static size_t effective_cpus() {
 }
 size_t Workers::host_threads() { return std::min<size_t>(effective_cpus(), OW_MAX_SLICES); }
 
-// Stages of the staged render: big ranges only (a stage must still fill the chip: 16 384 engines = 8 voice wavefronts per SIMD slot).
-// OW_PIPE=n forces the count (1 = one stream, the round-1 behaviour).
-static inline int pipeline_stages(int ne) {
+// Stages of the staged render: only when the block goes to the host, and for big ranges only (a stage must still fill the chip:
+// 16 384 engines = 8 voice wavefronts per SIMD slot).  OW_PIPE=n forces the count (1 = never staged).
+static inline int pipeline_stages(int ne, bool to_host) {
     static const int forced = [] { const char* env = std::getenv("OW_PIPE"); const int v = env ? std::atoi(env) : 0; return (v >= 1 && v <= OW_MAX_STAGES) ? v : 0; }();
-    if (ne < 16384) return 1;
+    if (ne < 32768) return 1;
     if (forced) return forced;
-    return ne >= 65536 ? 4 : 2;
+    return to_host ? 4 : 1;
+}
+// OW_PIPE_OVERLAP=1: chain the stages voice kernel to voice kernel instead of stage to stage, so that the chain kernels of stage k run
+// beside the voice kernel of stage k+1.  Measured slower at every stage count (DESIGN.md "what did not work"); kept as a switch so the
+// measurement can be repeated.
+static inline bool pipeline_overlap() {
+    static const bool on = [] { const char* env = std::getenv("OW_PIPE_OVERLAP"); return env && env[0] == '1'; }();
+    return on;
 }
 
 // Deal the sounding voices of engines [e0, e0+ne) into wavefront-sized blocks (see ow_kernels.h, "Packed dispatch").
@@ -536,7 +543,7 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
     // Big ranges are cut into T engine slices that are packed independently (each slice starts on a block boundary, so at most
     // T - 1 blocks are less full than they could be): pass 1 sizes the three lists of every slice, a prefix sum places them,
     // pass 2 writes the entries.
-    const int NP = pipeline_stages(ne);
+    const int NP = pipeline_stages(ne, true);                  // stage boundaries exist whether or not this block uses them
     size_t T = ne >= 16384 ? std::min<size_t>(effective_cpus(), 32) : 1;
     if (NP > 1) T = std::max<size_t>(NP, T - T % (size_t)NP);   // stages are whole numbers of slices
     const int per = (int)((ne + T - 1) / T);
@@ -708,7 +715,8 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         p->lists_valid = !any_dirty;     // engines with ops were classified "general" for this block only
     }
     // ---- stages (see ow_pool::slice_start).  Without voices the lists are not built: one stage.
-    const int NP = voices ? std::min(pipeline_stages(ne), p->slice_T) : 1;
+    const int NP = voices ? std::min(pipeline_stages(ne, out_host != nullptr), p->slice_T) : 1;
+    const bool overlap = pipeline_overlap();
     p->last_np = NP;
     if (NP > 1) HIP_OK(hipEventRecord(p->ev_ready, st));      // args, ops and voice lists are in place
     const bool tabs = (size_t)p->vl_general.n_blocks * 4 < (size_t)ne;   // sparse general list (played input): tabulated phase gains
@@ -720,7 +728,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         const int sne = se1 - se0;
         if (k > 0) {
             HIP_OK(hipStreamWaitEvent(s, p->ev_ready, 0));
-            HIP_OK(hipStreamWaitEvent(s, p->ev_voice_done[k - 1], 0));   // voice kernels run one stage after the other ...
+            HIP_OK(hipStreamWaitEvent(s, p->ev_voice_done[k - 1], 0));   // the kernels of the stages run one stage after the other
         }
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][0], s));
         if (voices) {
@@ -736,7 +744,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
             if (bt)
                 owdev::k_voice<false><<<dim3(bt), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_steal.d + a0.t, p->d_sum, p->d_eout, I, L, Lcap, 1);
         }
-        if (NP > 1 && k + 1 < NP) HIP_OK(hipEventRecord(p->ev_voice_done[k], s));   // ... so that this stage's chain runs beside the next stage's voices
+        if (overlap && k + 1 < NP) HIP_OK(hipEventRecord(p->ev_voice_done[k], s));
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][1], s));
         HIP_OK(hipStreamWaitEvent(s, p->ev_trem[rb_now_idx], 0));
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][2], s));
@@ -755,6 +763,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
                 owdev::k_post<false><<<dim3((sne + 63) / 64), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, Lcap, se0, sne);
         }
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][4], s));
+        if (!overlap && k + 1 < NP) HIP_OK(hipEventRecord(p->ev_voice_done[k], s));   // the next stage computes while this one's rows are copied
         if (out_host && sne > 0)          // the stage's rows go out while the later stages still compute
             HIP_OK(hipMemcpy2DAsync(out_host + (size_t)(se0 - e0) * out_stride, out_stride * sizeof(float), p->d_out + (size_t)se0 * p->Lcap,
                                     p->Lcap * sizeof(float), len * sizeof(float), (size_t)sne, hipMemcpyDeviceToHost, s));

@@ -278,7 +278,12 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
 // only the fields that path needs (fewer registers) and has no phase tests in its sample loop; engines that fail the
 // test are left to k_voice.  Arithmetic per block is the same as VoiceRegs::step<true>.
 struct VoiceSteady {
-    double s[7], c[7], env[7], drift[7], cos_inc[7], sin_inc[7], phase_inc[7], amp[7], decay[7];
+    // ae = amplitude * envelope carried as ONE recurrence (ae *= decay_mult): the modal sum is then one FMA per mode, where
+    // reed.rs:276 multiplies amplitude * s * onset * envelope (two multiplies + add with onset == 1).  The product is reassociated and
+    // rounded once per sample instead of twice: a relative random walk of ~1e-16 per sample against the reference's envelope, 3e-14
+    // after 10 s of a voice's life, inside the 1e-12 bar of the voice-sum tap (the general kernel keeps the reference's order).  The
+    // record keeps `envelope`: it is recovered as ae / amplitude when the block ends.
+    double s[7], c[7], ae[7], drift[7], cos_inc[7], sin_inc[7], phase_inc[7], decay[7];
     double ci[7], si[7];   // jitter-corrected rotation (reed.rs:281-283): depends on drift only, which changes every 16 samples
     double q, ds, gain;
     double beta, revert, diffusion;   // the voice's own pickup beta / jitter constants (VF_BETA..), read once per kernel: a load inside the
@@ -325,12 +330,12 @@ struct VoiceSteady {
         double sum = 0.0;
 #pragma unroll
         for (int m = 0; m < 7; ++m) {
-            sum += amp[m] * s[m] * env[m];                 // onset == 1.0 (x * 1.0 == x)
+            sum += s[m] * ae[m];                           // onset == 1.0 (x * 1.0 == x)
             const double s_new = s[m] * ci[m] + c[m] * si[m];
             const double c_new = c[m] * ci[m] - s[m] * si[m];
             s[m] = s_new;
             c[m] = c_new;
-            env[m] *= decay[m];
+            ae[m] *= decay[m];
         }
         const double x = 0.0 + sum;
         double y = x * ds;
@@ -379,9 +384,9 @@ __global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict_
         if ((flags & 1u) || smp < onset_n || noise_rem > 0u) eout[w.e].transient = 2u;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-            v.s[i] = rec[(VF_S + i) * 64]; v.c[i] = rec[(VF_C + i) * 64]; v.env[i] = rec[(VF_ENV + i) * 64];
+            v.s[i] = rec[(VF_S + i) * 64]; v.c[i] = rec[(VF_C + i) * 64]; v.ae[i] = rec[(VF_AMP + i) * 64] * rec[(VF_ENV + i) * 64];
             v.drift[i] = rec[(VF_DRIFT + i) * 64]; v.cos_inc[i] = rec[(VF_COS_INC + i) * 64]; v.sin_inc[i] = rec[(VF_SIN_INC + i) * 64];
-            v.phase_inc[i] = rec[(VF_PHASE_INC + i) * 64]; v.amp[i] = rec[(VF_AMP + i) * 64]; v.decay[i] = rec[(VF_DECAY + i) * 64];
+            v.phase_inc[i] = rec[(VF_PHASE_INC + i) * 64]; v.decay[i] = rec[(VF_DECAY + i) * 64];
         }
         v.q = rec[VF_Q * 64]; v.ds = rec[VF_DS * 64]; v.gain = rec[VF_GAIN * 64];
         v.beta = rec[VF_BETA * 64]; v.revert = rec[VF_JREV * 64]; v.diffusion = rec[VF_JDIFF * 64];
@@ -414,9 +419,13 @@ __global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict_
         bool all_quiet = true;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-            rec[(VF_S + i) * 64] = v.s[i]; rec[(VF_C + i) * 64] = v.c[i]; rec[(VF_ENV + i) * 64] = v.env[i]; rec[(VF_DRIFT + i) * 64] = v.drift[i];
-            fin = fin && isfinite(v.s[i]) && isfinite(v.c[i]) && isfinite(v.env[i]);
-            all_quiet = all_quiet && (fabs(v.amp[i] * v.env[i]) <= 1e-4);
+            // envelope = ae / amplitude (amplitude read again here rather than held in 14 registers across the block); a mode without
+            // amplitude contributes nothing whatever its envelope is: it keeps decaying by the closed form
+            const double amp = rec[(VF_AMP + i) * 64];
+            const double env = amp != 0.0 ? v.ae[i] / amp : rec[(VF_ENV + i) * 64] * pow(v.decay[i], (double)L);
+            rec[(VF_S + i) * 64] = v.s[i]; rec[(VF_C + i) * 64] = v.c[i]; rec[(VF_ENV + i) * 64] = env; rec[(VF_DRIFT + i) * 64] = v.drift[i];
+            fin = fin && isfinite(v.s[i]) && isfinite(v.c[i]) && isfinite(v.ae[i]);
+            all_quiet = all_quiet && (fabs(v.ae[i]) <= 1e-4);
         }
         rec[VF_Q * 64] = v.q;
         rec[VF_SAMPLE * 64] = bitsd(v.sample);
