@@ -78,7 +78,7 @@ typedef struct ow_midi_event {
     float value;
 } ow_midi_event;
 void ow_pool_midi(ow_pool*, const ow_midi_event* events, size_t n_events);
-/* Device pointer of the last rendered block, f32 [n_engines][*stride]. */
+/* Device pointer of the last rendered block, f32 [n_engines][*stride]; *stride = the length of that block (rows are packed). */
 const float* ow_pool_device_output(const ow_pool*, size_t* stride);
 /* Stage-wise taps of the last rendered block, copied to host (parity tests): voice sum f64 [n_engines][len]. */
 int ow_pool_read_voice_sum(ow_pool*, double* out_host, size_t out_stride, size_t len);

@@ -234,6 +234,8 @@ struct ow_pool {
     double* d_rbuf = nullptr;
     double* d_pre = nullptr;
     float* d_out = nullptr;
+    size_t out_ld = 0;                // row stride of d_out for the block it holds: rows are packed at the block length, so that the copy of
+                                      // a block to the host is ONE linear transfer (copy engine) instead of a pitched one (blit kernel)
     OwEngineArgs* d_args = nullptr;
     OwEngineOut* d_eout = nullptr;
     OwOp* d_ops = nullptr;
@@ -520,13 +522,13 @@ static size_t effective_cpus() {
 }
 size_t Workers::host_threads() { return std::min<size_t>(effective_cpus(), OW_MAX_SLICES); }
 
-// Stages of the staged render: only when the block goes to the host, and for big ranges only (a stage must still fill the chip:
-// 16 384 engines = 8 voice wavefronts per SIMD slot).  OW_PIPE=n forces the count (1 = never staged).
+// Stages of the staged render.  Off by default: OW_PIPE=n (2..8) cuts big ranges (>= 32 768 engines) into n engine stages on their own
+// streams, chained stage to stage, so that the output copy of a stage runs beside the kernels of the next one.
 static inline int pipeline_stages(int ne, bool to_host) {
     static const int forced = [] { const char* env = std::getenv("OW_PIPE"); const int v = env ? std::atoi(env) : 0; return (v >= 1 && v <= OW_MAX_STAGES) ? v : 0; }();
+    (void)to_host;
     if (ne < 32768) return 1;
-    if (forced) return forced;
-    return to_host ? 4 : 1;
+    return forced ? forced : 1;       // measured: stages cost more than the copy overlap they buy ("what did not work")
 }
 // OW_PIPE_OVERLAP=1: chain the stages voice kernel to voice kernel instead of stage to stage, so that the chain kernels of stage k run
 // beside the voice kernel of stage k+1.  Measured slower at every stage count (DESIGN.md "what did not work"); kept as a switch so the
@@ -602,6 +604,7 @@ static void launch_tremolo(ow_pool* p, hipStream_t tt, double* rbuf, int n_os) {
 void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, float* out_host = nullptr, size_t out_stride = 0) {
     const int I = (int)p->I;
     const int L = (int)len, Lcap = (int)p->Lcap;
+    p->out_ld = len;
     hipStream_t st = p->stream, tt = p->stream_trem;
     // ---- tremolo stream: CdS cell resistance of this block (already there if the block-ahead speculation hit)
     const int n_os = L * (p->hc.oversample ? 2 : 1);
@@ -758,15 +761,18 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][3], s));
         if (sne > 0) {
             if (p->hc.oversample)
-                owdev::k_post<true><<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, Lcap, se0, sne);
+                owdev::k_post<true><<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, L, se0, sne);
             else
-                owdev::k_post<false><<<dim3((sne + 63) / 64), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, Lcap, se0, sne);
+                owdev::k_post<false><<<dim3((sne + 63) / 64), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, L, se0, sne);
         }
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][4], s));
         if (!overlap && k + 1 < NP) HIP_OK(hipEventRecord(p->ev_voice_done[k], s));   // the next stage computes while this one's rows are copied
-        if (out_host && sne > 0)          // the stage's rows go out while the later stages still compute
-            HIP_OK(hipMemcpy2DAsync(out_host + (size_t)(se0 - e0) * out_stride, out_stride * sizeof(float), p->d_out + (size_t)se0 * p->Lcap,
-                                    p->Lcap * sizeof(float), len * sizeof(float), (size_t)sne, hipMemcpyDeviceToHost, s));
+        if (out_host && sne > 0) {        // the stage's rows go out while the later stages still compute
+            float* dst = out_host + (size_t)(se0 - e0) * out_stride;
+            const float* src = p->d_out + (size_t)se0 * len;
+            if (out_stride == len) HIP_OK(hipMemcpyAsync(dst, src, sizeof(float) * len * (size_t)sne, hipMemcpyDeviceToHost, s));
+            else HIP_OK(hipMemcpy2DAsync(dst, out_stride * sizeof(float), src, len * sizeof(float), len * sizeof(float), (size_t)sne, hipMemcpyDeviceToHost, s));
+        }
         if (k > 0) HIP_OK(hipEventRecord(p->ev_stage_done[k], s));
     }
     for (int k = 1; k < NP; ++k) HIP_OK(hipStreamWaitEvent(st, p->ev_stage_done[k], 0));
@@ -1134,13 +1140,13 @@ void ow_pool_render(ow_pool* p, float* out_host, size_t out_stride, size_t len) 
         for (int k = 0; k < OW_MAX_STAGES; ++k) if (p->pipe_stream[k]) hipStreamSynchronize(p->pipe_stream[k]);
         if (out_host && out_stride >= len)
             for (size_t e = 0; e < p->I; ++e) std::memset(out_host + e * out_stride, 0, len * sizeof(float));
-        if (p->d_out && len <= p->Lcap) hipMemset2D(p->d_out, p->Lcap * sizeof(float), 0, len * sizeof(float), p->I);   // the HBM copy of the block too
+        if (p->d_out && len <= p->Lcap) { hipMemset(p->d_out, 0, sizeof(float) * len * p->I); p->out_ld = len; }   // the HBM copy of the block too
     }
 }
 
 const float* ow_pool_device_output(const ow_pool* p, size_t* stride) {
     if (!p) return nullptr;
-    if (stride) *stride = p->Lcap;
+    if (stride) *stride = p->out_ld;
     return p->d_out;
 }
 
@@ -1960,7 +1966,7 @@ int ow_alias_audit_run(const uint8_t* notes, const uint8_t* velocities, size_t n
             const size_t len = std::min<size_t>(1024, total - pos);
             ow_pool_render(pool, nullptr, 0, len);
             owdev::k_audit_gather<<<dim3((unsigned)((len + 255) / 256), (unsigned)n), dim3(256), 0, pool->stream>>>(
-                pool->d_out, pool->Lcap, d_sig.as<double>(), total, pos, (uint32_t)len);
+                pool->d_out, pool->out_ld, d_sig.as<double>(), total, pos, (uint32_t)len);
             pos += len;
         }
         HIP_OK(hipGetLastError());

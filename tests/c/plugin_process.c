@@ -277,7 +277,7 @@ static int cmd_fault(size_t n_eng) {
     if (!host) return 2;
     for (size_t e = 0; e < n_eng; ++e) { ow_engine* en = ow_pool_engine(pool, e); ow_engine_note_on(en, (uint8_t)(40 + e % 40), 0.8f); }
     for (int i = 0; i < 3; ++i) ow_pool_render(pool, host, stride, L);
-    for (size_t i = 0; i < n_eng * stride; ++i) if (fabs((double)host[i]) > peak_before) peak_before = fabs((double)host[i]);
+    for (size_t e = 0; e < n_eng; ++e) for (size_t i = 0; i < L; ++i) if (fabs((double)host[e * stride + i]) > peak_before) peak_before = fabs((double)host[e * stride + i]);
     for (size_t i = 0; i < n_eng * stride; ++i) host[i] = 123.0f;               /* poison: a failing render must overwrite [e][0..L) of every row */
     ow_test_inject_render_faults(pool, 1);
     ow_pool_render(pool, host, stride, L);
