@@ -7,6 +7,7 @@
 #include "ow_chain.hpp"
 #include "ow_tremolo.hpp"
 #include "ow_melange.hpp"
+#include "ow_power_amp.hpp"
 #include <memory>
 
 namespace owo {
@@ -68,7 +69,13 @@ struct WurliEngine {
     double pre_process(double x) { return preamp_kind ? mel.process_sample(x) : preamp.process_sample(x); }
     Tremolo tremolo;
     Oversampler oversampler;
-    PowerAmp power_amp;
+    PowerAmp power_amp;       // behavioural amp of the default build (`legacy-power-amp`)
+    MelangePowerAmp mel_pa;   // melange 7-BJT amp of a `--no-default-features` build (power_amp.rs:279-465)
+    int power_amp_kind = 0;   // 0 = behavioural, 1 = melange
+    double* pa_tap = nullptr; // optional: power-amp output per chain-rate sample
+    double pa_process(double x) { return power_amp_kind ? mel_pa.process(x) : power_amp.process(x); }
+    void set_rail_sag(bool on) { if (power_amp_kind) mel_pa.set_rail_sag(on); }          // engine.rs:406-408
+    bool rail_sag_enabled() const { return power_amp_kind ? mel_pa.rail_sag_on : false; } // :410-412
     Speaker speaker;
     std::vector<double> voice_buf, sum_buf, up_buf, out_buf;
     double sample_rate = 0, os_sample_rate = 0;
@@ -77,13 +84,15 @@ struct WurliEngine {
     uint64_t nan_guard_fires = 0;
 
     // engine.rs:194-229
-    explicit WurliEngine(double sr, int kind = 0) {
+    explicit WurliEngine(double sr, int kind = 0, int pa_kind = 0) {
         preamp_kind = kind;
+        power_amp_kind = pa_kind;
         oversample = sr < 88200.0;
         const double os_sr = oversample ? sr * 2.0 : sr;
         const uint32_t ramp = ramp_samples_for_rate(sr);
         pre_init(os_sr);
         tremolo.init(0.5, os_sr);
+        if (power_amp_kind) mel_pa.init(os_sr);        // PowerAmp::new_at_sample_rate(os_sr), engine.rs:213
         speaker.init(sr);
         voice_buf.assign(MAX_BLOCK_SIZE, 0.0);
         sum_buf.assign(MAX_BLOCK_SIZE, 0.0);
@@ -102,6 +111,7 @@ struct WurliEngine {
         pre_reset();
         tremolo.reset();
         oversampler.reset();
+        if (power_amp_kind) mel_pa.reset();            // power_amp.reset() (a no-op on the behavioural amp)
         speaker.reset();
         age_counter = 0;
         sustain_held = false;
@@ -129,6 +139,7 @@ struct WurliEngine {
         pre_init(os_sample_rate);
         tremolo.init(tremolo_depth.target, os_sample_rate);
         oversampler.reset();
+        if (power_amp_kind) mel_pa.init(os_sample_rate);   // PowerAmp::new_at_sample_rate (engine.rs:279): rail sag back to its default (on), last_good 0
         speaker.init(sr);
         const uint32_t ramp = ramp_samples_for_rate(sr);
         volume.set_ramp_samples(ramp);
@@ -240,6 +251,7 @@ struct WurliEngine {
             else {
                 pre_reset();
                 oversampler.reset();
+                if (power_amp_kind) mel_pa.reset();
                 speaker.reset();
                 out[i] = 0.0f;
             }
@@ -308,7 +320,8 @@ struct WurliEngine {
                     const double pre = pre_process(up_buf[idx]);
                     if (preamp_tap) preamp_tap[idx] = pre;
                     if (r_tap) r_tap[idx] = r;
-                    up_buf[idx] = power_amp.process(pre * FIXED_CIRCUIT_DRIVE);
+                    up_buf[idx] = pa_process(pre * FIXED_CIRCUIT_DRIVE);
+                    if (pa_tap) pa_tap[idx] = up_buf[idx];
                 }
             }
             oversampler.downsample_2x(up_buf.data(), out_buf.data() + offset, len);
@@ -321,7 +334,8 @@ struct WurliEngine {
                 const double pre = pre_process(sum_buf[i]);
                 if (preamp_tap) preamp_tap[i] = pre;
                 if (r_tap) r_tap[i] = r;
-                out_buf[offset + i] = power_amp.process(pre * FIXED_CIRCUIT_DRIVE);
+                out_buf[offset + i] = pa_process(pre * FIXED_CIRCUIT_DRIVE);
+                if (pa_tap) pa_tap[i] = out_buf[offset + i];
             }
         }
     }

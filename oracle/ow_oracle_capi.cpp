@@ -21,7 +21,53 @@ extern "C" {
 // ---- engine mirror (engine.rs public API) ----
 void* owo_engine_new(double sr) { return new WurliEngine(sr); }
 void* owo_engine_new_kind(double sr, int preamp_kind) { return new WurliEngine(sr, preamp_kind); }
+void* owo_engine_new_kinds(double sr, int preamp_kind, int power_amp_kind) { return new WurliEngine(sr, preamp_kind, power_amp_kind); }
 void owo_engine_free(void* e) { delete (WurliEngine*)e; }
+void owo_engine_set_rail_sag(void* e, int on) { ((WurliEngine*)e)->set_rail_sag(on != 0); }
+int owo_engine_rail_sag_enabled(void* e) { return ((WurliEngine*)e)->rail_sag_enabled() ? 1 : 0; }
+// power_amp_diag (engine.rs:418-420): clamp_count, nr_max_iter_count, peak_output_volts; + oracle-only guard reset count
+void owo_engine_power_amp_diag(void* e, unsigned long long* clamp, unsigned long long* nr_max, double* peak, unsigned long long* guard_resets) {
+    const WurliEngine* w = (const WurliEngine*)e;
+    *clamp = w->power_amp_kind ? w->mel_pa.state.diag_clamp_count : 0ull;
+    *nr_max = w->power_amp_kind ? w->mel_pa.state.diag_nr_max_iter_count : 0ull;
+    *peak = w->power_amp_kind ? w->mel_pa.state.diag_peak_output : 0.0;
+    *guard_resets = w->power_amp_kind ? w->mel_pa.guard_resets : 0ull;
+}
+// render with the power-amp tap (chain rate) besides the output
+void owo_engine_render_pa_tap(void* e, float* out, double* pa, size_t n) {
+    WurliEngine* w = (WurliEngine*)e;
+    w->pa_tap = pa;
+    w->render(out, n);
+    w->pa_tap = nullptr;
+}
+
+// ---- melange power amp alone (power_amp.rs melange_adapter::PowerAmp), for the known-answer tests and solver-internal taps ----
+void* owo_mpa_new(double sr) { MelangePowerAmp* p = new MelangePowerAmp(); p->init(sr); return p; }
+void owo_mpa_free(void* p) { delete (MelangePowerAmp*)p; }
+void owo_mpa_reset(void* p) { ((MelangePowerAmp*)p)->reset(); }
+void owo_mpa_set_rail_sag(void* p, int on) { ((MelangePowerAmp*)p)->set_rail_sag(on != 0); }
+// out[n]; taps (optional, [n][4]): outer Newton iterations (70 = exhausted), inner iterations summed, BE retry used, guard resets so far
+void owo_mpa_process(void* p, const double* in, double* out, double* taps, size_t n) {
+    MelangePowerAmp* a = (MelangePowerAmp*)p;
+    for (size_t i = 0; i < n; ++i) {
+        out[i] = a->process(in[i]);
+        if (taps) {
+            taps[4 * i + 0] = (double)a->state.tap_outer_iters; taps[4 * i + 1] = (double)a->state.tap_inner_iters;
+            taps[4 * i + 2] = (double)a->state.tap_be_used; taps[4 * i + 3] = (double)a->guard_resets;
+        }
+    }
+}
+void owo_mpa_rails(void* p, double* pos, double* neg) {
+    const MelangePowerAmp* a = (const MelangePowerAmp*)p;
+    *pos = a->rail_sag_on ? a->rails.v_rail_pos : 22.5; *neg = a->rail_sag_on ? a->rails.v_rail_neg : 22.5;
+}
+void owo_mpa_state(void* p, double* v20) { for (int i = 0; i < 20; ++i) v20[i] = ((MelangePowerAmp*)p)->state.v_prev[i]; }
+void owo_mpa_poke_node(void* p, int node, double v) { ((MelangePowerAmp*)p)->state.v_prev[node] = v; }   // forced-divergence tests
+// RailDynamics alone (power_amp.rs:65-165)
+void owo_rail_run(double sr, const double* v_out, size_t n, double* pos, double* neg) {
+    RailDynamics r; r.init(sr);
+    for (size_t i = 0; i < n; ++i) { r.step(v_out[i]); pos[i] = r.v_rail_pos; neg[i] = r.v_rail_neg; }
+}
 void owo_engine_set_sample_rate(void* e, double sr) { ((WurliEngine*)e)->set_sample_rate(sr); }
 void owo_engine_reset(void* e) { ((WurliEngine*)e)->reset(); }
 void owo_engine_warm_up(void* e) { ((WurliEngine*)e)->warm_up(); }

@@ -1,0 +1,182 @@
+"""Known-answer tests that pin the ORACLE's melange 7-BJT power amp + RailDynamics: all twelve tests of the reference's own
+`power_amp.rs` test module (power_amp.rs:493-804), restated against the restatement.  `PowerAmp::new()` = 44.1 kHz, as there.
+Plus the baked operating point: a zero-input step from DC_OP stays at DC_OP (gen_power_amp.rs:8150-8198)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+SR = 44100.0
+# DC_OP of gen_power_amp.rs:8150-8171 (the baked operating point the reference's codegen solved for)
+DC_OP_JSON = ("[0.0, 3.83906281848339984e-2, 6.54729553363387007e-1, 2.25000000000000036e1, -2.18102080249387704e1, -2.24999985400864659e1, "
+              "1.78232478106927737e-2, -2.25000000000000036e1, -6.46942607764731253e-2, 1.78232478067716568e-2, -7.28189413688267950e-1, "
+              "1.14703941079910479e1, 4.40788236628799790e-1, -5.28863215670770381e-2, 2.24984982857430502e1, -6.46916357745051240e-2, "
+              "-2.19649521749592225e1, -6.85002591476917555e-2, -8.31764783048376775e-3, -1.64018711659791872e-2]")
+
+
+class Mpa:
+    def __init__(self, L, sr=SR):
+        self.L = L
+        L.owo_mpa_new.restype = C.c_void_p
+        self.h = C.c_void_p(L.owo_mpa_new(C.c_double(sr)))
+
+    def close(self):
+        self.L.owo_mpa_free(self.h)
+
+    def process(self, x, taps=False):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros(x.size)
+        t = np.zeros((x.size, 4)) if taps else None
+        self.L.owo_mpa_process(self.h, x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                               t.ctypes.data_as(C.c_void_p) if taps else None, C.c_size_t(x.size))
+        return (out, t) if taps else out
+
+    def set_rail_sag(self, on):
+        self.L.owo_mpa_set_rail_sag(self.h, 1 if on else 0)
+
+    def rails(self):
+        a, b = C.c_double(), C.c_double()
+        self.L.owo_mpa_rails(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def state(self):
+        v = np.zeros(20)
+        self.L.owo_mpa_state(self.h, v.ctypes.data_as(C.c_void_p))
+        return v
+
+
+@pytest.fixture()
+def pa(oracle):
+    p = Mpa(oracle.lib())
+    yield p
+    p.close()
+
+
+def _sine(freq, amp, n, start=0):
+    return amp * np.sin(2 * np.pi * freq * np.arange(start, start + n) / SR)
+
+
+def _dft_mag(s, freq):
+    ph = 2 * np.pi * freq * np.arange(s.size) / SR
+    return np.hypot(np.sum(s * np.cos(ph)), np.sum(s * np.sin(ph))) / s.size
+
+
+def test_closed_loop_gain(pa):                       # power_amp.rs:493-501
+    settle = int(SR * 0.3)
+    y = pa.process(_sine(1000.0, 0.001, settle + int(SR * 0.1)))
+    gain_db = 20 * np.log10(np.max(np.abs(y[settle:])) / 0.001)
+    assert 5.0 < gain_db < 20.0
+    assert abs(gain_db - 9.9) < 1.5                  # 69x / 22 V normalisation (the comment in the reference's test)
+
+
+def test_rail_clipping(pa):                          # :503-519
+    y = pa.process(_sine(100.0, 5.0, int(SR * 0.2)))
+    peak = np.max(np.abs(y[int(SR * 0.1) + 1:]))
+    assert 0.85 < peak <= 1.0
+
+
+def test_crossover_reduced_by_feedback(pa):          # :521-544
+    n = int(SR * 0.3)
+    y = pa.process(_sine(440.0, 0.001, n))[n // 2 + 1:]
+    h3_db = 20 * np.log10(_dft_mag(y, 1320.0) / _dft_mag(y, 440.0))
+    assert h3_db < -30.0
+
+
+def test_output_bounded(pa):                         # :546-560
+    for x in (0.0, 0.001, 0.01, 0.1, 0.5, 1.0, 5.0, -0.1, -1.0, -5.0):
+        y = pa.process(np.full(101, x))
+        assert np.all(np.isfinite(y)) and abs(y[-1]) <= 1.0
+
+
+def test_rail_sag_default_is_on_and_off_preserves_static_bias(oracle):      # :578-617
+    a = Mpa(oracle.lib())
+    a.process(np.zeros(10))
+    assert a.rails() != (22.5, 22.5)                 # default ON: rails already moving towards 24.5 V
+    b = Mpa(oracle.lib())
+    b.set_rail_sag(False)
+    assert b.rails() == (22.5, 22.5)
+    b.process(np.zeros(100))
+    assert b.rails() == (22.5, 22.5)
+    a.close(); b.close()
+
+
+def test_rail_sag_idle_voltage(pa):                  # :619-642
+    pa.set_rail_sag(True)
+    pa.process(np.zeros(int(SR) // 4))
+    vp, vn = pa.rails()
+    assert abs(vp - 24.5) < 0.05 and abs(vn - 24.5) < 0.05
+
+
+def test_rail_sag_sustained_load_drops_rails(pa):    # :644-683
+    pa.process(np.zeros(int(SR) // 10))
+    vp_idle, _ = pa.rails()
+    pa.process(_sine(220.0, 0.20, int(SR * 0.5)))
+    vp, vn = pa.rails()
+    assert vp < vp_idle - 0.1 and vn < vp_idle - 0.1 and vp > 20.0 and vn > 20.0
+
+
+def test_rail_sag_recovery_after_load(pa):           # :685-714
+    pa.process(_sine(110.0, 0.3, int(SR * 0.2)))
+    vp_loaded, _ = pa.rails()
+    assert vp_loaded < 24.0
+    pa.process(np.zeros(int(SR * 0.2)))
+    vp_rec, _ = pa.rails()
+    assert vp_rec > vp_loaded + 0.5 and abs(vp_rec - 24.5) < 0.05
+
+
+def test_rail_sag_toggle_zeros_offsets(pa):          # :716-733
+    pa.process(_sine(220.0, 0.5, int(SR * 0.05)))
+    pa.set_rail_sag(False)
+    assert pa.rails() == (22.5, 22.5)
+
+
+def _rail_run(oracle, v_out):
+    L = oracle.lib()
+    v = np.ascontiguousarray(v_out, dtype=np.float64)
+    pos, neg = np.zeros(v.size), np.zeros(v.size)
+    L.owo_rail_run(C.c_double(SR), v.ctypes.data_as(C.c_void_p), C.c_size_t(v.size), pos.ctypes.data_as(C.c_void_p), neg.ctypes.data_as(C.c_void_p))
+    return pos, neg
+
+
+def test_rail_dynamics_unit_and_offsets(oracle):     # :735-803
+    n_idle, n_load = int(SR) // 4, int(SR * 0.3)
+    pos, neg = _rail_run(oracle, np.concatenate([np.zeros(n_idle), np.full(n_load, 8.0)]))
+    assert abs(pos[n_idle - 1] - 24.5) < 0.05                       # unloaded: towards 24.5 V (release tau 15 ms)
+    assert abs(pos[-1] - 21.0) < 0.1 and abs(neg[-1] - 24.5) < 0.05  # 1 A on the positive rail: 24.5 - 3.5
+    assert abs((pos[n_idle - 1] - 22.5) - 2.0) < 0.05               # offsets() = rail - 22.5
+    assert -2.0 < pos[-1] - 22.5 < -1.0 and abs((neg[-1] - 22.5) - 2.0) < 0.05
+    # first step from the 22.5 V start: one release step towards 24.5 (alpha = 1 - exp(-dt / 15 ms)), exact
+    a = 1.0 - np.exp(-(1.0 / SR) / 0.015)
+    assert pos[0] == 22.5 + a * (24.5 - 22.5)
+
+
+def test_zero_input_stays_at_the_operating_point(pa):
+    """The settled state (44 100 silent samples at the codegen rate, then re-rated) is the operating point: another second of silence
+    moves no node by more than 1 mV (the slow coupling-capacitor tail: WARMUP_SAMPLES_RECOMMENDED = 5 tau_max = 39 690 samples),
+    the DC-blocked output stays at zero, the solver converges at once and the guard never fires."""
+    pa.set_rail_sag(False)
+    v0 = pa.state()
+    y, taps = pa.process(np.zeros(int(SR)), taps=True)
+    assert np.max(np.abs(pa.state() - v0)) < 1e-3
+    # set_sample_rate zeroes the DC blocker's memory (gen_power_amp.rs:8618-8620): the first sample shows V(OUT) = -64.7 mV / 22 V and the
+    # 5 Hz blocker then forgets it
+    assert abs(y[0] - (-6.3e-2 / 22.0)) < 2e-4 and abs(y[-1]) < 1e-9 and np.all(np.abs(np.diff(y)) < 1e-5)
+    assert np.max(np.abs(pa.state() - np.array(__import__('json').loads(DC_OP_JSON)))) < 0.05      # gen_power_amp.rs:8150-8171
+    assert taps[:, 0].max() <= 1 and taps[:, 2].sum() == 0 and taps[-1, 3] == 0
+
+
+def test_divergence_guard_holds_last_good_and_recovers(oracle):
+    """power_amp.rs:373-421: a node forced past 100 V trips the guard on that sample -- the output repeats the last good value, the solver
+    restarts from the settled state, and the following samples track the input again."""
+    L = oracle.lib()
+    a = Mpa(L)
+    x = _sine(330.0, 0.01, 3000)
+    y1 = a.process(x[:1500])
+    L.owo_mpa_poke_node(a.h, 8, C.c_double(1e6))     # NODE_OUT driven insane before the next sample
+    y2, taps = a.process(x[1500:], taps=True)
+    assert taps[:, 3].max() >= 1                     # the guard fired ...
+    first = int(np.argmax(taps[:, 3] >= 1))
+    assert y2[first] == y1[-1] if first == 0 else y2[first] == y2[first - 1]   # ... and held the last good sample
+    tail = y2[-500:]
+    assert np.all(np.isfinite(y2)) and np.max(np.abs(tail)) > 0.01 * 3 * 0.5   # tracking again (gain ~3.4 on a 10 mV sine)
+    a.close()

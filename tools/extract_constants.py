@@ -87,6 +87,43 @@ def extract(path: Path, prefix: str, want_arrays, want_scalars, dim_env):
     return out
 
 
+def power_amp_tables():
+    """melange 7-BJT Class-AB power amp (gen_power_amp.rs): N = 20 unknowns (18 nodes + 2 source rows), M = 16 ports (8 BJTs).
+    Besides the literal tables, the EMITTED SPARSITY of process_sample is data too: which A_neg entries build_rhs touches
+    (gen_power_amp.rs:8854-8913) and which two node voltages form each port voltage (:8936-8951)."""
+    path = REF / "gen_power_amp.rs"
+    src = path.read_text()
+    arrays = ["G", "C", "A_NEG_DEFAULT", "A_NEG_BE_DEFAULT", "N_V", "N_I", "S_DEFAULT", "K_DEFAULT", "S_NI_DEFAULT",
+              "S_BE_DEFAULT", "K_BE_DEFAULT", "S_NI_BE_DEFAULT", "RHS_CONST", "RHS_CONST_BE", "DC_OP", "DC_NL_I"]
+    scalars = ["SAMPLE_RATE", "INPUT_RESISTANCE", "MAX_ITER", "DC_BLOCK_R"]
+    out = ["", "/* ---- melange 7-BJT Class-AB power amp (gen_power_amp.rs), N=20 unknowns, M=16 NL ports ---- */"]
+    out += extract(path, "PA_", arrays, scalars, {"N": 20, "M": 16, "NUM_OUTPUTS": 1})
+    fields = ["IS", "VT", "BETA_F", "BETA_R", "NF", "NR", "ISE", "NE", "ISC", "NC", "SIGN", "VAF", "VAR", "IKF", "IKR", "VCRIT", "RB", "RC", "RE"]
+    for f in fields:
+        vals = []
+        for d in range(8):
+            m = re.search(rf"const DEVICE_{d}_{f}: f64 = ([^;]+);", src)
+            if not m:
+                raise SystemExit(f"gen_power_amp.rs: DEVICE_{d}_{f} missing")
+            vals.append(m.group(1).strip().replace("_", ""))
+        out.append(f"OW_DATA_DECL double PA_DEV_{f}[8] = {{" + ", ".join(vals) + "};")
+    gp = [re.search(rf"const DEVICE_{d}_USE_GP: bool = (true|false);", src).group(1) for d in range(8)]
+    out.append("OW_DATA_DECL double PA_DEV_USE_GP[8] = {" + ", ".join("1.0" if g == "true" else "0.0" for g in gp) + "};")
+    body = src[src.index("pub fn process_sample("):]
+    nz = re.findall(r"rhs\[(\d+)\] \+= state\.a_neg\[(\d+)\]\[(\d+)\] \* state\.v_prev\[(\d+)\];", body)
+    assert nz and all(a == b and c == d for a, b, c, d in nz)
+    out.append(f"#define PA_RHS_NNZ {len(nz)}")
+    out.append("OW_DATA_DECL double PA_RHS_NZ_ROW[PA_RHS_NNZ] = {" + ", ".join(a for a, _, _, _ in nz) + "};")
+    out.append("OW_DATA_DECL double PA_RHS_NZ_COL[PA_RHS_NNZ] = {" + ", ".join(c for _, _, c, _ in nz) + "};")
+    pv = re.findall(r"p\[(\d+)\] = N_V\[(\d+)\]\[(\d+)\] \* v_pred\[(\d+)\] \+ N_V\[(\d+)\]\[(\d+)\] \* v_pred\[(\d+)\];", body)
+    assert len(pv) == 16 and all(int(x[0]) == i for i, x in enumerate(pv))
+    out.append("OW_DATA_DECL double PA_P_NODE_A[16] = {" + ", ".join(x[2] for x in pv) + "};")
+    out.append("OW_DATA_DECL double PA_P_NODE_B[16] = {" + ", ".join(x[5] for x in pv) + "};")
+    m = re.search(r"dc_block_x_prev: \[([-0-9.e+]+)\]", src)
+    out.append(f"OW_DATA_DECL double PA_DC_BLOCK_X0 = {m.group(1)};")
+    return out
+
+
 def main():
     lines = [
         "/* GENERATED by tools/extract_constants.py -- numeric DATA only.",
@@ -133,6 +170,7 @@ def main():
                    "DEVICE_1_IS", "DEVICE_1_VT", "DEVICE_1_NF", "DEVICE_1_VCRIT",
                    "DEVICE_2_IS", "DEVICE_2_VT", "DEVICE_2_NF", "DEVICE_2_VCRIT"]
     lines += extract(REF / "gen_preamp.rs", "PRE_", pre_arrays, pre_scalars, {"N": 12, "M": 3, "NUM_OUTPUTS": 1, "NOISE_THERMAL_N": 11})
+    lines += power_amp_tables()
     lines += ["", "#endif /* OW_GEN_DATA_H */", ""]
     OUT.parent.mkdir(parents=True, exist_ok=True)
     OUT.write_text("\n".join(lines))
