@@ -32,6 +32,9 @@ typedef struct ow_engine ow_engine;
 enum { OW_VOICE_FREE = 0, OW_VOICE_HELD = 1, OW_VOICE_SUSTAINED = 2, OW_VOICE_RELEASING = 3 };
 /* preamp solver selection: cargo features of crates/openwurli-dsp/Cargo.toml:9-17 become a runtime enum */
 enum { OW_PREAMP_LEGACY8 = 0, OW_PREAMP_MELANGE12 = 1 };
+/* power amp selection (crates/openwurli-dsp/Cargo.toml:9-17: `legacy-power-amp` is a default feature; a `--no-default-features` build
+ * gets the melange-generated 7-BJT Class-AB solver with rail dynamics, power_amp.rs:279-465 + gen_power_amp.rs) */
+enum { OW_POWER_AMP_BEHAVIORAL = 0, OW_POWER_AMP_MELANGE = 1 };
 
 /* Introspection block (engine.rs:606-670 test/inspection helpers + diag counters of the solvers). */
 typedef struct ow_diag {
@@ -53,7 +56,8 @@ void ow_clear_error(void);
 /* n_engines >= 1 engines at `sample_rate` on HIP device `device`.  Like WurliEngine::new
  * (engine.rs:194-229) the engines are NOT warmed up; call ow_pool_set_sample_rate or
  * ow_engine_set_sample_rate (what the plugin's initialize() does, plugin/src/lib.rs:96-97). */
-ow_pool* ow_pool_new(double sample_rate, size_t n_engines, int device, int preamp_kind);
+ow_pool* ow_pool_new(double sample_rate, size_t n_engines, int device, int preamp_kind);       /* behavioural power amp */
+ow_pool* ow_pool_new_with(double sample_rate, size_t n_engines, int device, int preamp_kind, int power_amp_kind);
 void ow_pool_free(ow_pool*);
 size_t ow_pool_size(const ow_pool*);
 ow_engine* ow_pool_engine(ow_pool*, size_t index);
@@ -96,6 +100,7 @@ void ow_pool_last_kernel_ms(const ow_pool*, float ms[5]);
 
 /* ---- engines: the WurliEngine API (engine.rs) -------------------------------------------- */
 ow_engine* ow_engine_new(double sample_rate, int device, int preamp_kind);        /* WurliEngine::new        :194 */
+ow_engine* ow_engine_new_with(double sample_rate, int device, int preamp_kind, int power_amp_kind);
 void ow_engine_free(ow_engine*);                                                  /* Drop (pool-of-one only)      */
 void ow_engine_set_sample_rate(ow_engine*, double sample_rate);                   /* set_sample_rate         :272 */
 void ow_engine_reset(ow_engine*);                                                 /* reset                   :231 */
@@ -110,6 +115,18 @@ void ow_engine_set_speaker_character(ow_engine*, double c);                     
 void ow_engine_set_mlp_enabled(ow_engine*, int on);                               /* set_mlp_enabled         :390 */
 void ow_engine_set_noise_enabled(ow_engine*, int on);                             /* set_noise_enabled       :394 (melange preamp; no-op on legacy) */
 void ow_engine_set_noise_gain(ow_engine*, double gain);                           /* set_noise_gain          :398 (-> set_thermal_gain; no-op on legacy) */
+void ow_engine_set_rail_sag(ow_engine*, int on);                                  /* set_rail_sag            :406 (melange power amp; no-op otherwise) */
+int ow_engine_rail_sag_enabled(const ow_engine*);                                 /* rail_sag_enabled        :410 */
+/* power_amp_diag (engine.rs:418-420: clamp_count, nr_max_iter_count, peak_output_volts of the solver state) plus what the adapter
+ * keeps besides: NaN resets of the solver, divergence-guard resets (power_amp.rs:410-421; the reference does not count them) and
+ * the rail magnitudes (PowerAmp::rail_voltages, :359-365).  All zero / 22.5 V on the behavioural amp. */
+typedef struct ow_power_amp_diag {
+    uint64_t clamp_count, nr_max_iter_count;
+    double peak_output_volts;
+    uint64_t nan_resets, guard_resets;
+    double rail_pos_volts, rail_neg_volts;
+} ow_power_amp_diag;
+void ow_engine_power_amp_diag(const ow_engine*, ow_power_amp_diag* out);
 /* gen_preamp::CircuitState::set_seed (gen_preamp.rs:2094-2100) of this engine's main preamp state: restarts its 11 thermal-noise
  * streams from `seed` (0 = the process-wide clock entropy every engine starts from, like the reference) and clears the lag.  Not
  * reachable through WurliEngine in the reference (whose noise is therefore never reproducible); exported so parity can be tested.

@@ -53,6 +53,15 @@ int ow_test_pool_stagger_tremolo(ow_pool*, size_t n_groups);
 /* Number of tremolo phase groups of the pool (1 for a fresh pool, +1 for every engine reset / warmed up on its own). */
 size_t ow_test_pool_tremolo_groups(const ow_pool*);
 
+/* ---- melange power amp: solver taps ------------------------------------------------------------ */
+/* Keep the amp's output of every chain-rate sample of the last block (before the half-band down-sampler): f64 [n_engines][n_os] through
+ * ow_test_pool_read_power_amp_out.  Costs 16 B per engine and chain-rate sample of the block capacity; off until enabled. */
+int ow_test_pool_enable_power_amp_tap(ow_pool*);
+int ow_test_pool_read_power_amp_out(ow_pool*, double* out_host, size_t out_stride, size_t n_os);
+/* Overwrite one node voltage of the amp's solver state (v_prev[node], node < 20) before the next block: the way to force the
+ * divergence guard (power_amp.rs:410-421: |node| > 100 V -> reset + hold last good) at a known sample. */
+int ow_test_engine_poke_power_amp_node(ow_engine*, int node, double volts);
+
 /* ---- fault injection ------------------------------------------------------------------------ */
 /* The next n_renders calls of ow_pool_render / ow_engine_render on this pool fail before their first launch, exactly as a HIP
  * error would (exception inside the guarded region): the caller's block must come back as silence in every row, ow_last_error

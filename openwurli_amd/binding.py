@@ -19,6 +19,11 @@ class OwDiag(C.Structure):
     ]
 
 
+class OwPowerAmpDiag(C.Structure):
+    _fields_ = [("clamp_count", C.c_uint64), ("nr_max_iter_count", C.c_uint64), ("peak_output_volts", C.c_double),
+                ("nan_resets", C.c_uint64), ("guard_resets", C.c_uint64), ("rail_pos_volts", C.c_double), ("rail_neg_volts", C.c_double)]
+
+
 class OwJob(C.Structure):
     _fields_ = [("note", C.c_uint8), ("velocity", C.c_uint8), ("mlp", C.c_uint8), ("poweramp", C.c_uint8),
                 ("volume", C.c_double), ("speaker", C.c_double), ("r_ldr", C.c_double)]
@@ -71,6 +76,7 @@ SYMBOLS = {
     "ow_last_error": (C.c_char_p, []),
     "ow_clear_error": (None, []),
     "ow_pool_new": (_VP, [C.c_double, C.c_size_t, C.c_int, C.c_int]),
+    "ow_pool_new_with": (_VP, [C.c_double, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "ow_pool_free": (None, [_VP]),
     "ow_pool_size": (C.c_size_t, [_VP]),
     "ow_pool_engine": (_VP, [_VP, C.c_size_t]),
@@ -88,6 +94,10 @@ SYMBOLS = {
     "ow_pool_set_profiling": (None, [_VP, C.c_int]),
     "ow_pool_last_kernel_ms": (None, [_VP, C.POINTER(C.c_float)]),
     "ow_engine_new": (_VP, [C.c_double, C.c_int, C.c_int]),
+    "ow_engine_new_with": (_VP, [C.c_double, C.c_int, C.c_int, C.c_int]),
+    "ow_engine_set_rail_sag": (None, [_VP, C.c_int]),
+    "ow_engine_rail_sag_enabled": (C.c_int, [_VP]),
+    "ow_engine_power_amp_diag": (None, [_VP, C.POINTER(OwPowerAmpDiag)]),
     "ow_engine_free": (None, [_VP]),
     "ow_engine_set_sample_rate": (None, [_VP, C.c_double]),
     "ow_engine_reset": (None, [_VP]),
@@ -137,6 +147,9 @@ TEST_SYMBOLS = {
     "ow_debug_div_const": (C.c_int, [C.c_int, _VP, C.c_size_t, _VP, _VP, _VP, C.c_int]),
     "ow_debug_unary": (C.c_int, [C.c_int, _VP, C.c_size_t, _VP, _VP, C.c_int]),
     "ow_test_inject_render_faults": (None, [_VP, C.c_int]),
+    "ow_test_pool_enable_power_amp_tap": (C.c_int, [_VP]),
+    "ow_test_pool_read_power_amp_out": (C.c_int, [_VP, _VP, C.c_size_t, C.c_size_t]),
+    "ow_test_engine_poke_power_amp_node": (C.c_int, [_VP, C.c_int, C.c_double]),
     "ow_test_pool_stagger_tremolo": (C.c_int, [_VP, C.c_size_t]),
     "ow_test_pool_tremolo_groups": (C.c_size_t, [_VP]),
 }

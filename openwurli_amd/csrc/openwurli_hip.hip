@@ -22,6 +22,7 @@
 #include "ow_job_kernels.h"
 #include "ow_mlp_mfma.h"
 #include "ow_melange_dev.h"
+#include "ow_power_amp_dev.h"
 #include "ow_features.h"
 #include "ow_trem_wide.h"
 #include "ow_audit.h"
@@ -29,6 +30,7 @@
 #include "ow_chain_wide.h"
 #include <condition_variable>
 #include <map>
+#include <memory>
 #include <mutex>
 
 using owdev::OwEngineOut;
@@ -191,6 +193,7 @@ struct ow_engine {
     }
     uint64_t age_counter = 0;
     bool sustain_held = false, mlp_enabled = true;
+    bool rail_sag = true;           // melange power amp: rail sag (PowerAmp::new_at_sample_rate starts with it on, power_amp.rs:335-346)
     bool noise_on = false;          // melange preamp thermal noise (engine.rs:394-400); DkPreamp::new starts with off / 1.0
     double thermal_gain = 1.0;
     HostSmoother volume{0.5}, depth{0.5}, spk{0.0};
@@ -228,6 +231,12 @@ struct ow_pool {
     double* d_nt = nullptr;
     double* d_vrec = nullptr;
     double* d_cs = nullptr;
+    int power_amp_kind = 0;           // OW_POWER_AMP_BEHAVIORAL / OW_POWER_AMP_MELANGE
+    OwPaConsts* dPa = nullptr;        // melange power amp: constants at the chain rate
+    double* d_pa = nullptr;           // melange power amp: per-engine state, [PAS_COUNT][I]
+    double* d_pa_settled = nullptr;   // settled circuit state (PAS_CIRCUIT_END doubles), power_amp.rs:288-296
+    double* d_pa_tap = nullptr;       // test tap: amp output per chain-rate sample, [2 * Lcap][I] (ow_test_pool_enable_power_amp_tap)
+    size_t pa_tap_cap = 0;
     double* d_mel_settled = nullptr;  // melange preamp: settled codegen-rate state (18 doubles)
     double* d_noise = nullptr;        // melange preamp: thermal-noise state of the main solver states, [NZ_COUNT][I]
     double* d_sum = nullptr;
@@ -318,6 +327,10 @@ void alloc_stream_buffers(ow_pool* p, size_t cap) {
     HIP_OK(hipMalloc(&p->d_pre, sizeof(double) * 2 * cap * I));
     HIP_OK(hipMalloc(&p->d_out, sizeof(float) * I * cap));
     HIP_OK(hipMemsetAsync(p->d_out, 0, sizeof(float) * I * cap, p->stream));
+    if (p->d_pa_tap) {      // the test tap follows the block capacity
+        hipFree(p->d_pa_tap); p->d_pa_tap = nullptr;
+        HIP_OK(hipMalloc(&p->d_pa_tap, sizeof(double) * 2 * cap * I));
+    }
     p->Lcap = cap;
 }
 
@@ -357,6 +370,30 @@ void mel_settled_to_device(int device, double* d_dst, hipStream_t st) {
         return;
     }
     HIP_OK(hipMemcpyAsync(d_dst, it->second.data(), sizeof(double) * 18, hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
+}
+
+// Settled state of the melange power amp (power_amp.rs:288-296): always computed with the codegen-rate matrices, once per device.
+std::map<int, std::vector<double>> g_pa_settled;
+void pa_settled_to_device(int device, double* d_dst, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_mel_mu);
+    auto it = g_pa_settled.find(device);
+    if (it == g_pa_settled.end()) {
+        OwPaConsts* h88 = new OwPaConsts();
+        std::unique_ptr<OwPaConsts> own(h88);
+        owhip::build_pa_consts(*h88, PA_SAMPLE_RATE);
+        DevMem dk;
+        dk.alloc(sizeof(OwPaConsts));
+        HIP_OK(hipMemcpyAsync(dk.p, h88, sizeof(OwPaConsts), hipMemcpyHostToDevice, st));
+        owdev::k_mpa_settle<<<dim3(1), dim3(64), 0, st>>>(dk.as<OwPaConsts>(), d_dst);
+        HIP_OK(hipGetLastError());
+        std::vector<double> h(owdev::PAS_CIRCUIT_END);
+        HIP_OK(hipMemcpyAsync(h.data(), d_dst, sizeof(double) * h.size(), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        g_pa_settled[device] = h;
+        return;
+    }
+    HIP_OK(hipMemcpyAsync(d_dst, it->second.data(), sizeof(double) * it->second.size(), hipMemcpyHostToDevice, st));
     HIP_OK(hipStreamSynchronize(st));
 }
 
@@ -473,6 +510,8 @@ void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<do
     }
     if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)   // DkPreamp::new / reset of the melange adapter: settled state at the chain rate
         owdev::k_mel_init<<<dim3((2 * ne + 63) / 64), dim3(64), 0, p->stream>>>(p->d_cs, p->d_mel_settled, p->d_noise, I, e0, ne);
+    if (p->power_amp_kind == OW_POWER_AMP_MELANGE)  // PowerAmp::new_at_sample_rate (new / set_sample_rate) or PowerAmp::reset (reset keeps last_good)
+        owdev::k_mpa_init<<<dim3((ne + 63) / 64), dim3(64), 0, p->stream>>>(p->dPa, p->d_pa_settled, p->d_pa, I, e0, ne, mode != INIT_RESET ? 1 : 0);
     const int nl = p->n_lead;          // == 1: the range is one phase group
     const int blocks = (nl + 63) / 64;
     const long long n_settle = (long long)owhip::sat_u32(p->hc.os_sr * 2.0);
@@ -494,6 +533,12 @@ void upload_consts(ow_pool* p, double sr, int preamp_kind) {
     owhip::build_consts(k48, 24000.0, preamp_kind);  // os_sr = 48 kHz -> codegen-rate tremolo matrices
     HIP_OK(hipMemcpyAsync(p->dK, &p->hc, sizeof(OwConsts), hipMemcpyHostToDevice, p->stream));
     HIP_OK(hipMemcpyAsync(p->dK48, &k48, sizeof(OwConsts), hipMemcpyHostToDevice, p->stream));
+    if (p->power_amp_kind == OW_POWER_AMP_MELANGE) {
+        std::unique_ptr<OwPaConsts> hpa(new OwPaConsts());
+        owhip::build_pa_consts(*hpa, p->hc.os_sr);          // the amp runs at the chain rate (engine.rs:207-213)
+        HIP_OK(hipMemcpyAsync(p->dPa, hpa.get(), sizeof(OwPaConsts), hipMemcpyHostToDevice, p->stream));
+        HIP_OK(hipStreamSynchronize(p->stream));
+    }
     HIP_OK(hipStreamSynchronize(p->stream));
 }
 
@@ -679,6 +724,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
                 // engine.rs:471-473: a Free slot renders nothing unless it still carries a steal voice
                 a.main_mask = en->main_mask; a.steal_mask = en->steal_mask;
                 a.noise_on = en->noise_on ? 1u : 0u; a.thermal_gain = en->thermal_gain;
+                a.pa_flags = en->rail_sag ? 1u : 0u;
                 a.op_begin = (uint32_t)op_pos;
                 a.op_count = (uint32_t)en->ops.size();
                 if (!en->ops.empty()) std::memcpy(p->h_ops + op_pos, en->ops.data(), sizeof(OwOp) * en->ops.size());
@@ -759,7 +805,10 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
                 owdev::k_preamp<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, rb_now, p->d_lead, p->d_pre, I, L, Lcap, se0, sne);
         }
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][3], s));
-        if (sne > 0) {
+        if (sne > 0 && p->power_amp_kind == OW_POWER_AMP_MELANGE) {
+            owdev::k_post_mpa<<<dim3((sne + 63) / 64), dim3(64), 0, s>>>(p->dK, p->dPa, p->d_pa_settled, p->d_cs, p->d_pa, p->d_args, p->d_eout, p->d_pre, p->d_out,
+                                                                          p->d_pa_tap, I, L, L, se0, sne);
+        } else if (sne > 0) {
             if (p->hc.oversample)
                 owdev::k_post<true><<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, L, se0, sne);
             else
@@ -912,9 +961,10 @@ void push_op(ow_engine* en, uint8_t type, int slot, uint8_t note, bool mlp, uint
     en->touch();
 }
 
-ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int preamp_kind) {
+ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int preamp_kind, int power_amp_kind = OW_POWER_AMP_BEHAVIORAL) {
     if (!(sample_rate > 0.0) || n_engines == 0) throw std::runtime_error("invalid sample rate or engine count");
     if (preamp_kind != OW_PREAMP_LEGACY8 && preamp_kind != OW_PREAMP_MELANGE12) throw std::runtime_error("unknown preamp_kind");
+    if (power_amp_kind != OW_POWER_AMP_BEHAVIORAL && power_amp_kind != OW_POWER_AMP_MELANGE) throw std::runtime_error("unknown power_amp_kind");
     int ndev = 0;
     HIP_OK(hipGetDeviceCount(&ndev));
     if (ndev <= 0) throw std::runtime_error("no HIP device: openwurli-hip has no CPU fallback");
@@ -922,6 +972,7 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     ow_pool* p = new ow_pool();
     p->device = device;
     p->I = n_engines;
+    p->power_amp_kind = power_amp_kind;
     HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&p->stream_trem, hipStreamNonBlocking));
     for (auto& e : p->ev) HIP_OK(hipEventCreate(&e));
@@ -968,6 +1019,13 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     HIP_OK(hipMemsetAsync(p->d_vrec, 0, sizeof(double) * n_engines * 2 * OW_VREC_DOUBLES, p->stream));
     HIP_OK(hipMemsetAsync(p->d_cs, 0, sizeof(double) * CS_COUNT * n_engines, p->stream));
     alloc_stream_buffers(p, n_engines == 1 ? (size_t)OW_MAX_BLOCK : (size_t)1024);  // engine.rs:25 MAX_BLOCK_SIZE for a lone engine
+    if (power_amp_kind == OW_POWER_AMP_MELANGE) {
+        HIP_OK(hipMalloc(&p->dPa, sizeof(OwPaConsts)));
+        HIP_OK(hipMalloc(&p->d_pa, sizeof(double) * owdev::PAS_COUNT * n_engines));
+        HIP_OK(hipMemsetAsync(p->d_pa, 0, sizeof(double) * owdev::PAS_COUNT * n_engines, p->stream));
+        HIP_OK(hipMalloc(&p->d_pa_settled, sizeof(double) * owdev::PAS_CIRCUIT_END));
+        pa_settled_to_device(device, p->d_pa_settled, p->stream);
+    }
     upload_consts(p, sample_rate, preamp_kind);
     owdev::k_note_table<<<dim3(1), dim3(64), 0, p->stream>>>(p->d_nt);
     if (preamp_kind == OW_PREAMP_MELANGE12) {
@@ -999,6 +1057,8 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     chain_init_range(p, 0, 1, INIT_NEW, std::vector<double>(1, 0.5));
     if (n_engines > 1)
         owdev::k_chain_replicate<<<dim3((unsigned)((n_engines + 63) / 64)), dim3(64), 0, p->stream>>>(p->d_cs, (int)n_engines, 0, 0, (int)n_engines);
+    if (power_amp_kind == OW_POWER_AMP_MELANGE && n_engines > 1)          // the amp state is not part of the replicated chain rows
+        owdev::k_mpa_init<<<dim3((unsigned)((n_engines + 63) / 64)), dim3(64), 0, p->stream>>>(p->dPa, p->d_pa_settled, p->d_pa, (int)n_engines, 0, (int)n_engines, 1);
     for (size_t i = 0; i < n_engines; ++i) p->h_lead[i] = 0u;             // identical oscillators: one tremolo phase group led by engine 0
     trem_groups_changed(p);
     if (p->d_noise)   // the replicated chain state does not carry the noise columns: seed every engine's streams
@@ -1016,6 +1076,10 @@ void pool_destroy(ow_pool* p) {
     hipFree(p->dK); hipFree(p->dK48); hipFree(p->d_nt); hipFree(p->d_vrec); hipFree(p->d_cs);
     if (p->d_mel_settled) hipFree(p->d_mel_settled);
     if (p->d_noise) hipFree(p->d_noise);
+    if (p->dPa) hipFree(p->dPa);
+    if (p->d_pa) hipFree(p->d_pa);
+    if (p->d_pa_settled) hipFree(p->d_pa_settled);
+    if (p->d_pa_tap) hipFree(p->d_pa_tap);
     hipFree(p->d_args); hipFree(p->d_eout);
     if (p->d_ops) hipFree(p->d_ops);
     if (p->h_ops) hipHostFree(p->h_ops);
@@ -1064,6 +1128,10 @@ ow_pool* ow_pool_new(double sample_rate, size_t n_engines, int device, int pream
     try { return pool_create(sample_rate, n_engines, device, preamp_kind); }
     catch (const std::exception& ex) { set_err(std::string("ow_pool_new: ") + ex.what()); return nullptr; }
 }
+ow_pool* ow_pool_new_with(double sample_rate, size_t n_engines, int device, int preamp_kind, int power_amp_kind) {
+    try { return pool_create(sample_rate, n_engines, device, preamp_kind, power_amp_kind); }
+    catch (const std::exception& ex) { set_err(std::string("ow_pool_new_with: ") + ex.what()); return nullptr; }
+}
 void ow_pool_free(ow_pool* p) { pool_destroy(p); }
 size_t ow_pool_size(const ow_pool* p) { return p ? p->I : 0; }
 ow_engine* ow_pool_engine(ow_pool* p, size_t i) { return (p && i < p->I) ? p->engines[i] : nullptr; }
@@ -1080,6 +1148,7 @@ int ow_pool_set_sample_rate(ow_pool* p, double sr) {
         for (ow_engine* en : p->engines) {
             en->sr = sr;
             en->noise_on = false; en->thermal_gain = 1.0;   // set_sample_rate builds a new DkPreamp (engine.rs:276): noise off, gain 1.0
+            en->rail_sag = true;                            // ... and a new PowerAmp (engine.rs:279): rail sag back on
             en->touch();
         }
         // voices keep their records (the reference keeps Voice objects too, engine.rs:272-286), chain objects are rebuilt
@@ -1207,7 +1276,34 @@ ow_engine* ow_engine_new(double sample_rate, int device, int preamp_kind) {
     p->engines[0]->owns_pool = true;
     return p->engines[0];
 }
+ow_engine* ow_engine_new_with(double sample_rate, int device, int preamp_kind, int power_amp_kind) {
+    ow_pool* p = ow_pool_new_with(sample_rate, 1, device, preamp_kind, power_amp_kind);
+    if (!p) return nullptr;
+    p->engines[0]->owns_pool = true;
+    return p->engines[0];
+}
 void ow_engine_free(ow_engine* e) { if (e && e->owns_pool) pool_destroy(e->pool); }
+// engine.rs:406-420.  No-ops / zeros on the behavioural amp, which has no separable rails (power_amp.rs:262-272).
+void ow_engine_set_rail_sag(ow_engine* e, int on) {
+    if (!e || !e->pool || e->pool->power_amp_kind != OW_POWER_AMP_MELANGE) return;
+    if (e->rail_sag != (on != 0)) { e->rail_sag = on != 0; e->touch(); }
+}
+int ow_engine_rail_sag_enabled(const ow_engine* e) { return (e && e->pool && e->pool->power_amp_kind == OW_POWER_AMP_MELANGE && e->rail_sag) ? 1 : 0; }
+void ow_engine_power_amp_diag(const ow_engine* e, ow_power_amp_diag* d) {
+    if (!d) return;
+    std::memset(d, 0, sizeof *d);
+    d->rail_pos_volts = 22.5; d->rail_neg_volts = 22.5;
+    if (!e || !e->pool || e->pool->power_amp_kind != OW_POWER_AMP_MELANGE) return;
+    ow_pool* p = e->pool;
+    double col[owdev::PAS_COUNT];
+    if (hipSetDevice(p->device) != hipSuccess) return;
+    hipStreamSynchronize(p->stream);
+    if (hipMemcpy2D(col, sizeof(double), p->d_pa + e->index, sizeof(double) * p->I, sizeof(double), owdev::PAS_COUNT, hipMemcpyDeviceToHost) != hipSuccess) return;
+    auto u64 = [&](int r) { uint64_t b; std::memcpy(&b, &col[r], 8); return b; };
+    d->clamp_count = u64(owdev::PAS_CLAMP); d->nr_max_iter_count = u64(owdev::PAS_NRMAX); d->peak_output_volts = col[owdev::PAS_PEAK];
+    d->nan_resets = u64(owdev::PAS_NAN); d->guard_resets = u64(owdev::PAS_GUARD);
+    if (e->rail_sag) { d->rail_pos_volts = col[owdev::PAS_RAILP]; d->rail_neg_volts = col[owdev::PAS_RAILN]; }
+}
 
 void ow_engine_set_sample_rate(ow_engine* e, double sr) {
     if (!e) return;
@@ -1474,6 +1570,30 @@ size_t ow_test_pool_tremolo_groups(const ow_pool* p) {
     size_t n = 0;
     for (size_t e = 0; e < p->I; ++e) n += p->h_lead[e] == (uint32_t)e;
     return n;
+}
+int ow_test_pool_enable_power_amp_tap(ow_pool* p) {
+    if (!p || p->power_amp_kind != OW_POWER_AMP_MELANGE) return -1;
+    if (p->d_pa_tap) return 0;
+    if (hipSetDevice(p->device) != hipSuccess || hipStreamSynchronize(p->stream) != hipSuccess) return -1;
+    return hipMalloc(&p->d_pa_tap, sizeof(double) * 2 * p->Lcap * p->I) == hipSuccess ? 0 : -1;
+}
+int ow_test_pool_read_power_amp_out(ow_pool* p, double* out_host, size_t out_stride, size_t n_os) {
+    if (!p || !out_host || !p->d_pa_tap || n_os > 2 * p->Lcap) return -1;
+    try {
+        HIP_OK(hipSetDevice(p->device));
+        const size_t I = p->I;
+        std::vector<double> a(I * n_os);
+        HIP_OK(hipMemcpy(a.data(), p->d_pa_tap, sizeof(double) * I * n_os, hipMemcpyDeviceToHost));  // [n_os][I]
+        for (size_t e = 0; e < I; ++e)
+            for (size_t n = 0; n < n_os; ++n) out_host[e * out_stride + n] = a[n * I + e];
+        return 0;
+    } catch (const std::exception& ex) { set_err(std::string("ow_test_pool_read_power_amp_out: ") + ex.what()); return -1; }
+}
+int ow_test_engine_poke_power_amp_node(ow_engine* e, int node, double volts) {
+    if (!e || !e->pool || e->pool->power_amp_kind != OW_POWER_AMP_MELANGE || node < 0 || node >= PA_N) return -1;
+    ow_pool* p = e->pool;
+    if (hipSetDevice(p->device) != hipSuccess || hipStreamSynchronize(p->stream) != hipSuccess) return -1;
+    return hipMemcpy(p->d_pa + (size_t)(owdev::PAS_V + node) * p->I + e->index, &volts, sizeof volts, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
 }
 void ow_test_inject_render_faults(ow_pool* p, int n_renders) { if (p) p->inject_faults = n_renders > 0 ? n_renders : 0; }
 

@@ -261,6 +261,75 @@ static void build_melange_consts(OwConsts& c) {
     }
 }
 
+// Melange 7-BJT power amp at the chain rate `rate` (gen_power_amp.rs:8588-8755: set_sample_rate / rebuild_matrices with the
+// backward-Euler companion A = G + C/T, A_neg = C/T, source rows of A_neg zeroed; the codegen tables when the rate is the codegen
+// rate) + RailDynamics::set_sample_rate (power_amp.rs:108-113) + the per-device constant quotients of bjt_evaluate.
+static void build_pa_consts(OwPaConsts& c, double rate) {
+    std::memset(&c, 0, sizeof c);
+    c.rate_is_codegen = std::fabs(rate - PA_SAMPLE_RATE) <= 0.5 ? 1 : 0;
+    if (std::fabs(rate - PA_SAMPLE_RATE) < 0.5) {
+        std::memcpy(c.a_neg, PA_A_NEG_DEFAULT, sizeof c.a_neg); std::memcpy(c.a_neg_be, PA_A_NEG_BE_DEFAULT, sizeof c.a_neg_be);
+        std::memcpy(c.s, PA_S_DEFAULT, sizeof c.s); std::memcpy(c.k, PA_K_DEFAULT, sizeof c.k); std::memcpy(c.s_ni, PA_S_NI_DEFAULT, sizeof c.s_ni);
+        std::memcpy(c.s_be, PA_S_BE_DEFAULT, sizeof c.s_be); std::memcpy(c.k_be, PA_K_BE_DEFAULT, sizeof c.k_be); std::memcpy(c.s_ni_be, PA_S_NI_BE_DEFAULT, sizeof c.s_ni_be);
+        c.dc_block_r = PA_DC_BLOCK_R;
+    } else {
+        const double alpha = rate * 1.0, alpha_be = rate * 1.0;
+        static thread_local double a[PA_N][PA_N], a_be[PA_N][PA_N], inv[PA_N][PA_N];
+        for (int i = 0; i < PA_N; ++i)
+            for (int j = 0; j < PA_N; ++j) {
+                a[i][j] = PA_G[i][j] + alpha * PA_C[i][j];
+                c.a_neg[i][j] = alpha * PA_C[i][j];
+                a_be[i][j] = PA_G[i][j] + alpha_be * PA_C[i][j];
+                c.a_neg_be[i][j] = alpha_be * PA_C[i][j];
+            }
+        for (int i = 18; i < 20; ++i)
+            for (int j = 0; j < PA_N; ++j) { c.a_neg[i][j] = 0.0; c.a_neg_be[i][j] = 0.0; }
+        auto derive = [](const double S[PA_N][PA_N], double K[PA_M][PA_M], double SNI[PA_N][PA_M]) {
+            for (int i = 0; i < PA_M; ++i)
+                for (int j = 0; j < PA_M; ++j) {
+                    double sum = 0.0;
+                    for (int aa = 0; aa < PA_N; ++aa) {
+                        double s_ni_aj = 0.0;
+                        for (int b = 0; b < PA_N; ++b) s_ni_aj += S[aa][b] * PA_N_I[b][j];
+                        sum += PA_N_V[i][aa] * s_ni_aj;
+                    }
+                    K[i][j] = sum;
+                }
+            for (int i = 0; i < PA_N; ++i)
+                for (int j = 0; j < PA_M; ++j) {
+                    double sum = 0.0;
+                    for (int aa = 0; aa < PA_N; ++aa) sum += S[i][aa] * PA_N_I[aa][j];
+                    SNI[i][j] = sum;
+                }
+        };
+        // a failed inversion keeps the previous (codegen) matrices in the reference; it cannot fail for a positive rate, so say so
+        if (!lu_invert<PA_N>(&a[0][0], &inv[0][0])) throw std::runtime_error("power amp: singular system matrix");
+        std::memcpy(c.s, inv, sizeof c.s); derive(c.s, c.k, c.s_ni);
+        if (!lu_invert<PA_N>(&a_be[0][0], &inv[0][0])) throw std::runtime_error("power amp: singular BE system matrix");
+        std::memcpy(c.s_be, inv, sizeof c.s_be); derive(c.s_be, c.k_be, c.s_ni_be);
+        c.dc_block_r = 1.0 - 2.0 * 3.14159265358979323846 * 5.0 / rate;
+    }
+    const double dt = 1.0 / rate;
+    c.alpha_attack = 1.0 - std::exp(-dt / 0.008);
+    c.alpha_release = 1.0 - std::exp(-dt / 0.015);
+    c.alpha_i_avg = 1.0 - std::exp(-dt / 0.030);
+    for (int d = 0; d < 8; ++d) {
+        if (PA_DEV_USE_GP[d] == 0.0) throw std::runtime_error("power amp: a device without Gummel-Poon terms (only the GP branch is built)");
+        OwPaConsts::Dev& D = c.dev[d];
+        const double is = PA_DEV_IS[d], vt = PA_DEV_VT[d], nf = PA_DEV_NF[d], nr = PA_DEV_NR[d], bf = PA_DEV_BETA_F[d], br = PA_DEV_BETA_R[d];
+        const double ise = PA_DEV_ISE[d], ne = PA_DEV_NE[d], isc = PA_DEV_ISC[d], nc = PA_DEV_NC[d];
+        D.is = is; D.vt = vt; D.sign = PA_DEV_SIGN[d]; D.vcrit = PA_DEV_VCRIT[d]; D.rb = PA_DEV_RB[d]; D.rc = PA_DEV_RC[d]; D.re = PA_DEV_RE[d];
+        D.nf_vt = nf * vt; D.nr_vt = nr * vt; D.ne_vt = ne * vt; D.nc_vt = nc * vt;
+        D.var = PA_DEV_VAR[d]; D.vaf = PA_DEV_VAF[d]; D.ikf = PA_DEV_IKF[d]; D.ikr = PA_DEV_IKR[d];
+        D.is_bf = is / bf; D.is_br = is / br;
+        D.c_dib_fwd = is / (bf * D.nf_vt); D.c_dib_rev = is / (br * D.nr_vt);
+        D.ise = ise; D.isc = isc; D.c_leak_be = ise / (ne * vt); D.c_leak_bc = isc / (nc * vt);
+        D.c_dq2_be = is / (D.nf_vt * D.ikf); D.c_dq2_bc = is / (D.nr_vt * D.ikr);
+        D.c_dicc_be = is / D.nf_vt; D.c_dicc_bc = -is / D.nr_vt;
+        D.max_step = 4.0 * vt;
+    }
+}
+
 static void build_consts(OwConsts& c, double sample_rate, int preamp_kind) {
     std::memset(&c, 0, sizeof c);
     c.sr = sample_rate;

@@ -138,6 +138,32 @@ struct OwConsts {
     double m_noise_scale;    // sqrt(8 k_B T fs_chain), T = 290 K (gen_preamp.rs:1752,1936)
 };
 
+#define PA_N 20   /* gen_power_amp.rs:29 */
+#define PA_M 16   /* gen_power_amp.rs:38 */
+// Pool-uniform constants of the amp at the chain rate (host: ow_consts_host.hpp build_pa_consts).
+struct OwPaConsts {
+    double a_neg[PA_N][PA_N], s[PA_N][PA_N], k[PA_M][PA_M], s_ni[PA_N][PA_M];
+    double a_neg_be[PA_N][PA_N], s_be[PA_N][PA_N], k_be[PA_M][PA_M], s_ni_be[PA_N][PA_M];
+    double dc_block_r;
+    double alpha_attack, alpha_release, alpha_i_avg;      // RailDynamics::set_sample_rate
+    int rate_is_codegen;                                   // |rate - 88 200| <= 0.5: init_state skips set_sample_rate (power_amp.rs:299-301)
+    int pad;
+    // per-device constants and the constant quotients the device model forms on every call (IEEE divisions done once on the host:
+    // the same bits as forming them per call)
+    struct Dev {
+        double is, vt, sign, vcrit, rb, rc, re;
+        double nf_vt, nr_vt, ne_vt, nc_vt;        // n * VT
+        double var, vaf, ikf, ikr;
+        double is_bf, is_br;                      // is / beta_f, is / beta_r
+        double c_dib_fwd, c_dib_rev;              // is / (beta_f * nf_vt), is / (beta_r * nr_vt)
+        double ise, isc, c_leak_be, c_leak_bc;    // ise / (ne * vt), isc / (nc * vt)
+        double c_dq2_be, c_dq2_bc;                // is / (nf_vt * ikf), is / (nr_vt * ikr)
+        double c_dicc_be, c_dicc_bc;              // is / nf_vt, -is / nr_vt
+        double max_step;                          // 4 * vt
+    } dev[8];
+};
+
+
 // per-engine per-render parameters (host -> device)
 // Thermal-noise state of the melange preamp's main solver state, one column per engine in a separate [NZ_COUNT][I] buffer
 // (gen_preamp.rs:1708-1745): 11 xoshiro256++ streams, Marsaglia-polar second values, two-draw lag, BE-replay cache.
@@ -160,4 +186,6 @@ struct OwEngineArgs {
     uint32_t set_flags;      // bit0 depth, bit1 spk, bit2 vol
     uint32_t noise_on;       // melange preamp thermal noise enabled (engine.rs:394; block-rate, persists)
     double thermal_gain;     // set_noise_gain -> set_thermal_gain (engine.rs:398-399)
+    uint32_t pa_flags;       // melange power amp: bit0 rail sag on (engine.rs:406-408; block-rate, persists)
+    uint32_t pad;
 };

@@ -11,7 +11,7 @@ import enum
 import numpy as np
 
 from . import binding
-from .binding import OwDiag, OwError
+from .binding import OwDiag, OwError, OwPowerAmpDiag
 
 
 class VoiceState(enum.IntEnum):  # engine.rs:30-37
@@ -56,6 +56,19 @@ class _EngineHandle:
 
     def set_noise_gain(self, g):
         self._lib.ow_engine_set_noise_gain(self._h, float(g))
+
+    def set_rail_sag(self, on):
+        """engine.rs:406-408 (melange power amp; a no-op on the behavioural one)."""
+        self._lib.ow_engine_set_rail_sag(self._h, 1 if on else 0)
+
+    def rail_sag_enabled(self):
+        return bool(self._lib.ow_engine_rail_sag_enabled(self._h))
+
+    def power_amp_diag(self):
+        """engine.rs:418-420 ``(clamp_count, nr_max_iter_count, peak_output_volts)`` as the first three fields of the returned struct."""
+        d = OwPowerAmpDiag()
+        self._lib.ow_engine_power_amp_diag(self._h, C.byref(d))
+        return d
 
     def set_noise_seed(self, seed):
         """gen_preamp::set_seed of the melange preamp's main state (0 = process-wide clock entropy, the reference's only mode)."""
@@ -109,9 +122,9 @@ class _EngineHandle:
 class WurliEngine(_EngineHandle):
     """One engine on one GPU (a pool of one).  ``WurliEngine(sr)`` == ``WurliEngine::new(sr)``."""
 
-    def __init__(self, sample_rate, device=0, preamp_kind=0):
+    def __init__(self, sample_rate, device=0, preamp_kind=0, power_amp_kind=0):
         lib = binding.load_library()
-        h = lib.ow_engine_new(float(sample_rate), int(device), int(preamp_kind))
+        h = lib.ow_engine_new_with(float(sample_rate), int(device), int(preamp_kind), int(power_amp_kind))
         if not h:
             raise OwError(binding.take_error(lib))
         super().__init__(lib, h)
@@ -148,9 +161,9 @@ class WurliEngine(_EngineHandle):
 class EnginePool:
     """I independent engines rendered in lock-step (lane = engine on the GPU)."""
 
-    def __init__(self, sample_rate, n_engines, device=0, preamp_kind=0):
+    def __init__(self, sample_rate, n_engines, device=0, preamp_kind=0, power_amp_kind=0):
         self._lib = binding.load_library()
-        h = self._lib.ow_pool_new(float(sample_rate), int(n_engines), int(device), int(preamp_kind))
+        h = self._lib.ow_pool_new_with(float(sample_rate), int(n_engines), int(device), int(preamp_kind), int(power_amp_kind))
         if not h:
             raise OwError(binding.take_error(self._lib))
         self._h = C.c_void_p(h)
@@ -245,6 +258,17 @@ class EnginePool:
         if self._lib.ow_pool_read_preamp_out(self._h, out.ctypes.data_as(C.c_void_p), int(n_os), int(n_os)) != 0:
             raise OwError(binding.take_error(self._lib))
         return out
+
+    def power_amp_out(self, n_os):
+        """Test tap (openwurli_hip_test.h): the melange power amp's output per chain-rate sample of the last block, float64 [n, n_os]."""
+        out = np.zeros((self.n, int(n_os)), dtype=np.float64)
+        if self._lib.ow_test_pool_read_power_amp_out(self._h, out.ctypes.data_as(C.c_void_p), int(n_os), int(n_os)) != 0:
+            raise OwError(binding.take_error(self._lib) or "power-amp tap not enabled")
+        return out
+
+    def enable_power_amp_tap(self):
+        if self._lib.ow_test_pool_enable_power_amp_tap(self._h) != 0:
+            raise OwError("power-amp tap: not a melange power-amp pool")
 
     def set_profiling(self, on):
         self._lib.ow_pool_set_profiling(self._h, 1 if on else 0)

@@ -33,6 +33,7 @@ void owo_engine_power_amp_diag(void* e, unsigned long long* clamp, unsigned long
     *peak = w->power_amp_kind ? w->mel_pa.state.diag_peak_output : 0.0;
     *guard_resets = w->power_amp_kind ? w->mel_pa.guard_resets : 0ull;
 }
+void owo_engine_poke_pa_node(void* e, int node, double v) { ((WurliEngine*)e)->mel_pa.state.v_prev[node] = v; }
 // render with the power-amp tap (chain rate) besides the output
 void owo_engine_render_pa_tap(void* e, float* out, double* pa, size_t n) {
     WurliEngine* w = (WurliEngine*)e;

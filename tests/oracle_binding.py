@@ -24,6 +24,7 @@ def _configure(L):
     if True:
         L.owo_engine_new.restype = C.c_void_p
         L.owo_engine_new_kind.restype = C.c_void_p
+        L.owo_engine_new_kinds.restype = C.c_void_p
         for name in ("owo_midi_to_freq", "owo_tip_mass_ratio", "owo_reed_length_mm", "owo_pickup_displacement_scale",
                      "owo_fundamental_decay_rate", "owo_output_scale", "owo_velocity_exponent", "owo_velocity_scurve",
                      "owo_register_trim_db", "owo_pickup_rms_proxy", "owo_freq_detune", "owo_dwell_time", "owo_onset_ramp_time",
@@ -65,9 +66,9 @@ def _p(a):
 class OracleEngine:
     """CPU restatement of WurliEngine with the reference's method names."""
 
-    def __init__(self, sr, perturbed=False, preamp_kind=0):
+    def __init__(self, sr, perturbed=False, preamp_kind=0, power_amp_kind=0):
         self.L = lib_perturbed() if perturbed else lib()
-        self.h = C.c_void_p(self.L.owo_engine_new_kind(C.c_double(sr), int(preamp_kind)))
+        self.h = C.c_void_p(self.L.owo_engine_new_kinds(C.c_double(sr), int(preamp_kind), int(power_amp_kind)))
 
     def close(self):
         if self.h:
@@ -109,6 +110,24 @@ class OracleEngine:
         r = np.zeros(int(n) * osr, dtype=np.float64)
         self.L.owo_engine_render_taps(self.h, _p(out), _p(vs), _p(pre), _p(r), C.c_size_t(int(n)))
         return out, vs, pre, r
+
+    def set_rail_sag(self, on): self.L.owo_engine_set_rail_sag(self.h, 1 if on else 0)
+    def rail_sag_enabled(self): return bool(self.L.owo_engine_rail_sag_enabled(self.h))
+
+    def power_amp_diag(self):
+        """(clamp_count, nr_max_iter_count, peak_output_volts, guard_resets)"""
+        a, b, g = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
+        pk = C.c_double()
+        self.L.owo_engine_power_amp_diag(self.h, C.byref(a), C.byref(b), C.byref(pk), C.byref(g))
+        return a.value, b.value, pk.value, g.value
+
+    def render_pa_tap(self, n, osr=2):
+        out = np.zeros(int(n), dtype=np.float32)
+        pa = np.zeros(int(n) * osr, dtype=np.float64)
+        self.L.owo_engine_render_pa_tap(self.h, _p(out), _p(pa), C.c_size_t(int(n)))
+        return out, pa
+
+    def poke_power_amp_node(self, node, volts): self.L.owo_engine_poke_pa_node(self.h, int(node), C.c_double(volts))
 
     def count_voices_in_state(self, st): return self.L.owo_engine_count_state(self.h, int(st))
     def active_voice_count(self): return self.L.owo_engine_active_voice_count(self.h)

@@ -1,0 +1,140 @@
+"""Melange 7-BJT power amp + rail dynamics on the GPU (power_amp.rs:65-165,279-465; gen_power_amp.rs) against the
+oracle: the amp's own output per chain-rate sample (solver tap), the engine output, rail voltages, diag counters, set_rail_sag,
+reset / set_sample_rate, and a FORCED divergence whose guard reset must land on the same sample on both sides."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PA = 1   # OW_POWER_AMP_MELANGE
+
+
+def _pair(ow, oracle, sr, n=1, preamp_kind=0):
+    g = ow.EnginePool(sr, n, preamp_kind=preamp_kind, power_amp_kind=PA)
+    cs = [oracle.OracleEngine(sr, preamp_kind=preamp_kind, power_amp_kind=PA) for _ in range(n)]
+    g.enable_power_amp_tap()
+    return g, cs
+
+
+def _compare(oracle, g, cs, blocks, length, tag, osr=2, floor=None):
+    floor = oracle.ABS_FLOOR_OUTPUT if floor is None else floor
+    worst = 0.0
+    for b in range(blocks):
+        go = g.render(length)
+        gp = g.power_amp_out(osr * length)
+        for k, c in enumerate(cs):
+            co, cp = c.render_pa_tap(length, osr=osr)
+            # the amp's normalised output (+-1): the solver is the reference's operation order, so the tap is held far tighter than the bar
+            rp = oracle.parity_report(gp[k], cp, rel=1e-9, floor_frac=1.0, abs_floor=1e-12)
+            ro = oracle.parity_report(go[k], co, abs_floor=floor)
+            assert rp["n_bad"] == 0, (tag, "amp tap", b, k, rp)
+            assert ro["n_bad"] == 0, (tag, "out", b, k, ro)
+            worst = max(worst, ro["worst_ratio"])
+    return worst
+
+
+@pytest.mark.parametrize("sr", [44100.0, 48000.0, 96000.0])
+def test_engine_with_melange_power_amp(hiplib, oracle, sr):
+    """44.1 kHz host = the amp at its codegen rate (88.2 kHz chain: baked matrices); 48 kHz = rebuilt matrices at 96 kHz; 96 kHz host =
+    no oversampling, amp at 96 kHz in the base-rate loop."""
+    import openwurli_amd as ow
+    g, cs = _pair(ow, oracle, sr, n=2)
+    osr = 2 if sr < 88200.0 else 1
+    g.set_sample_rate(sr)
+    for c in cs:
+        c.set_sample_rate(sr)
+    for k in range(2):
+        for e in (g[k], cs[k]):
+            e.set_volume(0.6); e.set_tremolo_depth(0.4 + 0.5 * k); e.set_speaker_character(0.3 * k)
+            for n in ((45, 57, 64) if k == 0 else (40, 52, 60, 67, 76, 88)):
+                e.note_on(n, 0.95)
+    _compare(oracle, g, cs, 10, 256, ("chords", sr), osr=osr)
+    for k in range(2):
+        dg = g[k].power_amp_diag()
+        dc = cs[k].power_amp_diag()
+        assert (dg.clamp_count, dg.nr_max_iter_count, dg.guard_resets) == (dc[0], dc[1], dc[3])
+        assert abs(dg.peak_output_volts - dc[2]) <= 1e-9 * max(1.0, dc[2])
+        assert g[k].rail_sag_enabled() and 22.5 < dg.rail_pos_volts <= 24.5
+    # rail sag off on engine 0 (offsets zero from the next block on), then on again; engine 1 is re-struck meanwhile
+    g[0].set_rail_sag(False); cs[0].set_rail_sag(False)
+    for e in (g[1], cs[1]):
+        e.note_off(60); e.note_on(60, 1.0)
+    _compare(oracle, g, cs, 4, 256, ("sag off", sr), osr=osr)
+    assert not g[0].rail_sag_enabled() and g[0].power_amp_diag().rail_pos_volts == 22.5
+    g[0].set_rail_sag(True); cs[0].set_rail_sag(True)
+    _compare(oracle, g, cs, 3, 333, ("sag on again", sr), osr=osr)
+    g.close()
+
+
+def test_forced_divergence_guard_lands_on_the_same_sample(hiplib, oracle):
+    """power_amp.rs:373-421: a node past 100 V trips the guard -- state back to the settled point, rails reset, output = last good sample.
+    Both sides are poked between two blocks; the hold, the reset and the recovery must coincide sample for sample."""
+    import openwurli_amd as ow
+    sr = 48000.0
+    g, cs = _pair(ow, oracle, sr, n=3)
+    g.set_sample_rate(sr)
+    for c in cs:
+        c.set_sample_rate(sr)
+    for k in range(3):
+        for e in (g[k], cs[k]):
+            e.set_volume(0.5); e.set_tremolo_depth(0.5)
+            for n in (48, 55, 60, 64, 67):
+                e.note_on(n, 0.9)
+    _compare(oracle, g, cs, 4, 256, "before")
+    # engine 1: NODE_OUT (8) forced to 1e6 V; engine 2: a NaN on the inverting input node (6): the solver's own NaN reset + the guard
+    assert hiplib.ow_test_engine_poke_power_amp_node(g[1]._h, 8, 1e6) == 0
+    cs[1].poke_power_amp_node(8, 1e6)
+    assert hiplib.ow_test_engine_poke_power_amp_node(g[2]._h, 6, float("nan")) == 0
+    cs[2].poke_power_amp_node(6, float("nan"))
+    _compare(oracle, g, cs, 6, 256, "after the poke")
+    d = [g[k].power_amp_diag() for k in range(3)]
+    oc = [cs[k].power_amp_diag() for k in range(3)]
+    assert d[0].guard_resets == oc[0][3] == 0
+    assert d[1].guard_resets == oc[1][3] >= 1 and d[2].guard_resets == oc[2][3] >= 1
+    assert [x.nr_max_iter_count for x in d] == [x[1] for x in oc]
+    g.close()
+
+
+def test_reset_and_pool_of_many(hiplib, oracle):
+    """reset() = PowerAmp::reset (settled state, rails back to 22.5 V, last_good kept) inside WurliEngine::reset; a pool of 70 engines with
+    different scripts (two wavefronts of the lane = engine kernel, ragged second one)."""
+    import openwurli_amd as ow
+    sr, n = 44100.0, 70
+    g = ow.EnginePool(sr, n, power_amp_kind=PA)
+    g.enable_power_amp_tap()
+    picks = (0, 1, 63, 64, 69)
+    cs = {k: oracle.OracleEngine(sr, power_amp_kind=PA) for k in picks}
+    for k in range(n):
+        g[k].set_tremolo_depth((k % 5) / 4.0)
+        for nn in (40 + k % 30, 60 + k % 20):
+            g[k].note_on(nn, 0.5 + 0.5 * ((k * 7) % 10) / 10.0)
+    for k, c in cs.items():
+        c.set_tremolo_depth((k % 5) / 4.0)
+        for nn in (40 + k % 30, 60 + k % 20):
+            c.note_on(nn, np.float32(0.5 + 0.5 * ((k * 7) % 10) / 10.0))
+    for b in range(6):
+        go = g.render(256)
+        for k, c in cs.items():
+            rep = oracle.parity_report(go[k], c.render(256), abs_floor=oracle.ABS_FLOOR_OUTPUT)
+            assert rep["n_bad"] == 0, ("pool", b, k, rep)
+    g[64].reset(); cs[64].reset()
+    g[1].reset(); cs[1].reset()
+    for k in (1, 64):
+        for e in (g[k], cs[k]):
+            e.note_on(72, 0.8)
+    for b in range(4):
+        go = g.render(300)
+        for k, c in cs.items():
+            rep = oracle.parity_report(go[k], c.render(300), abs_floor=oracle.ABS_FLOOR_OUTPUT)
+            assert rep["n_bad"] == 0, ("after reset", b, k, rep)
+    assert np.all(np.isfinite(go)) and np.max(np.abs(go)) > 1e-3
+    g.close()
+
+
+def test_behavioural_pool_reports_no_rails(hiplib):
+    import openwurli_amd as ow
+    e = ow.WurliEngine(48000.0)
+    e.set_rail_sag(True)                               # a no-op: the behavioural amp has no separable rails (power_amp.rs:262-272)
+    d = e.power_amp_diag()
+    assert not e.rail_sag_enabled() and (d.clamp_count, d.nr_max_iter_count, d.peak_output_volts) == (0, 0, 0.0)
+    e.close()
