@@ -53,6 +53,14 @@ int ow_test_pool_stagger_tremolo(ow_pool*, size_t n_groups);
 /* Number of tremolo phase groups of the pool (1 for a fresh pool, +1 for every engine reset / warmed up on its own). */
 size_t ow_test_pool_tremolo_groups(const ow_pool*);
 
+/* The melange power amp ALONE (melange_adapter::PowerAmp::new_at_sample_rate(sample_rate) + process, power_amp.rs:335-431) on n_rows
+ * independent input rows of n samples each (f64 [n_rows][n]), one solver per row.  poke_at / poke_node / poke_val (each [n_rows], or all
+ * NULL): before sample poke_at[r] of row r, node voltage poke_node[r] of the solver state is overwritten with poke_val[r] (forced
+ * divergence).  out: [n_rows][n] normalised amp output; taps (or NULL): [n_rows][n][3] = outer Newton iterations of the sample (70 =
+ * exhausted), divergence-guard resets so far, positive rail voltage after the sample.  Returns 0, <0 on error. */
+int ow_debug_power_amp(double sample_rate, const double* in, size_t n_rows, size_t n, int rail_sag, const long long* poke_at, const int* poke_node,
+                       const double* poke_val, double* out, double* taps, int device);
+
 /* ---- melange power amp: solver taps ------------------------------------------------------------ */
 /* Keep the amp's output of every chain-rate sample of the last block (before the half-band down-sampler): f64 [n_engines][n_os] through
  * ow_test_pool_read_power_amp_out.  Costs 16 B per engine and chain-rate sample of the block capacity; off until enabled. */

@@ -1571,6 +1571,38 @@ size_t ow_test_pool_tremolo_groups(const ow_pool* p) {
     for (size_t e = 0; e < p->I; ++e) n += p->h_lead[e] == (uint32_t)e;
     return n;
 }
+int ow_debug_power_amp(double sample_rate, const double* in, size_t n_rows, size_t n, int rail_sag, const long long* poke_at, const int* poke_node,
+                       const double* poke_val, double* out, double* taps, int device) {
+    try {
+        if (!in || !out || n_rows == 0 || n == 0 || !(sample_rate > 0.0)) throw std::runtime_error("bad argument");
+        HIP_OK(hipSetDevice(device));
+        StreamOwner so;
+        HIP_OK(hipStreamCreateWithFlags(&so.s, hipStreamNonBlocking));
+        std::unique_ptr<OwPaConsts> hc(new OwPaConsts());
+        owhip::build_pa_consts(*hc, sample_rate);
+        DevMem dC, dS, dIn, dOut, dT, dPa, dPn, dPv;
+        dC.alloc(sizeof(OwPaConsts)); dS.alloc(sizeof(double) * owdev::PAS_CIRCUIT_END);
+        dIn.alloc(sizeof(double) * n_rows * n); dOut.alloc(sizeof(double) * n_rows * n);
+        if (taps) dT.alloc(sizeof(double) * n_rows * n * 3);
+        pa_settled_to_device(device, dS.as<double>(), so.s);
+        HIP_OK(hipMemcpyAsync(dC.p, hc.get(), sizeof(OwPaConsts), hipMemcpyHostToDevice, so.s));
+        HIP_OK(hipMemcpyAsync(dIn.p, in, sizeof(double) * n_rows * n, hipMemcpyHostToDevice, so.s));
+        if (poke_at) {
+            dPa.alloc(sizeof(long long) * n_rows); dPn.alloc(sizeof(int) * n_rows); dPv.alloc(sizeof(double) * n_rows);
+            HIP_OK(hipMemcpyAsync(dPa.p, poke_at, sizeof(long long) * n_rows, hipMemcpyHostToDevice, so.s));
+            HIP_OK(hipMemcpyAsync(dPn.p, poke_node, sizeof(int) * n_rows, hipMemcpyHostToDevice, so.s));
+            HIP_OK(hipMemcpyAsync(dPv.p, poke_val, sizeof(double) * n_rows, hipMemcpyHostToDevice, so.s));
+        }
+        owdev::k_mpa_debug<<<dim3((unsigned)n_rows), dim3(64), 0, so.s>>>(dC.as<OwPaConsts>(), dS.as<double>(), dIn.as<double>(), dOut.as<double>(),
+                                                                          taps ? dT.as<double>() : nullptr, (long long)n, rail_sag, poke_at ? dPa.as<long long>() : nullptr,
+                                                                          dPn.as<int>(), dPv.as<double>());
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpyAsync(out, dOut.p, sizeof(double) * n_rows * n, hipMemcpyDeviceToHost, so.s));
+        if (taps) HIP_OK(hipMemcpyAsync(taps, dT.p, sizeof(double) * n_rows * n * 3, hipMemcpyDeviceToHost, so.s));
+        HIP_OK(hipStreamSynchronize(so.s));
+        return 0;
+    } catch (const std::exception& ex) { set_err(std::string("ow_debug_power_amp: ") + ex.what()); return -1; }
+}
 int ow_test_pool_enable_power_amp_tap(ow_pool* p) {
     if (!p || p->power_amp_kind != OW_POWER_AMP_MELANGE) return -1;
     if (p->d_pa_tap) return 0;

@@ -456,6 +456,28 @@ __global__ __launch_bounds__(64) void k_mpa_settle(const OwPaConsts* __restrict_
     settled[PAS_CLAMP] = bitsd(st.clamp_cnt); settled[PAS_NRMAX] = bitsd(st.nrmax_cnt); settled[PAS_NAN] = bitsd(st.nan_cnt);
 }
 
+// The amp alone on given input (debug hook ow_debug_power_amp): lane b of block b processes row b of `in`.  taps [row][n][3]: outer Newton
+// iterations of the sample (70 = exhausted), guard resets so far, positive rail after the sample.
+__global__ __launch_bounds__(64) void k_mpa_debug(const OwPaConsts* __restrict__ C, const double* __restrict__ settled, const double* __restrict__ in,
+                                                  double* __restrict__ out, double* __restrict__ taps, long long n, int rail_sag, const long long* __restrict__ poke_at,
+                                                  const int* __restrict__ poke_node, const double* __restrict__ poke_val) {
+    __shared__ double JA_all[PA_M * PA_M * 64];
+    if (threadIdx.x != 0) return;
+    const size_t row = blockIdx.x;
+    PaState st;
+    pa_init_state(&st, settled, C);
+    pa_rails_reset(&st);
+    st.last_good = 0.0; st.guard_cnt = 0ull;
+    for (long long i = 0; i < n; ++i) {
+        if (poke_at && poke_at[row] == i) st.v[poke_node[row]] = poke_val[row];
+        out[row * n + i] = pa_process(&st, C, settled, in[row * n + i], rail_sag != 0, JA_all);
+        if (taps) {
+            double* t = taps + (row * n + i) * 3;
+            t[0] = (double)st.last_nr; t[1] = (double)st.guard_cnt; t[2] = st.rail_p;
+        }
+    }
+}
+
 // PowerAmp::new_at_sample_rate (mode 1: fresh object -- last_good 0, rails at the DC bias) / PowerAmp::reset (mode 0: state and
 // rails only, last_good survives) for engines [e0, e0+ne), power_amp.rs:335-347,453-458
 __global__ void k_mpa_init(const OwPaConsts* __restrict__ C, const double* __restrict__ settled, double* __restrict__ pa, int I, int e0, int ne, int fresh) {

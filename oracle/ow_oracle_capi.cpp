@@ -58,6 +58,15 @@ void owo_mpa_process(void* p, const double* in, double* out, double* taps, size_
         }
     }
 }
+// the same interface as the product's debug hook ow_debug_power_amp (one row): taps [n][3] = outer iterations, guard resets, positive rail
+void owo_mpa_run(double sr, const double* in, size_t n, int rail_sag, long long poke_at, int poke_node, double poke_val, double* out, double* taps) {
+    MelangePowerAmp a; a.init(sr); a.set_rail_sag(rail_sag != 0);
+    for (size_t i = 0; i < n; ++i) {
+        if (poke_at == (long long)i) a.state.v_prev[poke_node] = poke_val;
+        out[i] = a.process(in[i]);
+        if (taps) { taps[3 * i] = (double)a.state.last_nr_iterations; taps[3 * i + 1] = (double)a.guard_resets; taps[3 * i + 2] = a.rails.v_rail_pos; }
+    }
+}
 void owo_mpa_rails(void* p, double* pos, double* neg) {
     const MelangePowerAmp* a = (const MelangePowerAmp*)p;
     *pos = a->rail_sag_on ? a->rails.v_rail_pos : 22.5; *neg = a->rail_sag_on ? a->rails.v_rail_neg : 22.5;

@@ -16,6 +16,43 @@ def _pair(ow, oracle, sr, n=1, preamp_kind=0):
     return g, cs
 
 
+def test_solver_alone_follows_the_oracle_bit_for_bit(hiplib, oracle):
+    """The amp by itself on given input (ow_debug_power_amp against the oracle's adapter): sines from small signal to hard clipping, noise,
+    at the codegen rate (88.2 kHz, baked matrices) and at 96 kHz (rebuilt), rail sag on and off, with a node poked past 100 V and a NaN
+    mid-stream.  The device runs the reference's operation order with IEEE division / sqrt and the arithmetic-only fast_exp, so outputs,
+    Newton iteration counts and guard resets must be IDENTICAL on every row, outputs and rail voltages bit-identical on the smooth rows
+    and within 1e-12 where pnjlim's logarithm (glibc vs the device library, <= 1 ulp apart) takes part: clipping, white noise, and the
+    restart after a guard reset (measured 1e-14)."""
+    import ctypes as C
+    L = oracle.lib()
+    n = 3600
+    rng = np.random.default_rng(5)
+    for sr in (88200.0, 96000.0):
+        t = np.arange(n) / sr
+        rows = [0.001 * np.sin(2 * np.pi * 1000 * t), 0.05 * np.sin(2 * np.pi * 220 * t), 0.3 * np.sin(2 * np.pi * 110 * t),
+                5.0 * np.sin(2 * np.pi * 100 * t), 0.02 * rng.standard_normal(n), 0.05 * np.sin(2 * np.pi * 330 * t), 0.05 * np.sin(2 * np.pi * 330 * t)]
+        poke_at = np.array([-1, -1, -1, -1, -1, 1500, 2100], dtype=np.int64)
+        poke_node = np.array([0, 0, 0, 0, 0, 8, 6], dtype=np.int32)
+        poke_val = np.array([0, 0, 0, 0, 0, 1e6, float("nan")])
+        x = np.ascontiguousarray(np.stack(rows))
+        for sag in (1, 0):
+            out = np.zeros_like(x); taps = np.zeros(x.shape + (3,))
+            assert hiplib.ow_debug_power_amp(sr, x.ctypes.data_as(C.c_void_p), x.shape[0], n, sag, poke_at.ctypes.data_as(C.c_void_p),
+                                             poke_node.ctypes.data_as(C.c_void_p), poke_val.ctypes.data_as(C.c_void_p),
+                                             out.ctypes.data_as(C.c_void_p), taps.ctypes.data_as(C.c_void_p), 0) == 0
+            for r in range(x.shape[0]):
+                co = np.zeros(n); ct = np.zeros((n, 3))
+                L.owo_mpa_run(C.c_double(sr), x[r].ctypes.data_as(C.c_void_p), C.c_size_t(n), sag, C.c_longlong(int(poke_at[r])), int(poke_node[r]),
+                              C.c_double(poke_val[r]), co.ctypes.data_as(C.c_void_p), ct.ctypes.data_as(C.c_void_p))
+                assert np.array_equal(taps[r, :, 1], ct[:, 1]), ("guard resets", sr, sag, r)          # the guard fires on the same samples
+                assert np.array_equal(taps[r, :, 0], ct[:, 0]), ("newton iterations", sr, sag, r)
+                assert np.max(np.abs(out[r] - co)) < 1e-12 and np.max(np.abs(taps[r, :, 2] - ct[:, 2])) < 1e-12, (sr, sag, r, np.max(np.abs(out[r] - co)))
+                if r in (0, 1, 2):      # smooth signals never reach pnjlim's logarithm: every bit agrees
+                    assert np.array_equal(out[r], co) and np.array_equal(taps[r, :, 2], ct[:, 2]), (sr, sag, r, np.max(np.abs(out[r] - co)))
+            assert taps[5, -1, 1] >= 1 and taps[6, -1, 1] >= 1 and taps[0, -1, 1] == 0
+            assert np.max(np.abs(out[3])) > 0.85                                                        # the clipping row does clip
+
+
 def _compare(oracle, g, cs, blocks, length, tag, osr=2, floor=None):
     floor = oracle.ABS_FLOOR_OUTPUT if floor is None else floor
     worst = 0.0
@@ -24,8 +61,10 @@ def _compare(oracle, g, cs, blocks, length, tag, osr=2, floor=None):
         gp = g.power_amp_out(osr * length)
         for k, c in enumerate(cs):
             co, cp = c.render_pa_tap(length, osr=osr)
-            # the amp's normalised output (+-1): the solver is the reference's operation order, so the tap is held far tighter than the bar
-            rp = oracle.parity_report(gp[k], cp, rel=1e-9, floor_frac=1.0, abs_floor=1e-12)
+            # the amp's normalised output (+-1).  Its INPUT is the preamp's output, which carries the legacy preamp's Newton-stop floor
+            # (2e-9 V, oracle_binding.ABS_FLOOR_PREAMP) x 0.25 drive x the amp's gain 69/22: the tap cannot be tighter than that; the
+            # solver by itself is compared bit for bit in test_solver_alone_follows_the_oracle_bit_for_bit
+            rp = oracle.parity_report(gp[k], cp, abs_floor=oracle.ABS_FLOOR_PREAMP)
             ro = oracle.parity_report(go[k], co, abs_floor=floor)
             assert rp["n_bad"] == 0, (tag, "amp tap", b, k, rp)
             assert ro["n_bad"] == 0, (tag, "out", b, k, ro)
@@ -53,7 +92,7 @@ def test_engine_with_melange_power_amp(hiplib, oracle, sr):
         dg = g[k].power_amp_diag()
         dc = cs[k].power_amp_diag()
         assert (dg.clamp_count, dg.nr_max_iter_count, dg.guard_resets) == (dc[0], dc[1], dc[3])
-        assert abs(dg.peak_output_volts - dc[2]) <= 1e-9 * max(1.0, dc[2])
+        assert abs(dg.peak_output_volts - dc[2]) <= 1e-7      # volts at the amp's output node: the preamp's 2e-9 V Newton floor x 0.25 x 69
         assert g[k].rail_sag_enabled() and 22.5 < dg.rail_pos_volts <= 24.5
     # rail sag off on engine 0 (offsets zero from the next block on), then on again; engine 1 is re-struck meanwhile
     g[0].set_rail_sag(False); cs[0].set_rail_sag(False)
