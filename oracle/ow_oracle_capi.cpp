@@ -147,6 +147,9 @@ size_t owo_batch_render_job_kind(int note, int vel_u8, double dur_s, double sr, 
 // ---- unit-level hooks for the known-answer tests ----
 double owo_midi_to_freq(int m) { return midi_to_freq(m); }
 double owo_tip_mass_ratio(int m) { return tip_mass_ratio(m); }
+void owo_eigenvalues(double mu, double* out) { eigenvalues(mu, out); }
+double owo_mode_shape(double beta, double xi) { return mode_shape(beta, xi); }
+double owo_reed_compliance(int m) { return reed_compliance(m); }
 void owo_mode_ratios(double mu, double* out) { mode_ratios(mu, out); }
 double owo_reed_length_mm(int m) { return reed_length_mm(m); }
 void owo_reed_blank_dims(int m, double* wt) { reed_blank_dims(m, wt[0], wt[1]); }
@@ -326,6 +329,23 @@ void owo_speaker_run(double sr, double character, double* x, size_t n) {
     s.init(sr);
     s.set_character(character);
     for (size_t i = 0; i < n; ++i) x[i] = s.process(x[i]);
+}
+void owo_oversampler_down(const double* up, double* y, size_t n_out) { Oversampler os; os.downsample_2x(up, y, n_out); }
+// G (without R_ldr), 2w and v at the DC point of the legacy preamp, for the layer-1 / layer-4 tests of the reference's pyramid
+void owo_preamp_gw(double sr, double* g64, double* two_w8) {
+    DkPreamp p;
+    p.init(sr);
+    for (int i = 0; i < 8; ++i) { for (int j = 0; j < 8; ++j) g64[i * 8 + j] = p.g_dc_base[i][j]; two_w8[i] = p.two_w[i]; }
+}
+// legacy preamp with R_ldr set BEFORE reset() (the pyramid's time-domain tests), then n_pre samples of x_pre, an R step, n samples of x
+void owo_preamp_step(double sr, double r0, size_t n_pre, double r1, const double* x, double* y, size_t n, double* v8_end) {
+    DkPreamp p;
+    p.init(sr);
+    p.set_ldr_resistance(r0); p.reset();
+    for (size_t i = 0; i < n_pre; ++i) p.process_sample(0.0);
+    p.set_ldr_resistance(r1);
+    for (size_t i = 0; i < n; ++i) y[i] = p.process_sample(x ? x[i] : 0.0);
+    if (v8_end) for (int i = 0; i < 8; ++i) v8_end[i] = p.main.v[i];
 }
 void owo_oversampler_roundtrip(const double* x, double* up, double* y, size_t n) {
     Oversampler os;

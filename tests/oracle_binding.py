@@ -29,7 +29,7 @@ def _configure(L):
                      "owo_fundamental_decay_rate", "owo_output_scale", "owo_velocity_exponent", "owo_velocity_scurve",
                      "owo_register_trim_db", "owo_pickup_rms_proxy", "owo_freq_detune", "owo_dwell_time", "owo_onset_ramp_time",
                      "owo_pickup_soft_saturate", "owo_fast_exp", "owo_power_amp", "owo_alias_dft_magnitude", "owo_alias_bandpass_rms",
-                     "owo_alias_plateau_metric"):
+                     "owo_alias_plateau_metric", "owo_mode_shape", "owo_reed_compliance"):
             getattr(L, name).restype = C.c_double
         L.owo_render_note.restype = C.c_size_t
         L.owo_batch_render_job.restype = C.c_size_t

@@ -69,6 +69,45 @@ def test_spatial_coupling_normalised(oracle):
     assert k[6] < k[1]                                   # higher bending modes cancel more inside the plate window
 
 
+def test_tables_remaining_reference_tests(oracle):
+    """The rest of tables.rs's own test module (tables.rs:837-1222; the intermod-risk report :675-801 and its three tests are outside the
+    hot path): tip-mass range, decay monotone in pitch, mode shapes (clamped at the root, alive at the tip), spatial coupling
+    (mode 1 exactly 1, decreasing, register variation), eigenvalues <-> mode_ratios, blank dimensions incl. the smooth bass/mid
+    transition, compliance, displacement-scale range."""
+    L = oracle.lib()
+    assert L.owo_tip_mass_ratio(33) > 0.05 and L.owo_tip_mass_ratio(57) < 0.02                                    # :863-867
+    assert L.owo_fundamental_decay_rate(60) > L.owo_fundamental_decay_rate(48)                                    # :869-873
+    assert L.owo_fundamental_decay_rate(84) > L.owo_fundamental_decay_rate(72)
+    b = np.zeros(7); r = np.zeros(7)
+    for mu in (0.0, 0.05, 0.10, 0.20, 0.50):                                                                      # :988-1016
+        L.owo_eigenvalues(d(mu), _p(b))
+        for beta in b:
+            assert abs(L.owo_mode_shape(d(beta), d(1.0))) > 0.1
+            assert abs(L.owo_mode_shape(d(beta), d(0.0))) < 1e-10
+    for mu in (0.0, 0.01, 0.05, 0.10, 0.15, 0.20, 0.30, 0.50):                                                    # :1078-1094
+        L.owo_eigenvalues(d(mu), _p(b)); L.owo_mode_ratios(d(mu), _p(r))
+        assert np.max(np.abs(b * b / (b[0] * b[0]) - r)) < 1e-10
+    k = np.zeros(7)
+    for midi in range(33, 97, 4):                                                                                 # :1018-1058
+        L.owo_spatial_coupling(d(L.owo_tip_mass_ratio(midi)), d(L.owo_reed_length_mm(midi)), _p(k))
+        assert abs(k[0] - 1.0) < 1e-10 and np.all(k[1:] <= k[0] + 1e-6) and k[1] < k[0]
+    kb, kt = np.zeros(7), np.zeros(7)                                                                             # :1060-1076
+    L.owo_spatial_coupling(d(L.owo_tip_mass_ratio(33)), d(L.owo_reed_length_mm(33)), _p(kb))
+    L.owo_spatial_coupling(d(L.owo_tip_mass_ratio(96)), d(L.owo_reed_length_mm(96)), _p(kt))
+    assert np.all(kt[2:] < kb[2:])
+    wt = np.zeros(2)
+    L.owo_reed_blank_dims(74, _p(wt))                                                                             # :1097-1112
+    assert abs(wt[0] - 0.121 * 25.4) < 0.01 and abs(wt[1] - 0.034 * 25.4) < 0.01
+    t = {}
+    for m in (48, 53, 58):                                                                                        # :1114-1134
+        L.owo_reed_blank_dims(m, _p(wt)); t[m] = wt[1]
+    assert abs(t[48] - 0.026 * 25.4) < 0.01 and abs(t[58] - 0.034 * 25.4) < 0.01 and t[48] + 0.02 < t[53] < t[58] - 0.02
+    cb, cm, ct = (L.owo_reed_compliance(m) for m in (33, 60, 96))                                                 # :1136-1151
+    assert cb > 5.0 * cm and cm > 2.0 * ct
+    ds33, ds60, ds96 = (L.owo_pickup_displacement_scale(m) for m in (33, 60, 96))                                 # :1153-1205
+    assert ds33 >= ds60 > ds96 and ds33 > 0.50 and ds96 < 0.35 and ds33 / ds96 > 2.5
+
+
 def test_velocity_curves(oracle):
     L = oracle.lib()
     assert abs(L.owo_velocity_scurve(d(0.0))) < 1e-12 and abs(L.owo_velocity_scurve(d(1.0)) - 1.0) < 1e-12
@@ -230,7 +269,196 @@ def test_oversampler_roundtrip(oracle):                   # oversampler.rs tests
     assert abs(20 * np.log10(g)) < 0.5
 
 
-# ---------------------------------------------------------------- dk_preamp_legacy.rs:901-981,1296-1530,1921-2082
+def test_oversampler_stopband_and_white_noise_gain(oracle):       # oversampler.rs:197-262
+    L = oracle.lib()
+    n = 4096
+    up = np.sin(2 * np.pi * 30000.0 * np.arange(2 * n) / 88200.0)
+    y = np.zeros(n)
+    L.owo_oversampler_down(_p(up), _p(y), C.c_size_t(n))
+    att = 20 * np.log10(np.max(np.abs(y[n // 2:])) / np.max(np.abs(up[n:])))
+    assert att < -20.0
+    # white noise through the decimator: half the band is removed and the two branches are averaged (the reference prints the drop;
+    # it is the theoretical 3 dB of a half-band decimator, not the "~9 dB" of its comment) -- xorshift64 stream of the reference's test
+    state = 0x9E3779B97F4A7C15
+    vals = np.zeros(2 * n)
+    for i in range(2 * n):
+        state ^= (state << 13) & 0xFFFFFFFFFFFFFFFF
+        state ^= state >> 7
+        state ^= (state << 17) & 0xFFFFFFFFFFFFFFFF
+        vals[i] = ((state >> 11) * (1.0 / (1 << 53)) - 0.5) * np.sqrt(12.0)
+    out = np.zeros(n)
+    L.owo_oversampler_down(_p(vals), _p(out), C.c_size_t(n))
+    drop = 20 * np.log10(np.sqrt(np.mean(vals[128:] ** 2)) / np.sqrt(np.mean(out[64:] ** 2)))
+    assert abs(np.sqrt(np.mean(vals ** 2)) - 1.0) < 0.05 and 2.0 < drop < 4.5
+
+
+# ---------------------------------------------------------------- dk_preamp_legacy.rs: the layered test pyramid
+R1, R2, R3, RE1, RC1, RE2A, RE2B, RC2, R9, R10 = 22e3, 2e6, 470e3, 33e3, 150e3, 270.0, 820.0, 1.8e3, 6.8e3, 56e3
+CIN, C3, C4, CE1, CE2, VCC = 0.022e-6, 100e-12, 100e-12, 4.7e-6, 22e-6, 15.0
+BASE1, EMIT1, COLL1, EMIT2, EMIT2B, COLL2, OUT, FB = range(8)
+
+
+def _preamp_gcw(oracle, sr=88200.0):
+    L = oracle.lib()
+    g = np.zeros(64); w2 = np.zeros(8)
+    L.owo_preamp_gw(d(sr), _p(g), _p(w2))
+    s = np.zeros(64); an = np.zeros(64); k = np.zeros(4); sff = C.c_double(0)
+    L.owo_preamp_matrices(d(sr), _p(s), _p(an), _p(k), C.byref(sff))
+    G = g.reshape(8, 8)
+    # A_neg = 2C/T - G_trap, where the trapezoidal G carries the Cin-R1 companion conductance g_cin at [base1][base1] on top of the
+    # DC conductances (dk_preamp_legacy.rs:283-309): g_cin = 2 Cin / (T + 2 R1 Cin) (bilinear series RC)
+    t = 1.0 / sr
+    g_cin = 2.0 * 0.022e-6 / (t + 2.0 * 22e3 * 0.022e-6)
+    Gt = G.copy(); Gt[0, 0] += g_cin
+    Cm = (an.reshape(8, 8) + Gt) / (2.0 * sr)
+    return G, Cm, w2 / 2.0
+
+
+def test_preamp_layer1_matrix_stamps(oracle):                     # dk_preamp_legacy.rs:1108-1290
+    G, Cm, w = _preamp_gcw(oracle)
+    eps = 1e-12
+    diag = {BASE1: 1 / R2 + 1 / R3, EMIT1: 1 / RE1, COLL1: 1 / RC1, EMIT2: 1 / RE2A, EMIT2B: 1 / RE2A + 1 / RE2B, COLL2: 1 / RC2 + 1 / R9,
+            OUT: 1 / R9 + 1 / R10, FB: 1 / R10}
+    for i, v in diag.items():
+        assert abs(G[i, i] - v) < eps, i
+    off = {(EMIT2, EMIT2B): -1 / RE2A, (COLL2, OUT): -1 / R9, (OUT, FB): -1 / R10}
+    for i in range(8):
+        for j in range(8):
+            if i == j:
+                continue
+            want = off.get((i, j), off.get((j, i), 0.0))
+            assert abs(G[i, j] - want) < eps, (i, j)
+    ce = 1e-15
+    cd = {BASE1: C3, EMIT1: CE1, COLL1: C3 + C4, EMIT2: CE2, EMIT2B: CE2, COLL2: C4, OUT: 0.0, FB: CE1}
+    for i, v in cd.items():
+        assert abs(Cm[i, i] - v) < ce, i
+    for (i, j), v in {(BASE1, COLL1): -C3, (COLL2, COLL1): -C4, (EMIT1, FB): -CE1, (EMIT2, EMIT2B): -CE2}.items():
+        assert abs(Cm[i, j] - v) < ce and abs(Cm[j, i] - v) < ce
+    assert np.max(np.abs(Cm - Cm.T)) < 1e-20 + 1e-15
+    want_w = np.zeros(8); want_w[BASE1] = VCC / R2; want_w[COLL1] = VCC / RC1; want_w[COLL2] = VCC / RC2
+    assert np.max(np.abs(w - want_w)) < eps
+
+
+def _ss_gain_db(G, Cm, gm1, gm2, r_ldr, f):                        # small_signal_gain_db, dk_preamp_legacy.rs:819-876
+    jw = 2j * np.pi * f
+    g = G.astype(complex).copy()
+    g[FB, FB] += 1.0 / r_ldr
+    g[EMIT1, BASE1] += gm1; g[EMIT1, EMIT1] -= gm1; g[COLL1, BASE1] -= gm1; g[COLL1, EMIT1] += gm1
+    g[EMIT2, COLL1] += gm2; g[EMIT2, EMIT2] -= gm2; g[COLL2, COLL1] -= gm2; g[COLL2, EMIT2] += gm2
+    y_cin = jw * CIN / (1.0 + jw * R1 * CIN)
+    a = jw * Cm + g
+    a[BASE1, BASE1] += y_cin
+    b = np.zeros(8, dtype=complex); b[BASE1] = y_cin
+    return 20 * np.log10(abs(np.linalg.solve(a, b)[OUT]))
+
+
+def _bandwidth(G, Cm, gm1, gm2, r):
+    target = _ss_gain_db(G, Cm, gm1, gm2, r, 1000.0) - 3.0
+    lo, hi = 1000.0, 200000.0
+    for _ in range(60):
+        mid = np.sqrt(lo * hi)
+        if _ss_gain_db(G, Cm, gm1, gm2, r, mid) > target:
+            lo = mid
+        else:
+            hi = mid
+    return np.sqrt(lo * hi)
+
+
+def test_preamp_layer4_small_signal_transfer_function(oracle):     # dk_preamp_legacy.rs:1534-1670
+    L = oracle.lib()
+    G, Cm, _ = _preamp_gcw(oracle)
+
+    def gms(sr):
+        v = np.zeros(10)
+        L.owo_preamp_dc(d(sr), _p(v))
+        return tuple((3.03e-14 / 0.026) * np.exp(min(max(x, -1.0), 0.85) / 0.026) for x in (v[8], v[9]))   # bjt_gm at the DC junction voltages
+    gm1, gm2 = gms(88200.0)
+    g_lo = _ss_gain_db(G, Cm, gm1, gm2, 1e6, 1000.0)
+    g_hi = _ss_gain_db(G, Cm, gm1, gm2, 19e3, 1000.0)
+    assert 3.0 < g_lo < 12.0 and 8.0 < g_hi < 18.0 and 3.0 < g_hi - g_lo < 10.0
+    bw_lo, bw_hi = _bandwidth(G, Cm, gm1, gm2, 1e6), _bandwidth(G, Cm, gm1, gm2, 19e3)
+    assert bw_lo > 8000.0 and bw_hi > 8000.0 and abs(bw_lo - bw_hi) / bw_lo < 0.25
+    assert 10 ** (g_hi / 20) * bw_hi > 1.2 * 10 ** (g_lo / 20) * bw_lo                      # GBW scales with gain
+    assert abs(_ss_gain_db(G, Cm, gm1, gm2, 1e6, 100.0) - g_lo) < 3.0 and abs(_ss_gain_db(G, Cm, gm1, gm2, 1e6, 10000.0) - g_lo) < 4.0
+    ga, gb = gms(44100.0), gms(192000.0)
+    for f in (100.0, 1000.0, 5000.0, 10000.0):
+        assert abs(_ss_gain_db(G, Cm, ga[0], ga[1], 1e6, f) - _ss_gain_db(G, Cm, gb[0], gb[1], 1e6, f)) < 0.01
+    # the discrete-time solver agrees with its own continuous-time model at 1 kHz (published 6.51 / 12.61 dB, CHANGELOG.md:206)
+    assert abs(g_lo - 6.51) < 0.5 and abs(g_hi - 12.61) < 0.5
+
+
+def _preamp_gain(oracle, sr, r, f, amp=0.001):                     # measure_gain, dk_preamp_legacy.rs:878-899
+    L = oracle.lib()
+    n_settle, n_meas = int(sr * 0.3), int(sr * 0.2)
+    x = amp * np.sin(2 * np.pi * f * np.arange(n_settle + n_meas) / sr)
+    y = np.zeros(x.size)
+    L.owo_preamp_run(d(sr), _p(x), None, d(r), _p(y), C.c_size_t(x.size))
+    return np.max(np.abs(y[n_settle:])) / amp
+
+
+def test_preamp_layer5_time_domain(oracle):                        # dk_preamp_legacy.rs:984-1100,1676-1920
+    L = oracle.lib()
+    sr = 88200.0
+    n = int(sr * 0.3)
+    x = 0.005 * np.sin(2 * np.pi * 440.0 * np.arange(n) / sr)
+    y = np.zeros(n)
+    L.owo_preamp_run(d(sr), _p(x), None, d(1e6), _p(y), C.c_size_t(n))
+    tail = y[n * 3 // 4:]
+    ph = 2 * np.pi * np.arange(tail.size) / sr
+
+    def mag(f):
+        return np.hypot(np.sum(tail * np.cos(ph * f)), np.sum(tail * np.sin(ph * f))) / tail.size
+    assert mag(880.0) > mag(1320.0)                                # H2 dominates H3
+    imp = np.zeros(int(sr * 2.0) + 1); imp[0] = 0.01               # stability after an impulse
+    yi = np.zeros(imp.size)
+    L.owo_preamp_run(d(sr), _p(imp), None, d(1e6), _p(yi), C.c_size_t(imp.size))
+    assert abs(yi[-1]) < 1e-3
+    g1k, g10k, g15k = (_preamp_gain(oracle, sr, 1e6, f) for f in (1000.0, 10000.0, 15000.0))
+    t1k, t10k = (_preamp_gain(oracle, sr, 19e3, f) for f in (1000.0, 10000.0))
+    assert g15k < g1k                                              # HF roll-off
+    assert abs(20 * np.log10(g10k / g1k) - 20 * np.log10(t10k / t1k)) < 6.0          # bandwidth independent of R_ldr
+    assert t1k * 10000.0 * (t10k / t1k) > 0.8 * g1k * 10000.0 * (g10k / g1k)         # GBW scales with gain
+    # R_ldr step 1 M -> 50 k with no input: bounded, settles back to ~0 (the shadow cancels the pump)
+    ystep = np.zeros(1000 + int(sr * 2.0) + 1)
+    L.owo_preamp_step(d(sr), d(1e6), C.c_size_t(int(sr * 0.5)), d(50e3), None, _p(ystep), C.c_size_t(ystep.size), None)
+    assert np.max(np.abs(ystep[:1000])) < 10.0 and abs(ystep[-1]) < 0.01
+    # step convergence: 5 s after the step the main state sits where a fresh solver at 50 k sits after 2 s
+    va, vb = np.zeros(8), np.zeros(8)
+    scratch = np.zeros(int(sr * 5.0))
+    L.owo_preamp_step(d(sr), d(50e3), C.c_size_t(int(sr * 2.0)), d(50e3), None, _p(scratch[:1]), C.c_size_t(1), _p(va))
+    L.owo_preamp_step(d(sr), d(1e6), C.c_size_t(int(sr * 2.0)), d(50e3), None, _p(scratch), C.c_size_t(scratch.size), _p(vb))
+    assert abs(va[COLL2] - vb[COLL2]) < 1.0
+
+
+@pytest.mark.parametrize("kind", ["legacy", "melange"])
+def test_preamp_ldr_sweep_no_click_and_no_nyquist_limit_cycle(oracle, kind):   # dk_preamp/mod.rs:118-220 (run against whichever solver the build selects)
+    L = oracle.lib()
+    sr = 88200.0
+    freq, amp = 1000.0, 0.3
+    n0, dur = int(sr * 0.1), int(sr * 0.4)
+    t_norm = np.arange(dur) / dur
+    r_sweep = np.where(t_norm < 0.5, 1e6 + (19e3 - 1e6) * (t_norm * 2.0), 19e3 + (1e6 - 19e3) * ((t_norm - 0.5) * 2.0))
+    r = np.concatenate([np.full(n0, 100e3), r_sweep])
+    x = amp * np.sin(2 * np.pi * freq * np.arange(n0 + dur) / sr)
+    y = np.zeros(x.size)
+    if kind == "legacy":
+        L.owo_preamp_run(d(sr), _p(x), _p(r), d(0.0), _p(y), C.c_size_t(x.size))
+    else:
+        L.owo_melange_run(d(sr), _p(x), _p(r), _p(y), C.c_size_t(x.size))
+    max_jump = np.max(np.abs(np.diff(y[n0:])))
+    assert max_jump < 20.0 * (amp * 2 * np.pi * freq / sr) * 10 ** (7.5 / 20)
+    n_idle, burst, sil = int(sr * 0.1), int(sr * 0.05), int(sr * 0.1)
+    xb = np.concatenate([np.zeros(n_idle), 0.01 * np.sin(2 * np.pi * 19000.0 * np.arange(burst) / sr), np.zeros(sil)])
+    rb = np.full(xb.size, 1e6)
+    yb = np.zeros(xb.size)
+    if kind == "legacy":
+        L.owo_preamp_run(d(sr), _p(xb), _p(rb), d(0.0), _p(yb), C.c_size_t(xb.size))
+    else:
+        L.owo_melange_run(d(sr), _p(xb), _p(rb), _p(yb), C.c_size_t(xb.size))
+    tail = yb[n_idle + burst + int(sr * 0.05):]
+    assert 20 * np.log10(max(np.sqrt(np.mean(tail ** 2)), 1e-20)) < -60.0
+
+
 def test_preamp_dc_operating_point(oracle):
     L = oracle.lib()
     v = np.zeros(10)
@@ -428,11 +656,20 @@ def test_golden_spectral_baseline(oracle):
         assert abs(best_f - ent["f0_hz"]) < 0.051, (ent["note"], best_f)
         h1 = _dft_mag(tail, best_f, sr)
         dbc = [20 * np.log10(_dft_mag(tail, (k + 1) * best_f, sr) / h1) for k in range(12)]
-        assert abs(dbc[1] - ent["harmonic_dbc"][1]) < 1.0          # H2 (pickup bark) within 1 dB of the v0.5.1 capture
+        delta = np.array(dbc) - np.array(ent["harmonic_dbc"])
+        print(f"note {ent['note']}: harmonic_dbc(oracle @ v0.6.0) - harmonic_dbc(v0.5.1 capture), H1..H12 =", np.round(delta, 2).tolist())
+        # The capture is v0.5.1, the restatement v0.6.0.  What v0.6.0 changed (CHANGELOG 0.6.0: power-amp drive decoupled from volume,
+        # PSG, tremolo divider, onset ramp, HPF) acts on the ODD harmonics (the symmetric nonlinearity of the output stage) and on the
+        # absolute level; the EVEN harmonics are the pickup's 1/(1-y) bark through the preamp and did not move: they pin the oracle.
+        # Measured deltas: H2 <= 0.19 dB, H4 <= 0.88, H6 <= 0.40, H8 <= 0.69, H10 <= 0.73, H12 <= 0.54 on all three notes.
+        assert abs(delta[1]) < 0.3                                  # H2 (was: 1 dB)
+        assert abs(delta[3]) < 1.0 and abs(delta[5]) < 0.5          # H4, H6
+        assert all(abs(delta[k]) < 1.0 for k in (7, 9, 11))         # H8, H10, H12
+        assert np.all(np.abs(delta) < 16.0)                         # odd harmonics: reported above, bounded only loosely (C5 H11 moved by -15 dB)
         shifts.append(20 * np.log10(h1) - ent["h1_dbfs"])
-        # one-sided regression limits of the reference test (alias_audit_regression.rs:29-30)
+        # the reference's own one-sided regression limit (alias_audit_regression.rs:29-30): no more than 1.5 dB above the capture
         plateau = max(dbc[i + 1] - dbc[i] for i in range(5, 10))
-        assert plateau - ent["max_step_up_db"] <= 6.0
+        assert plateau - ent["max_step_up_db"] <= 1.5
     # v0.5.1 -> v0.6.0 changed PSG / tremolo divider / HPF: the level shift must be the same for all three notes
     assert max(shifts) - min(shifts) < 0.1, shifts
 
