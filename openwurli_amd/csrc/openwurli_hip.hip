@@ -22,6 +22,7 @@
 #include "ow_job_kernels.h"
 #include "ow_mlp_mfma.h"
 #include "ow_melange_dev.h"
+#include "ow_melange_lit.h"
 #include "ow_power_amp_dev.h"
 #include "ow_features.h"
 #include "ow_trem_wide.h"
@@ -567,6 +568,14 @@ static size_t effective_cpus() {
 }
 size_t Workers::host_threads() { return std::min<size_t>(effective_cpus(), OW_MAX_SLICES); }
 
+// Melange preamp: the default kernel re-factors the 12x12 system for every sample whose R_ldr moved, operation for operation like the
+// reference (ow_melange_lit.h).  OW_MEL_RANK1=1 selects the rank-one (Sherman-Morrison) kernel instead: ~3x faster, mathematically the
+// same, but without the LU's rounding noise, i.e. up to 1.8e-7 V away from the reference while R_ldr moves fast (DESIGN.md deviation 6).
+static inline bool melange_rank_one() {
+    const char* env = std::getenv("OW_MEL_RANK1");
+    return env && env[0] == '1';
+}
+
 // Stages of the staged render.  Off by default: OW_PIPE=n (2..8) cuts big ranges (>= 32 768 engines) into n engine stages on their own
 // streams, chained stage to stage, so that the output copy of a stage runs beside the kernels of the next one.
 static inline int pipeline_stages(int ne, bool to_host) {
@@ -798,7 +807,10 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         HIP_OK(hipStreamWaitEvent(s, p->ev_trem[rb_now_idx], 0));
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][2], s));
         if (sne > 0) {
-            if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)
+            if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one())
+                owdev::k_preamp_mel_lit<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
+                                                                                 p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne);
+            else if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)
                 owdev::k_preamp_mel<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
                                                                              p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne);
             else

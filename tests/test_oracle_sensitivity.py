@@ -59,6 +59,34 @@ def test_melange_floor(oracle):
     assert np.max(np.abs(o1 - o0)) < 2e-8          # f32 rounding flips at |x| ~ 0.1 are 7.5e-9
 
 
+def test_melange_floor_with_r_ldr_off_by_one_ulp(oracle):
+    """The melange preamp re-inverts its 12x12 system whenever R_ldr moved; the rounding noise of that LU inverse (eps * cond(A)) is a
+    chaotic function of R's bits.  R comes out of exp() / powf() (tremolo.rs:140-141), so two builds of the REFERENCE with libms that
+    differ in the last place hear different noise.  Measured here on the oracle alone: the tremolo's R stream at depth 1.0, then the
+    same stream with every value moved to its neighbouring double.  This is the floor the GPU (whose device library is such a
+    different libm) can be held to at the preamp node: 5e-8 V covers it with margin; the output floor follows through the chain gain."""
+    import ctypes as C
+    L = oracle.lib()
+    sr = 96000.0
+    n = int(sr * 1.0)
+    r = np.zeros(n)
+    L.owo_tremolo_run(C.c_double(1.0), C.c_double(sr), r.ctypes.data_as(C.c_void_p), C.c_size_t(n))
+    x = 0.01 * np.sin(2 * np.pi * 440.0 * np.arange(n) / sr)
+
+    def run(rr):
+        y = np.zeros(n)
+        L.owo_melange_run(C.c_double(sr), x.ctypes.data_as(C.c_void_p), rr.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), C.c_size_t(n))
+        return y
+    y0 = run(r)
+    y1 = run(np.nextafter(r, np.inf))
+    d = float(np.max(np.abs(y1 - y0)))
+    assert 1e-9 < d < oracle.ABS_FLOOR_MELANGE_LIT_PREAMP, d          # measured 1.4e-8 V on a 71 mV signal
+    # a fast sweep of R (what a depth-knob ramp does to the shunt): same experiment
+    rs = 19e3 + (1e6 - 19e3) * (0.5 + 0.5 * np.sin(2 * np.pi * 40.0 * np.arange(n) / sr))
+    d2 = float(np.max(np.abs(run(np.nextafter(rs, np.inf)) - run(rs))))
+    assert d2 < oracle.ABS_FLOOR_MELANGE_LIT_PREAMP, d2
+
+
 def test_alias_audit_stimulus_floor(oracle):
     """The audit stimulus (alias_audit.rs:135-160) under the same one-ulp exp() experiment: quiet samples move by up to 2.5e-9,
     and the audit's dB figures (harmonics 70-110 dB below H1) by up to a few 1e-3 dB -- the tolerances of tests/test_gpu_alias_audit.py."""
