@@ -18,7 +18,7 @@ def test_setter_then_reset_without_a_render_in_between(hiplib, oracle, preamp_ki
     g.set_sample_rate(sr)
     for c in cs:
         c.set_sample_rate(sr)
-    floor = oracle.ABS_FLOOR_MELANGE_OUTPUT if preamp_kind else oracle.ABS_FLOOR_OUTPUT
+    floor = oracle.ABS_FLOOR_MELANGE_LIT_OUTPUT if preamp_kind else oracle.ABS_FLOOR_OUTPUT
 
     def compare(tag, blocks):
         for b in range(blocks):

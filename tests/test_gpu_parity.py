@@ -616,8 +616,18 @@ def test_mlp_mfma(hiplib, oracle):
 
 
 # ------------------------------------------------------------------ melange 12-node preamp (second solver)
-def test_melange_engine_parity(hiplib, oracle):
+@pytest.mark.parametrize("kernel", ["literal", "rank1"])
+def test_melange_engine_parity(hiplib, oracle, kernel, monkeypatch):
+    """The default kernel re-factors the 12x12 system per sample like the reference (ow_melange_lit.h) and is held to the LEGACY preamp's
+    floors (2e-9 V at the node; measured 3.5e-10 steady, 5.1e-10 under depth-knob ramps).  OW_MEL_RANK1=1 selects the rank-one kernel: its
+    floors are the loose ones of deviation 6 (1.8e-7 V while R_ldr moves), asserted relative to peak."""
     import openwurli_amd as ow
+    if kernel == "rank1":
+        monkeypatch.setenv("OW_MEL_RANK1", "1")
+    else:
+        monkeypatch.delenv("OW_MEL_RANK1", raising=False)
+    fl_p = oracle.ABS_FLOOR_MELANGE_PREAMP if kernel == "rank1" else oracle.ABS_FLOOR_PREAMP
+    fl_o = oracle.ABS_FLOOR_MELANGE_OUTPUT if kernel == "rank1" else oracle.ABS_FLOOR_OUTPUT
     sr = 48000.0
     g = ow.EnginePool(sr, 2, preamp_kind=1)
     cs = [oracle.OracleEngine(sr, preamp_kind=1) for _ in range(2)]
@@ -630,12 +640,16 @@ def test_melange_engine_parity(hiplib, oracle):
             for n in (48, 60, 67) if k == 0 else (40, 72, 76, 91):
                 e.note_on(n, 0.8)
     for b in range(12):
+        if b in (4, 8):                       # depth-knob ramps: R_ldr moves fast -- where the rank-one kernel leaves the reference's LU noise
+            for k in range(2):
+                for e in (g[k], cs[k]):
+                    e.set_tremolo_depth(0.1 if b == 4 else 1.0)
         go = g.render(512)
         gp = g.preamp_out(1024)
         for k in range(2):
             co, _, cp, _ = cs[k].render_taps(512)
-            rp = oracle.parity_report(gp[k], cp, abs_floor=oracle.ABS_FLOOR_MELANGE_PREAMP)
-            ro = oracle.parity_report(go[k], co, abs_floor=oracle.ABS_FLOOR_MELANGE_OUTPUT)
+            rp = oracle.parity_report(gp[k], cp, abs_floor=fl_p)
+            ro = oracle.parity_report(go[k], co, abs_floor=fl_o)
             _check(rp, ("melange preamp", b, k)); _check(ro, ("melange out", b, k))
             assert rp["max_err_rel_peak"] < 1e-5 and ro["max_err_rel_peak"] < 1e-5      # the north-star bar, relative to peak
     for k in range(2):
@@ -673,8 +687,8 @@ def test_melange_thermal_noise_parity(hiplib, oracle):
             gp = g.preamp_out(2 * length)
             for k in range(3):
                 co, _, cp, _ = cs[k].render_taps(length)
-                rp = oracle.parity_report(gp[k], cp, abs_floor=oracle.ABS_FLOOR_MELANGE_PREAMP)
-                ro = oracle.parity_report(go[k], co, abs_floor=oracle.ABS_FLOOR_MELANGE_OUTPUT)
+                rp = oracle.parity_report(gp[k], cp, abs_floor=oracle.ABS_FLOOR_MELANGE_LIT_PREAMP)
+                ro = oracle.parity_report(go[k], co, abs_floor=oracle.ABS_FLOOR_MELANGE_LIT_OUTPUT)
                 _check(rp, (tag, "preamp", b, k)); _check(ro, (tag, "out", b, k))
             idle_peak = max(idle_peak, float(np.max(np.abs(go[0]))))
         return go, idle_peak
@@ -747,14 +761,14 @@ def test_melange_static_ldr_and_reset(hiplib, oracle):
     for b in range(6):
         go = g.render(512)[0]
         co = c.render(512)
-        _check(oracle.parity_report(go, co, abs_floor=oracle.ABS_FLOOR_MELANGE_OUTPUT), ("melange static", b))
+        _check(oracle.parity_report(go, co, abs_floor=oracle.ABS_FLOOR_MELANGE_LIT_OUTPUT), ("melange static", b))
     g[0].reset(); c.reset()
     for e in (g[0], c):
         e.note_on(64, 0.7)
     for b in range(6):
         go = g.render(512)[0]
         co = c.render(512)
-        _check(oracle.parity_report(go, co, abs_floor=oracle.ABS_FLOOR_MELANGE_OUTPUT), ("melange reset", b))
+        _check(oracle.parity_report(go, co, abs_floor=oracle.ABS_FLOOR_MELANGE_LIT_OUTPUT), ("melange reset", b))
     g.close()
 
 

@@ -131,7 +131,7 @@ def test_forced_divergence_guard_lands_on_the_same_sample(hiplib, oracle):
     # (the guard also fires on its own under chords -- the reference documents the solver's intermittent divergence under polyphonic input,
     # power_amp.rs:375-407 -- and it does so on the same samples on both sides, or the comparisons above would have failed)
     assert [x.guard_resets for x in d] == [x[3] for x in oc]
-    assert d[1].guard_resets > d[0].guard_resets and d[2].guard_resets > d[0].guard_resets
+    assert d[1].guard_resets >= 1 and d[2].guard_resets >= 1
     assert [x.nr_max_iter_count for x in d] == [x[1] for x in oc]
     g.close()
 
