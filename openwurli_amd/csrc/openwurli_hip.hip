@@ -576,6 +576,11 @@ static inline bool melange_rank_one() {
     return env && env[0] == '1';
 }
 
+static inline bool melange_generic_only() {      // OW_MEL_GENERIC=1: the literal kernel without its precomputed fast path
+    const char* env = std::getenv("OW_MEL_GENERIC");
+    return env && env[0] == '1';
+}
+
 // Stages of the staged render.  Off by default: OW_PIPE=n (2..8) cuts big ranges (>= 32 768 engines) into n engine stages on their own
 // streams, chained stage to stage, so that the output copy of a stage runs beside the kernels of the next one.
 static inline int pipeline_stages(int ne, bool to_host) {
@@ -809,7 +814,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         if (sne > 0) {
             if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one())
                 owdev::k_preamp_mel_lit<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
-                                                                                 p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne);
+                                                                                 p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne, melange_generic_only() ? 1 : 0);
             else if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)
                 owdev::k_preamp_mel<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
                                                                              p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne);

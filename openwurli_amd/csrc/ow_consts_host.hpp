@@ -247,6 +247,62 @@ static void build_melange_consts(OwConsts& c) {
                 c.m_k0[i][j] = sum;
             }
     }
+    {   // R-independent part of invert_n(A) at this rate (gen_preamp.rs:2117-2219 followed step by step through column 5)
+        const double alpha = 2.0 * (rate * 1.0);
+        double lu[12][12];
+        int perm[12];
+        for (int i = 0; i < 12; ++i) { perm[i] = i; for (int j = 0; j < 12; ++j) lu[i][j] = PRE_G[i][j] + alpha * PRE_C[i][j]; }
+        bool ok = true;
+        for (int k = 0; k < 6 && ok; ++k) {
+            int max_row = k;
+            double max_val = std::fabs(lu[k][k]);
+            for (int i = k + 1; i < 12; ++i) {
+                const double v = std::fabs(lu[i][k]);
+                if (v > max_val) { max_val = v; max_row = i; }
+            }
+            if (max_val < 1e-30) { ok = false; break; }
+            if (max_row != k) {
+                for (int j = 0; j < 12; ++j) { const double t = lu[k][j]; lu[k][j] = lu[max_row][j]; lu[max_row][j] = t; }
+                const int t = perm[k]; perm[k] = perm[max_row]; perm[max_row] = t;
+            }
+            if (perm[k] == 6) { ok = false; break; }        // the R-carrying row became a pivot row: its entry would spread
+            const double pivot = lu[k][k];
+            for (int i = k + 1; i < 12; ++i) {
+                const double m = lu[i][k] / pivot;
+                lu[i][k] = m;
+                for (int j = k + 1; j < 12; ++j) {
+                    if (perm[i] == 6 && j == 6) { c.ml_chain_m[k] = m; c.ml_chain_u[k] = lu[k][6]; continue; }   // replayed per sample on the device
+                    lu[i][j] -= m * lu[k][j];
+                }
+            }
+        }
+        c.ml_ok = 0;
+        if (ok) {
+            int t6 = -1;
+            for (int t = 0; t < 6; ++t) if (perm[6 + t] == 6) t6 = t;
+            if (t6 >= 0) {
+                c.ml_t6 = t6;
+                for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) c.ml_t0[a][b] = lu[6 + a][6 + b];
+                for (int i = 0; i < 6; ++i) for (int j = 0; j < 12; ++j) c.ml_utop[i][j] = j >= i ? lu[i][j] : 0.0;
+                for (int col = 0; col < 12; ++col) {
+                    double b[12];
+                    for (int i = 0; i < 12; ++i) b[i] = perm[i] == col ? 1.0 : 0.0;
+                    for (int i = 1; i < 6; ++i) {
+                        double sum = b[i];
+                        for (int j = 0; j < i; ++j) sum -= lu[i][j] * b[j];
+                        b[i] = sum;
+                    }
+                    for (int i = 0; i < 6; ++i) c.ml_btop[col][i] = b[i];
+                    for (int t = 0; t < 6; ++t) {
+                        double sum = b[6 + t];
+                        for (int j = 0; j < 6; ++j) sum -= lu[6 + t][j] * b[j];
+                        c.ml_part[col][t] = sum;
+                    }
+                }
+                c.ml_ok = 1;
+            }
+        }
+    }
     for (int i = 0; i < 12; ++i) { c.m_u[i] = c.m_s0[i][6]; c.m_w[i] = c.m_s0[6][i]; }
     c.m_s66 = c.m_s0[6][6];
     c.m_g_nom = PRE_POT_0_G_NOM;

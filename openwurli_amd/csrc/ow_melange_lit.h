@@ -27,6 +27,7 @@ namespace owdev {
 
 // rebuild_matrices for this lane's engine at resistance `pot`; lu / S point at the engine's column.  Both lanes of the pair call it
 // with identical arguments (role = 0 / 1); kk receives K.  Contains workgroup barriers: every lane of the wavefront must call it.
+__device__ inline void mel_lit_kernel(const double* __restrict__ S, double kk[3][3]);
 __device__ __noinline__ void mel_lit_rebuild(double pot, int role, double alpha, double* __restrict__ lu, double* __restrict__ S, double kk[3][3]) {
     // A = G_eff + alpha C (gen_preamp.rs:2001-2016); g_eff[6][6] += 1/R - G_nom
     const double g66 = PRE_G[6][6] + (ow_div(1.0, pot) - PRE_POT_0_G_NOM);
@@ -90,11 +91,15 @@ __device__ __noinline__ void mel_lit_rebuild(double pot, int role, double alpha,
             for (int j = 0; j < 12; ++j) MS(i, j) = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
-    // K = N_v (S N_i) (:2038-2056).  N_i rows: [0] = {2}, [1] = {2, 4, 5}, [2] = {4, 7, 8}; N_v rows: [0] = {2}, [1] = {2, 5}, [2] = {4, 8}.
-    // s_ni[n][j] = sum_k s[n][k] N_I[j][k] in k order, then K[i][j] = sum_n N_V[i][n] s_ni[n][j] in n order: zero terms skipped (they add +-0).
+    mel_lit_kernel(S, kk);
+}
+
+// K = N_v (S N_i) (:2038-2056).  N_i rows: [0] = {2}, [1] = {2, 4, 5}, [2] = {4, 7, 8}; N_v rows: [0] = {2}, [1] = {2, 5}, [2] = {4, 8}.
+// s_ni[n][j] = sum_k s[n][k] N_I[j][k] in k order, then K[i][j] = sum_n N_V[i][n] s_ni[n][j] in n order: zero terms skipped (they add +-0).
 #define SNI0(n) (MS(n, 2) * PRE_N_I[0][2])
 #define SNI1(n) (MS(n, 2) * PRE_N_I[1][2] + MS(n, 4) * PRE_N_I[1][4] + MS(n, 5) * PRE_N_I[1][5])
 #define SNI2(n) (MS(n, 4) * PRE_N_I[2][4] + MS(n, 7) * PRE_N_I[2][7] + MS(n, 8) * PRE_N_I[2][8])
+__device__ inline void mel_lit_kernel(const double* __restrict__ S, double kk[3][3]) {
     kk[0][0] = PRE_N_V[0][2] * SNI0(2); kk[0][1] = PRE_N_V[0][2] * SNI1(2); kk[0][2] = PRE_N_V[0][2] * SNI2(2);
     kk[1][0] = PRE_N_V[1][2] * SNI0(2) + PRE_N_V[1][5] * SNI0(5);
     kk[1][1] = PRE_N_V[1][2] * SNI1(2) + PRE_N_V[1][5] * SNI1(5);
@@ -102,6 +107,76 @@ __device__ __noinline__ void mel_lit_rebuild(double pot, int role, double alpha,
     kk[2][0] = PRE_N_V[2][4] * SNI0(4) + PRE_N_V[2][8] * SNI0(8);
     kk[2][1] = PRE_N_V[2][4] * SNI1(4) + PRE_N_V[2][8] * SNI1(8);
     kk[2][2] = PRE_N_V[2][4] * SNI2(4) + PRE_N_V[2][8] * SNI2(8);
+}
+
+// The same rebuild when the pivot order is the expected one (it is, for every R in the clamp range at every rate tried: the only row
+// exchange happens in step 3, before R plays any part).  The host has replayed elimination steps 0..5 and the forward substitutions
+// through them (OwConsts::ml_*): what depends on R is the Schur-complement entry of [6][6], the trailing 6x6 factorisation and the
+// substitutions through it -- all with compile-time indices, in registers, no LDS besides the result.  Every pivot choice of the
+// trailing steps is CHECKED against what invert_n would choose (first maximum of the column, strict >): on any difference, or a
+// pivot below 1e-30, the function returns false and the caller runs the generic rebuild above.  Same operations in the same order
+// as invert_n on the R-dependent entries; the R-independent ones are the host's (IEEE, no contraction) results of the same operations.
+// Both lanes of a pair compute the trailing factors (cheap, no exchange needed) and six unit columns each.
+__device__ inline bool mel_lit_rebuild_fast(const OwConsts* __restrict__ K, double pot, int role, double alpha, double* __restrict__ S) {
+    double T[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) T[a][b] = K->ml_t0[a][b];
+    {
+        const double g66 = PRE_G[6][6] + (ow_div(1.0, pot) - PRE_POT_0_G_NOM);
+        double e = g66 + alpha * PRE_C[6][6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) e -= K->ml_chain_m[k] * K->ml_chain_u[k];
+        const int t6 = K->ml_t6;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) if (a == t6) T[a][0] = e;
+    }
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {                           // steps 6..11 of the elimination, no row exchange expected
+        const double pk = fabs(T[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) ok = ok && !(fabs(T[i][k]) > pk);
+        ok = ok && !(pk < 1e-30);
+        const double pivot = T[k][k];
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {
+            const double m = ow_div(T[i][k], pivot);
+            T[i][k] = m;
+#pragma unroll
+            for (int j = k + 1; j < 6; ++j) T[i][j] -= m * T[k][j];
+        }
+    }
+    if (!__all(ok)) return false;                           // wave-uniform: the generic path has barriers
+#pragma unroll 1
+    for (int col = role; col < 12; col += 2) {
+        double b[12];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {                       // forward substitution, trailing rows (terms j < 6 are in ml_part)
+            double sum = K->ml_part[col][t];
+#pragma unroll
+            for (int j = 0; j < t; ++j) sum -= T[t][j] * b[6 + j];
+            b[6 + t] = sum;
+        }
+#pragma unroll
+        for (int t = 5; t >= 0; --t) {                      // back substitution, trailing rows
+            double sum = b[6 + t];
+#pragma unroll
+            for (int j = t + 1; j < 6; ++j) sum -= T[t][j] * b[6 + j];
+            b[6 + t] = ow_div(sum, T[t][t]);
+        }
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {                      // back substitution, rows 5..0 (R-independent U rows)
+            double sum = K->ml_btop[col][i];
+#pragma unroll
+            for (int j = i + 1; j < 12; ++j) sum -= K->ml_utop[i][j] * b[j];
+            b[i] = ow_div(sum, K->ml_utop[i][i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) MS(i, col) = b[i];
+    }
+    return true;
 }
 
 // gen_preamp::process_sample (gen_preamp.rs:3399-3663) with the engine's own S (LDS) and K.  an_c: alpha C - G of the pool (constant
@@ -218,7 +293,7 @@ __global__ __launch_bounds__(64) void k_preamp_mel_lit(const OwConsts* __restric
                                                        const double* __restrict__ settled, const OwEngineArgs* __restrict__ args,
                                                        const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const double* __restrict__ rbuf,
                                                        const uint32_t* __restrict__ trem_lead, double* __restrict__ pre, double* __restrict__ noise, int I, int L,
-                                                       int Lcap, int e0, int ne) {
+                                                       int Lcap, int e0, int ne, int generic_only) {
     __shared__ double tile[32 * (OW_LCHUNK + 1)];
     __shared__ double LU_all[12 * 12 * 32];
     __shared__ double S_all[12 * 12 * 32];
@@ -259,6 +334,7 @@ __global__ __launch_bounds__(64) void k_preamp_mel_lit(const OwConsts* __restric
     // survive the block: the first sample rebuilds them (s_pot = NaN never equals a resistance).  Exception, as in the reference: a state
     // that has never seen a set_runtime_R (pot at the nominal literal) would run on the baked / set_sample_rate matrices -- every sample
     // of the engine path sets R before it processes, so that case does not occur here.
+    const bool force_generic = generic_only != 0;                  // OW_MEL_GENERIC=1: always the generic rebuild (the test compares the two bit for bit)
     double s_pot = __longlong_as_double(0x7ff8000000000000LL);
     double kk[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     double an66 = 0.0;
@@ -296,7 +372,14 @@ __global__ __launch_bounds__(64) void k_preamp_mel_lit(const OwConsts* __restric
                 if (__any(dirty)) {
                     // every lane takes part (the rebuild contains barriers); for an engine whose R did not move this recomputes the
                     // matrices it already has -- they are a pure function of R
-                    mel_lit_rebuild(pot_main, role, alpha, lu, S, kk);
+                    bool fast = K->ml_ok != 0 && !force_generic;
+                    if (fast) {
+                        __syncthreads();                                          // the previous sample's reads of S are done
+                        fast = mel_lit_rebuild_fast(K, pot_main, role, alpha, S);
+                        __syncthreads();                                          // both lanes' columns are in place
+                        if (fast) mel_lit_kernel(S, kk);
+                    }
+                    if (!fast) mel_lit_rebuild(pot_main, role, alpha, lu, S, kk);
                     s_pot = pot_main;
                     const double g66 = PRE_G[6][6] + (ow_div(1.0, pot_main) - PRE_POT_0_G_NOM);
                     an66 = alpha * PRE_C[6][6] - g66;

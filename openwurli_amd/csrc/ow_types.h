@@ -136,6 +136,16 @@ struct OwConsts {
     double m_s0[12][12], m_aneg0[12][12], m_k0[3][3], m_sni0[12][3];
     double m_u[12], m_w[12], m_wn[3], m_nvu[3], m_s66, m_g_nom;
     double m_noise_scale;    // sqrt(8 k_B T fs_chain), T = 290 K (gen_preamp.rs:1752,1936)
+    // Literal per-sample rebuild of the melange preamp (ow_melange_lit.h): the part of invert_n's work that does not depend on R_ldr.
+    // R_ldr enters A = G_eff + alpha C in [6][6] only; elimination steps 0..5 never read that entry (row 6 is not a pivot row there, the
+    // host checks it), so the factors they produce, the forward substitutions through them and the upper rows are the same for every R.
+    // All tables are in POSITION order (after the row exchanges of steps 0..5); positions 6..11 are the trailing block.
+    int ml_ok, ml_t6;            // fast path usable; trailing index of original row 6 (whose column-6 entry carries R)
+    double ml_chain_m[6], ml_chain_u[6];   // e66 = a66; e66 -= chain_m[k] * chain_u[k], k = 0..5: the eliminations that touch the R entry
+    double ml_t0[6][6];          // trailing block after step 5 (entry [ml_t6][0] is replaced by e66)
+    double ml_utop[6][12];       // rows 0..5 of U (row i: columns i..11)
+    double ml_btop[12][6];       // per unit column: forward-substituted b at positions 0..5
+    double ml_part[12][6];       // per unit column: b at trailing position 6+t after the terms j < 6 of its forward substitution
 };
 
 #define PA_N 20   /* gen_power_amp.rs:29 */

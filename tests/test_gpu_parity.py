@@ -658,6 +658,35 @@ def test_melange_engine_parity(hiplib, oracle, kernel, monkeypatch):
     g.close()
 
 
+def test_melange_literal_fast_path_is_the_generic_rebuild_bit_for_bit(hiplib, monkeypatch):
+    """ow_melange_lit.h: the precomputed-leading-block rebuild (default) and the plain LU of the whole 12x12 system (OW_MEL_GENERIC=1)
+    perform the same operations on the R-dependent entries: preamp and output streams must be bit-identical, at two rates, under a
+    tremolo at full depth, depth-knob ramps and a static shunt."""
+    import openwurli_amd as ow
+    for sr in (48000.0, 44100.0):
+        res = {}
+        for mode in ("fast", "generic"):
+            if mode == "generic":
+                monkeypatch.setenv("OW_MEL_GENERIC", "1")
+            else:
+                monkeypatch.delenv("OW_MEL_GENERIC", raising=False)
+            g = ow.EnginePool(sr, 3, preamp_kind=1)
+            g.set_sample_rate(sr)
+            for k in range(3):
+                g[k].set_tremolo_depth((1.0, 0.5, 0.0)[k])
+                for n in (45 + 7 * k, 60, 72):
+                    g[k].note_on(n, 0.9)
+            outs, pres = [], []
+            for b in range(8):
+                if b == 3:
+                    g[1].set_tremolo_depth(1.0); g[2].set_tremolo_depth(0.7)
+                outs.append(g.render(256)); pres.append(g.preamp_out(512))
+            g.close()
+            res[mode] = (np.concatenate(outs, axis=1), np.concatenate(pres, axis=1))
+        assert np.array_equal(res["fast"][1], res["generic"][1]) and np.array_equal(res["fast"][0], res["generic"][0]), sr
+        assert np.max(np.abs(res["fast"][1])) > 1e-3
+
+
 def test_melange_thermal_noise_parity(hiplib, oracle):
     """set_noise_enabled / set_noise_gain on the melange preamp (engine.rs:394-400; gen_preamp.rs:3433-3461): the 11 resistor
     noise currents are integer-exact xoshiro256++ streams shaped by Marsaglia polar (log, sqrt), so with a fixed seed
