@@ -279,6 +279,9 @@ def main(argv=None):
     ap.add_argument("--preamp", choices=["legacy", "melange"], default="legacy",
                     help="legacy = the 8-node DK solver of the reference's default build (the metric's config); melange = the generated "
                          "12-node solver of its `--features melange-preamp` build")
+    ap.add_argument("--power-amp", choices=["behavioral", "melange"], default="behavioral",
+                    help="behavioral = the closed-loop Newton amp of the reference's default build (the metric's config); melange = the generated "
+                         "7-BJT Class-AB solver + rail dynamics of its `--no-default-features` build")
     ap.add_argument("--host-rate", type=float, default=48000.0,
                     help="host sample rate: 48000 = BASELINE configs[1] (the metric's config, default); 96000 = configs[2] (no oversampling)")
     ap.add_argument("--tremolo-groups", type=int, default=1,
@@ -362,7 +365,8 @@ def main(argv=None):
                 "cpu_baseline": None,
             }
     else:
-        pool = ow.EnginePool(SR, n_inst, device=local_rank, preamp_kind=preamp_kind)
+        pa_kind = 1 if args.power_amp == "melange" else 0
+        pool = ow.EnginePool(SR, n_inst, device=local_rank, preamp_kind=preamp_kind, power_amp_kind=pa_kind)
         pool.set_sample_rate(SR)          # the plugin's initialize(): chain build + 0.6 s warm-up (not timed)
         pool.ensure_buffer_capacity(BUF)
         groups = max(1, min(args.tremolo_groups, n_inst))
@@ -480,6 +484,7 @@ def main(argv=None):
                 except Exception:
                     traffic = None
             solver = "melange 12-node DK" if preamp_kind else "legacy DK"
+            amp = "melange 7-BJT power amp + rail sag" if pa_kind else "behavioural power amp"
             line = {
                 "metric": f"audio samples/s, 64-voice full chain (x real-time @{SR / 1000:.0f} kHz = value / {SR:.0f})",
                 "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -487,7 +492,7 @@ def main(argv=None):
                 "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {
                     "workload": (f"cfg2: 64-voice all-keys-sustained (1.0 s re-strike), 48 kHz host / 96 kHz chain, full chain "
-                                 f"(tremolo+{solver} preamp+behavioural power amp+speaker), MLP on, buffers of 512") if SR == 48000.0 else
+                                 f"(tremolo+{solver} preamp+{amp}+speaker), MLP on, buffers of 512") if SR == 48000.0 else
                                 (f"cfg3: 64-voice all-keys-sustained (1.0 s re-strike), {SR:.0f} Hz host"
                                  f"{' (no oversampling)' if SR >= 88200.0 else ' / 2x chain'}, full chain, MLP on, buffers of 512"),
                     "instances_per_gpu": n_inst, "buffer": BUF, "parallelism": f"{world} x independent pools (no data-path collective)",

@@ -8,13 +8,8 @@
 //   power_amp.rs:65-165          RailDynamics
 //   power_amp.rs:279-465         adapter: rail offsets, divergence guard (reset + hold last good), clamp
 //
-// Mapping: lane = engine, ONE wavefront per workgroup.  The 16x16 Newton Jacobian of every lane lives in LDS (lane-minor, 128 KB:
-// no bank conflicts, and partial pivoting is an address: rows are reached through a per-lane permutation kept as 16 nibbles of one
-// 64-bit register, so a row exchange moves no data).  The wave-uniform circuit matrices (S 20x20, K 16x16, S_NI 20x16, sparse A_neg)
-// come from the constant block through scalar loads; the per-lane vectors are private arrays.  Every sum keeps the reference's
-// operand order and the library is built without FMA contraction: fast_exp is pure arithmetic, divisions and square roots are IEEE,
-// so the solver follows the CPU restatement bit for bit (only pnjlim's logarithm -- large forward steps -- can differ in the last
-// place), which is what keeps the divergence guard firing on the same sample on both sides.
+// Mapping and LDS layout: see the block above pa_newton (a lane pair per engine, 32 engines per wavefront, solver vectors in LDS).
+// The wave-uniform circuit matrices (S 20x20, K 16x16, S_NI 20x16, sparse A_neg) come from the constant block through scalar loads.
 #pragma once
 #include "ow_chain_dev.h"
 
@@ -145,335 +140,396 @@ OW_DEV double pa_pnjlim(double vnew, double vold, double vt, double vcrit) {   /
     return vnew;
 }
 
-// The solver state of one lane.  Private arrays (dynamic indices): the compiler keeps them in scratch, which the 64 lanes of the
-// wavefront touch coalesced; the O(16^2) Jacobian traffic goes to LDS instead.
-struct PaState {
-    double v[PA_N], ip[PA_M], ipp[PA_M];
+// ---------------------------------------------------------------------------------------------------------------------------
+// Mapping.  32 engines per wavefront, a LANE PAIR per engine (lane el = role 0, lane el + 32 = role 1), one wavefront per workgroup.
+// Everything the solver indexes dynamically lives in LDS, engine-minor (row r of engine el at W[r * 32], W = base + el): the 16x16 Newton
+// Jacobian, the vectors of the Newton sweep, the node / port state and the vectors of process_sample -- 512 rows = 128 KB.  (The first
+// version kept the vectors in private arrays: 8.4 KB of scratch per lane, every access a trip to L2 / HBM, 6 ms per chain-rate sample.)
+// The two lanes of a pair run the same control flow on the same values and share the O(16^2) work: four of the eight transistors each
+// (device model + their Jacobian rows), every other row of an elimination step / matrix-vector product.  O(16) vector work is done by
+// both lanes redundantly (same values written twice).  Partial pivoting moves no data: logical row r of the Jacobian AND of its
+// right-hand side is physical row (perm >> 4r) & 15, perm a 64-bit register that both lanes keep.  PA_SYNC() orders the LDS traffic
+// where one lane reads what its partner wrote (single-wavefront workgroup: the barrier itself is free).
+// Every sum keeps the reference's operand order; the library is built without FMA contraction: the solver follows the CPU
+// restatement bit for bit (pnjlim's logarithm excepted), which keeps the divergence guard firing on the same sample on both sides.
+#define PA_EPW 32
+enum {
+    PL_J = 0,         // [16][16] Jacobian
+    PL_B = 256,       // [16] right-hand side, by PHYSICAL row
+    PL_X = 272,       // [16] solution of the linear system (delta)
+    PL_VD = 288, PL_F = 304, PL_INL = 320, PL_P = 336,
+    PL_T0 = 352,      // dv_trial / dv
+    PL_T1 = 368,      // v_lim / alpha
+    PL_T2 = 384,      // i_trial
+    PL_V = 400,       // [20] v_prev
+    PL_IP = 420, PL_IPP = 436,
+    PL_RHS = 452, PL_VPRED = 472, PL_VNEW = 492,
+    PL_ROWS = 512
+};
+#define PL(r) W[(r) * PA_EPW]
+#define PA_JE(r, c) W[(PL_J + (r) * PA_M + (c)) * PA_EPW]
+#define PA_SYNC() __syncthreads()
+#define PA_PERM(p, r) ((int)(((p) >> (4 * (r))) & 15ull))
+
+struct PaScal {      // per-engine scalars, identical in both lanes of the pair
     double dcx, dcy, peak, last_good, rail_p, rail_n, iavg_p, iavg_n;
     unsigned long long clamp_cnt, nrmax_cnt, nan_cnt, guard_cnt;
     uint32_t last_nr;
 };
 
-#define PA_J(r, c) JA[(((r) * PA_M) + (c)) * 64]     // JA already points at this lane's column
-
-// One Newton solve (the main sweep with K, or the BE retry with K_be): gen_power_amp.rs:8956-10680 / 10745-12245.
+// One Newton solve (main sweep with K, or the BE retry with K_be): gen_power_amp.rs:8956-10680 / 10745-12245.  p in PL_P, i_nl in PL_INL.
 template <bool BE>
-__device__ __noinline__ void pa_newton(const OwPaConsts* __restrict__ C, const double* __restrict__ p, double* __restrict__ i_nl, double* __restrict__ JA,
-                                       uint32_t* __restrict__ last_nr) {
+__device__ __noinline__ uint32_t pa_newton(const OwPaConsts* __restrict__ C, double* __restrict__ W, int role) {
     const double (*__restrict__ kk)[PA_M] = BE ? C->k_be : C->k;
     for (int iter = 0; iter < 70; ++iter) {
-        double vd[PA_M], f[PA_M], b[PA_M];
-        for (int i = 0; i < PA_M; ++i) {
-            double acc = p[i];
-            for (int j = 0; j < PA_M; ++j) acc = acc + kk[i][j] * i_nl[j];
-            vd[i] = acc;
-        }
-        for (int d = 0; d < 8; ++d) {
-            const PaBjt e = pa_bjt_with_parasitics(vd[2 * d], vd[2 * d + 1], &C->dev[d]);
-            f[2 * d] = i_nl[2 * d] - e.ic;
-            f[2 * d + 1] = i_nl[2 * d + 1] - e.ib;
-            for (int j = 0; j < PA_M; ++j) {                     // J[i][j] = delta_ij - jdev[i][2d] K[2d][j] - jdev[i][2d+1] K[2d+1][j]
+        for (int d = role; d < 8; d += 2) {                       // four transistors per lane
+            double vd2[2];
+            for (int q = 0; q < 2; ++q) {
+                const int r = 2 * d + q;
+                double acc = PL(PL_P + r);
+                for (int j = 0; j < PA_M; ++j) acc = acc + kk[r][j] * PL(PL_INL + j);
+                vd2[q] = acc;
+                PL(PL_VD + r) = acc;
+            }
+            const PaBjt e = pa_bjt_with_parasitics(vd2[0], vd2[1], &C->dev[d]);
+            const double f0 = PL(PL_INL + 2 * d) - e.ic, f1 = PL(PL_INL + 2 * d + 1) - e.ib;
+            PL(PL_F + 2 * d) = f0; PL(PL_F + 2 * d + 1) = f1;
+            PL(PL_B + 2 * d) = f0; PL(PL_B + 2 * d + 1) = f1;
+            for (int j = 0; j < PA_M; ++j) {                      // J[i][j] = delta_ij - jdev[i][2d] K[2d][j] - jdev[i][2d+1] K[2d+1][j]
                 const double k0 = kk[2 * d][j], k1 = kk[2 * d + 1][j];
-                PA_J(2 * d, j) = (j == 2 * d ? 1.0 : 0.0) - e.j0 * k0 - e.j1 * k1;
-                PA_J(2 * d + 1, j) = (j == 2 * d + 1 ? 1.0 : 0.0) - e.j2 * k0 - e.j3 * k1;
+                PA_JE(2 * d, j) = (j == 2 * d ? 1.0 : 0.0) - e.j0 * k0 - e.j1 * k1;
+                PA_JE(2 * d + 1, j) = (j == 2 * d + 1 ? 1.0 : 0.0) - e.j2 * k0 - e.j3 * k1;
             }
         }
-        for (int i = 0; i < PA_M; ++i) b[i] = f[i];
-        // pivoted elimination; logical row r lives in physical row (perm >> 4r) & 15
+        PA_SYNC();
         unsigned long long perm = 0xFEDCBA9876543210ull;
         bool singular = false;
-        for (int col = 0; col < PA_M && !singular; ++col) {
+        for (int col = 0; col < PA_M; ++col) {
             int max_row = col;
-            double max_val = fabs(PA_J((int)((perm >> (4 * col)) & 15ull), col));
+            double max_val = fabs(PA_JE(PA_PERM(perm, col), col));
             for (int row = col + 1; row < PA_M; ++row) {
-                const double v = fabs(PA_J((int)((perm >> (4 * row)) & 15ull), col));
+                const double v = fabs(PA_JE(PA_PERM(perm, row), col));
                 if (v > max_val) { max_val = v; max_row = row; }
             }
             if (max_val < 1e-15) { singular = true; break; }
             if (max_row != col) {
                 const unsigned long long pc = (perm >> (4 * col)) & 15ull, pm = (perm >> (4 * max_row)) & 15ull;
                 perm = (perm & ~(15ull << (4 * col)) & ~(15ull << (4 * max_row))) | (pm << (4 * col)) | (pc << (4 * max_row));
-                const double t = b[col]; b[col] = b[max_row]; b[max_row] = t;
             }
-            const int pr = (int)((perm >> (4 * col)) & 15ull);
-            const double pivot = PA_J(pr, col);
-            const double bcol = b[col];
-            for (int row = col + 1; row < PA_M; ++row) {
-                const int rr = (int)((perm >> (4 * row)) & 15ull);
-                const double factor = ow_div(PA_J(rr, col), pivot);
-                for (int j = col + 1; j < PA_M; ++j) PA_J(rr, j) -= factor * PA_J(pr, j);
-                b[row] -= factor * bcol;
+            const int pr = PA_PERM(perm, col);
+            const double pivot = PA_JE(pr, col);
+            const double bcol = PL(PL_B + pr);
+            for (int row = col + 1 + role; row < PA_M; row += 2) {     // the pair shares the rows below the pivot
+                const int rr = PA_PERM(perm, row);
+                const double factor = ow_div(PA_JE(rr, col), pivot);
+                for (int j = col + 1; j < PA_M; ++j) PA_JE(rr, j) -= factor * PA_JE(pr, j);
+                PL(PL_B + rr) -= factor * bcol;
             }
+            PA_SYNC();
         }
         if (!singular) {
-            for (int i = PA_M - 1; i >= 0; --i) {
-                const int ri = (int)((perm >> (4 * i)) & 15ull);
-                double sum = b[i];
-                for (int j = i + 1; j < PA_M; ++j) sum -= PA_J(ri, j) * b[j];
-                const double aii = PA_J(ri, i);
+            for (int i = PA_M - 1; i >= 0; --i) {                 // both lanes: same values, each reads back what it wrote itself
+                const int ri = PA_PERM(perm, i);
+                double sum = PL(PL_B + ri);
+                for (int j = i + 1; j < PA_M; ++j) sum -= PA_JE(ri, j) * PL(PL_X + j);
+                const double aii = PA_JE(ri, i);
                 if (fabs(aii) < 1e-15) { singular = true; break; }
-                b[i] = ow_div(sum, aii);
+                PL(PL_X + i) = ow_div(sum, aii);
             }
         }
+        PA_SYNC();
         if (singular) {
             for (int i = 0; i < PA_M; ++i) {
-                const double cl = BE ? 0.01 : fmax(fabs(i_nl[i]) * 0.1, 0.01);
-                i_nl[i] -= clampd(f[i] * 0.5, -cl, cl);
+                const double inl = PL(PL_INL + i);
+                const double cl = BE ? 0.01 : fmax(fabs(inl) * 0.1, 0.01);
+                PL(PL_INL + i) = inl - clampd(PL(PL_F + i) * 0.5, -cl, cl);
             }
+            PA_SYNC();
             continue;
         }
+        bool converged = false;
         if (!BE) {
-            double dv_trial[PA_M], v_lim[PA_M], i_trial[PA_M];
-            for (int i = 0; i < PA_M; ++i) i_trial[i] = i_nl[i] - b[i];
-            for (int i = 0; i < PA_M; ++i) {
-                double acc = p[i];
-                for (int j = 0; j < PA_M; ++j) acc = acc + kk[i][j] * i_trial[j];
-                dv_trial[i] = acc - vd[i];
-                v_lim[i] = fabs(dv_trial[i]) > 1e-4 ? pa_pnjlim(acc, vd[i], C->dev[i >> 1].vt, C->dev[i >> 1].vcrit) : acc;
+            for (int i = 0; i < PA_M; ++i) PL(PL_T2 + i) = PL(PL_INL + i) - PL(PL_X + i);       // i_trial (both lanes, same values)
+            for (int i = role; i < PA_M; i += 2) {                                            // v_trial rows shared
+                double acc = PL(PL_P + i);
+                for (int j = 0; j < PA_M; ++j) acc = acc + kk[i][j] * PL(PL_T2 + j);
+                const double vdi = PL(PL_VD + i);
+                const double dvt = acc - vdi;
+                PL(PL_T0 + i) = dvt;
+                PL(PL_T1 + i) = fabs(dvt) > 1e-4 ? pa_pnjlim(acc, vdi, C->dev[i >> 1].vt, C->dev[i >> 1].vcrit) : acc;
             }
+            PA_SYNC();
             bool any_limited = false;
             double ga = 1.0;
             for (int i = 0; i < PA_M; ++i) {
-                const double dv_lim = v_lim[i] - vd[i];
-                if (fabs(dv_trial[i]) > 1e-15) {
-                    const double r = dv_trial[i] * dv_lim < 0.0 ? 0.0 : clampd(ow_div(dv_lim, dv_trial[i]), 0.0, 1.0);
+                const double dvt = PL(PL_T0 + i);
+                const double dv_lim = PL(PL_T1 + i) - PL(PL_VD + i);
+                if (fabs(dvt) > 1e-15) {
+                    const double r = dvt * dv_lim < 0.0 ? 0.0 : clampd(ow_div(dv_lim, dvt), 0.0, 1.0);
                     if (r < ga) { ga = r; any_limited = true; }
                 }
             }
-            double max_dv = fabs(dv_trial[0] * ga);
-            for (int i = 1; i < PA_M; ++i) max_dv = fmax(max_dv, fabs(dv_trial[i] * ga));
+            double max_dv = fabs(PL(PL_T0) * ga);
+            for (int i = 1; i < PA_M; ++i) max_dv = fmax(max_dv, fabs(PL(PL_T0 + i) * ga));
             if (max_dv > 3.5) { ga *= fmax(ow_div(3.5, max_dv), 0.1); any_limited = true; }
-            for (int i = 0; i < PA_M; ++i) i_nl[i] -= ga * b[i];
+            for (int i = 0; i < PA_M; ++i) PL(PL_INL + i) = PL(PL_INL + i) - ga * PL(PL_X + i);
             if (!any_limited) {
                 bool conv = true;
                 for (int i = 0; i < PA_M; ++i) {
-                    const double dv = dv_trial[i] * ga;
-                    const double thr = 1e-3 * fmax(fabs(vd[i]), fabs(vd[i] + dv)) + 1e-6;
+                    const double dv = PL(PL_T0 + i) * ga, vdi = PL(PL_VD + i);
+                    const double thr = 1e-3 * fmax(fabs(vdi), fabs(vdi + dv)) + 1e-6;
                     if (fabs(dv) > thr) conv = false;
                 }
-                if (conv) { *last_nr = (uint32_t)iter; return; }
+                converged = conv;
             }
         } else {
-            double dv[PA_M], al[PA_M];
-            for (int i = 0; i < PA_M; ++i) {
-                double acc = kk[i][0] * b[0];
-                for (int j = 1; j < PA_M; ++j) acc = acc + kk[i][j] * b[j];
-                dv[i] = -acc;
-                al[i] = 1.0;
+            for (int i = role; i < PA_M; i += 2) {                                            // dv rows shared
+                double acc = kk[i][0] * PL(PL_X);
+                for (int j = 1; j < PA_M; ++j) acc = acc + kk[i][j] * PL(PL_X + j);
+                PL(PL_T0 + i) = -acc;
             }
+            PA_SYNC();
             bool any_limited = false;
             for (int i = 0; i < PA_M; ++i) {
-                if (fabs(dv[i]) > 1e-4) {
-                    const double vl = pa_pnjlim(vd[i] + dv[i], vd[i], C->dev[i >> 1].vt, C->dev[i >> 1].vcrit);
-                    const double ratio = fmax(ow_div(vl - vd[i], dv[i]), 0.01);
-                    if (ratio < al[i]) { al[i] = ratio; if (ratio < 1.0) any_limited = true; }
+                const double dvi = PL(PL_T0 + i), vdi = PL(PL_VD + i);
+                double al = 1.0;
+                if (fabs(dvi) > 1e-4) {
+                    const double vl = pa_pnjlim(vdi + dvi, vdi, C->dev[i >> 1].vt, C->dev[i >> 1].vcrit);
+                    const double ratio = fmax(ow_div(vl - vdi, dvi), 0.01);
+                    if (ratio < al) { al = ratio; if (ratio < 1.0) any_limited = true; }
                 }
+                PL(PL_T1 + i) = al;
             }
-            for (int d = 0; d < 8; ++d) { const double m = fmin(al[2 * d], al[2 * d + 1]); al[2 * d] = m; al[2 * d + 1] = m; }
-            double max_dv = fabs(dv[0] * al[0]);
-            for (int i = 1; i < PA_M; ++i) max_dv = fmax(max_dv, fabs(dv[i] * al[i]));
+            for (int d = 0; d < 8; ++d) { const double m = fmin(PL(PL_T1 + 2 * d), PL(PL_T1 + 2 * d + 1)); PL(PL_T1 + 2 * d) = m; PL(PL_T1 + 2 * d + 1) = m; }
+            double max_dv = fabs(PL(PL_T0) * PL(PL_T1));
+            for (int i = 1; i < PA_M; ++i) max_dv = fmax(max_dv, fabs(PL(PL_T0 + i) * PL(PL_T1 + i)));
             if (max_dv > 3.5) {
                 const double factor = fmax(ow_div(3.5, max_dv), 0.1);
-                for (int i = 0; i < PA_M; ++i) al[i] *= factor;
+                for (int i = 0; i < PA_M; ++i) PL(PL_T1 + i) = PL(PL_T1 + i) * factor;
             }
-            for (int i = 0; i < PA_M; ++i) i_nl[i] -= al[i] * b[i];
+            for (int i = 0; i < PA_M; ++i) PL(PL_INL + i) = PL(PL_INL + i) - PL(PL_T1 + i) * PL(PL_X + i);
             if (!any_limited) {
                 bool conv = true;
                 for (int i = 0; i < PA_M; ++i) {
-                    const double stp = dv[i] * al[i];
-                    const double thr = 1e-3 * fmax(fabs(vd[i]), fabs(vd[i] + stp)) + 1e-6;
+                    const double stp = PL(PL_T0 + i) * PL(PL_T1 + i), vdi = PL(PL_VD + i);
+                    const double thr = 1e-3 * fmax(fabs(vdi), fabs(vdi + stp)) + 1e-6;
                     if (fabs(stp) > thr) conv = false;
                 }
-                if (conv) { *last_nr = (uint32_t)iter; return; }
+                converged = conv;
             }
         }
+        PA_SYNC();
+        if (converged) return (uint32_t)iter;
     }
+    return 70u;
 }
 
 // gen_power_amp.rs:8838-12337.  off_p / off_n: the runtime rail offsets (v_rail_pos_offset / v_rail_neg_offset of the state).
-__device__ __noinline__ double pa_process_sample(PaState* __restrict__ st, const OwPaConsts* __restrict__ C, double input_in, double off_p, double off_n,
-                                                 double* __restrict__ JA) {
+__device__ __noinline__ double pa_process_sample(PaScal* __restrict__ sc, const OwPaConsts* __restrict__ C, double* __restrict__ W, int role, double input_in,
+                                                 double off_p, double off_n) {
     const double input = isfinite(input_in) ? clampd(input_in, -100.0, 100.0) : 0.0;
-    for (int i = 0; i < PA_N; ++i) st->v[i] = st->v[i] + 1e-25 - 1e-25;
-    for (int i = 0; i < PA_M; ++i) st->ip[i] = st->ip[i] + 1e-25 - 1e-25;
-    double rhs[PA_N], v_pred[PA_N], p[PA_M], i_nl[PA_M], v[PA_N];
-    for (int i = 0; i < PA_N; ++i) rhs[i] = PA_RHS_CONST[i];
+    for (int i = 0; i < PA_N; ++i) PL(PL_V + i) = PL(PL_V + i) + 1e-25 - 1e-25;
+    for (int i = 0; i < PA_M; ++i) PL(PL_IP + i) = PL(PL_IP + i) + 1e-25 - 1e-25;
+    for (int i = 0; i < PA_N; ++i) PL(PL_RHS + i) = PA_RHS_CONST[i];
     for (int q = 0; q < PA_RHS_NNZ; ++q) {
         const int i = (int)PA_RHS_NZ_ROW[q], j = (int)PA_RHS_NZ_COL[q];
-        rhs[i] += C->a_neg[i][j] * st->v[j];
+        PL(PL_RHS + i) = PL(PL_RHS + i) + C->a_neg[i][j] * PL(PL_V + j);
     }
-    rhs[0] += input * (1.0 / PA_INPUT_RESISTANCE);
-    rhs[18] += off_p;
-    rhs[19] += off_n;
-    for (int i = 0; i < PA_N; ++i) {
+    PL(PL_RHS + 0) = PL(PL_RHS + 0) + input * (1.0 / PA_INPUT_RESISTANCE);
+    PL(PL_RHS + 18) = PL(PL_RHS + 18) + off_p;
+    PL(PL_RHS + 19) = PL(PL_RHS + 19) + off_n;
+    for (int i = role; i < PA_N; i += 2) {                        // v_pred = S rhs, rows shared
         double sum = 0.0;
-        for (int j = 0; j < PA_N; ++j) sum += C->s[i][j] * rhs[j];
-        v_pred[i] = sum;
+        for (int j = 0; j < PA_N; ++j) sum += C->s[i][j] * PL(PL_RHS + j);
+        PL(PL_VPRED + i) = sum;
     }
+    PA_SYNC();
     for (int i = 0; i < PA_M; ++i) {
         const int na = (int)PA_P_NODE_A[i], nb = (int)PA_P_NODE_B[i];
-        p[i] = PA_N_V[i][na] * v_pred[na] + PA_N_V[i][nb] * v_pred[nb];
+        PL(PL_P + i) = PA_N_V[i][na] * PL(PL_VPRED + na) + PA_N_V[i][nb] * PL(PL_VPRED + nb);
+        PL(PL_INL + i) = 2.0 * PL(PL_IP + i) - PL(PL_IPP + i);
     }
-    for (int i = 0; i < PA_M; ++i) i_nl[i] = 2.0 * st->ip[i] - st->ipp[i];
-    st->last_nr = 70u;
-    pa_newton<false>(C, p, i_nl, JA, &st->last_nr);
-    for (int i = 0; i < PA_N; ++i) {
-        double x = v_pred[i];
-        for (int j = 0; j < PA_M; ++j) x += C->s_ni[i][j] * i_nl[j];
-        v[i] = x;
+    PA_SYNC();
+    sc->last_nr = pa_newton<false>(C, W, role);
+    for (int i = role; i < PA_N; i += 2) {
+        double x = PL(PL_VPRED + i);
+        for (int j = 0; j < PA_M; ++j) x += C->s_ni[i][j] * PL(PL_INL + j);
+        PL(PL_VNEW + i) = x;
     }
-    if (__builtin_expect(!(st->last_nr < 70u), 0)) {       // backward-Euler-matrix retry
-        st->nrmax_cnt += 1ull;
-        double rhs_be[PA_N], v_pred_be[PA_N], p_be[PA_M];
-        for (int i = 0; i < PA_N; ++i) {
+    PA_SYNC();
+    if (__builtin_expect(!(sc->last_nr < 70u), 0)) {              // backward-Euler-matrix retry
+        sc->nrmax_cnt += 1ull;
+        for (int i = role; i < PA_N; i += 2) {
             double sum = PA_RHS_CONST_BE[i];
-            for (int j = 0; j < PA_N; ++j) sum += C->a_neg_be[i][j] * st->v[j];
-            for (int j = 0; j < PA_M; ++j) sum += PA_N_I[i][j] * st->ip[j];
-            rhs_be[i] = sum;
+            for (int j = 0; j < PA_N; ++j) sum += C->a_neg_be[i][j] * PL(PL_V + j);
+            for (int j = 0; j < PA_M; ++j) sum += PA_N_I[i][j] * PL(PL_IP + j);
+            PL(PL_RHS + i) = sum;
         }
-        rhs_be[0] += input * (1.0 / PA_INPUT_RESISTANCE);
-        for (int i = 0; i < PA_N; ++i) {
+        PA_SYNC();
+        PL(PL_RHS + 0) = PL(PL_RHS + 0) + input * (1.0 / PA_INPUT_RESISTANCE) * (role == 0 ? 1.0 : 0.0);   // one lane adds the input term
+        PA_SYNC();
+        for (int i = role; i < PA_N; i += 2) {
             double sum = 0.0;
-            for (int j = 0; j < PA_N; ++j) sum += C->s_be[i][j] * rhs_be[j];
-            v_pred_be[i] = sum;
+            for (int j = 0; j < PA_N; ++j) sum += C->s_be[i][j] * PL(PL_RHS + j);
+            PL(PL_VPRED + i) = sum;
         }
+        PA_SYNC();
         for (int i = 0; i < PA_M; ++i) {
             double sum = 0.0;
-            for (int j = 0; j < PA_N; ++j) sum += PA_N_V[i][j] * v_pred_be[j];
-            p_be[i] = sum;
+            for (int j = 0; j < PA_N; ++j) sum += PA_N_V[i][j] * PL(PL_VPRED + j);
+            PL(PL_P + i) = sum;
+            PL(PL_INL + i) = 2.0 * PL(PL_IP + i) - PL(PL_IPP + i);
         }
-        for (int i = 0; i < PA_M; ++i) i_nl[i] = 2.0 * st->ip[i] - st->ipp[i];
-        pa_newton<true>(C, p_be, i_nl, JA, &st->last_nr);
-        for (int i = 0; i < PA_N; ++i) {
-            double x = v_pred_be[i];
-            for (int j = 0; j < PA_M; ++j) x += C->s_ni_be[i][j] * i_nl[j];
-            v[i] = x;
+        PA_SYNC();
+        sc->last_nr = pa_newton<true>(C, W, role);
+        for (int i = role; i < PA_N; i += 2) {
+            double x = PL(PL_VPRED + i);
+            for (int j = 0; j < PA_M; ++j) x += C->s_ni_be[i][j] * PL(PL_INL + j);
+            PL(PL_VNEW + i) = x;
         }
+        PA_SYNC();
     }
     bool finite = true;
-    for (int i = 0; i < PA_N; ++i) finite = finite && isfinite(v[i]);
+    for (int i = 0; i < PA_N; ++i) finite = finite && isfinite(PL(PL_VNEW + i));
+    PA_SYNC();
     if (__builtin_expect(!finite, 0)) {
-        for (int i = 0; i < PA_N; ++i) st->v[i] = PA_DC_OP[i];            // dc_operating_point == DC_OP (never re-set by the adapter)
-        for (int i = 0; i < PA_M; ++i) { st->ip[i] = PA_DC_NL_I[i]; st->ipp[i] = PA_DC_NL_I[i]; }
-        st->dcx = 0.0; st->dcy = 0.0;
-        st->nan_cnt += 1ull;
+        for (int i = 0; i < PA_N; ++i) PL(PL_V + i) = PA_DC_OP[i];            // dc_operating_point == DC_OP (never re-set by the adapter)
+        for (int i = 0; i < PA_M; ++i) { PL(PL_IP + i) = PA_DC_NL_I[i]; PL(PL_IPP + i) = PA_DC_NL_I[i]; }
+        sc->dcx = 0.0; sc->dcy = 0.0;
+        sc->nan_cnt += 1ull;
+        PA_SYNC();
         return PA_DC_BLOCK_X0;
     }
-    for (int i = 0; i < PA_N; ++i) st->v[i] = v[i];
-    for (int i = 0; i < PA_M; ++i) { st->ipp[i] = st->ip[i]; st->ip[i] = i_nl[i]; }
-    const double raw_out = v[8];
-    const double dc_blocked = raw_out - st->dcx + C->dc_block_r * st->dcy;
-    st->dcx = raw_out;
-    st->dcy = dc_blocked;
+    for (int i = 0; i < PA_N; ++i) PL(PL_V + i) = PL(PL_VNEW + i);
+    for (int i = 0; i < PA_M; ++i) { PL(PL_IPP + i) = PL(PL_IP + i); PL(PL_IP + i) = PL(PL_INL + i); }
+    const double raw_out = PL(PL_VNEW + 8);
+    PA_SYNC();
+    const double dc_blocked = raw_out - sc->dcx + C->dc_block_r * sc->dcy;
+    sc->dcx = raw_out;
+    sc->dcy = dc_blocked;
     const double scaled = dc_blocked * 1.0;
     const double abs_out = fabs(scaled);
-    if (abs_out > st->peak) st->peak = abs_out;
-    if (abs_out > 3e1) st->clamp_cnt += 1ull;
+    if (abs_out > sc->peak) sc->peak = abs_out;
+    if (abs_out > 3e1) sc->clamp_cnt += 1ull;
     return clampd(scaled, -3e1, 3e1);
 }
 
 // state <- settled blob (+ the per-state part of set_sample_rate when the chain does not run at the codegen rate): init_state,
-// power_amp.rs:294-302
-__device__ inline void pa_init_state(PaState* __restrict__ st, const double* __restrict__ settled, const OwPaConsts* __restrict__ C) {
-    for (int i = 0; i < PA_N; ++i) st->v[i] = settled[PAS_V + i];
-    for (int i = 0; i < PA_M; ++i) { st->ip[i] = settled[PAS_IP + i]; st->ipp[i] = settled[PAS_IPP + i]; }
-    st->dcx = settled[PAS_DCX]; st->dcy = settled[PAS_DCY]; st->peak = settled[PAS_PEAK];
-    st->clamp_cnt = dbits(settled[PAS_CLAMP]); st->nrmax_cnt = dbits(settled[PAS_NRMAX]); st->nan_cnt = dbits(settled[PAS_NAN]);
-    if (!C->rate_is_codegen) { st->dcx = 0.0; st->dcy = 0.0; }
-    st->last_nr = 0u;
+// power_amp.rs:294-302.  Both lanes write the same values.
+__device__ inline void pa_init_state(PaScal* __restrict__ sc, double* __restrict__ W, const double* __restrict__ settled, const OwPaConsts* __restrict__ C) {
+    for (int i = 0; i < PA_N; ++i) PL(PL_V + i) = settled[PAS_V + i];
+    for (int i = 0; i < PA_M; ++i) { PL(PL_IP + i) = settled[PAS_IP + i]; PL(PL_IPP + i) = settled[PAS_IPP + i]; }
+    sc->dcx = settled[PAS_DCX]; sc->dcy = settled[PAS_DCY]; sc->peak = settled[PAS_PEAK];
+    sc->clamp_cnt = dbits(settled[PAS_CLAMP]); sc->nrmax_cnt = dbits(settled[PAS_NRMAX]); sc->nan_cnt = dbits(settled[PAS_NAN]);
+    if (!C->rate_is_codegen) { sc->dcx = 0.0; sc->dcy = 0.0; }
+    sc->last_nr = 0u;
+    PA_SYNC();
 }
-__device__ inline void pa_rails_reset(PaState* __restrict__ st) { st->rail_p = 22.5; st->rail_n = 22.5; st->iavg_p = 0.0; st->iavg_n = 0.0; }
+__device__ inline void pa_rails_reset(PaScal* __restrict__ sc) { sc->rail_p = 22.5; sc->rail_n = 22.5; sc->iavg_p = 0.0; sc->iavg_n = 0.0; }
 
 // melange_adapter::PowerAmp::process, power_amp.rs:373-431
-__device__ inline double pa_process(PaState* __restrict__ st, const OwPaConsts* __restrict__ C, const double* __restrict__ settled, double input, bool rail_sag,
-                                    double* __restrict__ JA) {
-    const double off_p = rail_sag ? st->rail_p - 22.5 : 0.0, off_n = rail_sag ? st->rail_n - 22.5 : 0.0;
-    const double raw = pa_process_sample(st, C, input, off_p, off_n, JA);
+__device__ inline double pa_process(PaScal* __restrict__ sc, const OwPaConsts* __restrict__ C, double* __restrict__ W, int role, const double* __restrict__ settled,
+                                    double input, bool rail_sag) {
+    const double off_p = rail_sag ? sc->rail_p - 22.5 : 0.0, off_n = rail_sag ? sc->rail_n - 22.5 : 0.0;
+    const double raw = pa_process_sample(sc, C, W, role, input, off_p, off_n);
     const double result = OW_DIV_C(raw, 22.0);
-    const bool nr_failed = st->last_nr >= 69u;
+    const bool nr_failed = sc->last_nr >= 69u;
     bool insane = false;
-    for (int i = 0; i < PA_N; ++i) insane = insane || !isfinite(st->v[i]) || fabs(st->v[i]) > 100.0;
+    for (int i = 0; i < PA_N; ++i) { const double v = PL(PL_V + i); insane = insane || !isfinite(v) || fabs(v) > 100.0; }
+    PA_SYNC();
     if (__builtin_expect(!isfinite(result) || nr_failed || insane, 0)) {
-        pa_init_state(st, settled, C);
-        pa_rails_reset(st);
-        st->guard_cnt += 1ull;
-        return st->last_good;
+        pa_init_state(sc, W, settled, C);
+        pa_rails_reset(sc);
+        sc->guard_cnt += 1ull;
+        return sc->last_good;
     }
     const double clamped = clampd(result, -1.0, 1.0);
-    st->last_good = clamped;
+    sc->last_good = clamped;
     if (rail_sag) {        // RailDynamics::step(raw), power_amp.rs:131-156
         const double i_pos = fmax(OW_DIV_C(raw, 8.0), 0.0);
         const double i_neg = fmax(OW_DIV_C(-raw, 8.0), 0.0);
-        st->iavg_p += C->alpha_i_avg * (i_pos - st->iavg_p);
-        st->iavg_n += C->alpha_i_avg * (i_neg - st->iavg_n);
-        const double target_pos = 24.5 - st->iavg_p * 3.5;
-        const double target_neg = 24.5 - st->iavg_n * 3.5;
-        const double alpha_p = target_pos < st->rail_p ? C->alpha_attack : C->alpha_release;
-        const double alpha_n = target_neg < st->rail_n ? C->alpha_attack : C->alpha_release;
-        st->rail_p += alpha_p * (target_pos - st->rail_p);
-        st->rail_n += alpha_n * (target_neg - st->rail_n);
+        sc->iavg_p += C->alpha_i_avg * (i_pos - sc->iavg_p);
+        sc->iavg_n += C->alpha_i_avg * (i_neg - sc->iavg_n);
+        const double target_pos = 24.5 - sc->iavg_p * 3.5;
+        const double target_neg = 24.5 - sc->iavg_n * 3.5;
+        const double alpha_p = target_pos < sc->rail_p ? C->alpha_attack : C->alpha_release;
+        const double alpha_n = target_neg < sc->rail_n ? C->alpha_attack : C->alpha_release;
+        sc->rail_p += alpha_p * (target_pos - sc->rail_p);
+        sc->rail_n += alpha_n * (target_neg - sc->rail_n);
     }
     return clamped;
 }
 
-OW_DEV void pa_load(PaState* __restrict__ st, const double* __restrict__ pa, int I, int e) {
-    for (int i = 0; i < PA_N; ++i) st->v[i] = pa[(size_t)(PAS_V + i) * I + e];
-    for (int i = 0; i < PA_M; ++i) { st->ip[i] = pa[(size_t)(PAS_IP + i) * I + e]; st->ipp[i] = pa[(size_t)(PAS_IPP + i) * I + e]; }
-    st->dcx = pa[(size_t)PAS_DCX * I + e]; st->dcy = pa[(size_t)PAS_DCY * I + e]; st->peak = pa[(size_t)PAS_PEAK * I + e];
-    st->clamp_cnt = dbits(pa[(size_t)PAS_CLAMP * I + e]); st->nrmax_cnt = dbits(pa[(size_t)PAS_NRMAX * I + e]); st->nan_cnt = dbits(pa[(size_t)PAS_NAN * I + e]);
-    st->last_good = pa[(size_t)PAS_LASTGOOD * I + e];
-    st->rail_p = pa[(size_t)PAS_RAILP * I + e]; st->rail_n = pa[(size_t)PAS_RAILN * I + e];
-    st->iavg_p = pa[(size_t)PAS_IAVGP * I + e]; st->iavg_n = pa[(size_t)PAS_IAVGN * I + e];
-    st->guard_cnt = dbits(pa[(size_t)PAS_GUARD * I + e]);
-    st->last_nr = 0u;
+// engine e's state rows <-> LDS (both lanes load the same values; one lane stores)
+OW_DEV void pa_load(PaScal* __restrict__ sc, double* __restrict__ W, const double* __restrict__ pa, int I, int e) {
+    for (int i = 0; i < PA_N; ++i) PL(PL_V + i) = pa[(size_t)(PAS_V + i) * I + e];
+    for (int i = 0; i < PA_M; ++i) { PL(PL_IP + i) = pa[(size_t)(PAS_IP + i) * I + e]; PL(PL_IPP + i) = pa[(size_t)(PAS_IPP + i) * I + e]; }
+    sc->dcx = pa[(size_t)PAS_DCX * I + e]; sc->dcy = pa[(size_t)PAS_DCY * I + e]; sc->peak = pa[(size_t)PAS_PEAK * I + e];
+    sc->clamp_cnt = dbits(pa[(size_t)PAS_CLAMP * I + e]); sc->nrmax_cnt = dbits(pa[(size_t)PAS_NRMAX * I + e]); sc->nan_cnt = dbits(pa[(size_t)PAS_NAN * I + e]);
+    sc->last_good = pa[(size_t)PAS_LASTGOOD * I + e];
+    sc->rail_p = pa[(size_t)PAS_RAILP * I + e]; sc->rail_n = pa[(size_t)PAS_RAILN * I + e];
+    sc->iavg_p = pa[(size_t)PAS_IAVGP * I + e]; sc->iavg_n = pa[(size_t)PAS_IAVGN * I + e];
+    sc->guard_cnt = dbits(pa[(size_t)PAS_GUARD * I + e]);
+    sc->last_nr = 0u;
+    PA_SYNC();
 }
-OW_DEV void pa_store(const PaState* __restrict__ st, double* __restrict__ pa, int I, int e) {
-    for (int i = 0; i < PA_N; ++i) pa[(size_t)(PAS_V + i) * I + e] = st->v[i];
-    for (int i = 0; i < PA_M; ++i) { pa[(size_t)(PAS_IP + i) * I + e] = st->ip[i]; pa[(size_t)(PAS_IPP + i) * I + e] = st->ipp[i]; }
-    pa[(size_t)PAS_DCX * I + e] = st->dcx; pa[(size_t)PAS_DCY * I + e] = st->dcy; pa[(size_t)PAS_PEAK * I + e] = st->peak;
-    pa[(size_t)PAS_CLAMP * I + e] = bitsd(st->clamp_cnt); pa[(size_t)PAS_NRMAX * I + e] = bitsd(st->nrmax_cnt); pa[(size_t)PAS_NAN * I + e] = bitsd(st->nan_cnt);
-    pa[(size_t)PAS_LASTGOOD * I + e] = st->last_good;
-    pa[(size_t)PAS_RAILP * I + e] = st->rail_p; pa[(size_t)PAS_RAILN * I + e] = st->rail_n;
-    pa[(size_t)PAS_IAVGP * I + e] = st->iavg_p; pa[(size_t)PAS_IAVGN * I + e] = st->iavg_n;
-    pa[(size_t)PAS_GUARD * I + e] = bitsd(st->guard_cnt);
+OW_DEV void pa_store(const PaScal* __restrict__ sc, const double* __restrict__ W, double* __restrict__ pa, int I, int e) {
+    for (int i = 0; i < PA_N; ++i) pa[(size_t)(PAS_V + i) * I + e] = PL(PL_V + i);
+    for (int i = 0; i < PA_M; ++i) { pa[(size_t)(PAS_IP + i) * I + e] = PL(PL_IP + i); pa[(size_t)(PAS_IPP + i) * I + e] = PL(PL_IPP + i); }
+    pa[(size_t)PAS_DCX * I + e] = sc->dcx; pa[(size_t)PAS_DCY * I + e] = sc->dcy; pa[(size_t)PAS_PEAK * I + e] = sc->peak;
+    pa[(size_t)PAS_CLAMP * I + e] = bitsd(sc->clamp_cnt); pa[(size_t)PAS_NRMAX * I + e] = bitsd(sc->nrmax_cnt); pa[(size_t)PAS_NAN * I + e] = bitsd(sc->nan_cnt);
+    pa[(size_t)PAS_LASTGOOD * I + e] = sc->last_good;
+    pa[(size_t)PAS_RAILP * I + e] = sc->rail_p; pa[(size_t)PAS_RAILN * I + e] = sc->rail_n;
+    pa[(size_t)PAS_IAVGP * I + e] = sc->iavg_p; pa[(size_t)PAS_IAVGN * I + e] = sc->iavg_n;
+    pa[(size_t)PAS_GUARD * I + e] = bitsd(sc->guard_cnt);
 }
 
 // Settled state of the amp (compute_settled_state, power_amp.rs:290-296): CircuitState::default() (DC_OP + 50 warm-up samples) and
-// 44 100 silent samples, all with the codegen-rate matrices.  One lane; cached per device by the host like the reference's OnceLock.
+// 44 100 silent samples, all with the codegen-rate matrices.  One lane pair; cached per device by the host like the reference's OnceLock.
 __global__ __launch_bounds__(64) void k_mpa_settle(const OwPaConsts* __restrict__ C88, double* __restrict__ settled) {
-    __shared__ double JA_all[PA_M * PA_M * 64];
+    __shared__ double WS[PL_ROWS * PA_EPW];
+    const int el = threadIdx.x & 31, role = threadIdx.x >> 5;
+    double* W = WS + el;                                   // all 32 pairs run the same silent settle (no divergence); pair 0 reports
+    PaScal sc;
+    for (int i = 0; i < PA_N; ++i) PL(PL_V + i) = PA_DC_OP[i];
+    for (int i = 0; i < PA_M; ++i) { PL(PL_IP + i) = PA_DC_NL_I[i]; PL(PL_IPP + i) = PA_DC_NL_I[i]; }
+    sc.dcx = PA_DC_BLOCK_X0; sc.dcy = 0.0; sc.peak = 0.0; sc.clamp_cnt = sc.nrmax_cnt = sc.nan_cnt = sc.guard_cnt = 0ull;
+    sc.last_good = 0.0; sc.last_nr = 0u;
+    pa_rails_reset(&sc);
+    PA_SYNC();
+    for (int n = 0; n < 50 + 44100; ++n) pa_process_sample(&sc, C88, W, role, 0.0, 0.0, 0.0);
     if (threadIdx.x != 0) return;
-    PaState st;
-    for (int i = 0; i < PA_N; ++i) st.v[i] = PA_DC_OP[i];
-    for (int i = 0; i < PA_M; ++i) { st.ip[i] = PA_DC_NL_I[i]; st.ipp[i] = PA_DC_NL_I[i]; }
-    st.dcx = PA_DC_BLOCK_X0; st.dcy = 0.0; st.peak = 0.0; st.clamp_cnt = st.nrmax_cnt = st.nan_cnt = st.guard_cnt = 0ull;
-    st.last_good = 0.0; st.last_nr = 0u;
-    pa_rails_reset(&st);
-    for (int n = 0; n < 50 + 44100; ++n) pa_process_sample(&st, C88, 0.0, 0.0, 0.0, JA_all);
-    for (int i = 0; i < PA_N; ++i) settled[PAS_V + i] = st.v[i];
-    for (int i = 0; i < PA_M; ++i) { settled[PAS_IP + i] = st.ip[i]; settled[PAS_IPP + i] = st.ipp[i]; }
-    settled[PAS_DCX] = st.dcx; settled[PAS_DCY] = st.dcy; settled[PAS_PEAK] = st.peak;
-    settled[PAS_CLAMP] = bitsd(st.clamp_cnt); settled[PAS_NRMAX] = bitsd(st.nrmax_cnt); settled[PAS_NAN] = bitsd(st.nan_cnt);
+    for (int i = 0; i < PA_N; ++i) settled[PAS_V + i] = PL(PL_V + i);
+    for (int i = 0; i < PA_M; ++i) { settled[PAS_IP + i] = PL(PL_IP + i); settled[PAS_IPP + i] = PL(PL_IPP + i); }
+    settled[PAS_DCX] = sc.dcx; settled[PAS_DCY] = sc.dcy; settled[PAS_PEAK] = sc.peak;
+    settled[PAS_CLAMP] = bitsd(sc.clamp_cnt); settled[PAS_NRMAX] = bitsd(sc.nrmax_cnt); settled[PAS_NAN] = bitsd(sc.nan_cnt);
 }
 
-// The amp alone on given input (debug hook ow_debug_power_amp): lane b of block b processes row b of `in`.  taps [row][n][3]: outer Newton
-// iterations of the sample (70 = exhausted), guard resets so far, positive rail after the sample.
+// The amp alone on given input (debug hook ow_debug_power_amp): pair p of block b processes row b * 32 + p of `in`.  taps [row][n][3]: outer
+// Newton iterations of the sample (70 = exhausted), guard resets so far, positive rail after the sample.
 __global__ __launch_bounds__(64) void k_mpa_debug(const OwPaConsts* __restrict__ C, const double* __restrict__ settled, const double* __restrict__ in,
-                                                  double* __restrict__ out, double* __restrict__ taps, long long n, int rail_sag, const long long* __restrict__ poke_at,
-                                                  const int* __restrict__ poke_node, const double* __restrict__ poke_val) {
-    __shared__ double JA_all[PA_M * PA_M * 64];
-    if (threadIdx.x != 0) return;
-    const size_t row = blockIdx.x;
-    PaState st;
-    pa_init_state(&st, settled, C);
-    pa_rails_reset(&st);
-    st.last_good = 0.0; st.guard_cnt = 0ull;
+                                                  double* __restrict__ out, double* __restrict__ taps, long long n, int n_rows, int rail_sag,
+                                                  const long long* __restrict__ poke_at, const int* __restrict__ poke_node, const double* __restrict__ poke_val) {
+    __shared__ double WS[PL_ROWS * PA_EPW];
+    const int el = threadIdx.x & 31, role = threadIdx.x >> 5;
+    double* W = WS + el;
+    const int row_raw = blockIdx.x * PA_EPW + el;
+    const bool valid = row_raw < n_rows;
+    const size_t row = valid ? row_raw : n_rows - 1;
+    PaScal sc;
+    pa_init_state(&sc, W, settled, C);
+    pa_rails_reset(&sc);
+    sc.last_good = 0.0; sc.guard_cnt = 0ull;
     for (long long i = 0; i < n; ++i) {
-        if (poke_at && poke_at[row] == i) st.v[poke_node[row]] = poke_val[row];
-        out[row * n + i] = pa_process(&st, C, settled, in[row * n + i], rail_sag != 0, JA_all);
-        if (taps) {
-            double* t = taps + (row * n + i) * 3;
-            t[0] = (double)st.last_nr; t[1] = (double)st.guard_cnt; t[2] = st.rail_p;
+        if (poke_at && poke_at[row] == i) { PL(PL_V + poke_node[row]) = poke_val[row]; }
+        PA_SYNC();
+        const double y = pa_process(&sc, C, W, role, settled, in[row * n + i], rail_sag != 0);
+        if (valid && role == 0) {
+            out[row * n + i] = y;
+            if (taps) {
+                double* t = taps + (row * n + i) * 3;
+                t[0] = (double)sc.last_nr; t[1] = (double)sc.guard_cnt; t[2] = sc.rail_p;
+            }
         }
     }
 }
@@ -490,19 +546,20 @@ __global__ void k_mpa_init(const OwPaConsts* __restrict__ C, const double* __res
     if (fresh) { pa[(size_t)PAS_LASTGOOD * I + e] = 0.0; pa[(size_t)PAS_GUARD * I + e] = bitsd(0ull); }
 }
 
-// Output stage with the melange power amp: lane = engine (the amp is a stateful recurrence at the chain rate, so the two chain-rate
-// samples of an output sample are solved one after the other by the same lane), then half-band down, speaker, gain, f32 as k_post.
-// One wavefront per workgroup (144 KB of the CU's 160 KB LDS).
+// Output stage with the melange power amp: a lane pair per engine (the amp is a stateful recurrence at the chain rate, so the two
+// chain-rate samples of an output sample are solved one after the other), then half-band down, speaker, gain, f32 as k_post -- that
+// cheap tail is computed by both lanes of the pair, lane 0 of the pair owns state and output.  One wavefront per workgroup.
 __global__ __launch_bounds__(64) void k_post_mpa(const OwConsts* __restrict__ K, const OwPaConsts* __restrict__ C, const double* __restrict__ settled,
                                                  double* __restrict__ cs, double* __restrict__ pa, const OwEngineArgs* __restrict__ args,
                                                  OwEngineOut* __restrict__ eout, const double* __restrict__ pre, float* __restrict__ out,
                                                  double* __restrict__ pa_tap, int I, int L, int Lout, int e0, int ne) {
-    __shared__ double JA_all[PA_M * PA_M * 64];          // 128 KB: the Jacobians of the 64 lanes
-    __shared__ float tile[64 * (OW_OCHUNK + 1)];
+    __shared__ double WS[PL_ROWS * PA_EPW];                      // 128 KB
+    __shared__ float tile[PA_EPW * (OW_OCHUNK + 1)];
     const int lane = threadIdx.x;
-    double* JA = JA_all + lane;
-    const int eb = e0 + blockIdx.x * 64;
-    const int e_raw = eb + lane;
+    const int el = lane & 31, role = lane >> 5;
+    double* W = WS + el;
+    const int eb = e0 + blockIdx.x * PA_EPW;
+    const int e_raw = eb + el;
     const bool valid = e_raw < e0 + ne;
     const int e = valid ? e_raw : (e0 + ne - 1);
     const int osr = K->oversample ? 2 : 1;
@@ -524,8 +581,8 @@ __global__ __launch_bounds__(64) void k_post_mpa(const OwConsts* __restrict__ K,
     smoother_load(sv, cs, I, e, CS_SM_VOL);
     if (args[e].set_flags & 2u) ss.retarget(args[e].spk_target, K->ramp_samples);
     if (args[e].set_flags & 4u) sv.retarget(args[e].vol_target, K->ramp_samples);
-    PaState st;
-    pa_load(&st, pa, I, e);
+    PaScal sc;
+    pa_load(&sc, W, pa, I, e);
     bool nan_fired = false;
     for (int base = 0; base < L; base += OW_OCHUNK) {
         const int cn = min(OW_OCHUNK, L - base);
@@ -533,8 +590,8 @@ __global__ __launch_bounds__(64) void k_post_mpa(const OwConsts* __restrict__ K,
             double y[2] = {0.0, 0.0};
             for (int j = 0; j < osr; ++j) {
                 const size_t idx = (size_t)(base + n) * osr + j;
-                y[j] = pa_process(&st, C, settled, pre[idx * I + e] * 0.25, rail_sag, JA);     // x FIXED_CIRCUIT_DRIVE, engine.rs:544-546
-                if (pa_tap && valid) pa_tap[idx * I + e] = y[j];
+                y[j] = pa_process(&sc, C, W, role, settled, pre[idx * I + e] * 0.25, rail_sag);     // x FIXED_CIRCUIT_DRIVE, engine.rs:544-546
+                if (pa_tap && valid && role == 0) pa_tap[idx * I + e] = y[j];
             }
             double o;
             if (osr == 2) {
@@ -553,20 +610,20 @@ __global__ __launch_bounds__(64) void k_post_mpa(const OwConsts* __restrict__ K,
                 f = 0.0f;
                 sp.hpf.s1 = sp.hpf.s2 = sp.lpf.s1 = sp.lpf.s2 = 0.0;
                 sp.ts = 0.0;
-                pa_init_state(&st, settled, C);
-                pa_rails_reset(&st);
+                pa_init_state(&sc, W, settled, C);
+                pa_rails_reset(&sc);
                 nan_fired = true;
             }
-            tile[lane * (OW_OCHUNK + 1) + n] = f;
+            if (role == 0) tile[el * (OW_OCHUNK + 1) + n] = f;
         }
         __syncthreads();
-        for (int r = 0; r < 64; ++r) {
+        for (int r = 0; r < PA_EPW; ++r) {
             const int er = eb + r;
             if (er < e0 + ne && lane < cn) out[(size_t)er * Lout + base + lane] = tile[r * (OW_OCHUNK + 1) + lane];
         }
         __syncthreads();
     }
-    if (!valid) return;
+    if (!valid || role != 0) return;
     if (nan_fired) {
         for (int i = 0; i < 3; ++i) { da[i] = 0.0; db[i] = 0.0; }
         dd = 0.0;
@@ -582,7 +639,7 @@ __global__ __launch_bounds__(64) void k_post_mpa(const OwConsts* __restrict__ K,
     }
     smoother_store(ss, cs, I, e, CS_SM_SPK);
     smoother_store(sv, cs, I, e, CS_SM_VOL);
-    pa_store(&st, pa, I, e);
+    pa_store(&sc, W, pa, I, e);
 }
 
 }  // namespace owdev
