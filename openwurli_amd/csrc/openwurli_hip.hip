@@ -823,7 +823,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         }
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][3], s));
         if (sne > 0 && p->power_amp_kind == OW_POWER_AMP_MELANGE) {
-            owdev::k_post_mpa<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->dPa, p->d_pa_settled, p->d_cs, p->d_pa, p->d_args, p->d_eout, p->d_pre, p->d_out,
+            owdev::k_post_mpa<<<dim3((sne + PA_EPB - 1) / PA_EPB), dim3(PA_WPB * 64), 0, s>>>(p->dK, p->dPa, p->d_pa_settled, p->d_cs, p->d_pa, p->d_args, p->d_eout, p->d_pre, p->d_out,
                                                                           p->d_pa_tap, I, L, L, se0, sne);
         } else if (sne > 0) {
             if (p->hc.oversample)
@@ -1610,7 +1610,7 @@ int ow_debug_power_amp(double sample_rate, const double* in, size_t n_rows, size
             HIP_OK(hipMemcpyAsync(dPn.p, poke_node, sizeof(int) * n_rows, hipMemcpyHostToDevice, so.s));
             HIP_OK(hipMemcpyAsync(dPv.p, poke_val, sizeof(double) * n_rows, hipMemcpyHostToDevice, so.s));
         }
-        owdev::k_mpa_debug<<<dim3((unsigned)((n_rows + 31) / 32)), dim3(64), 0, so.s>>>(dC.as<OwPaConsts>(), dS.as<double>(), dIn.as<double>(), dOut.as<double>(),
+        owdev::k_mpa_debug<<<dim3((unsigned)((n_rows + PA_EPB - 1) / PA_EPB)), dim3(PA_WPB * 64), 0, so.s>>>(dC.as<OwPaConsts>(), dS.as<double>(), dIn.as<double>(), dOut.as<double>(),
                                                                           taps ? dT.as<double>() : nullptr, (long long)n, (int)n_rows, rail_sag,
                                                                           poke_at ? dPa.as<long long>() : nullptr, dPn.as<int>(), dPv.as<double>());
         HIP_OK(hipGetLastError());

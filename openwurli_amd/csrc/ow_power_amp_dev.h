@@ -88,8 +88,8 @@ __device__ inline PaBjt pa_bjt_evaluate(double vbe, double vbc, const OwPaConsts
 }
 
 // gen_power_amp.rs:8032-8145
-__device__ __noinline__ PaBjt pa_bjt_with_parasitics(double vbe_ext, double vbc_ext, const OwPaConsts::Dev* __restrict__ Dp) {
-    const OwPaConsts::Dev D = *Dp;
+__device__ inline PaBjt pa_bjt_with_parasitics(double vbe_ext, double vbc_ext, const OwPaConsts::Dev* __restrict__ Dp) {
+    const OwPaConsts::Dev& D = *Dp;
     double vbe_int = vbe_ext, vbc_int = vbc_ext;
     for (int it = 0; it < 15; ++it) {
         const PaBjt e = pa_bjt_evaluate(vbe_int, vbc_int, D);
@@ -141,74 +141,110 @@ OW_DEV double pa_pnjlim(double vnew, double vold, double vt, double vcrit) {   /
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Mapping.  32 engines per wavefront, a LANE PAIR per engine (lane el = role 0, lane el + 32 = role 1), one wavefront per workgroup.
-// Everything the solver indexes dynamically lives in LDS, engine-minor (row r of engine el at W[r * 32], W = base + el): the 16x16 Newton
-// Jacobian, the vectors of the Newton sweep, the node / port state and the vectors of process_sample -- 512 rows = 128 KB.  (The first
-// version kept the vectors in private arrays: 8.4 KB of scratch per lane, every access a trip to L2 / HBM, 6 ms per chain-rate sample.)
-// The two lanes of a pair run the same control flow on the same values and share the O(16^2) work: four of the eight transistors each
-// (device model + their Jacobian rows), every other row of an elimination step / matrix-vector product.  O(16) vector work is done by
-// both lanes redundantly (same values written twice).  Partial pivoting moves no data: logical row r of the Jacobian AND of its
-// right-hand side is physical row (perm >> 4r) & 15, perm a 64-bit register that both lanes keep.  PA_SYNC() orders the LDS traffic
-// where one lane reads what its partner wrote (single-wavefront workgroup: the barrier itself is free).
-// Every sum keeps the reference's operand order; the library is built without FMA contraction: the solver follows the CPU
+// Mapping.  EIGHT LANES PER ENGINE -- one per transistor -- and eight engines per wavefront (lane = role * 8 + engine slot); four
+// wavefronts per workgroup, two workgroups per CU (LDS), so every SIMD holds two wavefronts.  The lanes of an engine sit in ONE
+// wavefront: they run in lock step, "synchronisation" between them is a compiler fence, not a barrier, and an engine whose Newton
+// sweep runs long (hard clipping: 60+ iterations) only holds up the seven other engines of its wavefront.
+//   lane `role` owns transistor `role`: its two controlling voltages, the device model (the expensive part: the exponentials and the
+//   inner 2x2 parasitic solve), and ROWS 2 role, 2 role + 1 of the 16x16 Newton Jacobian -- in REGISTERS, with their right-hand sides;
+//   Gaussian elimination with partial pivoting, column by column: every lane posts |J[row][col]| of its un-pivoted rows to LDS, all
+//   eight pick the pivot (the reference's scan order, through the 16-nibble row permutation every lane keeps), the owner posts the
+//   pivot row, every lane eliminates its own rows.  Back substitution: the owner of row i computes x_i (ascending-j sum, as the
+//   reference) and posts it.  No Jacobian in LDS at all; the K rows a lane needs come from a 2 KB LDS copy of K.
+//   Matrix-vector products (S rhs, S_NI i_nl, K i_trial) are split by rows over the eight lanes; O(16) vector passes (step limiting,
+//   convergence test, finiteness) are done by all eight on the same values.
+// LDS per engine: 217 doubles (vectors of the sweep + node / port state), engine-minor with a row stride of 9 doubles inside the
+// wavefront's slab (8 engines + 1 pad: the role-split accesses of consecutive rows fall in different banks).
+// (History: private arrays -- 8.4 KB scratch per lane -- 6.2 s per 512-sample block at 16 384 engines; lane pair per engine with the
+// Jacobian in LDS, one wavefront per CU: 3.3 s.)
+// Every sum keeps the reference's operand order and the library is built without FMA contraction: the solver follows the CPU
 // restatement bit for bit (pnjlim's logarithm excepted), which keeps the divergence guard firing on the same sample on both sides.
-#define PA_EPW 32
+#define PA_EPW 8              // engines per wavefront
+#define PA_WPB 4              // wavefronts per workgroup
+#define PA_EPB (PA_EPW * PA_WPB)
+#define PA_LS 9               // LDS row stride in doubles
 enum {
-    PL_J = 0,         // [16][16] Jacobian
-    PL_B = 256,       // [16] right-hand side, by PHYSICAL row
-    PL_X = 272,       // [16] solution of the linear system (delta)
-    PL_VD = 288, PL_F = 304, PL_INL = 320, PL_P = 336,
-    PL_T0 = 352,      // dv_trial / dv
-    PL_T1 = 368,      // v_lim / alpha
-    PL_T2 = 384,      // i_trial
-    PL_V = 400,       // [20] v_prev
-    PL_IP = 420, PL_IPP = 436,
-    PL_RHS = 452, PL_VPRED = 472, PL_VNEW = 492,
-    PL_ROWS = 512
+    // vectors of one Newton iteration
+    PL_CAND = 0,              // [16] |J[row][col]| of the rows not yet used as pivots, by physical row
+    PL_PROW = 16,             // [17] the pivot row (entries col..15) and its right-hand side at [16]
+    PL_X = 33,                // [16] solution of the linear system
+    PL_VD = 49, PL_T0 = 65 /* dv_trial / dv */, PL_T1 = 81 /* v_lim / alpha */, PL_T2 = 97 /* i_trial */,
+    PL_NT_END = 113,
+    PL_RHS = 0,               // [20] lives before the sweep only
+    PL_VNEW = 49,             // [20] lives after the sweep only
+    // carried through the sample / between samples
+    PL_INL = 113, PL_P = 129, PL_VPRED = 145, PL_V = 165, PL_IP = 185, PL_IPP = 201,
+    PL_ROWS = 217
 };
-#define PL(r) W[(r) * PA_EPW]
-#define PA_JE(r, c) W[(PL_J + (r) * PA_M + (c)) * PA_EPW]
-#define PA_SYNC() __syncthreads()
+#define PL(r) W[(r) * PA_LS]
+#define PA_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define PA_PERM(p, r) ((int)(((p) >> (4 * (r))) & 15ull))
+#define PA_LDS_DOUBLES (PA_WPB * PL_ROWS * PA_LS)
 
-struct PaScal {      // per-engine scalars, identical in both lanes of the pair
+// The workgroup's LDS copy of the tables its lanes index PER LANE (row = f(role)): from the constant block those would be vector loads
+// the compiler hoists out of the sample loop (loop-invariant, ~400 registers: spills); LDS reads stay where they are used.
+struct PaTab {
+    double k[PA_M * PA_M];
+    double s[PA_N * PA_N];
+    double s_ni[PA_N * PA_M];
+    OwPaConsts::Dev dev[8];
+};
+__device__ __forceinline__ void pa_stage_tables(PaTab* __restrict__ T, const OwPaConsts* __restrict__ C) {
+    for (int i = threadIdx.x; i < PA_M * PA_M; i += blockDim.x) T->k[i] = (&C->k[0][0])[i];
+    for (int i = threadIdx.x; i < PA_N * PA_N; i += blockDim.x) T->s[i] = (&C->s[0][0])[i];
+    for (int i = threadIdx.x; i < PA_N * PA_M; i += blockDim.x) T->s_ni[i] = (&C->s_ni[0][0])[i];
+    double* d = reinterpret_cast<double*>(&T->dev[0]);
+    const double* g = reinterpret_cast<const double*>(&C->dev[0]);
+    for (int i = threadIdx.x; i < (int)(8 * sizeof(OwPaConsts::Dev) / sizeof(double)); i += blockDim.x) d[i] = g[i];
+    __syncthreads();
+}
+
+struct PaScal {      // per-engine scalars, identical in the eight lanes of the engine
     double dcx, dcy, peak, last_good, rail_p, rail_n, iavg_p, iavg_n;
     unsigned long long clamp_cnt, nrmax_cnt, nan_cnt, guard_cnt;
     uint32_t last_nr;
 };
 
 // One Newton solve (main sweep with K, or the BE retry with K_be): gen_power_amp.rs:8956-10680 / 10745-12245.  p in PL_P, i_nl in PL_INL.
+// KM: the 16x16 K of this sweep (the LDS copy for the main sweep).
 template <bool BE>
-__device__ __noinline__ uint32_t pa_newton(const OwPaConsts* __restrict__ C, double* __restrict__ W, int role) {
-    const double (*__restrict__ kk)[PA_M] = BE ? C->k_be : C->k;
+__device__ __forceinline__ uint32_t pa_newton_body(double* __restrict__ W, const double* KM, const OwPaConsts::Dev* D, int role) {
+    const int r0 = 2 * role, r1 = 2 * role + 1;
+    const double vt = D->vt, vcrit = D->vcrit;
     for (int iter = 0; iter < 70; ++iter) {
-        for (int d = role; d < 8; d += 2) {                       // four transistors per lane
-            double vd2[2];
-            for (int q = 0; q < 2; ++q) {
-                const int r = 2 * d + q;
-                double acc = PL(PL_P + r);
-                for (int j = 0; j < PA_M; ++j) acc = acc + kk[r][j] * PL(PL_INL + j);
-                vd2[q] = acc;
-                PL(PL_VD + r) = acc;
-            }
-            const PaBjt e = pa_bjt_with_parasitics(vd2[0], vd2[1], &C->dev[d]);
-            const double f0 = PL(PL_INL + 2 * d) - e.ic, f1 = PL(PL_INL + 2 * d + 1) - e.ib;
-            PL(PL_F + 2 * d) = f0; PL(PL_F + 2 * d + 1) = f1;
-            PL(PL_B + 2 * d) = f0; PL(PL_B + 2 * d + 1) = f1;
-            for (int j = 0; j < PA_M; ++j) {                      // J[i][j] = delta_ij - jdev[i][2d] K[2d][j] - jdev[i][2d+1] K[2d+1][j]
-                const double k0 = kk[2 * d][j], k1 = kk[2 * d + 1][j];
-                PA_JE(2 * d, j) = (j == 2 * d ? 1.0 : 0.0) - e.j0 * k0 - e.j1 * k1;
-                PA_JE(2 * d + 1, j) = (j == 2 * d + 1 ? 1.0 : 0.0) - e.j2 * k0 - e.j3 * k1;
-            }
+        double vd0 = PL(PL_P + r0), vd1 = PL(PL_P + r1);
+#pragma unroll
+        for (int j = 0; j < PA_M; ++j) {
+            const double inl = PL(PL_INL + j);
+            vd0 = vd0 + KM[r0 * PA_M + j] * inl;
+            vd1 = vd1 + KM[r1 * PA_M + j] * inl;
         }
-        PA_SYNC();
+        const PaBjt e = pa_bjt_with_parasitics(vd0, vd1, D);
+        const double f0 = PL(PL_INL + r0) - e.ic, f1 = PL(PL_INL + r1) - e.ib;
+        PL(PL_VD + r0) = vd0; PL(PL_VD + r1) = vd1;
+        double A[PA_M], B[PA_M], bA = f0, bB = f1;                 // my two rows: J[i][j] = delta_ij - jdev[i][2d] K[2d][j] - jdev[i][2d+1] K[2d+1][j]
+#pragma unroll
+        for (int j = 0; j < PA_M; ++j) {
+            const double k0 = KM[r0 * PA_M + j], k1 = KM[r1 * PA_M + j];
+            A[j] = (j == r0 ? 1.0 : 0.0) - e.j0 * k0 - e.j1 * k1;
+            B[j] = (j == r1 ? 1.0 : 0.0) - e.j2 * k0 - e.j3 * k1;
+        }
+        // Gaussian elimination, one ROLLED loop over the columns (the unrolled form is 7000 instructions: with four wavefronts at
+        // different places in it the 64 KB instruction cache two CUs share thrashes, 5x slower).  The register rows ROTATE: after
+        // column c a row that is still being eliminated holds J[row][c+1 + j] at index j, so every column works on index 0 and the
+        // shift rides on the update itself (A[j-1] = A[j] - f prow[j]).  A row chosen as pivot at column c is frozen from then on:
+        // it keeps U[c][c + j] at index j for the back substitution.  Entries past the live width are stale and never read.
         unsigned long long perm = 0xFEDCBA9876543210ull;
-        bool singular = false;
+        bool singular = false, usedA = false, usedB = false;
+#pragma unroll 1
         for (int col = 0; col < PA_M; ++col) {
+            PL(PL_CAND + r0) = fabs(A[0]);                          // rows already used as pivots are never looked at again (perm)
+            PL(PL_CAND + r1) = fabs(B[0]);
+            PA_SYNC();
             int max_row = col;
-            double max_val = fabs(PA_JE(PA_PERM(perm, col), col));
+            double max_val = PL(PL_CAND + PA_PERM(perm, col));
             for (int row = col + 1; row < PA_M; ++row) {
-                const double v = fabs(PA_JE(PA_PERM(perm, row), col));
+                const double v = PL(PL_CAND + PA_PERM(perm, row));
                 if (v > max_val) { max_val = v; max_row = row; }
             }
             if (max_val < 1e-15) { singular = true; break; }
@@ -217,47 +253,77 @@ __device__ __noinline__ uint32_t pa_newton(const OwPaConsts* __restrict__ C, dou
                 perm = (perm & ~(15ull << (4 * col)) & ~(15ull << (4 * max_row))) | (pm << (4 * col)) | (pc << (4 * max_row));
             }
             const int pr = PA_PERM(perm, col);
-            const double pivot = PA_JE(pr, col);
-            const double bcol = PL(PL_B + pr);
-            for (int row = col + 1 + role; row < PA_M; row += 2) {     // the pair shares the rows below the pivot
-                const int rr = PA_PERM(perm, row);
-                const double factor = ow_div(PA_JE(rr, col), pivot);
-                for (int j = col + 1; j < PA_M; ++j) PA_JE(rr, j) -= factor * PA_JE(pr, j);
-                PL(PL_B + rr) -= factor * bcol;
+            if (pr == r0) {
+#pragma unroll
+                for (int j = 0; j < PA_M; ++j) PL(PL_PROW + j) = A[j];
+                PL(PL_PROW + 16) = bA;
+                usedA = true;
+            }
+            if (pr == r1) {
+#pragma unroll
+                for (int j = 0; j < PA_M; ++j) PL(PL_PROW + j) = B[j];
+                PL(PL_PROW + 16) = bB;
+                usedB = true;
+            }
+            PA_SYNC();
+            const double pivot = PL(PL_PROW), bcol = PL(PL_PROW + 16);
+            double prow[PA_M];
+#pragma unroll
+            for (int j = 1; j < PA_M; ++j) prow[j] = PL(PL_PROW + j);
+            if (!usedA) {
+                const double factor = ow_div(A[0], pivot);
+#pragma unroll
+                for (int j = 1; j < PA_M; ++j) A[j - 1] = A[j] - factor * prow[j];
+                bA -= factor * bcol;
+            }
+            if (!usedB) {
+                const double factor = ow_div(B[0], pivot);
+#pragma unroll
+                for (int j = 1; j < PA_M; ++j) B[j - 1] = B[j] - factor * prow[j];
+                bB -= factor * bcol;
             }
             PA_SYNC();
         }
-        if (!singular) {
-            for (int i = PA_M - 1; i >= 0; --i) {                 // both lanes: same values, each reads back what it wrote itself
-                const int ri = PA_PERM(perm, i);
-                double sum = PL(PL_B + ri);
-                for (int j = i + 1; j < PA_M; ++j) sum -= PA_JE(ri, j) * PL(PL_X + j);
-                const double aii = PA_JE(ri, i);
-                if (fabs(aii) < 1e-15) { singular = true; break; }
-                PL(PL_X + i) = ow_div(sum, aii);
-            }
-        }
-        PA_SYNC();
         if (singular) {
-            for (int i = 0; i < PA_M; ++i) {
-                const double inl = PL(PL_INL + i);
-                const double cl = BE ? 0.01 : fmax(fabs(inl) * 0.1, 0.01);
-                PL(PL_INL + i) = inl - clampd(PL(PL_F + i) * 0.5, -cl, cl);
-            }
+            const double i0 = PL(PL_INL + r0), i1 = PL(PL_INL + r1);
+            const double c0 = BE ? 0.01 : fmax(fabs(i0) * 0.1, 0.01), c1 = BE ? 0.01 : fmax(fabs(i1) * 0.1, 0.01);
+            PA_SYNC();
+            PL(PL_INL + r0) = i0 - clampd(f0 * 0.5, -c0, c0);
+            PL(PL_INL + r1) = i1 - clampd(f1 * 0.5, -c1, c1);
             PA_SYNC();
             continue;
         }
+        // back substitution: x_i = (b_i - sum_{j>i} U_ij x_j) / U_ii, j ascending, by the owner of logical row i (its frozen register
+        // row holds U_ij at index j - i); U_ii is the pivot of column i, so it passed the 1e-15 test above (the reference's second
+        // test on it can never fire)
+#pragma unroll
+        for (int i = PA_M - 1; i >= 0; --i) {
+            const int ri = PA_PERM(perm, i);
+            const bool slot = (ri & 1) != 0;
+            double sum = slot ? bB : bA;
+#pragma unroll
+            for (int j = i + 1; j < PA_M; ++j) sum -= (slot ? B[j - i] : A[j - i]) * PL(PL_X + j);
+            const double aii = slot ? B[0] : A[0];
+            if ((ri >> 1) == role) PL(PL_X + i) = ow_div(sum, aii);
+            PA_SYNC();
+        }
         bool converged = false;
+        const double x0 = PL(PL_X + r0), x1 = PL(PL_X + r1);
         if (!BE) {
-            for (int i = 0; i < PA_M; ++i) PL(PL_T2 + i) = PL(PL_INL + i) - PL(PL_X + i);       // i_trial (both lanes, same values)
-            for (int i = role; i < PA_M; i += 2) {                                            // v_trial rows shared
-                double acc = PL(PL_P + i);
-                for (int j = 0; j < PA_M; ++j) acc = acc + kk[i][j] * PL(PL_T2 + j);
-                const double vdi = PL(PL_VD + i);
-                const double dvt = acc - vdi;
-                PL(PL_T0 + i) = dvt;
-                PL(PL_T1 + i) = fabs(dvt) > 1e-4 ? pa_pnjlim(acc, vdi, C->dev[i >> 1].vt, C->dev[i >> 1].vcrit) : acc;
+            PL(PL_T2 + r0) = PL(PL_INL + r0) - x0;                                              // i_trial
+            PL(PL_T2 + r1) = PL(PL_INL + r1) - x1;
+            PA_SYNC();
+            double a0 = PL(PL_P + r0), a1 = PL(PL_P + r1);
+#pragma unroll
+            for (int j = 0; j < PA_M; ++j) {
+                const double it = PL(PL_T2 + j);
+                a0 = a0 + KM[r0 * PA_M + j] * it;
+                a1 = a1 + KM[r1 * PA_M + j] * it;
             }
+            const double dvt0 = a0 - vd0, dvt1 = a1 - vd1;
+            PL(PL_T0 + r0) = dvt0; PL(PL_T0 + r1) = dvt1;
+            PL(PL_T1 + r0) = fabs(dvt0) > 1e-4 ? pa_pnjlim(a0, vd0, vt, vcrit) : a0;
+            PL(PL_T1 + r1) = fabs(dvt1) > 1e-4 ? pa_pnjlim(a1, vd1, vt, vcrit) : a1;
             PA_SYNC();
             bool any_limited = false;
             double ga = 1.0;
@@ -272,7 +338,6 @@ __device__ __noinline__ uint32_t pa_newton(const OwPaConsts* __restrict__ C, dou
             double max_dv = fabs(PL(PL_T0) * ga);
             for (int i = 1; i < PA_M; ++i) max_dv = fmax(max_dv, fabs(PL(PL_T0 + i) * ga));
             if (max_dv > 3.5) { ga *= fmax(ow_div(3.5, max_dv), 0.1); any_limited = true; }
-            for (int i = 0; i < PA_M; ++i) PL(PL_INL + i) = PL(PL_INL + i) - ga * PL(PL_X + i);
             if (!any_limited) {
                 bool conv = true;
                 for (int i = 0; i < PA_M; ++i) {
@@ -282,222 +347,271 @@ __device__ __noinline__ uint32_t pa_newton(const OwPaConsts* __restrict__ C, dou
                 }
                 converged = conv;
             }
+            const double n0 = PL(PL_INL + r0) - ga * x0, n1 = PL(PL_INL + r1) - ga * x1;
+            PA_SYNC();
+            PL(PL_INL + r0) = n0; PL(PL_INL + r1) = n1;
         } else {
-            for (int i = role; i < PA_M; i += 2) {                                            // dv rows shared
-                double acc = kk[i][0] * PL(PL_X);
-                for (int j = 1; j < PA_M; ++j) acc = acc + kk[i][j] * PL(PL_X + j);
-                PL(PL_T0 + i) = -acc;
+            double a0 = KM[r0 * PA_M] * PL(PL_X), a1 = KM[r1 * PA_M] * PL(PL_X);
+#pragma unroll
+            for (int j = 1; j < PA_M; ++j) {
+                const double xj = PL(PL_X + j);
+                a0 = a0 + KM[r0 * PA_M + j] * xj;
+                a1 = a1 + KM[r1 * PA_M + j] * xj;
             }
+            const double dv0 = -a0, dv1 = -a1;
+            double al0 = 1.0, al1 = 1.0;
+            bool lim = false;
+            if (fabs(dv0) > 1e-4) {
+                const double vl = pa_pnjlim(vd0 + dv0, vd0, vt, vcrit);
+                const double ratio = fmax(ow_div(vl - vd0, dv0), 0.01);
+                if (ratio < al0) { al0 = ratio; if (ratio < 1.0) lim = true; }
+            }
+            if (fabs(dv1) > 1e-4) {
+                const double vl = pa_pnjlim(vd1 + dv1, vd1, vt, vcrit);
+                const double ratio = fmax(ow_div(vl - vd1, dv1), 0.01);
+                if (ratio < al1) { al1 = ratio; if (ratio < 1.0) lim = true; }
+            }
+            const double am = fmin(al0, al1);                                                    // one step length per transistor
+            PL(PL_T0 + r0) = dv0; PL(PL_T0 + r1) = dv1;
+            PL(PL_T1 + r0) = am; PL(PL_T1 + r1) = am;
+            PL(PL_T2 + r0) = lim ? 1.0 : 0.0;
             PA_SYNC();
             bool any_limited = false;
-            for (int i = 0; i < PA_M; ++i) {
-                const double dvi = PL(PL_T0 + i), vdi = PL(PL_VD + i);
-                double al = 1.0;
-                if (fabs(dvi) > 1e-4) {
-                    const double vl = pa_pnjlim(vdi + dvi, vdi, C->dev[i >> 1].vt, C->dev[i >> 1].vcrit);
-                    const double ratio = fmax(ow_div(vl - vdi, dvi), 0.01);
-                    if (ratio < al) { al = ratio; if (ratio < 1.0) any_limited = true; }
-                }
-                PL(PL_T1 + i) = al;
-            }
-            for (int d = 0; d < 8; ++d) { const double m = fmin(PL(PL_T1 + 2 * d), PL(PL_T1 + 2 * d + 1)); PL(PL_T1 + 2 * d) = m; PL(PL_T1 + 2 * d + 1) = m; }
+            for (int d = 0; d < 8; ++d) any_limited = any_limited || PL(PL_T2 + 2 * d) != 0.0;
             double max_dv = fabs(PL(PL_T0) * PL(PL_T1));
             for (int i = 1; i < PA_M; ++i) max_dv = fmax(max_dv, fabs(PL(PL_T0 + i) * PL(PL_T1 + i)));
-            if (max_dv > 3.5) {
-                const double factor = fmax(ow_div(3.5, max_dv), 0.1);
-                for (int i = 0; i < PA_M; ++i) PL(PL_T1 + i) = PL(PL_T1 + i) * factor;
-            }
-            for (int i = 0; i < PA_M; ++i) PL(PL_INL + i) = PL(PL_INL + i) - PL(PL_T1 + i) * PL(PL_X + i);
+            double fac = 1.0;
+            const bool scale = max_dv > 3.5;
+            if (scale) fac = fmax(ow_div(3.5, max_dv), 0.1);
             if (!any_limited) {
                 bool conv = true;
                 for (int i = 0; i < PA_M; ++i) {
-                    const double stp = PL(PL_T0 + i) * PL(PL_T1 + i), vdi = PL(PL_VD + i);
+                    const double al = scale ? PL(PL_T1 + i) * fac : PL(PL_T1 + i);
+                    const double stp = PL(PL_T0 + i) * al, vdi = PL(PL_VD + i);
                     const double thr = 1e-3 * fmax(fabs(vdi), fabs(vdi + stp)) + 1e-6;
                     if (fabs(stp) > thr) conv = false;
                 }
                 converged = conv;
             }
+            const double amf = scale ? am * fac : am;
+            const double n0 = PL(PL_INL + r0) - amf * x0, n1 = PL(PL_INL + r1) - amf * x1;
+            PA_SYNC();
+            PL(PL_INL + r0) = n0; PL(PL_INL + r1) = n1;
         }
         PA_SYNC();
         if (converged) return (uint32_t)iter;
     }
     return 70u;
 }
+// The rare paths.  Inlined naively, their table loads are loop-invariant, get hoisted out of the sample loop and sit in hundreds of
+// registers for nothing; a real function for the backward-Euler retry (it contains a whole Newton sweep) would set the register
+// count of every kernel that can call it.  So: the retry is inlined behind opaque table addresses, the two small resets are real
+// functions working on the LDS state and returning scalars by value.
+// (pa_opaque: the address comes out of an empty asm, so the loads behind it cannot be speculated out of the rare branch they are in)
+template <typename T> __device__ __forceinline__ T* pa_opaque(T* p) { asm volatile("" : "+s"(p)); return p; }
+__device__ __forceinline__ uint32_t pa_be_retry(const OwPaConsts* __restrict__ C_in, double* __restrict__ W, int role, double input) {
+    const OwPaConsts* C = pa_opaque(C_in);
+    const double* rhs_be = pa_opaque(&PA_RHS_CONST_BE[0]);
+    const double* n_i = pa_opaque(&PA_N_I[0][0]);
+    const double* n_v = pa_opaque(&PA_N_V[0][0]);
+    for (int i = role; i < PA_N; i += 8) {
+        double sum = rhs_be[i];
+        for (int j = 0; j < PA_N; ++j) sum += C->a_neg_be[i][j] * PL(PL_V + j);
+        for (int j = 0; j < PA_M; ++j) sum += n_i[i * PA_M + j] * PL(PL_IP + j);
+        if (i == 0) sum += input * (1.0 / PA_INPUT_RESISTANCE);
+        PL(PL_RHS + i) = sum;
+    }
+    PA_SYNC();
+    for (int i = role; i < PA_N; i += 8) {
+        double sum = 0.0;
+        for (int j = 0; j < PA_N; ++j) sum += C->s_be[i][j] * PL(PL_RHS + j);
+        PL(PL_VPRED + i) = sum;
+    }
+    PA_SYNC();
+    for (int i = role; i < PA_M; i += 8) {
+        double sum = 0.0;
+        for (int j = 0; j < PA_N; ++j) sum += n_v[i * PA_N + j] * PL(PL_VPRED + j);
+        PL(PL_P + i) = sum;
+        PL(PL_INL + i) = 2.0 * PL(PL_IP + i) - PL(PL_IPP + i);
+    }
+    PA_SYNC();
+    const uint32_t nr = pa_newton_body<true>(W, &C->k_be[0][0], &C->dev[role], role);
+    for (int i = role; i < PA_N; i += 8) {
+        double x = PL(PL_VPRED + i);
+        for (int j = 0; j < PA_M; ++j) x += C->s_ni_be[i][j] * PL(PL_INL + j);
+        PL(PL_VNEW + i) = x;
+    }
+    PA_SYNC();
+    return nr;
+}
+__device__ __noinline__ void pa_state_to_dc(double* __restrict__ W, int role) {     // the NaN reset of process_sample
+    PA_SYNC();
+    for (int i = role; i < PA_N; i += 8) PL(PL_V + i) = PA_DC_OP[i];           // dc_operating_point == DC_OP (never re-set by the adapter)
+    for (int i = role; i < PA_M; i += 8) { PL(PL_IP + i) = PA_DC_NL_I[i]; PL(PL_IPP + i) = PA_DC_NL_I[i]; }
+    PA_SYNC();
+}
+struct PaSettledScal { double dcx, dcy, peak; unsigned long long clamp_cnt, nrmax_cnt, nan_cnt; };
+__device__ __noinline__ PaSettledScal pa_state_from_settled(double* __restrict__ W, int role, const double* __restrict__ settled, int rate_is_codegen) {
+    PA_SYNC();
+    for (int i = role; i < PA_N; i += 8) PL(PL_V + i) = settled[PAS_V + i];
+    for (int i = role; i < PA_M; i += 8) { PL(PL_IP + i) = settled[PAS_IP + i]; PL(PL_IPP + i) = settled[PAS_IPP + i]; }
+    PaSettledScal r;
+    r.dcx = settled[PAS_DCX]; r.dcy = settled[PAS_DCY]; r.peak = settled[PAS_PEAK];
+    r.clamp_cnt = dbits(settled[PAS_CLAMP]); r.nrmax_cnt = dbits(settled[PAS_NRMAX]); r.nan_cnt = dbits(settled[PAS_NAN]);
+    if (!rate_is_codegen) { r.dcx = 0.0; r.dcy = 0.0; }
+    PA_SYNC();
+    return r;
+}
 
 // gen_power_amp.rs:8838-12337.  off_p / off_n: the runtime rail offsets (v_rail_pos_offset / v_rail_neg_offset of the state).
-__device__ __noinline__ double pa_process_sample(PaScal* __restrict__ sc, const OwPaConsts* __restrict__ C, double* __restrict__ W, int role, double input_in,
-                                                 double off_p, double off_n) {
+// T: the LDS tables.  Rows of the matrix-vector products and of the state vectors are dealt to the lanes as i = role, role + 8, ...
+__device__ __forceinline__ double pa_process_sample(PaScal& sc, const OwPaConsts* __restrict__ C, double* __restrict__ W, const PaTab* T, int role,
+                                                    double input_in, double off_p, double off_n) {
     const double input = isfinite(input_in) ? clampd(input_in, -100.0, 100.0) : 0.0;
-    for (int i = 0; i < PA_N; ++i) PL(PL_V + i) = PL(PL_V + i) + 1e-25 - 1e-25;
-    for (int i = 0; i < PA_M; ++i) PL(PL_IP + i) = PL(PL_IP + i) + 1e-25 - 1e-25;
-    for (int i = 0; i < PA_N; ++i) PL(PL_RHS + i) = PA_RHS_CONST[i];
-    for (int q = 0; q < PA_RHS_NNZ; ++q) {
+    for (int i = role; i < PA_N; i += 8) PL(PL_V + i) = PL(PL_V + i) + 1e-25 - 1e-25;
+    for (int i = role; i < PA_M; i += 8) PL(PL_IP + i) = PL(PL_IP + i) + 1e-25 - 1e-25;
+    for (int i = role; i < PA_N; i += 8) PL(PL_RHS + i) = PA_RHS_CONST[i];
+    PA_SYNC();
+    for (int q = 0; q < PA_RHS_NNZ; ++q) {                        // all eight lanes, same values
         const int i = (int)PA_RHS_NZ_ROW[q], j = (int)PA_RHS_NZ_COL[q];
         PL(PL_RHS + i) = PL(PL_RHS + i) + C->a_neg[i][j] * PL(PL_V + j);
     }
     PL(PL_RHS + 0) = PL(PL_RHS + 0) + input * (1.0 / PA_INPUT_RESISTANCE);
     PL(PL_RHS + 18) = PL(PL_RHS + 18) + off_p;
     PL(PL_RHS + 19) = PL(PL_RHS + 19) + off_n;
-    for (int i = role; i < PA_N; i += 2) {                        // v_pred = S rhs, rows shared
+    PA_SYNC();
+    for (int i = role; i < PA_N; i += 8) {                        // v_pred = S rhs
         double sum = 0.0;
-        for (int j = 0; j < PA_N; ++j) sum += C->s[i][j] * PL(PL_RHS + j);
+        for (int j = 0; j < PA_N; ++j) sum += T->s[i * PA_N + j] * PL(PL_RHS + j);
         PL(PL_VPRED + i) = sum;
     }
     PA_SYNC();
-    for (int i = 0; i < PA_M; ++i) {
+    for (int i = role; i < PA_M; i += 8) {
         const int na = (int)PA_P_NODE_A[i], nb = (int)PA_P_NODE_B[i];
         PL(PL_P + i) = PA_N_V[i][na] * PL(PL_VPRED + na) + PA_N_V[i][nb] * PL(PL_VPRED + nb);
         PL(PL_INL + i) = 2.0 * PL(PL_IP + i) - PL(PL_IPP + i);
     }
     PA_SYNC();
-    sc->last_nr = pa_newton<false>(C, W, role);
-    for (int i = role; i < PA_N; i += 2) {
+    sc.last_nr = pa_newton_body<false>(W, T->k, &T->dev[role], role);
+    for (int i = role; i < PA_N; i += 8) {
         double x = PL(PL_VPRED + i);
-        for (int j = 0; j < PA_M; ++j) x += C->s_ni[i][j] * PL(PL_INL + j);
+        for (int j = 0; j < PA_M; ++j) x += T->s_ni[i * PA_M + j] * PL(PL_INL + j);
         PL(PL_VNEW + i) = x;
     }
     PA_SYNC();
-    if (__builtin_expect(!(sc->last_nr < 70u), 0)) {              // backward-Euler-matrix retry
-        sc->nrmax_cnt += 1ull;
-        for (int i = role; i < PA_N; i += 2) {
-            double sum = PA_RHS_CONST_BE[i];
-            for (int j = 0; j < PA_N; ++j) sum += C->a_neg_be[i][j] * PL(PL_V + j);
-            for (int j = 0; j < PA_M; ++j) sum += PA_N_I[i][j] * PL(PL_IP + j);
-            PL(PL_RHS + i) = sum;
-        }
-        PA_SYNC();
-        PL(PL_RHS + 0) = PL(PL_RHS + 0) + input * (1.0 / PA_INPUT_RESISTANCE) * (role == 0 ? 1.0 : 0.0);   // one lane adds the input term
-        PA_SYNC();
-        for (int i = role; i < PA_N; i += 2) {
-            double sum = 0.0;
-            for (int j = 0; j < PA_N; ++j) sum += C->s_be[i][j] * PL(PL_RHS + j);
-            PL(PL_VPRED + i) = sum;
-        }
-        PA_SYNC();
-        for (int i = 0; i < PA_M; ++i) {
-            double sum = 0.0;
-            for (int j = 0; j < PA_N; ++j) sum += PA_N_V[i][j] * PL(PL_VPRED + j);
-            PL(PL_P + i) = sum;
-            PL(PL_INL + i) = 2.0 * PL(PL_IP + i) - PL(PL_IPP + i);
-        }
-        PA_SYNC();
-        sc->last_nr = pa_newton<true>(C, W, role);
-        for (int i = role; i < PA_N; i += 2) {
-            double x = PL(PL_VPRED + i);
-            for (int j = 0; j < PA_M; ++j) x += C->s_ni_be[i][j] * PL(PL_INL + j);
-            PL(PL_VNEW + i) = x;
-        }
-        PA_SYNC();
+    if (__builtin_expect(!(sc.last_nr < 70u), 0)) {               // backward-Euler-matrix retry
+        sc.nrmax_cnt += 1ull;
+        sc.last_nr = pa_be_retry(C, W, role, input);
     }
     bool finite = true;
     for (int i = 0; i < PA_N; ++i) finite = finite && isfinite(PL(PL_VNEW + i));
-    PA_SYNC();
-    if (__builtin_expect(!finite, 0)) {
-        for (int i = 0; i < PA_N; ++i) PL(PL_V + i) = PA_DC_OP[i];            // dc_operating_point == DC_OP (never re-set by the adapter)
-        for (int i = 0; i < PA_M; ++i) { PL(PL_IP + i) = PA_DC_NL_I[i]; PL(PL_IPP + i) = PA_DC_NL_I[i]; }
-        sc->dcx = 0.0; sc->dcy = 0.0;
-        sc->nan_cnt += 1ull;
-        PA_SYNC();
-        return PA_DC_BLOCK_X0;
-    }
-    for (int i = 0; i < PA_N; ++i) PL(PL_V + i) = PL(PL_VNEW + i);
-    for (int i = 0; i < PA_M; ++i) { PL(PL_IPP + i) = PL(PL_IP + i); PL(PL_IP + i) = PL(PL_INL + i); }
     const double raw_out = PL(PL_VNEW + 8);
     PA_SYNC();
-    const double dc_blocked = raw_out - sc->dcx + C->dc_block_r * sc->dcy;
-    sc->dcx = raw_out;
-    sc->dcy = dc_blocked;
+    if (__builtin_expect(!finite, 0)) {
+        pa_state_to_dc(W, role);
+        sc.dcx = 0.0; sc.dcy = 0.0;
+        sc.nan_cnt += 1ull;
+        return PA_DC_BLOCK_X0;
+    }
+    for (int i = role; i < PA_N; i += 8) PL(PL_V + i) = PL(PL_VNEW + i);
+    for (int i = role; i < PA_M; i += 8) { PL(PL_IPP + i) = PL(PL_IP + i); PL(PL_IP + i) = PL(PL_INL + i); }
+    PA_SYNC();
+    const double dc_blocked = raw_out - sc.dcx + C->dc_block_r * sc.dcy;
+    sc.dcx = raw_out;
+    sc.dcy = dc_blocked;
     const double scaled = dc_blocked * 1.0;
     const double abs_out = fabs(scaled);
-    if (abs_out > sc->peak) sc->peak = abs_out;
-    if (abs_out > 3e1) sc->clamp_cnt += 1ull;
+    if (abs_out > sc.peak) sc.peak = abs_out;
+    if (abs_out > 3e1) sc.clamp_cnt += 1ull;
     return clampd(scaled, -3e1, 3e1);
 }
 
 // state <- settled blob (+ the per-state part of set_sample_rate when the chain does not run at the codegen rate): init_state,
-// power_amp.rs:294-302.  Both lanes write the same values.
-__device__ inline void pa_init_state(PaScal* __restrict__ sc, double* __restrict__ W, const double* __restrict__ settled, const OwPaConsts* __restrict__ C) {
-    for (int i = 0; i < PA_N; ++i) PL(PL_V + i) = settled[PAS_V + i];
-    for (int i = 0; i < PA_M; ++i) { PL(PL_IP + i) = settled[PAS_IP + i]; PL(PL_IPP + i) = settled[PAS_IPP + i]; }
-    sc->dcx = settled[PAS_DCX]; sc->dcy = settled[PAS_DCY]; sc->peak = settled[PAS_PEAK];
-    sc->clamp_cnt = dbits(settled[PAS_CLAMP]); sc->nrmax_cnt = dbits(settled[PAS_NRMAX]); sc->nan_cnt = dbits(settled[PAS_NAN]);
-    if (!C->rate_is_codegen) { sc->dcx = 0.0; sc->dcy = 0.0; }
-    sc->last_nr = 0u;
-    PA_SYNC();
+// power_amp.rs:294-302
+__device__ __forceinline__ void pa_init_state(PaScal& sc, double* __restrict__ W, int role, const double* __restrict__ settled, const OwPaConsts* __restrict__ C) {
+    const PaSettledScal r = pa_state_from_settled(W, role, settled, C->rate_is_codegen);
+    sc.dcx = r.dcx; sc.dcy = r.dcy; sc.peak = r.peak;
+    sc.clamp_cnt = r.clamp_cnt; sc.nrmax_cnt = r.nrmax_cnt; sc.nan_cnt = r.nan_cnt;
+    sc.last_nr = 0u;
 }
-__device__ inline void pa_rails_reset(PaScal* __restrict__ sc) { sc->rail_p = 22.5; sc->rail_n = 22.5; sc->iavg_p = 0.0; sc->iavg_n = 0.0; }
+__device__ __forceinline__ void pa_rails_reset(PaScal& sc) { sc.rail_p = 22.5; sc.rail_n = 22.5; sc.iavg_p = 0.0; sc.iavg_n = 0.0; }
 
 // melange_adapter::PowerAmp::process, power_amp.rs:373-431
-__device__ inline double pa_process(PaScal* __restrict__ sc, const OwPaConsts* __restrict__ C, double* __restrict__ W, int role, const double* __restrict__ settled,
-                                    double input, bool rail_sag) {
-    const double off_p = rail_sag ? sc->rail_p - 22.5 : 0.0, off_n = rail_sag ? sc->rail_n - 22.5 : 0.0;
-    const double raw = pa_process_sample(sc, C, W, role, input, off_p, off_n);
+__device__ __forceinline__ double pa_process(PaScal& sc, const OwPaConsts* __restrict__ C, double* __restrict__ W, const PaTab* T, int role,
+                                             const double* __restrict__ settled, double input, bool rail_sag) {
+    const double off_p = rail_sag ? sc.rail_p - 22.5 : 0.0, off_n = rail_sag ? sc.rail_n - 22.5 : 0.0;
+    const double raw = pa_process_sample(sc, C, W, T, role, input, off_p, off_n);
     const double result = OW_DIV_C(raw, 22.0);
-    const bool nr_failed = sc->last_nr >= 69u;
+    const bool nr_failed = sc.last_nr >= 69u;
     bool insane = false;
     for (int i = 0; i < PA_N; ++i) { const double v = PL(PL_V + i); insane = insane || !isfinite(v) || fabs(v) > 100.0; }
-    PA_SYNC();
     if (__builtin_expect(!isfinite(result) || nr_failed || insane, 0)) {
-        pa_init_state(sc, W, settled, C);
+        pa_init_state(sc, W, role, settled, C);
         pa_rails_reset(sc);
-        sc->guard_cnt += 1ull;
-        return sc->last_good;
+        sc.guard_cnt += 1ull;
+        return sc.last_good;
     }
     const double clamped = clampd(result, -1.0, 1.0);
-    sc->last_good = clamped;
+    sc.last_good = clamped;
     if (rail_sag) {        // RailDynamics::step(raw), power_amp.rs:131-156
         const double i_pos = fmax(OW_DIV_C(raw, 8.0), 0.0);
         const double i_neg = fmax(OW_DIV_C(-raw, 8.0), 0.0);
-        sc->iavg_p += C->alpha_i_avg * (i_pos - sc->iavg_p);
-        sc->iavg_n += C->alpha_i_avg * (i_neg - sc->iavg_n);
-        const double target_pos = 24.5 - sc->iavg_p * 3.5;
-        const double target_neg = 24.5 - sc->iavg_n * 3.5;
-        const double alpha_p = target_pos < sc->rail_p ? C->alpha_attack : C->alpha_release;
-        const double alpha_n = target_neg < sc->rail_n ? C->alpha_attack : C->alpha_release;
-        sc->rail_p += alpha_p * (target_pos - sc->rail_p);
-        sc->rail_n += alpha_n * (target_neg - sc->rail_n);
+        sc.iavg_p += C->alpha_i_avg * (i_pos - sc.iavg_p);
+        sc.iavg_n += C->alpha_i_avg * (i_neg - sc.iavg_n);
+        const double target_pos = 24.5 - sc.iavg_p * 3.5;
+        const double target_neg = 24.5 - sc.iavg_n * 3.5;
+        const double alpha_p = target_pos < sc.rail_p ? C->alpha_attack : C->alpha_release;
+        const double alpha_n = target_neg < sc.rail_n ? C->alpha_attack : C->alpha_release;
+        sc.rail_p += alpha_p * (target_pos - sc.rail_p);
+        sc.rail_n += alpha_n * (target_neg - sc.rail_n);
     }
     return clamped;
 }
 
-// engine e's state rows <-> LDS (both lanes load the same values; one lane stores)
-OW_DEV void pa_load(PaScal* __restrict__ sc, double* __restrict__ W, const double* __restrict__ pa, int I, int e) {
-    for (int i = 0; i < PA_N; ++i) PL(PL_V + i) = pa[(size_t)(PAS_V + i) * I + e];
-    for (int i = 0; i < PA_M; ++i) { PL(PL_IP + i) = pa[(size_t)(PAS_IP + i) * I + e]; PL(PL_IPP + i) = pa[(size_t)(PAS_IPP + i) * I + e]; }
-    sc->dcx = pa[(size_t)PAS_DCX * I + e]; sc->dcy = pa[(size_t)PAS_DCY * I + e]; sc->peak = pa[(size_t)PAS_PEAK * I + e];
-    sc->clamp_cnt = dbits(pa[(size_t)PAS_CLAMP * I + e]); sc->nrmax_cnt = dbits(pa[(size_t)PAS_NRMAX * I + e]); sc->nan_cnt = dbits(pa[(size_t)PAS_NAN * I + e]);
-    sc->last_good = pa[(size_t)PAS_LASTGOOD * I + e];
-    sc->rail_p = pa[(size_t)PAS_RAILP * I + e]; sc->rail_n = pa[(size_t)PAS_RAILN * I + e];
-    sc->iavg_p = pa[(size_t)PAS_IAVGP * I + e]; sc->iavg_n = pa[(size_t)PAS_IAVGN * I + e];
-    sc->guard_cnt = dbits(pa[(size_t)PAS_GUARD * I + e]);
-    sc->last_nr = 0u;
+// engine e's state rows <-> LDS (rows dealt to the eight lanes; the scalars are read by all, stored by role 0)
+__device__ __forceinline__ void pa_load(PaScal& sc, double* __restrict__ W, int role, const double* __restrict__ pa, int I, int e) {
+    for (int i = role; i < PA_N; i += 8) PL(PL_V + i) = pa[(size_t)(PAS_V + i) * I + e];
+    for (int i = role; i < PA_M; i += 8) { PL(PL_IP + i) = pa[(size_t)(PAS_IP + i) * I + e]; PL(PL_IPP + i) = pa[(size_t)(PAS_IPP + i) * I + e]; }
+    sc.dcx = pa[(size_t)PAS_DCX * I + e]; sc.dcy = pa[(size_t)PAS_DCY * I + e]; sc.peak = pa[(size_t)PAS_PEAK * I + e];
+    sc.clamp_cnt = dbits(pa[(size_t)PAS_CLAMP * I + e]); sc.nrmax_cnt = dbits(pa[(size_t)PAS_NRMAX * I + e]); sc.nan_cnt = dbits(pa[(size_t)PAS_NAN * I + e]);
+    sc.last_good = pa[(size_t)PAS_LASTGOOD * I + e];
+    sc.rail_p = pa[(size_t)PAS_RAILP * I + e]; sc.rail_n = pa[(size_t)PAS_RAILN * I + e];
+    sc.iavg_p = pa[(size_t)PAS_IAVGP * I + e]; sc.iavg_n = pa[(size_t)PAS_IAVGN * I + e];
+    sc.guard_cnt = dbits(pa[(size_t)PAS_GUARD * I + e]);
+    sc.last_nr = 0u;
     PA_SYNC();
 }
-OW_DEV void pa_store(const PaScal* __restrict__ sc, const double* __restrict__ W, double* __restrict__ pa, int I, int e) {
-    for (int i = 0; i < PA_N; ++i) pa[(size_t)(PAS_V + i) * I + e] = PL(PL_V + i);
-    for (int i = 0; i < PA_M; ++i) { pa[(size_t)(PAS_IP + i) * I + e] = PL(PL_IP + i); pa[(size_t)(PAS_IPP + i) * I + e] = PL(PL_IPP + i); }
-    pa[(size_t)PAS_DCX * I + e] = sc->dcx; pa[(size_t)PAS_DCY * I + e] = sc->dcy; pa[(size_t)PAS_PEAK * I + e] = sc->peak;
-    pa[(size_t)PAS_CLAMP * I + e] = bitsd(sc->clamp_cnt); pa[(size_t)PAS_NRMAX * I + e] = bitsd(sc->nrmax_cnt); pa[(size_t)PAS_NAN * I + e] = bitsd(sc->nan_cnt);
-    pa[(size_t)PAS_LASTGOOD * I + e] = sc->last_good;
-    pa[(size_t)PAS_RAILP * I + e] = sc->rail_p; pa[(size_t)PAS_RAILN * I + e] = sc->rail_n;
-    pa[(size_t)PAS_IAVGP * I + e] = sc->iavg_p; pa[(size_t)PAS_IAVGN * I + e] = sc->iavg_n;
-    pa[(size_t)PAS_GUARD * I + e] = bitsd(sc->guard_cnt);
+__device__ __forceinline__ void pa_store(const PaScal& sc, const double* __restrict__ W, int role, double* __restrict__ pa, int I, int e) {
+    PA_SYNC();
+    for (int i = role; i < PA_N; i += 8) pa[(size_t)(PAS_V + i) * I + e] = PL(PL_V + i);
+    for (int i = role; i < PA_M; i += 8) { pa[(size_t)(PAS_IP + i) * I + e] = PL(PL_IP + i); pa[(size_t)(PAS_IPP + i) * I + e] = PL(PL_IPP + i); }
+    if (role != 0) return;
+    pa[(size_t)PAS_DCX * I + e] = sc.dcx; pa[(size_t)PAS_DCY * I + e] = sc.dcy; pa[(size_t)PAS_PEAK * I + e] = sc.peak;
+    pa[(size_t)PAS_CLAMP * I + e] = bitsd(sc.clamp_cnt); pa[(size_t)PAS_NRMAX * I + e] = bitsd(sc.nrmax_cnt); pa[(size_t)PAS_NAN * I + e] = bitsd(sc.nan_cnt);
+    pa[(size_t)PAS_LASTGOOD * I + e] = sc.last_good;
+    pa[(size_t)PAS_RAILP * I + e] = sc.rail_p; pa[(size_t)PAS_RAILN * I + e] = sc.rail_n;
+    pa[(size_t)PAS_IAVGP * I + e] = sc.iavg_p; pa[(size_t)PAS_IAVGN * I + e] = sc.iavg_n;
+    pa[(size_t)PAS_GUARD * I + e] = bitsd(sc.guard_cnt);
 }
-
 // Settled state of the amp (compute_settled_state, power_amp.rs:290-296): CircuitState::default() (DC_OP + 50 warm-up samples) and
-// 44 100 silent samples, all with the codegen-rate matrices.  One lane pair; cached per device by the host like the reference's OnceLock.
+// 44 100 silent samples, all with the codegen-rate matrices.  One wavefront (its eight engine slots run the same silent settle);
+// cached per device by the host like the reference's OnceLock.
 __global__ __launch_bounds__(64) void k_mpa_settle(const OwPaConsts* __restrict__ C88, double* __restrict__ settled) {
-    __shared__ double WS[PL_ROWS * PA_EPW];
-    const int el = threadIdx.x & 31, role = threadIdx.x >> 5;
-    double* W = WS + el;                                   // all 32 pairs run the same silent settle (no divergence); pair 0 reports
+    __shared__ double WS[PL_ROWS * PA_LS];
+    __shared__ PaTab TS;
+    pa_stage_tables(&TS, C88);
+    const PaTab* T = &TS;
+    const int role = threadIdx.x >> 3;
+    double* W = WS + (threadIdx.x & 7);
     PaScal sc;
-    for (int i = 0; i < PA_N; ++i) PL(PL_V + i) = PA_DC_OP[i];
-    for (int i = 0; i < PA_M; ++i) { PL(PL_IP + i) = PA_DC_NL_I[i]; PL(PL_IPP + i) = PA_DC_NL_I[i]; }
+    for (int i = role; i < PA_N; i += 8) PL(PL_V + i) = PA_DC_OP[i];
+    for (int i = role; i < PA_M; i += 8) { PL(PL_IP + i) = PA_DC_NL_I[i]; PL(PL_IPP + i) = PA_DC_NL_I[i]; }
     sc.dcx = PA_DC_BLOCK_X0; sc.dcy = 0.0; sc.peak = 0.0; sc.clamp_cnt = sc.nrmax_cnt = sc.nan_cnt = sc.guard_cnt = 0ull;
     sc.last_good = 0.0; sc.last_nr = 0u;
-    pa_rails_reset(&sc);
+    pa_rails_reset(sc);
     PA_SYNC();
-    for (int n = 0; n < 50 + 44100; ++n) pa_process_sample(&sc, C88, W, role, 0.0, 0.0, 0.0);
+    for (int n = 0; n < 50 + 44100; ++n) pa_process_sample(sc, C88, W, T, role, 0.0, 0.0, 0.0);
+    PA_SYNC();
     if (threadIdx.x != 0) return;
     for (int i = 0; i < PA_N; ++i) settled[PAS_V + i] = PL(PL_V + i);
     for (int i = 0; i < PA_M; ++i) { settled[PAS_IP + i] = PL(PL_IP + i); settled[PAS_IPP + i] = PL(PL_IPP + i); }
@@ -505,25 +619,29 @@ __global__ __launch_bounds__(64) void k_mpa_settle(const OwPaConsts* __restrict_
     settled[PAS_CLAMP] = bitsd(sc.clamp_cnt); settled[PAS_NRMAX] = bitsd(sc.nrmax_cnt); settled[PAS_NAN] = bitsd(sc.nan_cnt);
 }
 
-// The amp alone on given input (debug hook ow_debug_power_amp): pair p of block b processes row b * 32 + p of `in`.  taps [row][n][3]: outer
-// Newton iterations of the sample (70 = exhausted), guard resets so far, positive rail after the sample.
-__global__ __launch_bounds__(64) void k_mpa_debug(const OwPaConsts* __restrict__ C, const double* __restrict__ settled, const double* __restrict__ in,
-                                                  double* __restrict__ out, double* __restrict__ taps, long long n, int n_rows, int rail_sag,
-                                                  const long long* __restrict__ poke_at, const int* __restrict__ poke_node, const double* __restrict__ poke_val) {
-    __shared__ double WS[PL_ROWS * PA_EPW];
-    const int el = threadIdx.x & 31, role = threadIdx.x >> 5;
-    double* W = WS + el;
-    const int row_raw = blockIdx.x * PA_EPW + el;
+// The amp alone on given input (debug hook ow_debug_power_amp): engine slot s of block b processes row b * 32 + s of `in`.  taps
+// [row][n][3]: outer Newton iterations of the sample (70 = exhausted), guard resets so far, positive rail after the sample.
+__global__ __launch_bounds__(PA_WPB * 64, 2) void k_mpa_debug(const OwPaConsts* __restrict__ C, const double* __restrict__ settled, const double* __restrict__ in,
+                                                           double* __restrict__ out, double* __restrict__ taps, long long n, int n_rows, int rail_sag,
+                                                           const long long* __restrict__ poke_at, const int* __restrict__ poke_node, const double* __restrict__ poke_val) {
+    __shared__ double WS[PA_LDS_DOUBLES];
+    __shared__ PaTab TS;
+    pa_stage_tables(&TS, C);
+    const PaTab* T = &TS;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int role = lane >> 3, slot = wv * PA_EPW + (lane & 7);
+    double* W = WS + wv * (PL_ROWS * PA_LS) + (lane & 7);
+    const int row_raw = blockIdx.x * PA_EPB + slot;
     const bool valid = row_raw < n_rows;
     const size_t row = valid ? row_raw : n_rows - 1;
     PaScal sc;
-    pa_init_state(&sc, W, settled, C);
-    pa_rails_reset(&sc);
+    pa_init_state(sc, W, role, settled, C);
+    pa_rails_reset(sc);
     sc.last_good = 0.0; sc.guard_cnt = 0ull;
     for (long long i = 0; i < n; ++i) {
-        if (poke_at && poke_at[row] == i) { PL(PL_V + poke_node[row]) = poke_val[row]; }
+        if (poke_at && poke_at[row] == i) { PA_SYNC(); PL(PL_V + poke_node[row]) = poke_val[row]; }
         PA_SYNC();
-        const double y = pa_process(&sc, C, W, role, settled, in[row * n + i], rail_sag != 0);
+        const double y = pa_process(sc, C, W, T, role, settled, in[row * n + i], rail_sag != 0);
         if (valid && role == 0) {
             out[row * n + i] = y;
             if (taps) {
@@ -546,100 +664,101 @@ __global__ void k_mpa_init(const OwPaConsts* __restrict__ C, const double* __res
     if (fresh) { pa[(size_t)PAS_LASTGOOD * I + e] = 0.0; pa[(size_t)PAS_GUARD * I + e] = bitsd(0ull); }
 }
 
-// Output stage with the melange power amp: a lane pair per engine (the amp is a stateful recurrence at the chain rate, so the two
-// chain-rate samples of an output sample are solved one after the other), then half-band down, speaker, gain, f32 as k_post -- that
-// cheap tail is computed by both lanes of the pair, lane 0 of the pair owns state and output.  One wavefront per workgroup.
-__global__ __launch_bounds__(64) void k_post_mpa(const OwConsts* __restrict__ K, const OwPaConsts* __restrict__ C, const double* __restrict__ settled,
-                                                 double* __restrict__ cs, double* __restrict__ pa, const OwEngineArgs* __restrict__ args,
-                                                 OwEngineOut* __restrict__ eout, const double* __restrict__ pre, float* __restrict__ out,
-                                                 double* __restrict__ pa_tap, int I, int L, int Lout, int e0, int ne) {
-    __shared__ double WS[PL_ROWS * PA_EPW];                      // 128 KB
-    __shared__ float tile[PA_EPW * (OW_OCHUNK + 1)];
-    const int lane = threadIdx.x;
-    const int el = lane & 31, role = lane >> 5;
-    double* W = WS + el;
-    const int eb = e0 + blockIdx.x * PA_EPW;
-    const int e_raw = eb + el;
+// Output stage with the melange power amp: eight lanes per engine, 32 engines per workgroup (the amp is a stateful recurrence at the
+// chain rate, so the two chain-rate samples of an output sample are solved one after the other), then half-band down, speaker, gain,
+// f32 as k_post.  That cheap tail runs on the role-0 lane of the engine with its state (filters, smoothers) in LDS between samples:
+// in registers it would sit on top of the solver's ~430 and spill to scratch.
+struct PaTail { SpeakerSt sp; Smoother ss, sv; double da[3], db[3], dd; };
+__global__ __launch_bounds__(PA_WPB * 64, 2) void k_post_mpa(const OwConsts* __restrict__ K, const OwPaConsts* __restrict__ C, const double* __restrict__ settled,
+                                                          double* __restrict__ cs, double* __restrict__ pa, const OwEngineArgs* __restrict__ args,
+                                                          OwEngineOut* __restrict__ eout, const double* __restrict__ pre, float* __restrict__ out,
+                                                          double* __restrict__ pa_tap, int I, int L, int Lout, int e0, int ne) {
+    __shared__ double WS[PA_LDS_DOUBLES];                        // 61 KB
+    __shared__ PaTab TS;
+    __shared__ PaTail TL[PA_EPB];
+    pa_stage_tables(&TS, C);
+    const PaTab* T = &TS;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int role = lane >> 3, slot = wv * PA_EPW + (lane & 7);
+    double* W = WS + wv * (PL_ROWS * PA_LS) + (lane & 7);
+    const int eb = e0 + blockIdx.x * PA_EPB;
+    const int e_raw = eb + slot;
     const bool valid = e_raw < e0 + ne;
     const int e = valid ? e_raw : (e0 + ne - 1);
     const int osr = K->oversample ? 2 : 1;
-    const double sr = K->sr;
-    const double thermal_alpha = K->spk_thermal_alpha;
     const bool rail_sag = (args[e].pa_flags & 1u) != 0u;
-
-    double da[3], db[3], dd;
-    for (int i = 0; i < 3; ++i) { da[i] = CSF(CS_OS_DA + i); db[i] = CSF(CS_OS_DB + i); }
-    dd = CSF(CS_OS_DD);
-    SpeakerSt sp;
-    {
-        double* hp = &sp.hpf.b0; double* lp = &sp.lpf.b0;
+    PaTail& t = TL[slot];
+    if (role == 0) {
+        for (int i = 0; i < 3; ++i) { t.da[i] = CSF(CS_OS_DA + i); t.db[i] = CSF(CS_OS_DB + i); }
+        t.dd = CSF(CS_OS_DD);
+        double* hp = &t.sp.hpf.b0; double* lp = &t.sp.lpf.b0;
         for (int i = 0; i < 7; ++i) { hp[i] = CSF(CS_SPK_HPF + i); lp[i] = CSF(CS_SPK_LPF + i); }
-        sp.character = CSF(CS_SPK_CHAR); sp.a2 = CSF(CS_SPK_A2); sp.a3 = CSF(CS_SPK_A3); sp.tc = CSF(CS_SPK_TC); sp.ts = CSF(CS_SPK_TS);
+        t.sp.character = CSF(CS_SPK_CHAR); t.sp.a2 = CSF(CS_SPK_A2); t.sp.a3 = CSF(CS_SPK_A3); t.sp.tc = CSF(CS_SPK_TC); t.sp.ts = CSF(CS_SPK_TS);
+        smoother_load(t.ss, cs, I, e, CS_SM_SPK);
+        smoother_load(t.sv, cs, I, e, CS_SM_VOL);
+        if (args[e].set_flags & 2u) t.ss.retarget(args[e].spk_target, K->ramp_samples);
+        if (args[e].set_flags & 4u) t.sv.retarget(args[e].vol_target, K->ramp_samples);
     }
-    Smoother ss, sv;
-    smoother_load(ss, cs, I, e, CS_SM_SPK);
-    smoother_load(sv, cs, I, e, CS_SM_VOL);
-    if (args[e].set_flags & 2u) ss.retarget(args[e].spk_target, K->ramp_samples);
-    if (args[e].set_flags & 4u) sv.retarget(args[e].vol_target, K->ramp_samples);
     PaScal sc;
-    pa_load(&sc, W, pa, I, e);
+    pa_load(sc, W, role, pa, I, e);
     bool nan_fired = false;
-    for (int base = 0; base < L; base += OW_OCHUNK) {
-        const int cn = min(OW_OCHUNK, L - base);
-        for (int n = 0; n < cn; ++n) {
-            double y[2] = {0.0, 0.0};
-            for (int j = 0; j < osr; ++j) {
-                const size_t idx = (size_t)(base + n) * osr + j;
-                y[j] = pa_process(&sc, C, W, role, settled, pre[idx * I + e] * 0.25, rail_sag);     // x FIXED_CIRCUIT_DRIVE, engine.rs:544-546
-                if (pa_tap && valid && role == 0) pa_tap[idx * I + e] = y[j];
-            }
+    for (int n = 0; n < L; ++n) {
+        double y[2] = {0.0, 0.0};
+        for (int j = 0; j < osr; ++j) {
+            const size_t idx = (size_t)n * osr + j;
+            y[j] = pa_process(sc, C, W, T, role, settled, pre[idx * I + e] * 0.25, rail_sag);       // x FIXED_CIRCUIT_DRIVE, engine.rs:544-546
+            if (pa_tap && valid && role == 0) pa_tap[idx * I + e] = y[j];
+        }
+        if (role == 0) {
             double o;
             if (osr == 2) {
-                const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, y[0]);
-                const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, y[1]);
-                o = (a + dd) * 0.5;
-                dd = b;
+                const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, t.da, y[0]);
+                const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, t.db, y[1]);
+                o = (a + t.dd) * 0.5;
+                t.dd = b;
             } else {
                 o = y[0];
             }
-            speaker_set_character(sp, ss.next(), sr);
-            const double shaped = speaker_process(sp, o, thermal_alpha);
-            const double post = shaped * 7.498942093324558 * sv.next();
+            speaker_set_character(t.sp, t.ss.next(), K->sr);
+            const double shaped = speaker_process(t.sp, o, K->spk_thermal_alpha);
+            const double post = shaped * 7.498942093324558 * t.sv.next();
             float f = (float)post;
-            if (!isfinite(f)) {                                                 // engine.rs:450-458 (power_amp.reset() included)
+            const bool bad = !isfinite(f);
+            if (bad) {                                                          // engine.rs:450-458
                 f = 0.0f;
-                sp.hpf.s1 = sp.hpf.s2 = sp.lpf.s1 = sp.lpf.s2 = 0.0;
-                sp.ts = 0.0;
-                pa_init_state(&sc, W, settled, C);
-                pa_rails_reset(&sc);
-                nan_fired = true;
+                t.sp.hpf.s1 = t.sp.hpf.s2 = t.sp.lpf.s1 = t.sp.lpf.s2 = 0.0;
+                t.sp.ts = 0.0;
             }
-            if (role == 0) tile[el * (OW_OCHUNK + 1) + n] = f;
+            // 4 bytes per engine per output sample, straight to its row: 33 MB per block at 16 384 engines against >= 100 ms of
+            // solver time -- not worth 8 KB of LDS for a transposing tile
+            if (valid) out[(size_t)e * Lout + n] = f;
+            PL(PL_X) = bad ? 1.0 : 0.0;                                           // ... the engine's other lanes need to know: power_amp.reset()
         }
-        __syncthreads();
-        for (int r = 0; r < PA_EPW; ++r) {
-            const int er = eb + r;
-            if (er < e0 + ne && lane < cn) out[(size_t)er * Lout + base + lane] = tile[r * (OW_OCHUNK + 1) + lane];
+        PA_SYNC();
+        if (__builtin_expect(PL(PL_X) != 0.0, 0)) {
+            pa_init_state(sc, W, role, settled, C);
+            pa_rails_reset(sc);
+            nan_fired = true;
         }
-        __syncthreads();
+        PA_SYNC();
     }
+    if (valid) pa_store(sc, W, role, pa, I, e);
     if (!valid || role != 0) return;
     if (nan_fired) {
-        for (int i = 0; i < 3; ++i) { da[i] = 0.0; db[i] = 0.0; }
-        dd = 0.0;
+        for (int i = 0; i < 3; ++i) { t.da[i] = 0.0; t.db[i] = 0.0; }
+        t.dd = 0.0;
         CSF(CS_FLAGS) = bitsd(dbits(CSF(CS_FLAGS)) | 1ull);
         eout[e].out_nonfinite = 1u;
     }
-    for (int i = 0; i < 3; ++i) { CSF(CS_OS_DA + i) = da[i]; CSF(CS_OS_DB + i) = db[i]; }
-    CSF(CS_OS_DD) = dd;
+    for (int i = 0; i < 3; ++i) { CSF(CS_OS_DA + i) = t.da[i]; CSF(CS_OS_DB + i) = t.db[i]; }
+    CSF(CS_OS_DD) = t.dd;
     {
-        const double* hp = &sp.hpf.b0; const double* lp = &sp.lpf.b0;
+        const double* hp = &t.sp.hpf.b0; const double* lp = &t.sp.lpf.b0;
         for (int i = 0; i < 7; ++i) { CSF(CS_SPK_HPF + i) = hp[i]; CSF(CS_SPK_LPF + i) = lp[i]; }
-        CSF(CS_SPK_CHAR) = sp.character; CSF(CS_SPK_A2) = sp.a2; CSF(CS_SPK_A3) = sp.a3; CSF(CS_SPK_TC) = sp.tc; CSF(CS_SPK_TS) = sp.ts;
+        CSF(CS_SPK_CHAR) = t.sp.character; CSF(CS_SPK_A2) = t.sp.a2; CSF(CS_SPK_A3) = t.sp.a3; CSF(CS_SPK_TC) = t.sp.tc; CSF(CS_SPK_TS) = t.sp.ts;
     }
-    smoother_store(ss, cs, I, e, CS_SM_SPK);
-    smoother_store(sv, cs, I, e, CS_SM_VOL);
-    pa_store(&sc, W, pa, I, e);
+    smoother_store(t.ss, cs, I, e, CS_SM_SPK);
+    smoother_store(t.sv, cs, I, e, CS_SM_VOL);
 }
 
 }  // namespace owdev
