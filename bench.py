@@ -52,7 +52,13 @@ FLOPS_TREMOLO = 2 * (1000 + 25)    # Twin-T NR step + LDR law per OS sample, 2 O
 FLOPS_PREAMP = 2 * 1400 + 24       # main+shadow dk_step per OS sample + half-band up
 # melange 12-node preamp as the kernel EXECUTES it (rank-one update of the inverse, no per-sample LU): per state and chain-rate
 # sample build_rhs ~120 + S.rhs 288 + Sherman-Morrison correction ~50 + 3 Newton sweeps x ~150 + S_NI.i 72 + damp net ~50 = ~1050
-FLOPS_PREAMP_MELANGE = 2 * 2 * 1050 + 24
+FLOPS_PREAMP_MELANGE = 2 * 2 * 1050 + 24          # rank-one kernel (OW_MEL_RANK1=1): the Newton solve only, matrices updated by Sherman-Morrison
+# literal kernel (default): + the per-sample rebuild as the DEVICE does it (R-dependent trailing 6x6 block: Schur update, LU, the
+# columns of S the solve needs, K = N_v S N_i: ~1 200 flops; the reference's full 12x12 inverse would be ~6 100) -- conservative
+FLOPS_PREAMP_MELANGE_LIT = 2 * 2 * (1050 + 1200) + 24
+# melange power amp, per chain-rate sample with ONE Newton iteration (the count is data dependent: 1 on silence, 2..3 mean on a chord,
+# up to 70): device models 8 x ~300, Jacobian 1 024, 16x16 LU 2 730, substitution 256, K products 2 x 512, S rhs 800, S_NI i 640
+FLOPS_PA_MELANGE_PER_CHAIN_SAMPLE = 8 * 300 + 1024 + 2730 + 256 + 1024 + 800 + 640
 FLOPS_POST = 2 * 90 + 24 + 45      # power amp x2 + half-band down + speaker/gain
 KERNEL_OF = {"ops": "k_apply_ops", "voices": "k_voice_steady", "tremolo": "k_tremolo", "preamp": "k_preamp", "post": "k_post"}
 PEAK_FP64_VALU_TFLOPS = 78.6       # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (MI355X FP64 vector)
@@ -337,7 +343,8 @@ def main(argv=None):
             torch.cuda.synchronize()
 
     preamp_kind = 1 if args.preamp == "melange" else 0
-    flops_preamp = FLOPS_PREAMP_MELANGE if preamp_kind else FLOPS_PREAMP
+    flops_preamp = ((FLOPS_PREAMP_MELANGE if os.environ.get("OW_MEL_RANK1", "0") not in ("", "0") else FLOPS_PREAMP_MELANGE_LIT)
+                    if preamp_kind else FLOPS_PREAMP)
     n_inst = args.instances
     line = None
 
@@ -468,8 +475,10 @@ def main(argv=None):
             kms = script.kernel_ms / max(script.kernel_launches, 1)     # average ms per step, per kernel
             names = ["ops", "voices", "tremolo", "preamp", "post"]
             trem_per_engine = FLOPS_TREMOLO * groups / n_inst            # one oscillator per phase group
-            flops = {"ops": 0.0, "voices": FLOPS_VOICES, "tremolo": trem_per_engine, "preamp": flops_preamp, "post": FLOPS_POST}
-            per_sample = FLOPS_VOICES + trem_per_engine + flops_preamp + FLOPS_POST
+            osr = 2 if SR < 88200.0 else 1
+            flops_post = (FLOPS_POST - osr * 90 + osr * FLOPS_PA_MELANGE_PER_CHAIN_SAMPLE) if pa_kind else FLOPS_POST
+            flops = {"ops": 0.0, "voices": FLOPS_VOICES, "tremolo": trem_per_engine, "preamp": flops_preamp, "post": flops_post}
+            per_sample = FLOPS_VOICES + trem_per_engine + flops_preamp + flops_post
             audio = ["voices", "preamp", "post"] + (["tremolo"] if groups * 4 >= n_inst else [])   # the shared oscillator is not a pool-sized kernel
             dom = max(audio, key=lambda k: kms[names.index(k)])
             dom_ms = float(kms[names.index(dom)])
@@ -505,16 +514,19 @@ def main(argv=None):
                 "host_midi_s": script.t_midi, "render_calls_s": script.t_render, "elapsed_s": elapsed,
                 "single_instance_samples_per_s": single,
                 "roofline": {
-                    "bound": "valu_f64", "kernel": KERNEL_OF[dom] + ("_mel" if preamp_kind and dom == "preamp" else ""), "achieved": achieved,
+                    "bound": "valu_f64", "kernel": KERNEL_OF[dom] + (("_mel" if flops_preamp == FLOPS_PREAMP_MELANGE else "_mel_lit") if preamp_kind and dom == "preamp" else "") + ("_mpa" if pa_kind and dom == "post" else ""),
+                    "achieved": achieved,
                     "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
                     "kernel_ms_per_step": {n: float(k) for n, k in zip(names, kms)},
-                    "flops_per_output_sample": {"voices": FLOPS_VOICES, "tremolo": trem_per_engine, "preamp": flops_preamp, "post": FLOPS_POST},
+                    "flops_per_output_sample": {"voices": FLOPS_VOICES, "tremolo": trem_per_engine, "preamp": flops_preamp, "post": flops_post},
                     "whole_chain_frac": per_sample * value / world / 1e12 / PEAK_FP64_VALU_TFLOPS,
                     # the contract's own vocabulary, for reference: PMC HBM bytes of the dominant kernel / its duration against 8 TB/s
                     "hbm": ({"achieved": traffic / (dom_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                              "frac": traffic / (dom_ms * 1e-3) / 1e9 / 8000.0} if traffic and dom_ms > 0 else None),
                     "note": "path is FP64-VALU/latency bound (not HBM, not MFMA); achieved = algorithmic f64 flops of the dominant "
-                            "kernel per launch / its HIP-event duration",
+                            "kernel per launch / its HIP-event duration" +
+                            ("; melange power amp: the flop count assumes ONE Newton iteration per chain-rate sample (a lower bound: the count is data dependent)"
+                             if pa_kind else ""),
                 },
                 "cpu_baseline": cpu,
             }

@@ -188,6 +188,10 @@ struct PaTab {
     double s[PA_N * PA_N];
     double s_ni[PA_N * PA_M];
     OwPaConsts::Dev dev[8];
+    double rhs_const[PA_N];
+    double nz_coef[PA_RHS_NNZ];          // A_neg's non-zeros in the reference's order (sorted by row), as CSR
+    int nz_col[PA_RHS_NNZ];
+    int row_ptr[PA_N + 1];
 };
 __device__ __forceinline__ void pa_stage_tables(PaTab* __restrict__ T, const OwPaConsts* __restrict__ C) {
     for (int i = threadIdx.x; i < PA_M * PA_M; i += blockDim.x) T->k[i] = (&C->k[0][0])[i];
@@ -196,6 +200,17 @@ __device__ __forceinline__ void pa_stage_tables(PaTab* __restrict__ T, const OwP
     double* d = reinterpret_cast<double*>(&T->dev[0]);
     const double* g = reinterpret_cast<const double*>(&C->dev[0]);
     for (int i = threadIdx.x; i < (int)(8 * sizeof(OwPaConsts::Dev) / sizeof(double)); i += blockDim.x) d[i] = g[i];
+    for (int i = threadIdx.x; i < PA_N; i += blockDim.x) T->rhs_const[i] = PA_RHS_CONST[i];
+    for (int q = threadIdx.x; q < PA_RHS_NNZ; q += blockDim.x) {
+        const int i = (int)PA_RHS_NZ_ROW[q], j = (int)PA_RHS_NZ_COL[q];
+        T->nz_coef[q] = C->a_neg[i][j];
+        T->nz_col[q] = j;
+    }
+    for (int r = threadIdx.x; r <= PA_N; r += blockDim.x) {
+        int c = 0;
+        for (int q = 0; q < PA_RHS_NNZ; ++q) c += ((int)PA_RHS_NZ_ROW[q] < r) ? 1 : 0;
+        T->row_ptr[r] = c;
+    }
     __syncthreads();
 }
 
@@ -470,15 +485,15 @@ __device__ __forceinline__ double pa_process_sample(PaScal& sc, const OwPaConsts
     const double input = isfinite(input_in) ? clampd(input_in, -100.0, 100.0) : 0.0;
     for (int i = role; i < PA_N; i += 8) PL(PL_V + i) = PL(PL_V + i) + 1e-25 - 1e-25;
     for (int i = role; i < PA_M; i += 8) PL(PL_IP + i) = PL(PL_IP + i) + 1e-25 - 1e-25;
-    for (int i = role; i < PA_N; i += 8) PL(PL_RHS + i) = PA_RHS_CONST[i];
     PA_SYNC();
-    for (int q = 0; q < PA_RHS_NNZ; ++q) {                        // all eight lanes, same values
-        const int i = (int)PA_RHS_NZ_ROW[q], j = (int)PA_RHS_NZ_COL[q];
-        PL(PL_RHS + i) = PL(PL_RHS + i) + C->a_neg[i][j] * PL(PL_V + j);
+    for (int i = role; i < PA_N; i += 8) {                        // rhs = RHS_CONST + A_neg v_prev (sparse, the reference's term order) + sources
+        double acc = T->rhs_const[i];
+        for (int q = T->row_ptr[i]; q < T->row_ptr[i + 1]; ++q) acc = acc + T->nz_coef[q] * PL(PL_V + T->nz_col[q]);
+        if (i == 0) acc = acc + input * (1.0 / PA_INPUT_RESISTANCE);
+        if (i == 18) acc = acc + off_p;
+        if (i == 19) acc = acc + off_n;
+        PL(PL_RHS + i) = acc;
     }
-    PL(PL_RHS + 0) = PL(PL_RHS + 0) + input * (1.0 / PA_INPUT_RESISTANCE);
-    PL(PL_RHS + 18) = PL(PL_RHS + 18) + off_p;
-    PL(PL_RHS + 19) = PL(PL_RHS + 19) + off_n;
     PA_SYNC();
     for (int i = role; i < PA_N; i += 8) {                        // v_pred = S rhs
         double sum = 0.0;

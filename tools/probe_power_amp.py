@@ -88,3 +88,18 @@ if len(sys.argv) > 4 and sys.argv[4] == "pool2":
             d = g[5].power_amp_diag()
             print(f"{variant}: block {b}: post {ms['post']:.1f} ms; engine 5 diag nr_max {d.nr_max_iter_count} guard {d.guard_resets} peak {d.peak_output_volts:.4f}")
         g.close()
+
+if len(sys.argv) > 4 and sys.argv[4] == "diag":
+    import bench
+    import openwurli_amd as ow
+    ne = 64
+    g = ow.EnginePool(48000.0, ne, power_amp_kind=1)
+    g.set_sample_rate(48000.0)
+    g.set_profiling(True)
+    sc = bench.Script(g, ne)
+    for b in range(8):
+        sc.step(profile=True)
+        ds = [g[k].power_amp_diag() for k in range(ne)]
+        print(f"block {b}: post {g.last_kernel_ms()['post']:.1f} ms; BE retries so far: total {sum(d.nr_max_iter_count for d in ds)} (max per engine {max(d.nr_max_iter_count for d in ds)}), "
+              f"guard resets total {sum(d.guard_resets for d in ds)}, nan resets {sum(d.nan_resets for d in ds)}")
+    g.close()
