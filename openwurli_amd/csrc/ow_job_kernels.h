@@ -9,6 +9,7 @@
 #pragma once
 #include "ow_kernels.h"
 #include "ow_melange_dev.h"
+#include "ow_melange_lit.h"
 
 namespace owdev {
 
@@ -55,14 +56,18 @@ __global__ __launch_bounds__(64) void k_job_voice(const OwConsts* __restrict__ K
 }
 
 // Preamp + output stage, lane pair (job, main|shadow): 32 jobs per wavefront.  MEL selects the melange 12-node solver
-// (`--features melange-preamp` build of preamp-bench) instead of the legacy 8-node one.
+// (`--features melange-preamp` build of preamp-bench) instead of the legacy 8-node one.  A job's LDR is static, so its matrices
+// are built ONCE, by the reference's literal rebuild (ow_melange_lit.h: A -> LU -> S -> K in the reference's operation order), and
+// live in LDS, job-minor -- the per-lane rank-one state this kernel used to carry spilled 707 registers.  They are rebuilt lazily
+// when the adapter's NaN reset puts a state (and with it its resistance) back to the settled clone, as the reference's own
+// matrices go back with the state.
 template <bool MEL>
 __global__ __launch_bounds__(64) void k_job_chain(const OwConsts* __restrict__ K, const OwJobDev* __restrict__ jobs, const double* __restrict__ reed,
                                                   double* __restrict__ out, const double* __restrict__ settled, int n_jobs, long long n, long long stride) {
     __shared__ double tin[32 * (OW_PCHUNK + 1)];
     __shared__ double tout[32 * (OW_PCHUNK + 1)];
-    __shared__ MelMats M;
-    if (MEL) { mel_mats_load(&M, K, threadIdx.x, 64); __syncthreads(); }
+    __shared__ double LU_all[MEL ? 12 * 12 * 32 : 1];
+    __shared__ double S_all[MEL ? 12 * 12 * 32 : 1];
     const int lane = threadIdx.x;
     const int jl = lane & 31, role = lane >> 5;
     const int jb = blockIdx.x * 32;
@@ -77,6 +82,12 @@ __global__ __launch_bounds__(64) void k_job_chain(const OwConsts* __restrict__ K
     MelSt ms;
     double r_ldr = 1000000.0;
     double g_ldr = 1.0 / r_ldr, g_prev = g_ldr;
+    double* lu = LU_all + (MEL ? jl : 0);
+    double* S = S_all + (MEL ? jl : 0);
+    const double alpha = 2.0 * (K->os_sr * 1.0);       // gen_preamp.rs:1991-1992
+    double s_pot = __longlong_as_double(0x7ff8000000000000LL);    // resistance the LDS matrices were built for (NaN: none yet)
+    double kk[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    double an66 = 0.0;
     if (MEL) {
         mel_init_state(ms, settled);                  // new() and reset() both clone the settled state (melange_adapter.rs:22-29,88-93)
         ms.nan_resets = 0; ms.be_fallbacks = 0;
@@ -90,9 +101,19 @@ __global__ __launch_bounds__(64) void k_job_chain(const OwConsts* __restrict__ K
     auto preamp_step = [&](double x) -> double {
         double o;
         if (MEL) {
-            int z = 0;
-            asm volatile("" : "+v"(z));
-            o = mel_process(ms, x, &M + z);
+            const double pot_main = __shfl(ms.pot, jl);
+            if (__any(!(pot_main == s_pot))) {        // lazy rebuild (gen_preamp.rs:3408-3411); every lane takes part (barriers inside)
+                // the generic rebuild (a real function: it runs once per job, its registers must not weigh on the sample loop);
+                // bit-identical to the fast path the pool kernel prefers (tests/test_gpu_parity.py)
+                double kt[3][3];
+                mel_lit_rebuild(pot_main, role, alpha, lu, S, kt);
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) kk[a][b] = kt[a][b];
+                s_pot = pot_main;
+                const double g66 = PRE_G[6][6] + (ow_div(1.0, pot_main) - PRE_POT_0_G_NOM);
+                an66 = alpha * PRE_C[6][6] - g66;
+            }
+            o = mel_process_lit(ms, x, K->m_aneg0, an66, S, kk, nullptr, 0);
         } else {
             o = dk_step(st, x, g_ldr, g_prev, K);
             g_prev = g_ldr;

@@ -225,6 +225,9 @@ __device__ inline double mel_process_lit(MelSt& st, double input_in, const doubl
     const double p[3] = {-v_pred[2], v_pred[2] - v_pred[5], v_pred[4] - v_pred[8]};
     double i_nl[3];
     uint32_t last_it = mel_solve_nl(p, kk, st.ip, st.ipp, i_nl);
+    // (fence: the S entries below were all read for S rhs above; without it the compiler keeps those 60 doubles in registers across
+    // the Newton solve -- and spills -- instead of reading LDS again)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double vn[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {                                  // v = v_pred + (S N_i) i_nl

@@ -810,6 +810,9 @@ def test_batch_render_melange(hiplib, oracle):
     g = ow.batch_render(jobs, sample_rate=sr, duration_s=dur, preamp_kind=1)
     for i, j in enumerate(jobs):
         c = oracle.batch_render_job(j["note"], j["velocity"], dur, sr, r_ldr=j["r_ldr"], preamp_kind=1)
-        rep = oracle.parity_report(g[i], c, abs_floor=oracle.ABS_FLOOR_MELANGE_OUTPUT * 4)
+        # static LDR: the job's matrices come from ONE literal rebuild (ow_melange_lit.h), like the reference's set_pot -- the batch
+        # floor of the legacy path holds (it was 6e-6 with the rank-one matrices)
+        rep = oracle.parity_report(g[i], c, abs_floor=oracle.ABS_FLOOR_MELANGE_LIT_OUTPUT)
+        print("melange job", j, "max abs err", rep.get("max_abs_err"), "rel peak", rep["max_err_rel_peak"])
         _check(rep, ("melange job", j))
         assert rep["max_err_rel_peak"] < 1e-5
