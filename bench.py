@@ -279,7 +279,7 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", choices=["engines", "batch"], default="engines",
                     help="engines = configs[1] replicated per configs[4] (the metric's config); batch = configs[3] sharded over the ranks")
-    ap.add_argument("--instances", type=int, default=int(os.environ.get("OW_BENCH_INSTANCES", "65536")), help="engine instances per GPU")
+    ap.add_argument("--instances", type=int, default=int(os.environ.get("OW_BENCH_INSTANCES", "131072")), help="engine instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip pcie_inclusive / config4_literal / single_instance / batch objects")
     ap.add_argument("--preamp", choices=["legacy", "melange"], default="legacy",
