@@ -716,7 +716,7 @@ __global__ __launch_bounds__(PA_WPB * 64, 2) void k_post_mpa(const OwConsts* __r
     }
     PaScal sc;
     pa_load(sc, W, role, pa, I, e);
-    bool nan_fired = false;
+    bool bad_any = false;                                                 // output NaN guard fired in this block (role-0 lane)
     for (int n = 0; n < L; ++n) {
         double y[2] = {0.0, 0.0};
         for (int j = 0; j < osr; ++j) {
@@ -747,15 +747,16 @@ __global__ __launch_bounds__(PA_WPB * 64, 2) void k_post_mpa(const OwConsts* __r
             // 4 bytes per engine per output sample, straight to its row: 33 MB per block at 16 384 engines against >= 100 ms of
             // solver time -- not worth 8 KB of LDS for a transposing tile
             if (valid) out[(size_t)e * Lout + n] = f;
-            PL(PL_X) = bad ? 1.0 : 0.0;                                           // ... the engine's other lanes need to know: power_amp.reset()
+            bad_any = bad_any || bad;
         }
-        PA_SYNC();
-        if (__builtin_expect(PL(PL_X) != 0.0, 0)) {
-            pa_init_state(sc, W, role, settled, C);
-            pa_rails_reset(sc);
-            nan_fired = true;
-        }
-        PA_SYNC();
+    }
+    // engine.rs:450-458 resets preamp, oversampler and POWER AMP at the faulty output sample -- but render_voices_to_preamp_out has
+    // run all three over the whole block before the speaker loop starts (engine.rs:432-434), so those resets act on the post-block
+    // state: here, at the block's end.  Only the speaker is reset in-sample (above).
+    const bool nan_fired = __shfl((int)bad_any, lane & 7) != 0;          // from the engine's role-0 lane (same wavefront)
+    if (__builtin_expect(nan_fired, 0)) {
+        pa_init_state(sc, W, role, settled, C);
+        pa_rails_reset(sc);
     }
     if (valid) pa_store(sc, W, role, pa, I, e);
     if (!valid || role != 0) return;

@@ -57,6 +57,54 @@ def test_setter_then_reset_without_a_render_in_between(hiplib, oracle, preamp_ki
     g.close()
 
 
+@pytest.mark.parametrize("power_amp_kind", [0, 1])
+def test_output_nan_guard_and_the_blocks_after_it(hiplib, oracle, power_amp_kind):
+    """engine.rs:450-458 with a real non-finite output: an unbounded volume (set_volume does not clamp, engine.rs:378-380) makes every
+    sample of a block non-finite -> 0.0 out, speaker reset in-sample; preamp, oversampler and power amp have processed the whole block
+    before the speaker loop (engine.rs:432-434), so their resets land on the post-block state.  The blocks AFTER the guard are compared
+    with the oracle on the poisoned engine and on its untouched neighbour, for both power amps (no test covered parity after
+    a guard fires)."""
+    import openwurli_amd as ow
+    sr, n = 48000.0, 2
+    g = ow.EnginePool(sr, n, power_amp_kind=power_amp_kind)
+    cs = [oracle.OracleEngine(sr, power_amp_kind=power_amp_kind) for _ in range(n)]
+    g.set_sample_rate(sr)
+    for c in cs:
+        c.set_sample_rate(sr)
+    for k in range(n):
+        for e in (g[k], cs[k]):
+            e.set_tremolo_depth(0.6)
+            for note in (48, 60, 64, 67):
+                e.note_on(note + k, 0.8)
+
+    def compare(tag, blocks, length=256):
+        worst = 0.0
+        for b in range(blocks):
+            go = g.render(length)
+            for k in range(n):
+                co = cs[k].render(length)
+                rep = oracle.parity_report(go[k], co, abs_floor=oracle.ABS_FLOOR_OUTPUT)
+                assert rep["n_bad"] == 0, (tag, b, k, rep)
+                worst = max(worst, float(np.max(np.abs(co))))
+        return go, worst
+    compare("before", 4)
+    for e in (g[0], cs[0]):
+        e.set_volume(float("inf"))
+    go, _ = compare("poisoned block", 2)
+    assert np.all(go[0] == 0.0) and np.max(np.abs(go[1])) > 1e-3          # silence from the guard; the neighbour plays on
+    assert g[0].diag().output_nan_resets >= 1 and g[1].diag().output_nan_resets == 0
+    for e in (g[0], cs[0]):
+        e.set_volume(0.5)
+    # the smoother walks inf -> NaN -> 0.5 over its ramp, the guard keeps firing until it lands; then the engine must come back from
+    # the reset states exactly like the reference does
+    _, peak = compare("recovery", 10)
+    assert peak > 1e-3
+    for e in (g[0], cs[0]):
+        e.note_on(72, 0.9)
+    compare("new note after the guard", 6)
+    g.close()
+
+
 def test_render_failure_is_silence_and_is_reported(hiplib):
     import openwurli_amd as ow
     p = ow.EnginePool(48000.0, 5)
