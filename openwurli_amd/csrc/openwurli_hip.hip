@@ -239,6 +239,7 @@ struct ow_pool {
     double* d_pa_tap = nullptr;       // test tap: amp output per chain-rate sample, [2 * Lcap][I] (ow_test_pool_enable_power_amp_tap)
     size_t pa_tap_cap = 0;
     double* d_mel_settled = nullptr;  // melange preamp: settled codegen-rate state (18 doubles)
+    double* d_mel_lu = nullptr;       // literal kernel: LU workspace of the generic rebuild, [ceil(I/32) + OW_MAX_SLICES + 1][12][12][32]
     double* d_noise = nullptr;        // melange preamp: thermal-noise state of the main solver states, [NZ_COUNT][I]
     double* d_sum = nullptr;
     double* d_rbuf = nullptr;
@@ -814,7 +815,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         if (sne > 0) {
             if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one())
                 owdev::k_preamp_mel_lit<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
-                                                                                 p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne, melange_generic_only() ? 1 : 0);
+                                                                                 p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne, melange_generic_only() ? 1 : 0, p->d_mel_lu);
             else if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)
                 owdev::k_preamp_mel<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
                                                                              p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne);
@@ -1047,6 +1048,7 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     owdev::k_note_table<<<dim3(1), dim3(64), 0, p->stream>>>(p->d_nt);
     if (preamp_kind == OW_PREAMP_MELANGE12) {
         HIP_OK(hipMalloc(&p->d_mel_settled, sizeof(double) * 18));
+        HIP_OK(hipMalloc(&p->d_mel_lu, sizeof(double) * 12 * 12 * 32 * ((size_t)(n_engines + 31) / 32 + OW_MAX_SLICES + 1)));
         mel_settled_to_device(device, p->d_mel_settled, p->stream);
         // Noise streams: the reference clones one process-wide state whose RNGs were seeded from the clock (master seed 0,
         // gen_preamp.rs:1512-1521 via melange_adapter.rs:12-29), so every engine of a process starts on the same streams.
@@ -1092,6 +1094,7 @@ void pool_destroy(ow_pool* p) {
     free_stream_buffers(p);
     hipFree(p->dK); hipFree(p->dK48); hipFree(p->d_nt); hipFree(p->d_vrec); hipFree(p->d_cs);
     if (p->d_mel_settled) hipFree(p->d_mel_settled);
+    if (p->d_mel_lu) hipFree(p->d_mel_lu);
     if (p->d_noise) hipFree(p->d_noise);
     if (p->dPa) hipFree(p->dPa);
     if (p->d_pa) hipFree(p->d_pa);

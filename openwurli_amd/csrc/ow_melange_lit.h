@@ -20,7 +20,7 @@
 
 namespace owdev {
 
-#define OW_LCHUNK 16    // voice-sum staging tile: 32 rows x 16 samples, so that LDS stays under 80 KB (two wavefronts per CU)
+#define OW_LCHUNK 8     // voice-sum staging tile: 32 rows x 8 samples, so that LDS stays under 40 KB (four workgroups = one wavefront per SIMD per CU)
 #define MLU(r, c) lu[((r) * 12 + (c)) * 32]
 #define MS(r, c) S[((r) * 12 + (c)) * 32]
 #define PERM(p, r) ((int)(((p) >> (4 * (r))) & 15ull))
@@ -296,9 +296,8 @@ __global__ __launch_bounds__(64) void k_preamp_mel_lit(const OwConsts* __restric
                                                        const double* __restrict__ settled, const OwEngineArgs* __restrict__ args,
                                                        const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const double* __restrict__ rbuf,
                                                        const uint32_t* __restrict__ trem_lead, double* __restrict__ pre, double* __restrict__ noise, int I, int L,
-                                                       int Lcap, int e0, int ne, int generic_only) {
+                                                       int Lcap, int e0, int ne, int generic_only, double* __restrict__ lu_scratch) {
     __shared__ double tile[32 * (OW_LCHUNK + 1)];
-    __shared__ double LU_all[12 * 12 * 32];
     __shared__ double S_all[12 * 12 * 32];
     const int lane = threadIdx.x;
     const int el = lane & 31, role = lane >> 5;
@@ -309,7 +308,10 @@ __global__ __launch_bounds__(64) void k_preamp_mel_lit(const OwConsts* __restric
     const int osr = K->oversample ? 2 : 1;
     const int er_col = (int)trem_lead[ec];
     const double alpha = 2.0 * (K->os_sr * 1.0);                    // gen_preamp.rs:1991-1992
-    double* lu = LU_all + el;
+    // The LU workspace is only touched by the generic rebuild (the fallback of the fast path): it lives in HBM, one [12][12][32] slab
+    // per workgroup (slabs of disjoint engine ranges are disjoint: ceil(e0/32) + block), so that LDS holds S alone -- 39 KB, four
+    // workgroups per CU, every SIMD busy (with LU in LDS: two workgroups, half the SIMDs idle; 52.8 -> see DESIGN).
+    double* lu = lu_scratch + ((size_t)((e0 + 31) / 32) + blockIdx.x) * (12 * 12 * 32) + el;
     double* S = S_all + el;
 
     MelSt st;
