@@ -35,6 +35,9 @@ enum { OW_PREAMP_LEGACY8 = 0, OW_PREAMP_MELANGE12 = 1 };
 /* power amp selection (crates/openwurli-dsp/Cargo.toml:9-17: `legacy-power-amp` is a default feature; a `--no-default-features` build
  * gets the melange-generated 7-BJT Class-AB solver with rail dynamics, power_amp.rs:279-465 + gen_power_amp.rs) */
 enum { OW_POWER_AMP_BEHAVIORAL = 0, OW_POWER_AMP_MELANGE = 1 };
+/* tremolo oscillator selection (crates/openwurli-dsp/Cargo.toml:18 `legacy-tremolo`, tremolo.rs:8,53-57,80-90,170-178): the default is the
+ * melange-generated Twin-T circuit; the legacy build replaces it by a half-wave rectified 5.63 Hz sine LFO in front of the same CdS model */
+enum { OW_TREMOLO_TWIN_T = 0, OW_TREMOLO_LEGACY_LFO = 1 };
 
 /* Introspection block (engine.rs:606-670 test/inspection helpers + diag counters of the solvers). */
 typedef struct ow_diag {
@@ -58,6 +61,7 @@ void ow_clear_error(void);
  * ow_engine_set_sample_rate (what the plugin's initialize() does, plugin/src/lib.rs:96-97). */
 ow_pool* ow_pool_new(double sample_rate, size_t n_engines, int device, int preamp_kind);       /* behavioural power amp */
 ow_pool* ow_pool_new_with(double sample_rate, size_t n_engines, int device, int preamp_kind, int power_amp_kind);
+ow_pool* ow_pool_new_kinds(double sample_rate, size_t n_engines, int device, int preamp_kind, int power_amp_kind, int tremolo_kind);
 void ow_pool_free(ow_pool*);
 size_t ow_pool_size(const ow_pool*);
 ow_engine* ow_pool_engine(ow_pool*, size_t index);
@@ -101,6 +105,7 @@ void ow_pool_last_kernel_ms(const ow_pool*, float ms[5]);
 /* ---- engines: the WurliEngine API (engine.rs) -------------------------------------------- */
 ow_engine* ow_engine_new(double sample_rate, int device, int preamp_kind);        /* WurliEngine::new        :194 */
 ow_engine* ow_engine_new_with(double sample_rate, int device, int preamp_kind, int power_amp_kind);
+ow_engine* ow_engine_new_kinds(double sample_rate, int device, int preamp_kind, int power_amp_kind, int tremolo_kind);   /* every cargo feature of the crate as a runtime kind */
 void ow_engine_free(ow_engine*);                                                  /* Drop (pool-of-one only)      */
 void ow_engine_set_sample_rate(ow_engine*, double sample_rate);                   /* set_sample_rate         :272 */
 void ow_engine_reset(ow_engine*);                                                 /* reset                   :231 */

@@ -77,6 +77,7 @@ SYMBOLS = {
     "ow_clear_error": (None, []),
     "ow_pool_new": (_VP, [C.c_double, C.c_size_t, C.c_int, C.c_int]),
     "ow_pool_new_with": (_VP, [C.c_double, C.c_size_t, C.c_int, C.c_int, C.c_int]),
+    "ow_pool_new_kinds": (_VP, [C.c_double, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ow_pool_free": (None, [_VP]),
     "ow_pool_size": (C.c_size_t, [_VP]),
     "ow_pool_engine": (_VP, [_VP, C.c_size_t]),
@@ -95,6 +96,7 @@ SYMBOLS = {
     "ow_pool_last_kernel_ms": (None, [_VP, C.POINTER(C.c_float)]),
     "ow_engine_new": (_VP, [C.c_double, C.c_int, C.c_int]),
     "ow_engine_new_with": (_VP, [C.c_double, C.c_int, C.c_int, C.c_int]),
+    "ow_engine_new_kinds": (_VP, [C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ow_engine_set_rail_sag": (None, [_VP, C.c_int]),
     "ow_engine_rail_sag_enabled": (C.c_int, [_VP]),
     "ow_engine_power_amp_diag": (None, [_VP, C.POINTER(OwPowerAmpDiag)]),

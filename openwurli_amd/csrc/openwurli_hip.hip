@@ -233,6 +233,7 @@ struct ow_pool {
     double* d_vrec = nullptr;
     double* d_cs = nullptr;
     int power_amp_kind = 0;           // OW_POWER_AMP_BEHAVIORAL / OW_POWER_AMP_MELANGE
+    int tremolo_kind = 0;             // OW_TREMOLO_TWIN_T / OW_TREMOLO_LEGACY_LFO (the reference's `legacy-tremolo` cargo feature)
     OwPaConsts* dPa = nullptr;        // melange power amp: constants at the chain rate
     double* d_pa = nullptr;           // melange power amp: per-engine state, [PAS_COUNT][I]
     double* d_pa_settled = nullptr;   // settled circuit state (PAS_CIRCUIT_END doubles), power_amp.rs:288-296
@@ -517,7 +518,9 @@ void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<do
     const int nl = p->n_lead;          // == 1: the range is one phase group
     const int blocks = (nl + 63) / 64;
     const long long n_settle = (long long)owhip::sat_u32(p->hc.os_sr * 2.0);
-    if (trem_wide(nl)) {   // few oscillators: four lanes per engine (ow_trem_wide.h); the 2-second settle is pure serial latency
+    if (p->tremolo_kind == OW_TREMOLO_LEGACY_LFO) {
+        // legacy-tremolo build: nothing to settle, the LFO starts at phase 0 (k_chain_init)
+    } else if (trem_wide(nl)) {   // few oscillators: four lanes per engine (ow_trem_wide.h); the 2-second settle is pure serial latency
         owdev::k_tremolo_wide<true><<<dim3((nl + 15) / 16), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, nullptr, I, 50LL, p->d_leaders, nl);
         owdev::k_tremolo_wide<true><<<dim3((nl + 15) / 16), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, nullptr, I, n_settle, p->d_leaders, nl);
     } else {
@@ -531,8 +534,10 @@ void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<do
 void upload_consts(ow_pool* p, double sr, int preamp_kind) {
     invalidate_spec(p);
     owhip::build_consts(p->hc, sr, preamp_kind);
+    p->hc.tremolo_kind = (uint32_t)p->tremolo_kind;
     OwConsts k48;
     owhip::build_consts(k48, 24000.0, preamp_kind);  // os_sr = 48 kHz -> codegen-rate tremolo matrices
+    k48.tremolo_kind = (uint32_t)p->tremolo_kind;
     HIP_OK(hipMemcpyAsync(p->dK, &p->hc, sizeof(OwConsts), hipMemcpyHostToDevice, p->stream));
     HIP_OK(hipMemcpyAsync(p->dK48, &k48, sizeof(OwConsts), hipMemcpyHostToDevice, p->stream));
     if (p->power_amp_kind == OW_POWER_AMP_MELANGE) {
@@ -654,7 +659,8 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
 // one oscillator per phase group of the range (p->d_leaders, trem_leader_list)
 static void launch_tremolo(ow_pool* p, hipStream_t tt, double* rbuf, int n_os) {
     const int I = (int)p->I, nl = p->n_lead;
-    if (trem_wide(nl)) owdev::k_tremolo_wide<false><<<dim3((nl + 15) / 16), dim3(64), 0, tt>>>(p->dK, p->d_cs, rbuf, I, (long long)n_os, p->d_leaders, nl);
+    if (p->tremolo_kind == OW_TREMOLO_LEGACY_LFO) owdev::k_tremolo_lfo<<<dim3((nl + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, rbuf, I, (long long)n_os, p->d_leaders, nl, 0LL);
+    else if (trem_wide(nl)) owdev::k_tremolo_wide<false><<<dim3((nl + 15) / 16), dim3(64), 0, tt>>>(p->dK, p->d_cs, rbuf, I, (long long)n_os, p->d_leaders, nl);
     else owdev::k_tremolo<<<dim3((nl + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, rbuf, I, n_os, p->d_leaders, nl);
 }
 
@@ -979,8 +985,10 @@ void push_op(ow_engine* en, uint8_t type, int slot, uint8_t note, bool mlp, uint
     en->touch();
 }
 
-ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int preamp_kind, int power_amp_kind = OW_POWER_AMP_BEHAVIORAL) {
+ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int preamp_kind, int power_amp_kind = OW_POWER_AMP_BEHAVIORAL,
+                     int tremolo_kind = OW_TREMOLO_TWIN_T) {
     if (!(sample_rate > 0.0) || n_engines == 0) throw std::runtime_error("invalid sample rate or engine count");
+    if (tremolo_kind != OW_TREMOLO_TWIN_T && tremolo_kind != OW_TREMOLO_LEGACY_LFO) throw std::runtime_error("unknown tremolo_kind");
     if (preamp_kind != OW_PREAMP_LEGACY8 && preamp_kind != OW_PREAMP_MELANGE12) throw std::runtime_error("unknown preamp_kind");
     if (power_amp_kind != OW_POWER_AMP_BEHAVIORAL && power_amp_kind != OW_POWER_AMP_MELANGE) throw std::runtime_error("unknown power_amp_kind");
     int ndev = 0;
@@ -991,6 +999,7 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     p->device = device;
     p->I = n_engines;
     p->power_amp_kind = power_amp_kind;
+    p->tremolo_kind = tremolo_kind;
     HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&p->stream_trem, hipStreamNonBlocking));
     for (auto& e : p->ev) HIP_OK(hipEventCreate(&e));
@@ -1148,6 +1157,10 @@ ow_pool* ow_pool_new(double sample_rate, size_t n_engines, int device, int pream
     try { return pool_create(sample_rate, n_engines, device, preamp_kind); }
     catch (const std::exception& ex) { set_err(std::string("ow_pool_new: ") + ex.what()); return nullptr; }
 }
+ow_pool* ow_pool_new_kinds(double sample_rate, size_t n_engines, int device, int preamp_kind, int power_amp_kind, int tremolo_kind) {
+    try { return pool_create(sample_rate, n_engines, device, preamp_kind, power_amp_kind, tremolo_kind); }
+    catch (const std::exception& ex) { set_err(std::string("ow_pool_new_kinds: ") + ex.what()); return nullptr; }
+}
 ow_pool* ow_pool_new_with(double sample_rate, size_t n_engines, int device, int preamp_kind, int power_amp_kind) {
     try { return pool_create(sample_rate, n_engines, device, preamp_kind, power_amp_kind); }
     catch (const std::exception& ex) { set_err(std::string("ow_pool_new_with: ") + ex.what()); return nullptr; }
@@ -1292,6 +1305,12 @@ int ow_pool_read_tremolo_r(ow_pool* p, double* out_host, size_t out_stride, size
 // ---- engines ------------------------------------------------------------------------------------
 ow_engine* ow_engine_new(double sample_rate, int device, int preamp_kind) {
     ow_pool* p = ow_pool_new(sample_rate, 1, device, preamp_kind);
+    if (!p) return nullptr;
+    p->engines[0]->owns_pool = true;
+    return p->engines[0];
+}
+ow_engine* ow_engine_new_kinds(double sample_rate, int device, int preamp_kind, int power_amp_kind, int tremolo_kind) {
+    ow_pool* p = ow_pool_new_kinds(sample_rate, 1, device, preamp_kind, power_amp_kind, tremolo_kind);
     if (!p) return nullptr;
     p->engines[0]->owns_pool = true;
     return p->engines[0];
@@ -1579,7 +1598,10 @@ int ow_test_pool_stagger_tremolo(ow_pool* p, size_t n_groups) {
         // group g runs g * step samples ahead of group 0; the steps cover one period of the ~5.6 Hz oscillator
         const long long period = (long long)(p->hc.os_sr / 5.6);
         const long long step = std::max<long long>(1, period / (long long)G);
-        owdev::k_trem_settle<<<dim3((p->n_lead + 63) / 64), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, (int)I, p->d_leaders, p->n_lead, 0LL, step);
+        if (p->tremolo_kind == OW_TREMOLO_LEGACY_LFO)
+            owdev::k_tremolo_lfo<<<dim3((p->n_lead + 63) / 64), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, nullptr, (int)I, 0LL, p->d_leaders, p->n_lead, step);
+        else
+            owdev::k_trem_settle<<<dim3((p->n_lead + 63) / 64), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, (int)I, p->d_leaders, p->n_lead, 0LL, step);
         HIP_OK(hipGetLastError());
         HIP_OK(hipStreamSynchronize(p->stream));
         return 0;

@@ -135,6 +135,7 @@ static void build_tremolo_consts(OwConsts& c) {
     c.ldr_release = std::exp(-1.0 / (0.035 * rate));
     c.ln_r_max = std::log(1000000.0);
     c.ln_min_minus_max = std::log(9000.0) - std::log(1000000.0);
+    c.lfo_phase_inc = 2.0 * 3.14159265358979323846264338327950288 * 5.63 / rate;      // tremolo.rs:86
 }
 
 // Gauss-Jordan on [A | I] with partial pivoting (dk_preamp_legacy.rs:122-168).

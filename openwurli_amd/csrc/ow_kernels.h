@@ -495,6 +495,7 @@ __global__ __launch_bounds__(64) void k_chain_init(const OwConsts* __restrict__ 
     const double dci[4] = {7.72841164985201955e-5, 3.86420577732601037e-7, 2.20372764986731876e-3, 1.10186382445765932e-5};
     for (int i = 0; i < 7; ++i) CSF(CS_T_V + i) = dc[i];
     for (int i = 0; i < 4; ++i) { CSF(CS_T_I + i) = dci[i]; CSF(CS_T_IP + i) = dci[i]; }
+    if (K->tremolo_kind == 1u) CSF(CS_T_V) = 0.0;     // legacy-tremolo build: row 0 is the LFO phase, new() and reset() start it at 0 (tremolo.rs:84,196)
     CSF(CS_T_ENV) = 0.0;
     CSF(CS_T_RLDR) = 1000000.0;
     if (mode == 1) CSF(CS_T_BE) = bitsd(0ull);
@@ -611,6 +612,32 @@ __global__ __launch_bounds__(64) void k_tremolo(const OwConsts* __restrict__ K, 
         rbuf[(size_t)i * I + e] = trem_cell_r(t, &P, K, &M + z);
     }
     trem_store(t, &P, cs, I, e);
+}
+
+// `--features legacy-tremolo` (tremolo.rs:8, 53-57, 80-90, 170-178): the behavioural sine LFO in place of the Twin-T circuit, same CdS
+// model behind it.  lane = tremolo phase group; the phase lives in row CS_T_V.  n_extra: leader idx steps idx * n_extra more samples
+// (the stagger test hook); rbuf may be null (stepping only).
+__global__ __launch_bounds__(64) void k_tremolo_lfo(const OwConsts* __restrict__ K, double* __restrict__ cs, double* __restrict__ rbuf, int I, long long n_os,
+                                                    const uint32_t* __restrict__ leaders, int n_lead, long long n_extra) {
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= n_lead) return;
+    const int e = (int)leaders[idx];
+    double phase = CSF(CS_T_V), env = CSF(CS_T_ENV), r_ldr = CSF(CS_T_RLDR);
+    const double inc = K->lfo_phase_inc, two_pi = 2.0 * 3.14159265358979323846264338327950288;
+    const long long n = n_os + n_extra * idx;
+    for (long long i = 0; i < n; ++i) {
+        const double lfo = sin(phase);
+        phase += inc;
+        if (phase >= two_pi) phase -= two_pi;
+        const double led = lfo > 0.0 ? lfo : 0.0;                               // f64::max(lfo, 0.0)
+        const double coeff = led > env ? K->ldr_attack : K->ldr_release;        // tremolo.rs:126-146, as trem_cell_r
+        env = led + coeff * (env - led);
+        const double drive = clampd(env, 0.0, 1.0);
+        if (drive < 1e-6) r_ldr = 1000000.0;
+        else r_ldr = exp(K->ln_r_max + K->ln_min_minus_max * pow(drive, 0.9));
+        if (rbuf) rbuf[(size_t)i * I + e] = r_ldr;
+    }
+    CSF(CS_T_V) = phase; CSF(CS_T_ENV) = env; CSF(CS_T_RLDR) = r_ldr;
 }
 
 // ------------------------------------------------------------------ preamp stream

@@ -125,6 +125,8 @@ struct OwConsts {
     double t_a_neg[7][7], t_s[7][7], t_k[4][4], t_s_ni[7][4];
     double t_a_neg_be[7][7], t_s_be[7][7], t_k_be[4][4], t_s_ni_be[7][4];
     double ldr_attack, ldr_release, ln_r_max, ln_min_minus_max;  // tremolo.rs:104-112
+    double lfo_phase_inc;                      // legacy-tremolo build: 2 pi 5.63 / os_sr (tremolo.rs:76,86)
+    uint32_t tremolo_kind, pad_tk;             // OW_TREMOLO_TWIN_T | OW_TREMOLO_LEGACY_LFO
     // legacy DK preamp at os_sr (dk_preamp_legacy.rs:269-366)
     double p_s[8][8], p_a_neg[8][8], p_k[2][2], p_two_w[8], p_s_fb_col[8], p_s_fb_fb, p_nv_sfb[2], p_sfb_ni[2];
     double p_g_cin, p_c_cin, p_gc_1pc;

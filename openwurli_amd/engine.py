@@ -122,9 +122,9 @@ class _EngineHandle:
 class WurliEngine(_EngineHandle):
     """One engine on one GPU (a pool of one).  ``WurliEngine(sr)`` == ``WurliEngine::new(sr)``."""
 
-    def __init__(self, sample_rate, device=0, preamp_kind=0, power_amp_kind=0):
+    def __init__(self, sample_rate, device=0, preamp_kind=0, power_amp_kind=0, tremolo_kind=0):
         lib = binding.load_library()
-        h = lib.ow_engine_new_with(float(sample_rate), int(device), int(preamp_kind), int(power_amp_kind))
+        h = lib.ow_engine_new_kinds(float(sample_rate), int(device), int(preamp_kind), int(power_amp_kind), int(tremolo_kind))
         if not h:
             raise OwError(binding.take_error(lib))
         super().__init__(lib, h)
@@ -161,9 +161,9 @@ class WurliEngine(_EngineHandle):
 class EnginePool:
     """I independent engines rendered in lock-step (lane = engine on the GPU)."""
 
-    def __init__(self, sample_rate, n_engines, device=0, preamp_kind=0, power_amp_kind=0):
+    def __init__(self, sample_rate, n_engines, device=0, preamp_kind=0, power_amp_kind=0, tremolo_kind=0):
         self._lib = binding.load_library()
-        h = self._lib.ow_pool_new_with(float(sample_rate), int(n_engines), int(device), int(preamp_kind), int(power_amp_kind))
+        h = self._lib.ow_pool_new_kinds(float(sample_rate), int(n_engines), int(device), int(preamp_kind), int(power_amp_kind), int(tremolo_kind))
         if not h:
             raise OwError(binding.take_error(self._lib))
         self._h = C.c_void_p(h)

@@ -84,9 +84,10 @@ struct WurliEngine {
     uint64_t nan_guard_fires = 0;
 
     // engine.rs:194-229
-    explicit WurliEngine(double sr, int kind = 0, int pa_kind = 0) {
+    explicit WurliEngine(double sr, int kind = 0, int pa_kind = 0, int trem_kind = 0) {
         preamp_kind = kind;
         power_amp_kind = pa_kind;
+        tremolo.kind = trem_kind;                      // `--features legacy-tremolo` build
         oversample = sr < 88200.0;
         const double os_sr = oversample ? sr * 2.0 : sr;
         const uint32_t ramp = ramp_samples_for_rate(sr);

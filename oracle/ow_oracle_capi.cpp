@@ -22,6 +22,7 @@ extern "C" {
 void* owo_engine_new(double sr) { return new WurliEngine(sr); }
 void* owo_engine_new_kind(double sr, int preamp_kind) { return new WurliEngine(sr, preamp_kind); }
 void* owo_engine_new_kinds(double sr, int preamp_kind, int power_amp_kind) { return new WurliEngine(sr, preamp_kind, power_amp_kind); }
+void* owo_engine_new_kinds3(double sr, int preamp_kind, int power_amp_kind, int tremolo_kind) { return new WurliEngine(sr, preamp_kind, power_amp_kind, tremolo_kind); }
 void owo_engine_free(void* e) { delete (WurliEngine*)e; }
 void owo_engine_set_rail_sag(void* e, int on) { ((WurliEngine*)e)->set_rail_sag(on != 0); }
 int owo_engine_rail_sag_enabled(void* e) { return ((WurliEngine*)e)->rail_sag_enabled() ? 1 : 0; }
@@ -257,6 +258,14 @@ void owo_preamp_run(double sr, const double* x, const double* r, double r_static
 // tremolo: n shunt-impedance samples at depth d after Tremolo::new(d, sr); optional osc voltage tap
 void owo_tremolo_run(double depth, double sr, double* r_out, size_t n) {
     Tremolo* t = new Tremolo();
+    t->init(depth, sr);
+    for (size_t i = 0; i < n; ++i) r_out[i] = t->process();
+    delete t;
+}
+// the same for a given oscillator kind (1 = the `legacy-tremolo` LFO)
+void owo_tremolo_run_kind(int kind, double depth, double sr, double* r_out, size_t n) {
+    Tremolo* t = new Tremolo();
+    t->kind = kind;
     t->init(depth, sr);
     for (size_t i = 0; i < n; ++i) r_out[i] = t->process();
     delete t;

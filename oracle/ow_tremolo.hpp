@@ -472,8 +472,13 @@ struct Tremolo {
     TremCircuit osc;
     double sample_rate = 0, depth = 0, r_ldr = 0, ldr_envelope = 0, ldr_attack = 0, ldr_release = 0;
     double r_ldr_max = 1000000.0, gamma = 0.9, ln_r_max = 0, ln_min_minus_max = 0;
+    // `--features legacy-tremolo` (tremolo.rs:8, 53-57, 80-90, 170-178, 195-198): behavioural sine LFO instead of the Twin-T circuit.
+    // A cargo feature in the reference, a construction-time kind here (set before init()).
+    int kind = 0;                      // 0 = Twin-T circuit (default), 1 = legacy LFO
+    double phase = 0, phase_inc = 0;
 
     void settle_osc() {  // tremolo.rs:92-102 / 215-222
+        if (kind == 1) { phase = 0.0; return; }                  // legacy: new() and reset() both start the LFO at phase 0
         osc.init_default();
         if (std::fabs(sample_rate - TREM_SAMPLE_RATE) > 0.5) osc.set_sample_rate(sample_rate);
         const size_t n = (size_t)as_u64(sample_rate * 2.0);
@@ -481,6 +486,7 @@ struct Tremolo {
     }
     void init(double depth_, double sr) {
         sample_rate = sr;
+        phase_inc = 2.0 * 3.14159265358979323846264338327950288 * 5.63 / sr;      // tremolo.rs:86, LEGACY_RATE_HZ :76
         settle_osc();
         depth = depth_;
         r_ldr = 1000000.0;
@@ -501,9 +507,18 @@ struct Tremolo {
         const double low = r_lower > 0.0 ? r_lower * branch / (r_lower + branch) : 0.0;
         return top + low;
     }
-    double process() {  // tremolo.rs:121-146
+    double oscillator_drive() {  // tremolo.rs:170-186
+        if (kind == 1) {
+            const double lfo = std::sin(phase);
+            phase += phase_inc;
+            if (phase >= 2.0 * 3.14159265358979323846264338327950288) phase -= 2.0 * 3.14159265358979323846264338327950288;
+            return lfo > 0.0 ? lfo : 0.0;          // f64::max(lfo, 0.0): half-wave rectify (NaN -> 0.0, like max)
+        }
         const double v_out = osc.process_sample(0.0);
-        const double led_drive = rclamp((10.95 - v_out) / (10.95 - 0.70), 0.0, 1.0);
+        return rclamp((10.95 - v_out) / (10.95 - 0.70), 0.0, 1.0);
+    }
+    double process() {  // tremolo.rs:121-146
+        const double led_drive = oscillator_drive();
         const double coeff = led_drive > ldr_envelope ? ldr_attack : ldr_release;
         ldr_envelope = led_drive + coeff * (ldr_envelope - led_drive);
         const double drive = rclamp(ldr_envelope, 0.0, 1.0);

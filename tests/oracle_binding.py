@@ -25,6 +25,7 @@ def _configure(L):
         L.owo_engine_new.restype = C.c_void_p
         L.owo_engine_new_kind.restype = C.c_void_p
         L.owo_engine_new_kinds.restype = C.c_void_p
+        L.owo_engine_new_kinds3.restype = C.c_void_p
         for name in ("owo_midi_to_freq", "owo_tip_mass_ratio", "owo_reed_length_mm", "owo_pickup_displacement_scale",
                      "owo_fundamental_decay_rate", "owo_output_scale", "owo_velocity_exponent", "owo_velocity_scurve",
                      "owo_register_trim_db", "owo_pickup_rms_proxy", "owo_freq_detune", "owo_dwell_time", "owo_onset_ramp_time",
@@ -66,9 +67,9 @@ def _p(a):
 class OracleEngine:
     """CPU restatement of WurliEngine with the reference's method names."""
 
-    def __init__(self, sr, perturbed=False, preamp_kind=0, power_amp_kind=0):
+    def __init__(self, sr, perturbed=False, preamp_kind=0, power_amp_kind=0, tremolo_kind=0):
         self.L = lib_perturbed() if perturbed else lib()
-        self.h = C.c_void_p(self.L.owo_engine_new_kinds(C.c_double(sr), int(preamp_kind), int(power_amp_kind)))
+        self.h = C.c_void_p(self.L.owo_engine_new_kinds3(C.c_double(sr), int(preamp_kind), int(power_amp_kind), int(tremolo_kind)))
 
     def close(self):
         if self.h:

@@ -867,3 +867,33 @@ def test_tremolo_am_through_preamp_matches_published_swing(oracle):
     rate = np.sum((rr[:-1] < 0) & (rr[1:] >= 0)) / 3.0
     assert 4.0 <= swing <= 8.0 and 4.5 <= rate <= 7.5
     assert abs(swing - 7.33) < 0.02, swing
+
+
+def test_legacy_tremolo_lfo_kind(oracle):
+    """`--features legacy-tremolo` (tremolo.rs:8,76,80-90,170-178): half-wave rectified 5.63 Hz sine in front of the shared CdS model.
+    The oracle's LFO kind (Tremolo::new(1.0, 96 kHz) then process()) against an independent Python restatement of those lines at depth
+    1.0 (where the shunt is 50 kOhm || (680 + r_ldr)), and the constants the reference documents: dark 1 MOhm, ~9 kOhm floor, 5.63 Hz."""
+    import math
+    os_sr, n = 96000.0, 48000
+    r = np.zeros(n)
+    oracle.lib().owo_tremolo_run_kind(1, C.c_double(1.0), C.c_double(os_sr), r.ctypes.data_as(C.c_void_p), C.c_size_t(n))
+    inc = 2.0 * math.pi * 5.63 / os_sr
+    att, rel = math.exp(-1.0 / (0.0025 * os_sr)), math.exp(-1.0 / (0.035 * os_sr))
+    ph, env, want = 0.0, 0.0, []
+    for _ in range(n):
+        lfo = math.sin(ph)
+        ph += inc
+        if ph >= 2.0 * math.pi:
+            ph -= 2.0 * math.pi
+        led = max(lfo, 0.0)
+        env = led + (att if led > env else rel) * (env - led)
+        d = min(max(env, 0.0), 1.0)
+        cell = 1e6 if d < 1e-6 else math.exp(math.log(1e6) + (math.log(9000.0) - math.log(1e6)) * d ** 0.9)
+        branch = 680.0 + cell
+        want.append(50000.0 * branch / (50000.0 + branch))
+    want = np.array(want)
+    assert np.max(np.abs(r - want) / want) < 1e-12
+    assert want[0] > 47000.0                        # starts dark: 50 kOhm || 1.00068 MOhm
+    bright = r < 1.5e4
+    edges = np.flatnonzero(bright[1:] & ~bright[:-1])
+    assert abs(os_sr / np.diff(edges).mean() - 5.63) < 0.02
