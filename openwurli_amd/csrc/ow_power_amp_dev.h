@@ -256,11 +256,18 @@ __device__ __forceinline__ uint32_t pa_newton_body(double* __restrict__ W, const
             PL(PL_CAND + r0) = fabs(A[0]);                          // rows already used as pivots are never looked at again (perm)
             PL(PL_CAND + r1) = fabs(B[0]);
             PA_SYNC();
+            // the reference's scan (first strict maximum over logical rows col..15), with all sixteen candidates fetched at once: a
+            // rolled `for row = col + 1 ..` serialises sixteen LDS round trips per column, a third of the whole iteration
             int max_row = col;
             double max_val = PL(PL_CAND + PA_PERM(perm, col));
-            for (int row = col + 1; row < PA_M; ++row) {
-                const double v = PL(PL_CAND + PA_PERM(perm, row));
-                if (v > max_val) { max_val = v; max_row = row; }
+            double cand[PA_M];
+#pragma unroll
+            for (int row = 1; row < PA_M; ++row) cand[row] = PL(PL_CAND + PA_PERM(perm, row));
+#pragma unroll
+            for (int row = 1; row < PA_M; ++row) {
+                const bool take = row > col && cand[row] > max_val;
+                max_val = take ? cand[row] : max_val;
+                max_row = take ? row : max_row;
             }
             if (max_val < 1e-15) { singular = true; break; }
             if (max_row != col) {
