@@ -179,3 +179,49 @@ def test_behavioural_pool_reports_no_rails(hiplib):
     d = e.power_amp_diag()
     assert not e.rail_sag_enabled() and (d.clamp_count, d.nr_max_iter_count, d.peak_output_volts) == (0, 0, 0.0)
     e.close()
+
+
+def test_amp_alone_on_a_dense_performance_shares_every_guard_event(hiplib, oracle):
+    """The amp on IDENTICAL input, this time a realistic one: the preamp stream of the soak script (random dense play on four engines,
+    0.75 s, volumes up to 0.65) as the oracle computes it, fed to the oracle's amp (inside its engine) and to ow_debug_power_amp.
+    Under this script the divergence guard fires many times per engine; on equal input every one of those resets must land on the
+    same sample, and the outputs must agree to the pnjlim-logarithm bound -- which is what the engine-level comparison cannot show
+    once the two preamps differ by their floor (test_melange_power_amp_guard_timing_is_not_one_ulp_stable)."""
+    import ctypes as C
+    sr, length, n = 48000.0, 512, 4
+    # fresh engines (WurliEngine::new, no warm-up) so that the amp starts from its settled clone exactly like ow_debug_power_amp;
+    # two oracle engines per part in lock step: one hands out the preamp tap, the other the amp tap
+    a = [oracle.OracleEngine(sr, power_amp_kind=PA) for _ in range(n)]
+    b = [oracle.OracleEngine(sr, power_amp_kind=PA) for _ in range(n)]
+    rng = np.random.default_rng(99)
+    for k in range(n):
+        for e in (a[k], b[k]):
+            e.set_tremolo_depth(0.25 * k); e.set_volume(0.35 + 0.1 * k); e.set_speaker_character(0.3 * (k % 3))
+    held = [[] for _ in range(n)]
+    pre, amp = [[] for _ in range(n)], [[] for _ in range(n)]
+    for _ in range(int(0.75 * sr / length)):
+        for k in range(n):
+            if rng.random() < 0.08 + 0.03 * k:
+                note, vel = int(rng.integers(33, 97)), float(rng.uniform(0.2, 1.0))
+                for e in (a[k], b[k]):
+                    e.note_on(note, vel)
+                held[k].append(note)
+            if held[k] and rng.random() < 0.07:
+                note = held[k].pop(int(rng.integers(0, len(held[k]))))
+                for e in (a[k], b[k]):
+                    e.note_off(note)
+        for k in range(n):
+            _, _, p, _ = a[k].render_taps(length)
+            _, y = b[k].render_pa_tap(length)
+            pre[k].append(p); amp[k].append(y)
+    x = np.ascontiguousarray(np.stack([np.concatenate(p) for p in pre]) * 0.25)        # FIXED_CIRCUIT_DRIVE, engine.rs:544-546
+    want = np.stack([np.concatenate(y) for y in amp])
+    guards = [e.power_amp_diag()[3] for e in b]
+    out = np.zeros_like(x); taps = np.zeros(x.shape + (3,))
+    assert hiplib.ow_debug_power_amp(2.0 * sr, x.ctypes.data_as(C.c_void_p), x.shape[0], x.shape[1], 1, None, None, None,
+                                     out.ctypes.data_as(C.c_void_p), taps.ctypes.data_as(C.c_void_p), 0) == 0
+    print("guard resets per engine (oracle):", guards, " device:", taps[:, -1, 1].astype(int).tolist(),
+          " max |out - oracle|: %.3e" % np.max(np.abs(out - want)))
+    assert sum(guards) >= 4, guards                                                    # the script does exercise the guard
+    assert taps[:, -1, 1].astype(int).tolist() == guards
+    assert np.max(np.abs(out - want)) < 1e-11
