@@ -288,9 +288,19 @@ struct VoiceSteady {
     double q, ds, gain;
     double beta, revert, diffusion;   // the voice's own pickup beta / jitter constants (VF_BETA..), read once per kernel: a load inside the
                                       // sample loop is re-issued every sample (the noinline saturate call may write memory) and stalls the wave
-    uint64_t sample;
+    // The voice's sample counter only matters at every 16th sample (jitter, reed.rs:262) and every 1024th (renormalisation): the loop
+    // carries a countdown to the next multiple of 16 (compare + decrement per sample) instead of a 64-bit counter with two mask tests
+    // (7 VALU per voice-sample); the counter itself is rebuilt at those events and at the block's end.
+    uint64_t next_evt;        // sample index of the next jitter update
+    uint32_t cd;              // samples until it (0: this sample)
+    uint32_t renorm;          // this sample is also a renormalisation point
     uint32_t jitter_state;
 
+    OW_DEV void set_sample(uint64_t sample) {
+        cd = (16u - ((uint32_t)sample & 15u)) & 15u;
+        next_evt = sample + (uint64_t)cd;
+        renorm = 0u;
+    }
     OW_DEV void update_rotation() {
 #ifndef OW_STRICT_FP
 #pragma clang fp contract(fast)
@@ -311,7 +321,11 @@ struct VoiceSteady {
 #ifndef OW_STRICT_FP
 #pragma clang fp contract(fast)
 #endif
-        if (((uint32_t)sample & 15u) == 0u) {
+        if (cd == 0u) {
+            cd = 16u;
+            const uint64_t sample = next_evt;
+            next_evt += 16ull;
+            renorm = (((uint32_t)sample & 1023u) == 0u && sample > 0ull) ? 1u : 0u;      // reed.rs:292 (tested after the rotation, below)
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
                 jitter_state = lcg(jitter_state);
@@ -326,7 +340,6 @@ struct VoiceSteady {
 #ifndef OW_STRICT_FP
 #pragma clang fp contract(fast)
 #endif
-        const uint32_t lo = (uint32_t)sample;
         double sum = 0.0;
 #pragma unroll
         for (int m = 0; m < 7; ++m) {
@@ -340,7 +353,8 @@ struct VoiceSteady {
         const double x = 0.0 + sum;
         double y = x * ds;
         const double ay = fabs(y);
-        if ((lo & 1023u) == 0u && sample > 0ull) {
+        if (renorm) {
+            renorm = 0u;
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
                 const double r_sq = s[m] * s[m] + c[m] * c[m];
@@ -349,7 +363,7 @@ struct VoiceSteady {
                 c[m] *= r_inv;
             }
         }
-        sample += 1ull;
+        cd -= 1u;
         if (!(ay < 0.94)) y = pickup_saturate_hi(y, ay);
         return y;
     }
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict_
         }
         v.q = rec[VF_Q * 64]; v.ds = rec[VF_DS * 64]; v.gain = rec[VF_GAIN * 64];
         v.beta = rec[VF_BETA * 64]; v.revert = rec[VF_JREV * 64]; v.diffusion = rec[VF_JDIFF * 64];
-        v.sample = dbits(rec[VF_SAMPLE * 64]);
+        v.set_sample(dbits(rec[VF_SAMPLE * 64]));
         const uint64_t r = dbits(rec[VF_RNG * 64]);
         v.jitter_state = (uint32_t)r; noise_rng = (uint32_t)(r >> 32);
         v.update_rotation();
@@ -428,7 +442,7 @@ __global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict_
             all_quiet = all_quiet && (fabs(v.ae[i]) <= 1e-4);
         }
         rec[VF_Q * 64] = v.q;
-        rec[VF_SAMPLE * 64] = bitsd(v.sample);
+        rec[VF_SAMPLE * 64] = bitsd(dbits(rec[VF_SAMPLE * 64]) + (uint64_t)L);
         rec[VF_RNG * 64] = bitsd((uint64_t)v.jitter_state | ((uint64_t)noise_rng << 32));
         const unsigned long long bit = 1ull << w.slot;
         if (all_quiet) atomicOr((unsigned long long*)&eout[w.e].silent_mask, bit);   // damper inactive here: only the -80 dB test of Voice::is_silent
