@@ -364,7 +364,7 @@ struct VoiceSteady {
             }
         }
         cd -= 1u;
-        if (!(ay < 0.94)) y = pickup_saturate_hi(y, ay);
+        if (!(ay < 0.94)) y = pickup_saturate_hi(y);
         return y;
     }
     OW_DEV double pickup(double y) {                         // pickup.rs 1/(1-y) bilinear HPF + voice gain

@@ -384,7 +384,10 @@ __device__ __noinline__ __attribute__((const)) double onset_gain(double n, doubl
 }
 __device__ __noinline__ __attribute__((const)) double exp_neg(double x) { return exp(-x); }                         // reed.rs:238
 __device__ __noinline__ __attribute__((const)) double noise_fade_env(double t) { return 0.5 * (1.0 - cos(3.14159265358979323846 * t)); }  // hammer.rs:165
-__device__ __noinline__ __attribute__((const)) double pickup_saturate_hi(double y, double ay) {                      // pickup.rs:76-79
+// (one argument: with |y| passed in, the caller materialises it -- two instructions -- on every sample, ahead of the branch that is
+// taken once in a blue moon)
+__device__ __noinline__ __attribute__((const)) double pickup_saturate_hi(double y) {                                 // pickup.rs:76-79
+    const double ay = fabs(y);
     const double range = 0.98 - 0.94;
     return copysign(0.94 + range * tanh((ay - 0.94) / range), y);
 }
@@ -540,7 +543,7 @@ struct VoiceRegs {
         // pickup
         double y = x * ds;
         const double ay = fabs(y);
-        if (!(ay < 0.94)) y = pickup_saturate_hi(y, ay);
+        if (!(ay < 0.94)) y = pickup_saturate_hi(y);
         const double omy = 1.0 - y;
         const double alpha = beta * omy;
         const double q_next = ow_div(q * (1.0 - alpha) + 2.0 * beta, 1.0 + alpha);
