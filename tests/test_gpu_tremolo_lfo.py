@@ -75,3 +75,28 @@ def test_legacy_lfo_stream_is_the_rectified_sine(hiplib):
     period = np.diff(edges).mean() / 96000.0
     assert abs(1.0 / period - 5.63) < 0.02, 1.0 / period
     g.close()
+
+
+def test_every_non_default_kind_together(hiplib, oracle):
+    """A `--no-default-features --features melange-preamp,legacy-tremolo` build of the crate: melange 12-node preamp (literal rebuild),
+    melange 7-BJT power amp with rail sag, legacy LFO tremolo -- one pool, against the oracle with the same three kinds."""
+    import openwurli_amd as ow
+    sr, n = 48000.0, 2
+    g = ow.EnginePool(sr, n, preamp_kind=1, power_amp_kind=1, tremolo_kind=LFO)
+    cs = [oracle.OracleEngine(sr, preamp_kind=1, power_amp_kind=1, tremolo_kind=LFO) for _ in range(n)]
+    g.set_sample_rate(sr)
+    for c in cs:
+        c.set_sample_rate(sr)
+    for k in range(n):
+        for e in (g[k], cs[k]):
+            e.set_tremolo_depth(0.9 - 0.5 * k); e.set_volume(0.4)
+            for note in (50 + 2 * k, 62, 69):
+                e.note_on(note, 0.7)
+    for b in range(8):
+        go = g.render(256)
+        for k, c in enumerate(cs):
+            rep = oracle.parity_report(go[k], c.render(256), abs_floor=oracle.ABS_FLOOR_MELANGE_LIT_OUTPUT)
+            assert rep["n_bad"] == 0, (b, k, rep)
+    d = g[0].power_amp_diag()
+    assert d.guard_resets == cs[0].power_amp_diag()[3] and d.nan_resets == 0
+    g.close()
