@@ -147,9 +147,9 @@ OW_DEV double pa_pnjlim(double vnew, double vold, double vt, double vcrit) {   /
 // sweep runs long (hard clipping: 60+ iterations) only holds up the seven other engines of its wavefront.
 //   lane `role` owns transistor `role`: its two controlling voltages, the device model (the expensive part: the exponentials and the
 //   inner 2x2 parasitic solve), and ROWS 2 role, 2 role + 1 of the 16x16 Newton Jacobian -- in REGISTERS, with their right-hand sides;
-//   Gaussian elimination with partial pivoting, column by column: every lane posts |J[row][col]| of its un-pivoted rows to LDS, all
-//   eight pick the pivot (the reference's scan order, through the 16-nibble row permutation every lane keeps), the owner posts the
-//   pivot row, every lane eliminates its own rows.  Back substitution: the owner of row i computes x_i (ascending-j sum, as the
+//   Gaussian elimination with partial pivoting, column by column: every lane posts |J[row][col]| of its un-pivoted rows to LDS at
+//   their logical positions, all eight pick the pivot (the reference's scan order), the owner posts the pivot row, every lane
+//   eliminates its own rows.  Back substitution: the owner of row i computes x_i (ascending-j sum, as the
 //   reference) and posts it.  No Jacobian in LDS at all; the K rows a lane needs come from a 2 KB LDS copy of K.
 //   Matrix-vector products (S rhs, S_NI i_nl, K i_trial) are split by rows over the eight lanes; O(16) vector passes (step limiting,
 //   convergence test, finiteness) are done by all eight on the same values.
@@ -178,7 +178,6 @@ enum {
 };
 #define PL(r) W[(r) * PA_LS]
 #define PA_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-#define PA_PERM(p, r) ((int)(((p) >> (4 * (r))) & 15ull))
 #define PA_LDS_DOUBLES (PA_WPB * PL_ROWS * PA_LS)
 
 // The workgroup's LDS copy of the tables its lanes index PER LANE (row = f(role)): from the constant block those would be vector loads
@@ -249,39 +248,41 @@ __device__ __forceinline__ uint32_t pa_newton_body(double* __restrict__ W, const
         // column c a row that is still being eliminated holds J[row][c+1 + j] at index j, so every column works on index 0 and the
         // shift rides on the update itself (A[j-1] = A[j] - f prow[j]).  A row chosen as pivot at column c is frozen from then on:
         // it keeps U[c][c + j] at index j for the back substitution.  Entries past the live width are stale and never read.
-        unsigned long long perm = 0xFEDCBA9876543210ull;
+        // Row exchanges move no data either: every lane keeps the LOGICAL positions of its two rows (identity at the start), a pivot
+        // choice swaps two positions, candidates are posted at their logical position (so the scan below reads fixed LDS offsets in
+        // the reference's order), and the owner of logical row i is the lane that holds position i.
+        int posA = r0, posB = r1;
         bool singular = false, usedA = false, usedB = false;
 #pragma unroll 1
         for (int col = 0; col < PA_M; ++col) {
-            PL(PL_CAND + r0) = fabs(A[0]);                          // rows already used as pivots are never looked at again (perm)
-            PL(PL_CAND + r1) = fabs(B[0]);
+            PL(PL_CAND + posA) = fabs(A[0]);                        // rows already used as pivots sit at positions < col: never looked at again
+            PL(PL_CAND + posB) = fabs(B[0]);
             PA_SYNC();
-            // the reference's scan (first strict maximum over logical rows col..15), with all sixteen candidates fetched at once: a
-            // rolled `for row = col + 1 ..` serialises sixteen LDS round trips per column, a third of the whole iteration
+            // the reference's scan: first strict maximum over logical rows col..15; all candidates are fetched at once
             int max_row = col;
-            double max_val = PL(PL_CAND + PA_PERM(perm, col));
+            double max_val = PL(PL_CAND + col);
             double cand[PA_M];
 #pragma unroll
-            for (int row = 1; row < PA_M; ++row) cand[row] = PL(PL_CAND + PA_PERM(perm, row));
+            for (int row = 1; row < PA_M; ++row) cand[row] = PL(PL_CAND + row);
 #pragma unroll
             for (int row = 1; row < PA_M; ++row) {
-                const bool take = row > col && cand[row] > max_val;
-                max_val = take ? cand[row] : max_val;
-                max_row = take ? row : max_row;
+                if (row > col) {                                    // wave-uniform: col is the loop counter
+                    const bool take = cand[row] > max_val;
+                    max_val = take ? cand[row] : max_val;
+                    max_row = take ? row : max_row;
+                }
             }
             if (max_val < 1e-15) { singular = true; break; }
-            if (max_row != col) {
-                const unsigned long long pc = (perm >> (4 * col)) & 15ull, pm = (perm >> (4 * max_row)) & 15ull;
-                perm = (perm & ~(15ull << (4 * col)) & ~(15ull << (4 * max_row))) | (pm << (4 * col)) | (pc << (4 * max_row));
-            }
-            const int pr = PA_PERM(perm, col);
-            if (pr == r0) {
+            // exchange logical positions col <-> max_row (a no-op when they are equal)
+            posA = posA == col ? max_row : (posA == max_row ? col : posA);
+            posB = posB == col ? max_row : (posB == max_row ? col : posB);
+            if (posA == col) {
 #pragma unroll
                 for (int j = 0; j < PA_M; ++j) PL(PL_PROW + j) = A[j];
                 PL(PL_PROW + 16) = bA;
                 usedA = true;
             }
-            if (pr == r1) {
+            if (posB == col) {
 #pragma unroll
                 for (int j = 0; j < PA_M; ++j) PL(PL_PROW + j) = B[j];
                 PL(PL_PROW + 16) = bB;
@@ -320,13 +321,12 @@ __device__ __forceinline__ uint32_t pa_newton_body(double* __restrict__ W, const
         // test on it can never fire)
 #pragma unroll
         for (int i = PA_M - 1; i >= 0; --i) {
-            const int ri = PA_PERM(perm, i);
-            const bool slot = (ri & 1) != 0;
+            const bool slot = posB == i;
             double sum = slot ? bB : bA;
 #pragma unroll
             for (int j = i + 1; j < PA_M; ++j) sum -= (slot ? B[j - i] : A[j - i]) * PL(PL_X + j);
             const double aii = slot ? B[0] : A[0];
-            if ((ri >> 1) == role) PL(PL_X + i) = ow_div(sum, aii);
+            if (slot || posA == i) PL(PL_X + i) = ow_div(sum, aii);
             PA_SYNC();
         }
         bool converged = false;
