@@ -100,3 +100,21 @@ def test_every_non_default_kind_together(hiplib, oracle):
     d = g[0].power_amp_diag()
     assert d.guard_resets == cs[0].power_amp_diag()[3] and d.nan_resets == 0
     g.close()
+
+
+def test_legacy_lfo_stagger_hook(hiplib):
+    """ow_test_pool_stagger_tremolo on an LFO pool: four phase groups a quarter period apart, each engine reads its group's stream."""
+    import openwurli_amd as ow
+    sr = 48000.0
+    g = ow.EnginePool(sr, 8, tremolo_kind=LFO)
+    g.set_sample_rate(sr)
+    g.stagger_tremolo(4)
+    assert g.tremolo_groups() == 4
+    g.render(512)
+    r = g.tremolo_r(1024)
+    for k in range(8):
+        assert np.array_equal(r[k], r[k % 4])                    # engine k follows group k mod 4
+    assert not np.array_equal(r[0], r[1]) and not np.array_equal(r[1], r[2])
+    g.reset()                                                    # whole-pool reset: one group again, phase 0
+    assert g.tremolo_groups() == 1
+    g.close()
