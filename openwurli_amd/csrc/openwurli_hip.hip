@@ -425,6 +425,12 @@ static inline bool trem_wide(int ne) {
     if (const char* env = std::getenv("OW_TREM_WIDE")) return env[0] == '1';
     return ne <= 16384;
 }
+// legacy preamp with a quad per solver state (k_preamp_wide): while the pool leaves most SIMDs empty the kernel's time is the serial
+// latency of one sample, which the quad shortens; beyond ~4 096 engines the lane-pair kernel's lower instruction count wins
+static inline bool preamp_wide(int ne) {
+    if (const char* env = std::getenv("OW_PREAMP_WIDE")) return env[0] == '1';
+    return ne <= 4096;
+}
 // ---- tremolo phase groups (see ow_pool) ---------------------------------------------------------------------------------
 void trem_groups_changed(ow_pool* p) {
     HIP_OK(hipMemcpyAsync(p->d_lead, p->h_lead, sizeof(uint32_t) * p->I, hipMemcpyHostToDevice, p->stream));
@@ -825,6 +831,8 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
             else if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)
                 owdev::k_preamp_mel<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
                                                                              p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne);
+            else if (preamp_wide(sne))
+                owdev::k_preamp_wide<<<dim3((sne + 7) / 8), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, rb_now, p->d_lead, p->d_pre, I, L, Lcap, se0, sne);
             else
                 owdev::k_preamp<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, rb_now, p->d_lead, p->d_pre, I, L, Lcap, se0, sne);
         }

@@ -202,4 +202,102 @@ __global__ __launch_bounds__(64) void k_job_chain_wide(const OwConsts* __restric
     }
 }
 
+// k_preamp (ow_kernels.h) with a quad per solver state, for pools too small to fill the chip: 8 engines per wavefront (main quads in
+// lanes 0-31, shadow quads in lanes 32-63).  Same interface, same arithmetic statement for statement (dk_step_wide is bit-identical to
+// dk_step): tests/test_gpu_parity.py::test_preamp_wide_is_bit_identical.  In a pool of a few hundred engines the preamp's serial
+// latency is the block time once the tremolo is out of the way (paced single instance: 314 of the 425 us of a 64-sample buffer).
+__global__ __launch_bounds__(64) void k_preamp_wide(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args,
+                                                    const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const double* __restrict__ rbuf,
+                                                    const uint32_t* __restrict__ trem_lead, double* __restrict__ pre, int I, int L, int Lcap, int e0, int ne) {
+    __shared__ double tile[8 * (OW_WCHUNK + 1)];
+    const int lane = threadIdx.x;
+    const int q = lane & 3, el = (lane & 31) >> 2, role = lane >> 5;
+    const int eb = e0 + blockIdx.x * 8;
+    const int e = eb + el;
+    const bool valid = e < e0 + ne;
+    const int ec = valid ? e : (e0 + ne - 1);
+    const int osr = K->oversample ? 2 : 1;
+    DkWideRows R;
+    dk_wide_rows_load(R, K, q);
+
+    DkSt st;
+    double ua[3], ub[3];
+    double r_ldr, g_ldr, g_prev;
+    Smoother sd;
+    {
+        const int e = ec;
+        smoother_load(sd, cs, I, e, CS_SM_DEPTH);
+        if (args[e].set_flags & 1u) sd.retarget(args[e].depth_target, K->ramp_samples);
+        dk_load(st, cs, I, e, role ? CS_P_SHADOW : CS_P_MAIN);
+        for (int i = 0; i < 3; ++i) { ua[i] = CSF(CS_OS_UA + i); ub[i] = CSF(CS_OS_UB + i); }
+        r_ldr = CSF(CS_P_RLDR); g_ldr = CSF(CS_P_GLDR); g_prev = CSF(CS_P_GPREV);
+        const uint64_t fl = dbits(CSF(CS_FLAGS));
+        if (fl & 1ull) {  // deferred preamp.reset() + oversampler.reset() from the output NaN guard (engine.rs:450-457)
+            dk_dc_reset(K, r_ldr, st);
+            g_ldr = 1.0 / r_ldr; g_prev = g_ldr;
+            for (int i = 0; i < 3; ++i) { ua[i] = 0.0; ub[i] = 0.0; }
+        }
+    }
+    uint32_t nan_resets = 0;
+    const int er_col = (int)trem_lead[ec];
+    for (int base = 0; base < L; base += OW_WCHUNK) {
+        const int cn = min(OW_WCHUNK, L - base);
+        for (int r = 0; r < 8; ++r) {                 // stage 8 engine rows x 64 samples of the voice sum (slot pass + steal pass)
+            const int er = eb + r;
+            double x = 0.0;
+            if (er < e0 + ne && lane < cn && !eout[er].sum_nonfinite) {
+                if (args[er].main_mask) x = sum[((size_t)0 * I + er) * Lcap + base + lane];
+                if (args[er].steal_mask) x += sum[((size_t)1 * I + er) * Lcap + base + lane];
+            }
+            tile[r * (OW_WCHUNK + 1) + lane] = x;
+        }
+        __syncthreads();
+        for (int n = 0; n < cn; ++n) {
+            const double x = tile[el * (OW_WCHUNK + 1) + n];
+            const double depth = clampd(sd.next(), 0.0, 1.0);   // engine.rs:533-534, tremolo.rs:117-119
+            double in[2];
+            if (osr == 2) {
+                const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, ua, x);
+                const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, ub, x);
+                in[0] = role ? 0.0 : a;
+                in[1] = role ? 0.0 : b;
+            } else {
+                in[0] = role ? 0.0 : x;
+                in[1] = 0.0;
+            }
+            for (int j = 0; j < osr; ++j) {
+                const size_t idx = (size_t)((base + n) * osr + j);
+                const double r_new = fmax(trem_shunt(depth, rbuf[idx * I + er_col]), 1000.0);   // tremolo.rs:152-167; set_ldr_resistance
+                if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = ow_div(1.0, r_new); }
+                const double o = dk_step_wide(st, R, q, in[j], g_ldr, g_prev, K);
+                g_prev = g_ldr;
+                const double other = xor32(o);
+                double result = role ? (other - o) : (o - other);                 // main - pump
+                if (!isfinite(result)) {
+                    dk_dc_reset(K, r_ldr, st);
+                    g_ldr = 1.0 / r_ldr; g_prev = g_ldr;
+                    result = 0.0;
+                    nan_resets += 1u;
+                }
+                if (valid && role == 0 && q == 0) pre[idx * I + e] = result;
+            }
+        }
+        __syncthreads();
+    }
+    if (valid && q == 0) {
+        dk_store(st, cs, I, e, role ? CS_P_SHADOW : CS_P_MAIN);
+        if (role == 0) {
+            for (int i = 0; i < 3; ++i) { CSF(CS_OS_UA + i) = ua[i]; CSF(CS_OS_UB + i) = ub[i]; }
+            CSF(CS_P_RLDR) = r_ldr; CSF(CS_P_GLDR) = g_ldr; CSF(CS_P_GPREV) = g_prev;
+            smoother_store(sd, cs, I, e, CS_SM_DEPTH);
+            const uint64_t fl = dbits(CSF(CS_FLAGS));
+            if (fl & 1ull) CSF(CS_FLAGS) = bitsd(fl & ~1ull);
+            if (nan_resets) {
+                const uint64_t d = dbits(CSF(CS_DIAG));
+                CSF(CS_DIAG) = bitsd((d & 0xFFFFFFFFull) | ((uint64_t)((uint32_t)(d >> 32) + nan_resets) << 32));
+            }
+        }
+    }
+}
+
 }  // namespace owdev

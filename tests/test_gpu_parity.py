@@ -316,6 +316,41 @@ def test_chain_wide_is_bit_identical(hiplib, oracle):
             assert rep["n_bad"] == 0, (sr, k, rep)
 
 
+def test_preamp_wide_is_bit_identical(hiplib, oracle):
+    """Small pools run the legacy preamp with a quad of lanes per solver state (k_preamp_wide), large ones with a lane pair per engine
+    (k_preamp).  Same bits at the preamp tap and at the output, with tremolo, depth ramps, reset and the steal pass in play, at both
+    rates; 11 engines = one full wavefront of the wide kernel and a ragged second one."""
+    import openwurli_amd as ow
+    for sr in (48000.0, 96000.0):
+        osr = 2 if sr < 88200.0 else 1
+        res = {}
+        for wide in ("0", "1"):
+            os.environ["OW_PREAMP_WIDE"] = wide
+            try:
+                g = ow.EnginePool(sr, 11)
+                g.set_sample_rate(sr)
+                for k in range(11):
+                    g[k].set_tremolo_depth(0.1 * k); g[k].set_volume(0.3 + 0.05 * k)
+                    for note in (40 + 3 * k, 60 + k, 72):
+                        g[k].note_on(note, 0.5 + 0.04 * k)
+                outs, pres = [], []
+                for b in range(10):
+                    if b == 3:
+                        g[4].set_tremolo_depth(1.0); g[7].note_on(60 + 7, 1.0)              # depth ramp; re-strike of a sounding key (steal pass)
+                    if b == 6:
+                        g[2].reset(); g[2].note_on(55, 0.9)
+                    outs.append(g.render(300 if b % 2 else 512).copy())
+                    pres.append(g.preamp_out((300 if b % 2 else 512) * osr).copy())
+                res[wide] = (outs, pres)
+                g.close()
+            finally:
+                del os.environ["OW_PREAMP_WIDE"]
+        for b in range(10):
+            assert np.array_equal(res["0"][1][b], res["1"][1][b]), (sr, b, "preamp tap")
+            assert np.array_equal(res["0"][0][b], res["1"][0][b]), (sr, b, "output")
+        assert np.max(np.abs(res["1"][0][5])) > 1e-3
+
+
 def test_pool_of_independent_engines(hiplib, oracle):
     """Lane = engine kernels: 5 engines with different scripts in one pool vs 5 separate oracle engines."""
     import openwurli_amd as ow
