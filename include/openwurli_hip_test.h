@@ -70,6 +70,15 @@ int ow_test_pool_read_power_amp_out(ow_pool*, double* out_host, size_t out_strid
  * divergence guard (power_amp.rs:410-421: |node| > 100 V -> reset + hold last good) at a known sample. */
 int ow_test_engine_poke_power_amp_node(ow_engine*, int node, double volts);
 
+/* ---- host constant builders ------------------------------------------------------------------ */
+/* The library's own set_sample_rate / rebuild_matrices of the three generated solvers (ow_consts_host.hpp; gen_tremolo.rs:2111-2342,
+ * gen_preamp.rs:1930-2219, gen_power_amp.rs:8588-8831) at chain rate `rate`, on the host, no device needed.  solver: 0 Twin-T tremolo
+ * (N 7, M 4), 1 melange preamp at the nominal pot (N 12, M 3), 2 melange power amp (N 20, M 16).  Outputs are row-major s[N][N] k[M][M]
+ * sni[N][M] aneg[N][N] and the backward-Euler set (any pointer may be NULL).  force_rebuild != 0 rebuilds even at the solver's codegen
+ * rate, where the reference copies its baked tables -- the tests compare that rebuild with the baked tables.  Returns N * 100 + M. */
+int ow_test_host_matrices(int solver, double rate, int force_rebuild, double* s, double* k, double* sni, double* aneg,
+                          double* s_be, double* k_be, double* sni_be, double* aneg_be);
+
 /* ---- fault injection ------------------------------------------------------------------------ */
 /* The next n_renders calls of ow_pool_render / ow_engine_render on this pool fail before their first launch, exactly as a HIP
  * error would (exception inside the guarded region): the caller's block must come back as silence in every row, ow_last_error

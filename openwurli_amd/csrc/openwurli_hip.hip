@@ -1677,6 +1677,39 @@ int ow_test_engine_poke_power_amp_node(ow_engine* e, int node, double volts) {
     if (hipSetDevice(p->device) != hipSuccess || hipStreamSynchronize(p->stream) != hipSuccess) return -1;
     return hipMemcpy(p->d_pa + (size_t)(owdev::PAS_V + node) * p->I + e->index, &volts, sizeof volts, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
 }
+// Host matrix builders (ow_consts_host.hpp) of the three generated solvers at `rate` (the solver's own rate: the chain rate), no device.
+// force_rebuild != 0 bypasses the "codegen rate -> baked tables" shortcut so that the rebuild can be checked against those tables.
+int ow_test_host_matrices(int solver, double rate, int force_rebuild, double* s, double* k, double* sni, double* aneg,
+                          double* s_be, double* k_be, double* sni_be, double* aneg_be) {
+    try {
+        if (!(rate > 0.0)) throw std::runtime_error("bad rate");
+        auto put = [](double* dst, const void* src, size_t n) { if (dst) std::memcpy(dst, src, sizeof(double) * n); };
+        struct Force { Force(bool on) { owhip::g_force_rebuild = on; } ~Force() { owhip::g_force_rebuild = false; } } force(force_rebuild != 0);
+        if (solver == 0 || solver == 1) {
+            std::unique_ptr<OwConsts> c(new OwConsts());
+            // build_consts takes the HOST rate; a host rate >= 88.2 kHz runs the chain at that rate without oversampling (engine.rs:195)
+            owhip::build_consts(*c, rate < 88200.0 ? rate * 0.5 : rate, solver == 1 ? OW_PREAMP_MELANGE12 : OW_PREAMP_LEGACY8);
+            if (c->os_sr != rate) throw std::runtime_error("rate is not reachable as a chain rate");
+            if (solver == 0) {
+                put(s, c->t_s, 49); put(k, c->t_k, 16); put(sni, c->t_s_ni, 28); put(aneg, c->t_a_neg, 49);
+                put(s_be, c->t_s_be, 49); put(k_be, c->t_k_be, 16); put(sni_be, c->t_s_ni_be, 28); put(aneg_be, c->t_a_neg_be, 49);
+                return 704;
+            }
+            put(s, c->m_s0, 144); put(k, c->m_k0, 9); put(sni, c->m_sni0, 36); put(aneg, c->m_aneg0, 144);
+            // the melange preamp's backward-Euler set is never rebuilt (gen_preamp.rs:2058-2061): the kernels read the baked tables
+            put(s_be, PRE_S_BE_DEFAULT, 144); put(k_be, PRE_K_BE_DEFAULT, 9); put(sni_be, PRE_S_NI_BE_DEFAULT, 36); put(aneg_be, PRE_A_NEG_BE_DEFAULT, 144);
+            return 1203;
+        }
+        if (solver == 2) {
+            std::unique_ptr<OwPaConsts> c(new OwPaConsts());
+            owhip::build_pa_consts(*c, rate);
+            put(s, c->s, 400); put(k, c->k, 256); put(sni, c->s_ni, 320); put(aneg, c->a_neg, 400);
+            put(s_be, c->s_be, 400); put(k_be, c->k_be, 256); put(sni_be, c->s_ni_be, 320); put(aneg_be, c->a_neg_be, 400);
+            return 2016;
+        }
+        throw std::runtime_error("unknown solver");
+    } catch (const std::exception& ex) { set_err(std::string("ow_test_host_matrices: ") + ex.what()); return -1; }
+}
 void ow_test_inject_render_faults(ow_pool* p, int n_renders) { if (p) p->inject_faults = n_renders > 0 ? n_renders : 0; }
 
 // ---- diagnostics ---------------------------------------------------------------------------------

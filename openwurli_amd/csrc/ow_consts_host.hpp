@@ -73,6 +73,10 @@ static bool lu_invert(const double* a, double* inv) {
 }
 
 // K = N_v S N_i and S_NI = S N_i with the loop nest of gen_tremolo.rs:2172-2194.
+// Test switch (ow_test_host_matrices): rebuild even at a solver's codegen rate, where the reference copies its baked tables, so that
+// the rebuild itself can be compared with those tables (tests/test_oracle_baked_matrices.py).
+static thread_local bool g_force_rebuild = false;
+
 static void trem_kernel_mats(const double s[7][7], double k[4][4], double s_ni[7][4]) {
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {
@@ -94,7 +98,7 @@ static void trem_kernel_mats(const double s[7][7], double k[4][4], double s_ni[7
 
 static void build_tremolo_consts(OwConsts& c) {
     const double rate = c.os_sr;
-    if (std::fabs(rate - TREM_SAMPLE_RATE) < 0.5) {  // gen_tremolo.rs:2117-2130 (codegen-rate defaults)
+    if (std::fabs(rate - TREM_SAMPLE_RATE) < 0.5 && !g_force_rebuild) {  // gen_tremolo.rs:2117-2130 (codegen-rate defaults)
         std::memcpy(c.t_a_neg, TREM_A_NEG_DEFAULT, sizeof c.t_a_neg);
         std::memcpy(c.t_a_neg_be, TREM_A_NEG_BE_DEFAULT, sizeof c.t_a_neg_be);
         std::memcpy(c.t_s, TREM_S_DEFAULT, sizeof c.t_s);
@@ -220,7 +224,7 @@ static void build_preamp_consts(OwConsts& c) {
 // 2117-2219; codegen tables within 0.5 Hz of 48 kHz, :1941-1957), plus the rank-one vectors of the R_ldr entry A[6][6].
 static void build_melange_consts(OwConsts& c) {
     const double rate = c.os_sr;
-    if (std::fabs(rate - PRE_SAMPLE_RATE) < 0.5) {
+    if (std::fabs(rate - PRE_SAMPLE_RATE) < 0.5 && !g_force_rebuild) {
         std::memcpy(c.m_s0, PRE_S_DEFAULT, sizeof c.m_s0);
         std::memcpy(c.m_aneg0, PRE_A_NEG_DEFAULT, sizeof c.m_aneg0);
         std::memcpy(c.m_k0, PRE_K_DEFAULT, sizeof c.m_k0);
@@ -324,7 +328,7 @@ static void build_melange_consts(OwConsts& c) {
 static void build_pa_consts(OwPaConsts& c, double rate) {
     std::memset(&c, 0, sizeof c);
     c.rate_is_codegen = std::fabs(rate - PA_SAMPLE_RATE) <= 0.5 ? 1 : 0;
-    if (std::fabs(rate - PA_SAMPLE_RATE) < 0.5) {
+    if (std::fabs(rate - PA_SAMPLE_RATE) < 0.5 && !g_force_rebuild) {
         std::memcpy(c.a_neg, PA_A_NEG_DEFAULT, sizeof c.a_neg); std::memcpy(c.a_neg_be, PA_A_NEG_BE_DEFAULT, sizeof c.a_neg_be);
         std::memcpy(c.s, PA_S_DEFAULT, sizeof c.s); std::memcpy(c.k, PA_K_DEFAULT, sizeof c.k); std::memcpy(c.s_ni, PA_S_NI_DEFAULT, sizeof c.s_ni);
         std::memcpy(c.s_be, PA_S_BE_DEFAULT, sizeof c.s_be); std::memcpy(c.k_be, PA_K_BE_DEFAULT, sizeof c.k_be); std::memcpy(c.s_ni_be, PA_S_NI_BE_DEFAULT, sizeof c.s_ni_be);

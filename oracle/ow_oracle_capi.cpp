@@ -403,4 +403,85 @@ size_t owo_render_midi(const double* time_s, const uint8_t* type, const uint8_t*
     return v.size();
 }
 
+// ---- baked matrices of the three generated solvers next to what the restated rebuild_matrices / invert_n produce AT THE CODEGEN RATE
+// with the "within 0.5 Hz -> copy the defaults" shortcut bypassed (gen_tremolo.rs:29-1132,2139-2342; gen_preamp.rs consts,1990-2219;
+// gen_power_amp.rs:965-7204,8624-8831).  solver: 0 tremolo (N 7, M 4), 1 preamp (N 12, M 3), 2 power amp (N 20, M 16).
+// Each output is row-major: s[N][N] k[M][M] sni[N][M] aneg[N][N], then the backward-Euler set.  The preamp's rebuild leaves its BE set
+// alone (gen_preamp.rs:2058-2061), so its rebuilt BE outputs ARE the baked ones.  Returns N * 100 + M, -1 for an unknown solver.
+static void owo_flat(const double* src, size_t n, double* dst) { if (dst) std::memcpy(dst, src, sizeof(double) * n); }
+int owo_baked_matrices(int solver, double* s, double* k, double* sni, double* aneg, double* s_be, double* k_be, double* sni_be, double* aneg_be) {
+    switch (solver) {
+        case 0: owo_flat(&TREM_S_DEFAULT[0][0], 49, s); owo_flat(&TREM_K_DEFAULT[0][0], 16, k); owo_flat(&TREM_S_NI_DEFAULT[0][0], 28, sni); owo_flat(&TREM_A_NEG_DEFAULT[0][0], 49, aneg);
+                owo_flat(&TREM_S_BE_DEFAULT[0][0], 49, s_be); owo_flat(&TREM_K_BE_DEFAULT[0][0], 16, k_be); owo_flat(&TREM_S_NI_BE_DEFAULT[0][0], 28, sni_be); owo_flat(&TREM_A_NEG_BE_DEFAULT[0][0], 49, aneg_be);
+                return 704;
+        case 1: owo_flat(&PRE_S_DEFAULT[0][0], 144, s); owo_flat(&PRE_K_DEFAULT[0][0], 9, k); owo_flat(&PRE_S_NI_DEFAULT[0][0], 36, sni); owo_flat(&PRE_A_NEG_DEFAULT[0][0], 144, aneg);
+                owo_flat(&PRE_S_BE_DEFAULT[0][0], 144, s_be); owo_flat(&PRE_K_BE_DEFAULT[0][0], 9, k_be); owo_flat(&PRE_S_NI_BE_DEFAULT[0][0], 36, sni_be); owo_flat(&PRE_A_NEG_BE_DEFAULT[0][0], 144, aneg_be);
+                return 1203;
+        case 2: owo_flat(&PA_S_DEFAULT[0][0], 400, s); owo_flat(&PA_K_DEFAULT[0][0], 256, k); owo_flat(&PA_S_NI_DEFAULT[0][0], 320, sni); owo_flat(&PA_A_NEG_DEFAULT[0][0], 400, aneg);
+                owo_flat(&PA_S_BE_DEFAULT[0][0], 400, s_be); owo_flat(&PA_K_BE_DEFAULT[0][0], 256, k_be); owo_flat(&PA_S_NI_BE_DEFAULT[0][0], 320, sni_be); owo_flat(&PA_A_NEG_BE_DEFAULT[0][0], 400, aneg_be);
+                return 2016;
+    }
+    return -1;
+}
+int owo_rebuilt_matrices_at_codegen_rate(int solver, double* s, double* k, double* sni, double* aneg, double* s_be, double* k_be, double* sni_be, double* aneg_be) {
+    switch (solver) {
+        case 0: {
+            TremCircuit* c = new TremCircuit();
+            c->init_default();
+            std::memset(c->s, 0, sizeof c->s); std::memset(c->k, 0, sizeof c->k); std::memset(c->s_ni, 0, sizeof c->s_ni); std::memset(c->a_neg, 0, sizeof c->a_neg);
+            std::memset(c->s_be, 0, sizeof c->s_be); std::memset(c->k_be, 0, sizeof c->k_be); std::memset(c->s_ni_be, 0, sizeof c->s_ni_be); std::memset(c->a_neg_be, 0, sizeof c->a_neg_be);
+            c->rebuild_matrices(TREM_SAMPLE_RATE * 1.0);
+            owo_flat(&c->s[0][0], 49, s); owo_flat(&c->k[0][0], 16, k); owo_flat(&c->s_ni[0][0], 28, sni); owo_flat(&c->a_neg[0][0], 49, aneg);
+            owo_flat(&c->s_be[0][0], 49, s_be); owo_flat(&c->k_be[0][0], 16, k_be); owo_flat(&c->s_ni_be[0][0], 28, sni_be); owo_flat(&c->a_neg_be[0][0], 49, aneg_be);
+            delete c;
+            return 704;
+        }
+        case 1: {
+            MelState* st = new MelState();
+            st->init_default();
+            std::memset(st->s, 0, sizeof st->s); std::memset(st->k, 0, sizeof st->k); std::memset(st->s_ni, 0, sizeof st->s_ni); std::memset(st->a_neg, 0, sizeof st->a_neg);
+            st->current_sample_rate = PRE_SAMPLE_RATE;          // pot at its nominal 100 kOhm, as the code generator had it
+            st->rebuild_matrices();
+            owo_flat(&st->s[0][0], 144, s); owo_flat(&st->k[0][0], 9, k); owo_flat(&st->s_ni[0][0], 36, sni); owo_flat(&st->a_neg[0][0], 144, aneg);
+            owo_flat(&st->s_be[0][0], 144, s_be); owo_flat(&st->k_be[0][0], 9, k_be); owo_flat(&st->s_ni_be[0][0], 36, sni_be); owo_flat(&st->a_neg_be[0][0], 144, aneg_be);
+            const int singular = (int)st->diag_singular_matrix_count;
+            delete st;
+            return singular ? -2 : 1203;
+        }
+        case 2: {
+            PaCircuit* c = new PaCircuit();
+            c->init_default();
+            std::memset(c->s, 0, sizeof c->s); std::memset(c->k, 0, sizeof c->k); std::memset(c->s_ni, 0, sizeof c->s_ni); std::memset(c->a_neg, 0, sizeof c->a_neg);
+            std::memset(c->s_be, 0, sizeof c->s_be); std::memset(c->k_be, 0, sizeof c->k_be); std::memset(c->s_ni_be, 0, sizeof c->s_ni_be); std::memset(c->a_neg_be, 0, sizeof c->a_neg_be);
+            c->rebuild_matrices(PA_SAMPLE_RATE * 1.0);
+            owo_flat(&c->s[0][0], 400, s); owo_flat(&c->k[0][0], 256, k); owo_flat(&c->s_ni[0][0], 320, sni); owo_flat(&c->a_neg[0][0], 400, aneg);
+            owo_flat(&c->s_be[0][0], 400, s_be); owo_flat(&c->k_be[0][0], 256, k_be); owo_flat(&c->s_ni_be[0][0], 320, sni_be); owo_flat(&c->a_neg_be[0][0], 400, aneg_be);
+            delete c;
+            return 2016;
+        }
+    }
+    return -1;
+}
+// G, C (N x N), N_v (M x N), N_i (N x M) and the codegen rate of a solver, for an independent numpy re-derivation in the tests.
+// (gen_preamp.rs stores N_I transposed, [M][N]; it is handed out as N x M like the others.)
+int owo_baked_circuit(int solver, double* g, double* c, double* nv, double* ni, double* rate) {
+    switch (solver) {
+        case 0: owo_flat(&TREM_G[0][0], 49, g); owo_flat(&TREM_C[0][0], 49, c); owo_flat(&TREM_N_V[0][0], 28, nv); owo_flat(&TREM_N_I[0][0], 28, ni); *rate = TREM_SAMPLE_RATE; return 704;
+        case 1: owo_flat(&PRE_G[0][0], 144, g); owo_flat(&PRE_C[0][0], 144, c); owo_flat(&PRE_N_V[0][0], 36, nv);
+                for (int i = 0; i < 12; ++i) for (int j = 0; j < 3; ++j) ni[i * 3 + j] = PRE_N_I[j][i];
+                *rate = PRE_SAMPLE_RATE; return 1203;
+        case 2: owo_flat(&PA_G[0][0], 400, g); owo_flat(&PA_C[0][0], 400, c); owo_flat(&PA_N_V[0][0], 320, nv); owo_flat(&PA_N_I[0][0], 320, ni); *rate = PA_SAMPLE_RATE; return 2016;
+    }
+    return -1;
+}
+// DC operating point the code generator baked (DC_OP, DC_NL_I) of a solver: v[N], i_nl[M]
+int owo_baked_dc(int solver, double* v, double* inl) {
+    switch (solver) {
+        case 0: owo_flat(TREM_DC_OP, 7, v); owo_flat(TREM_DC_NL_I, 4, inl); return 704;
+        case 1: owo_flat(PRE_DC_OP, 12, v); owo_flat(PRE_DC_NL_I, 3, inl); return 1203;
+        case 2: owo_flat(PA_DC_OP, 20, v); owo_flat(PA_DC_NL_I, 16, inl); return 2016;
+    }
+    return -1;
+}
+
 }  // extern "C"

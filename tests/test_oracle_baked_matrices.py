@@ -1,0 +1,309 @@
+"""Hard pin of the three generated-solver restatements against the matrices the reference itself carries.
+
+The reference's generated solvers hold their system matrices twice: as literal tables baked at code-generation time
+(`S_DEFAULT`, `K_DEFAULT`, `S_NI_DEFAULT`, `A_NEG_DEFAULT` and the backward-Euler set; gen_tremolo.rs:29-1132, the gen_preamp.rs consts,
+gen_power_amp.rs:965-7204) and as the `rebuild_matrices` / `invert_n` code that recomputes them from G and C when the sample rate is not
+the codegen rate (gen_tremolo.rs:2139-2342, gen_preamp.rs:1990-2219, gen_power_amp.rs:8624-8831).  An engine at 48 kHz runs its chain at
+96 kHz, never the codegen rate, so every parity claim rests on the REBUILT matrices.  Here the restated rebuild (CPU oracle) and the
+product's own host builder (ow_consts_host.hpp through ow_test_host_matrices) are run AT the codegen rate with the "within 0.5 Hz ->
+copy the defaults" shortcut bypassed, and must reproduce the baked tables: ~1 400 reference-held numbers that pin G, C, N_v, N_i, the
+trapezoid / backward-Euler companion conventions, the zeroed source rows of A_neg, invert_n and the K / S_NI products.
+
+Second pin: the baked DC operating points (`DC_OP`, `DC_NL_I`).  They satisfy Kirchhoff's current law with the baked G / N_i and the
+device laws restated INDEPENDENTLY below in numpy -- which pins the device models (Gummel-Poon with parasitic resistances for the power
+amp, Ebers-Moll for the Twin-T, the reduced junction laws of the preamp) -- and the restated power-amp solver settles on the independent
+DC solution of the full runtime model.  CPU only; the tables come from data/ow_gen_data.h (tools/extract_constants.py).
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+SOLVERS = {0: ("tremolo", 7, 4), 1: ("preamp", 12, 3), 2: ("power_amp", 20, 16)}
+NAMES = ("s", "k", "sni", "aneg", "s_be", "k_be", "sni_be", "aneg_be")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _sets(n, m):
+    return [np.zeros(s) for s in ((n, n), (m, m), (n, m), (n, n)) * 2]
+
+
+def _baked(L, solver):
+    _, n, m = SOLVERS[solver]
+    out = _sets(n, m)
+    assert L.owo_baked_matrices(solver, *[_p(a) for a in out]) == n * 100 + m
+    return dict(zip(NAMES, out))
+
+
+def _circuit(L, solver):
+    _, n, m = SOLVERS[solver]
+    g, c, nv, ni = np.zeros((n, n)), np.zeros((n, n)), np.zeros((m, n)), np.zeros((n, m))
+    rate = C.c_double(0.0)
+    assert L.owo_baked_circuit(solver, _p(g), _p(c), _p(nv), _p(ni), C.byref(rate)) == n * 100 + m
+    return g, c, nv, ni, rate.value
+
+
+def _close(got, want, rel_of_largest, what):
+    """Every entry within rel_of_largest of the table's largest entry, and the structural zeros of the baked table stay (numerically) zero."""
+    scale = np.abs(want).max()
+    assert scale > 0.0, what
+    err = np.abs(got - want).max()
+    assert err <= rel_of_largest * scale, f"{what}: max |diff| {err:.3e} against largest entry {scale:.3e} (ratio {err / scale:.2e})"
+
+
+# ------------------------------------------------------------------------------------------------------------------ the oracle's rebuild
+@pytest.mark.parametrize("solver", [0, 1, 2])
+def test_oracle_rebuild_at_the_codegen_rate_reproduces_the_baked_tables(oracle, solver):
+    L = oracle.lib()
+    name, n, m = SOLVERS[solver]
+    baked = _baked(L, solver)
+    reb = dict(zip(NAMES, _sets(n, m)))
+    assert L.owo_rebuilt_matrices_at_codegen_rate(solver, *[_p(reb[k]) for k in NAMES]) == n * 100 + m
+    for k in NAMES:
+        assert np.count_nonzero(baked[k]) > 0, (name, k)
+        # measured: bit-identical for the Twin-T trapezoid set and every A_neg, <= 5e-17 of the largest entry for the power amp and the
+        # Twin-T BE set, 4.7e-13 for the preamp (the code generator inverted that 12x12 system with another routine)
+        _close(reb[k], baked[k], 1e-11 if solver == 1 else 1e-15, f"{name}.{k}")
+        # entry by entry, not only against the largest one: 1e-9 relative wherever the table is not tiny
+        big = np.abs(baked[k]) > 1e-9 * np.abs(baked[k]).max()
+        assert np.max(np.abs(reb[k][big] / baked[k][big] - 1.0)) < 1e-9, (name, k)
+        # the structural zeros (and the zeroed source rows of A_neg) are exact zeros in both
+        if k.startswith("aneg"):
+            assert np.array_equal(reb[k] == 0.0, baked[k] == 0.0), (name, k)
+    if solver == 0:
+        for k in ("s", "k", "sni", "aneg", "aneg_be"):
+            assert np.array_equal(reb[k], baked[k]), k          # the restated invert_n rounds like the code generator's
+
+
+def test_the_preamp_rebuild_leaves_its_backward_euler_set_alone(oracle):
+    """gen_preamp.rs:2058-2061: rebuild_matrices recomputes only the trapezoid set.  The oracle entry point zeroes the trapezoid set before
+    rebuilding, so identical BE outputs mean "untouched", not "recomputed to the same values"."""
+    L = oracle.lib()
+    baked = _baked(L, 1)
+    reb = dict(zip(NAMES, _sets(12, 3)))
+    assert L.owo_rebuilt_matrices_at_codegen_rate(1, *[_p(reb[k]) for k in NAMES]) == 1203
+    for k in ("s_be", "k_be", "sni_be", "aneg_be"):
+        assert np.array_equal(reb[k], baked[k])
+
+
+# ------------------------------------------------------------------------------------------------------------------ independent numpy
+@pytest.mark.parametrize("solver", [0, 1, 2])
+def test_baked_tables_follow_from_g_and_c(oracle, solver):
+    """The conventions themselves, with numpy.linalg instead of any restated inversion: S = (G + alpha C)^-1, K = N_v S N_i,
+    S_NI = S N_i, A_neg = alpha C - G (trapezoid: alpha = 2 fs) or alpha C (backward Euler: alpha = fs) with the voltage-source rows
+    zeroed.  The power amp's "trapezoid" slot is a backward-Euler companion too (gen_power_amp.rs:8624-8640).  This covers the preamp's
+    BE set, which no rebuild code touches."""
+    L = oracle.lib()
+    name, n, m = SOLVERS[solver]
+    g, c, nv, ni, fs = _circuit(L, solver)
+    baked = _baked(L, solver)
+    src_rows = {0: [6], 1: [11], 2: [18, 19]}[solver]
+    for be in (False, True):
+        alpha = fs if (be or solver == 2) else 2.0 * fs
+        a = g + alpha * c
+        s = np.linalg.inv(a)
+        aneg = alpha * c if (be or solver == 2) else alpha * c - g
+        aneg[src_rows, :] = 0.0
+        sfx = "_be" if be else ""
+        _close(s, baked["s" + sfx], 1e-9, f"{name}.s{sfx}")
+        _close(nv @ s @ ni, baked["k" + sfx], 1e-9, f"{name}.k{sfx}")
+        _close(s @ ni, baked["sni" + sfx], 1e-9, f"{name}.sni{sfx}")
+        _close(aneg, baked["aneg" + sfx], 1e-15, f"{name}.aneg{sfx}")
+        sb = baked["s" + sfx]                                                   # S A = I with the baked S itself, to rounding
+        assert np.max(np.abs(sb @ a - np.eye(n))) < 1e-13 * n * np.abs(sb).max() * np.abs(a).max()
+
+
+# ------------------------------------------------------------------------------------------------------------------ the product's builder
+@pytest.mark.parametrize("solver", [0, 1, 2])
+def test_product_host_builder_reproduces_the_baked_tables(oracle, solver):
+    """openwurli_amd/csrc/ow_consts_host.hpp builds the constants the kernels read.  Forced to rebuild at the codegen rate it must give
+    the baked tables, and it must agree with the oracle's rebuild bit for bit (same elimination order); without the switch it hands out
+    the baked tables themselves like the reference's set_sample_rate."""
+    from openwurli_amd import binding
+    lib = binding.load_library()
+    L = oracle.lib()
+    name, n, m = SOLVERS[solver]
+    baked = _baked(L, solver)
+    rate = _circuit(L, solver)[4]
+    got = dict(zip(NAMES, _sets(n, m)))
+    assert lib.ow_test_host_matrices(solver, rate, 0, *[_p(got[k]) for k in NAMES]) == n * 100 + m, binding.last_error(lib)
+    for k in NAMES:
+        assert np.array_equal(got[k], baked[k]), (name, k)
+    assert lib.ow_test_host_matrices(solver, rate, 1, *[_p(got[k]) for k in NAMES]) == n * 100 + m, binding.last_error(lib)
+    reb = dict(zip(NAMES, _sets(n, m)))
+    assert L.owo_rebuilt_matrices_at_codegen_rate(solver, *[_p(reb[k]) for k in NAMES]) == n * 100 + m
+    for k in NAMES:
+        _close(got[k], baked[k], 1e-11 if solver == 1 else 1e-15, f"product {name}.{k}")
+        assert np.array_equal(got[k], reb[k]), (name, k)
+    # and at the rate the 48 kHz engine really runs them (96 kHz chain; the power amp too): product == oracle, S A = I
+    if solver != 1:
+        assert lib.ow_test_host_matrices(solver, 96000.0, 0, *[_p(got[k]) for k in NAMES]) == n * 100 + m
+        g, c, _, _, _ = _circuit(L, solver)
+        alpha = 96000.0 if solver == 2 else 2.0 * 96000.0
+        for sm, am in ((got["s"], g + alpha * c), (got["s_be"], g + 96000.0 * c)):
+            assert np.max(np.abs(sm @ am - np.eye(n))) < 1e-13 * n * np.abs(sm).max() * np.abs(am).max()
+
+
+def test_product_tremolo_matrices_equal_the_oracle_at_engine_rates(oracle):
+    from openwurli_amd import binding
+    lib = binding.load_library()
+    L = oracle.lib()
+    for rate in (88200.0, 96000.0, 176400.0, 192000.0):
+        got = dict(zip(NAMES, _sets(7, 4)))
+        assert lib.ow_test_host_matrices(0, rate, 0, *[_p(got[k]) for k in NAMES]) == 704
+        s = np.zeros(49); k = np.zeros(16); sni = np.zeros(28); an = np.zeros(49)
+        L.owo_tremolo_matrices(C.c_double(rate), _p(s), _p(k), _p(sni), _p(an))
+        assert np.array_equal(got["s"].ravel(), s) and np.array_equal(got["k"].ravel(), k)
+        assert np.array_equal(got["sni"].ravel(), sni) and np.array_equal(got["aneg"].ravel(), an)
+
+
+# ------------------------------------------------------------------------------------------------------------------ DC operating points
+def _table(name):
+    """A `double NAME[..] = {..};` table or scalar of data/ow_gen_data.h (numeric literals extracted from the reference)."""
+    src = _table.src if hasattr(_table, "src") else open(os.path.join(ROOT, "data", "ow_gen_data.h")).read()
+    _table.src = src
+    m = re.search(r"double " + name + r"((?:\[\w+\])+) = \{(.*?)\};", src, re.S)
+    if m:
+        vals = [float(x) for x in re.findall(r"[-+]?\d[\d.]*(?:[eE][-+]?\d+)?", m.group(2))]
+        return np.array(vals)
+    m = re.search(r"double " + name + r" = ([^;]+);", src)
+    assert m, name
+    return float(m.group(1))
+
+
+def _dc(L, solver):
+    _, n, m = SOLVERS[solver]
+    v, i = np.zeros(n), np.zeros(m)
+    assert L.owo_baked_dc(solver, _p(v), _p(i)) == n * 100 + m
+    return v, i
+
+
+def test_tremolo_dc_operating_point_is_consistent_with_ebers_moll(oracle):
+    """gen_tremolo.rs:1829-1845 against bjt_evaluate (:1546-1633, Ebers-Moll branch) restated here with numpy's exp.  KCL closes to
+    1e-15 A on every node; the input node is left with exactly -v/R_in (the code generator's DC solve has no input source resistor)."""
+    L = oracle.lib()
+    g, _, nv, ni, _ = _circuit(L, 0)
+    v, i = _dc(L, 0)
+    vd = nv @ v
+    cur = []
+    for d in (0, 1):
+        IS, VT, NF, NR, BF, BR = (_table(f"TREM_DEVICE_{d}_{f}") for f in ("IS", "VT", "NF", "NR", "BETA_F", "BETA_R"))
+        ebe, ebc = np.exp(vd[2 * d] / (NF * VT)), np.exp(vd[2 * d + 1] / (NR * VT))
+        cur += [IS * (ebe - ebc) - IS / BR * (ebc - 1.0), IS / BF * (ebe - 1.0) + IS / BR * (ebc - 1.0)]
+    assert np.max(np.abs(np.array(cur) / i - 1.0)) < 1e-9
+    res = g @ v - ni @ i
+    res[6] -= 15.0                                           # the supply row: v[5] = 15 V
+    assert abs(res[0] + v[0] / _table("TREM_INPUT_RESISTANCE")) < 1e-15
+    res[0] = 0.0
+    assert np.max(np.abs(res)) < 1e-15
+
+
+def test_preamp_dc_operating_point_is_consistent_with_its_junction_laws(oracle):
+    """gen_preamp.rs:1568-1588 against the diode and the two forward-active BJT laws (:2416-2428, :3148-3157)."""
+    L = oracle.lib()
+    g, _, nv, ni, _ = _circuit(L, 1)
+    v, i = _dc(L, 1)
+    vd = nv @ v
+    # the reverse-biased diode (-2.835 V): -IS plus the code generator's GMIN of 1e-12 S across the junction (-2.835e-12 A, 0.11 % of IS)
+    cur = [_table("PRE_DEVICE_0_IS") * (np.exp(vd[0] / _table("PRE_DEVICE_0_N_VT")) - 1.0) + 1e-12 * vd[0]]
+    for d in (1, 2):
+        cur.append(_table(f"PRE_DEVICE_{d}_IS") * (np.exp(vd[d] / (_table(f"PRE_DEVICE_{d}_NF") * _table(f"PRE_DEVICE_{d}_VT"))) - 1.0))
+    assert np.max(np.abs(np.array(cur) / i - 1.0)) < 1e-8
+    res = g @ v - ni @ i
+    res[11] -= 15.0
+    assert np.max(np.abs(res)) < 1e-10                        # amperes; node currents are ~1e-4 A
+
+
+_GP_FIELDS = ("IS", "VT", "BETA_F", "BETA_R", "NF", "NR", "ISE", "NE", "ISC", "NC", "SIGN", "VAF", "VAR", "IKF", "IKR", "RB", "RC", "RE")
+
+
+def _gp(vbe, vbc, P, d, leak):
+    """Gummel-Poon collector / base current of power-amp device d (gen_power_amp.rs:7870-8017), numpy exp."""
+    g = lambda f: P[f][d]
+    s = g("SIGN")
+    vbe_e, vbc_e = s * vbe, s * vbc
+    ebe, ebc = np.exp(vbe_e / (g("NF") * g("VT"))), np.exp(vbc_e / (g("NR") * g("VT")))
+    icc = g("IS") * (ebe - ebc)
+    ib = g("IS") / g("BETA_F") * (ebe - 1.0) + g("IS") / g("BETA_R") * (ebc - 1.0)
+    if leak:
+        ib += g("ISE") * (np.exp(vbe_e / (g("NE") * g("VT"))) - 1.0) + g("ISC") * (np.exp(vbc_e / (g("NC") * g("VT"))) - 1.0)
+    q1 = 1.0 / (1.0 - vbe_e / g("VAR") - vbc_e / g("VAF"))
+    q2 = g("IS") * (ebe - 1.0) / g("IKF") + g("IS") * (ebc - 1.0) / g("IKR")
+    qb = q1 * (1.0 + np.sqrt(max(1.0 + 4.0 * q2, 0.0))) / 2.0
+    return s * (icc / qb - g("IS") / g("BETA_R") * (ebc - 1.0)), s * ib
+
+
+def _gp_terminal(vbe_x, vbc_x, P, d, leak):
+    """... behind its base / collector / emitter resistances (bjt_with_parasitics, :8032-8145): solved to 1e-15 here."""
+    from scipy.optimize import root
+
+    def f(x):
+        ic, ib = _gp(x[0], x[1], P, d, leak)
+        return [x[0] - vbe_x + ib * P["RB"][d] + (ic + ib) * P["RE"][d], x[1] - vbc_x + ib * P["RB"][d] - ic * P["RC"][d]]
+    x = root(f, [vbe_x, vbc_x], tol=1e-15).x
+    return _gp(x[0], x[1], P, d, leak)
+
+
+def test_power_amp_dc_operating_point(oracle):
+    """gen_power_amp.rs:8150-8195 (DC_OP, DC_NL_I).  Three statements, each to ~1e-8:
+    (1) KCL with the baked G / N_i closes on the baked point;
+    (2) the baked device currents are the Gummel-Poon law with parasitic resistances WITHOUT the ISE / ISC leakage terms -- the code
+        generator's DC solve leaves them out, the runtime bjt_evaluate has them (:7897-7930) -- so
+    (3) the runtime circuit's rest point is NOT DC_OP: it sits up to 7.27 mV away (node 6 / 9), and the restated solver settles on the
+        independent DC solution of the full runtime model (scipy on the numpy restatement above) to 1e-6 V.
+    (The round-2 test compared the settled state with DC_OP at 0.05 V; the gap is this leakage offset, now accounted for to 1e-6.)"""
+    from scipy.optimize import root
+    L = oracle.lib()
+    g, _, nv, ni, fs = _circuit(L, 2)
+    v0, i0 = _dc(L, 2)
+    P = {f: _table("PA_DEV_" + f) for f in _GP_FIELDS}
+    src = np.zeros(20); src[18] = src[19] = 22.5
+    assert np.max(np.abs(g @ v0 - ni @ i0 - src)) < 1e-10                                         # (1)
+    vd = nv @ v0
+    cur = np.array([c for d in range(8) for c in _gp_terminal(vd[2 * d], vd[2 * d + 1], P, d, leak=False)])
+    assert np.max(np.abs(cur / i0 - 1.0)) < 1e-7                                                    # (2) measured 7.6e-9
+    with_leak = np.array([c for d in range(8) for c in _gp_terminal(vd[2 * d], vd[2 * d + 1], P, d, leak=True)])
+    assert np.max(np.abs(with_leak[1::2] / i0[1::2] - 1.0)) > 0.05                                  # base currents differ by 10 % .. 10 x
+
+    def kcl(v, leak):
+        u = nv @ v
+        i = np.array([c for d in range(8) for c in _gp_terminal(u[2 * d], u[2 * d + 1], P, d, leak)])
+        return g @ v - ni @ i - src
+    no_leak = root(lambda v: kcl(v, False), v0, tol=1e-13)
+    assert no_leak.success and np.max(np.abs(no_leak.x - v0)) < 1e-6                               # DC_OP is the leak-free rest point (1.2e-8)
+    full = root(lambda v: kcl(v, True), v0, tol=1e-13)
+    assert full.success and np.max(np.abs(kcl(full.x, True))) < 1e-10
+    assert 7.0e-3 < np.max(np.abs(full.x - v0)) < 7.6e-3                                           # (3) the runtime rest point, 7.27 mV off DC_OP
+    L.owo_mpa_new.restype = C.c_void_p
+    h = C.c_void_p(L.owo_mpa_new(C.c_double(fs)))
+    L.owo_mpa_set_rail_sag(h, 0)
+    x = np.zeros(int(fs) * 3); y = np.zeros_like(x)
+    L.owo_mpa_process(h, _p(x), _p(y), None, C.c_size_t(len(x)))
+    st = np.zeros(20)
+    L.owo_mpa_state(h, _p(st))
+    L.owo_mpa_free(h)
+    assert np.max(np.abs(st - full.x)) < 1e-6                                                      # measured 3.0e-8 V
+
+
+def test_extracted_header_matches_the_reference_text_when_it_is_present():
+    """data/ow_gen_data.h is what tools/extract_constants.py makes of the reference's literals.  Where the reference tree exists (the
+    build container) the committed header must be exactly the generator's output; elsewhere there is nothing to compare with."""
+    if not os.path.isdir("/root/reference/crates/openwurli-dsp/src"):
+        pytest.skip("reference tree not present")
+    import importlib.util
+    import tempfile
+    spec = importlib.util.spec_from_file_location("extract_constants", os.path.join(ROOT, "tools", "extract_constants.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with tempfile.TemporaryDirectory() as td:
+        mod.OUT = __import__("pathlib").Path(td) / "ow_gen_data.h"
+        mod.main()
+        assert mod.OUT.read_text() == open(os.path.join(ROOT, "data", "ow_gen_data.h")).read()

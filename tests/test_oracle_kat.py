@@ -535,17 +535,17 @@ def test_tremolo(oracle):
     assert swings[0] < 1e-6 and all(b > a for a, b in zip(swings, swings[1:]))   # monotone depth -> swing
 
 
-def test_tremolo_matrices_at_codegen_rate_are_the_baked_ones(oracle):
+def test_tremolo_set_sample_rate_shortcut(oracle):
+    """gen_tremolo.rs:2117: within 0.5 Hz of the codegen rate set_sample_rate copies the baked tables, anywhere else it rebuilds.
+    (That the rebuild reproduces the baked tables is tests/test_oracle_baked_matrices.py.)"""
     L = oracle.lib()
     s = np.zeros(49); k = np.zeros(16); sni = np.zeros(28); an = np.zeros(49)
     L.owo_tremolo_matrices(d(48000.0), _p(s), _p(k), _p(sni), _p(an))
     s2 = np.zeros(49); k2 = np.zeros(16); sni2 = np.zeros(28); an2 = np.zeros(49)
-    L.owo_tremolo_matrices(d(48000.3), _p(s2), _p(k2), _p(sni2), _p(an2))         # within 0.5 Hz -> defaults (gen_tremolo.rs:2117)
+    L.owo_tremolo_matrices(d(48000.3), _p(s2), _p(k2), _p(sni2), _p(an2))
     assert np.array_equal(s, s2) and np.array_equal(k, k2)
-    L.owo_tremolo_matrices(d(96000.0), _p(s2), _p(k2), _p(sni2), _p(an2))
-    assert not np.array_equal(s, s2)
-    # rebuilt S must invert A = G + 2 fs C: check through K = N_v S N_i symmetry-free identity S_NI = S N_i
-    assert np.all(np.isfinite(s2)) and np.all(np.isfinite(k2))
+    L.owo_tremolo_matrices(d(48000.6), _p(s2), _p(k2), _p(sni2), _p(an2))         # past the 0.5 Hz window: rebuilt, 1e-5 away
+    assert not np.array_equal(s, s2) and np.max(np.abs(s2 - s)) < 1e-4 * np.max(np.abs(s))
 
 
 def test_fast_exp(oracle):

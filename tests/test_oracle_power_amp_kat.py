@@ -161,7 +161,11 @@ def test_zero_input_stays_at_the_operating_point(pa):
     # set_sample_rate zeroes the DC blocker's memory (gen_power_amp.rs:8618-8620): the first sample shows V(OUT) = -64.7 mV / 22 V and the
     # 5 Hz blocker then forgets it
     assert abs(y[0] - (-6.3e-2 / 22.0)) < 2e-4 and abs(y[-1]) < 1e-9 and np.all(np.abs(np.diff(y)) < 1e-5)
-    assert np.max(np.abs(pa.state() - np.array(__import__('json').loads(DC_OP_JSON)))) < 0.05      # gen_power_amp.rs:8150-8171
+    # gen_power_amp.rs:8150-8171: the rest point sits 7.27 mV off the baked DC_OP, which the code generator solved without the ISE / ISC
+    # leakage terms of the runtime device law; tests/test_oracle_baked_matrices.py::test_power_amp_dc_operating_point accounts for the
+    # gap to 1e-6 V against an independent DC solution
+    gap = np.max(np.abs(pa.state() - np.array(__import__('json').loads(DC_OP_JSON))))
+    assert 7.0e-3 < gap < 7.6e-3
     assert taps[:, 0].max() <= 1 and taps[:, 2].sum() == 0 and taps[-1, 3] == 0
 
 
