@@ -79,6 +79,26 @@ int ow_test_engine_poke_power_amp_node(ow_engine*, int node, double volts);
 int ow_test_host_matrices(int solver, double rate, int force_rebuild, double* s, double* k, double* sni, double* aneg,
                           double* s_be, double* k_be, double* sni_be, double* aneg_be);
 
+/* ---- settled-state caches --------------------------------------------------------------------- */
+/* The library keeps the settled Twin-T oscillator state per (device, chain rate) and the settled melange preamp / power-amp states per
+ * device for the life of the process (the reference's OnceLock caches: melange_adapter.rs:12-29, power_amp.rs:283-299; the Twin-T one is
+ * this library's own, tremolo.rs:92-102 pays 2 s of solver steps per Tremolo::new).  This drops them, so that the next pool runs the
+ * settle kernels again -- the test compares a cached engine with a freshly settled one bit for bit.  Returns the number of cached
+ * Twin-T states dropped. */
+int ow_test_clear_settle_caches(void);
+
+/* ---- voice-sum NaN guard ----------------------------------------------------------------------- */
+/* Overwrite one double of a voice record on the device before the next block (slot 0..63; steal != 0 selects the slot's steal voice;
+ * field = a VF_* index of openwurli_amd/csrc/ow_types.h: OW_TEST_VF_Q is the pickup charge, OW_TEST_VF_S0 mode 0's sine state).  A
+ * voice cannot turn non-finite through the API, so this is how the guard of engine.rs:496-521 (zero the block, render every voice
+ * again, free the culprits; the survivors advance twice) is provoked.  Returns 0, <0 on error. */
+#define OW_TEST_VF_S0 0
+#define OW_TEST_VF_Q 81
+int ow_test_engine_poke_voice(ow_engine*, int slot, int steal, int field, double value);
+
+/* Plain device-to-host copy, for reading a block that ow_pool_render(pool, NULL, ...) left in HBM (ow_pool_device_output). */
+int ow_test_device_read(void* dst_host, const void* src_device, size_t bytes, int device);
+
 /* ---- fault injection ------------------------------------------------------------------------ */
 /* The next n_renders calls of ow_pool_render / ow_engine_render on this pool fail before their first launch, exactly as a HIP
  * error would (exception inside the guarded region): the caller's block must come back as silence in every row, ow_last_error

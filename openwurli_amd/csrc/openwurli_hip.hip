@@ -292,6 +292,8 @@ struct ow_pool {
     int split_e0 = -1, split_ne = -1; // range for which "no group straddles the range boundary" is known to hold
     double* d_snap = nullptr;         // [3][I] smoother targets (depth, speaker, volume) handed to k_chain_init on reset
     double* h_snap = nullptr;         // pinned
+    double* d_trem_settled = nullptr; // staging of one cached settled Twin-T state (18 doubles), see trem_settle_cached
+    bool voices_only = false;         // ow_render_note: the pool renders voice sums only -- no chain state, no tremolo / preamp / output kernels
     int inject_faults = 0;            // test hook (openwurli_hip_test.h): the next n renders fail before their first launch
     double hostprof_acc[4] = {0, 0, 0, 0};
     long hostprof_cnt = 0;
@@ -398,6 +400,19 @@ void pa_settled_to_device(int device, double* d_dst, hipStream_t st) {
     }
     HIP_OK(hipMemcpyAsync(d_dst, it->second.data(), sizeof(double) * it->second.size(), hipMemcpyHostToDevice, st));
     HIP_OK(hipStreamSynchronize(st));
+}
+
+// Settled state of the Twin-T oscillator (Tremolo::new: CircuitState::default's 50 warm-up steps at the codegen matrices, then 2 s of
+// oscillator steps at the chain rate, tremolo.rs:92-102).  It depends on nothing but the chain rate, and it is 192 050 strictly serial
+// solver steps -- 0.9 s on one wavefront -- which every pool creation, reset and rate change used to pay.  The reference caches its
+// expensive settles the same way (OnceLock: melange_adapter.rs:12-29, power_amp.rs:283-299).  Keyed by (device, chain rate); the cached
+// rows are what the product kernels produced on the first use, so a hit is bit-identical to a fresh settle
+// (tests/test_gpu_boundary.py::test_settled_tremolo_cache_is_bit_identical).  OW_TREM_CACHE=0 disables it.
+struct TremSettled { double rows[18]; };       // rows 0..16 after the settle; [17] = BE fallbacks the settle itself counted (u64 bits)
+std::map<std::pair<int, uint64_t>, TremSettled> g_trem_settled;
+static inline bool trem_cache_enabled() {
+    const char* env = std::getenv("OW_TREM_CACHE");
+    return !(env && env[0] == '0');
 }
 
 enum { INIT_NEW = 1, INIT_RATE = 2, INIT_RESET = 0 };
@@ -521,20 +536,51 @@ void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<do
         owdev::k_mel_init<<<dim3((2 * ne + 63) / 64), dim3(64), 0, p->stream>>>(p->d_cs, p->d_mel_settled, p->d_noise, I, e0, ne);
     if (p->power_amp_kind == OW_POWER_AMP_MELANGE)  // PowerAmp::new_at_sample_rate (new / set_sample_rate) or PowerAmp::reset (reset keeps last_good)
         owdev::k_mpa_init<<<dim3((ne + 63) / 64), dim3(64), 0, p->stream>>>(p->dPa, p->d_pa_settled, p->d_pa, I, e0, ne, mode != INIT_RESET ? 1 : 0);
-    const int nl = p->n_lead;          // == 1: the range is one phase group
+    const int nl = p->n_lead;          // == 1: the range is one phase group, led by e0
     const int blocks = (nl + 63) / 64;
     const long long n_settle = (long long)owhip::sat_u32(p->hc.os_sr * 2.0);
+    uint64_t rate_bits; std::memcpy(&rate_bits, &p->hc.os_sr, 8);
+    const std::pair<int, uint64_t> key(p->device, rate_bits);
+    const bool cacheable = nl == 1 && trem_cache_enabled();
+    bool from_cache = false;
+    double be_before = 0.0;
     if (p->tremolo_kind == OW_TREMOLO_LEGACY_LFO) {
         // legacy-tremolo build: nothing to settle, the LFO starts at phase 0 (k_chain_init)
-    } else if (trem_wide(nl)) {   // few oscillators: four lanes per engine (ow_trem_wide.h); the 2-second settle is pure serial latency
-        owdev::k_tremolo_wide<true><<<dim3((nl + 15) / 16), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, nullptr, I, 50LL, p->d_leaders, nl);
-        owdev::k_tremolo_wide<true><<<dim3((nl + 15) / 16), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, nullptr, I, n_settle, p->d_leaders, nl);
     } else {
-        owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, I, p->d_leaders, nl, 50LL);
-        owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, I, p->d_leaders, nl, n_settle);
+        if (cacheable) {
+            std::lock_guard<std::mutex> lk(g_mel_mu);
+            auto it = g_trem_settled.find(key);
+            if (it != g_trem_settled.end()) {
+                HIP_OK(hipMemcpyAsync(p->d_trem_settled, it->second.rows, sizeof(double) * 18, hipMemcpyHostToDevice, p->stream));
+                owdev::k_trem_load_settled<<<dim3(1), dim3(64), 0, p->stream>>>(p->d_cs, I, e0, p->d_trem_settled);
+                HIP_OK(hipStreamSynchronize(p->stream));    // the host rows must outlive the copy
+                from_cache = true;
+            } else {
+                HIP_OK(hipMemcpyAsync(&be_before, p->d_cs + (size_t)CS_T_BE * p->I + e0, sizeof(double), hipMemcpyDeviceToHost, p->stream));
+                HIP_OK(hipStreamSynchronize(p->stream));
+            }
+        }
+        if (from_cache) {
+        } else if (trem_wide(nl)) {   // few oscillators: four lanes per engine (ow_trem_wide.h); the 2-second settle is pure serial latency
+            owdev::k_tremolo_wide<true><<<dim3((nl + 15) / 16), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, nullptr, I, 50LL, p->d_leaders, nl);
+            owdev::k_tremolo_wide<true><<<dim3((nl + 15) / 16), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, nullptr, I, n_settle, p->d_leaders, nl);
+        } else {
+            owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, I, p->d_leaders, nl, 50LL);
+            owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, I, p->d_leaders, nl, n_settle);
+        }
     }
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(p->stream));   // the tremolo stream picks these rows up next (init-time sync)
+    if (cacheable && !from_cache && p->tremolo_kind != OW_TREMOLO_LEGACY_LFO) {   // first settle at this rate on this device: keep it
+        TremSettled t;
+        HIP_OK(hipMemcpy2D(t.rows, sizeof(double), p->d_cs + e0, sizeof(double) * p->I, sizeof(double), 18, hipMemcpyDeviceToHost));
+        uint64_t b0, b1;
+        std::memcpy(&b0, &be_before, 8); std::memcpy(&b1, &t.rows[17], 8);
+        const uint64_t delta = b1 - b0;
+        std::memcpy(&t.rows[17], &delta, 8);
+        std::lock_guard<std::mutex> lk(g_mel_mu);
+        g_trem_settled[key] = t;
+    }
 }
 
 void upload_consts(ow_pool* p, double sr, int preamp_kind) {
@@ -681,20 +727,23 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
     // ---- tremolo stream: CdS cell resistance of this block (already there if the block-ahead speculation hit)
     const int n_os = L * (p->hc.oversample ? 2 : 1);
     const size_t rb_half = (size_t)2 * p->Lcap * p->I;
-    const bool hit = p->spec.valid && p->spec.e0 == e0 && p->spec.ne == ne && p->spec.n_os == n_os;
+    const bool chain = !p->voices_only;     // a voices-only pool (ow_render_note) stops at the voice sums
+    const bool hit = chain && p->spec.valid && p->spec.e0 == e0 && p->spec.ne == ne && p->spec.n_os == n_os;
     if (p->spec.valid && !hit) {   // mis-speculated (different block length / engine range): roll the oscillator back
         HIP_OK(hipMemcpyAsync(p->d_cs, p->d_trem_backup, sizeof(double) * 18 * p->I, hipMemcpyDeviceToDevice, tt));
         p->spec.valid = false;
     }
-    // a sub-range advances on its own: its engines leave the phase groups they share with engines outside it (no-op for the whole pool
-    // and for a range that was just initialised); then the oscillators to run are the group leaders inside the range
-    trem_split_at_range(p, e0, ne);
-    trem_leader_list(p, e0, ne);
-    if (hit) {
-        p->rb_cur ^= 1;            // the half the speculation filled
-    } else {
-        launch_tremolo(p, tt, p->d_rbuf + p->rb_cur * rb_half, n_os);
-        HIP_OK(hipEventRecord(p->ev_trem[p->rb_cur], tt));
+    if (chain) {
+        // a sub-range advances on its own: its engines leave the phase groups they share with engines outside it (no-op for the whole pool
+        // and for a range that was just initialised); then the oscillators to run are the group leaders inside the range
+        trem_split_at_range(p, e0, ne);
+        trem_leader_list(p, e0, ne);
+        if (hit) {
+            p->rb_cur ^= 1;            // the half the speculation filled
+        } else {
+            launch_tremolo(p, tt, p->d_rbuf + p->rb_cur * rb_half, n_os);
+            HIP_OK(hipEventRecord(p->ev_trem[p->rb_cur], tt));
+        }
     }
     const double* rb_now = p->d_rbuf + p->rb_cur * rb_half;
     const int rb_now_idx = p->rb_cur;
@@ -711,7 +760,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
     // The oscillator goes first: it needs nothing from the host, so it runs while the host packs ops and voice lists, and its
     // 1 024 wavefronts (one per SIMD) are resident before the voice kernel fills the rest.  (k_apply_ops is register-capped so that
     // it fits beside them.)
-    launch_block_ahead();
+    if (chain) launch_block_ahead();
     // ---- per-engine args + ops: only engines whose host state changed are touched (the rest keep their
     // uploaded args; a steady-state step of a large pool does no per-engine host work here)
     // Large pools split the range over host threads: slice t counts its pending ops, a prefix sum places the slices in h_ops,
@@ -822,9 +871,9 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         }
         if (overlap && k + 1 < NP) HIP_OK(hipEventRecord(p->ev_voice_done[k], s));
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][1], s));
-        HIP_OK(hipStreamWaitEvent(s, p->ev_trem[rb_now_idx], 0));
+        if (chain) HIP_OK(hipStreamWaitEvent(s, p->ev_trem[rb_now_idx], 0));
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][2], s));
-        if (sne > 0) {
+        if (sne > 0 && chain) {
             if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one())
                 owdev::k_preamp_mel_lit<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
                                                                                  p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne, melange_generic_only() ? 1 : 0, p->d_mel_lu);
@@ -837,7 +886,9 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
                 owdev::k_preamp<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, rb_now, p->d_lead, p->d_pre, I, L, Lcap, se0, sne);
         }
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][3], s));
-        if (sne > 0 && p->power_amp_kind == OW_POWER_AMP_MELANGE) {
+        if (!chain) {
+            // voice sums only
+        } else if (sne > 0 && p->power_amp_kind == OW_POWER_AMP_MELANGE) {
             owdev::k_post_mpa<<<dim3((sne + PA_EPB - 1) / PA_EPB), dim3(PA_WPB * 64), 0, s>>>(p->dK, p->dPa, p->d_pa_settled, p->d_cs, p->d_pa, p->d_args, p->d_eout, p->d_pre, p->d_out,
                                                                           p->d_pa_tap, I, L, L, se0, sne);
         } else if (sne > 0) {
@@ -889,6 +940,62 @@ void engine_post_render(ow_engine* en, uint32_t l32, const OwEngineOut& o) {
     }
 }
 
+// Second render of the voice-sum NaN guard (engine.rs:496-521).  When a block's voice sum was non-finite the reference zeroes the sum and
+// renders every voice the engine still has AGAIN, freeing the ones whose output is non-finite; the survivors have then advanced 2 * len
+// samples.  engine_post_render has already freed the voices that were non-finite in the first pass and dropped the steal voices whose
+// crossfade ended (the reference drops those at the end of the first pass, before the guard looks); here the survivors are stepped by
+// another `len` samples (k_voice in guard mode: same stepping, nothing summed), voices that turn non-finite in that second pass are freed
+// too, and the status the block leaves behind (silent voices, transient phases) is the status after the second pass.  Cold path.
+void engine_guard_second_pass_result(ow_engine* en, const OwEngineOut& o) {
+    for (int s = 0; s < OW_MAX_VOICES; ++s) {
+        Slot& sl = en->slots[s];
+        bool touched = false;
+        if ((o.bad_main >> s) & 1ull) { en->set_state(s, OW_VOICE_FREE); sl.has_voice = false; touched = true; }
+        if ((o.bad_steal >> s) & 1ull) { sl.has_steal = false; sl.steal_fade = 0; touched = true; }
+        if (touched) en->sync_masks(s);
+    }
+    for (uint64_t m = o.silent_mask & en->main_mask; m; m &= m - 1) {     // cleanup_voices sees the twice-advanced voices (engine.rs:461)
+        const int s = __builtin_ctzll(m);
+        Slot& sl = en->slots[s];
+        if (en->state_of(s) != OW_VOICE_FREE && sl.has_voice) { en->set_state(s, OW_VOICE_FREE); sl.has_voice = false; en->sync_masks(s); }
+    }
+}
+void guard_second_pass(ow_pool* p, const uint32_t* engs, size_t n_eng, size_t len) {
+    hipStream_t st = p->stream;
+    uint32_t nm = 0, ns = 0;          // entries; one block per engine and list
+    for (size_t i = 0; i < n_eng; ++i) {
+        const ow_engine* en = p->engines[engs[i]];
+        auto put = [&](uint32_t* a, uint32_t& n, uint64_t mask) {
+            if (!mask) return;
+            for (uint64_t m = mask; m; m &= m - 1) a[n++] = (engs[i] << 6) | (uint32_t)__builtin_ctzll(m);
+            while (n & 63u) a[n++] = 0xFFFFFFFFu;
+        };
+        put(p->vl_general.h, nm, en->main_mask);
+        put(p->vl_steal.h, ns, en->steal_mask);
+        HIP_OK(hipMemsetAsync(p->d_eout + engs[i], 0, sizeof(OwEngineOut), st));
+    }
+    p->lists_valid = false;           // the list buffers were borrowed
+    const int I = (int)p->I, L = (int)len, Lcap = (int)p->Lcap;
+    if (nm) {
+        HIP_OK(hipMemcpyAsync(p->vl_general.d, p->vl_general.h, sizeof(uint32_t) * nm, hipMemcpyHostToDevice, st));
+        owdev::k_voice<false><<<dim3(nm / 64), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_general.d, p->d_sum, p->d_eout, I, L, Lcap, 2);
+    }
+    if (ns) {
+        HIP_OK(hipMemcpyAsync(p->vl_steal.d, p->vl_steal.h, sizeof(uint32_t) * ns, hipMemcpyHostToDevice, st));
+        owdev::k_voice<false><<<dim3(ns / 64), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_steal.d, p->d_sum, p->d_eout, I, L, Lcap, 3);
+    }
+    HIP_OK(hipGetLastError());
+    for (size_t i = 0; i < n_eng; ++i)
+        HIP_OK(hipMemcpyAsync(p->h_eout + engs[i], p->d_eout + engs[i], sizeof(OwEngineOut), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    for (size_t i = 0; i < n_eng; ++i) {
+        OwEngineOut& o = p->h_eout[engs[i]];
+        engine_guard_second_pass_result(p->engines[engs[i]], o);
+        p->transient[engs[i]] = o.transient != 0u;
+        o.sum_nonfinite = 1u;         // the block's voice sum stays "zeroed by the guard" for ow_pool_read_voice_sum
+    }
+}
+
 // host bookkeeping after the block has been rendered (needs h_eout; call after stream sync)
 void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
     const uint32_t l32 = (uint32_t)std::min<size_t>(len, 0xFFFFFFFFull);
@@ -896,10 +1003,11 @@ void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
     // update (40 ms on one thread for 65 536 engines), so large ranges are cut into slices like the MIDI and op packing are
     const size_t T = ne >= 16384 ? std::min<size_t>(effective_cpus(), 32) : 1;
     const int per = (int)((ne + T - 1) / T);
-    uint8_t lists_changed[OW_MAX_SLICES] = {0}, misdispatch[OW_MAX_SLICES] = {0};
+    uint8_t lists_changed[OW_MAX_SLICES] = {0}, misdispatch[OW_MAX_SLICES] = {0}, guard_t[OW_MAX_SLICES] = {0};
+    bool any_guard = false;
     auto slice = [&](size_t t) {
         const int k1 = std::min(ne, (int)(t + 1) * per);
-        uint8_t changed = 0, bad = 0;
+        uint8_t changed = 0, bad = 0, grd = 0;
         for (int k = (int)t * per; k < k1; ++k) {
             const OwEngineOut& o = p->h_eout[e0 + k];
             const OwEngineArgs& a = p->h_args[e0 + k];
@@ -908,9 +1016,10 @@ void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
             if (tr != p->transient[e0 + k]) { p->transient[e0 + k] = tr; changed = 1; }
             // fast path on the contiguous status/args arrays: nothing to book-keep for this engine
             if (!a.steal_mask && !(o.silent_mask & a.main_mask) && !o.sum_nonfinite && !o.out_nonfinite) continue;
+            if (o.sum_nonfinite) grd = 1;
             engine_post_render(p->engines[e0 + k], l32, o);
         }
-        lists_changed[t] = changed; misdispatch[t] = bad;
+        lists_changed[t] = changed; misdispatch[t] = bad; guard_t[t] = grd;
     };
     // a steady block of a big pool has (almost) nothing to do per engine, which is not worth starting threads for (~0.1 ms): estimate
     // the engines with steal fades / silent voices from every 64th one and go parallel from ~8 000 of them
@@ -927,14 +1036,22 @@ void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
     for (size_t t = 0; t < T; ++t) {
         if (lists_changed[t]) p->lists_valid = false;
         if (misdispatch[t]) set_err("voice dispatch: an engine in a transient phase was sent to the steady kernel");
+        any_guard = any_guard || guard_t[t];
+    }
+    if (any_guard) {      // voice-sum NaN guard fired somewhere: the reference's second render pass for those engines
+        uint32_t* engs = p->h_op_engines;     // pinned scratch of I entries, free between renders
+        size_t n = 0;
+        for (int k = 0; k < ne; ++k) if (p->h_eout[e0 + k].sum_nonfinite) engs[n++] = (uint32_t)(e0 + k);
+        guard_second_pass(p, engs, n, len);
     }
 }
 
 void collect_profile(ow_pool* p) {
     if (!p->profiling) return;
-    hipEventSynchronize(p->ev[7]);   // in a small pool the block-ahead tremolo outlasts the audio stream; profiling waits for it, a normal render does not
+    if (p->voices_only) { p->last_ms[2] = 0.f; }
+    else hipEventSynchronize(p->ev[7]);   // in a small pool the block-ahead tremolo outlasts the audio stream; profiling waits for it, a normal render does not
     hipEventElapsedTime(&p->last_ms[0], p->ev[0], p->ev[1]);   // ops
-    hipEventElapsedTime(&p->last_ms[2], p->ev[6], p->ev[7]);   // tremolo (own stream)
+    if (!p->voices_only) hipEventElapsedTime(&p->last_ms[2], p->ev[6], p->ev[7]);   // tremolo (own stream)
     // per-stage intervals on the stage streams, summed: voices run one stage after the other (the sum is the voice kernels' time, with
     // the previous stage's chain kernels running beside them); preamp / post of a stage overlap the next stage's voices
     float v = 0.f, pr = 0.f, po = 0.f, x = 0.f;
@@ -994,7 +1111,7 @@ void push_op(ow_engine* en, uint8_t type, int slot, uint8_t note, bool mlp, uint
 }
 
 ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int preamp_kind, int power_amp_kind = OW_POWER_AMP_BEHAVIORAL,
-                     int tremolo_kind = OW_TREMOLO_TWIN_T) {
+                     int tremolo_kind = OW_TREMOLO_TWIN_T, bool voices_only = false) {
     if (!(sample_rate > 0.0) || n_engines == 0) throw std::runtime_error("invalid sample rate or engine count");
     if (tremolo_kind != OW_TREMOLO_TWIN_T && tremolo_kind != OW_TREMOLO_LEGACY_LFO) throw std::runtime_error("unknown tremolo_kind");
     if (preamp_kind != OW_PREAMP_LEGACY8 && preamp_kind != OW_PREAMP_MELANGE12) throw std::runtime_error("unknown preamp_kind");
@@ -1008,6 +1125,7 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     p->I = n_engines;
     p->power_amp_kind = power_amp_kind;
     p->tremolo_kind = tremolo_kind;
+    p->voices_only = voices_only;
     HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&p->stream_trem, hipStreamNonBlocking));
     for (auto& e : p->ev) HIP_OK(hipEventCreate(&e));
@@ -1021,6 +1139,7 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     }
     for (auto& e : p->ev_trem) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_OK(hipMalloc(&p->d_trem_backup, sizeof(double) * 18 * n_engines));
+    HIP_OK(hipMalloc(&p->d_trem_settled, sizeof(double) * 18));
     HIP_OK(hipMalloc(&p->dK, sizeof(OwConsts)));
     HIP_OK(hipMalloc(&p->dK48, sizeof(OwConsts)));
     HIP_OK(hipMalloc(&p->d_nt, sizeof(double) * NT_COUNT * 64));
@@ -1089,6 +1208,11 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
         en->ops.reserve(3 * OW_MAX_VOICES);
         p->engines[i] = en;
     }
+    if (voices_only) {          // Voice::render_note has no chain (voice.rs:191-221): nothing to initialise, nothing to settle
+        for (size_t i = 0; i < n_engines; ++i) p->h_lead[i] = 0u;
+        HIP_OK(hipStreamSynchronize(p->stream));
+        return p;
+    }
     // WurliEngine::new for engine 0 on the device, then replicate (every engine of a fresh pool is identical)
     chain_init_range(p, 0, 1, INIT_NEW, std::vector<double>(1, 0.5));
     if (n_engines > 1)
@@ -1142,6 +1266,7 @@ void pool_destroy(ow_pool* p) {
     }
     for (auto& e : p->ev_trem) if (e) hipEventDestroy(e);
     if (p->d_trem_backup) hipFree(p->d_trem_backup);
+    if (p->d_trem_settled) hipFree(p->d_trem_settled);
     if (p->stream_trem) hipStreamDestroy(p->stream_trem);
     if (p->stream) hipStreamDestroy(p->stream);
     for (ow_engine* en : p->engines) delete en;
@@ -1710,6 +1835,30 @@ int ow_test_host_matrices(int solver, double rate, int force_rebuild, double* s,
         throw std::runtime_error("unknown solver");
     } catch (const std::exception& ex) { set_err(std::string("ow_test_host_matrices: ") + ex.what()); return -1; }
 }
+// Forget the process-wide settled states (Twin-T per chain rate; melange preamp and power amp per device): the next pool settles
+// afresh on the device.  Returns the number of cached Twin-T states that were dropped.
+int ow_test_clear_settle_caches(void) {
+    std::lock_guard<std::mutex> lk(g_mel_mu);
+    const int n = (int)g_trem_settled.size();
+    g_trem_settled.clear(); g_mel_settled.clear(); g_pa_settled.clear();
+    return n;
+}
+// Overwrite one field of a voice record (VF_* of ow_types.h) on the device before the next block: the way to make a voice non-finite,
+// which no API call can (voice-sum NaN guard, engine.rs:496-521).
+static_assert(VF_Q == OW_TEST_VF_Q && VF_S == OW_TEST_VF_S0, "openwurli_hip_test.h names two voice-record fields by index");
+int ow_test_engine_poke_voice(ow_engine* e, int slot, int steal, int field, double value) {
+    if (!e || !e->pool || slot < 0 || slot >= OW_MAX_VOICES || field < 0 || field >= VF_COUNT) return -1;
+    ow_pool* p = e->pool;
+    if (hipSetDevice(p->device) != hipSuccess || hipStreamSynchronize(p->stream) != hipSuccess) return -1;
+    double* dst = p->d_vrec + ((size_t)e->index * 2 + (steal ? 1 : 0)) * OW_VREC_DOUBLES + (size_t)field * 64 + slot;
+    return hipMemcpy(dst, &value, sizeof value, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+// plain device-to-host copy (tests read blocks that a render left in HBM: ow_pool_device_output)
+int ow_test_device_read(void* dst_host, const void* src_device, size_t bytes, int device) {
+    if (!dst_host || !src_device) return -1;
+    if (hipSetDevice(device) != hipSuccess) return -1;
+    return hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
 void ow_test_inject_render_faults(ow_pool* p, int n_renders) { if (p) p->inject_faults = n_renders > 0 ? n_renders : 0; }
 
 // ---- diagnostics ---------------------------------------------------------------------------------
@@ -1793,7 +1942,9 @@ int ow_debug_unary(int which, const double* x, size_t n, double* fast, double* l
 // ---- offline ------------------------------------------------------------------------------------
 long long ow_render_note(uint8_t midi, double velocity, double dur_s, double sample_rate, int device, double* out, size_t cap) {
     try {
-        struct PoolGuard { ow_pool* p; ~PoolGuard() { pool_destroy(p); } } guard{pool_create(sample_rate, 1, device, OW_PREAMP_LEGACY8)};
+        // a voices-only pool: no chain state, no Twin-T settle, and render_range launches the voice kernels alone
+        struct PoolGuard { ow_pool* p; ~PoolGuard() { pool_destroy(p); } } guard{pool_create(sample_rate, 1, device, OW_PREAMP_LEGACY8, OW_POWER_AMP_BEHAVIORAL,
+                                                                                               OW_TREMOLO_TWIN_T, true)};
         ow_pool* p = guard.p;
         ow_engine* e = p->engines[0];
         // Voice::render_note: seed = midi * 2654435761, MLP off, no note clamping beyond the table range (voice.rs:206-207)
@@ -1803,13 +1954,20 @@ long long ow_render_note(uint8_t midi, double velocity, double dur_s, double sam
         push_op(e, OP_NOTE_ON, 0, note, false, (uint32_t)midi * 2654435761u, velocity);
         double x = dur_s * sample_rate;
         const size_t n = (!(x == x) || x <= 0.0) ? 0 : (size_t)x;
-        std::vector<double> chunk(1024);
+        const size_t chunk_len = p->Lcap;            // OW_MAX_BLOCK for a pool of one: few launches, few synchronisations
+        std::vector<double> chunk(chunk_len);
         size_t done = 0;
         while (done < n) {
-            const size_t len = std::min<size_t>(1024, n - done);
+            const size_t len = std::min<size_t>(chunk_len, n - done);
             render_range(p, 0, 1, len, true);
             HIP_OK(hipStreamSynchronize(p->stream));
-            // no cleanup_voices here: render_note keeps rendering the voice for the whole duration
+            // no cleanup_voices here: render_note keeps rendering the voice for the whole duration; only the kernel choice of the
+            // next chunk follows the device status (onset ramp / attack noise still running -> general kernel again)
+            {
+                const uint8_t tr = p->h_eout[0].transient != 0u;
+                if (p->h_eout[0].transient == 2u) throw std::runtime_error("voice dispatch: a voice in a transient phase was sent to the steady kernel");
+                if (tr != p->transient[0]) { p->transient[0] = tr; p->lists_valid = false; }
+            }
             if (ow_pool_read_voice_sum(p, chunk.data(), len, len) != 0) throw std::runtime_error(g_err);
             for (size_t i = 0; i < len && done + i < cap; ++i) out[done + i] = chunk[i];
             done += len;

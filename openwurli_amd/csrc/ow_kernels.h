@@ -164,6 +164,10 @@ OW_DEV void voice_reduce(const double* __restrict__ tile, const int* __restrict_
 
 // General step (any phase).  pass 0 = slot voices of the engines the host classified as "in a transient phase", pass 1 = steal voices
 // (one engine per block there, so the crossfade early-out below is per engine).
+// pass | 2 = the voice-sum NaN guard's second render (engine.rs:496-521): after a block whose voice sum was non-finite the reference
+// renders every remaining voice of the engine AGAIN to find the culprit, which advances the survivors by another `L` samples.  The same
+// stepping runs here with nothing summed or written but the voice records and the status bits; a steal voice's crossfade counter is
+// not touched (the reference decrements it in the first pass only).
 // TABS: tabulate phase gain curves per chunk (below).  The tables cost 14 KB of LDS (4 instead of 7 blocks per CU), so the host uses
 // this variant when the general list is sparse (played input) and the plain one when most engines are in it (a re-strike of everything).
 template <bool TABS>
@@ -177,6 +181,8 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
     const int lane = threadIdx.x;
     const VoiceLanes w = voice_lanes(entries, eng_l);
     const bool active = w.active;
+    const bool guard = (pass & 2) != 0;
+    pass &= 1;
     double* rec = vrec + ((size_t)(active ? w.e : 0) * 2 + pass) * OW_VREC_DOUBLES + w.slot;
 
     VoiceRegs v;
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
         // Steal pass: once every crossfade of this engine has run out (gain (fade - i)/len == 0 from here on, engine.rs:483-489)
         // the rest of the block only adds voice x 0.0, and the voices are dropped after the block (steal_fade reaches 0): stop
         // stepping them.  (The reference keeps rendering them; only a voice turning non-finite inside its last 5 ms would differ.)
-        if (pass && __all(!active || steal_fade <= (uint32_t)base)) {
+        if (pass && !guard && __all(!active || steal_fade <= (uint32_t)base)) {
             double* row = sum + ((size_t)pass * I + eng_l[0]) * Lcap;
             for (int i = base + lane; i < L; i += 64) row[i] = 0.0;
             break;
@@ -248,11 +254,11 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
         }
         if (active && !v.state_finite()) bad_voice = true;
         __syncthreads();
-        voice_reduce(tile, eng_l, w, cn, base, pass, sum, eout, I, Lcap);
+        if (!guard) voice_reduce(tile, eng_l, w, cn, base, pass, sum, eout, I, Lcap);
         __syncthreads();
     }
     if (active) {
-        if (pass) {  // slot.steal_fade.saturating_sub(len) (engine.rs:490)
+        if (pass && !guard) {  // slot.steal_fade.saturating_sub(len) (engine.rs:490)
             const uint32_t l32 = (uint32_t)L;
             steal_fade = steal_fade > l32 ? steal_fade - l32 : 0u;
             rec[VF_STEAL * 64] = bitsd((uint64_t)steal_fade | ((uint64_t)steal_len << 32));
@@ -583,6 +589,14 @@ __global__ __launch_bounds__(64) void k_trem_settle(const OwConsts* __restrict__
         else trem_osc_step(t, &P, K, &M + z);
     }
     trem_store(t, &P, cs, I, e);
+}
+
+// Settled Twin-T state from the process-wide cache (openwurli_hip.hip, trem_settle_cached): rows 0..16 of engine e are overwritten with
+// the cached post-settle values, the BE-fallback counter (row 17) advances by the count the settle itself produced.
+__global__ void k_trem_load_settled(double* __restrict__ cs, int I, int e, const double* __restrict__ settled18) {
+    const int f = threadIdx.x;
+    if (f < CS_T_BE) cs[(size_t)f * I + e] = settled18[f];
+    else if (f == CS_T_BE) cs[(size_t)f * I + e] = bitsd(dbits(cs[(size_t)f * I + e]) + dbits(settled18[f]));
 }
 
 // copy the chain state of engine `src` to engines [e0, e0+ne) (identical by determinism at pool creation)

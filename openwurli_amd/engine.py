@@ -74,6 +74,10 @@ class _EngineHandle:
         """gen_preamp::set_seed of the melange preamp's main state (0 = process-wide clock entropy, the reference's only mode)."""
         self._lib.ow_engine_set_noise_seed(self._h, int(seed))
 
+    def poke_voice(self, slot, steal, field, value):
+        """Test hook (openwurli_hip_test.h): overwrite one double of a voice record on the device."""
+        return self._lib.ow_test_engine_poke_voice(self._h, int(slot), 1 if steal else 0, int(field), float(value))
+
     def reset(self):
         self._lib.ow_engine_reset(self._h)
         binding.raise_if_error(self._lib)

@@ -34,6 +34,24 @@ void owo_engine_power_amp_diag(void* e, unsigned long long* clamp, unsigned long
     *peak = w->power_amp_kind ? w->mel_pa.state.diag_peak_output : 0.0;
     *guard_resets = w->power_amp_kind ? w->mel_pa.guard_resets : 0ull;
 }
+// test poke (mirror of the product's ow_test_engine_poke_voice): field 81 = pickup charge q, 0 = mode 0's sine state.  Returns 0, -1 if
+// the slot has no such voice.
+int owo_engine_poke_voice(void* e, int slot, int steal, int field, double value) {
+    WurliEngine* w = (WurliEngine*)e;
+    if (slot < 0 || slot >= MAX_VOICES) return -1;
+    Voice* v = steal ? w->voices[slot].steal_voice.get() : w->voices[slot].voice.get();
+    if (!v) return -1;
+    if (field == 81) v->pickup.q = value;
+    else if (field == 0) v->reed.modes[0].s = value;
+    else return -1;
+    return 0;
+}
+// n steps of the tremolo cell alone (Tremolo::process: oscillator + LED + CdS envelope), results discarded: what the product's
+// ow_test_pool_stagger_tremolo does to a phase group, so that staggered engines can be compared with the oracle
+void owo_engine_advance_tremolo(void* e, size_t n) {
+    WurliEngine* w = (WurliEngine*)e;
+    for (size_t i = 0; i < n; ++i) (void)w->tremolo.process();
+}
 void owo_engine_poke_pa_node(void* e, int node, double v) { ((WurliEngine*)e)->mel_pa.state.v_prev[node] = v; }
 // render with the power-amp tap (chain rate) besides the output
 void owo_engine_render_pa_tap(void* e, float* out, double* pa, size_t n) {

@@ -128,6 +128,12 @@ class OracleEngine:
         self.L.owo_engine_render_pa_tap(self.h, _p(out), _p(pa), C.c_size_t(int(n)))
         return out, pa
 
+    def advance_tremolo(self, n): self.L.owo_engine_advance_tremolo(self.h, C.c_size_t(int(n)))
+
+    def poke_voice(self, slot, steal, field, value):
+        """test poke: field 81 = pickup charge q, 0 = mode 0's sine state (the product's ow_test_engine_poke_voice)"""
+        return self.L.owo_engine_poke_voice(self.h, int(slot), 1 if steal else 0, int(field), C.c_double(value))
+
     def poke_power_amp_node(self, node, volts): self.L.owo_engine_poke_pa_node(self.h, int(node), C.c_double(volts))
 
     def count_voices_in_state(self, st): return self.L.owo_engine_count_state(self.h, int(st))

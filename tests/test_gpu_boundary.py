@@ -133,3 +133,164 @@ def test_render_failure_is_silence_and_is_reported(hiplib):
     hiplib.ow_clear_error()
     assert np.max(np.abs(e.render(2048))) > 1e-4
     e.close()
+
+
+def test_settled_tremolo_cache_is_bit_identical(hiplib, oracle):
+    """The 192 050-step Twin-T settle (tremolo.rs:92-102) is computed once per (device, chain rate) and copied afterwards (VERDICT r02
+    next-6).  A cached engine must be the freshly settled one bit for bit -- R stream, preamp tap and output -- through new, set_sample_rate,
+    reset of one engine and of the pool; and it must match the oracle like any other engine."""
+    import time
+    import openwurli_amd as ow
+    sr = 48000.0
+
+    def play(e):
+        e.set_tremolo_depth(1.0); e.set_volume(0.6)
+        for n in (45, 60, 67):
+            e.note_on(n, 0.8)
+        out = [e.render(512) for _ in range(6)]
+        return np.concatenate(out)
+
+    def lifecycle(make):
+        t0 = time.perf_counter()
+        e = make()
+        e.set_sample_rate(sr)
+        dt = time.perf_counter() - t0
+        a = play(e)
+        r = e.read_tremolo_r(1024) if hasattr(e, "read_tremolo_r") else None
+        e.reset()
+        b = play(e)
+        e.set_sample_rate(44100.0)
+        c = play(e)
+        e.close()
+        return dt, a, b, c, r
+
+    hiplib.ow_test_clear_settle_caches()
+    t_fresh, a0, b0, c0, r0 = lifecycle(lambda: ow.WurliEngine(sr))             # misses: 96 kHz (new, rate, reset), then 88.2 kHz
+    t_hit, a1, b1, c1, r1 = lifecycle(lambda: ow.WurliEngine(sr))               # hits everywhere
+    assert hiplib.ow_test_clear_settle_caches() == 2                            # chain rates 96 000 and 88 200
+    t_again, a2, b2, c2, r2 = lifecycle(lambda: ow.WurliEngine(sr))             # settles afresh again
+    for x, y, z in ((a0, a1, a2), (b0, b1, b2), (c0, c1, c2)):
+        assert np.max(np.abs(x)) > 1e-3
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    if r0 is not None:
+        assert np.array_equal(r0, r1) and np.array_equal(r0, r2)
+    # new + set_sample_rate of a second engine: no 0.9 s settle any more (warm-up of 0.6 s of audio remains: 57 blocks)
+    assert t_hit < 0.5 * t_fresh or t_hit < 0.35, (t_fresh, t_hit, t_again)
+    # and the cached engine is the reference's engine
+    g = ow.WurliEngine(sr); c = oracle.OracleEngine(sr)
+    g.set_sample_rate(sr); c.set_sample_rate(sr)
+    rep = oracle.parity_report(play(g), play(c), abs_floor=oracle.ABS_FLOOR_OUTPUT)
+    assert rep["n_bad"] == 0, rep
+    # a pool: engine 3 reset alone (leaves the phase group, takes the cached state), then the whole pool
+    p = ow.EnginePool(sr, 6)
+    p.set_sample_rate(sr)
+    cs = [oracle.OracleEngine(sr) for _ in range(6)]
+    for k, o in enumerate(cs):
+        o.set_sample_rate(sr)
+        for e in (p[k], o):
+            e.set_tremolo_depth(0.9); e.note_on(50 + 3 * k, 0.7)
+    for blk in range(3):
+        go = p.render(512)
+        for k in range(6):
+            assert oracle.parity_report(go[k], cs[k].render(512), abs_floor=oracle.ABS_FLOOR_OUTPUT)["n_bad"] == 0, (blk, k)
+    p[3].reset(); cs[3].reset()
+    for e in (p[3], cs[3]):
+        e.note_on(62, 0.8)
+    for blk in range(4):
+        go = p.render(512)
+        for k in range(6):
+            assert oracle.parity_report(go[k], cs[k].render(512), abs_floor=oracle.ABS_FLOOR_OUTPUT)["n_bad"] == 0, ("after reset", blk, k)
+    d = p[3].diag()
+    assert d.tremolo_be_fallbacks == p[0].diag().tremolo_be_fallbacks or d.tremolo_be_fallbacks >= 0
+    p.close(); g.close()
+
+
+VF_S0, VF_Q = 0, 81      # openwurli_hip_test.h: OW_TEST_VF_S0, OW_TEST_VF_Q
+
+
+@pytest.mark.parametrize("scenario", ["slot_voice_q", "slot_voice_s0", "steal_voice", "steal_voice_survives_first_pass", "two_culprits_steady_kernel"])
+def test_voice_sum_nan_guard_second_pass(hiplib, oracle, scenario):
+    """engine.rs:496-521.  A voice is made non-finite on both sides (test poke; no API call can do it).  The block it poisons comes out as
+    the chain's response to a zeroed voice sum; the culprit -- and only the culprit -- is freed; nan_guard_fires counts one; and because
+    the reference finds the culprit by rendering EVERY voice a second time, the survivors have advanced 2 x len samples: the blocks
+    after the guard only match the oracle if the second pass is reproduced (deviation 2 is closed)."""
+    import openwurli_amd as ow
+    sr, L = 48000.0, 256
+    g = ow.EnginePool(sr, 3)
+    cs = [oracle.OracleEngine(sr) for _ in range(3)]
+    g.set_sample_rate(sr)
+    for c in cs:
+        c.set_sample_rate(sr)
+
+    def compare(tag, blocks, length=L, taps=True):
+        for b in range(blocks):
+            go = g.render(length)
+            gv = g.voice_sum(length)
+            for k in range(3):
+                co, cv, _, _ = cs[k].render_taps(length)
+                rep = oracle.parity_report(go[k], co, abs_floor=oracle.ABS_FLOOR_OUTPUT)
+                assert rep["n_bad"] == 0, (scenario, tag, "out", b, k, rep)
+                rep = oracle.parity_report(gv[k], cv, rel=1e-12, floor_frac=1.0)
+                assert rep["n_bad"] == 0, (scenario, tag, "voice sum", b, k, rep)
+            for k in range(3):
+                for s in range(64):
+                    assert hiplib.ow_engine_slot_state(g[k]._h, s) == cs[k].slot_state(s), (scenario, tag, b, k, s)
+                assert g[k].diag().steal_voices == cs[k].steal_voice_count(), (scenario, tag, b, k)
+                assert g[k].nan_guard_fires() == cs[k].nan_guard_fires(), (scenario, tag, b, k)
+
+    chord = (40, 52, 59, 64, 67, 72, 88)
+    for k in range(3):
+        for e in (g[k], cs[k]):
+            e.set_tremolo_depth(0.7)
+            for n in chord:
+                e.note_on(n + k, 0.5 + 0.1 * k)
+    # slots 0..6 in note order.  The steady-kernel scenario waits until onset ramps and attack noise are over (engines leave k_voice)
+    compare("before", 12 if scenario == "two_culprits_steady_kernel" else 2)
+    if scenario.startswith("steal_voice"):
+        for e in (g[1], cs[1]):
+            for n in range(33, 97):
+                e.note_on(n, 0.4)             # 57 free slots, then the seven oldest Held voices (slots 0..6) are stolen ...
+            e.note_on(50, 0.9)                # ... and one more: eight 5 ms crossfades
+        assert g[1].diag().steal_voices == cs[1].steal_voice_count() == 8
+        compare("stolen", 1, length=64)       # 64 of the 240 crossfade samples
+        for e in (g[1], cs[1]):
+            assert e.poke_voice(0, True, VF_Q, float("nan")) == 0
+    elif scenario == "slot_voice_q":
+        for e in (g[1], cs[1]):
+            assert e.poke_voice(3, False, VF_Q, float("nan")) == 0
+    elif scenario == "slot_voice_s0":
+        for e in (g[1], cs[1]):
+            assert e.poke_voice(5, False, VF_S0, float("inf")) == 0
+        for e in (g[1], cs[1]):
+            e.note_off(52 + 1)                # a damper phase starts in the same block: the second pass runs it twice as far
+    else:
+        for e in (g[0], cs[0]):
+            assert e.poke_voice(1, False, VF_Q, float("nan")) == 0
+            assert e.poke_voice(6, False, VF_S0, float("nan")) == 0
+        for e in (g[2], cs[2]):
+            assert e.poke_voice(0, False, VF_Q, float("-inf")) == 0
+    fires_before = [c.nan_guard_fires() for c in cs]
+    active_before = [c.active_voice_count() for c in cs]
+    # 256 samples end all eight crossfades inside the block: the reference drops those steal voices at the end of its FIRST pass, the
+    # second pass finds no culprit and every slot voice advances twice.  With a 64-sample block the poisoned steal voice is still there
+    # (fade 176 -> 112), the second pass renders it again, finds it and drops it; the other seven keep fading from 112.
+    compare("poisoned block", 1, length=64 if scenario == "steal_voice_survives_first_pass" else L)
+    hit = {"steal_voice": [1], "steal_voice_survives_first_pass": [1], "slot_voice_q": [1], "slot_voice_s0": [1], "two_culprits_steady_kernel": [0, 2]}[scenario]
+    for k in range(3):
+        assert cs[k].nan_guard_fires() - fires_before[k] == (1 if k in hit else 0)
+    if scenario == "slot_voice_q":
+        assert cs[1].active_voice_count() == active_before[1] - 1 and cs[1].slot_state(3) == 0
+    if scenario == "two_culprits_steady_kernel":
+        assert cs[0].active_voice_count() == active_before[0] - 2 and cs[2].active_voice_count() == active_before[2] - 1
+    if scenario == "steal_voice":
+        assert cs[1].steal_voice_count() == 0 and cs[1].active_voice_count() == active_before[1]
+    if scenario == "steal_voice_survives_first_pass":
+        assert cs[1].steal_voice_count() == 7 and cs[1].active_voice_count() == active_before[1]
+        compare("rest of the crossfades", 2, length=64)
+    # the survivors are one block ahead of where a single render would have left them: ten more blocks, a re-strike among them
+    compare("after the guard", 5)
+    for k in range(3):
+        for e in (g[k], cs[k]):
+            e.note_off(64 + k); e.note_on(64 + k, 0.8)
+    compare("after the guard, new notes", 5)
+    g.close()
