@@ -47,7 +47,14 @@ EPOCH = 48000          # re-strike period in samples
 NOTES = list(range(33, 97))
 
 # Algorithmic f64 flops per OUTPUT sample of one 64-voice engine (restated in DESIGN.md):
-FLOPS_VOICES = 64 * 130            # 7 modes x 16 + jitter 3 + pickup 13 + gain/sum 2 per voice-sample
+# 7 modes x 15 (the reference's 16 minus the amplitude x envelope multiply that the steady kernel carries as one recurrence, DESIGN
+# deviation 9) + jitter 3 + pickup 13 + gain/sum 2 per voice-sample: the algorithm AS BUILT.  (SURVEY 8d counts 130 for the reference.)
+FLOPS_VOICE_SAMPLE = 123
+FLOPS_VOICES = 64 * FLOPS_VOICE_SAMPLE
+# f64 flops the steady voice kernel EXECUTES per voice-sample by its PMC instruction mix (9.2 add + 27.5 mul + 2 x 35.5 fma,
+# profiles/r02c_voice_steady_pmc.md): below the algorithmic count because the jitter-corrected rotation coefficients (4 flops per
+# mode, reed.rs:281-283 evaluates them every sample) only change with the drift, every 16th sample, and are hoisted there
+FLOPS_VOICE_SAMPLE_EXECUTED = 107.7
 FLOPS_TREMOLO = 2 * (1000 + 25)    # Twin-T NR step + LDR law per OS sample, 2 OS samples -- per tremolo PHASE GROUP, not per engine
 FLOPS_PREAMP = 2 * 1400 + 24       # main+shadow dk_step per OS sample + half-band up
 # melange 12-node preamp as the kernel EXECUTES it (rank-one update of the inverse, no per-sample LU): per state and chain-rate
@@ -93,10 +100,11 @@ def build_events(n_inst, kind):
 class Script:
     """Sample-accurate event script: renders one buffer per step, splitting at epoch boundaries."""
 
-    def __init__(self, pool, n_inst, buf=BUF, host_out=None):
+    def __init__(self, pool, n_inst, buf=BUF, host_out=None, epoch=None):
         self.pool = pool
         self.pos = 0
         self.buf = buf
+        self.epoch = epoch or EPOCH
         self.host_out = host_out          # (pointer, stride) of a pinned host block, or None = audio stays in HBM
         self.ev_strike = build_events(n_inst, "strike")
         self.ev_restrike = build_events(n_inst, "restrike")
@@ -109,10 +117,10 @@ class Script:
         done = 0
         while done < self.buf:
             t0 = time.perf_counter()
-            if self.pos % EPOCH == 0:
+            if self.pos % self.epoch == 0:
                 self.pool.midi(self.ev_strike if self.pos == 0 else self.ev_restrike)
             t1 = time.perf_counter()
-            nxt = min(self.buf - done, EPOCH - (self.pos % EPOCH))
+            nxt = min(self.buf - done, self.epoch - (self.pos % self.epoch))
             if self.host_out is None:
                 self.pool.render(nxt, to_host=False)
             else:
@@ -193,13 +201,34 @@ def cpu_baseline(seconds_audio=1.0, preamp_kind=0):
 
 
 # ---------------------------------------------------------------------------------------------------------------- launcher
-def spawn_ranks(n, argv):
+def visible_gpus():
+    """GPUs of this node counted WITHOUT touching HIP (the parent must stay GPU-free: it starts the ranks as children): the KFD
+    topology lists one node per agent, GPU agents have simd_count > 0; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES narrow it further.
+    None when the topology is not readable (then the ranks find out themselves)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            props = dict(ln.split()[:2] for ln in open(os.path.join(base, node, "properties")) if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def spawn_ranks(n, argv, poll_s=0.2):
     """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (one per GPU) before anything in this process
-    touches the GPU, relay rank 0's line, exit non-zero when any rank fails.  Never re-execs."""
+    touches the GPU (no torch / HIP call here at all), relay rank 0's line.  All children are polled: the first one that exits non-zero
+    takes the others down with it (a rank that dies before the rendezvous would otherwise leave the rest waiting for the store / RCCL
+    timeout), and the launcher exits non-zero.  Never re-execs."""
     if os.environ.get("OW_BENCH_DRYRUN_BACKEND") is None:
-        import torch                                   # device_count() does not initialise the GPU on this image
-        have = torch.cuda.device_count()
-        if have < n:
+        have = visible_gpus()
+        if have is not None and have < n:
             print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
             return 2
     s = socket.socket()
@@ -212,14 +241,35 @@ def spawn_ranks(n, argv):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    for ln in (out0 or "").splitlines():           # rank 0's JSON line goes to stdout; library chatter (gloo / RCCL banners) to stderr
-        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)   # drain rank 0 while polling
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            rc = p.poll()
+            if rc not in (None, 0):
+                failed = (r, rc)
+                break
+        time.sleep(poll_s)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=5.0)
+    for ln in out0:                                # rank 0's JSON line goes to stdout; library chatter (gloo / RCCL banners) to stderr
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln if ln.endswith("\n") else ln + "\n")
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print(f"bench.py: ranks failed: {bad}", file=sys.stderr)
+    if failed is not None or bad:
+        print(f"bench.py: rank {failed[0] if failed else bad[0][0]} failed first; exit codes {rcs}", file=sys.stderr)
         return 1
     return 0
 
@@ -290,9 +340,11 @@ def main(argv=None):
                          "7-BJT Class-AB solver + rail dynamics of its `--no-default-features` build")
     ap.add_argument("--host-rate", type=float, default=48000.0,
                     help="host sample rate: 48000 = BASELINE configs[1] (the metric's config, default); 96000 = configs[2] (no oversampling)")
-    ap.add_argument("--tremolo-groups", type=int, default=1,
-                    help="1 = a fresh pool: every instance was built at the same sample, so all share one tremolo phase (one oscillator "
-                         "per pool); G > 1 staggers the pool into G phase groups (test hook), G = instances prices the fully per-engine path")
+    ap.add_argument("--tremolo-groups", type=int, default=0,
+                    help="tremolo phase groups of the pool.  0 (default) = one per instance: every instance runs its own Twin-T oscillator, as "
+                         "independently created plugin instances do (the pool is staggered with the test hook after the warm-up); 1 = a fresh pool "
+                         "as it is: every instance was built at the same sample, all share one phase and ONE oscillator is computed per pool (the "
+                         "best case, reported as the `shared_tremolo_phase` extra of the default run); G = that many groups")
     args = ap.parse_args(argv)
     if args.steps is None:
         args.steps = 100 if args.workload == "engines" else 3
@@ -313,10 +365,14 @@ def main(argv=None):
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("OW_BENCH_DRYRUN_BACKEND") and os.environ.get("OW_BENCH_TEST_FAIL_RANK") == str(rank):
+        return 3                                     # launcher test: this rank dies before the rendezvous, the others would wait for it
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher decides; reporting n_gpus={world}", file=sys.stderr)
+    import datetime
     import torch
+    RENDEZVOUS_TIMEOUT = datetime.timedelta(seconds=float(os.environ.get("OW_BENCH_RENDEZVOUS_TIMEOUT_S", "300")))
     dist = None
     # OW_BENCH_DRYRUN_BACKEND=gloo: launcher / sharding / gather / JSON-contract dry run on CPU (tests/test_bench_launcher.py): the ranks
     # rendezvous over gloo and the batch render is a deterministic stand-in.  Nothing is measured in that mode and the line says so.
@@ -327,12 +383,12 @@ def main(argv=None):
             return 2
         if world > 1:
             import torch.distributed as dist
-            dist.init_process_group(dryrun, rank=rank, world_size=world)
+            dist.init_process_group(dryrun, rank=rank, world_size=world, timeout=RENDEZVOUS_TIMEOUT)
     else:
         torch.cuda.set_device(local_rank)
         if world > 1:
             import torch.distributed as dist
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=RENDEZVOUS_TIMEOUT)
 
     import openwurli_amd as ow
 
@@ -373,31 +429,55 @@ def main(argv=None):
             }
     else:
         pa_kind = 1 if args.power_amp == "melange" else 0
-        pool = ow.EnginePool(SR, n_inst, device=local_rank, preamp_kind=preamp_kind, power_amp_kind=pa_kind)
-        pool.set_sample_rate(SR)          # the plugin's initialize(): chain build + 0.6 s warm-up (not timed)
-        pool.ensure_buffer_capacity(BUF)
-        groups = max(1, min(args.tremolo_groups, n_inst))
-        if groups > 1:
-            pool.stagger_tremolo(groups)
-        # volume 0.5 / tremolo depth 0.5 / speaker character 0.0 / MLP on are the engine defaults (engine.rs:221-224)
-        for k in range(min(n_inst, 4096)):
-            e = pool[k]
-            e.set_volume(0.5); e.set_tremolo_depth(0.5); e.set_speaker_character(0.0); e.set_mlp_enabled(True)
+        groups = n_inst if args.tremolo_groups <= 0 else max(1, min(args.tremolo_groups, n_inst))
+
+        def make_pool(n, sr=None, preamp=preamp_kind, pa=pa_kind, n_groups=1):
+            """the plugin's initialize() for n instances: chain build + 0.6 s warm-up (not timed), then the tremolo phases"""
+            sr = SR if sr is None else sr
+            p = ow.EnginePool(sr, n, device=local_rank, preamp_kind=preamp, power_amp_kind=pa)
+            p.set_sample_rate(sr)
+            p.ensure_buffer_capacity(BUF)
+            if n_groups > 1:
+                p.stagger_tremolo(min(n_groups, n))
+            # volume 0.5 / tremolo depth 0.5 / speaker character 0.0 / MLP on are the engine defaults (engine.rs:221-224)
+            for k in range(min(n, 4096)):
+                e = p[k]
+                e.set_volume(0.5); e.set_tremolo_depth(0.5); e.set_speaker_character(0.0); e.set_mlp_enabled(True)
+            return p
+
+        def timed_steps(sc, k_steps, profile=False):
+            """k_steps of the script between barriers; max over ranks"""
+            barrier()
+            ta = time.perf_counter()
+            for _ in range(k_steps):
+                sc.step(profile=profile)
+            barrier()
+            el_ = time.perf_counter() - ta
+            if dist is not None:
+                t_ = torch.tensor([el_], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                el_ = float(t_.item())
+            return el_
+
+        def side_run(p, n, k_warm, k_steps, epoch=None, buf=BUF):
+            """a short profiled run of another configuration (extras): value, ms per step and per kernel"""
+            sc = Script(p, n, buf=buf, epoch=epoch)
+            for _ in range(k_warm):
+                sc.step()
+            p.set_profiling(True)
+            el_ = timed_steps(sc, k_steps, profile=True)
+            p.set_profiling(False)
+            kms_ = sc.kernel_ms / max(sc.kernel_launches, 1)
+            return {"value": k_steps * buf * n * world / el_, "unit": "samples/s", "ms_per_step": 1e3 * el_ / k_steps, "steps": k_steps, "warmup": k_warm,
+                    "instances_per_gpu": n, "kernel_ms_per_step": {nm: float(x) for nm, x in zip(("ops", "voices", "tremolo", "preamp", "post"), kms_)}}
+
+        pool = make_pool(n_inst, n_groups=groups)
         script = Script(pool, n_inst)
         for _ in range(args.warmup):
             script.step()
         pool.set_profiling(True)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            script.step(profile=True)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        elapsed = timed_steps(script, args.steps, profile=True)
         pool.set_profiling(False)
-        if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
 
         extras = {}
         if not args.no_extras:
@@ -406,28 +486,48 @@ def main(argv=None):
             sp = Script(pool, n_inst, host_out=host)
             sp.pos = script.pos
             k_steps = max(5, min(args.steps, 20))
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(k_steps):
-                sp.step()
-            barrier()
-            el = time.perf_counter() - t1
-            if dist is not None:
-                t = torch.tensor([el], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el = float(t.item())
+            el = timed_steps(sp, k_steps)
             extras["pcie_inclusive"] = {"value": k_steps * BUF * n_inst * world / el, "unit": "samples/s", "ms_per_step": 1e3 * el / k_steps, "steps": k_steps,
                                         "bytes_per_step_per_gpu": 4 * BUF * n_inst, "host_memory": "pinned (ow_host_alloc)"}
             pool.free_host_block(host)
+            # (a') the other tremolo regime on the SAME pool.  A whole-pool reset puts every instance on one phase again (one oscillator
+            # per pool: the best case, what round 2 reported as `value`); staggering a shared pool prices the per-instance oscillators.
+            if groups > 1:
+                pool.reset()
+                r = side_run(pool, n_inst, 3, 10)
+                r["tremolo_phase_groups"] = 1
+                r["note"] = ("every instance reset at the same sample: ONE Twin-T oscillator per pool, read by all (bit-exact, tests/test_gpu_tremolo_groups.py); "
+                             "independently created plugin instances do not share a phase -- `value` is the per-instance figure")
+                extras["shared_tremolo_phase"] = r
+            else:
+                pool.stagger_tremolo(n_inst)
+                r = side_run(pool, n_inst, 3, 10)
+                r["tremolo_phase_groups"] = n_inst
+                extras["tremolo_decorrelated"] = r
         pool.close()
+
+        if not args.no_extras and SR == 48000.0 and not preamp_kind and not pa_kind:
+            # (a'') the neighbouring BASELINE configs on the same pool size, short runs: configs[2] (96 kHz host, no oversampling) and the
+            # melange 12-node preamp the north star names (literal per-sample rebuild)
+            p3 = make_pool(n_inst, sr=96000.0, n_groups=groups)
+            r = side_run(p3, n_inst, 3, 10, epoch=96000)
+            r["x_realtime_at_96k"] = r["value"] / 96000.0
+            r["workload"] = "cfg3: 64-voice all-keys, 96 kHz host (no oversampling), full chain, MLP on, buffers of 512"
+            extras["config3"] = r
+            p3.close()
+            n_mel = min(n_inst, 65536)
+            pm = make_pool(n_mel, preamp=1, n_groups=min(groups, n_mel))
+            r = side_run(pm, n_mel, 2, 6)
+            r["workload"] = "cfg2 with the melange 12-node preamp (k_preamp_mel_lit: the reference's rebuild_matrices + invert_n per chain-rate sample)"
+            r["preamp_frac_of_fp64_peak"] = FLOPS_PREAMP_MELANGE_LIT * BUF * n_mel / (r["kernel_ms_per_step"]["preamp"] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS
+            extras["preamp_melange"] = r
+            pm.close()
 
         single = None
         cpu = None
         if rank == 0 and not args.no_extras:
-            # (b) configs[4] taken literally: ONE pool of 256 instances on this GPU
-            p256 = ow.EnginePool(SR, 256, device=local_rank, preamp_kind=preamp_kind)
-            p256.set_sample_rate(SR)
-            p256.ensure_buffer_capacity(BUF)
+            # (b) configs[4] taken literally: ONE pool of 256 instances on this GPU (its own 256 tremolo phases)
+            p256 = make_pool(256, n_groups=min(groups, 256))
             s256 = Script(p256, 256)
             for _ in range(3):
                 s256.step()
@@ -437,13 +537,13 @@ def main(argv=None):
                 s256.step()
             el = time.perf_counter() - t1
             extras["config4_literal"] = {"instances": 256, "value": 30 * BUF * 256 / el, "unit": "samples/s", "x_realtime_aggregate": 30 * BUF * 256 / el / SR,
-                                         "ms_per_step": 1e3 * el / 30}
+                                         "ms_per_step": 1e3 * el / 30, "tremolo_phase_groups": min(groups, 256),
+                                         "preamp": args.preamp, "power_amp": args.power_amp}
             p256.close()
             # (c) one instance (what one plugin instance sees): per-buffer latency at the usual host buffer sizes, audio copied to the host
             table = []
             for buf in (64, 128, 256, 512):
-                one = ow.EnginePool(SR, 1, device=local_rank, preamp_kind=preamp_kind)
-                one.set_sample_rate(SR)
+                one = make_pool(1)
                 one.ensure_buffer_capacity(buf)
                 s1 = Script(one, 1, buf=buf)
                 host1 = np.zeros((1, buf), dtype=np.float32)
@@ -482,7 +582,28 @@ def main(argv=None):
                               "paced_load": float(paced.mean() / (1e6 * period))})
                 one.close()
             extras["single_instance"] = table
+            extras["single_instance_config"] = {"preamp": args.preamp, "power_amp": args.power_amp}
             single = table[-1]["samples_per_s"]
+            # (d) instantiation and config 1: a second engine of the process (settled states cached), and Voice::render_note for 60 s
+            # (tools/reed-renderer; the reference publishes 0.08 s for it, CHANGELOG.md:185) next to the oracle on one host thread
+            t1 = time.perf_counter()
+            e2 = ow.WurliEngine(SR, device=local_rank, preamp_kind=preamp_kind, power_amp_kind=pa_kind)
+            t2 = time.perf_counter()
+            e2.set_sample_rate(SR)
+            t3 = time.perf_counter()
+            e2.close()
+            extras["instantiate_ms"] = {"engine_new": 1e3 * (t2 - t1), "set_sample_rate_incl_0.6s_warm_up": 1e3 * (t3 - t2)}
+            t1 = time.perf_counter()
+            rn = ow.render_note(60, 100 / 127.0, 60.0, SR, device=local_rank)
+            t2 = time.perf_counter()
+            rn_cpu_ms = None
+            if not args.no_cpu_baseline:
+                import oracle_binding as ob
+                t3 = time.perf_counter()
+                ob.render_note(60, 100 / 127.0, 60.0, SR)
+                rn_cpu_ms = 1e3 * (time.perf_counter() - t3)
+            extras["render_note_60s_ms"] = {"gpu": 1e3 * (t2 - t1), "cpu_oracle_one_thread": rn_cpu_ms, "samples": int(rn.size),
+                                            "note": "one voice = one lane: a serial recurrence, latency-bound on a GPU; voices only (no chain launches, no settle)"}
         if not args.no_extras:
             barrier()
             extras["batch"] = batch_bench(dist, world, steps=2, warmup=1)
@@ -528,7 +649,9 @@ def main(argv=None):
                     "tremolo_phase_groups": groups,
                     "tremolo_note": ("all instances of a pool were built at the same sample, so their Twin-T oscillators are bit-identical and ONE is computed "
                                      "per pool (its flops are not in the roofline numerator)") if groups == 1 else
-                                    f"pool staggered into {groups} tremolo phase groups (one oscillator each)",
+                                    (f"one Twin-T oscillator per instance ({groups} decorrelated phases; its flops are in whole_chain_frac)" if groups == n_inst else
+                                     f"pool staggered into {groups} tremolo phase groups (one oscillator each)"),
+                    "restrikes_in_timed_region": int((script.pos // EPOCH) - ((script.pos - args.steps * BUF) // EPOCH)),
                 },
                 "x_realtime_aggregate": value / SR,
                 "host_midi_s": script.t_midi, "render_calls_s": script.t_render, "elapsed_s": elapsed,
@@ -539,6 +662,13 @@ def main(argv=None):
                     "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
                     "kernel_ms_per_step": {n: float(k) for n, k in zip(names, kms)},
                     "flops_per_output_sample": {"voices": FLOPS_VOICES, "tremolo": trem_per_engine, "preamp": flops_preamp, "post": flops_post},
+                    "flops_per_voice_sample": FLOPS_VOICE_SAMPLE, "flops_executed_per_voice_sample": FLOPS_VOICE_SAMPLE_EXECUTED,
+                    "frac_executed": (64 * FLOPS_VOICE_SAMPLE_EXECUTED * BUF * n_inst / (float(kms[1]) * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS
+                                      if kms[1] > 0 else None),
+                    # with one oscillator per instance the tremolo kernel runs on its own stream INSIDE the voice kernel's interval and
+                    # competes for the same issue slots: the interval's flops are voices + tremolo
+                    "voices_plus_tremolo_frac": ((FLOPS_VOICES + trem_per_engine) * BUF * n_inst / (float(kms[1]) * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS
+                                                 if kms[1] > 0 else None),
                     "whole_chain_frac": per_sample * value / world / 1e12 / PEAK_FP64_VALU_TFLOPS,
                     # the contract's own vocabulary, for reference: PMC HBM bytes of the dominant kernel / its duration against 8 TB/s
                     "hbm": ({"achieved": traffic / (dom_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",

@@ -40,4 +40,32 @@ def test_single_rank_needs_no_launcher_and_no_process_group():
 
 def test_a_failing_rank_fails_the_launcher():
     r = _bench("--gpus", "2", "--workload", "engines", "--steps", "1", "--warmup", "0")      # the dry run refuses the engine workload
-    assert r.returncode != 0 and "ranks failed" in r.stderr
+    assert r.returncode != 0 and "failed first" in r.stderr
+
+
+def test_a_rank_that_dies_before_the_rendezvous_takes_the_others_down_quickly():
+    """rank 1 exits before init_process_group; rank 0 would sit in the rendezvous until the store timeout.  The launcher polls
+    every child, terminates the survivors and returns non-zero within seconds."""
+    import time
+    t0 = time.time()
+    r = _bench("--gpus", "2", "--workload", "batch", "--steps", "1", "--warmup", "0",
+               env_extra={"OW_BENCH_TEST_FAIL_RANK": "1", "OW_BENCH_RENDEZVOUS_TIMEOUT_S": "600"}, timeout=120)
+    assert r.returncode != 0 and "rank 1 failed first" in r.stderr, r.stderr[-1000:]
+    assert time.time() - t0 < 60.0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_gpu_count_comes_from_sysfs_not_from_torch():
+    """The parent of the ranks must not initialise HIP (a GPU-initialised process that forks rank children takes the box down on this
+    pool): bench.visible_gpus reads the KFD topology, and spawn_ranks imports neither torch nor the library."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    for fn in tree.body:
+        if isinstance(fn, ast.FunctionDef) and fn.name in ("spawn_ranks", "visible_gpus"):
+            names = {n.id for n in ast.walk(fn) if isinstance(n, ast.Name)} | {a.name for n in ast.walk(fn) if isinstance(n, ast.Import) for a in n.names}
+            assert "torch" not in names and "openwurli_amd" not in names, fn.name
+    sys.path.insert(0, ROOT)
+    import bench
+    n = bench.visible_gpus()
+    assert n is None or n >= 0
