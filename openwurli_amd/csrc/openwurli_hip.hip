@@ -23,6 +23,7 @@
 #include "ow_mlp_mfma.h"
 #include "ow_melange_dev.h"
 #include "ow_melange_lit.h"
+#include "ow_melange_col.h"
 #include "ow_power_amp_dev.h"
 #include "ow_features.h"
 #include "ow_trem_wide.h"
@@ -240,6 +241,7 @@ struct ow_pool {
     double* d_pa_tap = nullptr;       // test tap: amp output per chain-rate sample, [2 * Lcap][I] (ow_test_pool_enable_power_amp_tap)
     size_t pa_tap_cap = 0;
     double* d_mel_settled = nullptr;  // melange preamp: settled codegen-rate state (18 doubles)
+    size_t mel_lu_ld = 0;             // column-streamed literal kernel: lanes per row of d_mel_lu
     double* d_mel_lu = nullptr;       // literal kernel: LU workspace of the generic rebuild, [ceil(I/32) + OW_MAX_SLICES + 1][12][12][32]
     double* d_noise = nullptr;        // melange preamp: thermal-noise state of the main solver states, [NZ_COUNT][I]
     double* d_sum = nullptr;
@@ -634,6 +636,11 @@ static inline bool melange_rank_one() {
     return env && env[0] == '1';
 }
 
+static inline bool melange_lds_matrix() {        // OW_MEL_LDS=1: the round-2 literal kernel (S of every engine in LDS, lane pair shares one rebuild)
+    const char* env = std::getenv("OW_MEL_LDS");
+    return env && env[0] == '1';
+}
+
 static inline bool melange_generic_only() {      // OW_MEL_GENERIC=1: the literal kernel without its precomputed fast path
     const char* env = std::getenv("OW_MEL_GENERIC");
     return env && env[0] == '1';
@@ -874,7 +881,11 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         if (chain) HIP_OK(hipStreamWaitEvent(s, p->ev_trem[rb_now_idx], 0));
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][2], s));
         if (sne > 0 && chain) {
-            if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one())
+            if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one() && p->hc.ml_sparse_ok && !melange_lds_matrix())
+                owdev::k_preamp_mel_col<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
+                                                                                 p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne, melange_generic_only() ? 1 : 0,
+                                                                                 p->d_mel_lu, p->mel_lu_ld);
+            else if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one())
                 owdev::k_preamp_mel_lit<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
                                                                                  p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne, melange_generic_only() ? 1 : 0, p->d_mel_lu);
             else if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)
@@ -1184,7 +1195,11 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     owdev::k_note_table<<<dim3(1), dim3(64), 0, p->stream>>>(p->d_nt);
     if (preamp_kind == OW_PREAMP_MELANGE12) {
         HIP_OK(hipMalloc(&p->d_mel_settled, sizeof(double) * 18));
-        HIP_OK(hipMalloc(&p->d_mel_lu, sizeof(double) * 12 * 12 * 32 * ((size_t)(n_engines + 31) / 32 + OW_MAX_SLICES + 1)));
+        // LU workspace of the generic rebuild (the fallback of both literal kernels): the column-streamed kernel wants one [144] column
+        // per lane = (engine, state), lane-minor, + 32 spare engines for the masked lanes of a last partial wavefront; the LDS-matrix
+        // kernel one [144][32] slab per workgroup
+        p->mel_lu_ld = 2 * (n_engines + 32);
+        HIP_OK(hipMalloc(&p->d_mel_lu, sizeof(double) * 144 * std::max<size_t>(p->mel_lu_ld, 32 * ((size_t)(n_engines + 31) / 32 + OW_MAX_SLICES + 1))));
         mel_settled_to_device(device, p->d_mel_settled, p->stream);
         // Noise streams: the reference clones one process-wide state whose RNGs were seeded from the clock (master seed 0,
         // gen_preamp.rs:1512-1521 via melange_adapter.rs:12-29), so every engine of a process starts on the same streams.

@@ -308,6 +308,34 @@ static void build_melange_consts(OwConsts& c) {
             }
         }
     }
+    {   // pattern the column-streamed kernel compiles in (ow_melange_col.h): U rows 0..5, trailing factors, position of the R row
+        static const unsigned U_TOP[6] = {0x003u, 0x006u, 0x03Cu, 0x008u, 0x1B0u, 0x1E0u};            // bit j: U[i][j] may be non-zero
+        static const unsigned T_PAT[6] = {0x17u, 0x17u, 0x1Fu, 0x1Cu, 0x1Fu, 0x3Fu};                 // bit b: trailing factor [a][b] may be non-zero
+        bool ok = c.ml_ok != 0 && c.ml_t6 == 0;
+        for (int i = 0; i < 6 && ok; ++i)
+            for (int j = i; j < 12; ++j)
+                if (!((U_TOP[i] >> j) & 1u) && c.ml_utop[i][j] != 0.0) ok = false;
+        for (int i = 0; i < 6; ++i) c.ml_utop_rcp[i] = 1.0 / c.ml_utop[i][i];
+        const double rs[3] = {1000.0, 9.99999999999999854e4, 1000000.0};
+        for (int q = 0; q < 3 && ok; ++q) {          // the trailing elimination at three resistances: nothing outside the pattern
+            const double alpha = 2.0 * (rate * 1.0);
+            double T[6][6];
+            for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) T[a][b] = c.ml_t0[a][b];
+            double e = (PRE_G[6][6] + (1.0 / rs[q] - PRE_POT_0_G_NOM)) + alpha * PRE_C[6][6];
+            for (int k = 0; k < 6; ++k) e -= c.ml_chain_m[k] * c.ml_chain_u[k];
+            T[0][0] = e;
+            for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) if (!((T_PAT[a] >> b) & 1u) && T[a][b] != 0.0) ok = false;
+            for (int k = 0; k < 6 && ok; ++k) {
+                for (int i = k + 1; i < 6; ++i) {
+                    const double m = T[i][k] / T[k][k];
+                    T[i][k] = m;
+                    for (int j = k + 1; j < 6; ++j) T[i][j] -= m * T[k][j];
+                }
+                for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) if (!((T_PAT[a] >> b) & 1u) && T[a][b] != 0.0) ok = false;
+            }
+        }
+        c.ml_sparse_ok = ok ? 1 : 0;
+    }
     for (int i = 0; i < 12; ++i) { c.m_u[i] = c.m_s0[i][6]; c.m_w[i] = c.m_s0[6][i]; }
     c.m_s66 = c.m_s0[6][6];
     c.m_g_nom = PRE_POT_0_G_NOM;

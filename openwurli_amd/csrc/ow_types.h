@@ -148,6 +148,10 @@ struct OwConsts {
     double ml_utop[6][12];       // rows 0..5 of U (row i: columns i..11)
     double ml_btop[12][6];       // per unit column: forward-substituted b at positions 0..5
     double ml_part[12][6];       // per unit column: b at trailing position 6+t after the terms j < 6 of its forward substitution
+    // column-streamed kernel (ow_melange_col.h): correctly rounded reciprocals of U's R-independent pivots, and whether the factors have
+    // the sparsity pattern that kernel compiles in (checked on the host at three resistances; 0 -> the LDS-matrix kernel is used)
+    double ml_utop_rcp[6];
+    int ml_sparse_ok, ml_pad;
 };
 
 #define PA_N 20   /* gen_power_amp.rs:29 */

@@ -40,6 +40,29 @@ OW_DEV double ow_div(double a, double b) {
     return __builtin_amdgcn_div_fixup(__builtin_fma(r, y, q), b, a);
 #endif
 }
+// The two halves of ow_div, for several quotients over ONE divisor (pivot rows of the solvers): the refined reciprocal depends on the
+// divisor alone, so y = ow_rcp_refined(b) once and ow_div_y(a, b, y) per numerator is ow_div(a, b) instruction for instruction.
+OW_DEV double ow_rcp_refined(double b) {
+#ifdef OW_IEEE_DIV
+    return b;
+#else
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    return y;
+#endif
+}
+OW_DEV double ow_div_y(double a, double b, double y) {
+#ifdef OW_IEEE_DIV
+    return a / b;
+#else
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_amdgcn_div_fixup(__builtin_fma(r, y, q), b, a);
+#endif
+}
 // Division by a compile-time constant: y = 1.0 / B is folded by the compiler (correctly rounded), which leaves q = a*y, the exact
 // residual and the final correction of the sequence above -- the quotient is again the correctly rounded a / B (Markstein's
 // correction step with a correctly rounded reciprocal); v_div_fixup keeps zero / infinite / NaN numerators IEEE.  Checked on the
