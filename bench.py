@@ -60,9 +60,11 @@ FLOPS_PREAMP = 2 * 1400 + 24       # main+shadow dk_step per OS sample + half-ba
 # melange 12-node preamp as the kernel EXECUTES it (rank-one update of the inverse, no per-sample LU): per state and chain-rate
 # sample build_rhs ~120 + S.rhs 288 + Sherman-Morrison correction ~50 + 3 Newton sweeps x ~150 + S_NI.i 72 + damp net ~50 = ~1050
 FLOPS_PREAMP_MELANGE = 2 * 2 * 1050 + 24          # rank-one kernel (OW_MEL_RANK1=1): the Newton solve only, matrices updated by Sherman-Morrison
-# literal kernel (default): + the per-sample rebuild as the DEVICE does it (R-dependent trailing 6x6 block: Schur update, LU, the
-# columns of S the solve needs, K = N_v S N_i: ~1 200 flops; the reference's full 12x12 inverse would be ~6 100) -- conservative
-FLOPS_PREAMP_MELANGE_LIT = 2 * 2 * (1050 + 1200) + 24
+# literal kernel (default, k_preamp_mel_col): + the per-sample rebuild as the DEVICE does it, per solver state (the two states of an
+# engine no longer share it): trailing 6x6 factorisation 13 quotients + 26 multiply-subtracts, twelve sparse unit-column solves 309
+# multiply-subtracts + 123 quotients, folding the columns into v_pred / S N_i 123 + 84 multiply-adds: ~1 150 flops (quotient = 1; the
+# reference's dense 12x12 inverse would be ~6 100)
+FLOPS_PREAMP_MELANGE_LIT = 2 * 2 * (1050 + 1150) + 24
 # melange power amp, per chain-rate sample with ONE Newton iteration (the count is data dependent: 1 on silence, 2..3 mean on a chord,
 # up to 70): device models 8 x ~300, Jacobian 1 024, 16x16 LU 2 730, substitution 256, K products 2 x 512, S rhs 800, S_NI i 640
 FLOPS_PA_MELANGE_PER_CHAIN_SAMPLE = 8 * 300 + 1024 + 2730 + 256 + 1024 + 800 + 640
@@ -518,7 +520,7 @@ def main(argv=None):
             n_mel = min(n_inst, 65536)
             pm = make_pool(n_mel, preamp=1, n_groups=min(groups, n_mel))
             r = side_run(pm, n_mel, 2, 6)
-            r["workload"] = "cfg2 with the melange 12-node preamp (k_preamp_mel_lit: the reference's rebuild_matrices + invert_n per chain-rate sample)"
+            r["workload"] = "cfg2 with the melange 12-node preamp (k_preamp_mel_col: the reference's rebuild_matrices + invert_n per chain-rate sample, column-streamed)"
             r["preamp_frac_of_fp64_peak"] = FLOPS_PREAMP_MELANGE_LIT * BUF * n_mel / (r["kernel_ms_per_step"]["preamp"] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS
             extras["preamp_melange"] = r
             pm.close()

@@ -99,6 +99,10 @@ int ow_test_engine_poke_voice(ow_engine*, int slot, int steal, int field, double
 /* Plain device-to-host copy, for reading a block that ow_pool_render(pool, NULL, ...) left in HBM (ow_pool_device_output). */
 int ow_test_device_read(void* dst_host, const void* src_device, size_t bytes, int device);
 
+/* Fast paths of the melange preamp's literal rebuild the host found usable at chain rate `rate` (host only): bit 0 = leading block
+ * replayed once per rate, bit 1 = the LU factors have the compiled-in sparsity pattern of the column-streamed kernel.  <0 on error. */
+int ow_test_host_melange_paths(double rate);
+
 /* ---- fault injection ------------------------------------------------------------------------ */
 /* The next n_renders calls of ow_pool_render / ow_engine_render on this pool fail before their first launch, exactly as a HIP
  * error would (exception inside the guarded region): the caller's block must come back as silence in every row, ow_last_error

@@ -156,6 +156,7 @@ TEST_SYMBOLS = {
     "ow_test_pool_stagger_tremolo": (C.c_int, [_VP, C.c_size_t]),
     "ow_test_pool_tremolo_groups": (C.c_size_t, [_VP]),
     "ow_test_clear_settle_caches": (C.c_int, []),
+    "ow_test_host_melange_paths": (C.c_int, [C.c_double]),
     "ow_test_device_read": (C.c_int, [_VP, _VP, C.c_size_t, C.c_int]),
     "ow_test_engine_poke_voice": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_double]),
     "ow_test_host_matrices": (C.c_int, [C.c_int, C.c_double, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

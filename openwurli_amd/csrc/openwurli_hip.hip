@@ -1874,6 +1874,16 @@ int ow_test_device_read(void* dst_host, const void* src_device, size_t bytes, in
     if (hipSetDevice(device) != hipSuccess) return -1;
     return hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
+// Which literal-rebuild fast paths the host found usable for the melange preamp at chain rate `rate` (no device): bit 0 = the
+// R-independent leading block could be replayed (ml_ok), bit 1 = the factors have the sparsity pattern ow_melange_col.h compiles in.
+int ow_test_host_melange_paths(double rate) {
+    try {
+        std::unique_ptr<OwConsts> c(new OwConsts());
+        owhip::build_consts(*c, rate < 88200.0 ? rate * 0.5 : rate, OW_PREAMP_MELANGE12);
+        if (c->os_sr != rate) throw std::runtime_error("rate is not reachable as a chain rate");
+        return (c->ml_ok ? 1 : 0) | (c->ml_sparse_ok ? 2 : 0);
+    } catch (const std::exception& ex) { set_err(std::string("ow_test_host_melange_paths: ") + ex.what()); return -1; }
+}
 void ow_test_inject_render_faults(ow_pool* p, int n_renders) { if (p) p->inject_faults = n_renders > 0 ? n_renders : 0; }
 
 // ---- diagnostics ---------------------------------------------------------------------------------

@@ -73,6 +73,7 @@ OW_DEV Bjt bjt_eval(double vbe, double vbc) {  // gen_tremolo.rs:1546-1633 (Eber
 // row exchanges done with selects) -- gen_tremolo.rs:2515-2561.
 OW_DEV bool solve4(double a[4][4], double b[4]) {
     bool singular = false;
+    double yp[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int col = 0; col < 4; ++col) {
         int max_row = col;
@@ -102,9 +103,11 @@ OW_DEV bool solve4(double a[4][4], double b[4]) {
             }
             }
             const double pivot = a[col][col];
+            yp[col] = ow_rcp_refined(pivot);   // the quotients over this pivot (up to three factors + the back substitution) share its reciprocal:
+                                               // ow_div_y(x, pivot, y) is ow_div(x, pivot) instruction for instruction
 #pragma unroll
             for (int row = col + 1; row < 4; ++row) {
-                const double factor = ow_div(a[row][col], pivot);
+                const double factor = ow_div_y(a[row][col], pivot, yp[col]);
 #pragma unroll
                 for (int j = col + 1; j < 4; ++j) a[row][j] -= factor * a[col][j];
                 b[row] -= factor * b[col];
@@ -118,7 +121,7 @@ OW_DEV bool solve4(double a[4][4], double b[4]) {
 #pragma unroll
             for (int j = i + 1; j < 4; ++j) sum -= a[i][j] * b[j];
             if (!singular && fabs(a[i][i]) < 1e-15) singular = true;
-            if (!singular) b[i] = ow_div(sum, a[i][i]);
+            if (!singular) b[i] = ow_div_y(sum, a[i][i], yp[i]);
         }
     }
     return !singular;
@@ -181,6 +184,7 @@ __device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk
         if (ok) {
             if (!BE) {  // gen_tremolo.rs:2562-2713
                 double i_trial[4], dv_trial[4], v_lim[4];
+                bool lim_any = false;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) i_trial[q] = i_nl[q] - b[q];
                 int z2 = 0;
@@ -191,9 +195,13 @@ __device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk
                     const double v_trial = p[q] + kk[q][0] * i_trial[0] + kk[q][1] * i_trial[1] + kk[q][2] * i_trial[2] + kk[q][3] * i_trial[3];
                     dv_trial[q] = v_trial - vd[q];
                     v_lim[q] = (fabs(dv_trial[q]) > 1e-4) ? pnjlim(v_trial, vd[q], OW_T_VT, OW_T_VCRIT) : v_trial;
+                    lim_any = lim_any || !(v_lim[q] == v_trial);      // (a NaN trial counts as limited: the full path handles it)
                 }
                 bool any_limited = false;
                 double ga = 1.0;
+                // A junction the limiter left alone has v_lim == v_trial, so dv_lim is dv_trial bit for bit and the ratio below is x / x == 1:
+                // never below ga.  The four divisions only run when some lane of the wavefront was limited (start-up transients).
+                if (__builtin_amdgcn_ballot_w64(lim_any) != 0ull) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const double dv_lim = v_lim[q] - vd[q];
@@ -201,6 +209,7 @@ __device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk
                         const double r = (dv_trial[q] * dv_lim < 0.0) ? 0.0 : clampd(ow_div(dv_lim, dv_trial[q]), 0.0, 1.0);
                         if (r < ga) { ga = r; any_limited = true; }
                     }
+                }
                 }
                 const double max_dv = fmax(fmax(fmax(fabs(dv_trial[0] * ga), fabs(dv_trial[1] * ga)), fabs(dv_trial[2] * ga)), fabs(dv_trial[3] * ga));
                 if (max_dv > 3.5) { ga *= fmax(ow_div(3.5, max_dv), 0.1); any_limited = true; }

@@ -316,6 +316,14 @@ static void build_melange_consts(OwConsts& c) {
             for (int j = i; j < 12; ++j)
                 if (!((U_TOP[i] >> j) & 1u) && c.ml_utop[i][j] != 0.0) ok = false;
         for (int i = 0; i < 6; ++i) c.ml_utop_rcp[i] = 1.0 / c.ml_utop[i][i];
+        // zeros of the forward-substituted unit columns (MCOL_PART / MCOL_BTOP of ow_melange_col.h)
+        static const unsigned PART[12] = {0x3F, 0x3F, 0x3F, 0x20, 0x3F, 0x3F, 0x3F, 0x3E, 0x3C, 0x38, 0x30, 0x3F};
+        static const unsigned BTOP[12] = {0x37, 0x36, 0x34, 0x00, 0x30, 0x20, 0x00, 0x00, 0x00, 0x00, 0x00, 0x38};
+        for (int col = 0; col < 12 && ok; ++col)
+            for (int t = 0; t < 6; ++t) {
+                if (!((PART[col] >> t) & 1u) && c.ml_part[col][t] != 0.0) ok = false;
+                if (!((BTOP[col] >> t) & 1u) && c.ml_btop[col][t] != 0.0) ok = false;
+            }
         const double rs[3] = {1000.0, 9.99999999999999854e4, 1000000.0};
         for (int q = 0; q < 3 && ok; ++q) {          // the trailing elimination at three resistances: nothing outside the pattern
             const double alpha = 2.0 * (rate * 1.0);

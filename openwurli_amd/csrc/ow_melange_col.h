@@ -109,46 +109,105 @@ __device__ inline bool mel_col_factor(const OwConsts* __restrict__ K0, double po
     return ok;
 }
 
+// Structure of the unit columns.  Row exchanges put unknown 3's equation (the supply source row) at position 11 and equation 11 at
+// position 3; everything else stays.  So the permuted unit vector of column c sits at position c (c = 3 -> 11, c = 11 -> 3), the
+// forward substitution leaves zeros in front of it, and the host's tables are zero there:
+//   MCOL_PART[c] bit t: ml_part[c][t] may be non-zero;  MCOL_BTOP[c] bit i: ml_btop[c][i] may be non-zero  (verified by the host).
+// Column 3 is e_11 / U[11][11] (nothing else reaches column 11 of U), and unknown 3 is zero in every column but 11.  The solve below
+// carries "known zero" flags through the substitutions at compile time and leaves out operations whose operand is a known zero --
+// the reference subtracts 0 * x there.
+__device__ constexpr unsigned MCOL_PART[12] = {0x3F, 0x3F, 0x3F, 0x20, 0x3F, 0x3F, 0x3F, 0x3E, 0x3C, 0x38, 0x30, 0x3F};
+__device__ constexpr unsigned MCOL_BTOP[12] = {0x37, 0x36, 0x34, 0x00, 0x30, 0x20, 0x00, 0x00, 0x00, 0x00, 0x00, 0x38};
+
+// a / pivot with the pivot's refined reciprocal, without v_div_fixup: numerators here are finite sums of finite products and the pivots
+// were checked against 1e-30, so none of the special cases that instruction repairs (zero / infinite / NaN operands, exponents at the
+// ends of the range) can occur; for everything else it returns its first operand unchanged.
+OW_DEV double mcol_div(double a, double b, double y) {
+#ifdef OW_IEEE_DIV
+    return a / b;
+#else
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+#endif
+}
+
+template <int COL>
+struct MelColNz {      // which entries of the unit column are (structurally) non-zero at each stage
+    static constexpr unsigned P = MCOL_PART[COL], B = MCOL_BTOP[COL];
+    static constexpr bool f6 = P & 1, f7 = ((P >> 1) & 1) || f6, f8 = ((P >> 2) & 1) || f6 || f7, f9 = ((P >> 3) & 1) || f8,
+                          f10 = ((P >> 4) & 1) || f6 || f7 || f8 || f9, f11 = ((P >> 5) & 1) || f6 || f7 || f8 || f9 || f10;
+    static constexpr bool g11 = f11, g10 = f10, g9 = f9 || g10, g8 = f8 || g9 || g10, g7 = f7 || g8 || g10, g6 = f6 || g7 || g8 || g10;
+    static constexpr bool g5 = ((B >> 5) & 1) || g6 || g7 || g8, g4 = ((B >> 4) & 1) || g5 || g7 || g8, g3 = (B >> 3) & 1,
+                          g2 = ((B >> 2) & 1) || g3 || g4 || g5, g1 = ((B >> 1) & 1) || g2, g0 = (B & 1) || g1;
+    static constexpr bool nz(int i) {
+        return i == 0 ? g0 : i == 1 ? g1 : i == 2 ? g2 : i == 3 ? g3 : i == 4 ? g4 : i == 5 ? g5 : i == 6 ? g6 : i == 7 ? g7 : i == 8 ? g8 : i == 9 ? g9
+               : i == 10 ? g10 : g11;
+    }
+};
+
 // Unit column COL of S = A^-1: forward substitution through the trailing rows (the part through rows 0..5 is the host's ml_part /
 // ml_btop), back substitution through the trailing block and through U's rows 5..0 (gen_preamp.rs:2184-2215).
+#define MCOL_SUBZ(cond, sum, a, b) if constexpr (cond) MCOL_SUB(sum, a, b)
 template <int COL>
 __device__ inline void mel_col_solve(const OwConsts* __restrict__ K0, const MelColT& T, double b[12]) {
+    using Z = MelColNz<COL>;
     const OwConsts* __restrict__ K = k_reload(K0);
-    double b6 = K->ml_part[COL][0];
-    double b7 = K->ml_part[COL][1];   MCOL_SUB(b7, T.t10, b6);
-    double b8 = K->ml_part[COL][2];   MCOL_SUB(b8, T.t20, b6);  MCOL_SUB(b8, T.t21, b7);
-    double b9 = K->ml_part[COL][3];   MCOL_SUB(b9, T.t32, b8);
-    double b10 = K->ml_part[COL][4];  MCOL_SUB(b10, T.t40, b6); MCOL_SUB(b10, T.t41, b7); MCOL_SUB(b10, T.t42, b8); MCOL_SUB(b10, T.t43, b9);
-    double b11 = K->ml_part[COL][5];  MCOL_SUB(b11, T.t50, b6); MCOL_SUB(b11, T.t51, b7); MCOL_SUB(b11, T.t52, b8); MCOL_SUB(b11, T.t53, b9); MCOL_SUB(b11, T.t54, b10);
-    b11 = ow_div_y(b11, T.t55, T.y5);
-    b10 = ow_div_y(b10, T.t44, T.y4);
-    MCOL_SUB(b9, T.t34, b10);                                                         b9 = ow_div_y(b9, T.t33, T.y3);
-    MCOL_SUB(b8, T.t23, b9);  MCOL_SUB(b8, T.t24, b10);                               b8 = ow_div_y(b8, T.t22, T.y2);
-    MCOL_SUB(b7, T.t12, b8);  MCOL_SUB(b7, T.t14, b10);                               b7 = ow_div_y(b7, T.t11, T.y1);
-    MCOL_SUB(b6, T.t01, b7);  MCOL_SUB(b6, T.t02, b8);  MCOL_SUB(b6, T.t04, b10);     b6 = ow_div_y(b6, T.t00, T.y0);
+    double b6 = 0.0, b7 = 0.0, b8 = 0.0, b9 = 0.0, b10 = 0.0, b11 = 0.0;
+    if constexpr (Z::P & 1) b6 = K->ml_part[COL][0];
+    if constexpr ((Z::P >> 1) & 1) b7 = K->ml_part[COL][1];
+    MCOL_SUBZ(Z::f6, b7, T.t10, b6);
+    if constexpr ((Z::P >> 2) & 1) b8 = K->ml_part[COL][2];
+    MCOL_SUBZ(Z::f6, b8, T.t20, b6);  MCOL_SUBZ(Z::f7, b8, T.t21, b7);
+    if constexpr ((Z::P >> 3) & 1) b9 = K->ml_part[COL][3];
+    MCOL_SUBZ(Z::f8, b9, T.t32, b8);
+    if constexpr ((Z::P >> 4) & 1) b10 = K->ml_part[COL][4];
+    MCOL_SUBZ(Z::f6, b10, T.t40, b6); MCOL_SUBZ(Z::f7, b10, T.t41, b7); MCOL_SUBZ(Z::f8, b10, T.t42, b8); MCOL_SUBZ(Z::f9, b10, T.t43, b9);
+    if constexpr ((Z::P >> 5) & 1) b11 = K->ml_part[COL][5];
+    MCOL_SUBZ(Z::f6, b11, T.t50, b6); MCOL_SUBZ(Z::f7, b11, T.t51, b7); MCOL_SUBZ(Z::f8, b11, T.t52, b8); MCOL_SUBZ(Z::f9, b11, T.t53, b9);
+    MCOL_SUBZ(Z::f10, b11, T.t54, b10);
+    if constexpr (Z::g11) b11 = mcol_div(b11, T.t55, T.y5);
+    if constexpr (Z::g10) b10 = mcol_div(b10, T.t44, T.y4);
+    MCOL_SUBZ(Z::g10, b9, T.t34, b10);
+    if constexpr (Z::g9) b9 = mcol_div(b9, T.t33, T.y3);
+    MCOL_SUBZ(Z::g9, b8, T.t23, b9);  MCOL_SUBZ(Z::g10, b8, T.t24, b10);
+    if constexpr (Z::g8) b8 = mcol_div(b8, T.t22, T.y2);
+    MCOL_SUBZ(Z::g8, b7, T.t12, b8);  MCOL_SUBZ(Z::g10, b7, T.t14, b10);
+    if constexpr (Z::g7) b7 = mcol_div(b7, T.t11, T.y1);
+    MCOL_SUBZ(Z::g7, b6, T.t01, b7);  MCOL_SUBZ(Z::g8, b6, T.t02, b8);  MCOL_SUBZ(Z::g10, b6, T.t04, b10);
+    if constexpr (Z::g6) b6 = mcol_div(b6, T.t00, T.y0);
     // rows 5..0 of U (R-independent): row 5 = {6, 7, 8}, row 4 = {5, 7, 8}, row 3 = {}, row 2 = {3, 4, 5}, row 1 = {2}, row 0 = {1}
-    double b5 = K->ml_btop[COL][5];  MCOL_SUB(b5, K->ml_utop[5][6], b6); MCOL_SUB(b5, K->ml_utop[5][7], b7); MCOL_SUB(b5, K->ml_utop[5][8], b8);
-    b5 = ow_div_const(b5, K->ml_utop[5][5], K->ml_utop_rcp[5]);
-    double b4 = K->ml_btop[COL][4];  MCOL_SUB(b4, K->ml_utop[4][5], b5); MCOL_SUB(b4, K->ml_utop[4][7], b7); MCOL_SUB(b4, K->ml_utop[4][8], b8);
-    b4 = ow_div_const(b4, K->ml_utop[4][4], K->ml_utop_rcp[4]);
-    double b3 = ow_div_const(K->ml_btop[COL][3], K->ml_utop[3][3], K->ml_utop_rcp[3]);
-    double b2 = K->ml_btop[COL][2];  MCOL_SUB(b2, K->ml_utop[2][3], b3); MCOL_SUB(b2, K->ml_utop[2][4], b4); MCOL_SUB(b2, K->ml_utop[2][5], b5);
-    b2 = ow_div_const(b2, K->ml_utop[2][2], K->ml_utop_rcp[2]);
-    double b1 = K->ml_btop[COL][1];  MCOL_SUB(b1, K->ml_utop[1][2], b2);
-    b1 = ow_div_const(b1, K->ml_utop[1][1], K->ml_utop_rcp[1]);
-    double b0 = K->ml_btop[COL][0];  MCOL_SUB(b0, K->ml_utop[0][1], b1);
-    b0 = ow_div_const(b0, K->ml_utop[0][0], K->ml_utop_rcp[0]);
+    double b5 = 0.0, b4 = 0.0, b3 = 0.0, b2 = 0.0, b1 = 0.0, b0 = 0.0;
+    if constexpr ((Z::B >> 5) & 1) b5 = K->ml_btop[COL][5];
+    MCOL_SUBZ(Z::g6, b5, K->ml_utop[5][6], b6); MCOL_SUBZ(Z::g7, b5, K->ml_utop[5][7], b7); MCOL_SUBZ(Z::g8, b5, K->ml_utop[5][8], b8);
+    if constexpr (Z::g5) b5 = mcol_div(b5, K->ml_utop[5][5], K->ml_utop_rcp[5]);
+    if constexpr ((Z::B >> 4) & 1) b4 = K->ml_btop[COL][4];
+    MCOL_SUBZ(Z::g5, b4, K->ml_utop[4][5], b5); MCOL_SUBZ(Z::g7, b4, K->ml_utop[4][7], b7); MCOL_SUBZ(Z::g8, b4, K->ml_utop[4][8], b8);
+    if constexpr (Z::g4) b4 = mcol_div(b4, K->ml_utop[4][4], K->ml_utop_rcp[4]);
+    if constexpr (Z::g3) b3 = mcol_div(K->ml_btop[COL][3], K->ml_utop[3][3], K->ml_utop_rcp[3]);
+    if constexpr ((Z::B >> 2) & 1) b2 = K->ml_btop[COL][2];
+    MCOL_SUBZ(Z::g3, b2, K->ml_utop[2][3], b3); MCOL_SUBZ(Z::g4, b2, K->ml_utop[2][4], b4); MCOL_SUBZ(Z::g5, b2, K->ml_utop[2][5], b5);
+    if constexpr (Z::g2) b2 = mcol_div(b2, K->ml_utop[2][2], K->ml_utop_rcp[2]);
+    if constexpr ((Z::B >> 1) & 1) b1 = K->ml_btop[COL][1];
+    MCOL_SUBZ(Z::g2, b1, K->ml_utop[1][2], b2);
+    if constexpr (Z::g1) b1 = mcol_div(b1, K->ml_utop[1][1], K->ml_utop_rcp[1]);
+    if constexpr (Z::B & 1) b0 = K->ml_btop[COL][0];
+    MCOL_SUBZ(Z::g1, b0, K->ml_utop[0][1], b1);
+    if constexpr (Z::g0) b0 = mcol_div(b0, K->ml_utop[0][0], K->ml_utop_rcp[0]);
     b[0] = b0; b[1] = b1; b[2] = b2; b[3] = b3; b[4] = b4; b[5] = b5; b[6] = b6; b[7] = b7; b[8] = b8; b[9] = b9; b[10] = b10; b[11] = b11;
 }
 
 // running S N_i sums of this lane in LDS: sni[k][i][lane]
 #define MCOL_SNI(k, i) sni[((k) * 12 + (i)) * 64]
 
-// Fold column COL of S into v_pred and into the S N_i sums (N_i rows: [0] = {2}, [1] = {2, 4, 5}, [2] = {4, 7, 8}).
+// Fold column COL of S into v_pred and into the S N_i sums (N_i rows: [0] = {2}, [1] = {2, 4, 5}, [2] = {4, 7, 8}).  Entries that are
+// structurally zero add +-0 in the reference and are left out (none of them in the S N_i columns 2, 4, 5, 7, 8 besides unknown 3).
 template <int COL>
 __device__ inline void mel_col_fold(const double b[12], const double rhs[12], double acc[12], double* __restrict__ sni) {
+    using Z = MelColNz<COL>;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] += b[i] * rhs[COL];
+    for (int i = 0; i < 12; ++i)
+        if (Z::nz(i)) acc[i] += b[i] * rhs[COL];
     if (COL == 2) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) { MCOL_SNI(0, i) = b[i] * PRE_N_I[0][2]; MCOL_SNI(1, i) = b[i] * PRE_N_I[1][2]; }

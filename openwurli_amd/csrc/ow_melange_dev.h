@@ -64,6 +64,7 @@ __device__ inline uint32_t mel_solve_nl(const double p[3], const double kk[3][3]
 #pragma unroll
             for (int j = 0; j < 3; ++j) a[i][j] = (i == j ? 1.0 : 0.0) - jdev[i] * kk[i][j];
         bool singular = false;
+        double yp[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int col = 0; col < 3; ++col) {
             int max_row = col;
@@ -89,9 +90,10 @@ __device__ inline uint32_t mel_solve_nl(const double p[3], const double kk[3][3]
                     b[row] = sw ? x : y;
                 }
                 const double pivot = a[col][col];
+                yp[col] = ow_rcp_refined(pivot);       // every quotient over this pivot (elimination factors, back substitution) shares it
 #pragma unroll
                 for (int row = col + 1; row < 3; ++row) {
-                    const double factor = ow_div(a[row][col], pivot);
+                    const double factor = ow_div_y(a[row][col], pivot, yp[col]);
 #pragma unroll
                     for (int j = col + 1; j < 3; ++j) a[row][j] -= factor * a[col][j];
                     b[row] -= factor * b[col];
@@ -105,7 +107,7 @@ __device__ inline uint32_t mel_solve_nl(const double p[3], const double kk[3][3]
 #pragma unroll
                 for (int j = i + 1; j < 3; ++j) sum -= a[i][j] * b[j];
                 if (!singular && fabs(a[i][i]) < 1e-15) singular = true;
-                if (!singular) b[i] = ow_div(sum, a[i][i]);
+                if (!singular) b[i] = ow_div_y(sum, a[i][i], yp[i]);
             }
         }
         if (!singular) {

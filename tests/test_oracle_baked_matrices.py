@@ -152,6 +152,16 @@ def test_product_host_builder_reproduces_the_baked_tables(oracle, solver):
             assert np.max(np.abs(sm @ am - np.eye(n))) < 1e-13 * n * np.abs(sm).max() * np.abs(am).max()
 
 
+def test_melange_fast_paths_are_available_at_every_engine_rate():
+    """The column-streamed literal kernel compiles in the sparsity pattern of the preamp's LU factors (which nodes share a component --
+    rate-independent) and the position of the one row exchange; the host checks both against the factors it computes and falls back
+    to the LDS-matrix kernel otherwise.  At every chain rate an engine can run (host 44.1 ... 192 kHz) both must hold."""
+    from openwurli_amd import binding
+    lib = binding.load_library()
+    for rate in (48000.0, 88200.0, 96000.0, 128000.0, 176398.0, 176400.0, 192000.0, 384000.0):
+        assert lib.ow_test_host_melange_paths(rate) == 3, (rate, binding.last_error(lib))
+
+
 def test_product_tremolo_matrices_equal_the_oracle_at_engine_rates(oracle):
     from openwurli_amd import binding
     lib = binding.load_library()
