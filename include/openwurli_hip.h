@@ -147,23 +147,40 @@ int ow_engine_has_steal_voice_for(const ow_engine*, uint8_t note);              
 /* Voice::render_note (voice.rs:191-221): one voice, no chain, f64.  Returns the number of samples
  * of the note ((dur_s*sr) as usize); writes min(n, cap).  Negative on device error. */
 long long ow_render_note(uint8_t midi, double velocity, double dur_s, double sample_rate, int device, double* out, size_t cap);
+/* Voice::render_note_with_scale(.., Some(displacement_scale)) (voice.rs:201-221): the same with the pickup's displacement scale overridden. */
+long long ow_render_note_with_scale(uint8_t midi, double velocity, double dur_s, double sample_rate, double displacement_scale, int device,
+                                    double* out, size_t cap);
 
-/* `preamp-bench render` job (tools/preamp-bench/src/main.rs:371-549) as driven by ml/render_model_notes.py:49-116. */
+/* `preamp-bench render` job (tools/preamp-bench/src/main.rs:371-549) as driven by ml/render_model_notes.py:49-116.  One field per flag of
+ * the command that changes samples; zero-initialise and set the first seven for what the ML pipeline passes. */
 typedef struct ow_job {
     uint8_t note;        /* --note, 33..96 */
     uint8_t velocity;    /* --velocity, 0..127 (vel_norm = velocity/127) */
     uint8_t mlp;         /* !--no-mlp */
     uint8_t poweramp;    /* !--no-poweramp */
+    uint8_t no_preamp;               /* --no-preamp: the reed / pickup signal goes straight to the output stage (main.rs:425-427) */
+    uint8_t no_attack_noise;         /* --no-attack-noise: Voice::disable_attack_noise (main.rs:409-411, voice.rs:150-152) */
+    uint8_t has_displacement_scale;  /* --displacement-scale given (main.rs:388-392) */
+    uint8_t reserved;
     double volume;       /* --volume (audio taper: x volume^2) */
     double speaker;      /* --speaker character */
-    double r_ldr;        /* --ldr static resistance (tremolo depth 0) */
+    double r_ldr;        /* --ldr static resistance (used while tremolo_depth <= 0) */
+    double tremolo_depth;        /* --tremolo-depth: > 0 puts Tremolo::new(depth, preamp rate) in front of the preamp instead of the static --ldr
+                                  * (main.rs:430-441,447-463) */
+    double displacement_scale;   /* Voice::set_displacement_scale when has_displacement_scale (main.rs:406-408) */
 } ow_job;
 typedef struct ow_batch_cfg {
     double sample_rate;  /* --sample-rate (44100 in the reference, main.rs:27) */
     double duration_s;   /* --duration */
     int device;
     int preamp_kind;
+    int power_amp_kind;  /* which PowerAmp the command was built with (cargo feature legacy-power-amp, main.rs:480): OW_POWER_AMP_BEHAVIORAL, or
+                          * OW_POWER_AMP_MELANGE = PowerAmp::new() = the 7-BJT solver at 44.1 kHz whatever --sample-rate says (power_amp.rs:321-323) */
+    int no_rail_sag;     /* --no-rail-sag (main.rs:381,481-483; melange power amp only) */
 } ow_batch_cfg;
+/* --normalize (main.rs:505-511): the factor write_wav_24bit applies to a finished render, 0.7 / peak when the peak exceeds 0.7, else 1.0;
+ * pass it as `scale` to ow_wav24_write / ow_wav24_quantize.  (The samples ow_batch_render returns are never scaled, like final_output.) */
+double ow_normalize_scale(const double* samples, size_t n);
 /* Renders n_jobs independent jobs lane-parallel (lane = job).  out: f64 [n_jobs][stride], stride >= (duration*sr) as usize.
  * If out_is_device != 0, `out` is a device pointer and nothing is copied to the host.  Returns samples per job, <0 on error. */
 long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg* cfg, double* out, size_t stride, int out_is_device);
@@ -254,7 +271,9 @@ typedef struct ow_midi_render_cfg {
     double tail_s;       /* --tail, default 2.0                            */
     int no_poweramp;     /* --no-poweramp                                  */
     int device;
-    int preamp_kind;     /* OW_PREAMP_LEGACY8 only (`--model dk` of the default build) */
+    int preamp_kind;     /* OW_PREAMP_LEGACY8 (`--model dk` of the default build) or OW_PREAMP_MELANGE12 (melange-preamp build) */
+    int power_amp_kind;  /* the build's PowerAmp::new() (main.rs:1756): OW_POWER_AMP_BEHAVIORAL or OW_POWER_AMP_MELANGE (44.1 kHz, rail sag on) */
+    int no_rail_sag;     /* PowerAmp::set_rail_sag(false) (not a flag of render-midi; for parity with `render`) */
     int reserved;
 } ow_midi_render_cfg;
 typedef struct ow_midi_render_stats { uint64_t n_samples, note_ons, peak_polyphony; } ow_midi_render_stats;

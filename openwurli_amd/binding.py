@@ -26,7 +26,9 @@ class OwPowerAmpDiag(C.Structure):
 
 class OwJob(C.Structure):
     _fields_ = [("note", C.c_uint8), ("velocity", C.c_uint8), ("mlp", C.c_uint8), ("poweramp", C.c_uint8),
-                ("volume", C.c_double), ("speaker", C.c_double), ("r_ldr", C.c_double)]
+                ("no_preamp", C.c_uint8), ("no_attack_noise", C.c_uint8), ("has_displacement_scale", C.c_uint8), ("reserved", C.c_uint8),
+                ("volume", C.c_double), ("speaker", C.c_double), ("r_ldr", C.c_double),
+                ("tremolo_depth", C.c_double), ("displacement_scale", C.c_double)]
 
 
 class OwMidiEvent(C.Structure):
@@ -37,7 +39,8 @@ MIDI_DTYPE = [("engine", "<u4"), ("type", "u1"), ("note", "u1"), ("reserved", "<
 
 
 class OwBatchCfg(C.Structure):
-    _fields_ = [("sample_rate", C.c_double), ("duration_s", C.c_double), ("device", C.c_int), ("preamp_kind", C.c_int)]
+    _fields_ = [("sample_rate", C.c_double), ("duration_s", C.c_double), ("device", C.c_int), ("preamp_kind", C.c_int),
+                ("power_amp_kind", C.c_int), ("no_rail_sag", C.c_int)]
 
 
 class OwAliasAuditResult(C.Structure):
@@ -55,7 +58,7 @@ TIMED_EVENT_DTYPE = [("time_s", "<f8"), ("type", "u1"), ("note", "u1"), ("value"
 
 class OwMidiRenderCfg(C.Structure):
     _fields_ = [("volume", C.c_double), ("speaker", C.c_double), ("tail_s", C.c_double), ("no_poweramp", C.c_int), ("device", C.c_int),
-                ("preamp_kind", C.c_int), ("reserved", C.c_int)]
+                ("preamp_kind", C.c_int), ("power_amp_kind", C.c_int), ("no_rail_sag", C.c_int), ("reserved", C.c_int)]
 
 
 class OwMidiRenderStats(C.Structure):
@@ -121,6 +124,8 @@ SYMBOLS = {
     "ow_engine_slot_note": (C.c_int, [_VP, C.c_int]),
     "ow_engine_has_steal_voice_for": (C.c_int, [_VP, C.c_uint8]),
     "ow_render_note": (C.c_longlong, [C.c_uint8, C.c_double, C.c_double, C.c_double, C.c_int, _VP, C.c_size_t]),
+    "ow_render_note_with_scale": (C.c_longlong, [C.c_uint8, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _VP, C.c_size_t]),
+    "ow_normalize_scale": (C.c_double, [_VP, C.c_size_t]),
     "ow_batch_render": (C.c_longlong, [C.POINTER(OwJob), C.c_size_t, C.POINTER(OwBatchCfg), _VP, C.c_size_t, C.c_int]),
     "ow_device_alloc": (_VP, [C.c_size_t, C.c_int]),
     "ow_device_free": (None, [_VP, C.c_int]),

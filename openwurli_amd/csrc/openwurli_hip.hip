@@ -434,6 +434,79 @@ static void launch_job_chain_legacy(const OwConsts* dK, const owdev::OwJobDev* d
         owdev::k_job_chain<false><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_in, d_out, nullptr, (int)n_jobs, n, stride);
 }
 
+ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int preamp_kind, int power_amp_kind, int tremolo_kind, bool voices_only);
+void pool_destroy(ow_pool* p);
+void pa_settled_to_device(int device, double* d_dst, hipStream_t st);
+
+// The chain of the job paths (`preamp-bench render` / `render-midi`, tools/preamp-bench/src/main.rs:413-497, 1880-1890) for n_jobs rows
+// of voice signal d_in -> d_out (both [n_jobs][stride]), with everything the commands' flags can ask for:
+//   * --tremolo-depth > 0 on some job: ONE Twin-T stream for the call (Tremolo::new settles every job's oscillator to the same state,
+//     and the oscillator takes no input), produced by the product's own tremolo kernel from a freshly built pool of one; each job
+//     applies its own depth divider;
+//   * the melange preamp (`--features melange-preamp` build) through k_job_chain<true>;
+//   * the melange power amp (a build without `legacy-power-amp`): PowerAmp::new() is new_at_sample_rate(44 100) whatever the render's
+//     rate is (power_amp.rs:321-323), it runs at the BASE rate on preamp x volume^2 -- as its own launch (eight lanes per job,
+//     k_mpa_debug) between the chain kernel and the speaker stage.
+struct JobChainCfg { double sample_rate; int device, preamp_kind, power_amp_kind, no_rail_sag; };
+void run_job_chain(const JobChainCfg& cfg, const OwConsts* dK, const std::vector<owdev::OwJobDev>& hj, const owdev::OwJobDev* d_jobs, const double* d_in,
+                   double* d_out, size_t n_jobs, long long n, long long stride, hipStream_t st) {
+    if (cfg.preamp_kind != OW_PREAMP_LEGACY8 && cfg.preamp_kind != OW_PREAMP_MELANGE12) throw std::runtime_error("unknown preamp_kind");
+    if (cfg.power_amp_kind != OW_POWER_AMP_BEHAVIORAL && cfg.power_amp_kind != OW_POWER_AMP_MELANGE) throw std::runtime_error("unknown power_amp_kind");
+    bool any_trem = false, any_special = false, any_pa = false;
+    for (const auto& j : hj) {
+        any_trem = any_trem || (j.tremolo_depth > 0.0 && !j.no_preamp);
+        any_special = any_special || j.no_preamp;
+        any_pa = any_pa || j.poweramp;
+    }
+    const bool mpa = cfg.power_amp_kind == OW_POWER_AMP_MELANGE && any_pa;
+    DevMem d_r, d_settled, d_att, d_amp, d_pac, d_pas;
+    if (any_trem) {
+        const bool os = cfg.sample_rate < 88200.0;
+        const long long n_os = n * (os ? 2 : 1);
+        d_r.alloc(sizeof(double) * (size_t)n_os);
+        struct PoolGuard { ow_pool* p; ~PoolGuard() { pool_destroy(p); } } g{pool_create(cfg.sample_rate, 1, cfg.device, OW_PREAMP_LEGACY8, OW_POWER_AMP_BEHAVIORAL,
+                                                                                             OW_TREMOLO_TWIN_T, false)};
+        // the fresh pool's oscillator rows are Tremolo::new's settled state; n_os steps of Tremolo::process, R written per step
+        owdev::k_tremolo_wide<false><<<dim3(1), dim3(64), 0, g.p->stream>>>(g.p->dK, g.p->d_cs, d_r.as<double>(), 1, n_os, g.p->d_leaders, 1);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(g.p->stream));
+    }
+    const double* trem = any_trem ? d_r.as<double>() : nullptr;
+    double* chain_out = d_out;
+    if (mpa) {
+        d_att.alloc(sizeof(double) * n_jobs * (size_t)stride);
+        d_amp.alloc(sizeof(double) * n_jobs * (size_t)stride);
+        chain_out = d_att.as<double>();
+    }
+    const int out_mode = mpa ? owdev::JOB_OUT_PA_INPUT : owdev::JOB_OUT_FINAL;
+    if (cfg.preamp_kind == OW_PREAMP_MELANGE12) {
+        d_settled.alloc(sizeof(double) * 18);
+        mel_settled_to_device(cfg.device, d_settled.as<double>(), st);
+        owdev::k_job_chain<true><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_in, chain_out, d_settled.as<double>(), (int)n_jobs, n, stride,
+                                                                                            trem, out_mode);
+    } else if (!any_trem && !any_special && !mpa) {
+        launch_job_chain_legacy(dK, d_jobs, d_in, chain_out, n_jobs, n, stride, st);
+    } else {
+        owdev::k_job_chain<false><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_in, chain_out, nullptr, (int)n_jobs, n, stride, trem, out_mode);
+    }
+    HIP_OK(hipGetLastError());
+    if (mpa) {
+        std::unique_ptr<OwPaConsts> hpa(new OwPaConsts());
+        owhip::build_pa_consts(*hpa, 44100.0);
+        d_pac.alloc(sizeof(OwPaConsts));
+        d_pas.alloc(sizeof(double) * owdev::PAS_CIRCUIT_END);
+        pa_settled_to_device(cfg.device, d_pas.as<double>(), st);
+        HIP_OK(hipMemcpyAsync(d_pac.p, hpa.get(), sizeof(OwPaConsts), hipMemcpyHostToDevice, st));
+        owdev::k_mpa_debug<<<dim3((unsigned)((n_jobs + PA_EPB - 1) / PA_EPB)), dim3(PA_WPB * 64), 0, st>>>(d_pac.as<OwPaConsts>(), d_pas.as<double>(), d_att.as<double>(),
+                                                                                                       d_amp.as<double>(), nullptr, n, (int)n_jobs, cfg.no_rail_sag ? 0 : 1,
+                                                                                                       nullptr, nullptr, nullptr, stride);
+        owdev::k_job_speaker<<<dim3((unsigned)((n_jobs + 63) / 64)), dim3(64), 0, st>>>(dK, d_jobs, d_att.as<double>(), d_amp.as<double>(), d_out, (int)n_jobs, n, stride);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(st));      // hpa and the staging buffers go out of scope
+    }
+    HIP_OK(hipStreamSynchronize(st));
+}
+
 // chain (re)initialisation of engines [e0, e0+ne): DC states on the device, then the Twin-T settle
 // (50 warm-up steps at the codegen matrices + 2 s at the pool rate), all in the product kernels.
 // Pools this small leave SIMDs idle, and the oscillator's serial latency is their block time: four lanes per engine (ow_trem_wide.h).
@@ -1965,7 +2038,20 @@ int ow_debug_unary(int which, const double* x, size_t n, double* fast, double* l
 }
 
 // ---- offline ------------------------------------------------------------------------------------
+static long long render_note_impl(uint8_t midi, double velocity, double dur_s, double sample_rate, int device, double* out, size_t cap, const double* ds);
 long long ow_render_note(uint8_t midi, double velocity, double dur_s, double sample_rate, int device, double* out, size_t cap) {
+    return render_note_impl(midi, velocity, dur_s, sample_rate, device, out, cap, nullptr);
+}
+long long ow_render_note_with_scale(uint8_t midi, double velocity, double dur_s, double sample_rate, double displacement_scale, int device,
+                                    double* out, size_t cap) {
+    return render_note_impl(midi, velocity, dur_s, sample_rate, device, out, cap, &displacement_scale);
+}
+double ow_normalize_scale(const double* samples, size_t n) {     // main.rs:505-511
+    double peak = 0.0;
+    for (size_t i = 0; samples && i < n; ++i) peak = std::fmax(peak, std::fabs(samples[i]));
+    return peak > 0.7 ? 0.7 / peak : 1.0;
+}
+static long long render_note_impl(uint8_t midi, double velocity, double dur_s, double sample_rate, int device, double* out, size_t cap, const double* ds) {
     try {
         // a voices-only pool: no chain state, no Twin-T settle, and render_range launches the voice kernels alone
         struct PoolGuard { ow_pool* p; ~PoolGuard() { pool_destroy(p); } } guard{pool_create(sample_rate, 1, device, OW_PREAMP_LEGACY8, OW_POWER_AMP_BEHAVIORAL,
@@ -1977,6 +2063,7 @@ long long ow_render_note(uint8_t midi, double velocity, double dur_s, double sam
         e->slots[0].has_voice = true; e->set_state(0, OW_VOICE_HELD); e->midi_of[0] = note;
         e->sync_masks(0);
         push_op(e, OP_NOTE_ON, 0, note, false, (uint32_t)midi * 2654435761u, velocity);
+        if (ds) push_op(e, OP_SET_DS, 0, note, false, 0, *ds);      // voice.set_displacement_scale(scale) right after note_on (voice.rs:210-212)
         double x = dur_s * sample_rate;
         const size_t n = (!(x == x) || x <= 0.0) ? 0 : (size_t)x;
         const size_t chunk_len = p->Lcap;            // OW_MAX_BLOCK for a pool of one: few launches, few synchronisations
@@ -2018,18 +2105,21 @@ long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg*
         std::vector<owdev::OwJobDev> hj(n_jobs);
         for (size_t i = 0; i < n_jobs; ++i) {
             hj[i].note = jobs[i].note; hj[i].velocity = jobs[i].velocity; hj[i].mlp = jobs[i].mlp; hj[i].poweramp = jobs[i].poweramp;
-            hj[i].pad = 0; hj[i].volume = jobs[i].volume; hj[i].speaker = jobs[i].speaker; hj[i].r_ldr = jobs[i].r_ldr;
+            hj[i].no_preamp = jobs[i].no_preamp ? 1 : 0; hj[i].no_attack_noise = jobs[i].no_attack_noise ? 1 : 0;
+            hj[i].has_ds = jobs[i].has_displacement_scale ? 1 : 0; hj[i].pad8 = 0;
+            hj[i].volume = jobs[i].volume; hj[i].speaker = jobs[i].speaker; hj[i].r_ldr = jobs[i].r_ldr;
+            hj[i].tremolo_depth = jobs[i].tremolo_depth; hj[i].displacement_scale = jobs[i].displacement_scale;
         }
         const size_t vblocks = (n_jobs + 63) / 64;
         StreamOwner so;
         HIP_OK(hipStreamCreateWithFlags(&so.s, hipStreamNonBlocking));
         hipStream_t st = so.s;
-        DevMem m_K, m_nt, m_vrec, m_jobs, m_reed, m_out, m_settled;   // released on every exit path
+        DevMem m_K, m_nt, m_vrec, m_jobs, m_reed, m_out;   // released on every exit path
         m_K.alloc(sizeof(OwConsts));
         m_nt.alloc(sizeof(double) * NT_COUNT * 64);
         m_vrec.alloc(sizeof(double) * vblocks * OW_VREC_DOUBLES);
         m_jobs.alloc(sizeof(owdev::OwJobDev) * n_jobs);
-        m_reed.alloc(sizeof(double) * n_jobs * n);
+        m_reed.alloc(sizeof(double) * n_jobs * stride);      // same row stride as the output: the chain kernels index both with it
         if (!out_is_device) m_out.alloc(sizeof(double) * n_jobs * stride);
         OwConsts* dK = m_K.as<OwConsts>(); double* d_nt = m_nt.as<double>(); double* d_vrec = m_vrec.as<double>();
         owdev::OwJobDev* d_jobs = m_jobs.as<owdev::OwJobDev>(); double* d_reed = m_reed.as<double>();
@@ -2037,16 +2127,10 @@ long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg*
         HIP_OK(hipMemcpyAsync(dK, &hc, sizeof(OwConsts), hipMemcpyHostToDevice, st));
         HIP_OK(hipMemcpyAsync(d_jobs, hj.data(), sizeof(owdev::OwJobDev) * n_jobs, hipMemcpyHostToDevice, st));
         owdev::k_note_table<<<dim3(1), dim3(64), 0, st>>>(d_nt);
-        owdev::k_job_voice<<<dim3((unsigned)vblocks), dim3(64), 0, st>>>(dK, d_nt, d_vrec, d_jobs, d_reed, (int)n_jobs, (long long)n, (long long)n);
-        if (cfg->preamp_kind == OW_PREAMP_MELANGE12) {
-            m_settled.alloc(sizeof(double) * 18);
-            mel_settled_to_device(cfg->device, m_settled.as<double>(), st);
-            owdev::k_job_chain<true><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_reed, d_out, m_settled.as<double>(), (int)n_jobs,
-                                                                                                (long long)n, (long long)stride);
-        } else {
-            launch_job_chain_legacy(dK, d_jobs, d_reed, d_out, n_jobs, (long long)n, (long long)stride, st);
-        }
+        owdev::k_job_voice<<<dim3((unsigned)vblocks), dim3(64), 0, st>>>(dK, d_nt, d_vrec, d_jobs, d_reed, (int)n_jobs, (long long)n, (long long)stride);
         HIP_OK(hipGetLastError());
+        const JobChainCfg cc{cfg->sample_rate, cfg->device, cfg->preamp_kind, cfg->power_amp_kind, cfg->no_rail_sag};
+        run_job_chain(cc, dK, hj, d_jobs, d_reed, d_out, n_jobs, (long long)n, (long long)stride, st);
         if (!out_is_device) HIP_OK(hipMemcpyAsync(out, d_out, sizeof(double) * n_jobs * stride, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         return (long long)n;
@@ -2503,7 +2587,7 @@ long long ow_render_midi(const ow_timed_event* events, const size_t* job_offsets
                          double* out, size_t stride, ow_midi_render_stats* stats) {
     try {
         if (!job_offsets || !cfg || (!out && !stats)) throw std::runtime_error("null argument");
-        if (cfg->preamp_kind != OW_PREAMP_LEGACY8) throw std::runtime_error("render-midi is built for the legacy preamp (--model dk of the default build)");
+        if (cfg->preamp_kind != OW_PREAMP_LEGACY8 && cfg->preamp_kind != OW_PREAMP_MELANGE12) throw std::runtime_error("unknown preamp_kind");
         if (n_jobs == 0) return 0;
         const double SR = 44100.0;                       // BASE_SR, main.rs:27
         const size_t n_ev = job_offsets[n_jobs];
@@ -2545,9 +2629,15 @@ long long ow_render_midi(const ow_timed_event* events, const size_t* job_offsets
         if (ndev <= 0) throw std::runtime_error("no HIP device: openwurli-hip has no CPU fallback");
         HIP_OK(hipSetDevice(cfg->device));
         OwConsts hc;
-        owhip::build_consts(hc, SR, OW_PREAMP_LEGACY8);
+        owhip::build_consts(hc, SR, cfg->preamp_kind);
         std::vector<owdev::OwJobDev> hjob(n_jobs);       // chain parameters: Speaker(speaker), static 1 Mohm LDR, volume, power amp
-        for (auto& q : hjob) { q.note = 60; q.velocity = 0; q.mlp = 1; q.poweramp = cfg->no_poweramp ? 0 : 1; q.pad = 0; q.volume = cfg->volume; q.speaker = cfg->speaker; q.r_ldr = 1000000.0; }
+        for (auto& q : hjob) {
+            std::memset(&q, 0, sizeof q);
+            q.note = 60; q.mlp = 1; q.poweramp = cfg->no_poweramp ? 0 : 1; q.volume = cfg->volume; q.speaker = cfg->speaker;
+            // main.rs:1752-1754 sets 1 Mohm and THEN calls reset(): the legacy solver keeps its resistance, the melange adapter's reset() returns
+            // to the settled clone at the nominal pot (melange_adapter.rs:88-93) and the command never sets it again
+            q.r_ldr = cfg->preamp_kind == OW_PREAMP_MELANGE12 ? 9.99999999999999854e4 : 1000000.0;
+        }
         StreamOwner so;
         HIP_OK(hipStreamCreateWithFlags(&so.s, hipStreamNonBlocking));
         hipStream_t st = so.s;
@@ -2571,9 +2661,9 @@ long long ow_render_midi(const ow_timed_event* events, const size_t* job_offsets
         owdev::k_midi_voices<<<dim3((unsigned)n_jobs), dim3(64), 0, st>>>(dK.as<OwConsts>(), d_nt.as<double>(), d_vrec.as<double>(), d_jobs.as<owdev::OwMidiJobDev>(),
                                                                          d_ev.as<owdev::OwMidiEvDev>(), d_held.as<uint32_t>(), d_sum.as<double>(), (long long)longest,
                                                                          d_stats.as<owdev::OwMidiStatsDev>());
-        launch_job_chain_legacy(dK.as<OwConsts>(), d_chain.as<owdev::OwJobDev>(), d_sum.as<double>(), d_out.as<double>(), n_jobs, (long long)longest,
-                                (long long)longest, st);
         HIP_OK(hipGetLastError());
+        const JobChainCfg cc{SR, cfg->device, cfg->preamp_kind, cfg->power_amp_kind, cfg->no_rail_sag};
+        run_job_chain(cc, dK.as<OwConsts>(), hjob, d_chain.as<owdev::OwJobDev>(), d_sum.as<double>(), d_out.as<double>(), n_jobs, (long long)longest, (long long)longest, st);
         std::vector<owdev::OwMidiStatsDev> hs(n_jobs);
         HIP_OK(hipMemcpy2DAsync(out, stride * sizeof(double), d_out.p, longest * sizeof(double), longest * sizeof(double), n_jobs, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(hs.data(), d_stats.p, sizeof(owdev::OwMidiStatsDev) * n_jobs, hipMemcpyDeviceToHost, st));

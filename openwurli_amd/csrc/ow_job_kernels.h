@@ -15,9 +15,14 @@ namespace owdev {
 
 struct OwJobDev {           // device copy of ow_job
     uint8_t note, velocity, mlp, poweramp;
-    uint32_t pad;
+    uint8_t no_preamp, no_attack_noise, has_ds, pad8;
     double volume, speaker, r_ldr;
+    double tremolo_depth;        // > 0: Tremolo::new(depth, preamp_sr) drives the LDR (main.rs:430-431), the static --ldr is ignored
+    double displacement_scale;   // has_ds: Voice::set_displacement_scale (main.rs:406-408)
 };
+// what the chain kernel writes: the finished sample, or the power amp's input (volume^2 taper applied) when the melange power amp
+// runs as its own launch between the preamp and the speaker (ow_batch_render with OW_POWER_AMP_MELANGE)
+enum { JOB_OUT_FINAL = 0, JOB_OUT_PA_INPUT = 1 };
 
 // Voice::note_on + Voice::render for n samples, lane = job.  reed[job][n] (row stride `stride`).
 __global__ __launch_bounds__(64) void k_job_voice(const OwConsts* __restrict__ K, const double* __restrict__ nt, double* __restrict__ vrec,
@@ -39,6 +44,8 @@ __global__ __launch_bounds__(64) void k_job_voice(const OwConsts* __restrict__ K
         mlp_raw_scalar(clampd(((double)note - 21.0) / (108.0 - 21.0), 0.0, 1.0), clampd(vel, 0.0, 1.0), raw);
         const MlpOut corr = mlp_finish(note, raw, jd.mlp != 0);
         note_on_lane(rec, nt, K, note, vel, (uint32_t)jd.note * 2654435761u, corr);   // main.rs:404-405
+        if (jd.has_ds) rec[VF_DS * 64] = jd.displacement_scale;                        // --displacement-scale (pickup.rs:114-116)
+        if (jd.no_attack_noise) rec[VF_NCNT * 64] = bitsd(dbits(rec[VF_NCNT * 64]) & 0xFFFFFFFF00000000ull);   // --no-attack-noise: remaining = 0 (hammer.rs:187-189)
         v.load(rec);
         lcoef_load(lcoef + lane, rec);
     }
@@ -63,7 +70,8 @@ __global__ __launch_bounds__(64) void k_job_voice(const OwConsts* __restrict__ K
 // matrices go back with the state.
 template <bool MEL>
 __global__ __launch_bounds__(64) void k_job_chain(const OwConsts* __restrict__ K, const OwJobDev* __restrict__ jobs, const double* __restrict__ reed,
-                                                  double* __restrict__ out, const double* __restrict__ settled, int n_jobs, long long n, long long stride) {
+                                                  double* __restrict__ out, const double* __restrict__ settled, int n_jobs, long long n, long long stride,
+                                                  const double* __restrict__ trem_r = nullptr, int out_mode = JOB_OUT_FINAL) {
     __shared__ double tin[32 * (OW_PCHUNK + 1)];
     __shared__ double tout[32 * (OW_PCHUNK + 1)];
     __shared__ double LU_all[MEL ? 12 * 12 * 32 : 1];
@@ -88,18 +96,36 @@ __global__ __launch_bounds__(64) void k_job_chain(const OwConsts* __restrict__ K
     double s_pot = __longlong_as_double(0x7ff8000000000000LL);    // resistance the LDS matrices were built for (NaN: none yet)
     double kk[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     double an66 = 0.0;
+    // --tremolo-depth > 0: the oscillator's CdS stream (one per call: Tremolo::new settles every job's copy to the same state) through
+    // this job's vibrato-pot divider, set before every chain-rate sample (main.rs:447-463); else the static --ldr after reset()
+    const bool use_trem = trem_r != nullptr && jd.tremolo_depth > 0.0;
+    const double tdepth = clampd(jd.tremolo_depth, 0.0, 1.0);
+    long long os_idx = 0;
     if (MEL) {
         mel_init_state(ms, settled);                  // new() and reset() both clone the settled state (melange_adapter.rs:22-29,88-93)
         ms.nan_resets = 0; ms.be_fallbacks = 0;
-        mel_set_r(ms, jd.r_ldr);
+        if (!use_trem) mel_set_r(ms, jd.r_ldr);
     } else {
         dk_dc_reset(K, r_ldr, st);                   // new() and reset() both solve DC at the initial 1 Mohm
-        const double r_new = fmax(jd.r_ldr, 1000.0);
-        if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = 1.0 / r_new; }
+        if (!use_trem) {
+            const double r_new = fmax(jd.r_ldr, 1000.0);
+            if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = 1.0 / r_new; }
+        }
     }
     // one preamp sample for this lane's state (main: audio, shadow: 0.0), returns main - pump with the adapter's NaN reset
     auto preamp_step = [&](double x) -> double {
         double o;
+        if (trem_r != nullptr) {                      // wave-uniform: some job of the call has a tremolo
+            const double r = trem_shunt(tdepth, trem_r[os_idx]);
+            os_idx += 1;
+            if (use_trem) {
+                if (MEL) mel_set_r(ms, r);
+                else {
+                    const double r_new = fmax(r, 1000.0);                                  // set_ldr_resistance, dk_preamp_legacy.rs:620-626
+                    if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = ow_div(1.0, r_new); }
+                }
+            }
+        }
         if (MEL) {
             const double pot_main = __shfl(ms.pot, jl);
             if (__any(!(pot_main == s_pot))) {        // lazy rebuild (gen_preamp.rs:3408-3411); every lane takes part (barriers inside)
@@ -159,10 +185,15 @@ __global__ __launch_bounds__(64) void k_job_chain(const OwConsts* __restrict__ K
             } else {
                 pre = preamp_step(role ? 0.0 : x);
             }
+            if (jd.no_preamp) pre = x;                  // --no-preamp: the reed signal itself (main.rs:425-427)
             // main.rs:487-496: volume^2 (audio taper) -> optional power amp at base rate -> speaker -> PSG
             const double att = pre * vol2_a * vol2_a;
-            const double amp = jd.poweramp ? power_amp(att) : att;
-            const double y = speaker_process(sp, amp, K->spk_thermal_alpha) * 7.498942093324558;
+            double y;
+            if (out_mode == JOB_OUT_PA_INPUT) y = att;
+            else {
+                const double amp = jd.poweramp ? power_amp(att) : att;
+                y = speaker_process(sp, amp, K->spk_thermal_alpha) * 7.498942093324558;
+            }
             if (role == 0) tout[jl * (OW_PCHUNK + 1) + s] = y;
         }
         __syncthreads();
@@ -170,6 +201,23 @@ __global__ __launch_bounds__(64) void k_job_chain(const OwConsts* __restrict__ K
             if (jb + r < n_jobs && lane < cn) out[(size_t)(jb + r) * stride + base + lane] = tout[r * (OW_PCHUNK + 1) + lane];
         __syncthreads();
     }
+}
+
+// Output stage behind a power amp that ran as its own launch: per job, amp[n] (normalised amp output) or att[n] (--no-poweramp) ->
+// Speaker(character) -> x POST_SPEAKER_GAIN (main.rs:487-496).  lane = job; rows are read and written in place.
+__global__ __launch_bounds__(64) void k_job_speaker(const OwConsts* __restrict__ K, const OwJobDev* __restrict__ jobs, const double* __restrict__ att,
+                                                    const double* __restrict__ amp, double* __restrict__ out, int n_jobs, long long n, long long stride) {
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= n_jobs) return;
+    const OwJobDev jd = jobs[j];
+    SpeakerSt sp;
+    sp.character = 1.0; sp.ts = 0.0;
+    sp.hpf.s1 = sp.hpf.s2 = sp.lpf.s1 = sp.lpf.s2 = 0.0;
+    speaker_update(sp, K->sr);
+    speaker_set_character(sp, jd.speaker, K->sr);
+    const double* src = (jd.poweramp ? amp : att) + (size_t)j * stride;      // all three buffers share the row stride
+    double* dst = out + (size_t)j * stride;
+    for (long long i = 0; i < n; ++i) dst[i] = speaker_process(sp, src[i], K->spk_thermal_alpha) * 7.498942093324558;
 }
 
 }  // namespace owdev

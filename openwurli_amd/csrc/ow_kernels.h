@@ -93,6 +93,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         if (op.type == OP_DAMPER) {
             start_damper_lane(main_rec, K);
+        } else if (op.type == OP_SET_DS) {
+            main_rec[VF_DS * 64] = op.velocity;
         } else if (op.type == OP_MOVE_STEAL) {  // slot.steal_voice = slot.voice.take() (engine.rs:316-321)
             for (int f = 0; f < VF_COUNT; ++f) steal_rec[f * 64] = main_rec[f * 64];
             steal_rec[VF_STEAL * 64] = bitsd((uint64_t)op.seed | ((uint64_t)op.seed << 32));

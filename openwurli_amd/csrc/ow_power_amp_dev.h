@@ -645,7 +645,9 @@ __global__ __launch_bounds__(64) void k_mpa_settle(const OwPaConsts* __restrict_
 // [row][n][3]: outer Newton iterations of the sample (70 = exhausted), guard resets so far, positive rail after the sample.
 __global__ __launch_bounds__(PA_WPB * 64, 2) void k_mpa_debug(const OwPaConsts* __restrict__ C, const double* __restrict__ settled, const double* __restrict__ in,
                                                            double* __restrict__ out, double* __restrict__ taps, long long n, int n_rows, int rail_sag,
-                                                           const long long* __restrict__ poke_at, const int* __restrict__ poke_node, const double* __restrict__ poke_val) {
+                                                           const long long* __restrict__ poke_at, const int* __restrict__ poke_node, const double* __restrict__ poke_val,
+                                                           long long ld = 0) {
+    if (ld == 0) ld = n;                     // row stride of in / out (the batch path hands over rows of a wider buffer)
     __shared__ double WS[PA_LDS_DOUBLES];
     __shared__ PaTab TS;
     pa_stage_tables(&TS, C);
@@ -663,9 +665,9 @@ __global__ __launch_bounds__(PA_WPB * 64, 2) void k_mpa_debug(const OwPaConsts* 
     for (long long i = 0; i < n; ++i) {
         if (poke_at && poke_at[row] == i) { PA_SYNC(); PL(PL_V + poke_node[row]) = poke_val[row]; }
         PA_SYNC();
-        const double y = pa_process(sc, C, W, T, role, settled, in[row * n + i], rail_sag != 0);
+        const double y = pa_process(sc, C, W, T, role, settled, in[row * ld + i], rail_sag != 0);
         if (valid && role == 0) {
-            out[row * n + i] = y;
+            out[row * ld + i] = y;
             if (taps) {
                 double* t = taps + (row * n + i) * 3;
                 t[0] = (double)sc.last_nr; t[1] = (double)sc.guard_cnt; t[2] = sc.rail_p;

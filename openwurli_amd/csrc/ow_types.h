@@ -104,7 +104,8 @@ enum {
 };
 
 // ---- slot ops applied before a render (host voice-pool state machine -> device) ----
-enum { OP_NOTE_ON = 1, OP_DAMPER = 2, OP_MOVE_STEAL = 3 };
+enum { OP_NOTE_ON = 1, OP_DAMPER = 2, OP_MOVE_STEAL = 3,
+       OP_SET_DS = 4 /* Voice::set_displacement_scale(velocity field) on the slot voice (voice.rs:145-147; render_note_with_scale) */ };
 struct OwOp {              // 16 bytes
     uint8_t type, slot, note, mlp;
     uint32_t seed;

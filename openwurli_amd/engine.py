@@ -288,19 +288,32 @@ class EnginePool:
         return ptr, stride.value
 
 
-def render_note(midi_note, velocity, duration_secs, sample_rate, device=0):
-    """``Voice::render_note`` (voice.rs:191-199): one voice, reed + pickup only, float64."""
+def render_note(midi_note, velocity, duration_secs, sample_rate, device=0, displacement_scale=None):
+    """``Voice::render_note`` (voice.rs:191-199): one voice, reed + pickup only, float64.  ``displacement_scale`` given =
+    ``Voice::render_note_with_scale(.., Some(scale))`` (voice.rs:201-221)."""
     lib = binding.load_library()
     n = int(duration_secs * sample_rate)
     out = np.zeros(max(n, 1), dtype=np.float64)
-    got = lib.ow_render_note(int(midi_note) & 0xFF, float(velocity), float(duration_secs), float(sample_rate), int(device),
-                             out.ctypes.data_as(C.c_void_p), out.size)
+    if displacement_scale is None:
+        got = lib.ow_render_note(int(midi_note) & 0xFF, float(velocity), float(duration_secs), float(sample_rate), int(device),
+                                 out.ctypes.data_as(C.c_void_p), out.size)
+    else:
+        got = lib.ow_render_note_with_scale(int(midi_note) & 0xFF, float(velocity), float(duration_secs), float(sample_rate),
+                                            float(displacement_scale), int(device), out.ctypes.data_as(C.c_void_p), out.size)
     if got < 0:
         raise OwError(binding.take_error(lib))
     return out[:got]
 
 
-def batch_render(jobs, sample_rate=44100.0, duration_s=2.0, device=0, preamp_kind=0, out_device_ptr=None, stride=None):
+def normalize_scale(samples):
+    """``--normalize`` of ``preamp-bench render`` (main.rs:505-511): the factor its WAV writer applies (0.7 / peak above a 0.7 peak)."""
+    lib = binding.load_library()
+    a = np.ascontiguousarray(samples, dtype=np.float64)
+    return float(lib.ow_normalize_scale(a.ctypes.data_as(C.c_void_p), a.size))
+
+
+def batch_render(jobs, sample_rate=44100.0, duration_s=2.0, device=0, preamp_kind=0, out_device_ptr=None, stride=None, power_amp_kind=0,
+                 no_rail_sag=False):
     """``preamp-bench render`` for a list of jobs (tools/preamp-bench/src/main.rs:371-549), lane = job on the GPU.
 
     ``jobs``: iterable of dicts with keys note, velocity (0..127) and optional mlp, poweramp, volume, speaker, r_ldr
@@ -315,7 +328,14 @@ def batch_render(jobs, sample_rate=44100.0, duration_s=2.0, device=0, preamp_kin
         arr[i].mlp = 1 if j.get("mlp", False) else 0
         arr[i].poweramp = 1 if j.get("poweramp", False) else 0
         arr[i].volume = float(j.get("volume", 1.0)); arr[i].speaker = float(j.get("speaker", 0.0)); arr[i].r_ldr = float(j.get("r_ldr", 1e6))
-    cfg = binding.OwBatchCfg(float(sample_rate), float(duration_s), int(device), int(preamp_kind))
+        # the command's remaining flags: --tremolo-depth, --no-preamp, --no-attack-noise, --displacement-scale
+        arr[i].tremolo_depth = float(j.get("tremolo_depth", 0.0))
+        arr[i].no_preamp = 1 if j.get("no_preamp", False) else 0
+        arr[i].no_attack_noise = 1 if j.get("no_attack_noise", False) else 0
+        ds = j.get("displacement_scale")
+        arr[i].has_displacement_scale = 0 if ds is None else 1
+        arr[i].displacement_scale = 0.0 if ds is None else float(ds)
+    cfg = binding.OwBatchCfg(float(sample_rate), float(duration_s), int(device), int(preamp_kind), int(power_amp_kind), 1 if no_rail_sag else 0)
     n = int(duration_s * sample_rate)
     stride = int(stride or n)
     if out_device_ptr is not None:

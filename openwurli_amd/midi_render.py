@@ -38,14 +38,16 @@ def events(items: Sequence) -> np.ndarray:
     return ev
 
 
-def render_midi(jobs: Sequence[np.ndarray], volume=0.60, speaker=1.0, no_poweramp=False, tail=2.0, device=0, return_stats=False):
+def render_midi(jobs: Sequence[np.ndarray], volume=0.60, speaker=1.0, no_poweramp=False, tail=2.0, device=0, return_stats=False, preamp_kind=0,
+                power_amp_kind=0, no_rail_sag=False):
     """Render every event list of `jobs`; returns a list of f64 arrays (one per job, its own length)."""
     L = load_library()
     jobs = [np.ascontiguousarray(j, dtype=np.dtype(TIMED_EVENT_DTYPE)) for j in jobs]
     offs = np.zeros(len(jobs) + 1, dtype=np.uint64)
     offs[1:] = np.cumsum([j.size for j in jobs])
     allev = np.concatenate(jobs) if jobs else np.zeros(0, dtype=np.dtype(TIMED_EVENT_DTYPE))
-    cfg = OwMidiRenderCfg(float(volume), float(speaker), float(tail), 1 if no_poweramp else 0, int(device), 0, 0)
+    cfg = OwMidiRenderCfg(float(volume), float(speaker), float(tail), 1 if no_poweramp else 0, int(device), int(preamp_kind), int(power_amp_kind),
+                          1 if no_rail_sag else 0, 0)
     stats = (OwMidiRenderStats * max(len(jobs), 1))()
     evp = allev.ctypes.data_as(C.c_void_p) if allev.size else None
     longest = L.ow_render_midi(evp, offs.ctypes.data_as(C.c_void_p), len(jobs), C.byref(cfg), None, 0, C.cast(stats, C.c_void_p))

@@ -351,51 +351,84 @@ struct WurliEngine {
     int steal_voice_count() const { int c = 0; for (auto& s : voices) c += (s.steal_voice != nullptr); return c; }
 };
 
-// tools/preamp-bench/src/main.rs:371-549 with --no-poweramp, --tremolo-depth 0 (static LDR),
-// parametrised by mlp / speaker character / volume / r_ldr.  Output: final_output f64.
-inline std::vector<double> batch_render_job(int note, int velocity_u8, double duration, double sr, double volume,
-                                            double speaker_char, double r_ldr, bool mlp, bool poweramp, int preamp_kind = 0) {
+// tools/preamp-bench/src/main.rs:371-549, every flag of `preamp-bench render` that changes samples.  Output: final_output f64
+// (--normalize only scales what write_wav_24bit quantises, main.rs:512-523: see batch_normalize_scale).
+struct BatchJobOpts {
+    double volume = 0.60, speaker_char = 1.0, r_ldr = 1000000.0, tremolo_depth = 0.0;     // main.rs:375-378 defaults
+    bool mlp = true, poweramp = true, no_preamp = false, no_attack_noise = false, no_rail_sag = false;
+    bool has_displacement_scale = false;
+    double displacement_scale = 0.30;
+    int preamp_kind = 0;        // 0 legacy DkPreamp, 1 melange (cargo feature melange-preamp)
+    int power_amp_kind = 0;     // 0 behavioural (default feature legacy-power-amp), 1 melange 7-BJT: PowerAmp::new() = 44.1 kHz whatever --sample-rate says
+};
+inline std::vector<double> batch_render_job_ex(int note, int velocity_u8, double duration, double sr, const BatchJobOpts& o) {
     const bool do_os = sr < 88200.0;
     const double preamp_sr = do_os ? sr * 2.0 : sr;
     const double vel_norm = (double)velocity_u8 / 127.0;
     const uint32_t seed = (uint32_t)note * 2654435761u;
     Voice voice;
-    voice.note_on(note, vel_norm, sr, seed, mlp);
+    voice.note_on(note, vel_norm, sr, seed, o.mlp);
+    if (o.has_displacement_scale) voice.pickup.displacement_scale = o.displacement_scale;     // main.rs:406-408, voice.rs:145-147
+    if (o.no_attack_noise) voice.noise.remaining = 0;                                         // main.rs:409-411, hammer.rs:187-189
     const size_t n = (size_t)as_u64(duration * sr);
     std::vector<double> reed(n, 0.0);
     for (size_t off = 0; off < n; off += 1024) voice.render(reed.data() + off, std::min((size_t)1024, n - off));
 
-    DkPreamp legacy;
-    MelangePreamp mel;
-    if (preamp_kind) { mel.init(preamp_sr); mel.reset(); mel.set_ldr_resistance(r_ldr); }
-    else { legacy.init(preamp_sr); legacy.reset(); legacy.set_ldr_resistance(r_ldr); }
-    struct { DkPreamp* l; MelangePreamp* m; double process_sample(double x) { return m ? m->process_sample(x) : l->process_sample(x); } }
-        preamp{preamp_kind ? nullptr : &legacy, preamp_kind ? &mel : nullptr};
     std::vector<double> pre(n, 0.0);
-    if (do_os) {
-        Oversampler os;
-        for (size_t i = 0; i < n; ++i) {
-            double up[2], proc[2], down[1];
-            os.upsample_2x(&reed[i], 1, up);
-            proc[0] = preamp.process_sample(up[0]);
-            proc[1] = preamp.process_sample(up[1]);
-            os.downsample_2x(proc, down, 1);
-            pre[i] = down[0];
-        }
+    if (o.no_preamp) {                                                                        // main.rs:425-427
+        pre = reed;
     } else {
-        for (size_t i = 0; i < n; ++i) pre[i] = preamp.process_sample(reed[i]);
+        DkPreamp legacy;
+        MelangePreamp mel;
+        if (o.preamp_kind) mel.init(preamp_sr); else legacy.init(preamp_sr);
+        Tremolo trem;
+        const bool use_trem = o.tremolo_depth > 0.0;                                          // main.rs:430-441
+        if (use_trem) trem.init(o.tremolo_depth, preamp_sr);
+        else if (o.preamp_kind) { mel.reset(); mel.set_ldr_resistance(o.r_ldr); }
+        else { legacy.reset(); legacy.set_ldr_resistance(o.r_ldr); }
+        auto step = [&](double x) -> double {
+            if (use_trem) { const double r = trem.process(); if (o.preamp_kind) mel.set_ldr_resistance(r); else legacy.set_ldr_resistance(r); }
+            return o.preamp_kind ? mel.process_sample(x) : legacy.process_sample(x);
+        };
+        if (do_os) {
+            Oversampler os;
+            for (size_t i = 0; i < n; ++i) {
+                double up[2], proc[2], down[1];
+                os.upsample_2x(&reed[i], 1, up);
+                proc[0] = step(up[0]);
+                proc[1] = step(up[1]);
+                os.downsample_2x(proc, down, 1);
+                pre[i] = down[0];
+            }
+        } else {
+            for (size_t i = 0; i < n; ++i) pre[i] = step(reed[i]);
+        }
     }
     PowerAmp pa;
+    MelangePowerAmp mpa;
+    if (o.power_amp_kind) { mpa.init(44100.0); if (o.no_rail_sag) mpa.set_rail_sag(false); }  // main.rs:480-483; power_amp.rs:321-323
     Speaker spk;
     spk.init(sr);
-    spk.set_character(speaker_char);
+    spk.set_character(o.speaker_char);
     std::vector<double> out(n, 0.0);
     for (size_t i = 0; i < n; ++i) {
-        const double att = pre[i] * volume * volume;
-        const double amp = poweramp ? pa.process(att) : att;
+        const double att = pre[i] * o.volume * o.volume;
+        const double amp = o.poweramp ? (o.power_amp_kind ? mpa.process(att) : pa.process(att)) : att;
         out[i] = spk.process(amp) * POST_SPEAKER_GAIN;
     }
     return out;
+}
+// --normalize (main.rs:505-511): the factor write_wav_24bit applies
+inline double batch_normalize_scale(const double* x, size_t n) {
+    double peak = 0.0;
+    for (size_t i = 0; i < n; ++i) peak = std::fmax(peak, std::fabs(x[i]));
+    return peak > 0.7 ? 0.7 / peak : 1.0;
+}
+inline std::vector<double> batch_render_job(int note, int velocity_u8, double duration, double sr, double volume,
+                                            double speaker_char, double r_ldr, bool mlp, bool poweramp, int preamp_kind = 0) {
+    BatchJobOpts o;
+    o.volume = volume; o.speaker_char = speaker_char; o.r_ldr = r_ldr; o.mlp = mlp; o.poweramp = poweramp; o.preamp_kind = preamp_kind;
+    return batch_render_job_ex(note, velocity_u8, duration, sr, o);
 }
 
 }  // namespace owo

@@ -163,6 +163,34 @@ size_t owo_batch_render_job_kind(int note, int vel_u8, double dur_s, double sr, 
     return v.size();
 }
 
+// every sample-changing flag of `preamp-bench render`; opts: [volume, speaker, r_ldr, tremolo_depth, displacement_scale (NaN = none)];
+// flags bit0 mlp, 1 poweramp, 2 no_preamp, 3 no_attack_noise, 4 no_rail_sag
+size_t owo_batch_render_job_ex(int note, int vel_u8, double dur_s, double sr, const double* opts, unsigned flags, int preamp_kind, int power_amp_kind,
+                               double* out, size_t cap) {
+    BatchJobOpts o;
+    o.volume = opts[0]; o.speaker_char = opts[1]; o.r_ldr = opts[2]; o.tremolo_depth = opts[3];
+    o.has_displacement_scale = opts[4] == opts[4]; o.displacement_scale = opts[4];
+    o.mlp = flags & 1u; o.poweramp = flags & 2u; o.no_preamp = flags & 4u; o.no_attack_noise = flags & 8u; o.no_rail_sag = flags & 16u;
+    o.preamp_kind = preamp_kind; o.power_amp_kind = power_amp_kind;
+    std::vector<double> v = batch_render_job_ex(note, vel_u8, dur_s, sr, o);
+    const size_t n = std::min(cap, v.size());
+    for (size_t i = 0; i < n; ++i) out[i] = v[i];
+    return v.size();
+}
+double owo_batch_normalize_scale(const double* x, size_t n) { return batch_normalize_scale(x, n); }
+// Voice::render_note_with_scale (voice.rs:201-221)
+size_t owo_render_note_scaled(int midi, double vel, double dur, double sr, double scale, double* out, size_t cap) {
+    const uint32_t seed = (uint32_t)midi * 2654435761u;
+    Voice voice;
+    voice.note_on(midi, vel, sr, seed, false);
+    voice.pickup.displacement_scale = scale;
+    const size_t n = (size_t)as_u64(dur * sr);
+    std::vector<double> v(n, 0.0);
+    for (size_t off = 0; off < n; off += 1024) voice.render(v.data() + off, std::min((size_t)1024, n - off));
+    for (size_t i = 0; i < std::min(cap, n); ++i) out[i] = v[i];
+    return n;
+}
+
 // ---- unit-level hooks for the known-answer tests ----
 double owo_midi_to_freq(int m) { return midi_to_freq(m); }
 double owo_tip_mass_ratio(int m) { return tip_mass_ratio(m); }
@@ -500,6 +528,15 @@ int owo_baked_dc(int solver, double* v, double* inl) {
         case 2: owo_flat(PA_DC_OP, 20, v); owo_flat(PA_DC_NL_I, 16, inl); return 2016;
     }
     return -1;
+}
+
+size_t owo_render_midi_ex(const double* time_s, const uint8_t* type, const uint8_t* note, const uint8_t* value, size_t n, double volume,
+                          double speaker_char, int no_poweramp, double tail_s, int preamp_kind, int power_amp_kind, int no_rail_sag, double* out, size_t cap) {
+    std::vector<TimedEvent> ev(n);
+    for (size_t i = 0; i < n; ++i) ev[i] = TimedEvent{time_s[i], type[i], note[i], value[i]};
+    std::vector<double> v = render_midi(ev, volume, speaker_char, no_poweramp != 0, tail_s, nullptr, preamp_kind, power_amp_kind, no_rail_sag != 0);
+    for (size_t i = 0; i < std::min(cap, v.size()); ++i) out[i] = v[i];
+    return v.size();
 }
 
 }  // extern "C"

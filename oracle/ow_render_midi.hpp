@@ -103,8 +103,10 @@ inline std::vector<TimedEvent> smf_events(const uint8_t* d, size_t n, int track_
 struct MidiRenderStats { uint64_t note_ons, peak_polyphony; };
 
 // main.rs:1711-1891.  Returns the f64 output (empty when there are no events, where the reference prints and returns).
+// preamp_kind / power_amp_kind: which DkPreamp / PowerAmp the command was built with (cargo features melange-preamp, legacy-power-amp)
 inline std::vector<double> render_midi(std::vector<TimedEvent> events, double volume, double speaker_char, bool no_poweramp,
-                                       double tail_seconds, MidiRenderStats* stats = nullptr) {
+                                       double tail_seconds, MidiRenderStats* stats = nullptr, int preamp_kind = 0, int power_amp_kind = 0,
+                                       bool no_rail_sag = false) {
     std::stable_sort(events.begin(), events.end(), [](const TimedEvent& a, const TimedEvent& b) { return a.time_s < b.time_s; });   // :1712
     if (stats) { stats->note_ons = 0; stats->peak_polyphony = 0; }
     if (events.empty()) return {};
@@ -115,12 +117,20 @@ inline std::vector<double> render_midi(std::vector<TimedEvent> events, double vo
     struct Slot { Voice voice; bool has = false, active = false; uint8_t midi_note = 0; uint64_t age = 0; };
     std::vector<Slot> voices(MAXV);
     uint64_t age_counter = 0;
-    DkPreamp preamp;
-    preamp.init(MIDI_BASE_SR * 2.0);
-    preamp.set_ldr_resistance(1000000.0);
-    preamp.reset();
+    // main.rs:1752-1754: set_ldr_resistance(1 Mohm) and THEN reset(): the legacy solver keeps its resistance across reset(), the melange
+    // adapter's reset() goes back to the settled clone at the nominal 100 kOhm (melange_adapter.rs:88-93) and stays there
+    DkPreamp legacy;
+    MelangePreamp mel;
+    if (preamp_kind) { mel.init(MIDI_BASE_SR * 2.0); mel.set_ldr_resistance(1000000.0); mel.reset(); }
+    else { legacy.init(MIDI_BASE_SR * 2.0); legacy.set_ldr_resistance(1000000.0); legacy.reset(); }
+    struct { DkPreamp* l; MelangePreamp* m; double process_sample(double x) { return m ? m->process_sample(x) : l->process_sample(x); } }
+        preamp{preamp_kind ? nullptr : &legacy, preamp_kind ? &mel : nullptr};
     Oversampler os;
-    PowerAmp power_amp;
+    PowerAmp pa_behavioural;
+    MelangePowerAmp pa_melange;
+    if (power_amp_kind) { pa_melange.init(44100.0); if (no_rail_sag) pa_melange.set_rail_sag(false); }     // PowerAmp::new(), main.rs:1756
+    struct { PowerAmp* b; MelangePowerAmp* m; double process(double x) { return m ? m->process(x) : b->process(x); } }
+        power_amp{power_amp_kind ? nullptr : &pa_behavioural, power_amp_kind ? &pa_melange : nullptr};
     Speaker speaker;
     speaker.init(MIDI_BASE_SR);
     speaker.set_character(speaker_char);

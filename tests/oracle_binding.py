@@ -160,6 +160,48 @@ def batch_render_job(note, vel_u8, dur, sr, volume=1.0, speaker=0.0, r_ldr=1e6, 
     return out[:got]
 
 
+def batch_render_job_ex(note, vel_u8, dur, sr, volume=0.60, speaker=1.0, r_ldr=1e6, tremolo_depth=0.0, displacement_scale=None, mlp=True,
+                        poweramp=True, no_preamp=False, no_attack_noise=False, no_rail_sag=False, preamp_kind=0, power_amp_kind=0):
+    """`preamp-bench render` with every sample-changing flag (tools/preamp-bench/src/main.rs:371-549); defaults = the command's."""
+    L = lib()
+    L.owo_batch_render_job_ex.restype = C.c_size_t
+    n = int(dur * sr)
+    out = np.zeros(max(n, 1))
+    opts = np.array([volume, speaker, r_ldr, tremolo_depth, float("nan") if displacement_scale is None else displacement_scale])
+    flags = (1 if mlp else 0) | (2 if poweramp else 0) | (4 if no_preamp else 0) | (8 if no_attack_noise else 0) | (16 if no_rail_sag else 0)
+    got = L.owo_batch_render_job_ex(int(note), int(vel_u8), C.c_double(dur), C.c_double(sr), _p(opts), C.c_uint(flags), int(preamp_kind),
+                                    int(power_amp_kind), _p(out), C.c_size_t(out.size))
+    return out[:got]
+
+
+def render_note_scaled(midi, vel, dur, sr, scale):
+    L = lib()
+    L.owo_render_note_scaled.restype = C.c_size_t
+    n = int(dur * sr)
+    out = np.zeros(max(n, 1))
+    got = L.owo_render_note_scaled(int(midi), C.c_double(vel), C.c_double(dur), C.c_double(sr), C.c_double(scale), _p(out), C.c_size_t(out.size))
+    return out[:got]
+
+
+def render_midi_ex(time_s, types, notes, values, volume=0.6, speaker=1.0, no_poweramp=False, tail=2.0, preamp_kind=0, power_amp_kind=0, no_rail_sag=False):
+    L = lib()
+    L.owo_render_midi_ex.restype = C.c_size_t
+    t = np.ascontiguousarray(time_s, dtype=np.float64); ty = np.ascontiguousarray(types, dtype=np.uint8)
+    no = np.ascontiguousarray(notes, dtype=np.uint8); va = np.ascontiguousarray(values, dtype=np.uint8)
+    cap = int((float(t.max()) + tail) * 44100.0) + 16 if t.size else 1
+    out = np.zeros(cap)
+    got = L.owo_render_midi_ex(_p(t), _p(ty), _p(no), _p(va), C.c_size_t(t.size), C.c_double(volume), C.c_double(speaker), 1 if no_poweramp else 0,
+                               C.c_double(tail), int(preamp_kind), int(power_amp_kind), 1 if no_rail_sag else 0, _p(out), C.c_size_t(cap))
+    return out[:got]
+
+
+def normalize_scale(x):
+    L = lib()
+    L.owo_batch_normalize_scale.restype = C.c_double
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    return L.owo_batch_normalize_scale(_p(x), C.c_size_t(x.size))
+
+
 class AliasAuditResult(C.Structure):
     """alias_audit.rs:68-93 (same field order as include/openwurli_hip.h ow_alias_audit_result)."""
     _fields_ = [("f0_hz", C.c_double), ("h1_dbfs", C.c_double), ("harmonic_db", C.c_double * 12), ("harmonic_dbc", C.c_double * 12),
