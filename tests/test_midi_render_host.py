@@ -74,13 +74,13 @@ def test_render_length_rules_need_no_device(hiplib_host):
 
     def call(cfg, out=None, stride=0):
         return L.ow_render_midi(allev.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), 3, C.byref(cfg), out, stride, C.cast(stats, C.c_void_p))
-    cfg = binding.OwMidiRenderCfg(0.6, 1.0, 2.0, 0, 0, 0, 0)
+    cfg = binding.OwMidiRenderCfg(0.6, 1.0, 2.0, 0, 0, 0, 0, 0, 0)
     assert call(cfg) == int((3.0 + 2.0) * 44100.0)                            # (last_event_time + tail) * BASE_SR as usize (main.rs:1719-1721)
     assert [s.n_samples for s in stats] == [int(3.25 * 44100.0), 0, int(5.0 * 44100.0)]
     cfg.tail_s = 0.0
     assert call(cfg) == int(3.0 * 44100.0)
-    cfg.preamp_kind = 1
-    assert call(cfg) < 0                                                      # legacy preamp only
+    cfg.preamp_kind = 7
+    assert call(cfg) < 0                                                      # unknown preamp kind
     cfg.preamp_kind = 0
     allev[0]["time_s"] = np.nan
     assert call(cfg) < 0                                                      # partial_cmp().unwrap() panics in the reference
