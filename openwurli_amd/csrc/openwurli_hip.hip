@@ -84,7 +84,10 @@ class Workers {
     // fn(ctx, t) for t in [0, T); returns when all slices are done.  One dispatch at a time (callers of different pools serialise).
     void run(size_t T, void (*fn)(void*, size_t), void* ctx) {
         if (T <= 1 || th_.empty()) { for (size_t t = 0; t < T; ++t) fn(ctx, t); return; }
-        std::lock_guard<std::mutex> one(dispatch_mu_);
+        // One dispatch at a time.  A second caller (another pool rendering on another audio thread) does NOT wait for the workers -- a
+        // realtime thread blocked on a mutex that lower-priority work holds is a priority inversion -- it runs its slices itself.
+        std::unique_lock<std::mutex> one(dispatch_mu_, std::try_to_lock);
+        if (!one.owns_lock()) { for (size_t t = 0; t < T; ++t) fn(ctx, t); return; }
         {
             std::lock_guard<std::mutex> lk(mu_);
             fn_ = fn; ctx_ = ctx; total_ = T; next_.store(0); done_ = 0; ++gen_;
@@ -745,7 +748,9 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
     const int NP = pipeline_stages(ne, true);                  // stage boundaries exist whether or not this block uses them
     size_t T = ne >= 16384 ? std::min<size_t>(effective_cpus(), 32) : 1;
     if (NP > 1) T = std::max<size_t>(NP, T - T % (size_t)NP);   // stages are whole numbers of slices
-    const int per = (int)((ne + T - 1) / T);
+    // slices (and with them the stages of a staged render) start on multiples of 32 engines: the chain kernels' workgroups then never
+    // straddle a stage boundary, and per-workgroup scratch indexed by (first engine / 32 + block) is disjoint between stages
+    const int per = (int)(((ne + T - 1) / T + 31) / 32 * 32);
     using Fill = ow_pool::SliceStart;
     Fill size[OW_MAX_SLICES];
     Fill* start = p->slice_start;                              // T <= 32; kept: stage k launches the blocks of its slices

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) void k_preamp_mel_lit(const OwConsts* __restric
     // The LU workspace is only touched by the generic rebuild (the fallback of the fast path): it lives in HBM, one [12][12][32] slab
     // per workgroup (slabs of disjoint engine ranges are disjoint: ceil(e0/32) + block), so that LDS holds S alone -- 39 KB, four
     // workgroups per CU, every SIMD busy (with LU in LDS: two workgroups, half the SIMDs idle; 52.8 -> see DESIGN).
-    double* lu = lu_scratch + ((size_t)((e0 + 31) / 32) + blockIdx.x) * (12 * 12 * 32) + el;
+    double* lu = lu_scratch + ((size_t)(e0 / 32) + blockIdx.x) * (12 * 12 * 32) + el;     // stage starts are multiples of 32 engines (build_voice_lists)
     double* S = S_all + el;
 
     MelSt st;
