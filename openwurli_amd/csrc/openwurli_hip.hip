@@ -518,6 +518,15 @@ static inline bool trem_wide(int ne) {
     if (const char* env = std::getenv("OW_TREM_WIDE")) return env[0] == '1';
     return ne <= 16384;
 }
+// lane = group tremolo kernel at pool scale: serialise it in front of the voice kernel (OW_TREM_SERIAL=0/1 forces the choice)
+static inline bool trem_serialised(int n_leaders) {
+    // Measured at 131 072 engines / oscillators: serialised 31.8 ms per block (voices 12.8, tremolo 9.1 on an empty chip), overlapped
+    // 29.7 ms -- each kernel alone leaves issue slots the other can use.  So the default stays overlapped; OW_TREM_SERIAL=1 is how the
+    // two kernels' own times are measured (profiles/).
+    (void)n_leaders;
+    if (const char* env = std::getenv("OW_TREM_SERIAL")) return env[0] == '1';
+    return false;
+}
 // legacy preamp with a quad per solver state (k_preamp_wide): while the pool leaves most SIMDs empty the kernel's time is the serial
 // latency of one sample, which the quad shortens; beyond ~4 096 engines the lane-pair kernel's lower instruction count wins
 static inline bool preamp_wide(int ne) {
@@ -846,6 +855,8 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
     // 1 024 wavefronts (one per SIMD) are resident before the voice kernel fills the rest.  (k_apply_ops is register-capped so that
     // it fits beside them.)
     if (chain) launch_block_ahead();
+    // OW_TREM_SERIAL=1 (measurement switch, see trem_serialised): the voices of this block wait for the block-ahead oscillators
+    if (chain && trem_serialised(p->n_lead)) HIP_OK(hipStreamWaitEvent(st, p->ev_trem[p->rb_cur ^ 1], 0));
     // ---- per-engine args + ops: only engines whose host state changed are touched (the rest keep their
     // uploaded args; a steady-state step of a large pool does no per-engine host work here)
     // Large pools split the range over host threads: slice t counts its pending ops, a prefix sum places the slices in h_ops,

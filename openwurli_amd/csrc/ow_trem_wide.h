@@ -162,6 +162,10 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
         });
         double b[4] = {0.0, 0.0, 0.0, 0.0};
         if (!singular) {
+            // the four back-substitution quotients form a serial chain; their divisors (lane i's own diagonal) are known now, so every lane
+            // refines its reciprocal once, off that chain: ow_div_y(sum, d, y) is ow_div(sum, d) instruction for instruction
+            const double my_diag = q == 0 ? ar[0] : (q == 1 ? ar[1] : (q == 2 ? ar[2] : ar[3]));
+            const double y_diag = ow_rcp_refined(my_diag);
             static_for<0, 4>([&](auto KI) {
                 constexpr int i = 3 - KI;
                 double sum = br;
@@ -169,7 +173,7 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
                 for (int j = i + 1; j < 4; ++j) sum -= ar[j] * b[j];
                 const double diag = qget<i>(ar[i]);
                 if (!singular && fabs(diag) < 1e-15) singular = true;
-                if (!singular) b[i] = qget<i>(ow_div(sum, ar[i]));
+                if (!singular) b[i] = qget<i>(ow_div_y(sum, ar[i], y_diag));
                 else b[i] = qget<i>(br);      // the scalar code leaves b[i] unreduced once singular; its value is not used afterwards
             });
         }
@@ -185,7 +189,11 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
             const double v_lim = (fabs(dv_trial) > 1e-4) ? pnjlim(v_trial, vd, OW_T_VT, OW_T_VCRIT) : v_trial;
             const double dv_lim = v_lim - vd;
             double r_me = 1.0;           // ports that do not take part leave ga alone
-            if (fabs(dv_trial) > 1e-15) r_me = (dv_trial * dv_lim < 0.0) ? 0.0 : clampd(ow_div(dv_lim, dv_trial), 0.0, 1.0);
+            // an unlimited port has v_lim == v_trial, i.e. dv_lim is dv_trial bit for bit and the ratio is x / x == 1: the division only runs
+            // when some port of the wavefront was limited (start-up transients)
+            if (__builtin_amdgcn_ballot_w64(!(v_lim == v_trial)) != 0ull) {
+                if (fabs(dv_trial) > 1e-15) r_me = (dv_trial * dv_lim < 0.0) ? 0.0 : clampd(ow_div(dv_lim, dv_trial), 0.0, 1.0);
+            }
             // ga = min over the ports in port order with a strict "<" (a NaN ratio never wins, as in the scalar loop)
             double ga = 1.0;
             bool any_limited = false;
