@@ -39,6 +39,11 @@ int ow_debug_div(const double* a, const double* b, size_t n, double* fast, doubl
  * 3 preamp V_T 0.026, 4 power-amp 0.013^2, 5 power-amp headroom 22.  a == NULL runs every numerator of the jitter draw
  * (all 2^31 integers) on the device and stores the number of quotients that differ from `a / B` in *mismatches. */
 int ow_debug_div_const(int which, const double* a, size_t n, double* fast, double* ieee, uint64_t* mismatches, int device);
+/* The other short division forms of the kernels next to the compiler's `a / b`, element-wise: mode 0 = divisor with a host-computed
+ * reciprocal y[i] = 1.0 / b[i] (ow_div_const: the power amp's per-device constants), 1 = refined reciprocal shared among the quotients over
+ * one pivot (ow_rcp_refined + ow_div_y), 2 = the same without the final v_div_fixup (finite operands, pivots checked: the melange column
+ * kernel). */
+int ow_debug_div_forms(int mode, const double* a, const double* b, const double* y, size_t n, double* fast, double* ieee, int device);
 /* Element-wise, the kernels' own elementary functions next to the device library's: which = 0 the preamp's junction exponential
  * (exp without the overflow / underflow selects, for arguments inside the junction clamp) and exp(); 1 the power amp's / speaker's
  * tanh (expm1-based, <= 2 ulp) and tanh(). */

@@ -152,6 +152,7 @@ TEST_SYMBOLS = {
     "ow_debug_mlp_raw": (C.c_int, [_VP, _VP, C.c_size_t, _VP, C.c_int, C.c_int]),
     "ow_debug_div": (C.c_int, [_VP, _VP, C.c_size_t, _VP, _VP, C.c_int]),
     "ow_debug_div_const": (C.c_int, [C.c_int, _VP, C.c_size_t, _VP, _VP, _VP, C.c_int]),
+    "ow_debug_div_forms": (C.c_int, [C.c_int, _VP, _VP, _VP, C.c_size_t, _VP, _VP, C.c_int]),
     "ow_debug_unary": (C.c_int, [C.c_int, _VP, C.c_size_t, _VP, _VP, C.c_int]),
     "ow_test_inject_render_faults": (None, [_VP, C.c_int]),
     "ow_debug_power_amp": (C.c_int, [C.c_double, _VP, C.c_size_t, C.c_size_t, C.c_int, _VP, _VP, _VP, _VP, _VP, C.c_int]),

@@ -2037,6 +2037,24 @@ int ow_debug_div_const(int which, const double* a, size_t n, double* fast, doubl
     } catch (const std::exception& ex) { set_err(std::string("ow_debug_div_const: ") + ex.what()); return -1; }
 }
 
+int ow_debug_div_forms(int mode, const double* a, const double* b, const double* y, size_t n, double* fast, double* ieee, int device) {
+    try {
+        if (!a || !b || !fast || !ieee || mode < 0 || mode > 2 || (mode == 0 && !y)) throw std::runtime_error("bad argument");
+        if (n == 0) return 0;
+        HIP_OK(hipSetDevice(device));
+        DevMem da, db, dy, df, di;
+        da.alloc(n * sizeof(double)); db.alloc(n * sizeof(double)); dy.alloc(n * sizeof(double)); df.alloc(n * sizeof(double)); di.alloc(n * sizeof(double));
+        HIP_OK(hipMemcpy(da.p, a, n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(db.p, b, n * sizeof(double), hipMemcpyHostToDevice));
+        if (y) HIP_OK(hipMemcpy(dy.p, y, n * sizeof(double), hipMemcpyHostToDevice));
+        owdev::k_debug_div_forms<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(mode, da.as<double>(), db.as<double>(), dy.as<double>(), n, df.as<double>(), di.as<double>());
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpy(fast, df.p, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(ieee, di.p, n * sizeof(double), hipMemcpyDeviceToHost));
+        return 0;
+    } catch (const std::exception& ex) { set_err(std::string("ow_debug_div_forms: ") + ex.what()); return -1; }
+}
+
 int ow_debug_unary(int which, const double* x, size_t n, double* fast, double* lib, int device) {
     try {
         if (!x || !fast || !lib || which < 0 || which > 1) throw std::runtime_error("null argument or unknown function");

@@ -410,6 +410,8 @@ static void build_pa_consts(OwPaConsts& c, double rate) {
     c.alpha_attack = 1.0 - std::exp(-dt / 0.008);
     c.alpha_release = 1.0 - std::exp(-dt / 0.015);
     c.alpha_i_avg = 1.0 - std::exp(-dt / 0.030);
+    for (int i = 0; i < PA_N; ++i)      // the kernel writes the constant part of the right-hand side as "22.5 V on the two supply rows"
+        if (PA_RHS_CONST[i] != (i >= 18 ? 22.5 : 0.0)) throw std::runtime_error("power amp: RHS_CONST is not the two 22.5 V supply rows the kernel assumes");
     for (int d = 0; d < 8; ++d) {
         if (PA_DEV_USE_GP[d] == 0.0) throw std::runtime_error("power amp: a device without Gummel-Poon terms (only the GP branch is built)");
         OwPaConsts::Dev& D = c.dev[d];
@@ -424,6 +426,8 @@ static void build_pa_consts(OwPaConsts& c, double rate) {
         D.c_dq2_be = is / (D.nf_vt * D.ikf); D.c_dq2_bc = is / (D.nr_vt * D.ikr);
         D.c_dicc_be = is / D.nf_vt; D.c_dicc_bc = -is / D.nr_vt;
         D.max_step = 4.0 * vt;
+        D.r_nf_vt = 1.0 / D.nf_vt; D.r_nr_vt = 1.0 / D.nr_vt; D.r_ne_vt = 1.0 / D.ne_vt; D.r_nc_vt = 1.0 / D.nc_vt;
+        D.r_var = 1.0 / D.var; D.r_vaf = 1.0 / D.vaf; D.r_ikf = 1.0 / D.ikf; D.r_ikr = 1.0 / D.ikr;
     }
 }
 

@@ -120,8 +120,10 @@ __device__ constexpr unsigned MCOL_PART[12] = {0x3F, 0x3F, 0x3F, 0x20, 0x3F, 0x3
 __device__ constexpr unsigned MCOL_BTOP[12] = {0x37, 0x36, 0x34, 0x00, 0x30, 0x20, 0x00, 0x00, 0x00, 0x00, 0x00, 0x38};
 
 // a / pivot with the pivot's refined reciprocal, without v_div_fixup: numerators here are finite sums of finite products and the pivots
-// were checked against 1e-30, so none of the special cases that instruction repairs (zero / infinite / NaN operands, exponents at the
-// ends of the range) can occur; for everything else it returns its first operand unchanged.
+// were checked against 1e-30, so none of the special cases that instruction repairs (infinite / NaN operands, a zero divisor, exponents
+// at the ends of the range) can occur; for everything else it returns its first operand unchanged -- except that it also sets the SIGN of
+// a zero quotient: a zero numerator gives +0 here where IEEE gives -0 for unlike signs.  Equal as numbers, and a signed zero stays a zero
+// through everything that follows (x - 0 * y, sums, products; never a divisor).  tests/test_gpu_division.py checks both statements.
 OW_DEV double mcol_div(double a, double b, double y) {
 #ifdef OW_IEEE_DIV
     return a / b;

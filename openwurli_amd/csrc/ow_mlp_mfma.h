@@ -121,4 +121,24 @@ __global__ __launch_bounds__(256) void k_debug_div(const double* __restrict__ a,
     if (i < n) { fast[i] = ow_div(a[i], b[i]); ieee[i] = a[i] / b[i]; }
 }
 
+// The other short division forms next to the compiler's a / b (tests/test_gpu_division.py): mode 0 = ow_div_const(a, b, y) with a host
+// reciprocal y (the per-device divisors of the power amp), 1 = ow_div_y(a, b, ow_rcp_refined(b)) (shared pivot reciprocals), 2 = the
+// melange column kernel's quotient without v_div_fixup (mcol_div in ow_melange_col.h: same three operations).
+__global__ __launch_bounds__(256) void k_debug_div_forms(int mode, const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ y, size_t n,
+                                                         double* __restrict__ fast, double* __restrict__ ieee) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double r;
+    if (mode == 0) r = ow_div_const(a[i], b[i], y[i]);
+    else if (mode == 1) r = ow_div_y(a[i], b[i], ow_rcp_refined(b[i]));
+    else {
+        const double yy = ow_rcp_refined(b[i]);
+        const double q = a[i] * yy;
+        const double rr = __builtin_fma(-b[i], q, a[i]);
+        r = __builtin_fma(rr, yy, q);
+    }
+    fast[i] = r;
+    ieee[i] = a[i] / b[i];
+}
+
 }  // namespace owdev

@@ -38,11 +38,11 @@ struct PaBjt { double ic, ib, j0, j1, j2, j3; };
 // gen_power_amp.rs:7870-8017, Gummel-Poon branch (all eight devices of the netlist set USE_GP; the host refuses anything else)
 __device__ inline PaBjt pa_bjt_evaluate(double vbe, double vbc, const OwPaConsts::Dev& D) {
     const double vbe_eff = D.sign * vbe, vbc_eff = D.sign * vbc;
-    const double exp_be = fast_exp(ow_div(vbe_eff, D.nf_vt));
-    const double exp_bc = fast_exp(ow_div(vbc_eff, D.nr_vt));
+    const double exp_be = fast_exp(ow_div_const(vbe_eff, D.nf_vt, D.r_nf_vt));
+    const double exp_bc = fast_exp(ow_div_const(vbc_eff, D.nr_vt, D.r_nr_vt));
     const bool has_ise = D.ise > 0.0, has_isc = D.isc > 0.0;
-    const double exp_be_leak = has_ise ? fast_exp(ow_div(vbe_eff, D.ne_vt)) : 0.0;
-    const double exp_bc_leak = has_isc ? fast_exp(ow_div(vbc_eff, D.nc_vt)) : 0.0;
+    const double exp_be_leak = has_ise ? fast_exp(ow_div_const(vbe_eff, D.ne_vt, D.r_ne_vt)) : 0.0;
+    const double exp_bc_leak = has_isc ? fast_exp(ow_div_const(vbc_eff, D.nc_vt, D.r_nc_vt)) : 0.0;
     const double i_cc = D.is * (exp_be - exp_bc);
     const double ib_fwd = D.is_bf * (exp_be - 1.0);
     const double ib_rev = D.is_br * (exp_bc - 1.0);
@@ -52,22 +52,23 @@ __device__ inline PaBjt pa_bjt_evaluate(double vbe, double vbc, const OwPaConsts
     const double dib_rev_dvbc = D.c_dib_rev * exp_bc;
     const double dib_leak_dvbe = has_ise ? D.c_leak_be * exp_be_leak : 0.0;
     const double dib_leak_dvbc = has_isc ? D.c_leak_bc * exp_bc_leak : 0.0;
-    const double q1_denom = 1.0 - ow_div(vbe_eff, D.var) - ow_div(vbc_eff, D.vaf);
+    const double q1_denom = 1.0 - ow_div_const(vbe_eff, D.var, D.r_var) - ow_div_const(vbc_eff, D.vaf, D.r_vaf);
     double q1 = 1.0, dq1_dvbe = 0.0, dq1_dvbc = 0.0;
     if (!(q1_denom <= 0.0 || fabs(q1_denom) < 1e-30)) {
         q1 = ow_div(1.0, q1_denom);
-        dq1_dvbe = ow_div(q1 * q1, D.var);
-        dq1_dvbc = ow_div(q1 * q1, D.vaf);
+        dq1_dvbe = ow_div_const(q1 * q1, D.var, D.r_var);
+        dq1_dvbc = ow_div_const(q1 * q1, D.vaf, D.r_vaf);
     }
     const double cbe = D.is * (exp_be - 1.0);
     const double cbc = D.is * (exp_bc - 1.0);
-    const double q2 = ow_div(cbe, D.ikf) + ow_div(cbc, D.ikr);
+    const double q2 = ow_div_const(cbe, D.ikf, D.r_ikf) + ow_div_const(cbc, D.ikr, D.r_ikr);
     const double dq2_dvbe = D.c_dq2_be * exp_be;
     const double dq2_dvbc = D.c_dq2_bc * exp_bc;
     const double disc = fmax(1.0 + 4.0 * q2, 0.0);
     const double dd = sqrt(disc);
-    const double dd_dvbe = dd > 1e-15 ? ow_div(2.0 * dq2_dvbe, dd) : 0.0;
-    const double dd_dvbc = dd > 1e-15 ? ow_div(2.0 * dq2_dvbc, dd) : 0.0;
+    const double y_dd = ow_rcp_refined(dd);                        // two quotients over dd, two over qb2: one refined reciprocal each
+    const double dd_dvbe = dd > 1e-15 ? ow_div_y(2.0 * dq2_dvbe, dd, y_dd) : 0.0;
+    const double dd_dvbc = dd > 1e-15 ? ow_div_y(2.0 * dq2_dvbc, dd, y_dd) : 0.0;
     const double qb = q1 * (1.0 + dd) * 0.5;                       // x / 2.0 == x * 0.5 exactly
     const double dqb_dvbe = dq1_dvbe * (1.0 + dd) * 0.5 + q1 * dd_dvbe * 0.5;
     const double dqb_dvbc = dq1_dvbc * (1.0 + dd) * 0.5 + q1 * dd_dvbc * 0.5;
@@ -77,8 +78,9 @@ __device__ inline PaBjt pa_bjt_evaluate(double vbe, double vbc, const OwPaConsts
     const double dicc_dvbe = D.c_dicc_be * exp_be;
     const double dicc_dvbc = D.c_dicc_bc * exp_bc;
     const double qb2 = fmax(qb * qb, 1e-30);
-    const double quotient_dvbe = ow_div(dicc_dvbe * qb - i_cc * dqb_dvbe, qb2);
-    const double quotient_dvbc = ow_div(dicc_dvbc * qb - i_cc * dqb_dvbc, qb2);
+    const double y_qb2 = ow_rcp_refined(qb2);
+    const double quotient_dvbe = ow_div_y(dicc_dvbe * qb - i_cc * dqb_dvbe, qb2, y_qb2);
+    const double quotient_dvbc = ow_div_y(dicc_dvbc * qb - i_cc * dqb_dvbc, qb2, y_qb2);
     const double d_bc_term_dvbc = D.c_dib_rev * exp_bc;
     r.j0 = quotient_dvbe;
     r.j1 = quotient_dvbc - d_bc_term_dvbc;
@@ -91,17 +93,23 @@ __device__ inline PaBjt pa_bjt_evaluate(double vbe, double vbc, const OwPaConsts
 __device__ inline PaBjt pa_bjt_with_parasitics(double vbe_ext, double vbc_ext, const OwPaConsts::Dev* __restrict__ Dp) {
     const OwPaConsts::Dev& D = *Dp;
     double vbe_int = vbe_ext, vbc_int = vbc_ext;
+    // The reference evaluates the device once more after its inner loop (:8113); when the loop ended at the convergence test that is the
+    // evaluation the test itself just made, at the same voltages: it is kept (`held`) and only a lane that left the loop another way --
+    // iteration limit, singular 2x2 -- evaluates again.  (All lanes of the wavefront converging is the normal case.)
+    PaBjt held;
+    bool fresh = false;
     for (int it = 0; it < 15; ++it) {
         const PaBjt e = pa_bjt_evaluate(vbe_int, vbc_int, D);
+        held = e;
         const double f1 = vbe_int - vbe_ext + e.ib * D.rb + (e.ic + e.ib) * D.re;
         const double f2 = vbc_int - vbc_ext + e.ib * D.rb - e.ic * D.rc;
-        if (fabs(f1) < 1e-10 && fabs(f2) < 1e-10) break;
+        if (fabs(f1) < 1e-10 && fabs(f2) < 1e-10) { fresh = true; break; }
         const double j11 = 1.0 + e.j2 * D.rb + (e.j0 + e.j2) * D.re;
         const double j12 = e.j3 * D.rb + (e.j1 + e.j3) * D.re;
         const double j21 = e.j2 * D.rb - e.j0 * D.rc;
         const double j22 = 1.0 + e.j3 * D.rb - e.j1 * D.rc;
         const double det = j11 * j22 - j12 * j21;
-        if (fabs(det) < 1e-30) break;
+        if (fabs(det) < 1e-30) { fresh = true; break; }            // voltages unchanged since `held` was evaluated
         const double inv_det = ow_div(1.0, det);
         double dvbe = (j22 * f1 - j12 * f2) * inv_det;
         double dvbc = (j11 * f2 - j21 * f1) * inv_det;
@@ -110,7 +118,11 @@ __device__ inline PaBjt pa_bjt_with_parasitics(double vbe_ext, double vbc_ext, c
         vbe_int -= dvbe;
         vbc_int -= dvbc;
     }
-    const PaBjt e = pa_bjt_evaluate(vbe_int, vbc_int, D);
+    PaBjt e = held;
+    if (__builtin_amdgcn_ballot_w64(!fresh) != 0ull) {
+        const PaBjt e2 = pa_bjt_evaluate(vbe_int, vbc_int, D);
+        if (!fresh) e = e2;
+    }
     const double j11 = 1.0 + e.j2 * D.rb + (e.j0 + e.j2) * D.re;
     const double j12 = e.j3 * D.rb + (e.j1 + e.j3) * D.re;
     const double j21 = e.j2 * D.rb - e.j0 * D.rc;
@@ -187,10 +199,9 @@ struct PaTab {
     double s[PA_N * PA_N];
     double s_ni[PA_N * PA_M];
     OwPaConsts::Dev dev[8];
-    double rhs_const[PA_N];
     double nz_coef[PA_RHS_NNZ];          // A_neg's non-zeros in the reference's order (sorted by row), as CSR
-    int nz_col[PA_RHS_NNZ];
-    int row_ptr[PA_N + 1];
+    uint8_t nz_col[PA_RHS_NNZ];          // (bytes: with the two tables as ints the workgroup's LDS passed 80 KB and only one fit a CU)
+    uint8_t row_ptr[PA_N + 1];
 };
 __device__ __forceinline__ void pa_stage_tables(PaTab* __restrict__ T, const OwPaConsts* __restrict__ C) {
     for (int i = threadIdx.x; i < PA_M * PA_M; i += blockDim.x) T->k[i] = (&C->k[0][0])[i];
@@ -199,16 +210,15 @@ __device__ __forceinline__ void pa_stage_tables(PaTab* __restrict__ T, const OwP
     double* d = reinterpret_cast<double*>(&T->dev[0]);
     const double* g = reinterpret_cast<const double*>(&C->dev[0]);
     for (int i = threadIdx.x; i < (int)(8 * sizeof(OwPaConsts::Dev) / sizeof(double)); i += blockDim.x) d[i] = g[i];
-    for (int i = threadIdx.x; i < PA_N; i += blockDim.x) T->rhs_const[i] = PA_RHS_CONST[i];
     for (int q = threadIdx.x; q < PA_RHS_NNZ; q += blockDim.x) {
         const int i = (int)PA_RHS_NZ_ROW[q], j = (int)PA_RHS_NZ_COL[q];
         T->nz_coef[q] = C->a_neg[i][j];
-        T->nz_col[q] = j;
+        T->nz_col[q] = (uint8_t)j;
     }
     for (int r = threadIdx.x; r <= PA_N; r += blockDim.x) {
         int c = 0;
         for (int q = 0; q < PA_RHS_NNZ; ++q) c += ((int)PA_RHS_NZ_ROW[q] < r) ? 1 : 0;
-        T->row_ptr[r] = c;
+        T->row_ptr[r] = (uint8_t)c;
     }
     __syncthreads();
 }
@@ -253,60 +263,63 @@ __device__ __forceinline__ uint32_t pa_newton_body(double* __restrict__ W, const
         // the reference's order), and the owner of logical row i is the lane that holds position i.
         int posA = r0, posB = r1;
         bool singular = false, usedA = false, usedB = false;
-#pragma unroll 1
-        for (int col = 0; col < PA_M; ++col) {
-            PL(PL_CAND + posA) = fabs(A[0]);                        // rows already used as pivots sit at positions < col: never looked at again
-            PL(PL_CAND + posB) = fabs(B[0]);
-            PA_SYNC();
-            // the reference's scan: first strict maximum over logical rows col..15; all candidates are fetched at once
-            int max_row = col;
-            double max_val = PL(PL_CAND + col);
-            double cand[PA_M];
-#pragma unroll
-            for (int row = 1; row < PA_M; ++row) cand[row] = PL(PL_CAND + row);
-#pragma unroll
-            for (int row = 1; row < PA_M; ++row) {
-                if (row > col) {                                    // wave-uniform: col is the loop counter
-                    const bool take = cand[row] > max_val;
-                    max_val = take ? cand[row] : max_val;
-                    max_row = take ? row : max_row;
-                }
-            }
-            if (max_val < 1e-15) { singular = true; break; }
-            // exchange logical positions col <-> max_row (a no-op when they are equal)
-            posA = posA == col ? max_row : (posA == max_row ? col : posA);
-            posB = posB == col ? max_row : (posB == max_row ? col : posB);
-            if (posA == col) {
-#pragma unroll
-                for (int j = 0; j < PA_M; ++j) PL(PL_PROW + j) = A[j];
-                PL(PL_PROW + 16) = bA;
-                usedA = true;
-            }
-            if (posB == col) {
-#pragma unroll
-                for (int j = 0; j < PA_M; ++j) PL(PL_PROW + j) = B[j];
-                PL(PL_PROW + 16) = bB;
-                usedB = true;
-            }
-            PA_SYNC();
-            const double pivot = PL(PL_PROW), bcol = PL(PL_PROW + 16);
-            double prow[PA_M];
-#pragma unroll
-            for (int j = 1; j < PA_M; ++j) prow[j] = PL(PL_PROW + j);
-            if (!usedA) {
-                const double factor = ow_div(A[0], pivot);
-#pragma unroll
-                for (int j = 1; j < PA_M; ++j) A[j - 1] = A[j] - factor * prow[j];
-                bA -= factor * bcol;
-            }
-            if (!usedB) {
-                const double factor = ow_div(B[0], pivot);
-#pragma unroll
-                for (int j = 1; j < PA_M; ++j) B[j - 1] = B[j] - factor * prow[j];
-                bB -= factor * bcol;
-            }
-            PA_SYNC();
+        // Four rolled loops of four columns: after column c only entries 1 .. 15 - c of a live row matter, so the tier that starts at
+        // column c0 updates (and fetches from the pivot row) WIDTH = 15 - c0 entries instead of all 15 -- the same operations on the
+        // same values, minus the ones on stale entries past the live width.  The two quotients over a column's pivot share its refined
+        // reciprocal (ow_div_y == ow_div instruction for instruction).
+#define PA_ELIM_TIER(C0, C1, WIDTH)                                                                                          \
+        _Pragma("unroll 1") for (int col = (C0); col < (C1) && !singular; ++col) {                                              \
+            PL(PL_CAND + posA) = fabs(A[0]);        /* rows already used as pivots sit at positions < col: never looked at again */ \
+            PL(PL_CAND + posB) = fabs(B[0]);                                                                                    \
+            PA_SYNC();                                                                                                          \
+            /* the reference's scan: first strict maximum over logical rows col..15; all candidates are fetched at once */     \
+            int max_row = col;                                                                                                  \
+            double max_val = PL(PL_CAND + col);                                                                                 \
+            double cand[PA_M];                                                                                                  \
+            _Pragma("unroll") for (int row = (C0) + 1; row < PA_M; ++row) cand[row] = PL(PL_CAND + row);                         \
+            _Pragma("unroll") for (int row = (C0) + 1; row < PA_M; ++row) {                                                      \
+                if (row > col) {                    /* wave-uniform: col is the loop counter */                                \
+                    const bool take = cand[row] > max_val;                                                                      \
+                    max_val = take ? cand[row] : max_val;                                                                       \
+                    max_row = take ? row : max_row;                                                                             \
+                }                                                                                                               \
+            }                                                                                                                   \
+            if (max_val < 1e-15) { singular = true; break; }                                                                    \
+            /* exchange logical positions col <-> max_row (a no-op when they are equal) */                                     \
+            posA = posA == col ? max_row : (posA == max_row ? col : posA);                                                      \
+            posB = posB == col ? max_row : (posB == max_row ? col : posB);                                                      \
+            if (posA == col) {                                                                                                  \
+                _Pragma("unroll") for (int j = 0; j <= (WIDTH); ++j) PL(PL_PROW + j) = A[j];                                      \
+                PL(PL_PROW + 16) = bA;                                                                                          \
+                usedA = true;                                                                                                   \
+            }                                                                                                                   \
+            if (posB == col) {                                                                                                  \
+                _Pragma("unroll") for (int j = 0; j <= (WIDTH); ++j) PL(PL_PROW + j) = B[j];                                      \
+                PL(PL_PROW + 16) = bB;                                                                                          \
+                usedB = true;                                                                                                   \
+            }                                                                                                                   \
+            PA_SYNC();                                                                                                          \
+            const double pivot = PL(PL_PROW), bcol = PL(PL_PROW + 16);                                                          \
+            const double ypiv = ow_rcp_refined(pivot);                                                                          \
+            double prow[PA_M];                                                                                                  \
+            _Pragma("unroll") for (int j = 1; j <= (WIDTH); ++j) prow[j] = PL(PL_PROW + j);                                       \
+            if (!usedA) {                                                                                                       \
+                const double factor = ow_div_y(A[0], pivot, ypiv);                                                              \
+                _Pragma("unroll") for (int j = 1; j <= (WIDTH); ++j) A[j - 1] = A[j] - factor * prow[j];                          \
+                bA -= factor * bcol;                                                                                            \
+            }                                                                                                                   \
+            if (!usedB) {                                                                                                       \
+                const double factor = ow_div_y(B[0], pivot, ypiv);                                                              \
+                _Pragma("unroll") for (int j = 1; j <= (WIDTH); ++j) B[j - 1] = B[j] - factor * prow[j];                          \
+                bB -= factor * bcol;                                                                                            \
+            }                                                                                                                   \
+            PA_SYNC();                                                                                                          \
         }
+        PA_ELIM_TIER(0, 4, 15)
+        PA_ELIM_TIER(4, 8, 11)
+        PA_ELIM_TIER(8, 12, 7)
+        PA_ELIM_TIER(12, 16, 3)
+#undef PA_ELIM_TIER
         if (singular) {
             const double i0 = PL(PL_INL + r0), i1 = PL(PL_INL + r1);
             const double c0 = BE ? 0.01 : fmax(fabs(i0) * 0.1, 0.01), c1 = BE ? 0.01 : fmax(fabs(i1) * 0.1, 0.01);
@@ -344,19 +357,30 @@ __device__ __forceinline__ uint32_t pa_newton_body(double* __restrict__ W, const
             }
             const double dvt0 = a0 - vd0, dvt1 = a1 - vd1;
             PL(PL_T0 + r0) = dvt0; PL(PL_T0 + r1) = dvt1;
-            PL(PL_T1 + r0) = fabs(dvt0) > 1e-4 ? pa_pnjlim(a0, vd0, vt, vcrit) : a0;
-            PL(PL_T1 + r1) = fabs(dvt1) > 1e-4 ? pa_pnjlim(a1, vd1, vt, vcrit) : a1;
-            PA_SYNC();
+            const double vl0 = fabs(dvt0) > 1e-4 ? pa_pnjlim(a0, vd0, vt, vcrit) : a0;
+            const double vl1 = fabs(dvt1) > 1e-4 ? pa_pnjlim(a1, vd1, vt, vcrit) : a1;
+            // Step scale ga = min over the ports, in port order, of the limiter ratios dv_lim / dv_trial below ga (gen_power_amp.rs:9849-9960).
+            // A port the limiter left alone has v_lim == v_trial: dv_lim is dv_trial bit for bit, the ratio is x / x == 1 and never below ga.
+            // So when no port of the wavefront was limited (every sample but start-up and hard clipping) ga stays 1 without a division;
+            // otherwise each lane forms the ratios of its own two ports and all of them take the running minimum in port order.
             bool any_limited = false;
             double ga = 1.0;
-            for (int i = 0; i < PA_M; ++i) {
-                const double dvt = PL(PL_T0 + i);
-                const double dv_lim = PL(PL_T1 + i) - PL(PL_VD + i);
-                if (fabs(dvt) > 1e-15) {
-                    const double r = dvt * dv_lim < 0.0 ? 0.0 : clampd(ow_div(dv_lim, dvt), 0.0, 1.0);
+            if (__builtin_amdgcn_ballot_w64(!(vl0 == a0) || !(vl1 == a1)) != 0ull) {
+                double ra = 1.0, rb = 1.0;                                                       // 1.0: "takes no part" (1 < ga is never true)
+                {
+                    const double dl0 = vl0 - vd0, dl1 = vl1 - vd1;
+                    if (fabs(dvt0) > 1e-15) ra = dvt0 * dl0 < 0.0 ? 0.0 : clampd(ow_div(dl0, dvt0), 0.0, 1.0);
+                    if (fabs(dvt1) > 1e-15) rb = dvt1 * dl1 < 0.0 ? 0.0 : clampd(ow_div(dl1, dvt1), 0.0, 1.0);
+                }
+                PA_SYNC();                                                                       // everybody has read i_trial from PL_T2
+                PL(PL_T2 + r0) = ra; PL(PL_T2 + r1) = rb;
+                PA_SYNC();
+                for (int i = 0; i < PA_M; ++i) {
+                    const double r = PL(PL_T2 + i);
                     if (r < ga) { ga = r; any_limited = true; }
                 }
             }
+            PA_SYNC();
             double max_dv = fabs(PL(PL_T0) * ga);
             for (int i = 1; i < PA_M; ++i) max_dv = fmax(max_dv, fabs(PL(PL_T0 + i) * ga));
             if (max_dv > 3.5) { ga *= fmax(ow_div(3.5, max_dv), 0.1); any_limited = true; }
@@ -494,7 +518,7 @@ __device__ __forceinline__ double pa_process_sample(PaScal& sc, const OwPaConsts
     for (int i = role; i < PA_M; i += 8) PL(PL_IP + i) = PL(PL_IP + i) + 1e-25 - 1e-25;
     PA_SYNC();
     for (int i = role; i < PA_N; i += 8) {                        // rhs = RHS_CONST + A_neg v_prev (sparse, the reference's term order) + sources
-        double acc = T->rhs_const[i];
+        double acc = i >= 18 ? 22.5 : 0.0;                           // RHS_CONST (gen_power_amp.rs): the two supply rows
         for (int q = T->row_ptr[i]; q < T->row_ptr[i + 1]; ++q) acc = acc + T->nz_coef[q] * PL(PL_V + T->nz_col[q]);
         if (i == 0) acc = acc + input * (1.0 / PA_INPUT_RESISTANCE);
         if (i == 18) acc = acc + off_p;

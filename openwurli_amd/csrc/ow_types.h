@@ -177,6 +177,8 @@ struct OwPaConsts {
         double c_dq2_be, c_dq2_bc;                // is / (nf_vt * ikf), is / (nr_vt * ikr)
         double c_dicc_be, c_dicc_bc;              // is / nf_vt, -is / nr_vt
         double max_step;                          // 4 * vt
+        // correctly rounded reciprocals of the divisors bjt_evaluate divides by on every call (ow_div_const: same quotient bits)
+        double r_nf_vt, r_nr_vt, r_ne_vt, r_nc_vt, r_var, r_vaf, r_ikf, r_ikr;
     } dev[8];
 };
 

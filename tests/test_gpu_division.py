@@ -136,3 +136,58 @@ def test_tanh_fast_accuracy(hiplib):
     nan = np.array([np.nan]); fn = np.zeros(1); ln = np.zeros(1)
     assert hiplib.ow_debug_unary(1, nan.ctypes.data_as(C.c_void_p), 1, fn.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p), 0) == 0
     assert np.isnan(fn[0]) and np.isnan(ln[0])
+
+
+def _forms(hiplib, mode, a, b, y=None):
+    a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+    yy = np.ascontiguousarray(y, dtype=np.float64) if y is not None else None
+    f = np.zeros_like(a); i = np.zeros_like(a)
+    assert hiplib.ow_debug_div_forms(mode, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), yy.ctypes.data_as(C.c_void_p) if yy is not None else None,
+                                     a.size, f.ctypes.data_as(C.c_void_p), i.ctypes.data_as(C.c_void_p), 0) == 0
+    return f, i
+
+
+def _power_amp_divisors():
+    """The per-device constants bjt_evaluate divides by (gen_power_amp.rs:7870-8017): NF VT, NR VT, NE VT, NC VT, VAR, VAF, IKF, IKR of
+    the eight transistors, formed like ow_consts_host.hpp forms them."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "ow_gen_data.h")).read()
+
+    def tab(name):
+        m = re.search(r"double PA_DEV_" + name + r"\[8\] = \{(.*?)\};", src, re.S)
+        return np.array([float(x) if "INF" not in x else np.inf for x in m.group(1).replace(" ", "").split(",") if x])
+    vt = tab("VT")
+    out = [tab("NF") * vt, tab("NR") * vt, tab("NE") * vt, tab("NC") * vt, tab("VAR"), tab("VAF"), tab("IKF"), tab("IKR")]
+    d = np.unique(np.concatenate(out))
+    return d[np.isfinite(d) & (d != 0.0)]
+
+
+def test_short_division_forms_are_the_ieee_quotient(hiplib):
+    """Round 3 added three shorter forms of the same division: a host-computed reciprocal for divisors that are per-device constants
+    (the power amp's device law), one refined reciprocal shared by the quotients over a pivot (the 3x3 / 4x4 / 6x6 / 16x16 eliminations),
+    and that form without v_div_fixup where operands are finite and pivots checked (the melange column solves).  Each must give the
+    compiler's `a / b` bit for bit on the ranges it is used on."""
+    rng = np.random.default_rng(33)
+    n = 1 << 22
+    # (0) every power-amp divisor x junction-voltage / current sized numerators
+    for b0 in _power_amp_divisors():
+        a = np.concatenate([_rand(rng, 1 << 16, -60, 10), rng.uniform(-30.0, 30.0, 1 << 16), np.array([0.0, -0.0])])
+        b = np.full(a.size, b0)
+        fast, ieee = _forms(hiplib, 0, a, b, 1.0 / b)
+        assert _same_bits(fast, ieee), b0
+    # (1) shared refined reciprocal == ow_div for random operands, incl. the special values (the fixup is kept there)
+    a, b = _rand(rng, n, -200, 200), _rand(rng, n, -200, 200)
+    fast, ieee = _forms(hiplib, 1, a, b)
+    assert _same_bits(fast, ieee)
+    # (2) without the fixup: finite operands with moderate exponents (pivots and sums of the preamp's LU: 1e-30 < |b|, |a / b| far from
+    # the ends of the range), zero numerators of either sign included
+    a = _rand(rng, n, -80, 80)
+    b = _rand(rng, a.size, -90, 90)
+    fast, ieee = _forms(hiplib, 2, a, b)
+    assert _same_bits(fast, ieee)
+    # a zero numerator gives a zero quotient whose SIGN the fixup would have set (fma(r, y, q) adds +0 to -0): equal as numbers, and a
+    # signed zero cannot turn into anything else in the substitutions that follow (x - 0 * y, sums, products; no division by it)
+    a0 = np.concatenate([np.zeros(1024), -np.zeros(1024)])
+    fast, ieee = _forms(hiplib, 2, a0, _rand(rng, a0.size, -90, 90))
+    assert np.array_equal(fast, ieee) and np.all(fast == 0.0)
