@@ -149,12 +149,15 @@ struct TremState {   // register-resident part; v / i_prev / i_pp live in TremPa
 
 // NR sweep shared by the trapezoidal solve (sparse v_d as emitted, gen_tremolo.rs:2423-2438) and the
 // BE fallback (dense v_d, :2798-2817).  Returns true when converged within MAX_ITER (=50).
-template <bool BE>
+// SK: kk0 points into the constant block (wave-uniform): the kernel is re-read per sweep through an opaque SCALAR zero, i.e. by two
+// s_load_dwordx16 into SGPRs, instead of 48 LDS reads per sweep through an opaque vector zero.
+template <bool BE, bool SK = false>
 __device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk0)[4], double i_nl[4]) {
     for (int iter = 0; iter < 50; ++iter) {
-        int z = 0;
+        int z = 0, zs = 0;
         asm volatile("" : "+v"(z));   // opaque zero: K is re-read from LDS every sweep instead of held in 32 VGPRs
-        const double (*__restrict__ kk)[4] = kk0 + z;
+        asm volatile("" : "+s"(zs));
+        const double (*__restrict__ kk)[4] = SK ? kk0 + zs : kk0 + z;
         double vd[4];
         vd[0] = p[0] + kk[0][0] * i_nl[0] + kk[0][1] * i_nl[1] + kk[0][2] * i_nl[2] + kk[0][3] * i_nl[3];
         if (BE) {
@@ -170,8 +173,8 @@ __device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk
         const double f[4] = {i_nl[0] - d0.ic, i_nl[1] - d0.ib, i_nl[2] - d1.ic, i_nl[3] - d1.ib};
         double a[4][4];
         int z1 = 0;
-        asm volatile("" : "+v"(z1));
-        const double (*__restrict__ kj)[4] = kk0 + z1;
+        if (!SK) asm volatile("" : "+v"(z1));
+        const double (*__restrict__ kj)[4] = SK ? kk : kk0 + z1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             a[0][j] = (j == 0 ? 1.0 : 0.0) - d0.j0 * kj[0][j] - d0.j1 * kj[1][j];
@@ -188,11 +191,11 @@ __device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk
 #pragma unroll
                 for (int q = 0; q < 4; ++q) i_trial[q] = i_nl[q] - b[q];
                 int z2 = 0;
-                asm volatile("" : "+v"(z2));
-                const double (*__restrict__ kk)[4] = kk0 + z2;
+                if (!SK) asm volatile("" : "+v"(z2));
+                const double (*__restrict__ kt)[4] = SK ? kk : kk0 + z2;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const double v_trial = p[q] + kk[q][0] * i_trial[0] + kk[q][1] * i_trial[1] + kk[q][2] * i_trial[2] + kk[q][3] * i_trial[3];
+                    const double v_trial = p[q] + kt[q][0] * i_trial[0] + kt[q][1] * i_trial[1] + kt[q][2] * i_trial[2] + kt[q][3] * i_trial[3];
                     dv_trial[q] = v_trial - vd[q];
                     v_lim[q] = (fabs(dv_trial[q]) > 1e-4) ? pnjlim(v_trial, vd[q], OW_T_VT, OW_T_VCRIT) : v_trial;
                     lim_any = lim_any || !(v_lim[q] == v_trial);      // (a NaN trial counts as limited: the full path handles it)
@@ -371,7 +374,12 @@ __device__ inline double trem_osc_step(TremState& st, TremPark* __restrict__ P0,
 #pragma unroll
         for (int i = 0; i < 4; ++i) i_nl[i] = 2.0 * ip[i] - P->ipp[i][ln];
     }
-    const bool converged = trem_nr<false>(p, M->k, i_nl);
+    // the 4x4 kernel K is wave-uniform: the lane = group kernels read it per sweep by two scalar loads (SGPRs) instead of 48 LDS reads
+    // (k_tremolo 9.08 -> 8.64 ms per 131 072-oscillator block); OW_TREM_SK=0 restores the LDS path
+#ifndef OW_TREM_SK
+#define OW_TREM_SK 1
+#endif
+    const bool converged = OW_TREM_SK ? trem_nr<false, true>(p, K->t_k, i_nl) : trem_nr<false, false>(p, M->k, i_nl);
     TremPark* P = park_opaque(P0);
     double v[7];
 #pragma unroll

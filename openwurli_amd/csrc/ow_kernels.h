@@ -625,25 +625,28 @@ __global__ void k_trem_copy_rows_from(double* __restrict__ cs, const double* __r
 // ------------------------------------------------------------------ tremolo stream
 // CdS cell resistance for n_os chain-rate samples (no audio input, no depth dependence): runs a block ahead of the audio.
 // lane = tremolo phase group (its leader engine); engines of one group share one R stream (column of the leader).
-__global__ __launch_bounds__(64) void k_tremolo(const OwConsts* __restrict__ K, double* __restrict__ cs, double* __restrict__ rbuf, int I, int n_os,
-                                                const uint32_t* __restrict__ leaders, int n_lead) {
-    __shared__ TremMats M;
-    __shared__ TremPark P;   // oscillator state of this wavefront (LDS-resident, see ow_chain_dev.h)
-    trem_mats_load(&M, K, threadIdx.x, 64);
+__device__ __forceinline__ void tremolo_body(const OwConsts* __restrict__ K, double* __restrict__ cs, double* __restrict__ rbuf, int I, int n_os,
+                                             const uint32_t* __restrict__ leaders, int n_lead, TremMats* M, TremPark* P) {
+    trem_mats_load(M, K, threadIdx.x, 64);
     __syncthreads();
     const int idx = blockIdx.x * 64 + threadIdx.x;
     if (idx >= n_lead) return;
     const int e = (int)leaders[idx];
     TremState t;
-    trem_load(t, &P, cs, I, e);
+    trem_load(t, P, cs, I, e);
     for (int i = 0; i < n_os; ++i) {
         int z = 0;
         asm volatile("" : "+v"(z));    // opaque zero: keeps the LDS reads inside the loop
-        rbuf[(size_t)i * I + e] = trem_cell_r(t, &P, K, &M + z);
+        rbuf[(size_t)i * I + e] = trem_cell_r(t, P, K, M + z);
     }
-    trem_store(t, &P, cs, I, e);
+    trem_store(t, P, cs, I, e);
 }
-
+__global__ __launch_bounds__(64) void k_tremolo(const OwConsts* __restrict__ K, double* __restrict__ cs, double* __restrict__ rbuf, int I, int n_os,
+                                                const uint32_t* __restrict__ leaders, int n_lead) {
+    __shared__ TremMats M;
+    __shared__ TremPark P;   // oscillator state of this wavefront (LDS-resident, see ow_chain_dev.h)
+    tremolo_body(K, cs, rbuf, I, n_os, leaders, n_lead, &M, &P);
+}
 // `--features legacy-tremolo` (tremolo.rs:8, 53-57, 80-90, 170-178): the behavioural sine LFO in place of the Twin-T circuit, same CdS
 // model behind it.  lane = tremolo phase group; the phase lives in row CS_T_V.  n_extra: leader idx steps idx * n_extra more samples
 // (the stagger test hook); rbuf may be null (stepping only).

@@ -42,7 +42,10 @@ OW_DEV void mel_mats_load(MelMats* __restrict__ m, const OwConsts* __restrict__ 
 __device__ inline uint32_t mel_solve_nl(const double p[3], const double kk[3][3], const double ip[3], const double ipp[3], double i_nl[3]) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) i_nl[i] = 2.0 * ip[i] - ipp[i];
-    for (int iter = 0; iter < 265; ++iter) {
+#ifndef OW_MEL_MAXIT
+#define OW_MEL_MAXIT 265
+#endif
+    for (int iter = 0; iter < OW_MEL_MAXIT; ++iter) {
         double vd[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) vd[q] = p[q] + kk[q][0] * i_nl[0] + kk[q][1] * i_nl[1] + kk[q][2] * i_nl[2];
