@@ -494,16 +494,36 @@ def main(argv=None):
             pool.free_host_block(host)
             # (a') the other tremolo regime on the SAME pool.  A whole-pool reset puts every instance on one phase again (one oscillator
             # per pool: the best case, what round 2 reported as `value`); staggering a shared pool prices the per-instance oscillators.
+            # (a0) the same pool with the block-ahead oscillators serialised in front of the voices (OW_TREM_SERIAL=1: a measurement switch
+            # of the library, read per render): slower by a few percent, but every kernel's HIP-event interval is then its own time --
+            # in the default schedule the tremolo kernel runs inside the voice kernel's interval
+            if groups * 4 >= n_inst:
+                os.environ["OW_TREM_SERIAL"] = "1"
+                sser = Script(pool, n_inst)
+                sser.pos = sp.pos
+                for _ in range(2):
+                    sser.step()
+                pool.set_profiling(True)
+                el = timed_steps(sser, 10, profile=True)
+                pool.set_profiling(False)
+                del os.environ["OW_TREM_SERIAL"]
+                kser = sser.kernel_ms / max(sser.kernel_launches, 1)
+                extras["kernels_serialised"] = {
+                    "value": 10 * BUF * n_inst * world / el, "unit": "samples/s", "ms_per_step": 1e3 * el / 10, "steps": 10,
+                    "kernel_ms_per_step": {nm: float(x) for nm, x in zip(("ops", "voices", "tremolo", "preamp", "post"), kser)},
+                    "voices_frac_of_fp64_peak": FLOPS_VOICES * BUF * n_inst / (float(kser[1]) * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if kser[1] > 0 else None,
+                    "tremolo_frac_of_fp64_peak": FLOPS_TREMOLO * groups / n_inst * BUF * n_inst / (float(kser[2]) * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if kser[2] > 0 else None,
+                    "note": "OW_TREM_SERIAL=1: the voices wait for the block-ahead tremolo kernel instead of overlapping it"}
             if groups > 1:
                 pool.reset()
-                r = side_run(pool, n_inst, 3, 10)
+                r = side_run(pool, n_inst, 8, 10)
                 r["tremolo_phase_groups"] = 1
                 r["note"] = ("every instance reset at the same sample: ONE Twin-T oscillator per pool, read by all (bit-exact, tests/test_gpu_tremolo_groups.py); "
                              "independently created plugin instances do not share a phase -- `value` is the per-instance figure")
                 extras["shared_tremolo_phase"] = r
             else:
                 pool.stagger_tremolo(n_inst)
-                r = side_run(pool, n_inst, 3, 10)
+                r = side_run(pool, n_inst, 8, 10)
                 r["tremolo_phase_groups"] = n_inst
                 extras["tremolo_decorrelated"] = r
         pool.close()
@@ -512,14 +532,14 @@ def main(argv=None):
             # (a'') the neighbouring BASELINE configs on the same pool size, short runs: configs[2] (96 kHz host, no oversampling) and the
             # melange 12-node preamp the north star names (literal per-sample rebuild)
             p3 = make_pool(n_inst, sr=96000.0, n_groups=groups)
-            r = side_run(p3, n_inst, 3, 10, epoch=96000)
+            r = side_run(p3, n_inst, 8, 10, epoch=96000)      # 8 warm-up blocks: past the onset ramps and the 15 ms attack noise of the strike
             r["x_realtime_at_96k"] = r["value"] / 96000.0
             r["workload"] = "cfg3: 64-voice all-keys, 96 kHz host (no oversampling), full chain, MLP on, buffers of 512"
             extras["config3"] = r
             p3.close()
             n_mel = min(n_inst, 65536)
             pm = make_pool(n_mel, preamp=1, n_groups=min(groups, n_mel))
-            r = side_run(pm, n_mel, 2, 6)
+            r = side_run(pm, n_mel, 8, 6)
             r["workload"] = "cfg2 with the melange 12-node preamp (k_preamp_mel_col: the reference's rebuild_matrices + invert_n per chain-rate sample, column-streamed)"
             r["preamp_frac_of_fp64_peak"] = FLOPS_PREAMP_MELANGE_LIT * BUF * n_mel / (r["kernel_ms_per_step"]["preamp"] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS
             extras["preamp_melange"] = r
@@ -682,6 +702,11 @@ def main(argv=None):
                 },
                 "cpu_baseline": cpu,
             }
+            ks = extras.get("kernels_serialised")
+            if ks and dom == "voices":
+                # the dominant kernel's interval above contains the concurrently running tremolo kernel; serialised, its own time
+                line["roofline"]["dominant_kernel_own_ms"] = ks["kernel_ms_per_step"]["voices"]
+                line["roofline"]["frac_own_time"] = ks["voices_frac_of_fp64_peak"]
             line.update(extras)
     if rank == 0 and line is not None:
         print(json.dumps(line))
