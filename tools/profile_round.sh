@@ -1,5 +1,5 @@
 # Round profile: one gpurun call.  usage (on the GPU box): bash tools/profile_round.sh r03
-# Everything lands in gpurun_out/<round>/; tools/collect_profiles.sh turns it into the tracked files under profiles/.
+# Everything lands in gpurun_out/<round>/; tools/collect_profiles.py turns it into the tracked files under profiles/.
 # rocprofv3 gets the program itself after `--` (python3 ...), never a shell or env wrapper (the profiler's preloaded library has
 # initialised the GPU before the program starts: any exec hop in between takes the box down).  Counter passes are separate runs with
 # --kernel-trace only.
@@ -18,13 +18,15 @@ export OW_TREM_SERIAL=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_serial -o t -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/trace_serial.log 2>&1
 unset OW_TREM_SERIAL
 
-# ---- 2. counters of the default kernels: 4 096-engine pool, one oscillator per engine (the default), big-pool tremolo kernel forced
+# ---- 2. counters of the default kernels: 4 096-engine pool, one oscillator per engine (the default); the big-pool tremolo and preamp
+# kernels forced (a 4 096-engine pool would pick the quad-per-engine variants on its own)
 export OW_TREM_WIDE=0
+export OW_PREAMP_WIDE=0
 for g in "$G1" "$G2" "FETCH_SIZE" "WRITE_SIZE" "$G5"; do
   n=$(echo $g | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $g --output-format csv -d $O/pmc_$n -o p -- python3 bench.py --steps 8 --warmup 2 --instances 4096 --no-cpu-baseline --no-extras > $O/pmc_$n.log 2>&1
 done
-unset OW_TREM_WIDE
+unset OW_TREM_WIDE OW_PREAMP_WIDE
 
 # ---- 3. the non-default kernels: kernel trace + instruction-mix / cycle / memory-instruction passes each
 prof() {   # prof <tag> <bench args...>
