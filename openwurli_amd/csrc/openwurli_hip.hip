@@ -242,6 +242,9 @@ struct ow_pool {
     double* d_pa = nullptr;           // melange power amp: per-engine state, [PAS_COUNT][I]
     double* d_pa_settled = nullptr;   // settled circuit state (PAS_CIRCUIT_END doubles), power_amp.rs:288-296
     double* d_pa_tap = nullptr;       // test tap: amp output per chain-rate sample, [2 * Lcap][I] (ow_test_pool_enable_power_amp_tap)
+    uint32_t* d_pa_demand = nullptr;  // [I] Newton passes of the engine's last block (k_post_mpa), 0 = not rendered yet
+    uint32_t* d_pa_order = nullptr;   // [I] engines of a launch range by falling demand (k_pa_order_*)
+    uint32_t* d_pa_hist = nullptr;    // [OW_MAX_STAGES][256] class counts / cursors of the ranges
     size_t pa_tap_cap = 0;
     double* d_mel_settled = nullptr;  // melange preamp: settled codegen-rate state (18 doubles)
     size_t mel_lu_ld = 0;             // column-streamed literal kernel: lanes per row of d_mel_lu
@@ -513,6 +516,22 @@ void run_job_chain(const JobChainCfg& cfg, const OwConsts* dK, const std::vector
 // chain (re)initialisation of engines [e0, e0+ne): DC states on the device, then the Twin-T settle
 // (50 warm-up steps at the codegen matrices + 2 s at the pool rate), all in the product kernels.
 // Pools this small leave SIMDs idle, and the oscillator's serial latency is their block time: four lanes per engine (ow_trem_wide.h).
+// Melange power amp: engines dispatched by falling demand (OW_PA_SORT=0: in index order -- the same samples, tested)
+static bool power_amp_ordered() {     // read per block (a test flips it between two pools of one process)
+    const char* env = std::getenv("OW_PA_SORT");
+    return !(env && env[0] == '0');
+}
+static int power_amp_resident_engines(int device) {
+    static int cached[64] = {0};
+    const int d = (device >= 0 && device < 64) ? device : 0;
+    if (!cached[d]) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || cus <= 0) cus = 256;
+        cached[d] = cus * 2 * PA_EPB;
+    }
+    if (const char* env = std::getenv("OW_PA_SORT")) if (env[0] == '2') return PA_EPB;      // '2': order every block of more than one workgroup (tests)
+    return cached[d];
+}
 // OW_TREM_WIDE=0/1 forces the choice (the parity test compares the two kernels bit for bit).
 static inline bool trem_wide(int ne) {
     if (const char* env = std::getenv("OW_TREM_WIDE")) return env[0] == '1';
@@ -989,8 +1008,20 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         if (!chain) {
             // voice sums only
         } else if (sne > 0 && p->power_amp_kind == OW_POWER_AMP_MELANGE) {
+            // more engines than one workgroup: dispatch them by falling demand of their last block (see k_post_mpa)
+            // -- when the block has more engines than the chip holds at once (two workgroups of 32 per CU); below that every wavefront
+            // is resident from the start, the block lasts as long as its slowest engine and the order cannot matter
+            const bool ordered = power_amp_ordered() && ne > power_amp_resident_engines(p->device);
+            if (ordered) {
+                uint32_t* hist = p->d_pa_hist + (size_t)k * PA_ORDER_CLASSES;
+                const uint32_t total = (uint32_t)L * (p->hc.oversample ? 2u : 1u);
+                HIP_OK(hipMemsetAsync(hist, 0, sizeof(uint32_t) * PA_ORDER_CLASSES, s));
+                owdev::k_pa_order_hist<<<dim3((sne + 255) / 256), dim3(256), 0, s>>>(p->d_pa_demand, se0, sne, total, hist);
+                owdev::k_pa_order_scan<<<dim3(1), dim3(PA_ORDER_CLASSES), 0, s>>>(hist);
+                owdev::k_pa_order_scatter<<<dim3((sne + 255) / 256), dim3(256), 0, s>>>(p->d_pa_demand, se0, sne, total, hist, p->d_pa_order);
+            }
             owdev::k_post_mpa<<<dim3((sne + PA_EPB - 1) / PA_EPB), dim3(PA_WPB * 64), 0, s>>>(p->dK, p->dPa, p->d_pa_settled, p->d_cs, p->d_pa, p->d_args, p->d_eout, p->d_pre, p->d_out,
-                                                                          p->d_pa_tap, I, L, L, se0, sne);
+                                                                          p->d_pa_tap, I, L, L, se0, sne, ordered ? p->d_pa_order : nullptr, p->d_pa_demand);
         } else if (sne > 0) {
             if (p->hc.oversample)
                 owdev::k_post<true><<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, L, se0, sne);
@@ -1279,6 +1310,10 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
         HIP_OK(hipMemsetAsync(p->d_pa, 0, sizeof(double) * owdev::PAS_COUNT * n_engines, p->stream));
         HIP_OK(hipMalloc(&p->d_pa_settled, sizeof(double) * owdev::PAS_CIRCUIT_END));
         pa_settled_to_device(device, p->d_pa_settled, p->stream);
+        HIP_OK(hipMalloc(&p->d_pa_demand, sizeof(uint32_t) * n_engines));
+        HIP_OK(hipMemsetAsync(p->d_pa_demand, 0, sizeof(uint32_t) * n_engines, p->stream));
+        HIP_OK(hipMalloc(&p->d_pa_order, sizeof(uint32_t) * n_engines));
+        HIP_OK(hipMalloc(&p->d_pa_hist, sizeof(uint32_t) * PA_ORDER_CLASSES * OW_MAX_STAGES));
     }
     upload_consts(p, sample_rate, preamp_kind);
     owdev::k_note_table<<<dim3(1), dim3(64), 0, p->stream>>>(p->d_nt);
@@ -1345,6 +1380,9 @@ void pool_destroy(ow_pool* p) {
     if (p->d_pa) hipFree(p->d_pa);
     if (p->d_pa_settled) hipFree(p->d_pa_settled);
     if (p->d_pa_tap) hipFree(p->d_pa_tap);
+    if (p->d_pa_demand) hipFree(p->d_pa_demand);
+    if (p->d_pa_order) hipFree(p->d_pa_order);
+    if (p->d_pa_hist) hipFree(p->d_pa_hist);
     hipFree(p->d_args); hipFree(p->d_eout);
     if (p->d_ops) hipFree(p->d_ops);
     if (p->h_ops) hipHostFree(p->h_ops);

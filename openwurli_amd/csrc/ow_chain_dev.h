@@ -21,7 +21,7 @@ OW_DEV double fast_exp(double x0) {  // gen_tremolo.rs:1140-1166 (pure arithmeti
     const double SHIFT = 6755399441055744.0;
     const double z = x * 1.4426950408889634 + SHIFT;
     const long long n_i64 = __double_as_longlong(z) - __double_as_longlong(SHIFT);
-    const double n = (double)n_i64;
+    const double n = z - SHIFT;       // == (double)n_i64 exactly (z is SHIFT plus an integer of at most 58): one add instead of a 64-bit int -> f64 conversion
     const double f = (x - n * 0.6931471803691238) - n * 1.9082149292705877e-10;
     const double p = 1.0 + f * (1.0 + f * (0.5 + f * (0.16666666666666607 + f * (0.04166666666665876 + f * 0.008333333333492337))));
     const double pow2n = __longlong_as_double((long long)(((unsigned long long)(1023 + n_i64)) << 52));

@@ -229,13 +229,15 @@ struct PaScal {      // per-engine scalars, identical in the eight lanes of the 
     uint32_t last_nr;
 };
 
-// One Newton solve (main sweep with K, or the BE retry with K_be): gen_power_amp.rs:8956-10680 / 10745-12245.  p in PL_P, i_nl in PL_INL.
-// KM: the 16x16 K of this sweep (the LDS copy for the main sweep).
+// ONE pass of the Newton solve (main sweep with K, or the BE retry with K_be): gen_power_amp.rs:8956-10680 / 10745-12245, the body of
+// the `for iter in 0..MAX_ITER` loop.  p in PL_P, i_nl in PL_INL (updated).  KM: the 16x16 K of this sweep (the LDS copy for the main
+// sweep).  Returns true when the reference's loop would `break` converged after this pass.  Nothing is carried from one pass to the
+// next outside LDS, so the engines of a wavefront need not be in the same pass, nor in the same sample (k_post_mpa below).
 template <bool BE>
-__device__ __forceinline__ uint32_t pa_newton_body(double* __restrict__ W, const double* KM, const OwPaConsts::Dev* D, int role) {
+__device__ __forceinline__ bool pa_newton_pass(double* __restrict__ W, const double* KM, const OwPaConsts::Dev* D, int role) {
     const int r0 = 2 * role, r1 = 2 * role + 1;
     const double vt = D->vt, vcrit = D->vcrit;
-    for (int iter = 0; iter < 70; ++iter) {
+    {
         double vd0 = PL(PL_P + r0), vd1 = PL(PL_P + r1);
 #pragma unroll
         for (int j = 0; j < PA_M; ++j) {
@@ -269,9 +271,7 @@ __device__ __forceinline__ uint32_t pa_newton_body(double* __restrict__ W, const
         // reciprocal (ow_div_y == ow_div instruction for instruction).
 #define PA_ELIM_TIER(C0, C1, WIDTH)                                                                                          \
         _Pragma("unroll 1") for (int col = (C0); col < (C1) && !singular; ++col) {                                              \
-            PL(PL_CAND + posA) = fabs(A[0]);        /* rows already used as pivots sit at positions < col: never looked at again */ \
-            PL(PL_CAND + posB) = fabs(B[0]);                                                                                    \
-            PA_SYNC();                                                                                                          \
+            /* the candidates |J[row][col]| were posted at the end of the previous column (before its closing fence) */       \
             /* the reference's scan: first strict maximum over logical rows col..15; all candidates are fetched at once */     \
             int max_row = col;                                                                                                  \
             double max_val = PL(PL_CAND + col);                                                                                 \
@@ -313,8 +313,14 @@ __device__ __forceinline__ uint32_t pa_newton_body(double* __restrict__ W, const
                 _Pragma("unroll") for (int j = 1; j <= (WIDTH); ++j) B[j - 1] = B[j] - factor * prow[j];                          \
                 bB -= factor * bcol;                                                                                            \
             }                                                                                                                   \
+            /* candidates of the next column, by logical position (rows used as pivots sit at positions <= col: never looked at again) */ \
+            PL(PL_CAND + posA) = fabs(A[0]);                                                                                    \
+            PL(PL_CAND + posB) = fabs(B[0]);                                                                                    \
             PA_SYNC();                                                                                                          \
         }
+        PL(PL_CAND + posA) = fabs(A[0]);
+        PL(PL_CAND + posB) = fabs(B[0]);
+        PA_SYNC();
         PA_ELIM_TIER(0, 4, 15)
         PA_ELIM_TIER(4, 8, 11)
         PA_ELIM_TIER(8, 12, 7)
@@ -327,7 +333,7 @@ __device__ __forceinline__ uint32_t pa_newton_body(double* __restrict__ W, const
             PL(PL_INL + r0) = i0 - clampd(f0 * 0.5, -c0, c0);
             PL(PL_INL + r1) = i1 - clampd(f1 * 0.5, -c1, c1);
             PA_SYNC();
-            continue;
+            return false;
         }
         // back substitution: x_i = (b_i - sum_{j>i} U_ij x_j) / U_ii, j ascending, by the owner of logical row i (its frozen register
         // row holds U_ij at index j - i); U_ii is the pivot of column i, so it passed the 1e-15 test above (the reference's second
@@ -445,8 +451,14 @@ __device__ __forceinline__ uint32_t pa_newton_body(double* __restrict__ W, const
             PL(PL_INL + r0) = n0; PL(PL_INL + r1) = n1;
         }
         PA_SYNC();
-        if (converged) return (uint32_t)iter;
+        return converged;
     }
+}
+// The whole sweep in lock step (the BE retry, the settle and debug kernels): iterations spent, 70 = exhausted
+template <bool BE>
+__device__ __forceinline__ uint32_t pa_newton_body(double* __restrict__ W, const double* KM, const OwPaConsts::Dev* D, int role) {
+    _Pragma("unroll 1") for (int iter = 0; iter < 70; ++iter)
+        if (pa_newton_pass<BE>(W, KM, D, role)) return (uint32_t)iter;
     return 70u;
 }
 // The rare paths.  Inlined naively, their table loads are loop-invariant, get hoisted out of the sample loop and sit in hundreds of
@@ -511,8 +523,11 @@ __device__ __noinline__ PaSettledScal pa_state_from_settled(double* __restrict__
 
 // gen_power_amp.rs:8838-12337.  off_p / off_n: the runtime rail offsets (v_rail_pos_offset / v_rail_neg_offset of the state).
 // T: the LDS tables.  Rows of the matrix-vector products and of the state vectors are dealt to the lanes as i = role, role + 8, ...
-__device__ __forceinline__ double pa_process_sample(PaScal& sc, const OwPaConsts* __restrict__ C, double* __restrict__ W, const PaTab* T, int role,
-                                                    double input_in, double off_p, double off_n) {
+// The sample in three pieces, so that a kernel may run the passes of the main sweep one at a time (k_post_mpa):
+//   pa_sample_begin   :8838-8955  right-hand side, prediction, p, the extrapolated i_nl -- returns the sanitised input
+//   pa_newton_pass    the main sweep's passes, until one converges or 70 are spent (nr = passes before the converged one, or 70)
+//   pa_sample_end     :10681-12337 v_new, BE retry, NaN reset, state update, DC blocker, clamp
+__device__ __forceinline__ double pa_sample_begin(double* __restrict__ W, const PaTab* T, int role, double input_in, double off_p, double off_n) {
     const double input = isfinite(input_in) ? clampd(input_in, -100.0, 100.0) : 0.0;
     for (int i = role; i < PA_N; i += 8) PL(PL_V + i) = PL(PL_V + i) + 1e-25 - 1e-25;
     for (int i = role; i < PA_M; i += 8) PL(PL_IP + i) = PL(PL_IP + i) + 1e-25 - 1e-25;
@@ -538,7 +553,11 @@ __device__ __forceinline__ double pa_process_sample(PaScal& sc, const OwPaConsts
         PL(PL_INL + i) = 2.0 * PL(PL_IP + i) - PL(PL_IPP + i);
     }
     PA_SYNC();
-    sc.last_nr = pa_newton_body<false>(W, T->k, &T->dev[role], role);
+    return input;
+}
+__device__ __forceinline__ double pa_sample_end(PaScal& sc, const OwPaConsts* __restrict__ C, double* __restrict__ W, const PaTab* T, int role, double input,
+                                                uint32_t nr) {
+    sc.last_nr = nr;
     for (int i = role; i < PA_N; i += 8) {
         double x = PL(PL_VPRED + i);
         for (int j = 0; j < PA_M; ++j) x += T->s_ni[i * PA_M + j] * PL(PL_INL + j);
@@ -571,6 +590,13 @@ __device__ __forceinline__ double pa_process_sample(PaScal& sc, const OwPaConsts
     if (abs_out > 3e1) sc.clamp_cnt += 1ull;
     return clampd(scaled, -3e1, 3e1);
 }
+// the sample in lock step (settle and debug kernels)
+__device__ __forceinline__ double pa_process_sample(PaScal& sc, const OwPaConsts* __restrict__ C, double* __restrict__ W, const PaTab* T, int role,
+                                                    double input_in, double off_p, double off_n) {
+    const double input = pa_sample_begin(W, T, role, input_in, off_p, off_n);
+    const uint32_t nr = pa_newton_body<false>(W, T->k, &T->dev[role], role);
+    return pa_sample_end(sc, C, W, T, role, input, nr);
+}
 
 // state <- settled blob (+ the per-state part of set_sample_rate when the chain does not run at the codegen rate): init_state,
 // power_amp.rs:294-302
@@ -583,10 +609,9 @@ __device__ __forceinline__ void pa_init_state(PaScal& sc, double* __restrict__ W
 __device__ __forceinline__ void pa_rails_reset(PaScal& sc) { sc.rail_p = 22.5; sc.rail_n = 22.5; sc.iavg_p = 0.0; sc.iavg_n = 0.0; }
 
 // melange_adapter::PowerAmp::process, power_amp.rs:373-431
-__device__ __forceinline__ double pa_process(PaScal& sc, const OwPaConsts* __restrict__ C, double* __restrict__ W, const PaTab* T, int role,
-                                             const double* __restrict__ settled, double input, bool rail_sag) {
-    const double off_p = rail_sag ? sc.rail_p - 22.5 : 0.0, off_n = rail_sag ? sc.rail_n - 22.5 : 0.0;
-    const double raw = pa_process_sample(sc, C, W, T, role, input, off_p, off_n);
+// (pa_process_end: everything after process_sample returns `raw`)
+__device__ __forceinline__ double pa_process_end(PaScal& sc, const OwPaConsts* __restrict__ C, double* __restrict__ W, int role,
+                                                 const double* __restrict__ settled, double raw, bool rail_sag) {
     const double result = OW_DIV_C(raw, 22.0);
     const bool nr_failed = sc.last_nr >= 69u;
     bool insane = false;
@@ -612,6 +637,12 @@ __device__ __forceinline__ double pa_process(PaScal& sc, const OwPaConsts* __res
         sc.rail_n += alpha_n * (target_neg - sc.rail_n);
     }
     return clamped;
+}
+__device__ __forceinline__ double pa_process(PaScal& sc, const OwPaConsts* __restrict__ C, double* __restrict__ W, const PaTab* T, int role,
+                                             const double* __restrict__ settled, double input, bool rail_sag) {
+    const double off_p = rail_sag ? sc.rail_p - 22.5 : 0.0, off_n = rail_sag ? sc.rail_n - 22.5 : 0.0;
+    const double raw = pa_process_sample(sc, C, W, T, role, input, off_p, off_n);
+    return pa_process_end(sc, C, W, role, settled, raw, rail_sag);
 }
 
 // engine e's state rows <-> LDS (rows dealt to the eight lanes; the scalars are read by all, stored by role 0)
@@ -686,15 +717,36 @@ __global__ __launch_bounds__(PA_WPB * 64, 2) void k_mpa_debug(const OwPaConsts* 
     pa_init_state(sc, W, role, settled, C);
     pa_rails_reset(sc);
     sc.last_good = 0.0; sc.guard_cnt = 0ull;
-    for (long long i = 0; i < n; ++i) {
-        if (poke_at && poke_at[row] == i) { PA_SYNC(); PL(PL_V + poke_node[row]) = poke_val[row]; }
-        PA_SYNC();
-        const double y = pa_process(sc, C, W, T, role, settled, in[row * ld + i], rail_sag != 0);
-        if (valid && role == 0) {
-            out[row * ld + i] = y;
-            if (taps) {
-                double* t = taps + (row * n + i) * 3;
-                t[0] = (double)sc.last_nr; t[1] = (double)sc.guard_cnt; t[2] = sc.rail_p;
+    // one Newton pass per trip for every row that still has samples, each row on its own sample counter (see k_post_mpa)
+    long long i = 0;
+    uint32_t iter = 0u;
+    bool begun = false;
+    double input = 0.0;
+    while (__builtin_amdgcn_ballot_w64(i < n) != 0ull) {
+        if (i < n) {
+            if (!begun) {
+                if (poke_at && poke_at[row] == i) { PA_SYNC(); PL(PL_V + poke_node[row]) = poke_val[row]; }
+                PA_SYNC();
+                const double off_p = rail_sag ? sc.rail_p - 22.5 : 0.0, off_n = rail_sag ? sc.rail_n - 22.5 : 0.0;
+                input = pa_sample_begin(W, T, role, in[row * ld + i], off_p, off_n);
+                begun = true;
+                iter = 0u;
+            }
+            const bool conv = pa_newton_pass<false>(W, T->k, &T->dev[role], role);
+            if (conv || iter == 69u) {
+                const double raw = pa_sample_end(sc, C, W, T, role, input, conv ? iter : 70u);
+                const double y = pa_process_end(sc, C, W, role, settled, raw, rail_sag != 0);
+                if (valid && role == 0) {
+                    out[row * ld + i] = y;
+                    if (taps) {
+                        double* t = taps + (row * n + i) * 3;
+                        t[0] = (double)sc.last_nr; t[1] = (double)sc.guard_cnt; t[2] = sc.rail_p;
+                    }
+                }
+                ++i;
+                begun = false;
+            } else {
+                ++iter;
             }
         }
     }
@@ -712,6 +764,34 @@ __global__ void k_mpa_init(const OwPaConsts* __restrict__ C, const double* __res
     if (fresh) { pa[(size_t)PAS_LASTGOOD * I + e] = 0.0; pa[(size_t)PAS_GUARD * I + e] = bitsd(0ull); }
 }
 
+// Engines [e0, e0 + ne) by falling demand (Newton passes of their last block, `demand`, in units of 1/16 pass per chain-rate sample over
+// the minimum of one; 256 classes): counting sort in three launches.  The order INSIDE a class is whatever the atomics make it -- it
+// decides which engines share a wavefront, not what any engine computes.
+#define PA_ORDER_CLASSES 256
+__device__ __forceinline__ int pa_demand_class(uint32_t d, uint32_t total) {
+    if (d <= total) return 0;
+    const unsigned long long q = (unsigned long long)(d - total) * 16ull / (total ? total : 1u);
+    return q > (unsigned long long)(PA_ORDER_CLASSES - 1) ? PA_ORDER_CLASSES - 1 : (int)q;
+}
+__global__ void k_pa_order_hist(const uint32_t* __restrict__ demand, int e0, int ne, uint32_t total, uint32_t* __restrict__ hist) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ne) atomicAdd(&hist[pa_demand_class(demand[e0 + t], total)], 1u);
+}
+__global__ __launch_bounds__(PA_ORDER_CLASSES) void k_pa_order_scan(uint32_t* __restrict__ hist) {   // hist -> first position of the class (heaviest class first)
+    __shared__ uint32_t h[PA_ORDER_CLASSES];
+    h[threadIdx.x] = hist[threadIdx.x];
+    __syncthreads();
+    uint32_t base = 0;
+    for (int b = PA_ORDER_CLASSES - 1; b > (int)threadIdx.x; --b) base += h[b];
+    hist[threadIdx.x] = base;
+}
+__global__ void k_pa_order_scatter(const uint32_t* __restrict__ demand, int e0, int ne, uint32_t total, uint32_t* __restrict__ cursor, uint32_t* __restrict__ order) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ne) return;
+    const uint32_t pos = atomicAdd(&cursor[pa_demand_class(demand[e0 + t], total)], 1u);
+    order[e0 + pos] = (uint32_t)(e0 + t);
+}
+
 // Output stage with the melange power amp: eight lanes per engine, 32 engines per workgroup (the amp is a stateful recurrence at the
 // chain rate, so the two chain-rate samples of an output sample are solved one after the other), then half-band down, speaker, gain,
 // f32 as k_post.  That cheap tail runs on the role-0 lane of the engine with its state (filters, smoothers) in LDS between samples:
@@ -720,7 +800,8 @@ struct PaTail { SpeakerSt sp; Smoother ss, sv; double da[3], db[3], dd; };
 __global__ __launch_bounds__(PA_WPB * 64, 2) void k_post_mpa(const OwConsts* __restrict__ K, const OwPaConsts* __restrict__ C, const double* __restrict__ settled,
                                                           double* __restrict__ cs, double* __restrict__ pa, const OwEngineArgs* __restrict__ args,
                                                           OwEngineOut* __restrict__ eout, const double* __restrict__ pre, float* __restrict__ out,
-                                                          double* __restrict__ pa_tap, int I, int L, int Lout, int e0, int ne) {
+                                                          double* __restrict__ pa_tap, int I, int L, int Lout, int e0, int ne,
+                                                          const uint32_t* __restrict__ order, uint32_t* __restrict__ demand) {
     __shared__ double WS[PA_LDS_DOUBLES];                        // 61 KB
     __shared__ PaTab TS;
     __shared__ PaTail TL[PA_EPB];
@@ -729,10 +810,13 @@ __global__ __launch_bounds__(PA_WPB * 64, 2) void k_post_mpa(const OwConsts* __r
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int role = lane >> 3, slot = wv * PA_EPW + (lane & 7);
     double* W = WS + wv * (PL_ROWS * PA_LS) + (lane & 7);
-    const int eb = e0 + blockIdx.x * PA_EPB;
-    const int e_raw = eb + slot;
-    const bool valid = e_raw < e0 + ne;
-    const int e = valid ? e_raw : (e0 + ne - 1);
+    // position g of the range -> engine: in index order, or through `order` (the range's engines sorted by the Newton passes their
+    // last block took, heaviest first -- k_pa_order_*): a wavefront lasts as long as its slowest engine, a workgroup as its slowest
+    // wavefront, so engines of like demand share them and the long ones are dispatched first
+    const int g_raw = blockIdx.x * PA_EPB + slot;
+    const bool valid = g_raw < ne;
+    const int g = valid ? g_raw : ne - 1;
+    const int e = order ? (int)order[e0 + g] : e0 + g;
     const int osr = K->oversample ? 2 : 1;
     const bool rail_sag = (args[e].pa_flags & 1u) != 0u;
     PaTail& t = TL[slot];
@@ -750,37 +834,67 @@ __global__ __launch_bounds__(PA_WPB * 64, 2) void k_post_mpa(const OwConsts* __r
     PaScal sc;
     pa_load(sc, W, role, pa, I, e);
     bool bad_any = false;                                                 // output NaN guard fired in this block (role-0 lane)
-    for (int n = 0; n < L; ++n) {
-        double y[2] = {0.0, 0.0};
-        for (int j = 0; j < osr; ++j) {
-            const size_t idx = (size_t)n * osr + j;
-            y[j] = pa_process(sc, C, W, T, role, settled, pre[idx * I + e] * 0.25, rail_sag);       // x FIXED_CIRCUIT_DRIVE, engine.rs:544-546
-            if (pa_tap && valid && role == 0) pa_tap[idx * I + e] = y[j];
-        }
-        if (role == 0) {
-            double o;
-            if (osr == 2) {
-                const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, t.da, y[0]);
-                const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, t.db, y[1]);
-                o = (a + t.dd) * 0.5;
-                t.dd = b;
+    // The engines of the wavefront are NOT kept on the same sample.  Newton pass counts are spiky (a sample in fifty takes 40-70 passes
+    // where its neighbours take two or three; eight engines with different material: mean 2.8 passes per sample and engine, mean of
+    // the slowest of eight 7), and a wavefront that solved sample n for all its engines before going to n + 1 would pay the slowest one
+    // every time.  Instead every trip of the loop below is ONE pass for every engine that still has samples, preceded by the sample's
+    // set-up for the engines that begin one and followed by its completion for those whose pass converged: each engine (its eight
+    // lanes: they share c / iter / begun) walks its own sample counter, and the wavefront takes max over engines of the SUM of
+    // passes, not the sum of the maxima.  Nothing but the schedule changes: an engine's operations and their order are those of
+    // pa_process in a loop over its samples.
+    const int total = L * osr;
+    int c = 0;                                                            // chain-rate sample this engine is in
+    uint32_t iter = 0u;                                                   // passes of the main sweep already spent on it
+    uint32_t trips = 0u;                                                  // passes of this block (the engine's demand figure)
+    bool begun = false;
+    double input = 0.0, y0 = 0.0;
+    while (__builtin_amdgcn_ballot_w64(c < total) != 0ull) {
+        if (c < total) {
+            ++trips;
+            if (!begun) {
+                const double off_p = rail_sag ? sc.rail_p - 22.5 : 0.0, off_n = rail_sag ? sc.rail_n - 22.5 : 0.0;
+                input = pa_sample_begin(W, T, role, pre[(size_t)c * I + e] * 0.25, off_p, off_n);   // x FIXED_CIRCUIT_DRIVE, engine.rs:544-546
+                begun = true;
+                iter = 0u;
+            }
+            const bool conv = pa_newton_pass<false>(W, T->k, &T->dev[role], role);
+            if (conv || iter == 69u) {
+                const double raw = pa_sample_end(sc, C, W, T, role, input, conv ? iter : 70u);
+                const double y = pa_process_end(sc, C, W, role, settled, raw, rail_sag);
+                if (pa_tap && valid && role == 0) pa_tap[(size_t)c * I + e] = y;
+                const bool second = osr == 2 && (c & 1);
+                if (role == 0 && (osr == 1 || second)) {
+                    const int n = osr == 2 ? (c >> 1) : c;
+                    double o;
+                    if (osr == 2) {
+                        const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, t.da, y0);
+                        const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, t.db, y);
+                        o = (a + t.dd) * 0.5;
+                        t.dd = b;
+                    } else {
+                        o = y;
+                    }
+                    speaker_set_character(t.sp, t.ss.next(), K->sr);
+                    const double shaped = speaker_process(t.sp, o, K->spk_thermal_alpha);
+                    const double post = shaped * 7.498942093324558 * t.sv.next();
+                    float f = (float)post;
+                    const bool bad = !isfinite(f);
+                    if (bad) {                                                          // engine.rs:450-458
+                        f = 0.0f;
+                        t.sp.hpf.s1 = t.sp.hpf.s2 = t.sp.lpf.s1 = t.sp.lpf.s2 = 0.0;
+                        t.sp.ts = 0.0;
+                    }
+                    // 4 bytes per engine per output sample, straight to its row: 33 MB per block at 16 384 engines against >= 100 ms of
+                    // solver time -- not worth 8 KB of LDS for a transposing tile
+                    if (valid) out[(size_t)e * Lout + n] = f;
+                    bad_any = bad_any || bad;
+                }
+                y0 = y;
+                ++c;
+                begun = false;
             } else {
-                o = y[0];
+                ++iter;
             }
-            speaker_set_character(t.sp, t.ss.next(), K->sr);
-            const double shaped = speaker_process(t.sp, o, K->spk_thermal_alpha);
-            const double post = shaped * 7.498942093324558 * t.sv.next();
-            float f = (float)post;
-            const bool bad = !isfinite(f);
-            if (bad) {                                                          // engine.rs:450-458
-                f = 0.0f;
-                t.sp.hpf.s1 = t.sp.hpf.s2 = t.sp.lpf.s1 = t.sp.lpf.s2 = 0.0;
-                t.sp.ts = 0.0;
-            }
-            // 4 bytes per engine per output sample, straight to its row: 33 MB per block at 16 384 engines against >= 100 ms of
-            // solver time -- not worth 8 KB of LDS for a transposing tile
-            if (valid) out[(size_t)e * Lout + n] = f;
-            bad_any = bad_any || bad;
         }
     }
     // engine.rs:450-458 resets preamp, oversampler and POWER AMP at the faulty output sample -- but render_voices_to_preamp_out has
@@ -793,6 +907,7 @@ __global__ __launch_bounds__(PA_WPB * 64, 2) void k_post_mpa(const OwConsts* __r
     }
     if (valid) pa_store(sc, W, role, pa, I, e);
     if (!valid || role != 0) return;
+    if (demand) demand[e] = trips;
     if (nan_fired) {
         for (int i = 0; i < 3; ++i) { t.da[i] = 0.0; t.db[i] = 0.0; }
         t.dd = 0.0;

@@ -86,6 +86,11 @@ void owo_mpa_run(double sr, const double* in, size_t n, int rail_sag, long long 
         if (taps) { taps[3 * i] = (double)a.state.last_nr_iterations; taps[3 * i + 1] = (double)a.guard_resets; taps[3 * i + 2] = a.rails.v_rail_pos; }
     }
 }
+void owo_mpa_stats(unsigned long long* out21, int reset) {
+    PaStats& st = pa_stats();
+    if (out21) for (int i = 0; i < 21; ++i) out21[i] = st.v[i];
+    if (reset) st = PaStats{};
+}
 void owo_mpa_rails(void* p, double* pos, double* neg) {
     const MelangePowerAmp* a = (const MelangePowerAmp*)p;
     *pos = a->rail_sag_on ? a->rails.v_rail_pos : 22.5; *neg = a->rail_sag_on ? a->rails.v_rail_neg : 22.5;

@@ -108,6 +108,11 @@ inline PaBjt pa_bjt_evaluate(double vbe, double vbc, int d) {
 inline double pa_clamp(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }   // f64::clamp (NaN propagates)
 
 // gen_power_amp.rs:8032-8145.  inner_iters (diagnostic tap of the oracle): inner Newton iterations spent.
+// Statistics of the Newton passes since the last owo_mpa_stats(reset) -- numbers the GPU mapping was designed from:
+// [0] passes, [1] passes with at least one row exchange, [2] row exchanges, [3] sum over passes of the deepest inner loop of the pass,
+// [4] sum over passes and devices of the inner-loop trips, [5..20] row exchanges by column
+struct PaStats { unsigned long long v[21]; };
+inline PaStats& pa_stats() { static thread_local PaStats s = {}; return s; }
 inline PaBjt pa_bjt_with_parasitics(double vbe_ext, double vbc_ext, int d, int* inner_iters = nullptr) {
     const double rb = PA_DEV_RB[d], rc = PA_DEV_RC[d], re = PA_DEV_RE[d], vt = PA_DEV_VT[d];
     double vbe_int = vbe_ext, vbc_int = vbc_ext;
@@ -285,10 +290,13 @@ struct PaCircuit {
                 vd[i] = acc;
             }
             double idev[AM], jdev[AM][2];   // jdev[i] = row i of its device's 2x2 block (columns 2d, 2d+1)
+            int inner_max = 0, swaps = 0;
             for (int d = 0; d < 8; ++d) {
                 int inner = 0;
                 const PaBjt e = pa_bjt_with_parasitics(vd[2 * d], vd[2 * d + 1], d, &inner);
                 tap_inner_iters += (uint32_t)inner;
+                inner_max = inner > inner_max ? inner : inner_max;
+                pa_stats().v[4] += (unsigned long long)inner;
                 idev[2 * d] = e.ic; idev[2 * d + 1] = e.ib;
                 jdev[2 * d][0] = e.jac[0]; jdev[2 * d][1] = e.jac[1]; jdev[2 * d + 1][0] = e.jac[2]; jdev[2 * d + 1][1] = e.jac[3];
             }
@@ -309,6 +317,7 @@ struct PaCircuit {
                 if (max_row != col) {
                     for (int j = 0; j < AM; ++j) std::swap(a[col][j], a[max_row][j]);
                     std::swap(b[col], b[max_row]);
+                    ++swaps; pa_stats().v[5 + col] += 1;
                 }
                 const double pivot = a[col][col];
                 for (int row = col + 1; row < AM; ++row) {
@@ -317,6 +326,7 @@ struct PaCircuit {
                     b[row] -= factor * b[col];
                 }
             }
+            { PaStats& st = pa_stats(); st.v[0] += 1; st.v[1] += swaps ? 1 : 0; st.v[2] += (unsigned long long)swaps; st.v[3] += (unsigned long long)inner_max; }
             if (!singular) {
                 for (int i = AM - 1; i >= 0; --i) {
                     double sum = b[i];

@@ -225,3 +225,39 @@ def test_amp_alone_on_a_dense_performance_shares_every_guard_event(hiplib, oracl
     assert sum(guards) >= 4, guards                                                    # the script does exercise the guard
     assert taps[:, -1, 1].astype(int).tolist() == guards
     assert np.max(np.abs(out - want)) < 1e-11
+
+
+def test_demand_ordered_dispatch_changes_no_sample(hiplib, oracle, monkeypatch):
+    """k_post_mpa lets every engine of a wavefront walk its own sample counter (one Newton pass per trip) and, for blocks larger than
+    the chip holds at once, dispatches the engines by falling demand of their last block (k_pa_order_*).  Both only change the
+    schedule: a 300-engine pool with ten loudness classes rendered with the order forced on (OW_PA_SORT=2) and off (=0) is bit-identical,
+    engine by engine, and the picked engines match the oracle."""
+    import openwurli_amd as ow
+    sr, n = 48000.0, 300
+    picks = (0, 7, 8, 131, 299)
+
+    def script(e, k):
+        e.set_volume(0.5); e.set_tremolo_depth((k % 4) / 3.0)
+        for nn in (36 + k % 24, 48 + k % 17, 60 + k % 13, 72 + k % 11):
+            e.note_on(nn, np.float32(0.25 + 0.75 * ((k * 7) % 10) / 9.0))
+
+    def run(mode):
+        monkeypatch.setenv("OW_PA_SORT", mode)
+        g = ow.EnginePool(sr, n, power_amp_kind=PA)
+        for k in range(n):
+            script(g[k], k)
+        out = np.concatenate([g.render(256) for _ in range(5)], axis=1)
+        d = [g[k].power_amp_diag() for k in picks]
+        g.close()
+        return out, d
+    a, da = run("2")
+    b, db = run("0")
+    assert np.array_equal(a, b)
+    assert [(x.guard_resets, x.nr_max_iter_count) for x in da] == [(x.guard_resets, x.nr_max_iter_count) for x in db]
+    assert len({a[k].tobytes() for k in range(40)}) > 20                # the engines do differ
+    for k in picks:
+        c = oracle.OracleEngine(sr, power_amp_kind=PA)
+        script(c, k)
+        co = np.concatenate([c.render(256) for _ in range(5)])
+        rep = oracle.parity_report(a[k], co, abs_floor=oracle.ABS_FLOOR_OUTPUT)
+        assert rep["n_bad"] == 0, (k, rep)

@@ -41,7 +41,7 @@ prof melange --preamp melange --instances 65536 --steps 10 --warmup 2
 pmc melange insts "$G1" --preamp melange --instances 4096 --steps 6 --warmup 2
 pmc melange cycles "$G2" --preamp melange --instances 4096 --steps 6 --warmup 2
 pmc melange mem "$G5" --preamp melange --instances 4096 --steps 6 --warmup 2
-prof mpa --power-amp melange --instances 16384 --steps 3 --warmup 1 --tremolo-groups 1
+prof mpa --power-amp melange --instances 65536 --steps 2 --warmup 2 --tremolo-groups 1
 pmc mpa insts "$G1" --power-amp melange --instances 2048 --steps 3 --warmup 1 --tremolo-groups 1
 pmc mpa cycles "$G2" --power-amp melange --instances 2048 --steps 3 --warmup 1 --tremolo-groups 1
 pmc mpa mem "$G5" --power-amp melange --instances 2048 --steps 3 --warmup 1 --tremolo-groups 1
@@ -63,7 +63,8 @@ python bench.py --host-rate 96000 --steps 40 --warmup 5 --no-extras --no-cpu-bas
 python bench.py --preamp melange --instances 65536 --steps 20 --warmup 3 --no-extras > $O/bench_melange.log 2>&1
 OW_MEL_LDS=1 python bench.py --preamp melange --instances 65536 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_melange_lds_matrix.log 2>&1
 OW_MEL_RANK1=1 python bench.py --preamp melange --instances 65536 --steps 20 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_melange_rank1.log 2>&1
-python bench.py --power-amp melange --instances 16384 --steps 3 --warmup 1 --no-extras --no-cpu-baseline > $O/bench_power_amp_melange.log 2>&1
+python bench.py --power-amp melange --instances 65536 --steps 4 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_power_amp_melange.log 2>&1
+python bench.py --power-amp melange --instances 16384 --steps 4 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_power_amp_melange_16384.log 2>&1
 python bench.py --workload batch > $O/bench_batch.log 2>&1
 OW_TREM_SERIAL=1 python bench.py --steps 40 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_trem_serial.log 2>&1
 tail -1 $O/bench_default.log | cut -c1-700
