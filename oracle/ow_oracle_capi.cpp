@@ -8,6 +8,11 @@
 // The restatement is pinned against every known-answer value the reference's own tests
 // hold for this path (tests/test_oracle_kat.py) and against the
 // reference's only golden numeric fixture (tests/golden/alias_audit_v0_5_1.json).
+// Since round 3 the three generated solvers (Twin-T tremolo, 12-node preamp, 7-BJT power amp) are also pinned to the
+// reference's BAKED matrices: tools/extract_constants.py lifts S / K / S_NI / A_neg (and the backward-Euler sets, DC operating
+// points, device tables) out of the generated files as data, and tests/test_oracle_baked_matrices.py requires the oracle's own
+// rebuild at the codegen rate to reproduce them (1e-15 / 1e-11 of the largest entry), re-derives them in numpy from G and C,
+// and checks the DC operating points against independent device laws.
 // The melange-primitives Biquad boundary stays "parity unpinned" (see ow_voice.hpp).
 #include "ow_engine.hpp"
 #include "ow_alias_audit.hpp"
