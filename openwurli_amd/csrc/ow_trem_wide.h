@@ -141,6 +141,13 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
             }
             if (!singular && max_val < 1e-15) singular = true;
             if (!singular) {
+                // column 0 takes row 2 on every sweep seen (see solve4): one static quad permutation per dword when the whole wavefront
+                // agrees, the lane-dependent gather otherwise
+                if (col == 0 && __builtin_amdgcn_ballot_w64(max_row != 2) == 0ull) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ar[j] = qperm<0xC6>(ar[j]);      // quad_perm [2, 1, 0, 3]
+                    br = qperm<0xC6>(br);
+                } else
                 if (max_row != col) {   // row exchange col <-> max_row
                     const int src = q == col ? max_row : (q == max_row ? col : q);
 #pragma unroll

@@ -312,6 +312,7 @@ void owo_preamp_run(double sr, const double* x, const double* r, double r_static
 }
 
 // tremolo: n shunt-impedance samples at depth d after Tremolo::new(d, sr); optional osc voltage tap
+void owo_tremolo_stats(unsigned long long* out5) { for (int i = 0; i < 5; ++i) out5[i] = trem_stats()[i]; }
 void owo_tremolo_run(double depth, double sr, double* r_out, size_t n) {
     Tremolo* t = new Tremolo();
     t->init(depth, sr);

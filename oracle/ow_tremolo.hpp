@@ -15,6 +15,9 @@
 #include <cstring>
 
 namespace owo {
+// Newton sweeps and row exchanges per column of the Twin-T solver since process start (statistics for the GPU mapping, test infrastructure)
+inline unsigned long long* trem_stats() { static thread_local unsigned long long v[5] = {0, 0, 0, 0, 0}; return v; }
+
 
 // gen_tremolo.rs:1140-1166
 inline double fast_exp(double x0) {
@@ -256,6 +259,7 @@ struct TremCircuit {
             };
             double b[4] = {f0, f1, f2, f3};
             bool singular = false;
+            trem_stats()[0] += 1;
             for (int col = 0; col < 4; ++col) {
                 int max_row = col;
                 double max_val = std::fabs(a[col][col]);
@@ -263,6 +267,7 @@ struct TremCircuit {
                     if (std::fabs(a[row][col]) > max_val) { max_val = std::fabs(a[row][col]); max_row = row; }
                 if (max_val < 1e-15) { singular = true; break; }
                 if (max_row != col) {
+                    trem_stats()[1 + col] += 1;
                     for (int j = 0; j < 4; ++j) std::swap(a[col][j], a[max_row][j]);
                     std::swap(b[col], b[max_row]);
                 }
