@@ -100,8 +100,8 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
         const double kq0 = kk[q][0], kq1 = kk[q][1], kq2 = kk[q][2], kq3 = kk[q][3];
         // v_d as emitted (gen_tremolo.rs:2423-2438): v_d1 has no k[1][3] term, v_d2 no k[2][2] term
         double vd = pq + kq0 * i_nl[0] + kq1 * i_nl[1];
-        if (q != 2) vd = vd + kq2 * i_nl[2];
-        if (q != 1) vd = vd + kq3 * i_nl[3];
+        { const double t = vd + kq2 * i_nl[2]; vd = (q != 2) ? t : vd; }      // selects, not branches: the lanes of a quad differ here
+        { const double t = vd + kq3 * i_nl[3]; vd = (q != 1) ? t : vd; }
         // junction exponentials: lane 0 exp_be(Q1), 1 exp_bc(Q1), 2 exp_be(Q2), 3 exp_bc(Q2)   (bjt_eval: sign = nf = nr = 1)
         const double e_me = fast_exp(OW_DIV_C(1.0 * vd, 1.0 * OW_T_VT));
         const double e_ot = qswap1(e_me);

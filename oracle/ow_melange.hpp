@@ -465,6 +465,8 @@ struct MelState {
 
 // dk_preamp/melange_adapter.rs:12-94
 struct MelangePreamp {
+    // Newton sweeps spent (statistics for the GPU mapping, read by owo_engine_melange_stats): samples, main, shadow, max of the two
+    unsigned long long stat_samples = 0, stat_main = 0, stat_shadow = 0, stat_max = 0;
     MelState main, shadow;
     double sample_rate = 0;
     bool noise_enabled = false;          // melange_adapter.rs:35-36,45-46
@@ -498,6 +500,8 @@ struct MelangePreamp {
     double process_sample(double input) {
         const double m = main.process_sample(input);
         const double pump = shadow.process_sample(0.0);
+        stat_samples += 1; stat_main += main.last_nr_iterations + 1u; stat_shadow += shadow.last_nr_iterations + 1u;
+        stat_max += (main.last_nr_iterations > shadow.last_nr_iterations ? main.last_nr_iterations : shadow.last_nr_iterations) + 1u;
         const double result = m - pump;
         if (!std::isfinite(result)) { reset(); return 0.0; }
         return result;

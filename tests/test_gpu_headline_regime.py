@@ -158,3 +158,39 @@ def test_pool_of_32768_fully_decorrelated_lane_per_group_kernel(hiplib, oracle):
     """Smallest pool that takes the lane = group tremolo kernel with one group per engine, for the whole 1.1 s script."""
     worst, peak = _run(hiplib, oracle, 32768, TOTAL, ("hbm",), groups=32768)
     assert worst < 1.0 and 0.02 < peak < 4.0
+
+
+def test_melange_power_amp_pool_larger_than_the_chip_holds(hiplib, oracle):
+    """`--power-amp melange` at the size its bench line runs at takes the demand-ordered dispatch of k_post_mpa on its own (more
+    engines than the 16 384 the chip holds at once: DESIGN 14): a 17 408-engine pool, config-5 velocities on a 12-key chord, three
+    blocks of 128 (the first orders by the zero demand of a fresh pool, the later ones by the passes of the block before), sampled
+    engines against one oracle engine each, every engine against the engine 88 places before it (same velocity => bit-identical,
+    wherever the order put it)."""
+    import openwurli_amd as ow
+    n = 17408
+    g = ow.EnginePool(SR, n, power_amp_kind=1)
+    keys = (36, 40, 43, 48, 52, 55, 60, 64, 67, 72, 76, 79)
+    from openwurli_amd import binding
+    vel = ((40 + (37 * np.arange(n)) % 88) / 127.0).astype(np.float32)
+    ev = np.zeros((n, len(keys)), dtype=np.dtype(binding.MIDI_DTYPE))
+    ev["engine"] = np.arange(n, dtype=np.uint32)[:, None]
+    ev["note"] = np.array(keys, dtype=np.uint8)[None, :]
+    ev["value"] = vel[:, None]
+    g.midi(ev.reshape(-1))
+    picks = sorted({0, 1, 87, 88, 4097, n // 2, n - 1})
+    cs = {}
+    for k in picks:
+        c = oracle.OracleEngine(SR, power_amp_kind=1)
+        for key in keys:
+            c.note_on(key, np.float32(_velocity(k)))
+        cs[k] = c
+    try:
+        for b in range(3):
+            out = g.render(128)
+            assert np.array_equal(out[88:], out[:-88]), ("engine k vs k - 88", b)
+            assert len({out[k].tobytes() for k in range(88)}) > 60
+            for k, c in cs.items():
+                rep = oracle.parity_report(out[k], c.render(128), abs_floor=oracle.ABS_FLOOR_OUTPUT)
+                assert rep["n_bad"] == 0, ("melange power amp, ordered dispatch", b, k, rep)
+    finally:
+        g.close()
