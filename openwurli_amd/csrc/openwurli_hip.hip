@@ -2001,6 +2001,15 @@ int ow_test_device_read(void* dst_host, const void* src_device, size_t bytes, in
     if (hipSetDevice(device) != hipSuccess) return -1;
     return hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
+#ifdef OW_DBG_COUNTERS
+// development counters (built with OW_HIPCC_EXTRA=-DOW_DBG_COUNTERS only): read and clear
+extern "C" int ow_debug_counters(unsigned long long* out8, int device) {
+    if (hipSetDevice(device) != hipSuccess) return -1;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(owdev::g_ow_dbg), sizeof z) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(owdev::g_ow_dbg), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 // Which literal-rebuild fast paths the host found usable for the melange preamp at chain rate `rate` (no device): bit 0 = the
 // R-independent leading block could be replayed (ml_ok), bit 1 = the factors have the sparsity pattern ow_melange_col.h compiles in.
 int ow_test_host_melange_paths(double rate) {

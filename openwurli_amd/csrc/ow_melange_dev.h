@@ -39,6 +39,9 @@ OW_DEV void mel_mats_load(MelMats* __restrict__ m, const OwConsts* __restrict__ 
 }
 
 // solve_nonlinear (gen_preamp.rs:3122-3357) with the 3x3 kernel in registers; returns last_nr_iterations (265 = failed)
+#ifdef OW_DBG_COUNTERS
+__device__ unsigned long long g_ow_dbg[8];
+#endif
 __device__ inline uint32_t mel_solve_nl(const double p[3], const double kk[3][3], const double ip[3], const double ipp[3], double i_nl[3]) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) i_nl[i] = 2.0 * ip[i] - ipp[i];
@@ -46,6 +49,13 @@ __device__ inline uint32_t mel_solve_nl(const double p[3], const double kk[3][3]
 #define OW_MEL_MAXIT 265
 #endif
     for (int iter = 0; iter < OW_MEL_MAXIT; ++iter) {
+#ifdef OW_DBG_COUNTERS
+        {   // [0] sweep bodies summed over lanes, [1] sweep bodies as the wavefront executes them
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+            atomicAdd(&g_ow_dbg[0], 1ull);
+            if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) atomicAdd(&g_ow_dbg[1], 1ull);
+        }
+#endif
         double vd[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) vd[q] = p[q] + kk[q][0] * i_nl[0] + kk[q][1] * i_nl[1] + kk[q][2] * i_nl[2];

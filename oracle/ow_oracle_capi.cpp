@@ -30,6 +30,7 @@ void* owo_engine_new_kinds(double sr, int preamp_kind, int power_amp_kind) { ret
 void* owo_engine_new_kinds3(double sr, int preamp_kind, int power_amp_kind, int tremolo_kind) { return new WurliEngine(sr, preamp_kind, power_amp_kind, tremolo_kind); }
 void owo_engine_free(void* e) { delete (WurliEngine*)e; }
 void owo_engine_melange_stats(void* e, unsigned long long* out4) { const MelangePreamp& m = ((WurliEngine*)e)->mel; out4[0] = m.stat_samples; out4[1] = m.stat_main; out4[2] = m.stat_shadow; out4[3] = m.stat_max; }
+void owo_engine_melange_be(void* e, unsigned long long* out2) { const MelangePreamp& m = ((WurliEngine*)e)->mel; out2[0] = m.main.diag_be_fallback_count; out2[1] = m.shadow.diag_be_fallback_count; }
 void owo_engine_set_rail_sag(void* e, int on) { ((WurliEngine*)e)->set_rail_sag(on != 0); }
 int owo_engine_rail_sag_enabled(void* e) { return ((WurliEngine*)e)->rail_sag_enabled() ? 1 : 0; }
 // power_amp_diag (engine.rs:418-420): clamp_count, nr_max_iter_count, peak_output_volts; + oracle-only guard reset count
