@@ -544,7 +544,7 @@ def main(argv=None):
             r["preamp_frac_of_fp64_peak"] = FLOPS_PREAMP_MELANGE_LIT * BUF * n_mel / (r["kernel_ms_per_step"]["preamp"] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS
             extras["preamp_melange"] = r
             pm.close()
-            n_pa = min(n_inst, 65536)
+            n_pa = min(n_inst, 131072)
             pp = make_pool(n_pa, pa=1, n_groups=min(groups, n_pa))
             r = side_run(pp, n_pa, 3, 3)
             r["workload"] = ("cfg2 with the melange 7-BJT power amp + rail sag (k_post_mpa: eight lanes per engine, every engine on its own sample counter, "

@@ -63,7 +63,8 @@ python bench.py --host-rate 96000 --steps 40 --warmup 5 --no-extras --no-cpu-bas
 python bench.py --preamp melange --instances 65536 --steps 20 --warmup 3 --no-extras > $O/bench_melange.log 2>&1
 OW_MEL_LDS=1 python bench.py --preamp melange --instances 65536 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_melange_lds_matrix.log 2>&1
 OW_MEL_RANK1=1 python bench.py --preamp melange --instances 65536 --steps 20 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_melange_rank1.log 2>&1
-python bench.py --power-amp melange --instances 65536 --steps 4 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_power_amp_melange.log 2>&1
+python bench.py --power-amp melange --steps 4 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_power_amp_melange.log 2>&1
+python bench.py --power-amp melange --instances 65536 --steps 4 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_power_amp_melange_65536.log 2>&1
 python bench.py --power-amp melange --instances 16384 --steps 4 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_power_amp_melange_16384.log 2>&1
 python bench.py --workload batch > $O/bench_batch.log 2>&1
 OW_TREM_SERIAL=1 python bench.py --steps 40 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_trem_serial.log 2>&1
