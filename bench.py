@@ -479,6 +479,8 @@ def main(argv=None):
             script.step()
         pool.set_profiling(True)
         elapsed = timed_steps(script, args.steps, profile=True)
+        # melange power amp: Newton passes per chain-rate sample, mean over the engines, in the LAST block of the timed region
+        pa_passes = float(pool.power_amp_passes().mean()) / (BUF * (2 if SR < 88200.0 else 1)) if pa_kind else None
         pool.set_profiling(False)
 
         extras = {}
@@ -550,6 +552,9 @@ def main(argv=None):
             r["workload"] = ("cfg2 with the melange 7-BJT power amp + rail sag (k_post_mpa: eight lanes per engine, every engine on its own sample counter, "
                              "engines dispatched by falling Newton demand of their last block)")
             r["x_realtime_aggregate"] = r["value"] / SR
+            r["newton_passes_per_chain_sample"] = float(pp.power_amp_passes().mean()) / (BUF * 2)
+            r["post_frac_of_fp64_peak"] = ((2 * ((8 * 300 + 1024 + 2730 + 256 + 1024) * r["newton_passes_per_chain_sample"] + 800 + 640) + 24 + 45) * BUF * n_pa
+                                           / (r["kernel_ms_per_step"]["post"] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS)
             extras["power_amp_melange"] = r
             pp.close()
 
@@ -647,7 +652,8 @@ def main(argv=None):
             names = ["ops", "voices", "tremolo", "preamp", "post"]
             trem_per_engine = FLOPS_TREMOLO * groups / n_inst            # one oscillator per phase group
             osr = 2 if SR < 88200.0 else 1
-            flops_post = (FLOPS_POST - osr * 90 + osr * FLOPS_PA_MELANGE_PER_CHAIN_SAMPLE) if pa_kind else FLOPS_POST
+            flops_pa_sample = (8 * 300 + 1024 + 2730 + 256 + 1024) * (pa_passes or 1.0) + 800 + 640        # per pass: devices, Jacobian, LU, substitution, K products
+            flops_post = (FLOPS_POST - osr * 90 + osr * flops_pa_sample) if pa_kind else FLOPS_POST
             flops = {"ops": 0.0, "voices": FLOPS_VOICES, "tremolo": trem_per_engine, "preamp": flops_preamp, "post": flops_post}
             per_sample = FLOPS_VOICES + trem_per_engine + flops_preamp + flops_post
             audio = ["voices", "preamp", "post"] + (["tremolo"] if groups * 4 >= n_inst else [])   # the shared oscillator is not a pool-sized kernel
@@ -705,8 +711,9 @@ def main(argv=None):
                              "frac": traffic / (dom_ms * 1e-3) / 1e9 / 8000.0} if traffic and dom_ms > 0 else None),
                     "note": "path is FP64-VALU/latency bound (not HBM, not MFMA); achieved = algorithmic f64 flops of the dominant "
                             "kernel per launch / its HIP-event duration" +
-                            ("; melange power amp: the flop count assumes ONE Newton iteration per chain-rate sample (a lower bound: the count is data dependent)"
-                             if pa_kind else ""),
+                            (f"; melange power amp: the flop count is per-pass work x the {pa_passes:.2f} Newton passes per chain-rate sample the engines "
+                             "spent on the last block (mean; data dependent)" if pa_kind else ""),
+                    "power_amp_newton_passes_per_chain_sample": pa_passes,
                 },
                 "cpu_baseline": cpu,
             }

@@ -70,6 +70,9 @@ int ow_debug_power_amp(double sample_rate, const double* in, size_t n_rows, size
 /* Keep the amp's output of every chain-rate sample of the last block (before the half-band down-sampler): f64 [n_engines][n_os] through
  * ow_test_pool_read_power_amp_out.  Costs 16 B per engine and chain-rate sample of the block capacity; off until enabled. */
 int ow_test_pool_enable_power_amp_tap(ow_pool*);
+/* Melange power amp: Newton passes (main sweep) engine k spent on its LAST rendered block -- the figure the demand-ordered dispatch of
+ * k_post_mpa sorts by (0 = not rendered yet).  out: one uint32 per engine of the pool; n must equal the pool size.  -1 without the amp. */
+int ow_test_pool_power_amp_passes(ow_pool*, uint32_t* out, size_t n);
 int ow_test_pool_read_power_amp_out(ow_pool*, double* out_host, size_t out_stride, size_t n_os);
 /* Overwrite one node voltage of the amp's solver state (v_prev[node], node < 20) before the next block: the way to force the
  * divergence guard (power_amp.rs:410-421: |node| > 100 V -> reset + hold last good) at a known sample. */

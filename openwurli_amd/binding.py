@@ -157,6 +157,7 @@ TEST_SYMBOLS = {
     "ow_test_inject_render_faults": (None, [_VP, C.c_int]),
     "ow_debug_power_amp": (C.c_int, [C.c_double, _VP, C.c_size_t, C.c_size_t, C.c_int, _VP, _VP, _VP, _VP, _VP, C.c_int]),
     "ow_test_pool_enable_power_amp_tap": (C.c_int, [_VP]),
+    "ow_test_pool_power_amp_passes": (C.c_int, [_VP, _VP, C.c_size_t]),
     "ow_test_pool_read_power_amp_out": (C.c_int, [_VP, _VP, C.c_size_t, C.c_size_t]),
     "ow_test_engine_poke_power_amp_node": (C.c_int, [_VP, C.c_int, C.c_double]),
     "ow_test_pool_stagger_tremolo": (C.c_int, [_VP, C.c_size_t]),

@@ -1920,6 +1920,12 @@ int ow_debug_power_amp(double sample_rate, const double* in, size_t n_rows, size
         return 0;
     } catch (const std::exception& ex) { set_err(std::string("ow_debug_power_amp: ") + ex.what()); return -1; }
 }
+int ow_test_pool_power_amp_passes(ow_pool* p, uint32_t* out, size_t n) {
+    if (!p || !out || !p->d_pa_demand || n != (size_t)p->I) return -1;
+    if (hipSetDevice(p->device) != hipSuccess) return -1;
+    if (hipStreamSynchronize(p->stream) != hipSuccess) return -1;
+    return hipMemcpy(out, p->d_pa_demand, sizeof(uint32_t) * n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
 int ow_test_pool_enable_power_amp_tap(ow_pool* p) {
     if (!p || p->power_amp_kind != OW_POWER_AMP_MELANGE) return -1;
     if (p->d_pa_tap) return 0;

@@ -270,6 +270,13 @@ class EnginePool:
             raise OwError(binding.take_error(self._lib) or "power-amp tap not enabled")
         return out
 
+    def power_amp_passes(self):
+        """Newton passes every engine's melange power amp spent on the last rendered block (test hook; uint32 per engine)."""
+        out = np.zeros(self.n, dtype=np.uint32)
+        if self._lib.ow_test_pool_power_amp_passes(self._h, out.ctypes.data_as(C.c_void_p), out.size) != 0:
+            raise OwError("ow_test_pool_power_amp_passes failed (no melange power amp in this pool?)")
+        return out
+
     def enable_power_amp_tap(self):
         if self._lib.ow_test_pool_enable_power_amp_tap(self._h) != 0:
             raise OwError("power-amp tap: not a melange power-amp pool")

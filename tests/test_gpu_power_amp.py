@@ -248,10 +248,13 @@ def test_demand_ordered_dispatch_changes_no_sample(hiplib, oracle, monkeypatch):
             script(g[k], k)
         out = np.concatenate([g.render(256) for _ in range(5)], axis=1)
         d = [g[k].power_amp_diag() for k in picks]
+        passes = g.power_amp_passes()                       # of the last block: 512 chain-rate samples, 1..70 passes each
+        assert passes.shape == (n,) and passes.min() >= 512 and passes.max() <= 70 * 512
         g.close()
-        return out, d
-    a, da = run("2")
-    b, db = run("0")
+        return out, d, passes
+    a, da, pa = run("2")
+    b, db, pb = run("0")
+    assert np.array_equal(pa, pb)                           # the same Newton work whichever wavefront an engine sat in
     assert np.array_equal(a, b)
     assert [(x.guard_resets, x.nr_max_iter_count) for x in da] == [(x.guard_resets, x.nr_max_iter_count) for x in db]
     assert len({a[k].tobytes() for k in range(40)}) > 20                # the engines do differ
