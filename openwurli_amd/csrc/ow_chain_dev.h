@@ -76,12 +76,26 @@ OW_DEV bool solve4(double a[4][4], double b[4]) {
     double yp[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int col = 0; col < 4; ++col) {
-        int max_row = col;
-        double max_val = fabs(a[col][col]);
+        // Pivot choice: the scan (first strict maximum of |a[row][col]|, rows col..3 in order) ends at row 2 for column 0 and at the diagonal
+        // for the others on every sweep the oracle has seen; it does exactly when that entry beats the rows before it strictly and no row
+        // after it beats it -- three / two / one compares.  The scan itself only runs when some lane of the wavefront disagrees.
+        const int ex = col == 0 ? 2 : col;
+        int max_row = ex;
+        double max_val = fabs(a[ex][col]);
+        bool ok = true;
 #pragma unroll
-        for (int row = col + 1; row < 4; ++row) {
-            const double v = fabs(a[row][col]);
-            if (v > max_val) { max_val = v; max_row = row; }
+        for (int row = col; row < 4; ++row) {
+            if (row < ex) ok = ok && (max_val > fabs(a[row][col]));
+            if (row > ex) ok = ok && !(fabs(a[row][col]) > max_val);
+        }
+        if (__builtin_amdgcn_ballot_w64(!singular && !ok) != 0ull) {
+            max_row = col;
+            max_val = fabs(a[col][col]);
+#pragma unroll
+            for (int row = col + 1; row < 4; ++row) {
+                const double v = fabs(a[row][col]);
+                if (v > max_val) { max_val = v; max_row = row; }
+            }
         }
         if (!singular && max_val < 1e-15) singular = true;
         if (!singular) {

@@ -124,28 +124,38 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) ar[j] = (j == q ? 1.0 : 0.0) - jA * kk[r0][j] - jB * kk[r0 + 1][j];
         double br = f_me;
-        double f[4];
-        static_for<0, 4>([&](auto J) { f[J] = qget<J>(f_me); });
         // ---- solve4, one row per lane (same pivot choice, same row exchange, same updates per element)
         bool singular = false;
         static_for<0, 4>([&](auto COL) {
             constexpr int col = COL;
-            double cv[4];
-            static_for<0, 4>([&](auto R) { cv[R] = qget<R>(ar[col]); });
-            int max_row = col;
-            double max_val = fabs(cv[col]);
+            // Pivot choice.  The scan (first strict maximum of |J[row][col]|, rows col..3 in order) ends at the row it has ended at on
+            // every sweep the oracle has seen -- row 2 for column 0, the diagonal otherwise (see solve4) -- exactly when that row's entry
+            // beats the rows before it strictly and no row after it beats it.  Each lane tests that for its own row against the
+            // expected row's entry (one broadcast, one compare); only if some lane of the wavefront disagrees is the scan itself run on
+            // the gathered column.
+            constexpr int ex = col == 0 ? 2 : col;
+            const double pe = qget<ex>(ar[col]);
+            const double ape = fabs(pe), amine = fabs(ar[col]);
+            const bool ok_me = singular || q < col || q == ex || (q < ex ? (ape > amine) : !(amine > ape));
+            int max_row = ex;
+            double max_val = ape;
+            const bool usual = __builtin_amdgcn_ballot_w64(!ok_me) == 0ull;
+            if (!usual) {
+                double cv[4];
+                static_for<0, 4>([&](auto R) { cv[R] = qget<R>(ar[col]); });
+                max_row = col;
+                max_val = fabs(cv[col]);
 #pragma unroll
-            for (int row = col + 1; row < 4; ++row) {
-                const double v = fabs(cv[row]);
-                if (v > max_val) { max_val = v; max_row = row; }
+                for (int row = col + 1; row < 4; ++row) {
+                    const double v = fabs(cv[row]);
+                    if (v > max_val) { max_val = v; max_row = row; }
+                }
             }
             if (!singular && max_val < 1e-15) singular = true;
             if (!singular) {
-                // column 0 takes row 2 on every sweep seen (see solve4): one static quad permutation per dword when the whole wavefront
-                // agrees, the lane-dependent gather otherwise
-                if (col == 0 && __builtin_amdgcn_ballot_w64(max_row != 2) == 0ull) {
+                if (col == 0 && usual) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ar[j] = qperm<0xC6>(ar[j]);      // quad_perm [2, 1, 0, 3]
+                    for (int j = 0; j < 4; ++j) ar[j] = qperm<0xC6>(ar[j]);      // rows 0 <-> 2: quad_perm [2, 1, 0, 3], one move per dword
                     br = qperm<0xC6>(br);
                 } else
                 if (max_row != col) {   // row exchange col <-> max_row
@@ -204,14 +214,19 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
             // ga = min over the ports in port order with a strict "<" (a NaN ratio never wins, as in the scalar loop)
             double ga = 1.0;
             bool any_limited = false;
-            static_for<0, 4>([&](auto J) {
-                const double rj = qget<J>(r_me);
-                if (rj < ga) { ga = rj; any_limited = true; }
-            });
+            if (__builtin_amdgcn_ballot_w64(r_me < 1.0) != 0ull) {               // otherwise every ratio is 1 (or NaN): nothing is below ga
+                static_for<0, 4>([&](auto J) {
+                    const double rj = qget<J>(r_me);
+                    if (rj < ga) { ga = rj; any_limited = true; }
+                });
+            }
+            // the 3.5 V step cap (gen_tremolo.rs:2655-2668): max over the ports only matters when some port is above it
             const double adv = fabs(dv_trial * ga);
-            double max_dv = qget<0>(adv);
-            max_dv = fmax(max_dv, qget<1>(adv)); max_dv = fmax(max_dv, qget<2>(adv)); max_dv = fmax(max_dv, qget<3>(adv));
-            if (max_dv > 3.5) { ga *= fmax(ow_div(3.5, max_dv), 0.1); any_limited = true; }
+            if (__builtin_amdgcn_ballot_w64(adv > 3.5) != 0ull) {
+                double max_dv = qget<0>(adv);
+                max_dv = fmax(max_dv, qget<1>(adv)); max_dv = fmax(max_dv, qget<2>(adv)); max_dv = fmax(max_dv, qget<3>(adv));
+                if (max_dv > 3.5) { ga *= fmax(ow_div(3.5, max_dv), 0.1); any_limited = true; }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) i_nl[j] -= ga * b[j];
             if (!any_limited) {
@@ -221,7 +236,9 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
                 const uint64_t bal = __ballot(ok_me);                                    // all four ports of this quad within tolerance?
                 if (((bal >> (threadIdx.x & 60)) & 0xFull) == 0xFull) { converged = true; break; }
             }
-        } else {   // singular Jacobian: damped fallback (gen_tremolo.rs:2715-2733)
+        } else {   // singular Jacobian: damped fallback (gen_tremolo.rs:2715-2733); `singular` is uniform over the quad, so the gather may sit here
+            double f[4];
+            static_for<0, 4>([&](auto J) { f[J] = qget<J>(f_me); });
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const double cl = fmax(fabs(i_nl[j]) * 0.1, 0.01);
