@@ -141,8 +141,9 @@ OW_DEV bool solve4(double a[4][4], double b[4]) {
             double sum = b[i];
 #pragma unroll
             for (int j = i + 1; j < 4; ++j) sum -= a[i][j] * b[j];
-            if (!singular && fabs(a[i][i]) < 1e-15) singular = true;
-            if (!singular) b[i] = ow_div_y(sum, a[i][i], yp[i]);
+            // (the reference tests |a[i][i]| < 1e-15 again here: a[i][i] is column i's pivot, final since that column, and it passed
+            // this very test above -- or is NaN, which passes both -- so the second test can never fire)
+            b[i] = ow_div_y(sum, a[i][i], yp[i]);
         }
     }
     return !singular;

@@ -164,7 +164,7 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
                     for (int j = 0; j < 4; ++j) ar[j] = qget_dyn(ar[j], src);
                     br = qget_dyn(br, src);
                 }
-                const double pivot = qget<col>(ar[col]);
+                const double pivot = usual ? pe : qget<col>(ar[col]);      // the usual pivot row's entry is already here (before or after its move to lane col)
                 const double pb = qget<col>(br);
                 double prow[4];
 #pragma unroll
@@ -188,10 +188,7 @@ __device__ inline double trem_osc_step_wide(TremWide& st, const OwConsts* __rest
                 double sum = br;
 #pragma unroll
                 for (int j = i + 1; j < 4; ++j) sum -= ar[j] * b[j];
-                const double diag = qget<i>(ar[i]);
-                if (!singular && fabs(diag) < 1e-15) singular = true;
-                if (!singular) b[i] = qget<i>(ow_div_y(sum, ar[i], y_diag));
-                else b[i] = qget<i>(br);      // the scalar code leaves b[i] unreduced once singular; its value is not used afterwards
+                b[i] = qget<i>(ow_div_y(sum, ar[i], y_diag));      // (the reference's second |diagonal| < 1e-15 test cannot fire: see solve4)
             });
         }
         if (!singular) {   // gen_tremolo.rs:2562-2713
