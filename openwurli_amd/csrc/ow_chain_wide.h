@@ -15,11 +15,16 @@
 
 namespace owdev {
 
-struct DkWideRows { double s_lo[8], s_hi[8]; };   // rows q and q + 4 of S (lane q of the quad), loop-invariant
+// rows q and q + 4 (lane q of the quad) of S, of the two S N_i column differences and of S's feedback column, loop-invariant
+struct DkWideRows { double s_lo[8], s_hi[8], c1_lo, c1_hi, c2_lo, c2_hi, fb_lo, fb_hi; };
 
 __device__ inline void dk_wide_rows_load(DkWideRows& R, const OwConsts* __restrict__ K, int q) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { R.s_lo[j] = K->p_s[q][j]; R.s_hi[j] = K->p_s[q + 4][j]; }
+    // (s_base[i][EMIT1] - s_base[i][COLL1]) and (s_base[i][EMIT2] - s_base[i][COLL2]) of dk_step's last loop: differences of constants
+    R.c1_lo = K->p_s[q][1] - K->p_s[q][2];         R.c1_hi = K->p_s[q + 4][1] - K->p_s[q + 4][2];
+    R.c2_lo = K->p_s[q][3] - K->p_s[q][5];         R.c2_hi = K->p_s[q + 4][3] - K->p_s[q + 4][5];
+    R.fb_lo = K->p_s_fb_col[q];                    R.fb_hi = K->p_s_fb_col[q + 4];
 }
 
 // ic, gm of both junctions with one exponential per lane: even lanes of the quad evaluate vn0, odd lanes vn1 (dk_ic_gm, :686-690)
@@ -63,14 +68,17 @@ __device__ inline double dk_step_wide(DkSt& st, const DkWideRows& R, int q, doub
     double lo = 0.0, hi = 0.0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { lo += R.s_lo[j] * rhs[j]; hi += R.s_hi[j] * rhs[j]; }
-    double vpb[8];
-    static_for<0, 4>([&](auto i) { vpb[i] = qget<i>(lo); vpb[i + 4] = qget<i>(hi); });
+    // rows 0..3 (they feed p) and row 7 (the Sherman-Morrison scalar) go to every lane; rows 4..6 are only needed by their owners
+    double vpb[4];
+    static_for<0, 4>([&](auto i) { vpb[i] = qget<i>(lo); });
+    const double vpb7 = qget<3>(hi);
     K = k_reload(K0);
     const double sm_k = ow_div(g_ldr, 1.0 + K->p_s_fb_fb * g_ldr);
-    const double sm_vpred = sm_k * vpb[7];
-    double v_pred[8];
+    const double sm_vpred = sm_k * vpb7;
+    double v_pred[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v_pred[i] = vpb[i] - sm_vpred * K->p_s_fb_col[i];
+    for (int i = 0; i < 4; ++i) v_pred[i] = vpb[i] - sm_vpred * K->p_s_fb_col[i];
+    const double vp_lo = lo - sm_vpred * R.fb_lo, vp_hi = hi - sm_vpred * R.fb_hi;      // v_pred of this lane's rows q, q + 4
     const double p0 = v_pred[0] - v_pred[1], p1 = v_pred[2] - v_pred[3];
     const double k00 = K->p_k[0][0] - sm_k * K->p_nv_sfb[0] * K->p_sfb_ni[0];
     const double k01 = K->p_k[0][1] - sm_k * K->p_nv_sfb[0] * K->p_sfb_ni[1];
@@ -96,11 +104,11 @@ __device__ inline double dk_step_wide(DkSt& st, const DkWideRows& R, int q, doub
     dk_ic_pair(q, vn0, vn1, ic0, ic1);
     K = k_reload(K0);
     const double dot = K->p_sfb_ni[0] * ic0 + K->p_sfb_ni[1] * ic1;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const double s_ni_i = ic0 * (K->p_s[i][1] - K->p_s[i][2]) + ic1 * (K->p_s[i][3] - K->p_s[i][5]);
-        st.v[i] = v_pred[i] + s_ni_i - sm_k * dot * K->p_s_fb_col[i];
-    }
+    // v = v_pred + S N_i i_c - sm_k (s_fb N_i . i_c) s_fb_col: the same expression for every row with the row's constants -- each
+    // lane forms its rows q and q + 4, the quad gathers the eight
+    const double v_lo = vp_lo + (ic0 * R.c1_lo + ic1 * R.c2_lo) - sm_k * dot * R.fb_lo;
+    const double v_hi = vp_hi + (ic0 * R.c1_hi + ic1 * R.c2_hi) - sm_k * dot * R.fb_hi;
+    static_for<0, 4>([&](auto i) { st.v[i] = qget<i>(v_lo); st.v[i + 4] = qget<i>(v_hi); });
     st.cin_prev = cin_now;
     const double dv_cin = input - st.v[0];
     st.j_cin = -K->p_gc_1pc * dv_cin - K->p_c_cin * st.j_cin;
