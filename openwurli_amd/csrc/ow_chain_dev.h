@@ -606,7 +606,7 @@ __device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_
     const double dot = K->p_sfb_ni[0] * ic0 + K->p_sfb_ni[1] * ic1;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const double s_ni_i = ic0 * (K->p_s[i][1] - K->p_s[i][2]) + ic1 * (K->p_s[i][3] - K->p_s[i][5]);
+        const double s_ni_i = ic0 * K->p_sni_d1[i] + ic1 * K->p_sni_d2[i];      // the two column differences of S come from the host
         st.v[i] = v_pred[i] + s_ni_i - sm_k * dot * K->p_s_fb_col[i];
     }
     st.cin_prev = cin_now;

@@ -22,8 +22,8 @@ __device__ inline void dk_wide_rows_load(DkWideRows& R, const OwConsts* __restri
 #pragma unroll
     for (int j = 0; j < 8; ++j) { R.s_lo[j] = K->p_s[q][j]; R.s_hi[j] = K->p_s[q + 4][j]; }
     // (s_base[i][EMIT1] - s_base[i][COLL1]) and (s_base[i][EMIT2] - s_base[i][COLL2]) of dk_step's last loop: differences of constants
-    R.c1_lo = K->p_s[q][1] - K->p_s[q][2];         R.c1_hi = K->p_s[q + 4][1] - K->p_s[q + 4][2];
-    R.c2_lo = K->p_s[q][3] - K->p_s[q][5];         R.c2_hi = K->p_s[q + 4][3] - K->p_s[q + 4][5];
+    R.c1_lo = K->p_sni_d1[q];                      R.c1_hi = K->p_sni_d1[q + 4];
+    R.c2_lo = K->p_sni_d2[q];                      R.c2_hi = K->p_sni_d2[q + 4];
     R.fb_lo = K->p_s_fb_col[q];                    R.fb_hi = K->p_s_fb_col[q + 4];
 }
 

@@ -218,6 +218,7 @@ static void build_preamp_consts(OwConsts& c) {
     c.p_nv_sfb[1] = c.p_s_fb_col[COLL1] - c.p_s_fb_col[EMIT2];
     c.p_sfb_ni[0] = row[EMIT1] - row[COLL1];
     c.p_sfb_ni[1] = row[EMIT2] - row[COLL2];
+    for (int i = 0; i < 8; ++i) { c.p_sni_d1[i] = s[i][EMIT1] - s[i][COLL1]; c.p_sni_d2[i] = s[i][EMIT2] - s[i][COLL2]; }
 }
 
 // melange 12-node preamp: S0 = A^-1 at (chain rate, nominal 100 kOhm pot) with the reference's LU (gen_preamp.rs:1990-2062,

@@ -130,6 +130,9 @@ struct OwConsts {
     uint32_t tremolo_kind, pad_tk;             // OW_TREMOLO_TWIN_T | OW_TREMOLO_LEGACY_LFO
     // legacy DK preamp at os_sr (dk_preamp_legacy.rs:269-366)
     double p_s[8][8], p_a_neg[8][8], p_k[2][2], p_two_w[8], p_s_fb_col[8], p_s_fb_fb, p_nv_sfb[2], p_sfb_ni[2];
+    // (s_base[i][EMIT1] - s_base[i][COLL1]), (s_base[i][EMIT2] - s_base[i][COLL2]) of dk_step's last loop (:528-531): differences of
+    // constants, formed once on the host by the same f64 subtraction the reference performs per sample
+    double p_sni_d1[8], p_sni_d2[8];
     double p_g_cin, p_c_cin, p_gc_1pc;
     double p_g_dc_base[8][8];
     // speaker
