@@ -155,8 +155,9 @@ OW_DEV double pa_pnjlim(double vnew, double vold, double vt, double vcrit) {   /
 // ---------------------------------------------------------------------------------------------------------------------------
 // Mapping.  EIGHT LANES PER ENGINE -- one per transistor -- and eight engines per wavefront (lane = role * 8 + engine slot); four
 // wavefronts per workgroup, two workgroups per CU (LDS), so every SIMD holds two wavefronts.  The lanes of an engine sit in ONE
-// wavefront: they run in lock step, "synchronisation" between them is a compiler fence, not a barrier, and an engine whose Newton
-// sweep runs long (hard clipping: 60+ iterations) only holds up the seven other engines of its wavefront.
+// wavefront: they run in lock step, "synchronisation" between them is a compiler fence, not a barrier.  The eight ENGINES of a
+// wavefront are not in lock step: k_post_mpa / k_mpa_debug run one Newton pass per loop trip for every engine, each engine on its own
+// sample counter, so a sample that takes 60 passes on one engine does not make the other seven wait for it (see k_post_mpa).
 //   lane `role` owns transistor `role`: its two controlling voltages, the device model (the expensive part: the exponentials and the
 //   inner 2x2 parasitic solve), and ROWS 2 role, 2 role + 1 of the 16x16 Newton Jacobian -- in REGISTERS, with their right-hand sides;
 //   Gaussian elimination with partial pivoting, column by column: every lane posts |J[row][col]| of its un-pivoted rows to LDS at
