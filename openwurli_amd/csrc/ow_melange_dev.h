@@ -89,6 +89,9 @@ __device__ inline uint32_t mel_solve_nl(const double p[3], const double kk[3][3]
             }
             if (!singular && max_val < 1e-15) singular = true;
             if (!singular) {
+                // row exchange only when some lane of the wavefront picked an off-diagonal pivot (wave-uniform branch): the selects are
+                // no-ops for every other lane
+                if (__builtin_amdgcn_ballot_w64(max_row != col) != 0ull) {
 #pragma unroll
                 for (int row = col + 1; row < 3; ++row) {
                     const bool sw = (max_row == row);
@@ -101,6 +104,7 @@ __device__ inline uint32_t mel_solve_nl(const double p[3], const double kk[3][3]
                     const double x = b[col], y = b[row];
                     b[col] = sw ? y : x;
                     b[row] = sw ? x : y;
+                }
                 }
                 const double pivot = a[col][col];
                 yp[col] = ow_rcp_refined(pivot);       // every quotient over this pivot (elimination factors, back substitution) shares it
@@ -119,8 +123,7 @@ __device__ inline uint32_t mel_solve_nl(const double p[3], const double kk[3][3]
                 double sum = b[i];
 #pragma unroll
                 for (int j = i + 1; j < 3; ++j) sum -= a[i][j] * b[j];
-                if (!singular && fabs(a[i][i]) < 1e-15) singular = true;
-                if (!singular) b[i] = ow_div_y(sum, a[i][i], yp[i]);
+                b[i] = ow_div_y(sum, a[i][i], yp[i]);      // (the reference's second |a[i][i]| < 1e-15 test cannot fire: a[i][i] is column i's pivot)
             }
         }
         if (!singular) {
