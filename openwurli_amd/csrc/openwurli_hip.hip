@@ -521,16 +521,12 @@ static bool power_amp_ordered() {     // read per block (a test flips it between
     const char* env = std::getenv("OW_PA_SORT");
     return !(env && env[0] == '0');
 }
+// engines of k_post_mpa the chip holds at once: two workgroups of PA_EPB per CU (LDS)
 static int power_amp_resident_engines(int device) {
-    static int cached[64] = {0};
-    const int d = (device >= 0 && device < 64) ? device : 0;
-    if (!cached[d]) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || cus <= 0) cus = 256;
-        cached[d] = cus * 2 * PA_EPB;
-    }
     if (const char* env = std::getenv("OW_PA_SORT")) if (env[0] == '2') return PA_EPB;      // '2': order every block of more than one workgroup (tests)
-    return cached[d];
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    return cus * 2 * PA_EPB;
 }
 // OW_TREM_WIDE=0/1 forces the choice (the parity test compares the two kernels bit for bit).
 static inline bool trem_wide(int ne) {
