@@ -722,6 +722,9 @@ def main(argv=None):
                 # the dominant kernel's interval above contains the concurrently running tremolo kernel; serialised, its own time
                 line["roofline"]["dominant_kernel_own_ms"] = ks["kernel_ms_per_step"]["voices"]
                 line["roofline"]["frac_own_time"] = ks["voices_frac_of_fp64_peak"]
+                line["roofline"]["note"] += ("; `frac` is the voice kernel's flops over an interval it SHARES with the block-ahead tremolo kernel (own stream, one "
+                                             "oscillator per instance): the interval's content is voices_plus_tremolo_frac, the voice kernel alone "
+                                             "(kernels serialised, `kernels_serialised` extra) runs at frac_own_time")
             line.update(extras)
     if rank == 0 and line is not None:
         print(json.dumps(line))
