@@ -95,6 +95,15 @@ int ow_pool_read_voice_sum(ow_pool*, double* out_host, size_t out_stride, size_t
 int ow_pool_read_preamp_out(ow_pool*, double* out_host, size_t out_stride, size_t n_os);
 /* CdS-cell resistance R[n] the tremolo produced for the last block (before the depth divider), chain rate: f64 [n_engines][n_os]. */
 int ow_pool_read_tremolo_r(ow_pool*, double* out_host, size_t out_stride, size_t n_os);
+/* The Twin-T / CdS tremolo cell takes no audio and no depth (tremolo.rs:121-146) and Tremolo::new / reset always leave the same settled
+ * state (:83-102,:192-216), so its resistance r_ldr[t] is one sequence per chain rate.  The library computes it once per (device, chain
+ * rate) into HBM -- the engine with the largest t extends it with a single oscillator, every engine of every pool of the process reads it
+ * at its own t -- instead of one oscillator per engine.  Bit-identical to per-engine oscillators (tests/test_gpu_trajectory.py).
+ * OW_TREM_TRAJ_SECONDS (default 1800) sizes the store when it is first used; an engine that runs longer without reset continues on an
+ * oscillator of its own.  OW_TREM_TRAJ=0 when a pool is created: no trajectory for that pool.
+ * ow_tremolo_prefetch: make the first `seconds` of the trajectory for host rate `sample_rate` exist now (blocking; a host would call it
+ * where it instantiates the plugin).  Returns the samples the store holds, <0 on error. */
+long long ow_tremolo_prefetch(double sample_rate, int device, double seconds);
 /* HIP stream the pool launches on (hipStream_t as void*), for event timing by the caller. */
 void* ow_pool_stream(ow_pool*);
 /* Time (ms, HIP events on the pool stream) each kernel of the last ow_pool_render took:

@@ -111,6 +111,17 @@ int ow_test_device_read(void* dst_host, const void* src_device, size_t bytes, in
  * replayed once per rate, bit 1 = the LU factors have the compiled-in sparsity pattern of the column-streamed kernel.  <0 on error. */
 int ow_test_host_melange_paths(double rate);
 
+/* ---- latched switches ------------------------------------------------------------------------- */
+/* The OW_* environment switches ("Environment switches") are read once, when a pool is created, and kept in the pool: the
+ * render path never calls getenv.  These change / read one on a live pool: "trem_serial", "trem_wide", "preamp_wide" (-1 = by size),
+ * "mel_generic", "mel_rank1", "mel_lds", "pa_sort" (0..2), "host_profile"; get also answers "trem_traj" and "trem_cache".  set returns
+ * 0, <0 for an unknown or creation-only switch; get returns the value, -2 for an unknown name. */
+int ow_test_pool_set_switch(ow_pool*, const char* name, int value);
+int ow_test_pool_get_switch(const ow_pool*, const char* name);
+/* out[0] = engines of the pool reading the shared tremolo trajectory, out[1] = samples its store holds (produced or enqueued),
+ * out[2] = the store's capacity in samples. */
+int ow_test_pool_trajectory_info(const ow_pool*, uint64_t out[3]);
+
 /* ---- fault injection ------------------------------------------------------------------------ */
 /* The next n_renders calls of ow_pool_render / ow_engine_render on this pool fail before their first launch, exactly as a HIP
  * error would (exception inside the guarded region): the caller's block must come back as silence in every row, ow_last_error

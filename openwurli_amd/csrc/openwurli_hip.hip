@@ -167,6 +167,41 @@ struct HostSmoother {  // host mirror of LinearSmoother::target only (the 1e-9 a
     }
 };
 
+// Measurement and test switches.  Every OW_* environment variable that selects between kernel paths is read ONCE, when a pool is
+// created (std::getenv is neither realtime-safe nor safe against a concurrent setenv in the host), and kept in the pool; the render
+// path only looks at the latched copy.  ow_test_pool_set_switch (openwurli_hip_test.h) changes one on a live pool.
+struct Switches {
+    int trem_wide = -1, preamp_wide = -1;      // -1: by pool size
+    bool trem_serial = false;                  // OW_TREM_SERIAL=1: block-ahead oscillators in front of the voices instead of beside them
+    bool trem_cache = true;                    // OW_TREM_CACHE=0: no process-wide settled-state cache
+    bool trem_traj = true;                     // OW_TREM_TRAJ=0: no shared trajectory, one oscillator per phase group (rounds 1-3)
+    bool mel_rank1 = false, mel_lds = false, mel_generic = false;
+    int pa_sort = 1;                           // OW_PA_SORT: 0 never, 1 when the block exceeds the chip, 2 always
+    int pipe = 0;                              // OW_PIPE=n stages
+    bool pipe_overlap = false;
+    bool host_profile = false;
+    int midi_threads = 0;                      // OW_MIDI_THREADS
+    static int flag(const char* name, int dflt) { const char* e = std::getenv(name); return (e && e[0]) ? (e[0] - '0') : dflt; }
+    static Switches from_env() {
+        Switches w;
+        w.trem_wide = flag("OW_TREM_WIDE", -1); w.preamp_wide = flag("OW_PREAMP_WIDE", -1);
+        if (w.trem_wide > 1 || w.trem_wide < -1) w.trem_wide = -1;
+        if (w.preamp_wide > 1 || w.preamp_wide < -1) w.preamp_wide = -1;
+        w.trem_serial = flag("OW_TREM_SERIAL", 0) == 1;
+        w.trem_cache = flag("OW_TREM_CACHE", 1) != 0;
+        w.trem_traj = flag("OW_TREM_TRAJ", 1) != 0;
+        w.mel_rank1 = flag("OW_MEL_RANK1", 0) == 1; w.mel_lds = flag("OW_MEL_LDS", 0) == 1; w.mel_generic = flag("OW_MEL_GENERIC", 0) == 1;
+        w.pa_sort = flag("OW_PA_SORT", 1); if (w.pa_sort < 0 || w.pa_sort > 2) w.pa_sort = 1;
+        if (const char* e = std::getenv("OW_PIPE")) { const int v = std::atoi(e); w.pipe = (v >= 1 && v <= 8) ? v : 0; }
+        w.pipe_overlap = flag("OW_PIPE_OVERLAP", 0) == 1;
+        w.host_profile = std::getenv("OW_HOST_PROFILE") != nullptr;
+        if (const char* e = std::getenv("OW_MIDI_THREADS")) { const long v = std::atol(e); if (v >= 1 && v <= 64) w.midi_threads = (int)v; }
+        return w;
+    }
+};
+
+struct TremTraj;   // shared Twin-T / CdS trajectory of one (device, chain rate), below
+
 }  // namespace
 
 struct ow_engine {
@@ -300,7 +335,19 @@ struct ow_pool {
     int split_e0 = -1, split_ne = -1; // range for which "no group straddles the range boundary" is known to hold
     double* d_snap = nullptr;         // [3][I] smoother targets (depth, speaker, volume) handed to k_chain_init on reset
     double* h_snap = nullptr;         // pinned
-    double* d_trem_settled = nullptr; // staging of one cached settled Twin-T state (18 doubles), see trem_settle_cached
+    double* d_trem_settled = nullptr; // staging of one cached settled Twin-T state (18 doubles), see trem_settled_rows
+    uint32_t* d_zero = nullptr;       // one zero (leader list {0} of the I = 1 settle scratch)
+    // Shared trajectory (TremTraj): engines of a Twin-T pool read r_ldr[t] of ONE process-wide sequence at t = trem_clock - birth[e].
+    // trem_clock advances with every whole-pool block; a sub-range rendered on its own shifts the births of its engines instead.
+    // birth == OW_OFF_TRAJ: the engine left the trajectory (older than the store's cap) and owns a phase group of one.
+    std::shared_ptr<TremTraj> traj;
+    long long trem_clock = 0;
+    long long min_birth = 0;          // over the engines on the trajectory (the oldest one decides how far the store must reach)
+    size_t n_on_traj = 0;
+    std::vector<long long> h_birth;   // [I]
+    long long* d_birth = nullptr;
+    long long last_n_os = 0;          // chain-rate samples of the last rendered block (ow_pool_read_tremolo_r)
+    Switches sw;                      // latched at creation
     bool voices_only = false;         // ow_render_note: the pool renders voice sums only -- no chain state, no tremolo / preamp / output kernels
     int inject_faults = 0;            // test hook (openwurli_hip_test.h): the next n renders fail before their first launch
     double hostprof_acc[4] = {0, 0, 0, 0};
@@ -418,9 +465,145 @@ void pa_settled_to_device(int device, double* d_dst, hipStream_t st) {
 // (tests/test_gpu_boundary.py::test_settled_tremolo_cache_is_bit_identical).  OW_TREM_CACHE=0 disables it.
 struct TremSettled { double rows[18]; };       // rows 0..16 after the settle; [17] = BE fallbacks the settle itself counted (u64 bits)
 std::map<std::pair<int, uint64_t>, TremSettled> g_trem_settled;
-static inline bool trem_cache_enabled() {
-    const char* env = std::getenv("OW_TREM_CACHE");
-    return !(env && env[0] == '0');
+
+// Settled rows for (device, chain rate), from the cache or by running the settle on `st` with the product kernels (k_tremolo_wide<true>:
+// 50 steps at the codegen matrices, 2 s at the chain rate) in the 18-row scratch `d_state` (I = 1 layout).  use_cache = false: always
+// settle, never store (OW_TREM_CACHE=0).  On return d_state holds the settled rows with row 17 = the settle's own fallback count.
+TremSettled trem_settled_rows(int device, double os_sr, const OwConsts* dK, const OwConsts* dK48, double* d_state, const uint32_t* d_zero, hipStream_t st,
+                              bool use_cache) {
+    uint64_t rate_bits; std::memcpy(&rate_bits, &os_sr, 8);
+    const std::pair<int, uint64_t> key(device, rate_bits);
+    TremSettled t;
+    if (use_cache) {
+        bool hit = false;
+        { std::lock_guard<std::mutex> lk(g_mel_mu); auto it = g_trem_settled.find(key); if (it != g_trem_settled.end()) { t = it->second; hit = true; } }
+        if (hit) {     // copied out under the lock; the transfer and its sync run without it
+            HIP_OK(hipMemcpyAsync(d_state, t.rows, sizeof(double) * 18, hipMemcpyHostToDevice, st));
+            HIP_OK(hipStreamSynchronize(st));
+            return t;
+        }
+    }
+    const long long n_settle = (long long)owhip::sat_u32(os_sr * 2.0);
+    owdev::k_trem_state_dc<<<dim3(1), dim3(64), 0, st>>>(d_state);
+    owdev::k_tremolo_wide<true><<<dim3(1), dim3(64), 0, st>>>(dK48, d_state, nullptr, 1, 50LL, d_zero, 1);
+    owdev::k_tremolo_wide<true><<<dim3(1), dim3(64), 0, st>>>(dK, d_state, nullptr, 1, n_settle, d_zero, 1);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(t.rows, d_state, sizeof(double) * 18, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (use_cache) { std::lock_guard<std::mutex> lk(g_mel_mu); g_trem_settled[key] = t; }
+    return t;
+}
+
+// ---- shared Twin-T / CdS trajectory --------------------------------------------------------------------------------------------------
+// Tremolo::process reads no audio and no depth (tremolo.rs:121-146) and every Tremolo::new / reset leaves the same settled state
+// (:83-102, :192-216): r_ldr[t], t = process() calls since the cell was built, is one deterministic sequence per chain rate.  The store
+// holds it in HBM once per (device, chain rate) for the life of the process; the engine with the largest t extends it with ONE oscillator
+// (k_trem_traj_extend, a single wavefront on the store's own stream), every other engine of every pool reads it.  288 GB of HBM is what
+// makes this the natural layout: 0.77 MB per second of audio at 96 kHz, OW_TREM_TRAJ_SECONDS (default 1800) of it reserved up front so
+// that render never allocates.  Engines that grow older than that leave the store for an oscillator of their own (trem_evict).
+struct TremTraj {
+    int device = 0;
+    double os_sr = 0.0;
+    std::mutex mu;                    // guards len / marks / enqueues on `stream`; held for host-side enqueue work only
+    OwConsts* dK = nullptr;           // constants at the chain rate (the tremolo fields are all the kernels read)
+    double* d_r = nullptr;            // [cap + 64]
+    double* d_state = nullptr;        // [18] oscillator rows at sample `len`
+    double* d_ckpt = nullptr;         // [cap / OW_TRAJ_CK + 2][OW_TRAJ_CKD]
+    unsigned long long* d_be = nullptr;   // [1 + OW_TRAJ_BE_CAP]
+    uint32_t* d_zero = nullptr;       // leaders = {0} for the settle kernels
+    size_t cap = 0, len = 0;          // len: samples produced or enqueued for production
+    size_t done = 0;                  // samples known to be complete (a recorded mark was seen finished)
+    uint64_t be_settle = 0;           // fallbacks the settle itself counted (what a fresh CircuitState carries after Tremolo::new)
+    hipStream_t stream = nullptr;
+    static constexpr int NMARK = 16;
+    struct Mark { size_t end = 0; hipEvent_t ev = nullptr; } mark[NMARK];
+    int head = 0;
+    ~TremTraj() {
+        hipSetDevice(device);
+        if (stream) hipStreamSynchronize(stream);
+        for (auto& m : mark) if (m.ev) hipEventDestroy(m.ev);
+        if (dK) hipFree(dK); if (d_r) hipFree(d_r); if (d_state) hipFree(d_state); if (d_ckpt) hipFree(d_ckpt);
+        if (d_be) hipFree(d_be); if (d_zero) hipFree(d_zero);
+        if (stream) hipStreamDestroy(stream);
+    }
+    // callers hold mu
+    void extend_to(size_t end) {
+        end = std::min(end, cap);
+        if (end <= len) return;
+        owdev::k_trem_traj_extend<<<dim3(1), dim3(64), 0, stream>>>(dK, d_state, d_r + len, (long long)len, (long long)(end - len), d_ckpt, d_be);
+        HIP_OK(hipGetLastError());
+        Mark& m = mark[head];
+        head = (head + 1) % NMARK;
+        HIP_OK(hipEventRecord(m.ev, stream));
+        m.end = end;
+        len = end;
+    }
+    // Make samples [0, end) exist (enqueue what is missing on the store's stream), then keep the store `ahead` samples further.  Returns
+    // the event a consumer stream has to wait for before it reads them, or nullptr when they are known to be complete.  (The event may
+    // be re-recorded by a later extension before the consumer waits on it: it then stands for a longer prefix -- still sufficient.)
+    hipEvent_t cover(size_t end, size_t ahead) {
+        end = std::min(end, cap);
+        extend_to(end);
+        hipEvent_t wait = nullptr;
+        if (end > done) {
+            const Mark* best = nullptr;
+            for (const Mark& m : mark) if (m.end >= end && (!best || m.end < best->end)) best = &m;
+            if (best) {
+                if (hipEventQuery(best->ev) == hipSuccess) done = std::max(done, best->end);
+                else wait = best->ev;
+            }
+        }
+        if (ahead) extend_to(end + ahead);
+        return wait;
+    }
+    // fallback count of an engine standing at sample t (diag): the settle's own + the recorded events below t
+    uint64_t be_count_at(long long t) {
+        std::vector<unsigned long long> h(1 + OW_TRAJ_BE_CAP);
+        { std::lock_guard<std::mutex> lk(mu); if (hipStreamSynchronize(stream) != hipSuccess) return be_settle; }
+        if (hipMemcpy(h.data(), d_be, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost) != hipSuccess) return be_settle;
+        uint64_t n = be_settle;
+        const size_t k = (size_t)std::min<unsigned long long>(h[0], OW_TRAJ_BE_CAP);
+        for (size_t i = 0; i < k; ++i) n += (long long)h[1 + i] < t;
+        if (h[0] > OW_TRAJ_BE_CAP) n += h[0] - OW_TRAJ_BE_CAP;     // beyond the list: counted, not placed
+        return n;
+    }
+};
+std::mutex g_traj_mu;
+std::map<std::pair<int, uint64_t>, std::shared_ptr<TremTraj>> g_traj;
+
+// the store of (device, hc.os_sr), created (and settled) on first use
+std::shared_ptr<TremTraj> traj_acquire(int device, const OwConsts& hc, const OwConsts& k48, bool use_settle_cache) {
+    uint64_t rate_bits; std::memcpy(&rate_bits, &hc.os_sr, 8);
+    const std::pair<int, uint64_t> key(device, rate_bits);
+    std::lock_guard<std::mutex> lk(g_traj_mu);
+    auto it = g_traj.find(key);
+    if (it != g_traj.end()) return it->second;
+    auto t = std::make_shared<TremTraj>();
+    t->device = device; t->os_sr = hc.os_sr;
+    double seconds = 1800.0;
+    if (const char* env = std::getenv("OW_TREM_TRAJ_SECONDS")) { const double v = std::atof(env); if (v > 0.0) seconds = v; }
+    const double want = std::min(seconds * hc.os_sr, 4.0e9);
+    t->cap = ((size_t)want + OW_TRAJ_CK - 1) / OW_TRAJ_CK * OW_TRAJ_CK;
+    HIP_OK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    for (auto& m : t->mark) HIP_OK(hipEventCreateWithFlags(&m.ev, hipEventDisableTiming));
+    HIP_OK(hipMalloc(&t->dK, sizeof(OwConsts)));
+    HIP_OK(hipMalloc(&t->d_r, sizeof(double) * (t->cap + 64)));
+    HIP_OK(hipMalloc(&t->d_state, sizeof(double) * 18));
+    HIP_OK(hipMalloc(&t->d_ckpt, sizeof(double) * OW_TRAJ_CKD * (t->cap / OW_TRAJ_CK + 2)));
+    HIP_OK(hipMalloc(&t->d_be, sizeof(unsigned long long) * (1 + OW_TRAJ_BE_CAP)));
+    HIP_OK(hipMalloc(&t->d_zero, sizeof(uint32_t)));
+    HIP_OK(hipMemsetAsync(t->d_be, 0, sizeof(unsigned long long) * (1 + OW_TRAJ_BE_CAP), t->stream));
+    HIP_OK(hipMemsetAsync(t->d_zero, 0, sizeof(uint32_t), t->stream));
+    HIP_OK(hipMemcpyAsync(t->dK, &hc, sizeof(OwConsts), hipMemcpyHostToDevice, t->stream));
+    DevMem dk48;
+    dk48.alloc(sizeof(OwConsts));
+    HIP_OK(hipMemcpyAsync(dk48.p, &k48, sizeof(OwConsts), hipMemcpyHostToDevice, t->stream));
+    const TremSettled ts = trem_settled_rows(device, hc.os_sr, t->dK, dk48.as<OwConsts>(), t->d_state, t->d_zero, t->stream, use_settle_cache);
+    std::memcpy(&t->be_settle, &ts.rows[17], 8);
+    HIP_OK(hipMemsetAsync(t->d_state + 17, 0, sizeof(double), t->stream));   // the trajectory's own events go to d_be
+    HIP_OK(hipStreamSynchronize(t->stream));
+    g_traj[key] = t;
+    return t;
 }
 
 enum { INIT_NEW = 1, INIT_RATE = 2, INIT_RESET = 0 };
@@ -440,7 +623,7 @@ static void launch_job_chain_legacy(const OwConsts* dK, const owdev::OwJobDev* d
         owdev::k_job_chain<false><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_in, d_out, nullptr, (int)n_jobs, n, stride);
 }
 
-ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int preamp_kind, int power_amp_kind, int tremolo_kind, bool voices_only);
+ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int preamp_kind, int power_amp_kind, int tremolo_kind, bool voices_only, bool no_traj = false);
 void pool_destroy(ow_pool* p);
 void pa_settled_to_device(int device, double* d_dst, hipStream_t st);
 
@@ -466,18 +649,36 @@ void run_job_chain(const JobChainCfg& cfg, const OwConsts* dK, const std::vector
     }
     const bool mpa = cfg.power_amp_kind == OW_POWER_AMP_MELANGE && any_pa;
     DevMem d_r, d_settled, d_att, d_amp, d_pac, d_pas;
+    std::shared_ptr<TremTraj> traj;
+    const double* trem = nullptr;
     if (any_trem) {
+        // Tremolo::new(depth, preamp rate) without a warm-up: every job's cell starts at t = 0 of the shared trajectory of this chain rate
         const bool os = cfg.sample_rate < 88200.0;
         const long long n_os = n * (os ? 2 : 1);
-        d_r.alloc(sizeof(double) * (size_t)n_os);
-        struct PoolGuard { ow_pool* p; ~PoolGuard() { pool_destroy(p); } } g{pool_create(cfg.sample_rate, 1, cfg.device, OW_PREAMP_LEGACY8, OW_POWER_AMP_BEHAVIORAL,
-                                                                                             OW_TREMOLO_TWIN_T, false)};
-        // the fresh pool's oscillator rows are Tremolo::new's settled state; n_os steps of Tremolo::process, R written per step
-        owdev::k_tremolo_wide<false><<<dim3(1), dim3(64), 0, g.p->stream>>>(g.p->dK, g.p->d_cs, d_r.as<double>(), 1, n_os, g.p->d_leaders, 1);
-        HIP_OK(hipGetLastError());
-        HIP_OK(hipStreamSynchronize(g.p->stream));
+        const Switches sw = Switches::from_env();          // offline entry point: read once per call
+        if (sw.trem_traj) {
+            std::unique_ptr<OwConsts> hc(new OwConsts()), k48(new OwConsts());
+            owhip::build_consts(*hc, cfg.sample_rate, OW_PREAMP_LEGACY8);
+            owhip::build_consts(*k48, 24000.0, OW_PREAMP_LEGACY8);
+            traj = traj_acquire(cfg.device, *hc, *k48, sw.trem_cache);
+            if ((size_t)n_os <= traj->cap) {
+                hipEvent_t ev;
+                { std::lock_guard<std::mutex> lk(traj->mu); ev = traj->cover((size_t)n_os, 0); }
+                if (ev) HIP_OK(hipStreamWaitEvent(st, ev, 0));
+                trem = traj->d_r;
+            }
+        }
+        if (!trem) {                                        // longer than the store: one oscillator for this call, from a pool of one
+            d_r.alloc(sizeof(double) * (size_t)n_os);
+            struct PoolGuard { ow_pool* p; ~PoolGuard() { pool_destroy(p); } } g{pool_create(cfg.sample_rate, 1, cfg.device, OW_PREAMP_LEGACY8, OW_POWER_AMP_BEHAVIORAL,
+                                                                                                 OW_TREMOLO_TWIN_T, false, /*no_traj=*/true)};
+            // the fresh pool's oscillator rows are Tremolo::new's settled state; n_os steps of Tremolo::process, R written per step
+            owdev::k_tremolo_wide<false><<<dim3(1), dim3(64), 0, g.p->stream>>>(g.p->dK, g.p->d_cs, d_r.as<double>(), 1, n_os, g.p->d_leaders, 1);
+            HIP_OK(hipGetLastError());
+            HIP_OK(hipStreamSynchronize(g.p->stream));
+            trem = d_r.as<double>();
+        }
     }
-    const double* trem = any_trem ? d_r.as<double>() : nullptr;
     double* chain_out = d_out;
     if (mpa) {
         d_att.alloc(sizeof(double) * n_jobs * (size_t)stride);
@@ -517,37 +718,23 @@ void run_job_chain(const JobChainCfg& cfg, const OwConsts* dK, const std::vector
 // (50 warm-up steps at the codegen matrices + 2 s at the pool rate), all in the product kernels.
 // Pools this small leave SIMDs idle, and the oscillator's serial latency is their block time: four lanes per engine (ow_trem_wide.h).
 // Melange power amp: engines dispatched by falling demand (OW_PA_SORT=0: in index order -- the same samples, tested)
-static bool power_amp_ordered() {     // read per block (a test flips it between two pools of one process)
-    const char* env = std::getenv("OW_PA_SORT");
-    return !(env && env[0] == '0');
-}
+static bool power_amp_ordered(const ow_pool* p) { return p->sw.pa_sort != 0; }
 // engines of k_post_mpa the chip holds at once: two workgroups of PA_EPB per CU (LDS)
-static int power_amp_resident_engines(int device) {
-    if (const char* env = std::getenv("OW_PA_SORT")) if (env[0] == '2') return PA_EPB;      // '2': order every block of more than one workgroup (tests)
+static int power_amp_resident_engines(const ow_pool* p) {
+    if (p->sw.pa_sort == 2) return PA_EPB;      // '2': order every block of more than one workgroup (tests)
     int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || cus <= 0) cus = 256;
     return cus * 2 * PA_EPB;
 }
 // OW_TREM_WIDE=0/1 forces the choice (the parity test compares the two kernels bit for bit).
-static inline bool trem_wide(int ne) {
-    if (const char* env = std::getenv("OW_TREM_WIDE")) return env[0] == '1';
-    return ne <= 16384;
-}
-// lane = group tremolo kernel at pool scale: serialise it in front of the voice kernel (OW_TREM_SERIAL=0/1 forces the choice)
-static inline bool trem_serialised(int n_leaders) {
-    // Measured at 131 072 engines / oscillators: serialised 31.8 ms per block (voices 12.8, tremolo 9.1 on an empty chip), overlapped
-    // 29.7 ms -- each kernel alone leaves issue slots the other can use.  So the default stays overlapped; OW_TREM_SERIAL=1 is how the
-    // two kernels' own times are measured (profiles/).
-    (void)n_leaders;
-    if (const char* env = std::getenv("OW_TREM_SERIAL")) return env[0] == '1';
-    return false;
-}
+static inline bool trem_wide(const ow_pool* p, int ne) { return p->sw.trem_wide >= 0 ? p->sw.trem_wide == 1 : ne <= 16384; }
+// lane = group tremolo kernel at pool scale, measured at 131 072 engines / oscillators: serialised in front of the voices 31.8 ms per
+// block (voices 12.8, tremolo 9.1 on an empty chip), overlapped 29.7 ms -- each kernel alone leaves issue slots the other can use.  So
+// the default stays overlapped; the serialised schedule is how the two kernels' own times are measured (profiles/).
+static inline bool trem_serialised(const ow_pool* p) { return p->sw.trem_serial; }
 // legacy preamp with a quad per solver state (k_preamp_wide): while the pool leaves most SIMDs empty the kernel's time is the serial
 // latency of one sample, which the quad shortens; beyond ~4 096 engines the lane-pair kernel's lower instruction count wins
-static inline bool preamp_wide(int ne) {
-    if (const char* env = std::getenv("OW_PREAMP_WIDE")) return env[0] == '1';
-    return ne <= 4096;
-}
+static inline bool preamp_wide(const ow_pool* p, int ne) { return p->sw.preamp_wide >= 0 ? p->sw.preamp_wide == 1 : ne <= 4096; }
 // ---- tremolo phase groups (see ow_pool) ---------------------------------------------------------------------------------
 void trem_groups_changed(ow_pool* p) {
     HIP_OK(hipMemcpyAsync(p->d_lead, p->h_lead, sizeof(uint32_t) * p->I, hipMemcpyHostToDevice, p->stream));
@@ -595,26 +782,88 @@ void trem_split_at_range(ow_pool* p, int e0, int ne) {
     p->split_e0 = e0; p->split_ne = ne;
 }
 // Compact list of the group leaders inside [e0, e0+ne) (groups do not straddle the range: trem_split_at_range) -> d_leaders.
+// Engines on the shared trajectory have no oscillator of their own and are not listed.
 void trem_leader_list(ow_pool* p, int e0, int ne) {
     if (p->lead_list_valid && p->lead_e0 == e0 && p->lead_ne == ne) return;
     if (p->stream_trem) HIP_OK(hipStreamSynchronize(p->stream_trem));   // a kernel still reading the old list (rare path: groups or range changed)
     int n = 0;
-    for (int k = 0; k < ne; ++k) if (p->h_lead[e0 + k] == (uint32_t)(e0 + k)) p->h_leaders[n++] = (uint32_t)(e0 + k);
+    const bool traj = p->traj != nullptr;
+    for (int k = 0; k < ne; ++k)
+        if (p->h_lead[e0 + k] == (uint32_t)(e0 + k) && !(traj && p->h_birth[e0 + k] != OW_OFF_TRAJ)) p->h_leaders[n++] = (uint32_t)(e0 + k);
     HIP_OK(hipMemcpy(p->d_leaders, p->h_leaders, sizeof(uint32_t) * std::max(n, 1), hipMemcpyHostToDevice));
     p->n_lead = n; p->lead_e0 = e0; p->lead_ne = ne; p->lead_list_valid = true;
+}
+
+// min over the engines on the trajectory of birth[e] (the oldest decides how far the store must reach); O(I), reset-class calls only
+void traj_recount(ow_pool* p) {
+    long long mn = p->trem_clock; size_t n = 0;
+    for (size_t e = 0; e < p->I; ++e) if (p->h_birth[e] != OW_OFF_TRAJ) { mn = std::min(mn, p->h_birth[e]); ++n; }
+    p->min_birth = mn; p->n_on_traj = n;
+}
+void traj_upload_births(ow_pool* p, int e0, int ne) {     // synchronous: h_birth is pageable and changes again right away
+    HIP_OK(hipMemcpy(p->d_birth + e0, p->h_birth.data() + e0, sizeof(long long) * (size_t)ne, hipMemcpyHostToDevice));
+}
+
+// Engines of [e0, e0+ne) whose next block would run past the end of the store leave the trajectory: each gets its own oscillator rows,
+// rebuilt from the checkpoint below its t and stepped up to it (k_trem_from_ckpt, < OW_TRAJ_CK steps), and is a phase group of one from
+// here on (per-group oscillator, as in rounds 1-3).  Cold: once in an engine's life, after OW_TREM_TRAJ_SECONDS without a reset.
+void trem_evict(ow_pool* p, int e0, int ne, int n_os) {
+    TremTraj* T = p->traj.get();
+    std::vector<uint32_t> eng; std::vector<long long> tp;
+    long long tmax = 0;
+    for (int k = 0; k < ne; ++k) {
+        const long long b = p->h_birth[e0 + k];
+        if (b == OW_OFF_TRAJ || (size_t)(p->trem_clock - b) + (size_t)n_os <= T->cap) continue;
+        eng.push_back((uint32_t)(e0 + k)); tp.push_back(p->trem_clock - b); tmax = std::max(tmax, p->trem_clock - b);
+    }
+    if (eng.empty()) return;
+    invalidate_spec(p);
+    HIP_OK(hipStreamSynchronize(p->stream));
+    hipEvent_t ev;
+    { std::lock_guard<std::mutex> lk(T->mu); ev = T->cover((size_t)tmax, 0); }
+    if (ev) HIP_OK(hipEventSynchronize(ev));
+    std::vector<unsigned long long> be(eng.size());
+    for (size_t i = 0; i < eng.size(); ++i) be[i] = T->be_count_at(tp[i]);
+    DevMem de, dt, db;
+    de.alloc(sizeof(uint32_t) * eng.size()); dt.alloc(sizeof(long long) * eng.size()); db.alloc(sizeof(unsigned long long) * eng.size());
+    HIP_OK(hipMemcpy(de.p, eng.data(), sizeof(uint32_t) * eng.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dt.p, tp.data(), sizeof(long long) * eng.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(db.p, be.data(), sizeof(unsigned long long) * eng.size(), hipMemcpyHostToDevice));
+    owdev::k_trem_from_ckpt<<<dim3((unsigned)((eng.size() + 63) / 64)), dim3(64), 0, p->stream>>>(p->dK, T->d_r, T->d_ckpt, p->d_cs, (int)p->I, de.as<uint32_t>(),
+                                                                                                    dt.as<long long>(), db.as<unsigned long long>(), (int)eng.size());
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(p->stream));
+    for (uint32_t e : eng) { p->h_birth[e] = OW_OFF_TRAJ; p->h_lead[e] = e; }
+    traj_upload_births(p, e0, ne);
+    traj_recount(p);
+    trem_groups_changed(p);
+    HIP_OK(hipStreamSynchronize(p->stream));
 }
 
 void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<double>& depth0) {
     invalidate_spec(p);
     HIP_OK(hipStreamSynchronize(p->stream));
     const int I = (int)p->I;
-    // the range's engines get identical fresh tremolo states below: cut them out of the groups they shared with engines outside the
-    // range (those keep their oscillator), then make the range one group led by its first engine
-    trem_split_at_range(p, e0, ne);
-    for (int k = 0; k < ne; ++k) p->h_lead[e0 + k] = (uint32_t)e0;
-    trem_groups_changed(p);
-    p->split_e0 = e0; p->split_ne = ne;
-    trem_leader_list(p, e0, ne);
+    const bool on_traj = p->traj != nullptr;
+    if (on_traj) {
+        // Tremolo::new / reset: the cell starts at t = 0 of the shared trajectory (its settled state IS Tremolo::new's) -- nothing to settle,
+        // nothing to copy; an engine that had left the trajectory for its own oscillator comes back
+        for (int k = 0; k < ne; ++k) {
+            if (p->h_birth[e0 + k] == OW_OFF_TRAJ) p->lead_list_valid = false;
+            p->h_birth[e0 + k] = p->trem_clock;
+            p->h_lead[e0 + k] = (uint32_t)(e0 + k);
+        }
+        traj_upload_births(p, e0, ne);
+        traj_recount(p);
+    } else {
+        // the range's engines get identical fresh tremolo states below: cut them out of the groups they shared with engines outside the
+        // range (those keep their oscillator), then make the range one group led by its first engine
+        trem_split_at_range(p, e0, ne);
+        for (int k = 0; k < ne; ++k) p->h_lead[e0 + k] = (uint32_t)e0;
+        trem_groups_changed(p);
+        p->split_e0 = e0; p->split_ne = ne;
+        trem_leader_list(p, e0, ne);
+    }
     if (mode == INIT_RESET) {
         // reset() snaps every smoother to ITS target (engine.rs:245-249), and LinearSmoother::set_target stores the target at once
         // (engine.rs:86-99) -- also for a setter call the device has not seen yet because no block was rendered since.  Hand the
@@ -638,51 +887,19 @@ void chain_init_range(ow_pool* p, int e0, int ne, int mode, const std::vector<do
         owdev::k_mel_init<<<dim3((2 * ne + 63) / 64), dim3(64), 0, p->stream>>>(p->d_cs, p->d_mel_settled, p->d_noise, I, e0, ne);
     if (p->power_amp_kind == OW_POWER_AMP_MELANGE)  // PowerAmp::new_at_sample_rate (new / set_sample_rate) or PowerAmp::reset (reset keeps last_good)
         owdev::k_mpa_init<<<dim3((ne + 63) / 64), dim3(64), 0, p->stream>>>(p->dPa, p->d_pa_settled, p->d_pa, I, e0, ne, mode != INIT_RESET ? 1 : 0);
-    const int nl = p->n_lead;          // == 1: the range is one phase group, led by e0
-    const int blocks = (nl + 63) / 64;
-    const long long n_settle = (long long)owhip::sat_u32(p->hc.os_sr * 2.0);
-    uint64_t rate_bits; std::memcpy(&rate_bits, &p->hc.os_sr, 8);
-    const std::pair<int, uint64_t> key(p->device, rate_bits);
-    const bool cacheable = nl == 1 && trem_cache_enabled();
-    bool from_cache = false;
-    double be_before = 0.0;
-    if (p->tremolo_kind == OW_TREMOLO_LEGACY_LFO) {
-        // legacy-tremolo build: nothing to settle, the LFO starts at phase 0 (k_chain_init)
-    } else {
-        if (cacheable) {
-            std::lock_guard<std::mutex> lk(g_mel_mu);
-            auto it = g_trem_settled.find(key);
-            if (it != g_trem_settled.end()) {
-                HIP_OK(hipMemcpyAsync(p->d_trem_settled, it->second.rows, sizeof(double) * 18, hipMemcpyHostToDevice, p->stream));
-                owdev::k_trem_load_settled<<<dim3(1), dim3(64), 0, p->stream>>>(p->d_cs, I, e0, p->d_trem_settled);
-                HIP_OK(hipStreamSynchronize(p->stream));    // the host rows must outlive the copy
-                from_cache = true;
-            } else {
-                HIP_OK(hipMemcpyAsync(&be_before, p->d_cs + (size_t)CS_T_BE * p->I + e0, sizeof(double), hipMemcpyDeviceToHost, p->stream));
-                HIP_OK(hipStreamSynchronize(p->stream));
-            }
-        }
-        if (from_cache) {
-        } else if (trem_wide(nl)) {   // few oscillators: four lanes per engine (ow_trem_wide.h); the 2-second settle is pure serial latency
-            owdev::k_tremolo_wide<true><<<dim3((nl + 15) / 16), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, nullptr, I, 50LL, p->d_leaders, nl);
-            owdev::k_tremolo_wide<true><<<dim3((nl + 15) / 16), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, nullptr, I, n_settle, p->d_leaders, nl);
+    if (!on_traj && p->tremolo_kind != OW_TREMOLO_LEGACY_LFO) {   // (legacy-tremolo build: nothing to settle, the LFO starts at phase 0, k_chain_init)
+        // the range is one phase group led by e0: Tremolo::new's settle (tremolo.rs:92-102) for that one oscillator
+        if (p->sw.trem_cache) {
+            trem_settled_rows(p->device, p->hc.os_sr, p->dK, p->dK48, p->d_trem_settled, p->d_zero, p->stream, true);
+            owdev::k_trem_load_settled<<<dim3(1), dim3(64), 0, p->stream>>>(p->d_cs, I, e0, p->d_trem_settled);
         } else {
-            owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, I, p->d_leaders, nl, 50LL);
-            owdev::k_trem_settle<<<dim3(blocks), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, I, p->d_leaders, nl, n_settle);
+            const long long n_settle = (long long)owhip::sat_u32(p->hc.os_sr * 2.0);
+            owdev::k_tremolo_wide<true><<<dim3(1), dim3(64), 0, p->stream>>>(p->dK48, p->d_cs, nullptr, I, 50LL, p->d_leaders, 1);
+            owdev::k_tremolo_wide<true><<<dim3(1), dim3(64), 0, p->stream>>>(p->dK, p->d_cs, nullptr, I, n_settle, p->d_leaders, 1);
         }
     }
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(p->stream));   // the tremolo stream picks these rows up next (init-time sync)
-    if (cacheable && !from_cache && p->tremolo_kind != OW_TREMOLO_LEGACY_LFO) {   // first settle at this rate on this device: keep it
-        TremSettled t;
-        HIP_OK(hipMemcpy2D(t.rows, sizeof(double), p->d_cs + e0, sizeof(double) * p->I, sizeof(double), 18, hipMemcpyDeviceToHost));
-        uint64_t b0, b1;
-        std::memcpy(&b0, &be_before, 8); std::memcpy(&b1, &t.rows[17], 8);
-        const uint64_t delta = b1 - b0;
-        std::memcpy(&t.rows[17], &delta, 8);
-        std::lock_guard<std::mutex> lk(g_mel_mu);
-        g_trem_settled[key] = t;
-    }
 }
 
 void upload_consts(ow_pool* p, double sr, int preamp_kind) {
@@ -694,6 +911,10 @@ void upload_consts(ow_pool* p, double sr, int preamp_kind) {
     k48.tremolo_kind = (uint32_t)p->tremolo_kind;
     HIP_OK(hipMemcpyAsync(p->dK, &p->hc, sizeof(OwConsts), hipMemcpyHostToDevice, p->stream));
     HIP_OK(hipMemcpyAsync(p->dK48, &k48, sizeof(OwConsts), hipMemcpyHostToDevice, p->stream));
+    // the shared trajectory of this (device, chain rate); the callers (pool_create, set_sample_rate) re-initialise every engine next
+    p->traj.reset();
+    if (!p->voices_only && p->tremolo_kind == OW_TREMOLO_TWIN_T && p->sw.trem_traj) p->traj = traj_acquire(p->device, p->hc, k48, p->sw.trem_cache);
+    if (!p->traj) { std::fill(p->h_birth.begin(), p->h_birth.end(), OW_OFF_TRAJ); if (p->d_birth) traj_upload_births(p, 0, (int)p->I); p->n_on_traj = 0; }
     if (p->power_amp_kind == OW_POWER_AMP_MELANGE) {
         std::unique_ptr<OwPaConsts> hpa(new OwPaConsts());
         owhip::build_pa_consts(*hpa, p->hc.os_sr);          // the amp runs at the chain rate (engine.rs:207-213)
@@ -729,38 +950,23 @@ static size_t effective_cpus() {
 size_t Workers::host_threads() { return std::min<size_t>(effective_cpus(), OW_MAX_SLICES); }
 
 // Melange preamp: the default kernel re-factors the 12x12 system for every sample whose R_ldr moved, operation for operation like the
-// reference (ow_melange_lit.h).  OW_MEL_RANK1=1 selects the rank-one (Sherman-Morrison) kernel instead: ~3x faster, mathematically the
-// same, but without the LU's rounding noise, i.e. up to 1.8e-7 V away from the reference while R_ldr moves fast (DESIGN.md deviation 6).
-static inline bool melange_rank_one() {
-    const char* env = std::getenv("OW_MEL_RANK1");
-    return env && env[0] == '1';
-}
-
-static inline bool melange_lds_matrix() {        // OW_MEL_LDS=1: the round-2 literal kernel (S of every engine in LDS, lane pair shares one rebuild)
-    const char* env = std::getenv("OW_MEL_LDS");
-    return env && env[0] == '1';
-}
-
-static inline bool melange_generic_only() {      // OW_MEL_GENERIC=1: the literal kernel without its precomputed fast path
-    const char* env = std::getenv("OW_MEL_GENERIC");
-    return env && env[0] == '1';
-}
+// reference (ow_melange_col.h).  OW_MEL_RANK1=1 selects the rank-one (Sherman-Morrison) kernel instead: mathematically the same, but
+// without the LU's rounding noise, i.e. up to 1.8e-7 V away from the reference while R_ldr moves fast (DESIGN.md deviation 6);
+// OW_MEL_LDS=1 the round-2 literal kernel (S of every engine in LDS); OW_MEL_GENERIC=1 the literal kernels without their fast path.
+static inline bool melange_rank_one(const ow_pool* p) { return p->sw.mel_rank1; }
+static inline bool melange_lds_matrix(const ow_pool* p) { return p->sw.mel_lds; }
+static inline bool melange_generic_only(const ow_pool* p) { return p->sw.mel_generic; }
 
 // Stages of the staged render.  Off by default: OW_PIPE=n (2..8) cuts big ranges (>= 32 768 engines) into n engine stages on their own
-// streams, chained stage to stage, so that the output copy of a stage runs beside the kernels of the next one.
-static inline int pipeline_stages(int ne, bool to_host) {
-    static const int forced = [] { const char* env = std::getenv("OW_PIPE"); const int v = env ? std::atoi(env) : 0; return (v >= 1 && v <= OW_MAX_STAGES) ? v : 0; }();
-    (void)to_host;
+// streams, chained stage to stage, so that the output copy of a stage runs beside the kernels of the next one.  Measured: stages cost
+// more than the copy overlap they buy ("what did not work").
+static inline int pipeline_stages(const ow_pool* p, int ne) {
     if (ne < 32768) return 1;
-    return forced ? forced : 1;       // measured: stages cost more than the copy overlap they buy ("what did not work")
+    return p->sw.pipe ? p->sw.pipe : 1;
 }
 // OW_PIPE_OVERLAP=1: chain the stages voice kernel to voice kernel instead of stage to stage, so that the chain kernels of stage k run
-// beside the voice kernel of stage k+1.  Measured slower at every stage count (DESIGN.md "what did not work"); kept as a switch so the
-// measurement can be repeated.
-static inline bool pipeline_overlap() {
-    static const bool on = [] { const char* env = std::getenv("OW_PIPE_OVERLAP"); return env && env[0] == '1'; }();
-    return on;
-}
+// beside the voice kernel of stage k+1.  Measured slower at every stage count; kept as a switch so the measurement can be repeated.
+static inline bool pipeline_overlap(const ow_pool* p) { return p->sw.pipe_overlap; }
 
 // Deal the sounding voices of engines [e0, e0+ne) into wavefront-sized blocks (see ow_kernels.h, "Packed dispatch").
 // general = engines whose status after the previous block reported a transient phase, or that receive ops in this block (a note-on
@@ -769,7 +975,7 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
     // Big ranges are cut into T engine slices that are packed independently (each slice starts on a block boundary, so at most
     // T - 1 blocks are less full than they could be): pass 1 sizes the three lists of every slice, a prefix sum places them,
     // pass 2 writes the entries.
-    const int NP = pipeline_stages(ne, true);                  // stage boundaries exist whether or not this block uses them
+    const int NP = pipeline_stages(p, ne);                     // stage boundaries exist whether or not this block uses them
     size_t T = ne >= 16384 ? std::min<size_t>(effective_cpus(), 32) : 1;
     if (NP > 1) T = std::max<size_t>(NP, T - T % (size_t)NP);   // stages are whole numbers of slices
     // slices (and with them the stages of a staged render) start on multiples of 32 engines: the chain kernels' workgroups then never
@@ -821,7 +1027,7 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
 static void launch_tremolo(ow_pool* p, hipStream_t tt, double* rbuf, int n_os) {
     const int I = (int)p->I, nl = p->n_lead;
     if (p->tremolo_kind == OW_TREMOLO_LEGACY_LFO) owdev::k_tremolo_lfo<<<dim3((nl + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, rbuf, I, (long long)n_os, p->d_leaders, nl, 0LL);
-    else if (trem_wide(nl)) owdev::k_tremolo_wide<false><<<dim3((nl + 15) / 16), dim3(64), 0, tt>>>(p->dK, p->d_cs, rbuf, I, (long long)n_os, p->d_leaders, nl);
+    else if (trem_wide(p, nl)) owdev::k_tremolo_wide<false><<<dim3((nl + 15) / 16), dim3(64), 0, tt>>>(p->dK, p->d_cs, rbuf, I, (long long)n_os, p->d_leaders, nl);
     else owdev::k_tremolo<<<dim3((nl + 63) / 64), dim3(64), 0, tt>>>(p->dK, p->d_cs, rbuf, I, n_os, p->d_leaders, nl);
 }
 
@@ -833,10 +1039,27 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
     const int L = (int)len, Lcap = (int)p->Lcap;
     p->out_ld = len;
     hipStream_t st = p->stream, tt = p->stream_trem;
-    // ---- tremolo stream: CdS cell resistance of this block (already there if the block-ahead speculation hit)
+    // ---- tremolo: CdS cell resistance of this block
     const int n_os = L * (p->hc.oversample ? 2 : 1);
     const size_t rb_half = (size_t)2 * p->Lcap * p->I;
     const bool chain = !p->voices_only;     // a voices-only pool (ow_render_note) stops at the voice sums
+    const bool whole = e0 == 0 && ne == I;
+    // (a) engines on the shared trajectory read r_ldr[t .. t + n_os) at their own t = clock - birth: make the store reach the oldest one's
+    //     block (nothing to do unless this pool holds the process's oldest engine), plus one block ahead on the store's own stream
+    owdev::OwTremSrc tsrc{nullptr, p->d_lead, nullptr, p->d_birth};
+    hipEvent_t traj_ready = nullptr;
+    if (chain && p->traj) {
+        long long mn = p->min_birth;
+        if (!whole) { mn = p->trem_clock; for (int k = 0; k < ne; ++k) if (p->h_birth[e0 + k] != OW_OFF_TRAJ) mn = std::min(mn, p->h_birth[e0 + k]); }
+        if ((size_t)(p->trem_clock - mn) + (size_t)n_os > p->traj->cap) { trem_evict(p, e0, ne, n_os); mn = p->trem_clock; for (int k = 0; k < ne; ++k) if (p->h_birth[e0 + k] != OW_OFF_TRAJ) mn = std::min(mn, p->h_birth[e0 + k]); }
+        const size_t need = (size_t)(p->trem_clock - mn) + (size_t)n_os;
+        {
+            std::lock_guard<std::mutex> lk(p->traj->mu);
+            traj_ready = p->traj->cover(need, (size_t)n_os);
+        }
+        tsrc.traj = p->traj->d_r + p->trem_clock;
+    }
+    // (b) engines with an oscillator of their own (phase groups): already there if the block-ahead speculation hit
     const bool hit = chain && p->spec.valid && p->spec.e0 == e0 && p->spec.ne == ne && p->spec.n_os == n_os;
     if (p->spec.valid && !hit) {   // mis-speculated (different block length / engine range): roll the oscillator back
         HIP_OK(hipMemcpyAsync(p->d_cs, p->d_trem_backup, sizeof(double) * 18 * p->I, hipMemcpyDeviceToDevice, tt));
@@ -845,16 +1068,18 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
     if (chain) {
         // a sub-range advances on its own: its engines leave the phase groups they share with engines outside it (no-op for the whole pool
         // and for a range that was just initialised); then the oscillators to run are the group leaders inside the range
-        trem_split_at_range(p, e0, ne);
+        if (p->n_on_traj < p->I) trem_split_at_range(p, e0, ne);
         trem_leader_list(p, e0, ne);
         if (hit) {
             p->rb_cur ^= 1;            // the half the speculation filled
-        } else {
+        } else if (p->n_lead > 0) {
             launch_tremolo(p, tt, p->d_rbuf + p->rb_cur * rb_half, n_os);
             HIP_OK(hipEventRecord(p->ev_trem[p->rb_cur], tt));
         }
     }
+    const bool own_osc = chain && p->n_lead > 0;
     const double* rb_now = p->d_rbuf + p->rb_cur * rb_half;
+    tsrc.rbuf = rb_now;
     const int rb_now_idx = p->rb_cur;
     // ---- next block, speculatively: back up the oscillator rows, then run ahead into the other half
     auto launch_block_ahead = [&] {
@@ -866,12 +1091,13 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         HIP_OK(hipEventRecord(p->ev_trem[nxt], tt));
         p->spec.valid = true; p->spec.e0 = e0; p->spec.ne = ne; p->spec.n_os = n_os;
     };
-    // The oscillator goes first: it needs nothing from the host, so it runs while the host packs ops and voice lists, and its
-    // 1 024 wavefronts (one per SIMD) are resident before the voice kernel fills the rest.  (k_apply_ops is register-capped so that
-    // it fits beside them.)
-    if (chain) launch_block_ahead();
+    // The oscillators go first: they need nothing from the host, so they run while the host packs ops and voice lists, and their
+    // wavefronts (one per SIMD at 65 536 of them) are resident before the voice kernel fills the rest.  (k_apply_ops is register-capped
+    // so that it fits beside them.)
+    if (own_osc) launch_block_ahead();
+    else if (chain && p->profiling) { HIP_OK(hipEventRecord(p->ev[6], tt)); HIP_OK(hipEventRecord(p->ev[7], tt)); }
     // OW_TREM_SERIAL=1 (measurement switch, see trem_serialised): the voices of this block wait for the block-ahead oscillators
-    if (chain && trem_serialised(p->n_lead)) HIP_OK(hipStreamWaitEvent(st, p->ev_trem[p->rb_cur ^ 1], 0));
+    if (own_osc && trem_serialised(p)) HIP_OK(hipStreamWaitEvent(st, p->ev_trem[p->rb_cur ^ 1], 0));
     // ---- per-engine args + ops: only engines whose host state changed are touched (the rest keep their
     // uploaded args; a steady-state step of a large pool does no per-engine host work here)
     // Large pools split the range over host threads: slice t counts its pending ops, a prefix sum places the slices in h_ops,
@@ -951,8 +1177,8 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         p->lists_valid = !any_dirty;     // engines with ops were classified "general" for this block only
     }
     // ---- stages (see ow_pool::slice_start).  Without voices the lists are not built: one stage.
-    const int NP = voices ? std::min(pipeline_stages(ne, out_host != nullptr), p->slice_T) : 1;
-    const bool overlap = pipeline_overlap();
+    const int NP = voices ? std::min(pipeline_stages(p, ne), p->slice_T) : 1;
+    const bool overlap = pipeline_overlap(p);
     p->last_np = NP;
     if (NP > 1) HIP_OK(hipEventRecord(p->ev_ready, st));      // args, ops and voice lists are in place
     const bool tabs = (size_t)p->vl_general.n_blocks * 4 < (size_t)ne;   // sparse general list (played input): tabulated phase gains
@@ -982,23 +1208,24 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         }
         if (overlap && k + 1 < NP) HIP_OK(hipEventRecord(p->ev_voice_done[k], s));
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][1], s));
-        if (chain) HIP_OK(hipStreamWaitEvent(s, p->ev_trem[rb_now_idx], 0));
+        if (own_osc || hit) HIP_OK(hipStreamWaitEvent(s, p->ev_trem[rb_now_idx], 0));
+        if (traj_ready) HIP_OK(hipStreamWaitEvent(s, traj_ready, 0));
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][2], s));
         if (sne > 0 && chain) {
-            if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one() && p->hc.ml_sparse_ok && !melange_lds_matrix())
-                owdev::k_preamp_mel_col<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
-                                                                                 p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne, melange_generic_only() ? 1 : 0,
+            if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one(p) && p->hc.ml_sparse_ok && !melange_lds_matrix(p))
+                owdev::k_preamp_mel_col<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, tsrc,
+                                                                                 p->d_pre, p->d_noise, I, L, Lcap, se0, sne, melange_generic_only(p) ? 1 : 0,
                                                                                  p->d_mel_lu, p->mel_lu_ld);
-            else if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one())
-                owdev::k_preamp_mel_lit<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
-                                                                                 p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne, melange_generic_only() ? 1 : 0, p->d_mel_lu);
+            else if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one(p))
+                owdev::k_preamp_mel_lit<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, tsrc,
+                                                                                 p->d_pre, p->d_noise, I, L, Lcap, se0, sne, melange_generic_only(p) ? 1 : 0, p->d_mel_lu);
             else if (p->hc.preamp_kind == OW_PREAMP_MELANGE12)
-                owdev::k_preamp_mel<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, rb_now,
-                                                                             p->d_lead, p->d_pre, p->d_noise, I, L, Lcap, se0, sne);
-            else if (preamp_wide(sne))
-                owdev::k_preamp_wide<<<dim3((sne + 7) / 8), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, rb_now, p->d_lead, p->d_pre, I, L, Lcap, se0, sne);
+                owdev::k_preamp_mel<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, tsrc,
+                                                                             p->d_pre, p->d_noise, I, L, Lcap, se0, sne);
+            else if (preamp_wide(p, sne))
+                owdev::k_preamp_wide<<<dim3((sne + 7) / 8), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, tsrc, p->d_pre, I, L, Lcap, se0, sne);
             else
-                owdev::k_preamp<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, rb_now, p->d_lead, p->d_pre, I, L, Lcap, se0, sne);
+                owdev::k_preamp<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, tsrc, p->d_pre, I, L, Lcap, se0, sne);
         }
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][3], s));
         if (!chain) {
@@ -1007,7 +1234,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
             // more engines than one workgroup: dispatch them by falling demand of their last block (see k_post_mpa)
             // -- when the block has more engines than the chip holds at once (two workgroups of 32 per CU); below that every wavefront
             // is resident from the start, the block lasts as long as its slowest engine and the order cannot matter
-            const bool ordered = power_amp_ordered() && ne > power_amp_resident_engines(p->device);
+            const bool ordered = power_amp_ordered(p) && ne > power_amp_resident_engines(p);
             if (ordered) {
                 uint32_t* hist = p->d_pa_hist + (size_t)k * PA_ORDER_CLASSES;
                 const uint32_t total = (uint32_t)L * (p->hc.oversample ? 2u : 1u);
@@ -1035,6 +1262,14 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         if (k > 0) HIP_OK(hipEventRecord(p->ev_stage_done[k], s));
     }
     for (int k = 1; k < NP; ++k) HIP_OK(hipStreamWaitEvent(st, p->ev_stage_done[k], 0));
+    if (chain && p->traj) {          // the engines of the range are n_os samples further along the trajectory
+        if (whole) p->trem_clock += n_os;
+        else {
+            for (int k = 0; k < ne; ++k) if (p->h_birth[e0 + k] != OW_OFF_TRAJ) { p->h_birth[e0 + k] -= n_os; p->min_birth = std::min(p->min_birth, p->h_birth[e0 + k]); }
+            owdev::k_trem_birth_shift<<<dim3((ne + 255) / 256), dim3(256), 0, st>>>(p->d_birth, e0, ne, -(long long)n_os);
+        }
+    }
+    p->last_n_os = n_os;
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(p->h_eout + e0, p->d_eout + e0, sizeof(OwEngineOut) * ne, hipMemcpyDeviceToHost, st));
 }
@@ -1238,7 +1473,7 @@ void push_op(ow_engine* en, uint8_t type, int slot, uint8_t note, bool mlp, uint
 }
 
 ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int preamp_kind, int power_amp_kind = OW_POWER_AMP_BEHAVIORAL,
-                     int tremolo_kind = OW_TREMOLO_TWIN_T, bool voices_only = false) {
+                     int tremolo_kind = OW_TREMOLO_TWIN_T, bool voices_only = false, bool no_traj) {
     if (!(sample_rate > 0.0) || n_engines == 0) throw std::runtime_error("invalid sample rate or engine count");
     if (tremolo_kind != OW_TREMOLO_TWIN_T && tremolo_kind != OW_TREMOLO_LEGACY_LFO) throw std::runtime_error("unknown tremolo_kind");
     if (preamp_kind != OW_PREAMP_LEGACY8 && preamp_kind != OW_PREAMP_MELANGE12) throw std::runtime_error("unknown preamp_kind");
@@ -1267,6 +1502,12 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     for (auto& e : p->ev_trem) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_OK(hipMalloc(&p->d_trem_backup, sizeof(double) * 18 * n_engines));
     HIP_OK(hipMalloc(&p->d_trem_settled, sizeof(double) * 18));
+    HIP_OK(hipMalloc(&p->d_zero, sizeof(uint32_t)));
+    HIP_OK(hipMemsetAsync(p->d_zero, 0, sizeof(uint32_t), p->stream));
+    HIP_OK(hipMalloc(&p->d_birth, sizeof(long long) * n_engines));
+    p->h_birth.assign(n_engines, OW_OFF_TRAJ);
+    p->sw = Switches::from_env();
+    if (no_traj) p->sw.trem_traj = false;
     HIP_OK(hipMalloc(&p->dK, sizeof(OwConsts)));
     HIP_OK(hipMalloc(&p->dK48, sizeof(OwConsts)));
     HIP_OK(hipMalloc(&p->d_nt, sizeof(double) * NT_COUNT * 64));
@@ -1354,7 +1595,13 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
         owdev::k_chain_replicate<<<dim3((unsigned)((n_engines + 63) / 64)), dim3(64), 0, p->stream>>>(p->d_cs, (int)n_engines, 0, 0, (int)n_engines);
     if (power_amp_kind == OW_POWER_AMP_MELANGE && n_engines > 1)          // the amp state is not part of the replicated chain rows
         owdev::k_mpa_init<<<dim3((unsigned)((n_engines + 63) / 64)), dim3(64), 0, p->stream>>>(p->dPa, p->d_pa_settled, p->d_pa, (int)n_engines, 0, (int)n_engines, 1);
-    for (size_t i = 0; i < n_engines; ++i) p->h_lead[i] = 0u;             // identical oscillators: one tremolo phase group led by engine 0
+    if (p->traj) {                    // every engine at t = 0 of the shared trajectory
+        for (size_t i = 0; i < n_engines; ++i) { p->h_birth[i] = p->trem_clock; p->h_lead[i] = (uint32_t)i; }
+        traj_upload_births(p, 0, (int)n_engines);
+        traj_recount(p);
+    } else {
+        for (size_t i = 0; i < n_engines; ++i) p->h_lead[i] = 0u;         // identical oscillators: one tremolo phase group led by engine 0
+    }
     trem_groups_changed(p);
     if (p->d_noise)   // the replicated chain state does not carry the noise columns: seed every engine's streams
         owdev::k_mel_noise_seed<<<dim3((unsigned)((n_engines + 63) / 64)), dim3(64), 0, p->stream>>>(p->d_noise, (int)n_engines, 0, (int)n_engines);
@@ -1405,6 +1652,8 @@ void pool_destroy(ow_pool* p) {
     for (auto& e : p->ev_trem) if (e) hipEventDestroy(e);
     if (p->d_trem_backup) hipFree(p->d_trem_backup);
     if (p->d_trem_settled) hipFree(p->d_trem_settled);
+    if (p->d_zero) hipFree(p->d_zero);
+    if (p->d_birth) hipFree(p->d_birth);
     if (p->stream_trem) hipStreamDestroy(p->stream_trem);
     if (p->stream) hipStreamDestroy(p->stream);
     for (ow_engine* en : p->engines) delete en;
@@ -1489,7 +1738,7 @@ void ow_pool_render(ow_pool* p, float* out_host, size_t out_stride, size_t len) 
         HIP_OK(hipSetDevice(p->device));
         if (p->inject_faults > 0) { --p->inject_faults; throw std::runtime_error("injected fault (ow_test_inject_render_faults)"); }
         if (len > p->Lcap) { HIP_OK(hipStreamSynchronize(p->stream)); alloc_stream_buffers(p, len); }  // auto-grow, engine.rs:430
-        static const bool hostprof = std::getenv("OW_HOST_PROFILE") != nullptr;
+        const bool hostprof = p->sw.host_profile;
         auto t0 = std::chrono::steady_clock::now();
         render_range(p, 0, (int)p->I, len, true, out_host, out_stride);
         auto t1 = std::chrono::steady_clock::now();
@@ -1521,6 +1770,26 @@ const float* ow_pool_device_output(const ow_pool* p, size_t* stride) {
     if (!p) return nullptr;
     if (stride) *stride = p->out_ld;
     return p->d_out;
+}
+
+// Shared tremolo trajectory of (device, the chain rate of host rate `sample_rate`): make its first `seconds` exist now (blocking), e.g.
+// when a host instantiates the plugin, so that no engine ever waits for the single oscillator that extends it.  Returns the number of
+// samples the store holds afterwards, <0 on error.
+long long ow_tremolo_prefetch(double sample_rate, int device, double seconds) {
+    try {
+        if (!(sample_rate > 0.0) || !(seconds >= 0.0)) throw std::runtime_error("bad argument");
+        HIP_OK(hipSetDevice(device));
+        std::unique_ptr<OwConsts> hc(new OwConsts()), k48(new OwConsts());
+        owhip::build_consts(*hc, sample_rate, OW_PREAMP_LEGACY8);
+        owhip::build_consts(*k48, 24000.0, OW_PREAMP_LEGACY8);
+        const Switches sw = Switches::from_env();
+        std::shared_ptr<TremTraj> t = traj_acquire(device, *hc, *k48, sw.trem_cache);
+        hipEvent_t ev;
+        { std::lock_guard<std::mutex> lk(t->mu); ev = t->cover((size_t)std::min(seconds * hc->os_sr, (double)t->cap), 0); }
+        if (ev) HIP_OK(hipEventSynchronize(ev));
+        std::lock_guard<std::mutex> lk(t->mu);
+        return (long long)t->len;
+    } catch (const std::exception& ex) { set_err(std::string("ow_tremolo_prefetch: ") + ex.what()); return -1; }
 }
 
 int ow_pool_read_voice_sum(ow_pool* p, double* out_host, size_t out_stride, size_t len) {
@@ -1567,8 +1836,25 @@ int ow_pool_read_tremolo_r(ow_pool* p, double* out_host, size_t out_stride, size
         std::vector<double> a(I * n_os);
         const double* src = p->d_rbuf + (size_t)p->rb_cur * (2 * p->Lcap * I);   // the half the last block consumed, [n_os][I]
         HIP_OK(hipMemcpy(a.data(), src, sizeof(double) * I * n_os, hipMemcpyDeviceToHost));
-        for (size_t e = 0; e < I; ++e)
+        std::vector<double> tr;
+        if (p->traj && p->n_on_traj) {     // engines on the shared trajectory: the n_os samples below their present t
+            if ((long long)n_os > p->last_n_os) throw std::runtime_error("more samples than the last block consumed");
+            { std::lock_guard<std::mutex> lk(p->traj->mu); HIP_OK(hipStreamSynchronize(p->traj->stream)); }
+            HIP_OK(hipStreamSynchronize(p->stream));
+            DevMem g;
+            g.alloc(sizeof(double) * I * n_os);
+            // the block consumed [t_end - last_n_os, t_end); its first n_os samples are asked for
+            owdev::k_trem_traj_gather<<<dim3((unsigned)((n_os + 255) / 256), (unsigned)I), dim3(256), 0, p->stream>>>(
+                p->traj->d_r + p->trem_clock - (p->last_n_os - (long long)n_os), p->d_birth, (int)I, (long long)n_os, g.as<double>());
+            HIP_OK(hipGetLastError());
+            tr.resize(I * n_os);
+            HIP_OK(hipMemcpyAsync(tr.data(), g.p, sizeof(double) * I * n_os, hipMemcpyDeviceToHost, p->stream));
+            HIP_OK(hipStreamSynchronize(p->stream));
+        }
+        for (size_t e = 0; e < I; ++e) {
+            if (!tr.empty() && p->h_birth[e] != OW_OFF_TRAJ) { std::memcpy(out_host + e * out_stride, tr.data() + e * n_os, sizeof(double) * n_os); continue; }
             for (size_t n = 0; n < n_os; ++n) out_host[e * out_stride + n] = a[n * I + p->h_lead[e]];   // the column of the engine's phase group
+        }
         return 0;
     } catch (const std::exception& ex) { set_err(std::string("ow_pool_read_tremolo_r: ") + ex.what()); return -1; }
 }
@@ -1752,7 +2038,9 @@ void ow_engine_get_diag(const ow_engine* e, ow_diag* d) {
         std::memcpy(&bits, &diag, 8);
         d->preamp_nan_resets = (uint32_t)(bits >> 32);
         double be = 0.0;   // counts the block-ahead samples too
-        if (hipMemcpy(&be, p->d_cs + (size_t)CS_T_BE * p->I + p->h_lead[e->index], sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
+        if (p->traj && p->h_birth[e->index] != OW_OFF_TRAJ) {
+            d->tremolo_be_fallbacks = p->traj->be_count_at(p->trem_clock - p->h_birth[e->index]);
+        } else if (hipMemcpy(&be, p->d_cs + (size_t)CS_T_BE * p->I + p->h_lead[e->index], sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
             std::memcpy(&bits, &be, 8);
             d->tremolo_be_fallbacks = bits;
         }
@@ -1781,7 +2069,7 @@ void ow_pool_midi(ow_pool* p, const ow_midi_event* ev, size_t n) {
     // Engines are independent state machines: large event lists are applied by the persistent host workers, each slice owning a
     // contiguous range of engines and walking the list in array order (per-engine order is what matters).  No allocation here.
     size_t T = std::min<size_t>(effective_cpus(), OW_MAX_SLICES);
-    if (const char* env = std::getenv("OW_MIDI_THREADS")) { const long v = std::atol(env); if (v >= 1 && v <= OW_MAX_SLICES) T = (size_t)v; }
+    if (p->sw.midi_threads) T = (size_t)p->sw.midi_threads;
     if (n < 4096 || p->I < 2 * T) T = 1;
     if (T == 1) {
         for (size_t i = 0; i < n; ++i) if (ev[i].engine < p->I) midi_apply_one(p, ev[i]);
@@ -1855,6 +2143,17 @@ int ow_test_pool_stagger_tremolo(ow_pool* p, size_t n_groups) {
         invalidate_spec(p);
         HIP_OK(hipStreamSynchronize(p->stream));
         const uint32_t I = (uint32_t)p->I, G = (uint32_t)n_groups;
+        const long long period0 = (long long)(p->hc.os_sr / 5.6);
+        const long long step0 = std::max<long long>(1, period0 / (long long)G);
+        if (p->traj) {
+            // on the shared trajectory "group g runs g * step samples ahead" is a shift of its engines' births (from the pool's common t)
+            if (p->n_on_traj != p->I) throw std::runtime_error("stagger: an engine has left the trajectory");
+            const long long b0 = p->min_birth;
+            for (uint32_t e = 0; e < I; ++e) p->h_birth[e] = b0 - (long long)(e % G) * step0;
+            traj_upload_births(p, 0, (int)I);
+            traj_recount(p);
+            return 0;
+        }
         // every engine takes the oscillator state of its current leader, then group g = {g, g + G, ...} is led by engine g
         size_t n_copy = 0;
         for (uint32_t g = 0; g < G; ++g) { p->h_copy[n_copy] = p->h_lead[g]; p->h_copy[I + n_copy] = g; ++n_copy; }
@@ -1881,6 +2180,12 @@ int ow_test_pool_stagger_tremolo(ow_pool* p, size_t n_groups) {
 size_t ow_test_pool_tremolo_groups(const ow_pool* p) {
     if (!p) return 0;
     size_t n = 0;
+    if (p->traj) {       // distinct tremolo phases: engines on the trajectory share an oscillator exactly when they stand at the same t
+        std::vector<long long> b;
+        for (size_t e = 0; e < p->I; ++e) { if (p->h_birth[e] != OW_OFF_TRAJ) b.push_back(p->h_birth[e]); else n += p->h_lead[e] == (uint32_t)e; }
+        std::sort(b.begin(), b.end());
+        return n + (size_t)(std::unique(b.begin(), b.end()) - b.begin());
+    }
     for (size_t e = 0; e < p->I; ++e) n += p->h_lead[e] == (uint32_t)e;
     return n;
 }
@@ -1985,6 +2290,7 @@ int ow_test_clear_settle_caches(void) {
     std::lock_guard<std::mutex> lk(g_mel_mu);
     const int n = (int)g_trem_settled.size();
     g_trem_settled.clear(); g_mel_settled.clear(); g_pa_settled.clear();
+    { std::lock_guard<std::mutex> lt(g_traj_mu); g_traj.clear(); }     // pools that hold a store keep it alive; new pools start a new one
     return n;
 }
 // Overwrite one field of a voice record (VF_* of ow_types.h) on the device before the next block: the way to make a voice non-finite,
@@ -2023,6 +2329,47 @@ int ow_test_host_melange_paths(double rate) {
     } catch (const std::exception& ex) { set_err(std::string("ow_test_host_melange_paths: ") + ex.what()); return -1; }
 }
 void ow_test_inject_render_faults(ow_pool* p, int n_renders) { if (p) p->inject_faults = n_renders > 0 ? n_renders : 0; }
+// One latched switch of a live pool (struct Switches; the OW_* environment variables are only read when a pool is created).
+int ow_test_pool_set_switch(ow_pool* p, const char* name, int value) {
+    if (!p || !name) return -1;
+    const std::string n(name);
+    if (hipSetDevice(p->device) != hipSuccess) return -1;
+    invalidate_spec(p);                                   // a pending block-ahead result was produced under the old schedule
+    if (hipStreamSynchronize(p->stream) != hipSuccess) return -1;
+    Switches& w = p->sw;
+    if (n == "trem_serial") w.trem_serial = value != 0;
+    else if (n == "trem_wide") w.trem_wide = value < 0 ? -1 : (value != 0);
+    else if (n == "preamp_wide") w.preamp_wide = value < 0 ? -1 : (value != 0);
+    else if (n == "mel_generic") w.mel_generic = value != 0;
+    else if (n == "mel_rank1") w.mel_rank1 = value != 0;
+    else if (n == "mel_lds") w.mel_lds = value != 0;
+    else if (n == "pa_sort") { if (value < 0 || value > 2) return -1; w.pa_sort = value; }
+    else if (n == "host_profile") w.host_profile = value != 0;
+    else return -1;                                       // (trem_traj / trem_cache / pipe shape the pool at creation: environment only)
+    return 0;
+}
+int ow_test_pool_get_switch(const ow_pool* p, const char* name) {
+    if (!p || !name) return -2;
+    const std::string n(name);
+    const Switches& w = p->sw;
+    if (n == "trem_serial") return w.trem_serial;
+    if (n == "trem_wide") return w.trem_wide;
+    if (n == "preamp_wide") return w.preamp_wide;
+    if (n == "mel_generic") return w.mel_generic;
+    if (n == "mel_rank1") return w.mel_rank1;
+    if (n == "mel_lds") return w.mel_lds;
+    if (n == "pa_sort") return w.pa_sort;
+    if (n == "trem_traj") return p->traj ? 1 : 0;
+    if (n == "trem_cache") return w.trem_cache;
+    return -2;
+}
+// Engines of the pool that read the shared trajectory / samples the store of the pool's rate holds (produced or enqueued) / its capacity.
+int ow_test_pool_trajectory_info(const ow_pool* p, uint64_t out[3]) {
+    if (!p || !out) return -1;
+    out[0] = p->traj ? p->n_on_traj : 0; out[1] = 0; out[2] = 0;
+    if (p->traj) { std::lock_guard<std::mutex> lk(p->traj->mu); out[1] = p->traj->len; out[2] = p->traj->cap; }
+    return 0;
+}
 
 // ---- diagnostics ---------------------------------------------------------------------------------
 int ow_debug_mlp_raw(const uint8_t* notes, const double* velocities, size_t n, double* out, int use_mfma, int device) {

@@ -215,8 +215,8 @@ __global__ __launch_bounds__(64) void k_job_chain_wide(const OwConsts* __restric
 // dk_step): tests/test_gpu_parity.py::test_preamp_wide_is_bit_identical.  In a pool of a few hundred engines the preamp's serial
 // latency is the block time once the tremolo is out of the way (paced single instance: 314 of the 425 us of a 64-sample buffer).
 __global__ __launch_bounds__(64) void k_preamp_wide(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args,
-                                                    const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const double* __restrict__ rbuf,
-                                                    const uint32_t* __restrict__ trem_lead, double* __restrict__ pre, int I, int L, int Lcap, int e0, int ne) {
+                                                    const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const OwTremSrc tsrc,
+                                                    double* __restrict__ pre, int I, int L, int Lcap, int e0, int ne) {
     __shared__ double tile[8 * (OW_WCHUNK + 1)];
     const int lane = threadIdx.x;
     const int q = lane & 3, el = (lane & 31) >> 2, role = lane >> 5;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64) void k_preamp_wide(const OwConsts* __restrict__
         }
     }
     uint32_t nan_resets = 0;
-    const int er_col = (int)trem_lead[ec];
+    const TremCol rc = trem_col(tsrc, I, ec);
     for (int base = 0; base < L; base += OW_WCHUNK) {
         const int cn = min(OW_WCHUNK, L - base);
         for (int r = 0; r < 8; ++r) {                 // stage 8 engine rows x 64 samples of the voice sum (slot pass + steal pass)
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64) void k_preamp_wide(const OwConsts* __restrict__
             }
             for (int j = 0; j < osr; ++j) {
                 const size_t idx = (size_t)((base + n) * osr + j);
-                const double r_new = fmax(trem_shunt(depth, rbuf[idx * I + er_col]), 1000.0);   // tremolo.rs:152-167; set_ldr_resistance
+                const double r_new = fmax(trem_shunt(depth, trem_col_at(rc, (uint32_t)idx)), 1000.0);   // tremolo.rs:152-167; set_ldr_resistance
                 if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = ow_div(1.0, r_new); }
                 const double o = dk_step_wide(st, R, q, in[j], g_ldr, g_prev, K);
                 g_prev = g_ldr;

@@ -499,6 +499,30 @@ OW_DEV void dk_store(const DkSt& s, double* __restrict__ cs, int I, int e, int b
     CSF(base + 10) = s.i_nl[0]; CSF(base + 11) = s.i_nl[1]; CSF(base + 12) = s.v_nl[0]; CSF(base + 13) = s.v_nl[1];
 }
 
+// ------------------------------------------------------------------ where an engine's CdS resistance R[n] comes from
+// Tremolo::process takes no audio and no depth into the oscillator, the LED envelope or r_ldr (tremolo.rs:121-146; depth only enters
+// shunt_impedance, :152-167), and new() / reset() start from the same settled state (:83-102, :192-216): r_ldr[t] is ONE deterministic
+// sequence per chain rate, t = calls of process() since the cell was built.  The library keeps that sequence in HBM once per (device,
+// chain rate) -- the shared trajectory, openwurli_hip.hip `TremTraj` -- and an engine reads it at its own t = pool clock - birth[e].
+// Engines that are not on the trajectory (legacy-LFO build, trajectory switched off, older than the store's cap) read the column of
+// their phase-group leader in the pool's rbuf instead, as before.
+#define OW_OFF_TRAJ (-0x7FFFFFFFFFFFFFFFLL - 1)
+struct OwTremSrc {
+    const double* rbuf;        // [n_os][I] R of the phase-group leaders for the block being rendered
+    const uint32_t* lead;      // [I] leader of every engine
+    const double* traj;        // trajectory store AT THE POOL CLOCK (traj[i - birth[e]] = R of chain sample i of this block); null = none
+    const long long* birth;    // [I] pool clock at which engine e's cell was built; OW_OFF_TRAJ = the engine reads its phase group
+};
+struct TremCol { const char* p; uint32_t stride8; };     // R of chain sample i of the block = *(double*)(p + i * stride8): one v_mad_u64_u32
+OW_DEV TremCol trem_col(const OwTremSrc& ts, int I, int e) {
+    TremCol c;
+    const long long b = ts.traj ? ts.birth[e] : OW_OFF_TRAJ;
+    if (b != OW_OFF_TRAJ) { c.p = (const char*)(ts.traj - b); c.stride8 = 8u; }
+    else { c.p = (const char*)(ts.rbuf + ts.lead[e]); c.stride8 = 8u * (uint32_t)I; }
+    return c;
+}
+OW_DEV double trem_col_at(const TremCol& c, uint32_t i) { return *(const double*)(c.p + (uint64_t)i * c.stride8); }
+
 // ------------------------------------------------------------------ chain init / reset / settle
 // Chain state (re)initialisation, lane = engine.
 //   mode 1  WurliEngine::new (engine.rs:194-229): fresh chain objects, default smoothers
@@ -676,8 +700,8 @@ __global__ __launch_bounds__(64) void k_tremolo_lfo(const OwConsts* __restrict__
 // ------------------------------------------------------------------ preamp stream
 #define OW_PCHUNK 64
 __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args,
-                                               const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const double* __restrict__ rbuf,
-                                               const uint32_t* __restrict__ trem_lead, double* __restrict__ pre, int I, int L, int Lcap, int e0, int ne) {
+                                               const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const OwTremSrc tsrc,
+                                               double* __restrict__ pre, int I, int L, int Lcap, int e0, int ne) {
     __shared__ double tile[32 * (OW_PCHUNK + 1)];
     const int lane = threadIdx.x;
     const int el = lane & 31, role = lane >> 5;
@@ -716,10 +740,10 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
     }
     const int e_last = e0 + ne - 1;
     // R[n] is read one host sample ahead (registers), so its global-load latency is hidden behind the previous sample's solve
-    const int er = (int)trem_lead[ec];     // column of this engine's tremolo phase group (one column for a whole fresh pool: a broadcast load)
+    const TremCol tcol = trem_col(tsrc, I, ec);   // this engine's place on the shared trajectory, or the column of its phase group
     double rn[2];
-    rn[0] = rbuf[(size_t)0 * I + er];
-    rn[1] = osr == 2 ? rbuf[(size_t)1 * I + er] : 0.0;
+    rn[0] = trem_col_at(tcol, 0u);
+    rn[1] = osr == 2 ? trem_col_at(tcol, 1u) : 0.0;
     for (int base = 0; base < L; base += OW_PCHUNK) {
         const int cn = min(OW_PCHUNK, L - base);
         // stage 32 engine rows x 64 samples of the voice sum (slot pass + steal pass) through LDS
@@ -739,9 +763,9 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
             const double x = tile[el * (OW_PCHUNK + 1) + n];
             const double rc[2] = {rn[0], rn[1]};
             {
-                const size_t nx = (size_t)min(base + n + 1, L - 1) * osr;
-                rn[0] = rbuf[nx * I + er];
-                if (osr == 2) rn[1] = rbuf[(nx + 1) * I + er];
+                const uint32_t nx = (uint32_t)(min(base + n + 1, L - 1) * osr);
+                rn[0] = trem_col_at(tcol, nx);
+                if (osr == 2) rn[1] = trem_col_at(tcol, nx + 1u);
             }
             const double depth = clampd(sd.next(), 0.0, 1.0);   // engine.rs:533-534, tremolo.rs:117-119
             double in[2];

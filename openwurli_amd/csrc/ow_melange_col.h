@@ -458,8 +458,8 @@ __device__ inline double mel_process_col(MelSt& st, double input_in, double pot,
 // lane-minor, touched by the generic fallback only.
 __global__ __launch_bounds__(64, 2) void k_preamp_mel_col(const OwConsts* __restrict__ K, double* __restrict__ cs,
                                                           const double* __restrict__ settled, const OwEngineArgs* __restrict__ args,
-                                                          const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const double* __restrict__ rbuf,
-                                                          const uint32_t* __restrict__ trem_lead, double* __restrict__ pre, double* __restrict__ noise, int I, int L,
+                                                          const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const OwTremSrc tsrc,
+                                                          double* __restrict__ pre, double* __restrict__ noise, int I, int L,
                                                           int Lcap, int e0, int ne, int generic_only, double* __restrict__ lu_scratch, size_t lu_ld) {
     __shared__ double sni_all[36 * 64];
     const int lane = threadIdx.x;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64, 2) void k_preamp_mel_col(const OwConsts* __rest
     const bool valid = e < e0 + ne;
     const int ec = valid ? e : (e0 + ne - 1);
     const int osr = K->oversample ? 2 : 1;
-    const int er_col = (int)trem_lead[ec];
+    const TremCol rc = trem_col(tsrc, I, ec);
     const double alpha = 2.0 * (K->os_sr * 1.0);                    // gen_preamp.rs:1991-1992
     double* sni = sni_all + lane;
     double* lu = lu_scratch + (size_t)2 * (valid ? e : I + el) + role;   // this lane's workspace column (generic fallback); masked lanes get spare ones
@@ -507,9 +507,8 @@ __global__ __launch_bounds__(64, 2) void k_preamp_mel_col(const OwConsts* __rest
         if (row1) x += row1[n];
         return x;
     };
-    const double* rcol = rbuf + er_col;
     double x_next = voice_in(0);
-    double r_next = rcol[0];
+    double r_next = trem_col_at(rc, 0u);
     const int n_os = L * osr;
     for (int n = 0; n < L; ++n) {
         const double x = x_next;
@@ -529,7 +528,7 @@ __global__ __launch_bounds__(64, 2) void k_preamp_mel_col(const OwConsts* __rest
             const int s_i = n * osr + j;
             const size_t s_idx = (size_t)s_i;
             const double r_now = r_next;
-            if (s_i + 1 < n_os) r_next = rcol[(size_t)(s_i + 1) * I];
+            if (s_i + 1 < n_os) r_next = trem_col_at(rc, (uint32_t)(s_i + 1));
             mel_set_r(st, trem_shunt(depth, r_now));
             // the matrices follow the main state's resistance (see ow_melange_lit.h: a state NaN-reset on its own may sit within the 1e-12
             // hysteresis of its partner's value)

@@ -513,8 +513,8 @@ __global__ __launch_bounds__(64) void k_mel_noise_seed(double* __restrict__ nois
 // Preamp stream with the melange solver: same staging / lane-pair structure as k_preamp.
 __global__ __launch_bounds__(64) void k_preamp_mel(const OwConsts* __restrict__ K, double* __restrict__ cs,
                                                    const double* __restrict__ settled, const OwEngineArgs* __restrict__ args,
-                                                   const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const double* __restrict__ rbuf,
-                                                   const uint32_t* __restrict__ trem_lead, double* __restrict__ pre, double* __restrict__ noise, int I, int L,
+                                                   const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const OwTremSrc tsrc,
+                                                   double* __restrict__ pre, double* __restrict__ noise, int I, int L,
                                                    int Lcap, int e0, int ne) {
     __shared__ double tile[32 * (OW_PCHUNK + 1)];
     __shared__ MelMats M;
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64) void k_preamp_mel(const OwConsts* __restrict__ 
     const bool valid = e < e0 + ne;
     const int ec = valid ? e : (e0 + ne - 1);
     const int osr = K->oversample ? 2 : 1;
-    const int er_col = (int)trem_lead[ec];   // rbuf column of this engine's tremolo phase group
+    const TremCol rc = trem_col(tsrc, I, ec);
 
     MelSt st;
     double ua[3], ub[3];
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(64) void k_preamp_mel(const OwConsts* __restrict__ 
             }
             for (int j = 0; j < osr; ++j) {
                 const size_t s_idx = (size_t)((base + n) * osr + j);
-                mel_set_r(st, trem_shunt(depth, rbuf[s_idx * I + er_col]));            // tremolo.rs:152-167; melange_adapter.rs:82-85
+                mel_set_r(st, trem_shunt(depth, trem_col_at(rc, (uint32_t)s_idx)));            // tremolo.rs:152-167; melange_adapter.rs:82-85
                 int z = 0;
                 asm volatile("" : "+v"(z));                                        // keep the LDS constant reads inside the loop
                 const double* nzp = nullptr;

@@ -294,8 +294,8 @@ __device__ inline double mel_process_lit(MelSt& st, double input_in, const doubl
 // Preamp stream, literal rebuild.  Same interface as k_preamp_mel.
 __global__ __launch_bounds__(64) void k_preamp_mel_lit(const OwConsts* __restrict__ K, double* __restrict__ cs,
                                                        const double* __restrict__ settled, const OwEngineArgs* __restrict__ args,
-                                                       const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const double* __restrict__ rbuf,
-                                                       const uint32_t* __restrict__ trem_lead, double* __restrict__ pre, double* __restrict__ noise, int I, int L,
+                                                       const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const OwTremSrc tsrc,
+                                                       double* __restrict__ pre, double* __restrict__ noise, int I, int L,
                                                        int Lcap, int e0, int ne, int generic_only, double* __restrict__ lu_scratch) {
     __shared__ double tile[32 * (OW_LCHUNK + 1)];
     __shared__ double S_all[12 * 12 * 32];
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64) void k_preamp_mel_lit(const OwConsts* __restric
     const bool valid = e < e0 + ne;
     const int ec = valid ? e : (e0 + ne - 1);
     const int osr = K->oversample ? 2 : 1;
-    const int er_col = (int)trem_lead[ec];
+    const TremCol rc = trem_col(tsrc, I, ec);
     const double alpha = 2.0 * (K->os_sr * 1.0);                    // gen_preamp.rs:1991-1992
     // The LU workspace is only touched by the generic rebuild (the fallback of the fast path): it lives in HBM, one [12][12][32] slab
     // per workgroup (slabs of disjoint engine ranges are disjoint: ceil(e0/32) + block), so that LDS holds S alone -- 39 KB, four
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64) void k_preamp_mel_lit(const OwConsts* __restric
             }
             for (int j = 0; j < osr; ++j) {
                 const size_t s_idx = (size_t)((base + n) * osr + j);
-                mel_set_r(st, trem_shunt(depth, rbuf[s_idx * I + er_col]));
+                mel_set_r(st, trem_shunt(depth, trem_col_at(rc, (uint32_t)s_idx)));
                 // lazy rebuild (gen_preamp.rs:3408-3411), once per engine, keyed on the main state's resistance
                 const double pot_main = __shfl(st.pot, el);
                 const bool dirty = !(pot_main == s_pot);

@@ -338,4 +338,119 @@ __global__ __launch_bounds__(64) void k_tremolo_wide(const OwConsts* __restrict_
     if (valid && q == 0) trem_wide_store(t, cs, I, e);
 }
 
+
+// ------------------------------------------------------------------ shared trajectory (openwurli_hip.hip `TremTraj`)
+// r_ldr[t] of the Twin-T / CdS cell for t = 0, 1, 2, ... calls of Tremolo::process after Tremolo::new (tremolo.rs:83-146), computed ONCE per
+// (device, chain rate) and read by every engine at its own t (ow_kernels.h, OwTremSrc).  One wavefront extends it: its sixteen quads run
+// the same oscillator (the quad-lane step above; idle quads would diverge, shadows do not), lane 0 keeps the LED envelope of every step,
+// and the power law -- which is not fed back -- is applied afterwards by all 64 lanes on 64 samples at a time.
+//   state   18 rows (I = 1 layout of the chain-state tremolo rows) at sample t0; advanced to t0 + n
+//   r       &trajectory[t0]
+//   ckpt    oscillator state in front of every OW_TRAJ_CK-th sample ([t / CK][OW_TRAJ_CKD]: v[7] ip[4] ipp[4] env): an engine that
+//           outlives the store's cap continues from the checkpoint below its t (k_trem_from_ckpt)
+//   be      [0] = backward-Euler fallbacks so far, [1 + k] = sample index of the k-th (k < OW_TRAJ_BE_CAP): ow_diag's counter of an
+//           engine at t is the number of entries below t
+#define OW_TRAJ_CK 4096
+#define OW_TRAJ_CKD 16
+#define OW_TRAJ_BE_CAP 1023
+__global__ void k_trem_state_dc(double* __restrict__ state) {     // CircuitState at DC_OP, cell at rest (k_chain_init's tremolo rows)
+    const int f = threadIdx.x;
+    if (f < 7) state[CS_T_V + f] = OW_TREM_DC[f];
+    else if (f < 11) { state[CS_T_I + f - 7] = OW_TREM_DC[f]; state[CS_T_IP + f - 7] = OW_TREM_DC[f]; }
+    else if (f == 11) { state[CS_T_ENV] = 0.0; state[CS_T_RLDR] = 1000000.0; state[CS_T_BE] = bitsd(0ull); }
+}
+__global__ __launch_bounds__(64) void k_trem_traj_extend(const OwConsts* __restrict__ K, double* __restrict__ state, double* __restrict__ r, long long t0,
+                                                         long long n, double* __restrict__ ckpt, unsigned long long* __restrict__ be) {
+    __shared__ TremMats M;
+    trem_mats_load(&M, K, threadIdx.x, 64);
+    __syncthreads();
+    const int lane = threadIdx.x;
+    TremWide t;
+    trem_wide_load(t, state, 1, 0);
+    double drive = 0.0;
+    for (long long i = 0; i < n; ++i) {
+        if ((((t0 + i) & (long long)(OW_TRAJ_CK - 1)) == 0) && lane == 0) {
+            double* c = ckpt + (size_t)((t0 + i) / OW_TRAJ_CK) * OW_TRAJ_CKD;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) c[k] = t.v[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { c[7 + k] = t.ip[k]; c[11 + k] = t.ipp[k]; }
+            c[15] = t.env;
+        }
+        const uint32_t be0 = t.be_fallbacks;
+        drive = trem_cell_drive_wide(t, K, &M);
+        if (lane == 0) {
+            r[i] = drive;                                                  // the envelope for now; turned into R below
+            if (__builtin_expect(t.be_fallbacks != be0, 0)) {
+                const unsigned long long k = be[0];
+                if (k < OW_TRAJ_BE_CAP) be[1 + k] = (unsigned long long)(t0 + i);
+                be[0] = k + 1ull;
+            }
+        }
+    }
+    if ((((t0 + n) & (long long)(OW_TRAJ_CK - 1)) == 0) && lane == 0) {      // the state AT a checkpoint boundary the store ends on (an engine may leave from there)
+        double* c = ckpt + (size_t)((t0 + n) / OW_TRAJ_CK) * OW_TRAJ_CKD;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) c[k] = t.v[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[7 + k] = t.ip[k]; c[11 + k] = t.ipp[k]; }
+        c[15] = t.env;
+    }
+    if (n > 0) t.r_ldr = trem_cell_law(drive, K);
+    __threadfence_block();                                                 // lane 0's envelope stores before the wavefront reads them back
+    for (long long i = lane; i < n; i += 64) r[i] = trem_cell_law(r[i], K);
+    if (lane == 0) { t.be_fallbacks = 0; trem_wide_store(t, state, 1, 0); }
+}
+
+// Engines leaving the trajectory (lane = engine): engine engines[i] stands at sample tpos[i]; its own oscillator rows are rebuilt from the
+// checkpoint below tpos[i] and stepped up to it with the lane = engine cell (bit-identical to the quad-lane one), after which the engine
+// is a phase group of one.  be_count[i]: value of its fallback counter.
+__global__ __launch_bounds__(64) void k_trem_from_ckpt(const OwConsts* __restrict__ K, const double* __restrict__ traj_r, const double* __restrict__ ckpt,
+                                                       double* __restrict__ cs, int I, const uint32_t* __restrict__ engines, const long long* __restrict__ tpos,
+                                                       const unsigned long long* __restrict__ be_count, int n) {
+    __shared__ TremMats M;
+    __shared__ TremPark P;
+    trem_mats_load(&M, K, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int e = (int)engines[idx];
+    const int ln = threadIdx.x & 63;
+    const long long tp = tpos[idx];
+    const double* c = ckpt + (size_t)(tp / OW_TRAJ_CK) * OW_TRAJ_CKD;
+    TremState t;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) P.v[k][ln] = c[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { P.ip[k][ln] = c[7 + k]; P.ipp[k][ln] = c[11 + k]; }
+    t.env = c[15];
+    t.r_ldr = tp > 0 ? traj_r[tp - 1] : 1000000.0;
+    t.be_fallbacks = 0;
+    const long long steps = tp % OW_TRAJ_CK;
+    for (long long i = 0; i < steps; ++i) {
+        int z = 0;
+        asm volatile("" : "+v"(z));
+        trem_cell_r(t, &P, K, &M + z);
+    }
+    t.be_fallbacks = 0;                                                    // already part of be_count
+    CSF(CS_T_BE) = bitsd((uint64_t)be_count[idx]);
+    trem_store(t, &P, cs, I, e);
+}
+
+// rows of R the last block consumed, for engines on the trajectory (ow_pool_read_tremolo_r): out[e][i] = traj[t_end(e) - n_os + i]
+__global__ void k_trem_traj_gather(const double* __restrict__ traj_at_clock, const long long* __restrict__ birth, int I, long long n_os, double* __restrict__ out) {
+    const int e = blockIdx.y;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= I || i >= n_os) return;
+    const long long b = birth[e];
+    out[(size_t)e * n_os + i] = b == OW_OFF_TRAJ ? 0.0 : traj_at_clock[i - n_os - b];
+}
+// birth[e] += delta for e in [e0, e0 + ne) on the trajectory (a sub-range rendered on its own grows older than the pool clock says)
+__global__ void k_trem_birth_shift(long long* __restrict__ birth, int e0, int ne, long long delta) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ne) return;
+    const long long b = birth[e0 + k];
+    if (b != OW_OFF_TRAJ) birth[e0 + k] = b + delta;
+}
+
 }  // namespace owdev

@@ -239,6 +239,20 @@ class EnginePool:
     def tremolo_groups(self):
         return int(self._lib.ow_test_pool_tremolo_groups(self._h))
 
+    def set_switch(self, name, value):
+        """Test / bench hook: change one latched OW_* switch of this pool (openwurli_hip_test.h)."""
+        if self._lib.ow_test_pool_set_switch(self._h, name.encode(), int(value)) != 0:
+            raise OwError(f"unknown or creation-only switch {name!r}")
+
+    def get_switch(self, name):
+        return int(self._lib.ow_test_pool_get_switch(self._h, name.encode()))
+
+    def trajectory_info(self):
+        """(engines on the shared tremolo trajectory, samples its store holds, store capacity)."""
+        out = (C.c_uint64 * 3)()
+        self._lib.ow_test_pool_trajectory_info(self._h, out)
+        return int(out[0]), int(out[1]), int(out[2])
+
     def midi(self, events):
         """Apply a numpy structured array of events (dtype binding.MIDI_DTYPE) in order."""
         ev = np.ascontiguousarray(events, dtype=np.dtype(binding.MIDI_DTYPE))
@@ -293,6 +307,16 @@ class EnginePool:
         stride = C.c_size_t(0)
         ptr = self._lib.ow_pool_device_output(self._h, C.byref(stride))
         return ptr, stride.value
+
+
+def tremolo_prefetch(sample_rate, seconds, device=0):
+    """``ow_tremolo_prefetch``: make the first ``seconds`` of the shared Twin-T / CdS trajectory of this host rate exist in HBM now.
+    Returns the number of chain-rate samples the store holds."""
+    lib = binding.load_library()
+    n = lib.ow_tremolo_prefetch(float(sample_rate), int(device), float(seconds))
+    if n < 0:
+        raise OwError(binding.take_error(lib))
+    return int(n)
 
 
 def render_note(midi_note, velocity, duration_secs, sample_rate, device=0, displacement_scale=None):

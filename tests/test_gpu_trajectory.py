@@ -1,0 +1,220 @@
+"""The shared tremolo trajectory (openwurli_hip.hip `TremTraj`): Tremolo::process takes no audio and no depth into the oscillator, the
+LED envelope or r_ldr (tremolo.rs:121-146; depth only enters shunt_impedance, :152-167) and new() / reset() leave the same settled state
+(:83-102, :192-216), so r_ldr[t] is ONE sequence per chain rate.  The library keeps it in HBM once per (device, chain rate) and every
+engine reads it at its own t.  That must be invisible: a pool on the trajectory and a pool with one oscillator per phase group
+(OW_TREM_TRAJ=0 at creation: rounds 1-3) produce the same bits -- R rows, preamp tap and output -- under random offsets, mid-run reset,
+set_sample_rate, warm-up of one engine and depth ramps; both match the oracle; engines that outlive the store's capacity continue on their
+own oscillator without a seam; pools of one created at different times share one store."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class _Env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _pool(ow, sr, n, traj, **kw):
+    with _Env(OW_TREM_TRAJ=None if traj else "0"):
+        p = ow.EnginePool(sr, n, **kw)
+    assert p.get_switch("trem_traj") == (1 if traj else 0)
+    return p
+
+
+def _script(sr, n, groups, blocks):
+    """The same calls on both pools (and on oracle engines for a few k): returns per block (out, R rows, preamp tap)."""
+    def run(p, cs=None, step=0):
+        osr = 2 if sr < 88200.0 else 1
+        res = []
+        targets = [(k, p[k]) for k in range(n)] if cs is None else [(k, c) for k, c in cs.items()]
+        for k, e in targets:
+            e.set_tremolo_depth(0.15 + 0.8 * ((7 * k) % 10) / 10.0); e.set_volume(0.4 + 0.01 * (k % 9))
+            e.note_on(40 + (5 * k) % 50, 0.55 + 0.04 * (k % 10)); e.note_on(64 + k % 12, 0.8)
+        for b in range(blocks):
+            length = (512, 300, 512, 64, 512, 1, 512, 777)[b % 8]
+            if b == 3:
+                for k, e in targets:
+                    if k % 3 == 0:
+                        e.set_tremolo_depth(1.0)                      # depth ramp
+            if b == 5:
+                for k, e in targets:
+                    if k == 2:
+                        e.reset(); e.note_on(70, 0.7)                 # one engine starts over at t = 0
+            if b == 8:
+                for k, e in targets:
+                    if k == 4:
+                        e.warm_up()                                   # 0.6 s on one engine only: it runs ahead of the pool clock
+            if cs is None:
+                out = p.render(length)
+                res.append((out.copy(), p.tremolo_r(length * osr).copy(), p.preamp_out(length * osr).copy()))
+            else:
+                res.append({k: c.render_taps(length, osr) for k, c in cs.items()})
+        return res
+    return run
+
+
+@pytest.mark.parametrize("sr", [48000.0, 96000.0])
+def test_trajectory_is_bit_identical_to_per_group_oscillators(hiplib, oracle, sr):
+    import openwurli_amd as ow
+    n, groups, blocks = 70, 23, 12
+    run = _script(sr, n, groups, blocks)
+    res = {}
+    for traj in (True, False):
+        p = _pool(ow, sr, n, traj)
+        p.set_sample_rate(sr)
+        p.stagger_tremolo(groups)
+        assert p.tremolo_groups() == groups
+        on, held, cap = p.trajectory_info()
+        assert on == (n if traj else 0)
+        res[traj] = run(p)
+        if traj:                       # the reset engine and the warmed-up engine stand at their own t: two more phases
+            assert p.tremolo_groups() == groups + 2
+            d_t = [p[k].diag().tremolo_be_fallbacks for k in (0, 2, 4, 69)]
+        else:
+            d_g = [p[k].diag().tremolo_be_fallbacks for k in (0, 2, 4, 69)]
+        p.close()
+    for b in range(blocks):
+        for what, i in (("R", 1), ("preamp", 2), ("out", 0)):
+            assert np.array_equal(res[True][b][i], res[False][b][i]), (sr, b, what, np.max(np.abs(res[True][b][i] - res[False][b][i])))
+    assert d_t == d_g or all(x >= 0 for x in d_t)
+    # ... and the oracle's, for engines in different situations (plain, reset mid-run, warmed up alone, last)
+    step = max(1, int(int((2 if sr < 88200.0 else 1) * sr / 5.6) / groups))
+    cs = {}
+    for k in (0, 2, 4, 69):
+        c = oracle.OracleEngine(sr)
+        c.set_sample_rate(sr)
+        c.advance_tremolo((k % groups) * step)
+        cs[k] = c
+    ref = run(None, cs)
+    for b in range(blocks):
+        for k in cs:
+            co = ref[b][k][0]
+            rep = oracle.parity_report(res[True][b][0][k], co, abs_floor=oracle.ABS_FLOOR_OUTPUT)
+            assert rep["n_bad"] == 0, (sr, b, k, rep)
+    for c in cs.values():
+        c.close()
+
+
+def test_engines_older_than_the_store_continue_on_their_own_oscillator(hiplib, oracle):
+    """OW_TREM_TRAJ_SECONDS = 0.9 s at 96 kHz chain rate: the warm-up alone (0.6 s) nearly fills the store, staggered engines cross
+    its end one group after the other over the next blocks.  No seam: same bits as the per-group pool all the way."""
+    import openwurli_amd as ow
+    sr, n, groups = 48000.0, 12, 6
+    hiplib.ow_test_clear_settle_caches()
+    with _Env(OW_TREM_TRAJ_SECONDS="0.9"):
+        pt = _pool(ow, sr, n, True)
+    try:
+        pg = _pool(ow, sr, n, False)
+        outs = {}
+        counts = []
+        for name, p in (("t", pt), ("g", pg)):
+            p.set_sample_rate(sr)
+            p.stagger_tremolo(groups)
+            for k in range(n):
+                p[k].set_tremolo_depth(1.0); p[k].note_on(50 + k, 0.8)
+            o = []
+            for b in range(70):
+                length = 512 if b % 5 else 211
+                o.append((p.render(length).copy(), p.tremolo_r(2 * length).copy()))
+                if name == "t":
+                    counts.append(p.trajectory_info()[0])
+            outs[name] = o
+        cap = pt.trajectory_info()[2]
+        assert cap == 90112                                        # 0.9 s x 96 kHz rounded up to a checkpoint boundary
+        assert counts[0] == n and counts[-1] == 0 and sorted(counts, reverse=True) == counts and len(set(counts)) >= 4
+        for b in range(70):
+            assert np.array_equal(outs["t"][b][1], outs["g"][b][1]), (b, "R")
+            assert np.array_equal(outs["t"][b][0], outs["g"][b][0]), (b, "out")
+        # a reset brings an evicted engine back to t = 0 of the trajectory
+        for p in (pt, pg):
+            p[3].reset(); p[3].note_on(60, 0.9)
+        assert pt.trajectory_info()[0] == 1
+        for b in range(4):
+            a, c = pt.render(256), pg.render(256)
+            assert np.array_equal(a, c), b
+            assert np.array_equal(pt.tremolo_r(512), pg.tremolo_r(512)), b
+        pg.close()
+    finally:
+        pt.close()
+        hiplib.ow_test_clear_settle_caches()                       # drop the tiny store: later tests get a full-size one
+
+
+def test_pools_of_one_share_one_store(hiplib, oracle):
+    """The plugin case: every instance is its own pool.  The first one extends the trajectory; an instance created later reads what
+    is there (its t starts at 0) and both match their oracle engines."""
+    import openwurli_amd as ow
+    sr = 44100.0
+    a = ow.WurliEngine(sr)
+    a.set_sample_rate(sr)
+    ca = oracle.OracleEngine(sr); ca.set_sample_rate(sr)
+    for e in (a, ca):
+        e.set_tremolo_depth(0.9); e.note_on(57, 0.8)
+    for _ in range(20):
+        rep = oracle.parity_report(a.render(441), ca.render(441), abs_floor=oracle.ABS_FLOOR_OUTPUT)
+        assert rep["n_bad"] == 0, rep
+    b = ow.WurliEngine(sr)
+    b.set_sample_rate(sr)
+    cb = oracle.OracleEngine(sr); cb.set_sample_rate(sr)
+    for e in (b, cb):
+        e.set_tremolo_depth(0.6); e.note_on(45, 0.9)
+    for _ in range(10):
+        for g, c in ((a, ca), (b, cb)):
+            rep = oracle.parity_report(g.render(300), c.render(300), abs_floor=oracle.ABS_FLOOR_OUTPUT)
+            assert rep["n_bad"] == 0, rep
+    a.close(); b.close(); ca.close(); cb.close()
+
+
+def test_prefetch_and_batch_tremolo_read_the_store(hiplib, oracle):
+    """ow_tremolo_prefetch fills the store ahead of time; `preamp-bench render --tremolo-depth` jobs read it from t = 0 (Tremolo::new
+    without a warm-up) and equal the per-call oscillator of OW_TREM_TRAJ=0 bit for bit."""
+    import openwurli_amd as ow
+    sr = 44100.0
+    held = ow.tremolo_prefetch(sr, 1.5)
+    assert held >= int(1.5 * 2 * sr)
+    assert ow.tremolo_prefetch(sr, 0.1) >= held                    # never shrinks
+    jobs = [dict(note=60, velocity=100, mlp=False, poweramp=False, volume=1.0, speaker=0.0, r_ldr=1e6, tremolo_depth=d) for d in (1.0, 0.4, 0.0)]
+    with _Env(OW_TREM_TRAJ=None):
+        x = ow.batch_render(jobs, sr, 1.0)
+    with _Env(OW_TREM_TRAJ="0"):
+        y = ow.batch_render(jobs, sr, 1.0)
+    assert np.array_equal(x, y)
+    assert not np.array_equal(x[0], x[2])
+
+
+def test_latched_switches(hiplib):
+    """The OW_* switches are read when a pool is created and never on the render path: flipping the environment under a live pool
+    changes nothing, ow_test_pool_set_switch does."""
+    import openwurli_amd as ow
+    with _Env(OW_TREM_SERIAL="1", OW_PREAMP_WIDE="0"):
+        p = ow.EnginePool(48000.0, 4)
+    assert p.get_switch("trem_serial") == 1 and p.get_switch("preamp_wide") == 0
+    os.environ["OW_PREAMP_WIDE"] = "1"
+    try:
+        p.render(64)
+        assert p.get_switch("preamp_wide") == 0
+    finally:
+        del os.environ["OW_PREAMP_WIDE"]
+    p.set_switch("preamp_wide", -1); p.set_switch("trem_serial", 0)
+    assert p.get_switch("preamp_wide") == -1 and p.get_switch("trem_serial") == 0
+    with pytest.raises(ow.OwError):
+        p.set_switch("trem_traj", 0)
+    p.close()
