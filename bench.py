@@ -24,6 +24,9 @@ driver's 1/2/4/8-GPU runs show the batch path at both sizes.
 `--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself, before this process
 touches the GPU; under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.
 
+After the timed region the line verifies itself (`verified`): every row of the last block finite and inside the level band, eight
+engines spread over the pool with 64 active voices and zero NaN-guard / reset counters; a failed check exits non-zero.
+
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the roofline arithmetic.
 """
 import argparse
@@ -276,6 +279,44 @@ def spawn_ranks(n, argv, poll_s=0.2):
     return 0
 
 
+# ---------------------------------------------------------------------------------------------------------------- dry run stand-in
+class DryRunPool:
+    """OW_BENCH_DRYRUN_BACKEND=gloo, --workload engines: stands where an EnginePool would, so that the launcher, the barriers, the
+    max-over-ranks timing, the aggregation over ranks and the JSON contract of the engines workload run on CPU
+    (tests/test_bench_launcher.py).  A render sleeps a fixed 2 ms; nothing is measured and the line says so."""
+
+    class _Eng:
+        class _Diag:
+            active_voices = 64; nan_guard_fires = 0; output_nan_resets = 0; preamp_nan_resets = 0; tremolo_be_fallbacks = 0
+
+        def diag(self):
+            return self._Diag()
+
+        def set_volume(self, v): pass
+        def set_tremolo_depth(self, v): pass
+        def set_speaker_character(self, v): pass
+        def set_mlp_enabled(self, v): pass
+
+    def __init__(self, n):
+        self.n = n
+        self._block = np.zeros((n, BUF), dtype=np.float32)
+
+    def __getitem__(self, k): return self._Eng()
+    def midi(self, ev): pass
+    def render(self, length, to_host=True):
+        time.sleep(0.002)
+        bad = os.environ.get("OW_BENCH_TEST_BAD_BLOCK_RANK") == os.environ.get("RANK", "0")      # launcher test: this rank renders a NaN
+        self._block = np.full((self.n, int(length)), np.nan if bad else 0.1, dtype=np.float32)
+        return self._block if to_host else None
+    def render_into(self, ptr, stride, length): self.render(length, to_host=False)
+    def set_profiling(self, on): pass
+    def last_kernel_ms(self): return {"ops": 0.0, "voices": 1.0, "tremolo": 0.0, "preamp": 0.5, "post": 0.25}
+    def power_amp_passes(self): return np.ones(self.n, dtype=np.uint32)
+    def last_block(self): return self._block
+    def trajectory_info(self): return (self.n, 0, 0)
+    def close(self): pass
+
+
 # ---------------------------------------------------------------------------------------------------------------- batch path
 def batch_pass(jobs, sr, dur, dist, world, render_fn=None):
     """One pass of the sharded batch render: (elapsed_s over render + gather, max over ranks; per-phase maxima; ranks the collective saw)."""
@@ -380,9 +421,6 @@ def main(argv=None):
     # rendezvous over gloo and the batch render is a deterministic stand-in.  Nothing is measured in that mode and the line says so.
     dryrun = os.environ.get("OW_BENCH_DRYRUN_BACKEND")
     if dryrun:
-        if args.workload != "batch":
-            print("bench.py: the dry run covers --workload batch only", file=sys.stderr)
-            return 2
         if world > 1:
             import torch.distributed as dist
             dist.init_process_group(dryrun, rank=rank, world_size=world, timeout=RENDEZVOUS_TIMEOUT)
@@ -431,16 +469,36 @@ def main(argv=None):
             }
     else:
         pa_kind = 1 if args.power_amp == "melange" else 0
-        groups = n_inst if args.tremolo_groups <= 0 else max(1, min(args.tremolo_groups, n_inst))
+        phases = n_inst if args.tremolo_groups <= 0 else max(1, min(args.tremolo_groups, n_inst))
+        red_dev = "cpu" if dryrun else "cuda"
+        ranks_seen = 1
+        if dist is not None:
+            t_ = torch.ones(1, dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.SUM)
+            ranks_seen = int(round(float(t_.item())))
 
-        def make_pool(n, sr=None, preamp=preamp_kind, pa=pa_kind, n_groups=1):
-            """the plugin's initialize() for n instances: chain build + 0.6 s warm-up (not timed), then the tremolo phases"""
+        def make_pool(n, sr=None, preamp=preamp_kind, pa=pa_kind, n_phases=1, trajectory=True):
+            """the plugin's initialize() for n instances: chain build + 0.6 s warm-up (not timed), then the tremolo phases.
+            trajectory=False: a pool created under OW_TREM_TRAJ=0 -- one Twin-T oscillator per phase group instead of the shared
+            trajectory (rounds 1-3); the variable is read when the pool is created and restored right after."""
+            if dryrun:
+                return DryRunPool(n)
             sr = SR if sr is None else sr
-            p = ow.EnginePool(sr, n, device=local_rank, preamp_kind=preamp, power_amp_kind=pa)
+            old = os.environ.get("OW_TREM_TRAJ")
+            try:
+                if not trajectory:
+                    os.environ["OW_TREM_TRAJ"] = "0"
+                p = ow.EnginePool(sr, n, device=local_rank, preamp_kind=preamp, power_amp_kind=pa)
+            finally:
+                if not trajectory:
+                    if old is None:
+                        os.environ.pop("OW_TREM_TRAJ", None)
+                    else:
+                        os.environ["OW_TREM_TRAJ"] = old
             p.set_sample_rate(sr)
             p.ensure_buffer_capacity(BUF)
-            if n_groups > 1:
-                p.stagger_tremolo(min(n_groups, n))
+            if n_phases > 1:
+                p.stagger_tremolo(min(n_phases, n))
             # volume 0.5 / tremolo depth 0.5 / speaker character 0.0 / MLP on are the engine defaults (engine.rs:221-224)
             for k in range(min(n, 4096)):
                 e = p[k]
@@ -456,14 +514,16 @@ def main(argv=None):
             barrier()
             el_ = time.perf_counter() - ta
             if dist is not None:
-                t_ = torch.tensor([el_], dtype=torch.float64, device="cuda")
+                t_ = torch.tensor([el_], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t_, op=dist.ReduceOp.MAX)
                 el_ = float(t_.item())
             return el_
 
-        def side_run(p, n, k_warm, k_steps, epoch=None, buf=BUF):
+        def side_run(p, n, k_warm, k_steps, epoch=None, buf=BUF, pos=None):
             """a short profiled run of another configuration (extras): value, ms per step and per kernel"""
             sc = Script(p, n, buf=buf, epoch=epoch)
+            if pos is not None:
+                sc.pos = pos
             for _ in range(k_warm):
                 sc.step()
             p.set_profiling(True)
@@ -473,7 +533,23 @@ def main(argv=None):
             return {"value": k_steps * buf * n * world / el_, "unit": "samples/s", "ms_per_step": 1e3 * el_ / k_steps, "steps": k_steps, "warmup": k_warm,
                     "instances_per_gpu": n, "kernel_ms_per_step": {nm: float(x) for nm, x in zip(("ops", "voices", "tremolo", "preamp", "post"), kms_)}}
 
-        pool = make_pool(n_inst, n_groups=groups)
+        def verify(p, n):
+            """What the timed region rendered, looked at: every row of the last block finite and inside the level band of a 64-voice
+            chord at volume 0.5, eight engines spread over the pool with all 64 voices alive (the 1.0 s re-strike keeps them: the shortest
+            note reaches -80 dB after 1.4 s) and no NaN-guard / reset activity.  Returns (ok, details)."""
+            blk = p.last_block()
+            finite = bool(np.all(np.isfinite(blk)))
+            peaks = np.max(np.abs(blk), axis=1) if blk.size else np.zeros(n)
+            lo, hi = float(peaks.min()), float(peaks.max())
+            picks = sorted({k for k in (0, 1, 31, 32, 4095, 4096, n // 2, n - 1) if 0 <= k < n})
+            diags = [p[k].diag() for k in picks]
+            voices = [int(d.active_voices) for d in diags]
+            counters = int(sum(d.nan_guard_fires + d.output_nan_resets + d.preamp_nan_resets for d in diags))
+            ok = finite and lo > 1e-3 and hi < 4.0 and all(v == 64 for v in voices) and counters == 0
+            return ok, {"rows_checked": int(blk.shape[0]), "all_finite": finite, "row_peak_min": lo, "row_peak_max": hi, "engines_checked": picks,
+                        "active_voices": voices, "nan_guard_and_reset_counters": counters}
+
+        pool = make_pool(n_inst, n_phases=phases)
         script = Script(pool, n_inst)
         for _ in range(args.warmup):
             script.step()
@@ -482,9 +558,15 @@ def main(argv=None):
         # melange power amp: Newton passes per chain-rate sample, mean over the engines, in the LAST block of the timed region
         pa_passes = float(pool.power_amp_passes().mean()) / (BUF * (2 if SR < 88200.0 else 1)) if pa_kind else None
         pool.set_profiling(False)
+        verified, verify_details = verify(pool, n_inst)
+        on_traj = pool.trajectory_info()[0]
+        if dist is not None:
+            t_ = torch.tensor([1.0 if verified else 0.0], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MIN)
+            verified = bool(t_.item() > 0.5)
 
         extras = {}
-        if not args.no_extras:
+        if not args.no_extras and not dryrun:
             # (a) PCIe-inclusive: the same steps with every block copied into a pinned host buffer (what render(&mut [f32]) hands back)
             host = pool.alloc_host_block(BUF)
             sp = Script(pool, n_inst, host_out=host)
@@ -494,60 +576,52 @@ def main(argv=None):
             extras["pcie_inclusive"] = {"value": k_steps * BUF * n_inst * world / el, "unit": "samples/s", "ms_per_step": 1e3 * el / k_steps, "steps": k_steps,
                                         "bytes_per_step_per_gpu": 4 * BUF * n_inst, "host_memory": "pinned (ow_host_alloc)"}
             pool.free_host_block(host)
-            # (a') the other tremolo regime on the SAME pool.  A whole-pool reset puts every instance on one phase again (one oscillator
-            # per pool: the best case, what round 2 reported as `value`); staggering a shared pool prices the per-instance oscillators.
-            # (a0) the same pool with the block-ahead oscillators serialised in front of the voices (OW_TREM_SERIAL=1: a measurement switch
-            # of the library, read per render): slower by a few percent, but every kernel's HIP-event interval is then its own time --
-            # in the default schedule the tremolo kernel runs inside the voice kernel's interval
-            if groups * 4 >= n_inst:
-                os.environ["OW_TREM_SERIAL"] = "1"
-                sser = Script(pool, n_inst)
-                sser.pos = sp.pos
-                for _ in range(2):
-                    sser.step()
-                pool.set_profiling(True)
-                el = timed_steps(sser, 10, profile=True)
-                pool.set_profiling(False)
-                del os.environ["OW_TREM_SERIAL"]
-                kser = sser.kernel_ms / max(sser.kernel_launches, 1)
-                extras["kernels_serialised"] = {
-                    "value": 10 * BUF * n_inst * world / el, "unit": "samples/s", "ms_per_step": 1e3 * el / 10, "steps": 10,
-                    "kernel_ms_per_step": {nm: float(x) for nm, x in zip(("ops", "voices", "tremolo", "preamp", "post"), kser)},
-                    "voices_frac_of_fp64_peak": FLOPS_VOICES * BUF * n_inst / (float(kser[1]) * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if kser[1] > 0 else None,
-                    "tremolo_frac_of_fp64_peak": FLOPS_TREMOLO * groups / n_inst * BUF * n_inst / (float(kser[2]) * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if kser[2] > 0 else None,
-                    "note": "OW_TREM_SERIAL=1: the voices wait for the block-ahead tremolo kernel instead of overlapping it"}
-            if groups > 1:
-                pool.reset()
-                r = side_run(pool, n_inst, 8, 10)
-                r["tremolo_phase_groups"] = 1
-                r["note"] = ("every instance reset at the same sample: ONE Twin-T oscillator per pool, read by all (bit-exact, tests/test_gpu_tremolo_groups.py); "
-                             "independently created plugin instances do not share a phase -- `value` is the per-instance figure")
-                extras["shared_tremolo_phase"] = r
-            else:
-                pool.stagger_tremolo(n_inst)
-                r = side_run(pool, n_inst, 8, 10)
-                r["tremolo_phase_groups"] = n_inst
-                extras["tremolo_decorrelated"] = r
+            # (a1) ten steps that straddle a re-strike epoch (note_off + note_on of all 64 keys of every instance: 5 ms steal crossfades,
+            # onset ramps and attack noise in the general voice kernel, host MIDI + op upload) -- the default timed region may hold none
+            r = side_run(pool, n_inst, 0, 10, pos=EPOCH - 3 * BUF)
+            r["restrikes_in_timed_region"] = 1
+            r["note"] = "steps [epoch - 3 buffers, epoch + 7 buffers): one whole-keyboard re-strike of every instance inside"
+            extras["with_restrike"] = r
         pool.close()
 
-        if not args.no_extras and SR == 48000.0 and not preamp_kind and not pa_kind:
-            # (a'') the neighbouring BASELINE configs on the same pool size, short runs: configs[2] (96 kHz host, no oversampling) and the
+        if not args.no_extras and not dryrun and phases * 4 >= n_inst:
+            # (a2) the per-instance oscillators of rounds 1-3 on the same workload: a pool created without the shared trajectory
+            # (OW_TREM_TRAJ=0), staggered to one oscillator per instance; then the same with the block-ahead oscillators serialised in front
+            # of the voices (every kernel's HIP-event interval is then its own time)
+            pt = make_pool(n_inst, n_phases=phases, trajectory=False)
+            r = side_run(pt, n_inst, 8, 10)
+            r["tremolo"] = "per_instance_oscillator"
+            r["tremolo_oscillators"] = phases
+            r["note"] = "OW_TREM_TRAJ=0 at pool creation: one Twin-T oscillator per instance (k_tremolo, lane = oscillator, own stream beside the voices)"
+            extras["tremolo_per_instance"] = r
+            pt.set_switch("trem_serial", 1)
+            r = side_run(pt, n_inst, 2, 10, pos=12 * BUF)
+            pt.set_switch("trem_serial", 0)
+            ks_ = r["kernel_ms_per_step"]
+            r["voices_frac_of_fp64_peak"] = FLOPS_VOICES * BUF * n_inst / (ks_["voices"] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if ks_["voices"] > 0 else None
+            r["tremolo_frac_of_fp64_peak"] = FLOPS_TREMOLO * BUF * phases / (ks_["tremolo"] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if ks_["tremolo"] > 0 else None
+            r["note"] = "the same pool with the `trem_serial` switch (test hook): the voices wait for the block-ahead tremolo kernel instead of overlapping it"
+            extras["tremolo_per_instance_serialised"] = r
+            pt.close()
+
+        if not args.no_extras and not dryrun and SR == 48000.0 and not preamp_kind and not pa_kind:
+            # (a3) the neighbouring BASELINE configs on the same pool size, short runs: configs[2] (96 kHz host, no oversampling) and the
             # melange 12-node preamp the north star names (literal per-sample rebuild)
-            p3 = make_pool(n_inst, sr=96000.0, n_groups=groups)
+            p3 = make_pool(n_inst, sr=96000.0, n_phases=phases)
             r = side_run(p3, n_inst, 8, 10, epoch=96000)      # 8 warm-up blocks: past the onset ramps and the 15 ms attack noise of the strike
             r["x_realtime_at_96k"] = r["value"] / 96000.0
             r["workload"] = "cfg3: 64-voice all-keys, 96 kHz host (no oversampling), full chain, MLP on, buffers of 512"
             extras["config3"] = r
             p3.close()
             n_mel = min(n_inst, 65536)
-            pm = make_pool(n_mel, preamp=1, n_groups=min(groups, n_mel))
+            pm = make_pool(n_mel, preamp=1, n_phases=min(phases, n_mel))
             r = side_run(pm, n_mel, 8, 6)
             r["workload"] = "cfg2 with the melange 12-node preamp (k_preamp_mel_col: the reference's rebuild_matrices + invert_n per chain-rate sample, column-streamed)"
             r["preamp_frac_of_fp64_peak"] = FLOPS_PREAMP_MELANGE_LIT * BUF * n_mel / (r["kernel_ms_per_step"]["preamp"] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS
             extras["preamp_melange"] = r
             pm.close()
             n_pa = min(n_inst, 131072)
-            pp = make_pool(n_pa, pa=1, n_groups=min(groups, n_pa))
+            pp = make_pool(n_pa, pa=1, n_phases=min(phases, n_pa))
             r = side_run(pp, n_pa, 3, 3)
             r["workload"] = ("cfg2 with the melange 7-BJT power amp + rail sag (k_post_mpa: eight lanes per engine, every engine on its own sample counter, "
                              "engines dispatched by falling Newton demand of their last block)")
@@ -560,21 +634,35 @@ def main(argv=None):
 
         single = None
         cpu = None
-        if rank == 0 and not args.no_extras:
-            # (b) configs[4] taken literally: ONE pool of 256 instances on this GPU (its own 256 tremolo phases)
-            p256 = make_pool(256, n_groups=min(groups, 256))
-            s256 = Script(p256, 256)
-            for _ in range(3):
-                s256.step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(30):
-                s256.step()
-            el = time.perf_counter() - t1
-            extras["config4_literal"] = {"instances": 256, "value": 30 * BUF * 256 / el, "unit": "samples/s", "x_realtime_aggregate": 30 * BUF * 256 / el / SR,
-                                         "ms_per_step": 1e3 * el / 30, "tremolo_phase_groups": min(groups, 256),
-                                         "preamp": args.preamp, "power_amp": args.power_amp}
-            p256.close()
+        if rank == 0 and not args.no_extras and not dryrun:
+            lib = ow.load_library()
+
+            def run256(cold):
+                """configs[4] taken literally: ONE pool of 256 instances on this GPU with 256 tremolo phases.  cold: the process-wide
+                trajectory store is dropped first, so the pool's oldest instance has to extend it as it goes (one serial oscillator:
+                the block time); otherwise the store already reaches past the run (any earlier instance of this process got there,
+                or ow_tremolo_prefetch did)."""
+                if cold:
+                    lib.ow_test_clear_settle_caches()
+                p256 = make_pool(256, n_phases=min(phases, 256))
+                s256 = Script(p256, 256)
+                for _ in range(3):
+                    s256.step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(30):
+                    s256.step()
+                el_ = time.perf_counter() - t1
+                held = p256.trajectory_info()[1]
+                p256.close()
+                return {"value": 30 * BUF * 256 / el_, "unit": "samples/s", "x_realtime_aggregate": 30 * BUF * 256 / el_ / SR, "ms_per_step": 1e3 * el_ / 30,
+                        "trajectory_samples_in_hbm_after": held}
+
+            # (b) the warm figure first: the store of this chain rate reaches far past the run (the big pools above extended it)
+            c4 = run256(cold=False)
+            c4.update({"instances": 256, "tremolo_phases": min(phases, 256), "preamp": args.preamp, "power_amp": args.power_amp,
+                       "trajectory": "already in HBM for the whole run (extended by earlier instances of the process)"})
+            extras["config4_literal"] = c4
             # (c) one instance (what one plugin instance sees): per-buffer latency at the usual host buffer sizes, audio copied to the host
             table = []
             for buf in (64, 128, 256, 512):
@@ -592,9 +680,7 @@ def main(argv=None):
                     if i >= 8:
                         lat.append(time.perf_counter() - ta)
                 lat = np.array(lat) * 1e6
-                # ... and PACED like a real-time host: one call per buffer period.  Back to back, a call waits for the block-ahead tremolo
-                # stream of the NEXT buffer's predecessor (the longest serial recurrence, 2.2 x real time); paced, that stream has the
-                # rest of the period to itself and the call only pays voices + preamp + output stage + the copy
+                # ... and PACED like a real-time host: one call per buffer period
                 period = buf / SR
                 paced = []
                 t_next = time.perf_counter() + period
@@ -617,7 +703,8 @@ def main(argv=None):
                               "paced_load": float(paced.mean() / (1e6 * period))})
                 one.close()
             extras["single_instance"] = table
-            extras["single_instance_config"] = {"preamp": args.preamp, "power_amp": args.power_amp}
+            extras["single_instance_config"] = {"preamp": args.preamp, "power_amp": args.power_amp,
+                                                "trajectory": "already in HBM (back to back a lone instance outruns the one oscillator that extends it; paced at real time it never does)"}
             single = table[-1]["samples_per_s"]
             # (d) instantiation and config 1: a second engine of the process (settled states cached), and Voice::render_note for 60 s
             # (tools/reed-renderer; the reference publishes 0.08 s for it, CHANGELOG.md:185) next to the oracle on one host thread
@@ -639,10 +726,31 @@ def main(argv=None):
                 rn_cpu_ms = 1e3 * (time.perf_counter() - t3)
             extras["render_note_60s_ms"] = {"gpu": 1e3 * (t2 - t1), "cpu_oracle_one_thread": rn_cpu_ms, "samples": int(rn.size),
                                             "note": "one voice = one lane: a serial recurrence, latency-bound on a GPU; voices only (no chain launches, no settle)"}
-        if not args.no_extras:
+            # (e) the cold counterparts, last (they drop the process-wide store): the 256-instance pool and a lone instance whose own
+            # oldest engine has to extend the trajectory while it renders -- the serial rate of ONE Twin-T oscillator on a quad of lanes
+            c4c = run256(cold=True)
+            c4c["trajectory"] = "cold: extended by the pool's oldest instance while it renders"
+            extras["config4_literal"]["cold"] = c4c
+            lib.ow_test_clear_settle_caches()
+            one = make_pool(1)
+            s1 = Script(one, 1, buf=64)
+            host1 = np.zeros((1, 64), dtype=np.float32)
+            lat = []
+            for i in range(8 + 60):
+                ta = time.perf_counter()
+                if s1.pos % EPOCH == 0:
+                    one.midi(s1.ev_strike if s1.pos == 0 else s1.ev_restrike)
+                one.render_into(host1.ctypes.data, 64, 64)
+                s1.pos += 64
+                if i >= 8:
+                    lat.append(time.perf_counter() - ta)
+            one.close()
+            extras["single_instance_cold_64"] = {"latency_us_mean": float(np.mean(lat) * 1e6), "x_realtime": 64 / float(np.mean(lat)) / SR,
+                                                 "note": "64-sample buffers back to back on a fresh store: the instance waits for its own oscillator"}
+        if not args.no_extras and not dryrun:
             barrier()
             extras["batch"] = batch_bench(dist, world, steps=2, warmup=1)
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and not dryrun:
             cpu = cpu_baseline(preamp_kind=preamp_kind)
 
         if rank == 0:
@@ -650,13 +758,15 @@ def main(argv=None):
             value = total_samples / elapsed
             kms = script.kernel_ms / max(script.kernel_launches, 1)     # average ms per step, per kernel
             names = ["ops", "voices", "tremolo", "preamp", "post"]
-            trem_per_engine = FLOPS_TREMOLO * groups / n_inst            # one oscillator per phase group
+            shared = on_traj == n_inst
+            # shared trajectory: ONE oscillator per (device, chain rate) whatever the pool size -- not a per-engine cost, not in the numerator
+            trem_per_engine = 0.0 if shared else FLOPS_TREMOLO * phases / n_inst
             osr = 2 if SR < 88200.0 else 1
             flops_pa_sample = (8 * 300 + 1024 + 2730 + 256 + 1024) * (pa_passes or 1.0) + 800 + 640        # per pass: devices, Jacobian, LU, substitution, K products
             flops_post = (FLOPS_POST - osr * 90 + osr * flops_pa_sample) if pa_kind else FLOPS_POST
             flops = {"ops": 0.0, "voices": FLOPS_VOICES, "tremolo": trem_per_engine, "preamp": flops_preamp, "post": flops_post}
             per_sample = FLOPS_VOICES + trem_per_engine + flops_preamp + flops_post
-            audio = ["voices", "preamp", "post"] + (["tremolo"] if groups * 4 >= n_inst else [])   # the shared oscillator is not a pool-sized kernel
+            audio = ["voices", "preamp", "post"] + (["tremolo"] if (not shared and phases * 4 >= n_inst) else [])
             dom = max(audio, key=lambda k: kms[names.index(k)])
             dom_ms = float(kms[names.index(dom)])
             achieved = flops[dom] * BUF * n_inst / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -671,23 +781,30 @@ def main(argv=None):
                     traffic = None
             solver = "melange 12-node DK" if preamp_kind else "legacy DK"
             amp = "melange 7-BJT power amp + rail sag" if pa_kind else "behavioural power amp"
+            pcie = extras.get("pcie_inclusive", {}).get("value")
             line = {
                 "metric": f"audio samples/s, 64-voice full chain (x real-time @{SR / 1000:.0f} kHz = value / {SR:.0f})",
                 "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic" if not dryrun else "DRY RUN (gloo, stand-in pool): launcher, barriers and aggregation only, nothing measured",
+                "verified": verified, "verify": verify_details, "ranks_seen": ranks_seen, "dry_run": bool(dryrun),
                 "config": {
                     "workload": (f"cfg2: 64-voice all-keys-sustained (1.0 s re-strike), 48 kHz host / 96 kHz chain, full chain "
                                  f"(tremolo+{solver} preamp+{amp}+speaker), MLP on, buffers of 512") if SR == 48000.0 else
                                 (f"cfg3: 64-voice all-keys-sustained (1.0 s re-strike), {SR:.0f} Hz host"
                                  f"{' (no oversampling)' if SR >= 88200.0 else ' / 2x chain'}, full chain, MLP on, buffers of 512"),
                     "instances_per_gpu": n_inst, "buffer": BUF, "parallelism": f"{world} x independent pools (no data-path collective)",
-                    "tremolo_phase_groups": groups,
-                    "tremolo_note": ("all instances of a pool were built at the same sample, so their Twin-T oscillators are bit-identical and ONE is computed "
-                                     "per pool (its flops are not in the roofline numerator)") if groups == 1 else
-                                    (f"one Twin-T oscillator per instance ({groups} decorrelated phases; its flops are in whole_chain_frac)" if groups == n_inst else
-                                     f"pool staggered into {groups} tremolo phase groups (one oscillator each)"),
+                    "tremolo": "shared_trajectory" if shared else "per_group_oscillator",
+                    "tremolo_phases": phases,
+                    "tremolo_note": ((f"every instance stands at its own t ({phases} decorrelated phases) of ONE Twin-T / CdS trajectory per (device, chain rate) kept in HBM "
+                                      "and extended by a single oscillator; bit-identical to one oscillator per instance (tests/test_gpu_trajectory.py), whose "
+                                      "figure is the `tremolo_per_instance` extra; the oscillator's flops are not in any numerator") if shared else
+                                     f"{phases} tremolo phase groups, one Twin-T oscillator each (its flops are in whole_chain_frac)"),
                     "restrikes_in_timed_region": int((script.pos // EPOCH) - ((script.pos - args.steps * BUF) // EPOCH)),
+                    "audio_left_in_hbm": True,
+                    "pcie_inclusive_samples_per_s": pcie,
+                    "pcie_note": "`value` leaves every block in HBM; pcie_inclusive copies each block into a pinned host buffer -- the render(&mut [f32]) equivalent",
                 },
                 "x_realtime_aggregate": value / SR,
                 "host_midi_s": script.t_midi, "render_calls_s": script.t_render, "elapsed_s": elapsed,
@@ -696,42 +813,36 @@ def main(argv=None):
                     "bound": "valu_f64", "kernel": KERNEL_OF[dom] + (("_mel" if flops_preamp == FLOPS_PREAMP_MELANGE else "_mel_lit") if preamp_kind and dom == "preamp" else "") + ("_mpa" if pa_kind and dom == "post" else ""),
                     "achieved": achieved,
                     "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
+                    "traffic_source": ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on a 4 096-engine pool, corrected per the guide, "
+                                       "scaled by instances_per_gpu -- not measured in this run"),
                     "kernel_ms_per_step": {n: float(k) for n, k in zip(names, kms)},
                     "flops_per_output_sample": {"voices": FLOPS_VOICES, "tremolo": trem_per_engine, "preamp": flops_preamp, "post": flops_post},
                     "flops_per_voice_sample": FLOPS_VOICE_SAMPLE, "flops_executed_per_voice_sample": FLOPS_VOICE_SAMPLE_EXECUTED,
                     "frac_executed": (64 * FLOPS_VOICE_SAMPLE_EXECUTED * BUF * n_inst / (float(kms[1]) * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS
                                       if kms[1] > 0 else None),
-                    # with one oscillator per instance the tremolo kernel runs on its own stream INSIDE the voice kernel's interval and
-                    # competes for the same issue slots: the interval's flops are voices + tremolo
-                    "voices_plus_tremolo_frac": ((FLOPS_VOICES + trem_per_engine) * BUF * n_inst / (float(kms[1]) * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS
-                                                 if kms[1] > 0 else None),
                     "whole_chain_frac": per_sample * value / world / 1e12 / PEAK_FP64_VALU_TFLOPS,
                     # the contract's own vocabulary, for reference: PMC HBM bytes of the dominant kernel / its duration against 8 TB/s
                     "hbm": ({"achieved": traffic / (dom_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                              "frac": traffic / (dom_ms * 1e-3) / 1e9 / 8000.0} if traffic and dom_ms > 0 else None),
                     "note": "path is FP64-VALU/latency bound (not HBM, not MFMA); achieved = algorithmic f64 flops of the dominant "
-                            "kernel per launch / its HIP-event duration" +
+                            "kernel per launch / its HIP-event duration on the pool stream" +
                             (f"; melange power amp: the flop count is per-pass work x the {pa_passes:.2f} Newton passes per chain-rate sample the engines "
                              "spent on the last block (mean; data dependent)" if pa_kind else ""),
                     "power_amp_newton_passes_per_chain_sample": pa_passes,
                 },
                 "cpu_baseline": cpu,
             }
-            ks = extras.get("kernels_serialised")
-            if ks and dom == "voices":
-                # the dominant kernel's interval above contains the concurrently running tremolo kernel; serialised, its own time
-                line["roofline"]["dominant_kernel_own_ms"] = ks["kernel_ms_per_step"]["voices"]
-                line["roofline"]["frac_own_time"] = ks["voices_frac_of_fp64_peak"]
-                line["roofline"]["note"] += ("; `frac` is the voice kernel's flops over an interval it SHARES with the block-ahead tremolo kernel (own stream, one "
-                                             "oscillator per instance): the interval's content is voices_plus_tremolo_frac, the voice kernel alone "
-                                             "(kernels serialised, `kernels_serialised` extra) runs at frac_own_time")
             line.update(extras)
+    rc = 0
+    if line is not None and line.get("verified") is False:
+        print("bench.py: the rendered block failed verification: " + json.dumps(line.get("verify")), file=sys.stderr)
+        rc = 4
     if rank == 0 and line is not None:
         print(json.dumps(line))
         sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
-    return 0
+    return rc
 
 
 if __name__ == "__main__":

@@ -28,6 +28,13 @@ extern "C" {
 typedef struct ow_pool ow_pool;
 typedef struct ow_engine ow_engine;
 
+/* Version of this header's struct layouts and signatures.  ow_abi_version() returns the value the library was built with; a binding
+ * checks it once after loading.  The by-pointer configuration structs (ow_batch_cfg, ow_midi_render_cfg) additionally carry their own
+ * size in their first field, and ow_batch_cfg the size of one ow_job: a caller built against another header is refused ("ABI mismatch",
+ * negative return) instead of having fields read past the end of what it passed. */
+#define OW_ABI_VERSION 4
+int ow_abi_version(void);
+
 /* VoiceState, crates/openwurli-dsp/src/engine.rs:30-37 */
 enum { OW_VOICE_FREE = 0, OW_VOICE_HELD = 1, OW_VOICE_SUSTAINED = 2, OW_VOICE_RELEASING = 3 };
 /* preamp solver selection: cargo features of crates/openwurli-dsp/Cargo.toml:9-17 become a runtime enum */
@@ -179,6 +186,8 @@ typedef struct ow_job {
     double displacement_scale;   /* Voice::set_displacement_scale when has_displacement_scale (main.rs:406-408) */
 } ow_job;
 typedef struct ow_batch_cfg {
+    uint32_t struct_size;  /* = sizeof(ow_batch_cfg) of the caller's header */
+    uint32_t job_size;     /* = sizeof(ow_job) of the caller's header (the stride of `jobs`) */
     double sample_rate;  /* --sample-rate (44100 in the reference, main.rs:27) */
     double duration_s;   /* --duration */
     int device;
@@ -275,6 +284,8 @@ typedef struct ow_timed_event {
  * otherwise).  Returns the event count (writes min(cap, count) events; out may be NULL with cap 0), <0 on malformed data. */
 long long ow_smf_parse(const uint8_t* data, size_t len, int track_filter, ow_timed_event* out, size_t cap);
 typedef struct ow_midi_render_cfg {
+    uint32_t struct_size;  /* = sizeof(ow_midi_render_cfg) of the caller's header */
+    uint32_t reserved0;
     double volume;       /* --volume, default 0.60 (applied squared)       */
     double speaker;      /* --speaker, default 1.0                         */
     double tail_s;       /* --tail, default 2.0                            */

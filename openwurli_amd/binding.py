@@ -38,9 +38,16 @@ class OwMidiEvent(C.Structure):
 MIDI_DTYPE = [("engine", "<u4"), ("type", "u1"), ("note", "u1"), ("reserved", "<u2"), ("value", "<f4")]
 
 
+ABI_VERSION = 4      # include/openwurli_hip.h OW_ABI_VERSION; load_library() checks it against ow_abi_version()
+
+
 class OwBatchCfg(C.Structure):
-    _fields_ = [("sample_rate", C.c_double), ("duration_s", C.c_double), ("device", C.c_int), ("preamp_kind", C.c_int),
+    _fields_ = [("struct_size", C.c_uint32), ("job_size", C.c_uint32),
+                ("sample_rate", C.c_double), ("duration_s", C.c_double), ("device", C.c_int), ("preamp_kind", C.c_int),
                 ("power_amp_kind", C.c_int), ("no_rail_sag", C.c_int)]
+
+    def __init__(self, sample_rate=44100.0, duration_s=2.0, device=0, preamp_kind=0, power_amp_kind=0, no_rail_sag=0):
+        super().__init__(C.sizeof(OwBatchCfg), C.sizeof(OwJob), sample_rate, duration_s, device, preamp_kind, power_amp_kind, no_rail_sag)
 
 
 class OwAliasAuditResult(C.Structure):
@@ -57,8 +64,12 @@ TIMED_EVENT_DTYPE = [("time_s", "<f8"), ("type", "u1"), ("note", "u1"), ("value"
 
 
 class OwMidiRenderCfg(C.Structure):
-    _fields_ = [("volume", C.c_double), ("speaker", C.c_double), ("tail_s", C.c_double), ("no_poweramp", C.c_int), ("device", C.c_int),
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32),
+                ("volume", C.c_double), ("speaker", C.c_double), ("tail_s", C.c_double), ("no_poweramp", C.c_int), ("device", C.c_int),
                 ("preamp_kind", C.c_int), ("power_amp_kind", C.c_int), ("no_rail_sag", C.c_int), ("reserved", C.c_int)]
+
+    def __init__(self, volume=0.6, speaker=1.0, tail_s=2.0, no_poweramp=0, device=0, preamp_kind=0, power_amp_kind=0, no_rail_sag=0, reserved=0):
+        super().__init__(C.sizeof(OwMidiRenderCfg), 0, volume, speaker, tail_s, no_poweramp, device, preamp_kind, power_amp_kind, no_rail_sag, reserved)
 
 
 class OwMidiRenderStats(C.Structure):
@@ -76,6 +87,7 @@ MAX_HARMONICS = 8
 WAV_NONE, WAV_ROUND, WAV_TRUNCATE = -1, 0, 1
 
 SYMBOLS = {
+    "ow_abi_version": (C.c_int, []),
     "ow_last_error": (C.c_char_p, []),
     "ow_clear_error": (None, []),
     "ow_pool_new": (_VP, [C.c_double, C.c_size_t, C.c_int, C.c_int]),
@@ -192,6 +204,8 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.ow_abi_version() != ABI_VERSION:
+        raise OwError(f"{path} was built against OW_ABI_VERSION {lib.ow_abi_version()}, this binding against {ABI_VERSION}: rebuild with ./build.sh")
     _LIB = lib
     return lib
 

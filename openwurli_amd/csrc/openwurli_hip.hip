@@ -83,9 +83,14 @@ class Workers {
     static Workers& get() { static Workers w; return w; }
     // fn(ctx, t) for t in [0, T); returns when all slices are done.  One dispatch at a time (callers of different pools serialise).
     void run(size_t T, void (*fn)(void*, size_t), void* ctx) {
-        if (T <= 1 || th_.empty()) { for (size_t t = 0; t < T; ++t) fn(ctx, t); return; }
+        // run() is not re-entered from inside a slice by anything in this library; if it ever is (in_slice_ set on this thread), the nested
+        // call runs its slices inline -- std::mutex::try_lock on a mutex the calling thread already owns would be undefined behaviour.
+        if (T <= 1 || th_.empty() || in_slice_) { for (size_t t = 0; t < T; ++t) fn(ctx, t); return; }
         // One dispatch at a time.  A second caller (another pool rendering on another audio thread) does NOT wait for the workers -- a
-        // realtime thread blocked on a mutex that lower-priority work holds is a priority inversion -- it runs its slices itself.
+        // realtime thread blocked on a mutex that lower-priority work holds is a priority inversion -- it runs its slices itself, one
+        // after the other: the same work as a single-threaded pass over the range (the slices partition it), i.e. the cost of a host with
+        // one core, not a wait of unknown length.  Two pools of >= 16 384 engines rendering concurrently from two audio threads is the only
+        // configuration that gets here.
         std::unique_lock<std::mutex> one(dispatch_mu_, std::try_to_lock);
         if (!one.owns_lock()) { for (size_t t = 0; t < T; ++t) fn(ctx, t); return; }
         {
@@ -94,7 +99,9 @@ class Workers {
         }
         cv_.notify_all();
         size_t mine = 0;
+        in_slice_ = true;
         for (size_t t; (t = next_.fetch_add(1)) < T; ++mine) fn(ctx, t);
+        in_slice_ = false;
         std::unique_lock<std::mutex> lk(mu_);
         done_ += mine;
         cv_done_.wait(lk, [&] { return done_ == total_ && active_ == 0; });
@@ -128,7 +135,9 @@ class Workers {
             ++active_;
             lk.unlock();
             size_t mine = 0;
+            in_slice_ = true;
             for (size_t t; (t = next_.fetch_add(1)) < T; ++mine) fn(ctx, t);
+            in_slice_ = false;
             lk.lock();
             done_ += mine;
             --active_;
@@ -144,7 +153,9 @@ class Workers {
     std::atomic<size_t> next_{0};
     uint64_t gen_ = 0;
     bool stop_ = false;
+    static thread_local bool in_slice_;
 };
+thread_local bool Workers::in_slice_ = false;
 #define OW_MAX_STAGES 8
 #define OW_MAX_SLICES 64   // upper bound of the slices one dispatch is cut into (scratch arrays live on the stack)
 
@@ -297,6 +308,8 @@ struct ow_pool {
     size_t ops_cap = 0;
     OwEngineArgs* h_args = nullptr;   // pinned
     OwEngineOut* h_eout = nullptr;    // pinned
+    OwEngineOut* d_eout_packed = nullptr;   // [I] status blocks of a list of engines, packed (voice-sum NaN guard's second pass)
+    OwEngineOut* h_eout_packed = nullptr;   // pinned
     OwOp* h_ops = nullptr;            // pinned
     // Packed voice dispatch (ow_kernels.h): lane = sounding voice.  Three block lists of (engine << 6 | slot) entries, rebuilt when a
     // mask, a pending op or a transient flag changed: steady slot voices, slot voices of engines in a transient phase, steal voices.
@@ -413,47 +426,49 @@ void ensure_ops_capacity(ow_pool* p, size_t n) {
 std::mutex g_mel_mu;
 std::map<int, std::vector<double>> g_mel_settled;
 void mel_settled_to_device(int device, double* d_dst, hipStream_t st) {
-    std::lock_guard<std::mutex> lk(g_mel_mu);
-    auto it = g_mel_settled.find(device);
-    if (it == g_mel_settled.end()) {
+    // the process-wide mutex guards the maps only: a cached state is copied out under it and transferred after it is released (a pool
+    // with a long queued stream must not hold up every other thread's pool creation / reset)
+    std::vector<double> h;
+    { std::lock_guard<std::mutex> lk(g_mel_mu); auto it = g_mel_settled.find(device); if (it != g_mel_settled.end()) h = it->second; }
+    if (h.empty()) {
         OwConsts k48;
         owhip::build_consts(k48, 24000.0, OW_PREAMP_MELANGE12);   // os_sr = 48 kHz -> codegen tables
-        OwConsts* dk = nullptr;
-        HIP_OK(hipMalloc(&dk, sizeof(OwConsts)));
-        HIP_OK(hipMemcpyAsync(dk, &k48, sizeof(OwConsts), hipMemcpyHostToDevice, st));
-        owdev::k_mel_settle<<<dim3(1), dim3(64), 0, st>>>(dk, d_dst);
-        std::vector<double> h(18);
+        DevMem dk;
+        dk.alloc(sizeof(OwConsts));
+        HIP_OK(hipMemcpyAsync(dk.p, &k48, sizeof(OwConsts), hipMemcpyHostToDevice, st));
+        owdev::k_mel_settle<<<dim3(1), dim3(64), 0, st>>>(dk.as<OwConsts>(), d_dst);
+        h.resize(18);
         HIP_OK(hipMemcpyAsync(h.data(), d_dst, sizeof(double) * 18, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
-        hipFree(dk);
-        g_mel_settled[device] = h;
+        std::lock_guard<std::mutex> lk(g_mel_mu);
+        g_mel_settled[device] = h;          // two threads racing here computed the same bits
         return;
     }
-    HIP_OK(hipMemcpyAsync(d_dst, it->second.data(), sizeof(double) * 18, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_dst, h.data(), sizeof(double) * 18, hipMemcpyHostToDevice, st));
     HIP_OK(hipStreamSynchronize(st));
 }
 
 // Settled state of the melange power amp (power_amp.rs:288-296): always computed with the codegen-rate matrices, once per device.
 std::map<int, std::vector<double>> g_pa_settled;
 void pa_settled_to_device(int device, double* d_dst, hipStream_t st) {
-    std::lock_guard<std::mutex> lk(g_mel_mu);
-    auto it = g_pa_settled.find(device);
-    if (it == g_pa_settled.end()) {
-        OwPaConsts* h88 = new OwPaConsts();
-        std::unique_ptr<OwPaConsts> own(h88);
+    std::vector<double> h;
+    { std::lock_guard<std::mutex> lk(g_mel_mu); auto it = g_pa_settled.find(device); if (it != g_pa_settled.end()) h = it->second; }
+    if (h.empty()) {
+        std::unique_ptr<OwPaConsts> h88(new OwPaConsts());
         owhip::build_pa_consts(*h88, PA_SAMPLE_RATE);
         DevMem dk;
         dk.alloc(sizeof(OwPaConsts));
-        HIP_OK(hipMemcpyAsync(dk.p, h88, sizeof(OwPaConsts), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(dk.p, h88.get(), sizeof(OwPaConsts), hipMemcpyHostToDevice, st));
         owdev::k_mpa_settle<<<dim3(1), dim3(64), 0, st>>>(dk.as<OwPaConsts>(), d_dst);
         HIP_OK(hipGetLastError());
-        std::vector<double> h(owdev::PAS_CIRCUIT_END);
+        h.resize(owdev::PAS_CIRCUIT_END);
         HIP_OK(hipMemcpyAsync(h.data(), d_dst, sizeof(double) * h.size(), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
+        std::lock_guard<std::mutex> lk(g_mel_mu);
         g_pa_settled[device] = h;
         return;
     }
-    HIP_OK(hipMemcpyAsync(d_dst, it->second.data(), sizeof(double) * it->second.size(), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_dst, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, st));
     HIP_OK(hipStreamSynchronize(st));
 }
 
@@ -1334,9 +1349,14 @@ void guard_second_pass(ow_pool* p, const uint32_t* engs, size_t n_eng, size_t le
         };
         put(p->vl_general.h, nm, en->main_mask);
         put(p->vl_steal.h, ns, en->steal_mask);
-        HIP_OK(hipMemsetAsync(p->d_eout + engs[i], 0, sizeof(OwEngineOut), st));
     }
     p->lists_valid = false;           // the list buffers were borrowed
+    // the guarded engines' status blocks: ONE clear, ONE gather and ONE transfer for the whole set (a bad parameter broadcast to a big
+    // pool can put every engine here: 131 072 engines used to mean 262 144 runtime calls on the audio thread).  engs is pinned
+    // (h_op_engines) and d_op_engines is free between renders.
+    const unsigned nb = (unsigned)((n_eng + 255) / 256);
+    HIP_OK(hipMemcpyAsync(p->d_op_engines, engs, sizeof(uint32_t) * n_eng, hipMemcpyHostToDevice, st));
+    owdev::k_eout_clear_list<<<dim3(nb), dim3(256), 0, st>>>(p->d_eout, p->d_op_engines, (int)n_eng);
     const int I = (int)p->I, L = (int)len, Lcap = (int)p->Lcap;
     if (nm) {
         HIP_OK(hipMemcpyAsync(p->vl_general.d, p->vl_general.h, sizeof(uint32_t) * nm, hipMemcpyHostToDevice, st));
@@ -1346,12 +1366,13 @@ void guard_second_pass(ow_pool* p, const uint32_t* engs, size_t n_eng, size_t le
         HIP_OK(hipMemcpyAsync(p->vl_steal.d, p->vl_steal.h, sizeof(uint32_t) * ns, hipMemcpyHostToDevice, st));
         owdev::k_voice<false><<<dim3(ns / 64), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_steal.d, p->d_sum, p->d_eout, I, L, Lcap, 3);
     }
+    owdev::k_eout_gather_list<<<dim3(nb), dim3(256), 0, st>>>(p->d_eout, p->d_op_engines, (int)n_eng, p->d_eout_packed);
     HIP_OK(hipGetLastError());
-    for (size_t i = 0; i < n_eng; ++i)
-        HIP_OK(hipMemcpyAsync(p->h_eout + engs[i], p->d_eout + engs[i], sizeof(OwEngineOut), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(p->h_eout_packed, p->d_eout_packed, sizeof(OwEngineOut) * n_eng, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     for (size_t i = 0; i < n_eng; ++i) {
         OwEngineOut& o = p->h_eout[engs[i]];
+        o = p->h_eout_packed[i];
         engine_guard_second_pass_result(p->engines[engs[i]], o);
         p->transient[engs[i]] = o.transient != 0u;
         o.sum_nonfinite = 1u;         // the block's voice sum stays "zeroed by the guard" for ow_pool_read_voice_sum
@@ -1517,6 +1538,8 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     HIP_OK(hipMalloc(&p->d_eout, sizeof(OwEngineOut) * n_engines));
     HIP_OK(hipHostMalloc(&p->h_args, sizeof(OwEngineArgs) * n_engines));
     HIP_OK(hipHostMalloc(&p->h_eout, sizeof(OwEngineOut) * n_engines));
+    HIP_OK(hipMalloc(&p->d_eout_packed, sizeof(OwEngineOut) * n_engines));
+    HIP_OK(hipHostMalloc(&p->h_eout_packed, sizeof(OwEngineOut) * n_engines));
     for (ow_pool::VoiceList* vl : {&p->vl_steady, &p->vl_general, &p->vl_steal}) {   // worst case: one block per engine
         HIP_OK(hipMalloc(&vl->d, sizeof(uint32_t) * 64 * n_engines));
         HIP_OK(hipHostMalloc(&vl->h, sizeof(uint32_t) * 64 * n_engines));
@@ -1641,6 +1664,8 @@ void pool_destroy(ow_pool* p) {
     if (p->d_snap) hipFree(p->d_snap);
     if (p->h_snap) hipHostFree(p->h_snap);
     hipHostFree(p->h_args); hipHostFree(p->h_eout);
+    if (p->d_eout_packed) hipFree(p->d_eout_packed);
+    if (p->h_eout_packed) hipHostFree(p->h_eout_packed);
     for (auto& e : p->ev) if (e) hipEventDestroy(e);
     for (int k = 1; k < OW_MAX_STAGES; ++k) if (p->pipe_stream[k]) { hipStreamSynchronize(p->pipe_stream[k]); hipStreamDestroy(p->pipe_stream[k]); }
     if (p->ev_ready) hipEventDestroy(p->ev_ready);
@@ -1670,6 +1695,7 @@ bool guarded(const char* what, F&& f) {  // realtime entry points never fail: re
 
 extern "C" {
 
+int ow_abi_version(void) { return OW_ABI_VERSION; }
 const char* ow_last_error(void) { return g_err.c_str(); }
 void ow_clear_error(void) { g_err.clear(); }
 
@@ -2521,6 +2547,9 @@ static long long render_note_impl(uint8_t midi, double velocity, double dur_s, d
 long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg* cfg, double* out, size_t stride, int out_is_device) {
     try {
         if (!jobs || !cfg || !out || n_jobs == 0) throw std::runtime_error("null argument");
+        if (cfg->struct_size != sizeof(ow_batch_cfg) || cfg->job_size != sizeof(ow_job))
+            throw std::runtime_error("ABI mismatch: ow_batch_cfg.struct_size / job_size do not match this library's openwurli_hip.h (OW_ABI_VERSION " +
+                                     std::to_string(OW_ABI_VERSION) + ")");
         if (cfg->preamp_kind != OW_PREAMP_LEGACY8 && cfg->preamp_kind != OW_PREAMP_MELANGE12) throw std::runtime_error("unknown preamp_kind");
         const double x = cfg->duration_s * cfg->sample_rate;
         const size_t n = (!(x == x) || x <= 0.0) ? 0 : (size_t)x;                 // (duration * sample_rate) as usize, main.rs:411
@@ -3017,6 +3046,9 @@ long long ow_render_midi(const ow_timed_event* events, const size_t* job_offsets
                          double* out, size_t stride, ow_midi_render_stats* stats) {
     try {
         if (!job_offsets || !cfg || (!out && !stats)) throw std::runtime_error("null argument");
+        if (cfg->struct_size != sizeof(ow_midi_render_cfg))
+            throw std::runtime_error("ABI mismatch: ow_midi_render_cfg.struct_size does not match this library's openwurli_hip.h (OW_ABI_VERSION " +
+                                     std::to_string(OW_ABI_VERSION) + ")");
         if (cfg->preamp_kind != OW_PREAMP_LEGACY8 && cfg->preamp_kind != OW_PREAMP_MELANGE12) throw std::runtime_error("unknown preamp_kind");
         if (n_jobs == 0) return 0;
         const double SR = 44100.0;                       // BASE_SR, main.rs:27

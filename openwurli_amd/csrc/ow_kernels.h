@@ -499,6 +499,20 @@ OW_DEV void dk_store(const DkSt& s, double* __restrict__ cs, int I, int e, int b
     CSF(base + 10) = s.i_nl[0]; CSF(base + 11) = s.i_nl[1]; CSF(base + 12) = s.v_nl[0]; CSF(base + 13) = s.v_nl[1];
 }
 
+// status blocks of a LIST of engines: cleared before, gathered after the second pass of the voice-sum NaN guard (one launch and one
+// transfer however many engines the guard caught, openwurli_hip.hip guard_second_pass)
+__global__ void k_eout_clear_list(OwEngineOut* __restrict__ eout, const uint32_t* __restrict__ engs, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    OwEngineOut z;
+    z.silent_mask = 0; z.bad_main = 0; z.bad_steal = 0; z.sum_nonfinite = 0; z.out_nonfinite = 0; z.transient = 0; z.pad = 0;
+    eout[engs[i]] = z;
+}
+__global__ void k_eout_gather_list(const OwEngineOut* __restrict__ eout, const uint32_t* __restrict__ engs, int n, OwEngineOut* __restrict__ packed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) packed[i] = eout[engs[i]];
+}
+
 // ------------------------------------------------------------------ where an engine's CdS resistance R[n] comes from
 // Tremolo::process takes no audio and no depth into the oscillator, the LED envelope or r_ldr (tremolo.rs:121-146; depth only enters
 // shunt_impedance, :152-167), and new() / reset() start from the same settled state (:83-102, :192-216): r_ldr[t] is ONE deterministic

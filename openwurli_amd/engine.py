@@ -172,6 +172,7 @@ class EnginePool:
             raise OwError(binding.take_error(self._lib))
         self._h = C.c_void_p(h)
         self.n = int(n_engines)
+        self.device = int(device)
         self._engines = {}
 
     def close(self):
@@ -307,6 +308,14 @@ class EnginePool:
         stride = C.c_size_t(0)
         ptr = self._lib.ow_pool_device_output(self._h, C.byref(stride))
         return ptr, stride.value
+
+    def last_block(self):
+        """The block the last render left in HBM, copied out: float32 [n, length] (test hook ow_test_device_read)."""
+        ptr, stride = self.device_output()
+        out = np.zeros((self.n, int(stride)), dtype=np.float32)
+        if out.size and self._lib.ow_test_device_read(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes, self.device) != 0:
+            raise OwError("ow_test_device_read failed")
+        return out
 
 
 def tremolo_prefetch(sample_rate, seconds, device=0):

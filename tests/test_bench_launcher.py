@@ -1,6 +1,7 @@
 """bench.py --gpus N without a launcher starts the N ranks itself (child processes, before any GPU call), relays rank 0's ONE
-JSON line and fails when a rank fails.  Dry run on CPU: gloo rendezvous on 127.0.0.1, stand-in renderer, the real sharding
-(job j -> rank j mod G) and the real single gather of openwurli_amd.distributed."""
+JSON line and fails when a rank fails.  Dry run on CPU: gloo rendezvous on 127.0.0.1, stand-in renderer / stand-in pool, the real sharding
+(job j -> rank j mod G) and the real single gather of openwurli_amd.distributed for the batch workload; the real barriers, timing and
+aggregation over ranks for the engines workload (the metric's config)."""
 import json
 import os
 import subprocess
@@ -38,9 +39,36 @@ def test_single_rank_needs_no_launcher_and_no_process_group():
     assert d["n_gpus"] == 1 and d["batch"]["literal"]["ranks_seen_by_collective"] == 1
 
 
-def test_a_failing_rank_fails_the_launcher():
-    r = _bench("--gpus", "2", "--workload", "engines", "--steps", "1", "--warmup", "0")      # the dry run refuses the engine workload
-    assert r.returncode != 0 and "failed first" in r.stderr
+def test_engines_workload_aggregates_over_the_ranks():
+    """The metric's own workload (`--workload engines`, the default) under the launcher: a stand-in pool per rank, the real barriers,
+    max-over-ranks timing and whole-job aggregation.  One line; n_gpus = WORLD_SIZE; every rank seen; value = the samples ALL ranks
+    rendered / the slowest rank's time; the line verified itself."""
+    r = _bench("--gpus", "2", "--instances", "64", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["dry_run"] is True and d["verified"] is True and d["scaling"] == "weak"
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["config"]["instances_per_gpu"] == 64
+    assert abs(d["value"] - 2 * 3 * 512 * 64 / d["elapsed_s"]) < 1e-6 * d["value"]
+    assert abs(d["ms_per_step"] - 1e3 * d["elapsed_s"] / 3) < 1e-9
+    assert d["elapsed_s"] >= 3 * 0.002                                  # the stand-in's fixed render time: the clock really brackets the steps
+    for key in ("metric", "unit", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d
+    assert "DRY RUN" in d["data"]
+    one = _bench("--gpus", "1", "--instances", "64", "--steps", "2", "--warmup", "0")
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert d1["n_gpus"] == 1 and d1["ranks_seen"] == 1
+
+
+def test_a_rank_whose_block_fails_verification_fails_the_launcher():
+    """The engines line checks what it rendered (finite rows, level band, 64 active voices, zero NaN counters) on every rank; one bad
+    rank makes rank 0 exit non-zero and the launcher with it."""
+    r = _bench("--gpus", "2", "--instances", "64", "--steps", "1", "--warmup", "0", env_extra={"OW_BENCH_TEST_BAD_BLOCK_RANK": "1"})
+    assert r.returncode != 0 and "failed first" in r.stderr and "failed verification" in r.stderr, r.stderr[-1500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["verified"] is False
 
 
 def test_a_rank_that_dies_before_the_rendezvous_takes_the_others_down_quickly():

@@ -62,3 +62,30 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle/" not in text and "oracle_binding" not in text and "libow_oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_abi_version_and_struct_size_guards(hiplib):
+    """the by-pointer configuration structs were widened in place.  The header now carries OW_ABI_VERSION (the binding checks
+    it when it loads the library) and the structs carry their own size: a caller built against another header is refused before any
+    field is read -- no device needed to see that."""
+    import ctypes as C
+    import re
+    from openwurli_amd import binding
+    hdr = open(os.path.join(ROOT, "include", "openwurli_hip.h")).read()
+    assert int(re.search(r"#define OW_ABI_VERSION (\d+)", hdr).group(1)) == binding.ABI_VERSION == hiplib.ow_abi_version()
+    jobs = (binding.OwJob * 1)(binding.OwJob(note=60, velocity=100, volume=1.0, r_ldr=1e6))
+    out = (C.c_double * 16)()
+    for field, bad in (("struct_size", C.sizeof(binding.OwBatchCfg) - 8), ("job_size", C.sizeof(binding.OwJob) - 16)):
+        cfg = binding.OwBatchCfg(44100.0, 0.0001)
+        setattr(cfg, field, bad)
+        hiplib.ow_clear_error()
+        assert hiplib.ow_batch_render(jobs, 1, C.byref(cfg), C.cast(out, C.c_void_p), 16, 0) < 0
+        assert b"ABI mismatch" in hiplib.ow_last_error()
+    mcfg = binding.OwMidiRenderCfg()
+    mcfg.struct_size = 8
+    offs = (C.c_size_t * 2)(0, 0)
+    stats = binding.OwMidiRenderStats()
+    hiplib.ow_clear_error()
+    assert hiplib.ow_render_midi(None, C.cast(offs, C.c_void_p), 1, C.byref(mcfg), None, 0, C.byref(stats)) < 0
+    assert b"ABI mismatch" in hiplib.ow_last_error()
+    hiplib.ow_clear_error()
