@@ -98,6 +98,12 @@ void owo_mpa_stats(unsigned long long* out21, int reset) {
     if (out21) for (int i = 0; i < 21; ++i) out21[i] = st.v[i];
     if (reset) st = PaStats{};
 }
+// inner-loop trips of bjt_with_parasitics by device since the last reset: out[8][16] (what the device-phase mapping of k_post_mpa is sized from)
+void owo_mpa_inner_hist(unsigned long long* out128, int reset) {
+    PaStats& st = pa_stats();
+    if (out128) for (int d = 0; d < 8; ++d) for (int t = 0; t < 16; ++t) out128[d * 16 + t] = st.inner_hist[d][t];
+    if (reset) for (int d = 0; d < 8; ++d) for (int t = 0; t < 16; ++t) st.inner_hist[d][t] = 0;
+}
 void owo_mpa_rails(void* p, double* pos, double* neg) {
     const MelangePowerAmp* a = (const MelangePowerAmp*)p;
     *pos = a->rail_sag_on ? a->rails.v_rail_pos : 22.5; *neg = a->rail_sag_on ? a->rails.v_rail_neg : 22.5;

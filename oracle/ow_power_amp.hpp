@@ -111,7 +111,7 @@ inline double pa_clamp(double x, double lo, double hi) { return x < lo ? lo : (x
 // Statistics of the Newton passes since the last owo_mpa_stats(reset) -- numbers the GPU mapping was designed from:
 // [0] passes, [1] passes with at least one row exchange, [2] row exchanges, [3] sum over passes of the deepest inner loop of the pass,
 // [4] sum over passes and devices of the inner-loop trips, [5..20] row exchanges by column
-struct PaStats { unsigned long long v[21]; };
+struct PaStats { unsigned long long v[21]; unsigned long long inner_hist[8][16]; };   // inner_hist[d][t]: calls of device d whose inner loop made t trips
 inline PaStats& pa_stats() { static thread_local PaStats s = {}; return s; }
 inline PaBjt pa_bjt_with_parasitics(double vbe_ext, double vbc_ext, int d, int* inner_iters = nullptr) {
     const double rb = PA_DEV_RB[d], rc = PA_DEV_RC[d], re = PA_DEV_RE[d], vt = PA_DEV_VT[d];
@@ -138,7 +138,7 @@ inline PaBjt pa_bjt_with_parasitics(double vbe_ext, double vbc_ext, int d, int* 
         vbe_int -= dvbe;
         vbc_int -= dvbc;
     }
-    if (inner_iters) *inner_iters += it;
+    if (inner_iters) { *inner_iters += it; pa_stats().inner_hist[d][it < 15 ? it : 15] += 1; }
     const PaBjt e = pa_bjt_evaluate(vbe_int, vbc_int, d);
     const double dic_dvbe = e.jac[0], dic_dvbc = e.jac[1], dib_dvbe = e.jac[2], dib_dvbc = e.jac[3];
     const double j11 = 1.0 + dib_dvbe * rb + (dic_dvbe + dib_dvbe) * re;
