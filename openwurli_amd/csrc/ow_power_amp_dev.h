@@ -34,6 +34,15 @@ enum {
 };
 
 struct PaBjt { double ic, ib, j0, j1, j2, j3; };
+// development counters (-DOW_DBG_COUNTERS, tools/probe_power_amp_waves.py): how often a WAVEFRONT executes the pieces of the solver
+// [2] trips of k_post_mpa's main loop  [3] device evaluations  [4] passes of the backward-Euler retry  [5] limited pnjlim calls (lanes)
+// [6] sample completions  [7] passes of any kind (pa_newton_pass bodies)
+#ifdef OW_DBG_COUNTERS
+#define OW_DBG_WAVE(i) do { const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true); \
+                            if ((int)(threadIdx.x & 63) == __builtin_ctzll(act_)) atomicAdd(&g_ow_dbg[i], 1ull); } while (0)
+#else
+#define OW_DBG_WAVE(i) ((void)0)
+#endif
 
 // gen_power_amp.rs:7870-8017, Gummel-Poon branch (all eight devices of the netlist set USE_GP; the host refuses anything else)
 __device__ inline PaBjt pa_bjt_evaluate(double vbe, double vbc, const OwPaConsts::Dev& D) {
@@ -99,6 +108,7 @@ __device__ inline PaBjt pa_bjt_with_parasitics(double vbe_ext, double vbc_ext, c
     PaBjt held;
     bool fresh = false;
     for (int it = 0; it < 15; ++it) {
+        OW_DBG_WAVE(3);
         const PaBjt e = pa_bjt_evaluate(vbe_int, vbc_int, D);
         held = e;
         const double f1 = vbe_int - vbe_ext + e.ib * D.rb + (e.ic + e.ib) * D.re;
@@ -120,6 +130,7 @@ __device__ inline PaBjt pa_bjt_with_parasitics(double vbe_ext, double vbc_ext, c
     }
     PaBjt e = held;
     if (__builtin_amdgcn_ballot_w64(!fresh) != 0ull) {
+        OW_DBG_WAVE(3);
         const PaBjt e2 = pa_bjt_evaluate(vbe_int, vbc_int, D);
         if (!fresh) e = e2;
     }
@@ -238,6 +249,8 @@ template <bool BE>
 __device__ __forceinline__ bool pa_newton_pass(double* __restrict__ W, const double* KM, const OwPaConsts::Dev* D, int role) {
     const int r0 = 2 * role, r1 = 2 * role + 1;
     const double vt = D->vt, vcrit = D->vcrit;
+    OW_DBG_WAVE(7);
+    if (BE) OW_DBG_WAVE(4);
     {
         double vd0 = PL(PL_P + r0), vd1 = PL(PL_P + r1);
 #pragma unroll
@@ -850,6 +863,7 @@ __global__ __launch_bounds__(PA_WPB * 64, 2) void k_post_mpa(const OwConsts* __r
     bool begun = false;
     double input = 0.0, y0 = 0.0;
     while (__builtin_amdgcn_ballot_w64(c < total) != 0ull) {
+        OW_DBG_WAVE(2);
         if (c < total) {
             ++trips;
             if (!begun) {
@@ -860,6 +874,7 @@ __global__ __launch_bounds__(PA_WPB * 64, 2) void k_post_mpa(const OwConsts* __r
             }
             const bool conv = pa_newton_pass<false>(W, T->k, &T->dev[role], role);
             if (conv || iter == 69u) {
+                OW_DBG_WAVE(6);
                 const double raw = pa_sample_end(sc, C, W, T, role, input, conv ? iter : 70u);
                 const double y = pa_process_end(sc, C, W, role, settled, raw, rail_sag);
                 if (pa_tap && valid && role == 0) pa_tap[(size_t)c * I + e] = y;

@@ -104,6 +104,11 @@ void owo_mpa_inner_hist(unsigned long long* out128, int reset) {
     if (out128) for (int d = 0; d < 8; ++d) for (int t = 0; t < 16; ++t) out128[d * 16 + t] = st.inner_hist[d][t];
     if (reset) for (int d = 0; d < 8; ++d) for (int t = 0; t < 16; ++t) st.inner_hist[d][t] = 0;
 }
+void owo_mpa_deepest_hist(unsigned long long* out16, int reset) {    // passes by the trip count of their deepest device loop
+    PaStats& st = pa_stats();
+    if (out16) for (int t = 0; t < 16; ++t) out16[t] = st.deepest_hist[t];
+    if (reset) for (int t = 0; t < 16; ++t) st.deepest_hist[t] = 0;
+}
 void owo_mpa_rails(void* p, double* pos, double* neg) {
     const MelangePowerAmp* a = (const MelangePowerAmp*)p;
     *pos = a->rail_sag_on ? a->rails.v_rail_pos : 22.5; *neg = a->rail_sag_on ? a->rails.v_rail_neg : 22.5;

@@ -111,7 +111,7 @@ inline double pa_clamp(double x, double lo, double hi) { return x < lo ? lo : (x
 // Statistics of the Newton passes since the last owo_mpa_stats(reset) -- numbers the GPU mapping was designed from:
 // [0] passes, [1] passes with at least one row exchange, [2] row exchanges, [3] sum over passes of the deepest inner loop of the pass,
 // [4] sum over passes and devices of the inner-loop trips, [5..20] row exchanges by column
-struct PaStats { unsigned long long v[21]; unsigned long long inner_hist[8][16]; };   // inner_hist[d][t]: calls of device d whose inner loop made t trips
+struct PaStats { unsigned long long v[21]; unsigned long long inner_hist[8][16]; unsigned long long deepest_hist[16]; };   // inner_hist[d][t]: calls of device d whose inner loop made t trips; deepest_hist[t]: passes whose deepest device made t trips
 inline PaStats& pa_stats() { static thread_local PaStats s = {}; return s; }
 inline PaBjt pa_bjt_with_parasitics(double vbe_ext, double vbc_ext, int d, int* inner_iters = nullptr) {
     const double rb = PA_DEV_RB[d], rc = PA_DEV_RC[d], re = PA_DEV_RE[d], vt = PA_DEV_VT[d];
@@ -326,7 +326,7 @@ struct PaCircuit {
                     b[row] -= factor * b[col];
                 }
             }
-            { PaStats& st = pa_stats(); st.v[0] += 1; st.v[1] += swaps ? 1 : 0; st.v[2] += (unsigned long long)swaps; st.v[3] += (unsigned long long)inner_max; }
+            { PaStats& st = pa_stats(); st.deepest_hist[inner_max < 15 ? inner_max : 15] += 1; st.v[0] += 1; st.v[1] += swaps ? 1 : 0; st.v[2] += (unsigned long long)swaps; st.v[3] += (unsigned long long)inner_max; }
             if (!singular) {
                 for (int i = AM - 1; i >= 0; --i) {
                     double sum = b[i];
