@@ -587,21 +587,30 @@ __device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_
     const double k10 = K->p_k[1][0] - sm_k * K->p_nv_sfb[1] * K->p_sfb_ni[0];
     const double k11 = K->p_k[1][1] - sm_k * K->p_nv_sfb[1] * K->p_sfb_ni[1];
     double vn0 = st.v_nl[0], vn1 = st.v_nl[1];
+    // The reference evaluates the collector currents once more after the loop (:519-520) at the final junction voltages.  A lane that
+    // left the loop at one of its two `break`s has not moved them since the loop's last evaluation: bjt_ic is the same expression as the
+    // ic half of bjt_ic_gm (:663-666, :686-690), so that evaluation IS the one after the loop and is kept; only a lane that ran all six
+    // updates evaluates again (two exponentials per sample and state saved when no lane of the wavefront did).
+    double ic0 = 0.0, ic1 = 0.0;
+    bool at_eval = false;
     for (int iter = 0; iter < 6; ++iter) {
-        double ic0, gm0, ic1, gm1;
+        double gm0, gm1;
         dk_ic_gm(vn0, ic0, gm0);
         dk_ic_gm(vn1, ic1, gm1);
         const double f0 = vn0 - p0 - k00 * ic0 - k01 * ic1;
         const double f1 = vn1 - p1 - k10 * ic0 - k11 * ic1;
-        if (fabs(f0) < 1e-9 && fabs(f1) < 1e-9) break;
+        if (fabs(f0) < 1e-9 && fabs(f1) < 1e-9) { at_eval = true; break; }
         const double j00 = 1.0 - k00 * gm0, j01 = -k01 * gm1, j10 = -k10 * gm0, j11 = 1.0 - k11 * gm1;
         const double det = j00 * j11 - j01 * j10;
-        if (fabs(det) < 1e-30) break;
+        if (fabs(det) < 1e-30) { at_eval = true; break; }
         const double inv_det = ow_div(1.0, det);
         vn0 -= inv_det * (j11 * f0 - j01 * f1);
         vn1 -= inv_det * (j00 * f1 - j10 * f0);
     }
-    const double ic0 = dk_ic(vn0), ic1 = dk_ic(vn1);
+    if (__builtin_amdgcn_ballot_w64(!at_eval) != 0ull) {
+        const double a = dk_ic(vn0), b = dk_ic(vn1);
+        if (!at_eval) { ic0 = a; ic1 = b; }
+    }
     K = k_reload(K0);
     const double dot = K->p_sfb_ni[0] * ic0 + K->p_sfb_ni[1] * ic1;
 #pragma unroll

@@ -87,21 +87,26 @@ __device__ inline double dk_step_wide(DkSt& st, const DkWideRows& R, int q, doub
     double vn0 = st.v_nl[0], vn1 = st.v_nl[1];
     // The trip count is the same in the four lanes of a quad (replicated values), so the quad moves inside the loop always find
     // their source lanes active.
+    double ic0 = 0.0, ic1 = 0.0;
+    bool at_eval = false;              // left the loop at a `break`: the loop's last evaluation is the one the reference makes after it (dk_step)
     for (int iter = 0; iter < 6; ++iter) {
-        double ic0, gm0, ic1, gm1;
+        double gm0, gm1;
         dk_ic_gm_pair(q, vn0, vn1, ic0, gm0, ic1, gm1);
         const double f0 = vn0 - p0 - k00 * ic0 - k01 * ic1;
         const double f1 = vn1 - p1 - k10 * ic0 - k11 * ic1;
-        if (fabs(f0) < 1e-9 && fabs(f1) < 1e-9) break;
+        if (fabs(f0) < 1e-9 && fabs(f1) < 1e-9) { at_eval = true; break; }
         const double j00 = 1.0 - k00 * gm0, j01 = -k01 * gm1, j10 = -k10 * gm0, j11 = 1.0 - k11 * gm1;
         const double det = j00 * j11 - j01 * j10;
-        if (fabs(det) < 1e-30) break;
+        if (fabs(det) < 1e-30) { at_eval = true; break; }
         const double inv_det = ow_div(1.0, det);
         vn0 -= inv_det * (j11 * f0 - j01 * f1);
         vn1 -= inv_det * (j00 * f1 - j10 * f0);
     }
-    double ic0, ic1;
-    dk_ic_pair(q, vn0, vn1, ic0, ic1);
+    if (__builtin_amdgcn_ballot_w64(!at_eval) != 0ull) {       // wave-uniform: the quad moves inside dk_ic_pair run with every lane active
+        double a, b;
+        dk_ic_pair(q, vn0, vn1, a, b);
+        if (!at_eval) { ic0 = a; ic1 = b; }
+    }
     K = k_reload(K0);
     const double dot = K->p_sfb_ni[0] * ic0 + K->p_sfb_ni[1] * ic1;
     // v = v_pred + S N_i i_c - sm_k (s_fb N_i . i_c) s_fb_col: the same expression for every row with the row's constants -- each

@@ -291,6 +291,15 @@ void owo_reed_render(double f0, const double* ratios, const double* amps, const 
     r.render(out, n);
 }
 
+// attack noise alone (hammer.rs:223-239): AttackNoise::new(velocity, f0, sr, seed).render(out[0..n)) into zeros; returns is_done()
+int owo_attack_noise_render(double velocity, double f0, double sr, unsigned seed, double* out, size_t n) {
+    AttackNoise a;
+    a.init(velocity, f0, sr, seed);
+    for (size_t i = 0; i < n; ++i) out[i] = 0.0;
+    a.render(out, n);
+    return a.is_done() ? 1 : 0;
+}
+
 // biquad: kind 0=LP 1=HP 2=BP; filters x in place
 void owo_biquad_process(int kind, double fc, double q, double sr, double* x, size_t n) {
     Biquad b = Biquad::make((Biquad::Kind)kind, fc, q, sr);
