@@ -183,6 +183,7 @@ struct HostSmoother {  // host mirror of LinearSmoother::target only (the 1e-9 a
 // path only looks at the latched copy.  ow_test_pool_set_switch (openwurli_hip_test.h) changes one on a live pool.
 struct Switches {
     int trem_wide = -1, preamp_wide = -1;      // -1: by pool size
+    int chain_fused = -1;                      // OW_CHAIN_FUSED=0/1: preamp + output stage as one launch (k_chain_fused); -1: whenever the quad preamp is used
     bool trem_serial = false;                  // OW_TREM_SERIAL=1: block-ahead oscillators in front of the voices instead of beside them
     bool trem_cache = true;                    // OW_TREM_CACHE=0: no process-wide settled-state cache
     bool trem_traj = true;                     // OW_TREM_TRAJ=0: no shared trajectory, one oscillator per phase group (rounds 1-3)
@@ -198,6 +199,8 @@ struct Switches {
         w.trem_wide = flag("OW_TREM_WIDE", -1); w.preamp_wide = flag("OW_PREAMP_WIDE", -1);
         if (w.trem_wide > 1 || w.trem_wide < -1) w.trem_wide = -1;
         if (w.preamp_wide > 1 || w.preamp_wide < -1) w.preamp_wide = -1;
+        w.chain_fused = flag("OW_CHAIN_FUSED", -1);
+        if (w.chain_fused > 1 || w.chain_fused < -1) w.chain_fused = -1;
         w.trem_serial = flag("OW_TREM_SERIAL", 0) == 1;
         w.trem_cache = flag("OW_TREM_CACHE", 1) != 0;
         w.trem_traj = flag("OW_TREM_TRAJ", 1) != 0;
@@ -750,6 +753,11 @@ static inline bool trem_serialised(const ow_pool* p) { return p->sw.trem_serial;
 // legacy preamp with a quad per solver state (k_preamp_wide): while the pool leaves most SIMDs empty the kernel's time is the serial
 // latency of one sample, which the quad shortens; beyond ~4 096 engines the lane-pair kernel's lower instruction count wins
 static inline bool preamp_wide(const ow_pool* p, int ne) { return p->sw.preamp_wide >= 0 ? p->sw.preamp_wide == 1 : ne <= 4096; }
+// ... and the output stage in the same launch behind it (k_chain_fused): legacy preamp + behavioural power amp only
+static inline bool chain_fused(const ow_pool* p, int ne) {
+    if (p->hc.preamp_kind != OW_PREAMP_LEGACY8 || p->power_amp_kind != OW_POWER_AMP_BEHAVIORAL) return false;
+    return p->sw.chain_fused >= 0 ? p->sw.chain_fused == 1 : preamp_wide(p, ne);
+}
 // ---- tremolo phase groups (see ow_pool) ---------------------------------------------------------------------------------
 void trem_groups_changed(ow_pool* p) {
     HIP_OK(hipMemcpyAsync(p->d_lead, p->h_lead, sizeof(uint32_t) * p->I, hipMemcpyHostToDevice, p->stream));
@@ -1226,7 +1234,13 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         if (own_osc || hit) HIP_OK(hipStreamWaitEvent(s, p->ev_trem[rb_now_idx], 0));
         if (traj_ready) HIP_OK(hipStreamWaitEvent(s, traj_ready, 0));
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][2], s));
-        if (sne > 0 && chain) {
+        const bool fused = chain && sne > 0 && chain_fused(p, sne);
+        if (fused) {           // small pool: preamp and output stage as two wavefronts of one workgroup (ow_chain_wide.h)
+            if (p->hc.oversample)
+                owdev::k_chain_fused<true><<<dim3((sne + 7) / 8), dim3(128), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, tsrc, p->d_pre, p->d_out, I, L, Lcap, L, se0, sne);
+            else
+                owdev::k_chain_fused<false><<<dim3((sne + 7) / 8), dim3(128), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, tsrc, p->d_pre, p->d_out, I, L, Lcap, L, se0, sne);
+        } else if (sne > 0 && chain) {
             if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one(p) && p->hc.ml_sparse_ok && !melange_lds_matrix(p))
                 owdev::k_preamp_mel_col<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, tsrc,
                                                                                  p->d_pre, p->d_noise, I, L, Lcap, se0, sne, melange_generic_only(p) ? 1 : 0,
@@ -1243,8 +1257,8 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
                 owdev::k_preamp<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, tsrc, p->d_pre, I, L, Lcap, se0, sne);
         }
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][3], s));
-        if (!chain) {
-            // voice sums only
+        if (!chain || fused) {
+            // voice sums only / the output stage ran inside k_chain_fused
         } else if (sne > 0 && p->power_amp_kind == OW_POWER_AMP_MELANGE) {
             // more engines than one workgroup: dispatch them by falling demand of their last block (see k_post_mpa)
             // -- when the block has more engines than the chip holds at once (two workgroups of 32 per CU); below that every wavefront
@@ -2366,6 +2380,7 @@ int ow_test_pool_set_switch(ow_pool* p, const char* name, int value) {
     if (n == "trem_serial") w.trem_serial = value != 0;
     else if (n == "trem_wide") w.trem_wide = value < 0 ? -1 : (value != 0);
     else if (n == "preamp_wide") w.preamp_wide = value < 0 ? -1 : (value != 0);
+    else if (n == "chain_fused") w.chain_fused = value < 0 ? -1 : (value != 0);
     else if (n == "mel_generic") w.mel_generic = value != 0;
     else if (n == "mel_rank1") w.mel_rank1 = value != 0;
     else if (n == "mel_lds") w.mel_lds = value != 0;
@@ -2381,6 +2396,7 @@ int ow_test_pool_get_switch(const ow_pool* p, const char* name) {
     if (n == "trem_serial") return w.trem_serial;
     if (n == "trem_wide") return w.trem_wide;
     if (n == "preamp_wide") return w.preamp_wide;
+    if (n == "chain_fused") return w.chain_fused;
     if (n == "mel_generic") return w.mel_generic;
     if (n == "mel_rank1") return w.mel_rank1;
     if (n == "mel_lds") return w.mel_lds;

@@ -313,4 +313,205 @@ __global__ __launch_bounds__(64) void k_preamp_wide(const OwConsts* __restrict__
     }
 }
 
+
+// ------------------------------------------------------------------ preamp + output stage in ONE launch, for small pools
+// k_preamp_wide and k_post are two serial recurrences in a row: in a pool that leaves the chip empty the block time is the SUM of their
+// latencies (paced single instance, 64 samples: 213 + 64 us) plus a launch gap.  Here they are two wavefronts of one workgroup, eight
+// engines each: wavefront 0 runs the quad-lane preamp of k_preamp_wide on chunk c of the block while wavefront 1 runs k_post's power amp /
+// half-band / speaker / gain on chunk c - 1, handed over through a two-slot LDS ring (OW_FCHUNK host samples per slot), one
+// __syncthreads per chunk.  The output stage disappears behind the preamp: the block lasts as long as the preamp alone.  Every value is
+// produced by the same statements as in the two kernels (their parity tests run on this kernel whenever the pool is small:
+// tests/test_gpu_parity.py::test_chain_fused_is_bit_identical compares it with the two-launch path bit for bit).
+// North star: "one persistent kernel per audio buffer ... LDS hand-off" -- the voice kernels stay a launch of their own (a wavefront of
+// voices per engine, packed lists), so a pool-of-one block is two launches: voices, chain.
+#define OW_FCHUNK 16
+#define OW_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+template <bool SPLIT>
+__global__ __launch_bounds__(128) void k_chain_fused(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args,
+                                                     OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const OwTremSrc tsrc,
+                                                     double* __restrict__ pre, float* __restrict__ out, int I, int L, int Lcap, int Lout, int e0, int ne) {
+    constexpr int OSR = SPLIT ? 2 : 1;
+    __shared__ double tin[8 * (OW_FCHUNK + 1)];                 // voice sums of the chunk (wavefront 0 only)
+    __shared__ double ring[2][OW_FCHUNK * OSR][8];              // preamp out, chain rate: [slot][sample][engine of the block]
+    __shared__ float tout[8 * (OW_FCHUNK + 1)];                 // finished samples of the chunk (wavefront 1 only)
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int eb = e0 + blockIdx.x * 8;
+    const int n_chunks = (L + OW_FCHUNK - 1) / OW_FCHUNK;
+
+    // ---- wavefront 0: k_preamp_wide's lanes and state
+    const int q = lane & 3, el = (lane & 31) >> 2, role = lane >> 5;
+    // ---- wavefront 1: k_post<SPLIT>'s lanes (lane = (engine, oversample phase)); only eight engines per block here
+    const int pel = SPLIT ? (lane & 31) : lane, phase = SPLIT ? (lane >> 5) : 0;
+    const int e_raw = eb + (wv == 0 ? el : pel);
+    const bool in_block = (wv == 0) || pel < 8;
+    const bool valid = in_block && e_raw < e0 + ne;
+    const int e = valid ? e_raw : (e0 + ne - 1);
+
+    DkWideRows R;
+    DkSt st;
+    double ua[3] = {0, 0, 0}, ub[3] = {0, 0, 0};
+    double r_ldr = 1000000.0, g_ldr = 1e-6, g_prev = 1e-6;
+    Smoother sd;
+    uint32_t nan_resets = 0;
+    TremCol rc;
+    rc.p = nullptr; rc.stride8 = 0u;
+    double da[3] = {0, 0, 0}, db[3] = {0, 0, 0}, dd = 0.0;
+    SpeakerSt sp;
+    Smoother ss, sv;
+    bool nan_fired = false;
+    if (wv == 0) {
+        dk_wide_rows_load(R, K, q);
+        smoother_load(sd, cs, I, e, CS_SM_DEPTH);
+        if (args[e].set_flags & 1u) sd.retarget(args[e].depth_target, K->ramp_samples);
+        dk_load(st, cs, I, e, role ? CS_P_SHADOW : CS_P_MAIN);
+        for (int i = 0; i < 3; ++i) { ua[i] = CSF(CS_OS_UA + i); ub[i] = CSF(CS_OS_UB + i); }
+        r_ldr = CSF(CS_P_RLDR); g_ldr = CSF(CS_P_GLDR); g_prev = CSF(CS_P_GPREV);
+        const uint64_t fl = dbits(CSF(CS_FLAGS));
+        if (fl & 1ull) {  // deferred preamp.reset() + oversampler.reset() from the output NaN guard (engine.rs:450-457)
+            dk_dc_reset(K, r_ldr, st);
+            g_ldr = 1.0 / r_ldr; g_prev = g_ldr;
+            for (int i = 0; i < 3; ++i) { ua[i] = 0.0; ub[i] = 0.0; }
+        }
+        rc = trem_col(tsrc, I, e);
+    } else {
+        for (int i = 0; i < 3; ++i) { da[i] = CSF(CS_OS_DA + i); db[i] = CSF(CS_OS_DB + i); }
+        dd = CSF(CS_OS_DD);
+        double* hp = &sp.hpf.b0; double* lp = &sp.lpf.b0;
+        for (int i = 0; i < 7; ++i) { hp[i] = CSF(CS_SPK_HPF + i); lp[i] = CSF(CS_SPK_LPF + i); }
+        sp.character = CSF(CS_SPK_CHAR); sp.a2 = CSF(CS_SPK_A2); sp.a3 = CSF(CS_SPK_A3); sp.tc = CSF(CS_SPK_TC); sp.ts = CSF(CS_SPK_TS);
+        smoother_load(ss, cs, I, e, CS_SM_SPK);
+        smoother_load(sv, cs, I, e, CS_SM_VOL);
+        if (args[e].set_flags & 2u) ss.retarget(args[e].spk_target, K->ramp_samples);
+        if (args[e].set_flags & 4u) sv.retarget(args[e].vol_target, K->ramp_samples);
+    }
+    const double sr = K->sr, thermal_alpha = K->spk_thermal_alpha;
+
+    for (int c = 0; c <= n_chunks; ++c) {
+        if (wv == 0 && c < n_chunks) {
+            const int base = c * OW_FCHUNK;
+            const int cn = min(OW_FCHUNK, L - base);
+            {   // stage 8 engine rows x OW_FCHUNK samples of the voice sum (slot pass + steal pass): lanes = (row, sample)
+                for (int k = lane; k < 8 * OW_FCHUNK; k += 64) {
+                    const int r = k / OW_FCHUNK, n = k - r * OW_FCHUNK;
+                    const int er = eb + r;
+                    double x = 0.0;
+                    if (er < e0 + ne && n < cn && !eout[er].sum_nonfinite) {
+                        if (args[er].main_mask) x = sum[((size_t)0 * I + er) * Lcap + base + n];
+                        if (args[er].steal_mask) x += sum[((size_t)1 * I + er) * Lcap + base + n];
+                    }
+                    tin[r * (OW_FCHUNK + 1) + n] = x;
+                }
+                OW_WAVE_SYNC();
+            }
+            double (*slot)[8] = ring[c & 1];
+            for (int n = 0; n < cn; ++n) {
+                const double x = tin[el * (OW_FCHUNK + 1) + n];
+                const double depth = clampd(sd.next(), 0.0, 1.0);   // engine.rs:533-534, tremolo.rs:117-119
+                double in[2];
+                if (OSR == 2) {
+                    const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, ua, x);
+                    const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, ub, x);
+                    in[0] = role ? 0.0 : a;
+                    in[1] = role ? 0.0 : b;
+                } else {
+                    in[0] = role ? 0.0 : x;
+                    in[1] = 0.0;
+                }
+                for (int j = 0; j < OSR; ++j) {
+                    const size_t idx = (size_t)((base + n) * OSR + j);
+                    const double r_new = fmax(trem_shunt(depth, trem_col_at(rc, (uint32_t)idx)), 1000.0);   // tremolo.rs:152-167; set_ldr_resistance
+                    if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = ow_div(1.0, r_new); }
+                    const double o = dk_step_wide(st, R, q, in[j], g_ldr, g_prev, K);
+                    g_prev = g_ldr;
+                    const double other = xor32(o);
+                    double result = role ? (other - o) : (o - other);                 // main - pump
+                    if (!isfinite(result)) {
+                        dk_dc_reset(K, r_ldr, st);
+                        g_ldr = 1.0 / r_ldr; g_prev = g_ldr;
+                        result = 0.0;
+                        nan_resets += 1u;
+                    }
+                    if (role == 0 && q == 0) {
+                        slot[n * OSR + j][el] = result;
+                        if (valid) pre[idx * I + e] = result;                        // the preamp tap (ow_pool_read_preamp_out)
+                    }
+                }
+            }
+        }
+        if (wv == 1 && c >= 1) {
+            const int base = (c - 1) * OW_FCHUNK;
+            const int cn = min(OW_FCHUNK, L - base);
+            const double (*slot)[8] = ring[(c - 1) & 1];
+            const int pe = pel < 8 ? pel : 7;
+            for (int n = 0; n < cn; ++n) {
+                const double pc = slot[n * OSR + phase][pe];
+                const double y = power_amp(pc * 0.25);
+                double o;
+                if (SPLIT) {  // engine.rs:536-553
+                    const double yo = __shfl_xor(y, 32);
+                    const double y0 = phase ? yo : y, y1 = phase ? y : yo;
+                    const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, y0);
+                    const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, y1);
+                    o = (a + dd) * 0.5;
+                    dd = b;
+                } else {
+                    o = y;
+                }
+                speaker_set_character(sp, ss.next(), sr);                           // engine.rs:437-438
+                const double shaped = speaker_process(sp, o, thermal_alpha);
+                const double post = shaped * 7.498942093324558 * sv.next();         // POST_SPEAKER_GAIN x user volume
+                float f = (float)post;
+                if (!isfinite(f)) {                                                 // engine.rs:450-458
+                    f = 0.0f;
+                    sp.hpf.s1 = sp.hpf.s2 = sp.lpf.s1 = sp.lpf.s2 = 0.0;
+                    sp.ts = 0.0;
+                    nan_fired = true;
+                }
+                if (phase == 0 && pel < 8) tout[pel * (OW_FCHUNK + 1) + n] = f;
+            }
+            OW_WAVE_SYNC();
+            for (int k = lane; k < 8 * OW_FCHUNK; k += 64) {
+                const int r = k / OW_FCHUNK, n = k - r * OW_FCHUNK;
+                const int er = eb + r;
+                if (er < e0 + ne && n < cn) out[(size_t)er * Lout + base + n] = tout[r * (OW_FCHUNK + 1) + n];
+            }
+            OW_WAVE_SYNC();
+        }
+        __syncthreads();
+    }
+    // ---- state back: the preamp's half first (it clears the deferred-reset flag), then the output stage's (it may set it)
+    if (wv == 0 && valid && q == 0) {
+        dk_store(st, cs, I, e, role ? CS_P_SHADOW : CS_P_MAIN);
+        if (role == 0) {
+            for (int i = 0; i < 3; ++i) { CSF(CS_OS_UA + i) = ua[i]; CSF(CS_OS_UB + i) = ub[i]; }
+            CSF(CS_P_RLDR) = r_ldr; CSF(CS_P_GLDR) = g_ldr; CSF(CS_P_GPREV) = g_prev;
+            smoother_store(sd, cs, I, e, CS_SM_DEPTH);
+            const uint64_t fl = dbits(CSF(CS_FLAGS));
+            if (fl & 1ull) CSF(CS_FLAGS) = bitsd(fl & ~1ull);
+            if (nan_resets) {
+                const uint64_t d = dbits(CSF(CS_DIAG));
+                CSF(CS_DIAG) = bitsd((d & 0xFFFFFFFFull) | ((uint64_t)((uint32_t)(d >> 32) + nan_resets) << 32));
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (wv != 1 || !valid || phase != 0) return;
+    if (nan_fired) {  // preamp.reset()/oversampler.reset() act on post-block state: defer the preamp/up half to the next block's preamp
+        for (int i = 0; i < 3; ++i) { da[i] = 0.0; db[i] = 0.0; }
+        dd = 0.0;
+        CSF(CS_FLAGS) = bitsd(dbits(CSF(CS_FLAGS)) | 1ull);
+        eout[e].out_nonfinite = 1u;
+    }
+    for (int i = 0; i < 3; ++i) { CSF(CS_OS_DA + i) = da[i]; CSF(CS_OS_DB + i) = db[i]; }
+    CSF(CS_OS_DD) = dd;
+    {
+        const double* hp = &sp.hpf.b0; const double* lp = &sp.lpf.b0;
+        for (int i = 0; i < 7; ++i) { CSF(CS_SPK_HPF + i) = hp[i]; CSF(CS_SPK_LPF + i) = lp[i]; }
+        CSF(CS_SPK_CHAR) = sp.character; CSF(CS_SPK_A2) = sp.a2; CSF(CS_SPK_A3) = sp.a3; CSF(CS_SPK_TC) = sp.tc; CSF(CS_SPK_TS) = sp.ts;
+    }
+    smoother_store(ss, cs, I, e, CS_SM_SPK);
+    smoother_store(sv, cs, I, e, CS_SM_VOL);
+}
+
 }  // namespace owdev

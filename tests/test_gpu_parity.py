@@ -880,3 +880,54 @@ def test_batch_render_melange(hiplib, oracle):
         print("melange job", j, "max abs err", rep.get("max_abs_err"), "rel peak", rep["max_err_rel_peak"])
         _check(rep, ("melange job", j))
         assert rep["max_err_rel_peak"] < 1e-5
+
+
+def test_chain_fused_is_bit_identical(hiplib, oracle):
+    """Small pools run the preamp and the output stage as two wavefronts of ONE launch (k_chain_fused: quad-lane preamp on chunk c, power
+    amp / half-band / speaker / gain on chunk c - 1, handed over through LDS) instead of k_preamp_wide then k_post.  Same bits at the
+    preamp tap and at the output -- tremolo, depth / volume / speaker-character ramps through the 0.002 hysteresis, reset of one engine,
+    the steal pass, ragged block lengths incl. 1 and lengths that are no multiple of the 16-sample chunk, an output NaN guard event and
+    the blocks after it, at both rates; 11 engines = one full workgroup and a ragged second one.  And it is the oracle's engine."""
+    import openwurli_amd as ow
+    lengths = (512, 300, 1, 17, 64, 16, 15, 777, 512, 33)
+    for sr in (48000.0, 96000.0):
+        osr = 2 if sr < 88200.0 else 1
+        res = {}
+        for fused in (0, 1):
+            g = ow.EnginePool(sr, 11)
+            g.set_sample_rate(sr)
+            g.set_switch("chain_fused", fused)
+            assert g.get_switch("chain_fused") == fused
+            for k in range(11):
+                g[k].set_tremolo_depth(0.1 * k); g[k].set_volume(0.3 + 0.05 * k); g[k].set_speaker_character(0.08 * k)
+                for note in (40 + 3 * k, 60 + k, 72):
+                    g[k].note_on(note, 0.5 + 0.04 * k)
+            outs, pres, diags = [], [], []
+            for b, length in enumerate(lengths):
+                if b == 3:
+                    g[4].set_tremolo_depth(1.0); g[7].note_on(60 + 7, 1.0); g[5].set_speaker_character(1.0)
+                if b == 5:
+                    g[9].set_volume(1e308)                     # unbounded set_volume (the reference does not clamp): a non-finite output -> NaN guard
+                if b == 6:
+                    g[2].reset(); g[2].note_on(55, 0.9); g[9].set_volume(0.5)
+                outs.append(g.render(length).copy())
+                pres.append(g.preamp_out(length * osr).copy())
+                diags.append([(g[k].diag().output_nan_resets, g[k].diag().preamp_nan_resets) for k in (2, 9)])
+            res[fused] = (outs, pres, diags)
+            g.close()
+        for b in range(len(lengths)):
+            assert np.array_equal(res[0][1][b], res[1][1][b]), (sr, b, "preamp tap")
+            assert np.array_equal(res[0][0][b], res[1][0][b]), (sr, b, "output")
+            assert res[0][2][b] == res[1][2][b], (sr, b, "diag")
+        assert res[1][2][-1][1][0] >= 1                                # the guard did fire on engine 9
+    # the fused path against the oracle (the default for a pool of one)
+    g, c = ow.WurliEngine(48000.0), oracle.OracleEngine(48000.0)
+    g.set_sample_rate(48000.0); c.set_sample_rate(48000.0)
+    for e in (g, c):
+        e.set_tremolo_depth(0.8); e.set_speaker_character(0.4)
+        for n in (45, 60, 64, 79):
+            e.note_on(n, 0.8)
+    for length in (64, 64, 128, 7, 512):
+        rep = oracle.parity_report(g.render(length), c.render(length), abs_floor=oracle.ABS_FLOOR_OUTPUT)
+        assert rep["n_bad"] == 0, (length, rep)
+    g.close(); c.close()
