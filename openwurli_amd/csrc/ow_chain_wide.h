@@ -16,7 +16,15 @@
 namespace owdev {
 
 // rows q and q + 4 (lane q of the quad) of S, of the two S N_i column differences and of S's feedback column, loop-invariant
-struct DkWideRows { double s_lo[8], s_hi[8], c1_lo, c1_hi, c2_lo, c2_hi, fb_lo, fb_hi; };
+// ... and the step's wave-uniform constants, one copy per lane IN VECTOR REGISTERS: these kernels run one wavefront per SIMD and their
+// time is the dependent latency of one sample, so the twelve s_load / s_waitcnt round trips per sample with which the pool-sized kernel
+// keeps its constants out of the SGPR file (k_reload) sit right on the serial path here; 44 doubles of 512 available registers do not.
+struct DkWideRows {
+    double s_lo[8], s_hi[8], c1_lo, c1_hi, c2_lo, c2_hi, fb_lo, fb_hi;
+    double an[20];          // A_neg's structural non-zeros in dk_step's order of use
+    double two_w[8], fb_col[4], k[4], nv_sfb[2], sfb_ni[2], g_cin, s_fb_fb, gc_1pc, c_cin;
+};
+OW_DEV void vgpr_pin(double& x) { asm volatile("" : "+v"(x)); }      // the value stays in a vector register: no rematerialised scalar load
 
 __device__ inline void dk_wide_rows_load(DkWideRows& R, const OwConsts* __restrict__ K, int q) {
 #pragma unroll
@@ -25,6 +33,25 @@ __device__ inline void dk_wide_rows_load(DkWideRows& R, const OwConsts* __restri
     R.c1_lo = K->p_sni_d1[q];                      R.c1_hi = K->p_sni_d1[q + 4];
     R.c2_lo = K->p_sni_d2[q];                      R.c2_hi = K->p_sni_d2[q + 4];
     R.fb_lo = K->p_s_fb_col[q];                    R.fb_hi = K->p_s_fb_col[q + 4];
+    const double (*__restrict__ an)[8] = K->p_a_neg;
+    const double a20[20] = {an[0][0], an[0][2], an[1][1], an[1][7], an[2][0], an[2][2], an[2][5], an[3][3], an[3][4], an[4][3],
+                            an[4][4], an[5][2], an[5][5], an[5][6], an[6][5], an[6][6], an[6][7], an[7][1], an[7][6], an[7][7]};
+#pragma unroll
+    for (int i = 0; i < 20; ++i) { R.an[i] = a20[i]; vgpr_pin(R.an[i]); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { R.two_w[i] = K->p_two_w[i]; vgpr_pin(R.two_w[i]); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { R.fb_col[i] = K->p_s_fb_col[i]; vgpr_pin(R.fb_col[i]); }
+    R.k[0] = K->p_k[0][0]; R.k[1] = K->p_k[0][1]; R.k[2] = K->p_k[1][0]; R.k[3] = K->p_k[1][1];
+    R.nv_sfb[0] = K->p_nv_sfb[0]; R.nv_sfb[1] = K->p_nv_sfb[1]; R.sfb_ni[0] = K->p_sfb_ni[0]; R.sfb_ni[1] = K->p_sfb_ni[1];
+    R.g_cin = K->p_g_cin; R.s_fb_fb = K->p_s_fb_fb; R.gc_1pc = K->p_gc_1pc; R.c_cin = K->p_c_cin;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vgpr_pin(R.k[i]);
+    vgpr_pin(R.nv_sfb[0]); vgpr_pin(R.nv_sfb[1]); vgpr_pin(R.sfb_ni[0]); vgpr_pin(R.sfb_ni[1]);
+    vgpr_pin(R.g_cin); vgpr_pin(R.s_fb_fb); vgpr_pin(R.gc_1pc); vgpr_pin(R.c_cin);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { vgpr_pin(R.s_lo[j]); vgpr_pin(R.s_hi[j]); }
+    vgpr_pin(R.c1_lo); vgpr_pin(R.c1_hi); vgpr_pin(R.c2_lo); vgpr_pin(R.c2_hi); vgpr_pin(R.fb_lo); vgpr_pin(R.fb_hi);
 }
 
 // ic, gm of both junctions with one exponential per lane: even lanes of the quad evaluate vn0, odd lanes vn1 (dk_ic_gm, :686-690)
@@ -42,28 +69,27 @@ OW_DEV void dk_ic_pair(int q, double vn0, double vn1, double& ic0, double& ic1) 
 
 // dk_step (dk_preamp_legacy.rs:447-554), quad-parallel.  `st` is replicated in the four lanes.
 __device__ inline double dk_step_wide(DkSt& st, const DkWideRows& R, int q, double input, double g_ldr, double g_ldr_prev,
-                                      const OwConsts* __restrict__ K0) {
-    const OwConsts* __restrict__ K = k_reload(K0);
-    const double (*__restrict__ an)[8] = K->p_a_neg;
+                                      const OwConsts* __restrict__ /*K0: every constant is in R*/) {
+    const double* an = R.an;
     const double* v = st.v;
     double rhs[8];
-    rhs[0] = 0.0 + an[0][0] * v[0] + an[0][2] * v[2];
-    rhs[1] = 0.0 + an[1][1] * v[1] + an[1][7] * v[7];
-    rhs[2] = 0.0 + an[2][0] * v[0] + an[2][2] * v[2] + an[2][5] * v[5];
-    rhs[3] = 0.0 + an[3][3] * v[3] + an[3][4] * v[4];
-    rhs[4] = 0.0 + an[4][3] * v[3] + an[4][4] * v[4];
-    rhs[5] = 0.0 + an[5][2] * v[2] + an[5][5] * v[5] + an[5][6] * v[6];
-    rhs[6] = 0.0 + an[6][5] * v[5] + an[6][6] * v[6] + an[6][7] * v[7];
-    rhs[7] = 0.0 + an[7][1] * v[1] + an[7][6] * v[6] + an[7][7] * v[7];
+    rhs[0] = 0.0 + an[0] * v[0] + an[1] * v[2];
+    rhs[1] = 0.0 + an[2] * v[1] + an[3] * v[7];
+    rhs[2] = 0.0 + an[4] * v[0] + an[5] * v[2] + an[6] * v[5];
+    rhs[3] = 0.0 + an[7] * v[3] + an[8] * v[4];
+    rhs[4] = 0.0 + an[9] * v[3] + an[10] * v[4];
+    rhs[5] = 0.0 + an[11] * v[2] + an[12] * v[5] + an[13] * v[6];
+    rhs[6] = 0.0 + an[14] * v[5] + an[15] * v[6] + an[16] * v[7];
+    rhs[7] = 0.0 + an[17] * v[1] + an[18] * v[6] + an[19] * v[7];
     rhs[7] -= g_ldr_prev * st.v[7];
-    const double cin_now = K->p_g_cin * input + st.j_cin;
+    const double cin_now = R.g_cin * input + st.j_cin;
     rhs[0] += cin_now + st.cin_prev;
     rhs[1] += st.i_nl[0];
     rhs[2] -= st.i_nl[0];
     rhs[3] += st.i_nl[1];
     rhs[5] -= st.i_nl[1];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rhs[i] += K->p_two_w[i];
+    for (int i = 0; i < 8; ++i) rhs[i] += R.two_w[i];
     // v_pred_base = S rhs: this lane's two rows, then the quad's eight
     double lo = 0.0, hi = 0.0;
 #pragma unroll
@@ -72,18 +98,17 @@ __device__ inline double dk_step_wide(DkSt& st, const DkWideRows& R, int q, doub
     double vpb[4];
     static_for<0, 4>([&](auto i) { vpb[i] = qget<i>(lo); });
     const double vpb7 = qget<3>(hi);
-    K = k_reload(K0);
-    const double sm_k = ow_div(g_ldr, 1.0 + K->p_s_fb_fb * g_ldr);
+    const double sm_k = ow_div(g_ldr, 1.0 + R.s_fb_fb * g_ldr);
     const double sm_vpred = sm_k * vpb7;
     double v_pred[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v_pred[i] = vpb[i] - sm_vpred * K->p_s_fb_col[i];
+    for (int i = 0; i < 4; ++i) v_pred[i] = vpb[i] - sm_vpred * R.fb_col[i];
     const double vp_lo = lo - sm_vpred * R.fb_lo, vp_hi = hi - sm_vpred * R.fb_hi;      // v_pred of this lane's rows q, q + 4
     const double p0 = v_pred[0] - v_pred[1], p1 = v_pred[2] - v_pred[3];
-    const double k00 = K->p_k[0][0] - sm_k * K->p_nv_sfb[0] * K->p_sfb_ni[0];
-    const double k01 = K->p_k[0][1] - sm_k * K->p_nv_sfb[0] * K->p_sfb_ni[1];
-    const double k10 = K->p_k[1][0] - sm_k * K->p_nv_sfb[1] * K->p_sfb_ni[0];
-    const double k11 = K->p_k[1][1] - sm_k * K->p_nv_sfb[1] * K->p_sfb_ni[1];
+    const double k00 = R.k[0] - sm_k * R.nv_sfb[0] * R.sfb_ni[0];
+    const double k01 = R.k[1] - sm_k * R.nv_sfb[0] * R.sfb_ni[1];
+    const double k10 = R.k[2] - sm_k * R.nv_sfb[1] * R.sfb_ni[0];
+    const double k11 = R.k[3] - sm_k * R.nv_sfb[1] * R.sfb_ni[1];
     double vn0 = st.v_nl[0], vn1 = st.v_nl[1];
     // The trip count is the same in the four lanes of a quad (replicated values), so the quad moves inside the loop always find
     // their source lanes active.
@@ -107,8 +132,7 @@ __device__ inline double dk_step_wide(DkSt& st, const DkWideRows& R, int q, doub
         dk_ic_pair(q, vn0, vn1, a, b);
         if (!at_eval) { ic0 = a; ic1 = b; }
     }
-    K = k_reload(K0);
-    const double dot = K->p_sfb_ni[0] * ic0 + K->p_sfb_ni[1] * ic1;
+    const double dot = R.sfb_ni[0] * ic0 + R.sfb_ni[1] * ic1;
     // v = v_pred + S N_i i_c - sm_k (s_fb N_i . i_c) s_fb_col: the same expression for every row with the row's constants -- each
     // lane forms its rows q and q + 4, the quad gathers the eight
     const double v_lo = vp_lo + (ic0 * R.c1_lo + ic1 * R.c2_lo) - sm_k * dot * R.fb_lo;
@@ -116,7 +140,7 @@ __device__ inline double dk_step_wide(DkSt& st, const DkWideRows& R, int q, doub
     static_for<0, 4>([&](auto i) { st.v[i] = qget<i>(v_lo); st.v[i + 4] = qget<i>(v_hi); });
     st.cin_prev = cin_now;
     const double dv_cin = input - st.v[0];
-    st.j_cin = -K->p_gc_1pc * dv_cin - K->p_c_cin * st.j_cin;
+    st.j_cin = -R.gc_1pc * dv_cin - R.c_cin * st.j_cin;
     st.i_nl[0] = ic0; st.i_nl[1] = ic1;
     st.v_nl[0] = vn0; st.v_nl[1] = vn1;
     return st.v[6];
@@ -253,6 +277,9 @@ __global__ __launch_bounds__(64) void k_preamp_wide(const OwConsts* __restrict__
     }
     uint32_t nan_resets = 0;
     const TremCol rc = trem_col(tsrc, I, ec);
+    double rnx[2];                                               // R one host sample ahead (registers): the global load is off the serial path
+    rnx[0] = trem_col_at(rc, 0u);
+    rnx[1] = osr == 2 ? trem_col_at(rc, 1u) : 0.0;
     for (int base = 0; base < L; base += OW_WCHUNK) {
         const int cn = min(OW_WCHUNK, L - base);
         for (int r = 0; r < 8; ++r) {                 // stage 8 engine rows x 64 samples of the voice sum (slot pass + steal pass)
@@ -267,6 +294,12 @@ __global__ __launch_bounds__(64) void k_preamp_wide(const OwConsts* __restrict__
         __syncthreads();
         for (int n = 0; n < cn; ++n) {
             const double x = tile[el * (OW_WCHUNK + 1) + n];
+            const double rcur[2] = {rnx[0], rnx[1]};
+            {
+                const uint32_t nx = (uint32_t)(min(base + n + 1, L - 1) * osr);
+                rnx[0] = trem_col_at(rc, nx);
+                if (osr == 2) rnx[1] = trem_col_at(rc, nx + 1u);
+            }
             const double depth = clampd(sd.next(), 0.0, 1.0);   // engine.rs:533-534, tremolo.rs:117-119
             double in[2];
             if (osr == 2) {
@@ -280,7 +313,7 @@ __global__ __launch_bounds__(64) void k_preamp_wide(const OwConsts* __restrict__
             }
             for (int j = 0; j < osr; ++j) {
                 const size_t idx = (size_t)((base + n) * osr + j);
-                const double r_new = fmax(trem_shunt(depth, trem_col_at(rc, (uint32_t)idx)), 1000.0);   // tremolo.rs:152-167; set_ldr_resistance
+                const double r_new = fmax(trem_shunt(depth, rcur[j]), 1000.0);   // tremolo.rs:152-167; set_ldr_resistance
                 if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = ow_div(1.0, r_new); }
                 const double o = dk_step_wide(st, R, q, in[j], g_ldr, g_prev, K);
                 g_prev = g_ldr;
@@ -355,6 +388,7 @@ __global__ __launch_bounds__(128) void k_chain_fused(const OwConsts* __restrict_
     uint32_t nan_resets = 0;
     TremCol rc;
     rc.p = nullptr; rc.stride8 = 0u;
+    double rnx[2] = {1000000.0, 1000000.0};                     // R one host sample ahead (registers): the global load is off the serial path
     double da[3] = {0, 0, 0}, db[3] = {0, 0, 0}, dd = 0.0;
     SpeakerSt sp;
     Smoother ss, sv;
@@ -373,6 +407,8 @@ __global__ __launch_bounds__(128) void k_chain_fused(const OwConsts* __restrict_
             for (int i = 0; i < 3; ++i) { ua[i] = 0.0; ub[i] = 0.0; }
         }
         rc = trem_col(tsrc, I, e);
+        rnx[0] = trem_col_at(rc, 0u);
+        if (OSR == 2) rnx[1] = trem_col_at(rc, 1u);
     } else {
         for (int i = 0; i < 3; ++i) { da[i] = CSF(CS_OS_DA + i); db[i] = CSF(CS_OS_DB + i); }
         dd = CSF(CS_OS_DD);
@@ -385,27 +421,47 @@ __global__ __launch_bounds__(128) void k_chain_fused(const OwConsts* __restrict_
         if (args[e].set_flags & 4u) sv.retarget(args[e].vol_target, K->ramp_samples);
     }
     const double sr = K->sr, thermal_alpha = K->spk_thermal_alpha;
+    double nxt[8 * OW_FCHUNK / 64];
+    auto fetch_sums = [&](int chunk) {                           // wavefront 0: voice sums of `chunk` into registers
+        const int b0 = chunk * OW_FCHUNK;
+#pragma unroll
+        for (int u = 0; u < 8 * OW_FCHUNK / 64; ++u) {
+            const int k = lane + 64 * u;
+            const int r = k / OW_FCHUNK, n = k % OW_FCHUNK;
+            const int er = eb + r;
+            double x = 0.0;
+            if (er < e0 + ne && b0 + n < L && !eout[er].sum_nonfinite) {
+                if (args[er].main_mask) x = sum[((size_t)0 * I + er) * Lcap + b0 + n];
+                if (args[er].steal_mask) x += sum[((size_t)1 * I + er) * Lcap + b0 + n];
+            }
+            nxt[u] = x;
+        }
+    };
 
     for (int c = 0; c <= n_chunks; ++c) {
         if (wv == 0 && c < n_chunks) {
             const int base = c * OW_FCHUNK;
             const int cn = min(OW_FCHUNK, L - base);
-            {   // stage 8 engine rows x OW_FCHUNK samples of the voice sum (slot pass + steal pass): lanes = (row, sample)
-                for (int k = lane; k < 8 * OW_FCHUNK; k += 64) {
-                    const int r = k / OW_FCHUNK, n = k - r * OW_FCHUNK;
-                    const int er = eb + r;
-                    double x = 0.0;
-                    if (er < e0 + ne && n < cn && !eout[er].sum_nonfinite) {
-                        if (args[er].main_mask) x = sum[((size_t)0 * I + er) * Lcap + base + n];
-                        if (args[er].steal_mask) x += sum[((size_t)1 * I + er) * Lcap + base + n];
-                    }
-                    tin[r * (OW_FCHUNK + 1) + n] = x;
+            {   // 8 engine rows x OW_FCHUNK samples of the voice sum (slot pass + steal pass), lanes = (row, sample): the values were
+                // fetched while the previous chunk was being solved (registers), so the serial loop never waits for HBM
+                if (c == 0) fetch_sums(0);
+#pragma unroll
+                for (int u = 0; u < 8 * OW_FCHUNK / 64; ++u) {
+                    const int k = lane + 64 * u;
+                    tin[(k / OW_FCHUNK) * (OW_FCHUNK + 1) + (k % OW_FCHUNK)] = nxt[u];
                 }
                 OW_WAVE_SYNC();
+                if (c + 1 < n_chunks) fetch_sums(c + 1);
             }
             double (*slot)[8] = ring[c & 1];
             for (int n = 0; n < cn; ++n) {
                 const double x = tin[el * (OW_FCHUNK + 1) + n];
+                const double rcur[2] = {rnx[0], rnx[1]};            // R of this sample, fetched one host sample ago
+                {
+                    const uint32_t nx = (uint32_t)(min(base + n + 1, L - 1) * OSR);
+                    rnx[0] = trem_col_at(rc, nx);
+                    if (OSR == 2) rnx[1] = trem_col_at(rc, nx + 1u);
+                }
                 const double depth = clampd(sd.next(), 0.0, 1.0);   // engine.rs:533-534, tremolo.rs:117-119
                 double in[2];
                 if (OSR == 2) {
@@ -419,7 +475,7 @@ __global__ __launch_bounds__(128) void k_chain_fused(const OwConsts* __restrict_
                 }
                 for (int j = 0; j < OSR; ++j) {
                     const size_t idx = (size_t)((base + n) * OSR + j);
-                    const double r_new = fmax(trem_shunt(depth, trem_col_at(rc, (uint32_t)idx)), 1000.0);   // tremolo.rs:152-167; set_ldr_resistance
+                    const double r_new = fmax(trem_shunt(depth, rcur[j]), 1000.0);   // tremolo.rs:152-167; set_ldr_resistance
                     if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = ow_div(1.0, r_new); }
                     const double o = dk_step_wide(st, R, q, in[j], g_ldr, g_prev, K);
                     g_prev = g_ldr;
