@@ -3,7 +3,7 @@
 usage: python tools/collect_profiles.py r03
 
   profiles/<r>_kernel_stats.csv, <r>_kernel_trace_summary.md      default line (trace/)
-  profiles/<r>_kernel_trace_serial.md                             the same with OW_TREM_SERIAL=1 (each kernel's own time)
+  profiles/<r>_kernel_trace_serial.md                             the same with OW_TREM_TRAJ=0: one oscillator per instance (k_tremolo beside the voices), rounds 1-3
   profiles/<r>_pmc_summary.md, <r>_pmc_per_sample.md, hbm_traffic.json   counters of the default kernels (4 096-engine pool)
   profiles/<r>_<tag>_kernel_trace.md, <r>_<tag>_pmc.md            melange preamp / melange power amp / batch / 256-engine pool
   profiles/<r>_bench_<name>.json                                  one file per bench line (the last line of each bench_*.log)
@@ -50,7 +50,7 @@ def pmc_table(files):
 
 
 def main():
-    r = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    r = sys.argv[1] if len(sys.argv) > 1 else "r04"
     src = os.path.join(ROOT, "gpurun_out", r)
     dst = os.path.join(ROOT, "profiles")
     py = sys.executable
@@ -104,6 +104,10 @@ def main():
             open(os.path.join(dst, f"{r}_{tag}_pmc.md"), "w").write(pmc_table(files))
             made.append(os.path.join(dst, f"{r}_{tag}_pmc.md"))
     # bench lines
+    for log in sorted(glob.glob(f"{src}/probe_*.log")):
+        out = os.path.join(dst, f"{r}_{os.path.basename(log)[:-4]}.txt")
+        open(out, "w").write(open(log).read())
+        made.append(out)
     for log in sorted(glob.glob(f"{src}/bench_*.log")):
         line = [ln for ln in open(log).read().splitlines() if ln.startswith("{")]
         if not line:
