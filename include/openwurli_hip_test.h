@@ -46,7 +46,8 @@ int ow_debug_div_const(int which, const double* a, size_t n, double* fast, doubl
 int ow_debug_div_forms(int mode, const double* a, const double* b, const double* y, size_t n, double* fast, double* ieee, int device);
 /* Element-wise, the kernels' own elementary functions next to the device library's: which = 0 the preamp's junction exponential
  * (exp without the overflow / underflow selects, for arguments inside the junction clamp) and exp(); 1 the power amp's / speaker's
- * tanh (expm1-based, <= 2 ulp) and tanh(). */
+ * tanh (expm1-based, <= 2 ulp) and tanh(); 2 / 3 / 4 the reed's onset gain (reed.rs:251-264: (0.5 (1 - cos x))^p as exp(p ln .)) at phase x
+ * with p = 1.25 / 1.5 / 1.9 and the same expression with the library's pow(). */
 int ow_debug_unary(int which, const double* x, size_t n, double* fast, double* lib, int device);
 
 /* ---- tremolo phase groups -------------------------------------------------------------------- */

@@ -587,13 +587,18 @@ struct TremTraj {
     }
 };
 std::mutex g_traj_mu;
-std::map<std::pair<int, uint64_t>, std::shared_ptr<TremTraj>> g_traj;
+// The registry is LEAKED on purpose (never destroyed): a static map's destructor would run ~TremTraj -- HIP calls -- during exit(),
+// after the HIP runtime and any profiler attached to it have begun to shut down (rocprofv3 aborts there and the process hangs).  Stores
+// die when ow_test_clear_settle_caches drops them and the last pool lets go; at process exit the driver reclaims the memory.
+using TrajMap = std::map<std::pair<int, uint64_t>, std::shared_ptr<TremTraj>>;
+TrajMap& traj_registry() { static TrajMap* m = new TrajMap(); return *m; }
 
 // the store of (device, hc.os_sr), created (and settled) on first use
 std::shared_ptr<TremTraj> traj_acquire(int device, const OwConsts& hc, const OwConsts& k48, bool use_settle_cache) {
     uint64_t rate_bits; std::memcpy(&rate_bits, &hc.os_sr, 8);
     const std::pair<int, uint64_t> key(device, rate_bits);
     std::lock_guard<std::mutex> lk(g_traj_mu);
+    TrajMap& g_traj = traj_registry();
     auto it = g_traj.find(key);
     if (it != g_traj.end()) return it->second;
     auto t = std::make_shared<TremTraj>();
@@ -2330,7 +2335,7 @@ int ow_test_clear_settle_caches(void) {
     std::lock_guard<std::mutex> lk(g_mel_mu);
     const int n = (int)g_trem_settled.size();
     g_trem_settled.clear(); g_mel_settled.clear(); g_pa_settled.clear();
-    { std::lock_guard<std::mutex> lt(g_traj_mu); g_traj.clear(); }     // pools that hold a store keep it alive; new pools start a new one
+    { std::lock_guard<std::mutex> lt(g_traj_mu); traj_registry().clear(); }     // pools that hold a store keep it alive; new pools start a new one
     return n;
 }
 // Overwrite one field of a voice record (VF_* of ow_types.h) on the device before the next block: the way to make a voice non-finite,
@@ -2495,7 +2500,7 @@ int ow_debug_div_forms(int mode, const double* a, const double* b, const double*
 
 int ow_debug_unary(int which, const double* x, size_t n, double* fast, double* lib, int device) {
     try {
-        if (!x || !fast || !lib || which < 0 || which > 1) throw std::runtime_error("null argument or unknown function");
+        if (!x || !fast || !lib || which < 0 || which > 4) throw std::runtime_error("null argument or unknown function");
         if (n == 0) return 0;
         HIP_OK(hipSetDevice(device));
         DevMem dx, df, dl;

@@ -403,7 +403,16 @@ __device__ __noinline__ __attribute__((const)) double onset_gain(double n, doubl
     const double cosine = 0.5 * (1.0 - cos(n * onset_inc));
     if (onset_exp <= 1.001) return cosine;
     if (onset_exp >= 1.999) return cosine * cosine;
+#ifdef OW_LIB_POW
     return pow(cosine, onset_exp);
+#else
+    // cosine^p as exp(p ln cosine), cosine in [0, 1), p in (1.001, 1.999).  The library's pow carries ln in double-double to stay below
+    // 1 ulp for every argument (~250 instructions; every lane of a re-struck wavefront pays it on every sample of its onset ramp).
+    // Here the result is a GAIN in [0, 1): the error of p ln c is |p ln c| eps relative on the result, i.e. c^p |p ln c| eps absolute,
+    // whose maximum over c is eps / e = 4e-17 -- below half an ulp of the gains near 1 that carry the signal, and the reference's own
+    // f64::powf (glibc) is only specified to 1 ulp.  pow(0, p) = 0 = exp(-inf).  (tests/test_gpu_division.py::test_onset_gain_accuracy)
+    return exp(onset_exp * log(cosine));
+#endif
 }
 __device__ __noinline__ __attribute__((const)) double exp_neg(double x) { return exp(-x); }                         // reed.rs:238
 __device__ __noinline__ __attribute__((const)) double noise_fade_env(double t) { return 0.5 * (1.0 - cos(3.14159265358979323846 * t)); }  // hammer.rs:165

@@ -191,3 +191,32 @@ def test_short_division_forms_are_the_ieee_quotient(hiplib):
     a0 = np.concatenate([np.zeros(1024), -np.zeros(1024)])
     fast, ieee = _forms(hiplib, 2, a0, _rand(rng, a0.size, -90, 90))
     assert np.array_equal(fast, ieee) and np.all(fast == 0.0)
+
+
+def test_onset_gain_accuracy(hiplib):
+    """The reed's onset gain (reed.rs:251-264) for mid velocities is cosine^p with p in (1.001, 1.999); the kernels form it as
+    exp(p ln cosine) instead of the library's pow (which carries the logarithm in double-double: ~250 instructions per lane and sample of
+    a re-struck wavefront).  The result is a gain in [0, 1): its absolute error stays below 2.5e-16 -- about one ulp of the gains near 1
+    that carry the signal -- over the whole ramp incl. its first samples (cosine ~ 1e-7) and the end points, and equals the library's
+    pow to 4 ulp relative where the gain is not tiny."""
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(0.0, np.pi, 1 << 22), np.pi * np.arange(1, 2049) / 2049.0, np.ldexp(np.pi, -np.arange(1, 40)),
+                        np.array([0.0, np.pi, np.pi / 2, 1e-9])])
+    for which, p in ((2, 1.25), (3, 1.5), (4, 1.9)):
+        f = np.zeros_like(x); l = np.zeros_like(x)
+        assert hiplib.ow_debug_unary(which, x.ctypes.data_as(C.c_void_p), x.size, f.ctypes.data_as(C.c_void_p), l.ctypes.data_as(C.c_void_p), 0) == 0
+        xl = x.astype(np.longdouble)
+        ref = (0.5 * (1.0 - np.cos(xl))) ** np.longdouble(p)
+        # the cosine itself is formed in f64 on the device (1 - cos x cancels for small x exactly as in the reference): compare on the
+        # device's own cosine, i.e. against pow of the f64 value
+        c64 = 0.5 * (1.0 - np.cos(x))
+        ref64 = (c64.astype(np.longdouble)) ** np.longdouble(p)
+        err = np.abs(f.astype(np.longdouble) - ref64).astype(np.float64)
+        lib_err = np.abs(l.astype(np.longdouble) - ref64).astype(np.float64)
+        assert np.max(err) <= 2.5e-16 + 4 * np.max(lib_err), (p, np.max(err), np.max(lib_err))
+        big = l > 1e-3                                                    # (device cosine on both sides: its own ulp cancels out)
+        rel = np.abs(f[big] - l[big]) / l[big]
+        assert np.max(rel) <= 4 * 2.2204e-16 * 8, (p, np.max(rel))       # <= |p ln c| eps + the two library calls' own ulp
+        assert f[x == 0.0][0] == 0.0 and np.all(f >= 0.0) and np.all(f <= 1.0)
+        assert np.all(np.isfinite(f))
+        del ref
