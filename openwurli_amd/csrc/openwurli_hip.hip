@@ -574,17 +574,22 @@ struct TremTraj {
         if (ahead) extend_to(end + ahead);
         return wait;
     }
+    // the recorded fallback events ([0] = count, [1 + k] = sample index), one transfer however many engines ask
+    std::vector<unsigned long long> be_events() {
+        std::vector<unsigned long long> h(1 + OW_TRAJ_BE_CAP, 0ull);
+        if (hipStreamSynchronize(stream) != hipSuccess) return h;      // (no lock: a render on another thread must not wait behind an inspection call)
+        if (hipMemcpy(h.data(), d_be, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost) != hipSuccess) std::fill(h.begin(), h.end(), 0ull);
+        return h;
+    }
     // fallback count of an engine standing at sample t (diag): the settle's own + the recorded events below t
-    uint64_t be_count_at(long long t) {
-        std::vector<unsigned long long> h(1 + OW_TRAJ_BE_CAP);
-        { std::lock_guard<std::mutex> lk(mu); if (hipStreamSynchronize(stream) != hipSuccess) return be_settle; }
-        if (hipMemcpy(h.data(), d_be, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost) != hipSuccess) return be_settle;
+    uint64_t be_count_at(long long t, const std::vector<unsigned long long>& h) const {
         uint64_t n = be_settle;
         const size_t k = (size_t)std::min<unsigned long long>(h[0], OW_TRAJ_BE_CAP);
         for (size_t i = 0; i < k; ++i) n += (long long)h[1 + i] < t;
         if (h[0] > OW_TRAJ_BE_CAP) n += h[0] - OW_TRAJ_BE_CAP;     // beyond the list: counted, not placed
         return n;
     }
+    uint64_t be_count_at(long long t) { return be_count_at(t, be_events()); }
 };
 std::mutex g_traj_mu;
 // The registry is LEAKED on purpose (never destroyed): a static map's destructor would run ~TremTraj -- HIP calls -- during exit(),
@@ -829,6 +834,7 @@ void traj_recount(ow_pool* p) {
     p->min_birth = mn; p->n_on_traj = n;
 }
 void traj_upload_births(ow_pool* p, int e0, int ne) {     // synchronous: h_birth is pageable and changes again right away
+    HIP_OK(hipStreamSynchronize(p->stream));              // a k_trem_birth_shift of a sub-range render still queued would shift the new values again
     HIP_OK(hipMemcpy(p->d_birth + e0, p->h_birth.data() + e0, sizeof(long long) * (size_t)ne, hipMemcpyHostToDevice));
 }
 
@@ -851,7 +857,10 @@ void trem_evict(ow_pool* p, int e0, int ne, int n_os) {
     { std::lock_guard<std::mutex> lk(T->mu); ev = T->cover((size_t)tmax, 0); }
     if (ev) HIP_OK(hipEventSynchronize(ev));
     std::vector<unsigned long long> be(eng.size());
-    for (size_t i = 0; i < eng.size(); ++i) be[i] = T->be_count_at(tp[i]);
+    {
+        const std::vector<unsigned long long> events = T->be_events();
+        for (size_t i = 0; i < eng.size(); ++i) be[i] = T->be_count_at(tp[i], events);
+    }
     DevMem de, dt, db;
     de.alloc(sizeof(uint32_t) * eng.size()); dt.alloc(sizeof(long long) * eng.size()); db.alloc(sizeof(unsigned long long) * eng.size());
     HIP_OK(hipMemcpy(de.p, eng.data(), sizeof(uint32_t) * eng.size(), hipMemcpyHostToDevice));
@@ -941,7 +950,12 @@ void upload_consts(ow_pool* p, double sr, int preamp_kind) {
     HIP_OK(hipMemcpyAsync(p->dK48, &k48, sizeof(OwConsts), hipMemcpyHostToDevice, p->stream));
     // the shared trajectory of this (device, chain rate); the callers (pool_create, set_sample_rate) re-initialise every engine next
     p->traj.reset();
-    if (!p->voices_only && p->tremolo_kind == OW_TREMOLO_TWIN_T && p->sw.trem_traj) p->traj = traj_acquire(p->device, p->hc, k48, p->sw.trem_cache);
+    if (!p->voices_only && p->tremolo_kind == OW_TREMOLO_TWIN_T && p->sw.trem_traj) {
+        // a store that cannot be had (no room for it on a crowded device) is not an error: the pool runs one oscillator per phase
+        // group, as under OW_TREM_TRAJ=0 -- the same samples
+        try { p->traj = traj_acquire(p->device, p->hc, k48, p->sw.trem_cache); }
+        catch (const std::exception& ex) { p->traj.reset(); (void)hipGetLastError(); std::fprintf(stderr, "openwurli-hip: no tremolo trajectory store (%s): per-group oscillators\n", ex.what()); }
+    }
     if (!p->traj) { std::fill(p->h_birth.begin(), p->h_birth.end(), OW_OFF_TRAJ); if (p->d_birth) traj_upload_births(p, 0, (int)p->I); p->n_on_traj = 0; }
     if (p->power_amp_kind == OW_POWER_AMP_MELANGE) {
         std::unique_ptr<OwPaConsts> hpa(new OwPaConsts());
@@ -1889,7 +1903,7 @@ int ow_pool_read_tremolo_r(ow_pool* p, double* out_host, size_t out_stride, size
             DevMem g;
             g.alloc(sizeof(double) * I * n_os);
             // the block consumed [t_end - last_n_os, t_end); its first n_os samples are asked for
-            owdev::k_trem_traj_gather<<<dim3((unsigned)((n_os + 255) / 256), (unsigned)I), dim3(256), 0, p->stream>>>(
+            owdev::k_trem_traj_gather<<<dim3((unsigned)((I * n_os + 255) / 256)), dim3(256), 0, p->stream>>>(
                 p->traj->d_r + p->trem_clock - (p->last_n_os - (long long)n_os), p->d_birth, (int)I, (long long)n_os, g.as<double>());
             HIP_OK(hipGetLastError());
             tr.resize(I * n_os);

@@ -439,9 +439,10 @@ __global__ __launch_bounds__(64) void k_trem_from_ckpt(const OwConsts* __restric
 
 // rows of R the last block consumed, for engines on the trajectory (ow_pool_read_tremolo_r): out[e][i] = traj[t_end(e) - n_os + i]
 __global__ void k_trem_traj_gather(const double* __restrict__ traj_at_clock, const long long* __restrict__ birth, int I, long long n_os, double* __restrict__ out) {
-    const int e = blockIdx.y;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= I || i >= n_os) return;
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = (int)(k / n_os);
+    const long long i = k - (long long)e * n_os;
+    if (e >= I) return;
     const long long b = birth[e];
     out[(size_t)e * n_os + i] = b == OW_OFF_TRAJ ? 0.0 : traj_at_clock[i - n_os - b];
 }
