@@ -61,8 +61,11 @@ def _config5_events(n_inst, restrike):
 
 def _run_config4(ow, oracle, trem_wide, with_oracle):
     n_inst, total = 256, int(1.2 * SR)
-    with _Env("OW_TREM_WIDE", trem_wide):
+    # trem_wide None = the default pool: shared tremolo trajectory + fused preamp / output launch; "0" / "1" = created under OW_TREM_TRAJ=0 with
+    # the lane-per-group / quad-per-group oscillator kernel forced (the per-group path of rounds 1-3, bit-identical to the trajectory)
+    with _Env("OW_TREM_WIDE", trem_wide), _Env("OW_TREM_TRAJ", None if trem_wide is None else "0"):
         g = ow.EnginePool(SR, n_inst)
+        assert g.get_switch("trem_traj") == (1 if trem_wide is None else 0)
         g.set_sample_rate(SR)
         g.ensure_buffer_capacity(512)
         cs = {}
@@ -129,6 +132,8 @@ def test_config4_tremolo_kernels_agree_at_256(hiplib, oracle):
     a, _, _ = _run_config4(ow, oracle, "1", False)
     b, _, _ = _run_config4(ow, oracle, "0", False)
     assert np.array_equal(a, b)
+    c, _, _ = _run_config4(ow, oracle, None, False)          # ... and equal the default pool's (trajectory, fused chain launch)
+    assert np.array_equal(a, c)
 
 
 SUBSET = [(n, v) for n in (33, 48, 60, 72, 84, 91, 96, 40) for v in (50, 127)]     # SURVEY 8d parity subset of config 4

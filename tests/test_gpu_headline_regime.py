@@ -51,12 +51,24 @@ def _period(n, groups):
     return 88 if groups in (None, 1) else int(np.lcm(88, groups))
 
 
-def _run(hiplib, oracle, n_inst, total, modes, groups=None, restrike_at=EPOCH):
+def _run(hiplib, oracle, n_inst, total, modes, groups=None, restrike_at=EPOCH, trajectory=True):
     """modes: per block, cycled: 'host' (pageable numpy block), 'hbm' (left on the device, read back through the test hook),
     'pinned' (render straight into a page-locked block).  groups: ow_test_pool_stagger_tremolo(groups) after the warm-up."""
     import openwurli_amd as ow
     from openwurli_amd import binding
-    g = ow.EnginePool(SR, n_inst)
+    import os
+    saved = os.environ.get("OW_TREM_TRAJ")
+    if not trajectory:
+        os.environ["OW_TREM_TRAJ"] = "0"            # read when the pool is created: one oscillator per tremolo phase group (rounds 1-3)
+    try:
+        g = ow.EnginePool(SR, n_inst)
+    finally:
+        if not trajectory:
+            if saved is None:
+                del os.environ["OW_TREM_TRAJ"]
+            else:
+                os.environ["OW_TREM_TRAJ"] = saved
+    assert g.get_switch("trem_traj") == (1 if trajectory else 0)
     g.set_sample_rate(SR)
     g.ensure_buffer_capacity(512)
     step = 0
@@ -148,14 +160,22 @@ def test_pool_of_16384_with_64_tremolo_groups(hiplib, oracle):
 
 
 def test_pool_of_131072_fully_decorrelated(hiplib, oracle):
-    """One oscillator per engine at the bench's pool size: the lane = group k_tremolo with 2 048 wavefronts, every engine reading its
-    own column of the R buffer.  0.35 s with a whole-keyboard re-strike at 0.25 s."""
+    """One tremolo phase per engine at the bench's pool size -- the bench's own configuration: 131 072 engines at 131 072 different t of
+    the shared trajectory.  0.35 s with a whole-keyboard re-strike at 0.25 s."""
     worst, peak = _run(hiplib, oracle, 131072, int(0.35 * SR), ("hbm", "pinned"), groups=131072, restrike_at=12000)
     assert worst < 1.0 and 0.02 < peak < 4.0
 
 
 def test_pool_of_32768_fully_decorrelated_lane_per_group_kernel(hiplib, oracle):
-    """Smallest pool that takes the lane = group tremolo kernel with one group per engine, for the whole 1.1 s script."""
+    """Smallest pool that takes the lane = group tremolo kernel with one group per engine, for the whole 1.1 s script.  Created under
+    OW_TREM_TRAJ=0: since round 4 a default pool reads the shared trajectory and runs no oscillator of its own; this keeps the per-group
+    path (what engines older than the trajectory store fall back to) under the oracle at pool scale."""
+    worst, peak = _run(hiplib, oracle, 32768, TOTAL, ("hbm",), groups=32768, trajectory=False)
+    assert worst < 1.0 and 0.02 < peak < 4.0
+
+
+def test_pool_of_32768_fully_decorrelated_on_the_trajectory(hiplib, oracle):
+    """The same pool and script on the shared trajectory (the default): 32 768 engines at 32 768 different t."""
     worst, peak = _run(hiplib, oracle, 32768, TOTAL, ("hbm",), groups=32768)
     assert worst < 1.0 and 0.02 < peak < 4.0
 

@@ -249,8 +249,10 @@ def test_tremolo_wide_is_bit_identical(hiplib, oracle):
         streams = {}
         for wide in ("0", "1"):
             os.environ["OW_TREM_WIDE"] = wide
+            os.environ["OW_TREM_TRAJ"] = "0"        # per-group oscillators: on the shared trajectory (the default) neither kernel runs per pool
             try:
                 p = ow.EnginePool(sr, 3)
+                assert p.get_switch("trem_traj") == 0 and p.get_switch("trem_wide") == int(wide)
                 p.set_sample_rate(sr)
                 rs = []
                 for length in (512, 512, 100, 512, 37):
@@ -259,6 +261,7 @@ def test_tremolo_wide_is_bit_identical(hiplib, oracle):
                 p.close()
             finally:
                 del os.environ["OW_TREM_WIDE"]
+                del os.environ["OW_TREM_TRAJ"]
             streams[wide] = np.concatenate(rs)
         assert np.array_equal(streams["0"], streams["1"]), (sr, np.max(np.abs(streams["0"] - streams["1"])))
         assert 1e3 < streams["1"].min() < streams["1"].max() <= 1e6

@@ -84,8 +84,10 @@ def test_staggered_groups_run_the_same_oscillator_at_different_times(hiplib):
     outs = {}
     for wide in ("0", "1"):
         os.environ["OW_TREM_WIDE"] = wide
+        os.environ["OW_TREM_TRAJ"] = "0"            # per-group oscillators (the default pool reads the shared trajectory: test_gpu_trajectory.py)
         try:
             p = ow.EnginePool(sr, n)
+            assert p.get_switch("trem_traj") == 0
             p.set_sample_rate(sr)
             assert hiplib.ow_test_pool_stagger_tremolo(p._h, G) == 0
             assert _groups(hiplib, p) == G
@@ -98,6 +100,7 @@ def test_staggered_groups_run_the_same_oscillator_at_different_times(hiplib):
             p.close()
         finally:
             del os.environ["OW_TREM_WIDE"]
+            del os.environ["OW_TREM_TRAJ"]
         streams[wide] = np.concatenate(rs, axis=1)
         outs[wide] = np.concatenate(os_, axis=1)
     assert np.array_equal(streams["0"], streams["1"]) and np.array_equal(outs["0"], outs["1"])
