@@ -108,6 +108,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // behind the last one.  An engine that sounds 8 voices then costs an eighth of a wavefront instead of a whole one; with all 64 keys
 // down a block is one engine as before.  The ordered voice sum (engine.rs:469-479) is taken per engine over its lanes, which are in
 // slot order, so it is still the reference's sequential sum -- without the +0.0 terms of the silent slots.
+// k_voice: capped at 256 registers (two wavefronts per SIMD).  Uncapped the compiler takes ~350 (one wavefront per SIMD, 42-110 of them
+// accumulator registers it shuffles through): a re-struck pool's three general blocks ran 17 % slower.
+#ifndef OW_VOICE_GENERAL_ATTR
+#define OW_VOICE_GENERAL_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 #define OW_VCHUNK 24   // 64 voices x 24 samples x f64 = 12.8 KB tile: 8 voice blocks + 4 tremolo blocks fit the 160 KB LDS of a CU
 #define OW_NO_VOICE 0xFFFFFFFFu
 #define OW_GT_MAX 16      // lanes in an onset ramp / damper ramp up to which their gain curves are tabulated per chunk (k_voice)
@@ -133,6 +138,7 @@ OW_DEV VoiceLanes voice_lanes(const uint32_t* __restrict__ entries, int* __restr
     return w;
 }
 // Sum the voices of each engine of the block in slot order for sample (base + lane) and write its row of sum[pass][engine][.].
+template <int CH = OW_VCHUNK>
 OW_DEV void voice_reduce(const double* __restrict__ tile, const int* __restrict__ eng_l, const VoiceLanes& w, int cn, int base, int pass,
                          double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int Lcap) {
     const int lane = threadIdx.x;
@@ -141,10 +147,10 @@ OW_DEV void voice_reduce(const double* __restrict__ tile, const int* __restrict_
             double acc = 0.0;
             if (w.nvalid == 64) {
 #pragma unroll 16
-                for (int l = 0; l < 64; ++l) acc += tile[l * (OW_VCHUNK + 1) + lane];
+                for (int l = 0; l < 64; ++l) acc += tile[l * (CH + 1) + lane];
             } else {
 #pragma unroll 4
-                for (int l = 0; l < w.nvalid; ++l) acc += tile[l * (OW_VCHUNK + 1) + lane];
+                for (int l = 0; l < w.nvalid; ++l) acc += tile[l * (CH + 1) + lane];
             }
             const int e = eng_l[0];
             if (!isfinite(acc)) atomicOr(&eout[e].sum_nonfinite, 1u);
@@ -153,7 +159,7 @@ OW_DEV void voice_reduce(const double* __restrict__ tile, const int* __restrict_
         }
         double acc = 0.0;
         for (int l = 0; l < w.nvalid; ++l) {
-            acc += tile[l * (OW_VCHUNK + 1) + lane];
+            acc += tile[l * (CH + 1) + lane];
             if ((w.seg_end >> l) & 1ull) {
                 const int e = eng_l[l];
                 if (!isfinite(acc)) atomicOr(&eout[e].sum_nonfinite, 1u);
@@ -173,12 +179,13 @@ OW_DEV void voice_reduce(const double* __restrict__ tile, const int* __restrict_
 // TABS: tabulate phase gain curves per chunk (below).  The tables cost 14 KB of LDS (4 instead of 7 blocks per CU), so the host uses
 // this variant when the general list is sparse (played input) and the plain one when most engines are in it (a re-strike of everything).
 template <bool TABS>
-__global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, double* __restrict__ vrec, const uint32_t* __restrict__ entries,
+__global__ __launch_bounds__(64) OW_VOICE_GENERAL_ATTR void k_voice(const OwConsts* __restrict__ K, double* __restrict__ vrec, const uint32_t* __restrict__ entries,
                                               double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int L, int Lcap, int pass) {
-    __shared__ double tile[64 * (OW_VCHUNK + 1)];
+    constexpr int CH = OW_VCHUNK;       // (a 16-sample tile for the dense variant -- eight workgroups per CU instead of six -- measured no different)
+    __shared__ double tile[64 * (CH + 1)];
     __shared__ double lcoef[OW_LCOEF_ROWS * 64];
-    __shared__ double gtab[TABS ? OW_GT_MAX * OW_VCHUNK : 1];       // onset gains of this chunk, one row per lane inside its onset ramp
-    __shared__ double dtab[TABS ? OW_DT_MAX * OW_VCHUNK * 7 : 1];   // damper-ramp factors of this chunk, [lane in its ramp][sample][mode]
+    __shared__ double gtab[TABS ? OW_GT_MAX * CH : 1];       // onset gains of this chunk, one row per lane inside its onset ramp
+    __shared__ double dtab[TABS ? OW_DT_MAX * CH * 7 : 1];   // damper-ramp factors of this chunk, [lane in its ramp][sample][mode]
     __shared__ int eng_l[64];
     const int lane = threadIdx.x;
     const VoiceLanes w = voice_lanes(entries, eng_l);
@@ -200,8 +207,8 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
     }
     __syncthreads();                     // eng_l
     bool bad_voice = false;
-    for (int base = 0; base < L; base += OW_VCHUNK) {
-        const int cn = min(OW_VCHUNK, L - base);
+    for (int base = 0; base < L; base += CH) {
+        const int cn = min(CH, L - base);
         // Steal pass: once every crossfade of this engine has run out (gain (fade - i)/len == 0 from here on, engine.rs:483-489)
         // the rest of the block only adds voice x 0.0, and the voices are dropped after the block (steal_fade reaches 0): stop
         // stepping them.  (The reference keeps rendering them; only a voice turning non-finite inside its last 5 ms would differ.)
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
                 const int l = __builtin_ctzll(m);
                 const unsigned long long s0 = __shfl((unsigned long long)v.sample, l), on = __shfl((unsigned long long)v.onset_n, l);
                 const double inc = __shfl(v.onset_inc, l), ex = __shfl(v.onset_exp, l);
-                if (lane < cn) gtab[r * OW_VCHUNK + lane] = (s0 + lane < on) ? onset_gain((double)(s0 + lane), inc, ex) : 1.0;
+                if (lane < cn) gtab[r * CH + lane] = (s0 + lane < on) ? onset_gain((double)(s0 + lane), inc, ex) : 1.0;
             }
         }
         if (tab_rp) {
@@ -236,12 +243,12 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
                 for (int q = lane; q < cn * 7; q += 64) {
                     const int i = q / 7, md = q - 7 * i;
                     const double t = d0 + (double)(i + 1);      // dcount after this sample's increment (exact: a sample count)
-                    dtab[(r * OW_VCHUNK + i) * 7 + md] = exp_neg(lcoef[(5 + md) * 64 + l] * t / dr);
+                    dtab[(r * CH + i) * 7 + md] = exp_neg(lcoef[(5 + md) * 64 + l] * t / dr);
                 }
             }
         }
-        const double* my_gt = (tab_on && ((m_on >> lane) & 1ull)) ? gtab + __popcll(m_on & ((1ull << lane) - 1ull)) * OW_VCHUNK : nullptr;
-        const double* my_dt = (tab_rp && ((m_rp >> lane) & 1ull)) ? dtab + __popcll(m_rp & ((1ull << lane) - 1ull)) * OW_VCHUNK * 7 : nullptr;
+        const double* my_gt = (tab_on && ((m_on >> lane) & 1ull)) ? gtab + __popcll(m_on & ((1ull << lane) - 1ull)) * CH : nullptr;
+        const double* my_dt = (tab_rp && ((m_rp >> lane) & 1ull)) ? dtab + __popcll(m_rp & ((1ull << lane) - 1ull)) * CH * 7 : nullptr;
         for (int n = 0; n < cn; ++n) {
             double o = 0.0;
             if (active) {
@@ -252,11 +259,11 @@ __global__ __launch_bounds__(64) void k_voice(const OwConsts* __restrict__ K, do
                     o = o * ((double)remaining / (double)steal_len);
                 }
             }
-            tile[lane * (OW_VCHUNK + 1) + n] = o;
+            tile[lane * (CH + 1) + n] = o;
         }
         if (active && !v.state_finite()) bad_voice = true;
         __syncthreads();
-        if (!guard) voice_reduce(tile, eng_l, w, cn, base, pass, sum, eout, I, Lcap);
+        if (!guard) voice_reduce<CH>(tile, eng_l, w, cn, base, pass, sum, eout, I, Lcap);
         __syncthreads();
     }
     if (active) {

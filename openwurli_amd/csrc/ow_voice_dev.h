@@ -399,19 +399,65 @@ __device__ inline void start_damper_lane(double* __restrict__ rec, const OwConst
 // Rare-phase transcendentals are kept out of line so their temporaries do not inflate the register
 // footprint of the steady-state loop (onset ramp: first ~1-2 periods; damper ramp: 8-50 ms after note-off;
 // attack noise fade-in: 16 samples; pickup saturation: only |y| >= 0.94).
+// cos on [0, pi] (the onset ramp's phase n * pi / N, n < N): quadrant by Cody-Waite with the first 33 bits of pi/2 (k <= 2: the product is
+// exact) and the fdlibm kernels (k_cos.c / k_sin.c polynomials) with explicit fused steps; <= 1.5 ulp.  The library's cos carries a
+// Payne-Hanek path for huge arguments and costs ~150 instructions per lane and sample of an onset ramp; this is ~35.
+OW_DEV double cos_0_pi(double x) {
+    const double kf = floor(x * 6.36619772367581382433e-01 + 0.5);                      // 0, 1 or 2
+    const double r = __builtin_fma(-kf, 6.07710050650619224932e-11, __builtin_fma(-kf, 1.57079632673412561417e+00, x));
+    const double z = r * r;
+    // cos(r)
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cr = w + (((1.0 - w) - hz) + z * (z * pc));                              // 1 - z/2 + z^2 pc with the rounding error of 1 - z/2 fed back
+    // sin(r)
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    const double sr = __builtin_fma(z * r, __builtin_fma(z, ps, -1.66666666666666324348e-01), r);
+    return kf == 0.0 ? cr : (kf == 1.0 ? -sr : -cr);
+}
+// ln on (0, 1] (fdlibm e_log.c: x = 2^k (1 + f), s = f / (2 + f), the Lg1..Lg7 series, k ln2 split in hi / lo); <= 1 ulp.  Normal
+// arguments only (the onset cosine is 0 -- handled by the caller -- or >= ~1e-8).
+OW_DEV double log_unit(double x) {
+    int k = __builtin_amdgcn_frexp_exp(x);                                               // x = m 2^k, m in [0.5, 1)
+    double m = __builtin_amdgcn_frexp_mant(x);
+    if (m < 7.07106781186547524401e-01) { m += m; k -= 1; }                              // m in [sqrt(1/2), sqrt(2))
+    const double f = m - 1.0;
+    const double s = ow_div(f, 2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                                        6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
 __device__ __noinline__ __attribute__((const)) double onset_gain(double n, double onset_inc, double onset_exp) {  // reed.rs:251-264
+#ifdef OW_LIB_POW
     const double cosine = 0.5 * (1.0 - cos(n * onset_inc));
     if (onset_exp <= 1.001) return cosine;
     if (onset_exp >= 1.999) return cosine * cosine;
-#ifdef OW_LIB_POW
     return pow(cosine, onset_exp);
 #else
+    // The ramp's phase n * inc lies in [0, pi): a cosine for that interval alone (cos_0_pi).
+    const double cosine = 0.5 * (1.0 - cos_0_pi(n * onset_inc));
+    if (onset_exp <= 1.001) return cosine;
+    if (onset_exp >= 1.999) return cosine * cosine;
     // cosine^p as exp(p ln cosine), cosine in [0, 1), p in (1.001, 1.999).  The library's pow carries ln in double-double to stay below
-    // 1 ulp for every argument (~250 instructions; every lane of a re-struck wavefront pays it on every sample of its onset ramp).
+    // 1 ulp for every argument (~215 instructions; every lane of a re-struck wavefront pays it on every sample of its onset ramp).
     // Here the result is a GAIN in [0, 1): the error of p ln c is |p ln c| eps relative on the result, i.e. c^p |p ln c| eps absolute,
     // whose maximum over c is eps / e = 4e-17 -- below half an ulp of the gains near 1 that carry the signal, and the reference's own
-    // f64::powf (glibc) is only specified to 1 ulp.  pow(0, p) = 0 = exp(-inf).  (tests/test_gpu_division.py::test_onset_gain_accuracy)
-    return exp(onset_exp * log(cosine));
+    // f64::powf (glibc) is only specified to 1 ulp.  pow(0, p) = 0.  (tests/test_gpu_division.py::test_onset_gain_accuracy)
+    if (!(cosine > 0.0)) return 0.0;
+    return exp(onset_exp * log_unit(cosine));
 #endif
 }
 __device__ __noinline__ __attribute__((const)) double exp_neg(double x) { return exp(-x); }                         // reed.rs:238
@@ -434,6 +480,7 @@ OW_DEV void lcoef_load(double* __restrict__ lcoef, const double* __restrict__ re
 
 struct VoiceRegs {
     double s[7], c[7], env[7], drift[7], cos_inc[7], sin_inc[7], phase_inc[7], amp[7], decay[7];
+    double ci[7], si[7];                // jitter-corrected rotation (reed.rs:281-283): a function of the drift alone, which moves every 16th sample
     double onset_inc, onset_exp, dramp, dcount, q, ds, gain;
     double namp, ns1, ns2;              // attack noise: amplitude and BPF state; the five BPF coefficients stay in the record / LDS
     double beta, jrev, jdiff, ndecay;   // per-voice rate constants (fixed at note-on; loaded once per kernel, never re-read in the sample loop)
@@ -457,6 +504,20 @@ struct VoiceRegs {
         const uint64_t r = dbits(rec[VF_RNG * 64]); jitter_state = (uint32_t)r; noise_rng = (uint32_t)(r >> 32);
         const uint64_t n = dbits(rec[VF_NCNT * 64]); noise_rem = (uint32_t)n; noise_fade = (uint32_t)(n >> 32);
         const uint64_t f = dbits(rec[VF_FLAGS * 64]); flags = (uint32_t)f; midi = (uint32_t)(f >> 32);
+        update_rotation();
+    }
+    // ci / si of reed.rs:281-283.  The reference forms them on every sample from the same four numbers; they only change when the drift
+    // does (every 16th sample, below), so they are formed there -- the same expressions on the same operands, the same bits.
+    OW_DEV void update_rotation() {
+#ifndef OW_STRICT_FP
+#pragma clang fp contract(fast)
+#endif
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            const double delta_phase = drift[m] * phase_inc[m];
+            ci[m] = cos_inc[m] - delta_phase * sin_inc[m];
+            si[m] = sin_inc[m] + delta_phase * cos_inc[m];
+        }
     }
     OW_DEV void store(double* __restrict__ rec) const {
 #pragma unroll
@@ -530,17 +591,15 @@ struct VoiceRegs {
                 const double noise = (u * 2.0 - 1.0) * 1.7320508080;
                 drift[m] = revert * drift[m] + diffusion * noise;
             }
+            update_rotation();
         }
         double sum = 0.0;
 #pragma unroll
         for (int m = 0; m < 7; ++m) {
             if (STEADY) sum += amp[m] * s[m] * env[m];          // onset == 1.0: x * 1.0 == x exactly
             else sum += amp[m] * s[m] * onset * env[m];
-            const double delta_phase = drift[m] * phase_inc[m];
-            const double ci = cos_inc[m] - delta_phase * sin_inc[m];
-            const double si = sin_inc[m] + delta_phase * cos_inc[m];
-            const double s_new = s[m] * ci + c[m] * si;
-            const double c_new = c[m] * ci - s[m] * si;
+            const double s_new = s[m] * ci[m] + c[m] * si[m];
+            const double c_new = c[m] * ci[m] - s[m] * si[m];
             s[m] = s_new;
             c[m] = c_new;
             env[m] *= decay[m];
