@@ -24,6 +24,7 @@
 #include "ow_melange_dev.h"
 #include "ow_melange_lit.h"
 #include "ow_melange_col.h"
+#include "ow_melange_eng.h"
 #include "ow_power_amp_dev.h"
 #include "ow_features.h"
 #include "ow_trem_wide.h"
@@ -188,6 +189,7 @@ struct Switches {
     bool trem_cache = true;                    // OW_TREM_CACHE=0: no process-wide settled-state cache
     bool trem_traj = true;                     // OW_TREM_TRAJ=0: no shared trajectory, one oscillator per phase group (rounds 1-3)
     bool mel_rank1 = false, mel_lds = false, mel_generic = false;
+    int mel_eng = 0;                           // OW_MEL_ENG=1: lane = engine melange kernel (k_preamp_mel_eng; measured -3 % at 131 072 engines, 2x slower at 65 536)
     int pa_sort = 1;                           // OW_PA_SORT: 0 never, 1 when the block exceeds the chip, 2 always
     int pipe = 0;                              // OW_PIPE=n stages
     bool pipe_overlap = false;
@@ -205,6 +207,7 @@ struct Switches {
         w.trem_cache = flag("OW_TREM_CACHE", 1) != 0;
         w.trem_traj = flag("OW_TREM_TRAJ", 1) != 0;
         w.mel_rank1 = flag("OW_MEL_RANK1", 0) == 1; w.mel_lds = flag("OW_MEL_LDS", 0) == 1; w.mel_generic = flag("OW_MEL_GENERIC", 0) == 1;
+        w.mel_eng = flag("OW_MEL_ENG", 0) == 1;
         w.pa_sort = flag("OW_PA_SORT", 1); if (w.pa_sort < 0 || w.pa_sort > 2) w.pa_sort = 1;
         if (const char* e = std::getenv("OW_PIPE")) { const int v = std::atoi(e); w.pipe = (v >= 1 && v <= 8) ? v : 0; }
         w.pipe_overlap = flag("OW_PIPE_OVERLAP", 0) == 1;
@@ -998,6 +1001,9 @@ size_t Workers::host_threads() { return std::min<size_t>(effective_cpus(), OW_MA
 static inline bool melange_rank_one(const ow_pool* p) { return p->sw.mel_rank1; }
 static inline bool melange_lds_matrix(const ow_pool* p) { return p->sw.mel_lds; }
 static inline bool melange_generic_only(const ow_pool* p) { return p->sw.mel_generic; }
+// OW_MEL_ENG=1: lane = engine (ow_melange_eng.h: the rebuild once per engine instead of once per solver state, 64 engines per wavefront).
+// Bit-identical; measured 39.2 against 40.4 ms per 131 072-engine block and 45 against 21 ms at 65 536 (one wavefront per SIMD): not the default.
+static inline bool melange_lane_engine(const ow_pool* p, int) { return p->sw.mel_eng != 0; }
 
 // Stages of the staged render.  Off by default: OW_PIPE=n (2..8) cuts big ranges (>= 32 768 engines) into n engine stages on their own
 // streams, chained stage to stage, so that the output copy of a stage runs beside the kernels of the next one.  Measured: stages cost
@@ -1260,7 +1266,11 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
             else
                 owdev::k_chain_fused<false><<<dim3((sne + 7) / 8), dim3(128), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, tsrc, p->d_pre, p->d_out, I, L, Lcap, L, se0, sne);
         } else if (sne > 0 && chain) {
-            if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one(p) && p->hc.ml_sparse_ok && !melange_lds_matrix(p))
+            if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one(p) && p->hc.ml_sparse_ok && !melange_lds_matrix(p) && melange_lane_engine(p, sne))
+                owdev::k_preamp_mel_eng<<<dim3((sne + 63) / 64), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, tsrc,
+                                                                                 p->d_pre, p->d_noise, I, L, Lcap, se0, sne, melange_generic_only(p) ? 1 : 0,
+                                                                                 p->d_mel_lu, p->mel_lu_ld);
+            else if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one(p) && p->hc.ml_sparse_ok && !melange_lds_matrix(p))
                 owdev::k_preamp_mel_col<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, tsrc,
                                                                                  p->d_pre, p->d_noise, I, L, Lcap, se0, sne, melange_generic_only(p) ? 1 : 0,
                                                                                  p->d_mel_lu, p->mel_lu_ld);
@@ -2403,6 +2413,7 @@ int ow_test_pool_set_switch(ow_pool* p, const char* name, int value) {
     else if (n == "mel_generic") w.mel_generic = value != 0;
     else if (n == "mel_rank1") w.mel_rank1 = value != 0;
     else if (n == "mel_lds") w.mel_lds = value != 0;
+    else if (n == "mel_eng") w.mel_eng = value != 0;
     else if (n == "pa_sort") { if (value < 0 || value > 2) return -1; w.pa_sort = value; }
     else if (n == "host_profile") w.host_profile = value != 0;
     else return -1;                                       // (trem_traj / trem_cache / pipe shape the pool at creation: environment only)
@@ -2419,6 +2430,7 @@ int ow_test_pool_get_switch(const ow_pool* p, const char* name) {
     if (n == "mel_generic") return w.mel_generic;
     if (n == "mel_rank1") return w.mel_rank1;
     if (n == "mel_lds") return w.mel_lds;
+    if (n == "mel_eng") return w.mel_eng;
     if (n == "pa_sort") return w.pa_sort;
     if (n == "trem_traj") return p->traj ? 1 : 0;
     if (n == "trem_cache") return w.trem_cache;

@@ -205,11 +205,7 @@ __device__ inline void mel_col_solve(const OwConsts* __restrict__ K0, const MelC
 // Fold column COL of S into v_pred and into the S N_i sums (N_i rows: [0] = {2}, [1] = {2, 4, 5}, [2] = {4, 7, 8}).  Entries that are
 // structurally zero add +-0 in the reference and are left out (none of them in the S N_i columns 2, 4, 5, 7, 8 besides unknown 3).
 template <int COL>
-__device__ inline void mel_col_fold(const double b[12], const double rhs[12], double acc[12], double* __restrict__ sni) {
-    using Z = MelColNz<COL>;
-#pragma unroll
-    for (int i = 0; i < 12; ++i)
-        if (Z::nz(i)) acc[i] += b[i] * rhs[COL];
+__device__ inline void mel_col_fold_sni(const double b[12], double* __restrict__ sni) {
     if (COL == 2) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) { MCOL_SNI(0, i) = b[i] * PRE_N_I[0][2]; MCOL_SNI(1, i) = b[i] * PRE_N_I[1][2]; }
@@ -226,6 +222,14 @@ __device__ inline void mel_col_fold(const double b[12], const double rhs[12], do
 #pragma unroll
         for (int i = 0; i < 12; ++i) MCOL_SNI(2, i) = MCOL_SNI(2, i) + b[i] * PRE_N_I[2][8];
     }
+}
+template <int COL>
+__device__ inline void mel_col_fold(const double b[12], const double rhs[12], double acc[12], double* __restrict__ sni) {
+    using Z = MelColNz<COL>;
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+        if (Z::nz(i)) acc[i] += b[i] * rhs[COL];
+    mel_col_fold_sni<COL>(b, sni);
 }
 
 template <int COL>
@@ -308,18 +312,22 @@ __device__ __noinline__ void mel_col_generic(double pot, double alpha, double* _
 #undef GLU
 }
 
-// gen_preamp::process_sample (gen_preamp.rs:3399-3663) with the column-streamed rebuild above.  pot: the resistance the matrices are
+// gen_preamp::process_sample (gen_preamp.rs:3399-3663) with the column-streamed rebuild above, in three pieces so that the
+// lane = engine kernel (ow_melange_eng.h) can run the middle one once for both solver states.  pot: the resistance the matrices are
 // built for (the engine's main state, as in k_preamp_mel_lit).
-__device__ inline double mel_process_col(MelSt& st, double input_in, double pot, double alpha, const OwConsts* __restrict__ K0, double* __restrict__ sni,
-                                         bool force_generic, double* __restrict__ lu, size_t lu_ld, const double* nz, int nz_stride) {
+// (1) input clamp, denormal flush, BE cooldown, build_rhs (:3399-3468, 3041-3095)
+__device__ inline void mel_col_pre(MelSt& st, double input_in, double pot, double alpha, const OwConsts* __restrict__ K0, const double* nz, int nz_stride,
+                                   double rhs[12], double& input_out, bool& force_be_out) {
     const double input = isfinite(input_in) ? clampd(input_in, -100.0, 100.0) : 0.0;
 #pragma unroll
     for (int i = 0; i < 12; ++i) st.v[i] = st.v[i] + 1e-25 - 1e-25;
 #pragma unroll
     for (int i = 0; i < 3; ++i) st.ip[i] = st.ip[i] + 1e-25 - 1e-25;
-    const bool force_be = st.be_cooldown > 0u;
+    force_be_out = st.be_cooldown > 0u;
     if (st.be_cooldown > 0u) st.be_cooldown -= 1u;
-    double rhs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 15.0};     // RHS_CONST (gen_preamp.rs:760-773); build_rhs :3041-3095
+#pragma unroll
+    for (int i = 0; i < 11; ++i) rhs[i] = 0.0;                     // RHS_CONST (gen_preamp.rs:760-773); build_rhs :3041-3095
+    rhs[11] = 15.0;
     {
         const OwConsts* __restrict__ K = k_reload(K0);
         const double (*__restrict__ an)[12] = K->m_aneg0;
@@ -349,38 +357,11 @@ __device__ inline double mel_process_col(MelSt& st, double input_in, double pot,
     rhs[8] += PRE_N_I[2][8] * st.ip[2];
     rhs[0] += (input + st.input_prev) / PRE_INPUT_RESISTANCE;
     if (nz) nz_stamp(rhs, nz, nz_stride);
-    // ---- rebuild_matrices + v_pred = S rhs + S N_i, one unit column of S at a time
-    double v_pred[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) v_pred[i] = 0.0;
-    bool fast = !force_generic;
-    if (fast) {
-        MelColT T;
-        fast = mel_col_factor(K0, pot, alpha, T);
-        if (__builtin_expect(fast, 1)) {
-            mel_col_step<0>(K0, T, rhs, v_pred, sni);
-            mel_col_step<1>(K0, T, rhs, v_pred, sni);
-            mel_col_step<2>(K0, T, rhs, v_pred, sni);
-            mel_col_step<3>(K0, T, rhs, v_pred, sni);
-            mel_col_step<4>(K0, T, rhs, v_pred, sni);
-            mel_col_step<5>(K0, T, rhs, v_pred, sni);
-            mel_col_step<6>(K0, T, rhs, v_pred, sni);
-            mel_col_step<7>(K0, T, rhs, v_pred, sni);
-            mel_col_step<8>(K0, T, rhs, v_pred, sni);
-            mel_col_step<9>(K0, T, rhs, v_pred, sni);
-            mel_col_step<10>(K0, T, rhs, v_pred, sni);
-            mel_col_step<11>(K0, T, rhs, v_pred, sni);
-        }
-    }
-    if (__builtin_expect(!fast, 0)) {
-        MelColGen g;
-        for (int i = 0; i < 12; ++i) g.rhs[i] = rhs[i];
-        mel_col_generic(pot, alpha, lu, lu_ld, &g);
-        for (int i = 0; i < 12; ++i) v_pred[i] = g.acc[i];
-        for (int k = 0; k < 3; ++k) for (int i = 0; i < 12; ++i) MCOL_SNI(k, i) = g.sni[k][i];
-    }
-    // K = N_v (S N_i) (:2038-2056); N_v rows: [0] = {2}, [1] = {2, 5}, [2] = {4, 8}
-    double kk[3][3];
+    input_out = input;
+}
+
+// K = N_v (S N_i) from the lane's running sums (:2038-2056); N_v rows: [0] = {2}, [1] = {2, 5}, [2] = {4, 8}
+__device__ inline void mel_col_kernel(const double* __restrict__ sni, double kk[3][3]) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const double s2 = MCOL_SNI(j, 2), s4 = MCOL_SNI(j, 4), s5 = MCOL_SNI(j, 5), s8 = MCOL_SNI(j, 8);
@@ -388,6 +369,11 @@ __device__ inline double mel_process_col(MelSt& st, double input_in, double pot,
         kk[1][j] = PRE_N_V[1][2] * s2 + PRE_N_V[1][5] * s5;
         kk[2][j] = PRE_N_V[2][4] * s4 + PRE_N_V[2][8] * s8;
     }
+}
+
+// (3) Newton on the junctions, v = v_pred + (S N_i) i_nl, BE fallback, voltage-damp net, NaN reset, state update (:3478-3663)
+__device__ inline double mel_col_post(MelSt& st, double input, bool force_be, const double v_pred[12], const double kk[3][3], const double* __restrict__ sni,
+                                      const double* nz, int nz_stride) {
     const double p[3] = {-v_pred[2], v_pred[2] - v_pred[5], v_pred[4] - v_pred[8]};
     double i_nl[3];
     uint32_t last_it = mel_solve_nl(p, kk, st.ip, st.ipp, i_nl);
@@ -452,6 +438,46 @@ __device__ inline double mel_process_col(MelSt& st, double input_in, double pot,
     st.input_prev = input;
     const double raw = isfinite(vn[10]) ? vn[10] : 0.0;
     return raw * 1.0;
+}
+
+__device__ inline double mel_process_col(MelSt& st, double input_in, double pot, double alpha, const OwConsts* __restrict__ K0, double* __restrict__ sni,
+                                         bool force_generic, double* __restrict__ lu, size_t lu_ld, const double* nz, int nz_stride) {
+    double rhs[12], input;
+    bool force_be;
+    mel_col_pre(st, input_in, pot, alpha, K0, nz, nz_stride, rhs, input, force_be);
+    // ---- (2) rebuild_matrices + v_pred = S rhs + S N_i, one unit column of S at a time
+    double v_pred[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v_pred[i] = 0.0;
+    bool fast = !force_generic;
+    if (fast) {
+        MelColT T;
+        fast = mel_col_factor(K0, pot, alpha, T);
+        if (__builtin_expect(fast, 1)) {
+            mel_col_step<0>(K0, T, rhs, v_pred, sni);
+            mel_col_step<1>(K0, T, rhs, v_pred, sni);
+            mel_col_step<2>(K0, T, rhs, v_pred, sni);
+            mel_col_step<3>(K0, T, rhs, v_pred, sni);
+            mel_col_step<4>(K0, T, rhs, v_pred, sni);
+            mel_col_step<5>(K0, T, rhs, v_pred, sni);
+            mel_col_step<6>(K0, T, rhs, v_pred, sni);
+            mel_col_step<7>(K0, T, rhs, v_pred, sni);
+            mel_col_step<8>(K0, T, rhs, v_pred, sni);
+            mel_col_step<9>(K0, T, rhs, v_pred, sni);
+            mel_col_step<10>(K0, T, rhs, v_pred, sni);
+            mel_col_step<11>(K0, T, rhs, v_pred, sni);
+        }
+    }
+    if (__builtin_expect(!fast, 0)) {
+        MelColGen g;
+        for (int i = 0; i < 12; ++i) g.rhs[i] = rhs[i];
+        mel_col_generic(pot, alpha, lu, lu_ld, &g);
+        for (int i = 0; i < 12; ++i) v_pred[i] = g.acc[i];
+        for (int k = 0; k < 3; ++k) for (int i = 0; i < 12; ++i) MCOL_SNI(k, i) = g.sni[k][i];
+    }
+    double kk[3][3];
+    mel_col_kernel(sni, kk);
+    return mel_col_post(st, input, force_be, v_pred, kk, sni, nz, nz_stride);
 }
 
 // Preamp stream, literal rebuild, column-streamed.  Same interface as k_preamp_mel_lit; lu_scratch: [144][2 * ceil(I / 32) * 32] doubles,

@@ -754,6 +754,49 @@ def test_melange_literal_fast_path_is_the_generic_rebuild_bit_for_bit(hiplib, mo
         assert np.max(np.abs(res["fast"][1])) > 1e-3
 
 
+def test_melange_lane_engine_kernel_is_bit_identical(hiplib, monkeypatch):
+    """ow_melange_eng.h (one lane per engine: factorisation, unit columns and S N_i once for both solver states, the per-state parts as
+    a rolled loop) against k_preamp_mel_col (one lane per state): the same operations on the same operands per state, so preamp and
+    output streams are bit-identical -- 70 engines (two workgroups of the lane = engine kernel, a ragged tail in both), thermal noise on
+    some, depth ramps, a reset and a re-rate mid-run, the generic rebuild (OW_MEL_GENERIC=1) through both kernels as well."""
+    import openwurli_amd as ow
+    sr, n = 48000.0, 70
+    res = {}
+    for mode in ("col", "eng", "eng_generic"):
+        monkeypatch.setenv("OW_MEL_ENG", "0" if mode == "col" else "1")
+        if mode == "eng_generic":
+            monkeypatch.setenv("OW_MEL_GENERIC", "1")
+        else:
+            monkeypatch.delenv("OW_MEL_GENERIC", raising=False)
+        g = ow.EnginePool(sr, n, preamp_kind=1)
+        assert g.get_switch("mel_eng") == (0 if mode == "col" else 1)
+        g.set_sample_rate(sr)
+        g.stagger_tremolo(23)
+        for k in range(n):
+            g[k].set_tremolo_depth((1.0, 0.5, 0.0, 0.8)[k % 4]); g[k].set_volume(0.3 + 0.01 * (k % 7))
+            if k % 5 == 0:
+                g[k].set_noise_seed(1000 + k); g[k].set_noise_gain(3.0); g[k].set_noise_enabled(True)
+            for m in (40 + (3 * k) % 40, 60 + k % 12, 84):
+                g[k].note_on(m, 0.5 + 0.05 * (k % 9))
+        outs, pres = [], []
+        for b in range(7):
+            if b == 2:
+                for k in range(0, n, 3):
+                    g[k].set_tremolo_depth(0.1 + 0.9 * ((k // 3) % 2))
+            if b == 4:
+                g[5].reset(); g[5].note_on(64, 0.9); g[69].reset(); g[69].note_on(50, 0.7)
+            length = (256, 100, 256, 1, 256, 333, 64)[b]
+            outs.append(g.render(length)); pres.append(g.preamp_out(2 * length))
+        d = [g[k].diag().preamp_nan_resets for k in (0, 5, 69)]
+        g.close()
+        res[mode] = (np.concatenate(outs, axis=1), np.concatenate(pres, axis=1), d)
+    for mode in ("eng", "eng_generic"):
+        assert np.array_equal(res[mode][1], res["col"][1]), mode
+        assert np.array_equal(res[mode][0], res["col"][0]), mode
+        assert res[mode][2] == res["col"][2]
+    assert np.max(np.abs(res["col"][1])) > 1e-3
+
+
 def test_melange_thermal_noise_parity(hiplib, oracle):
     """set_noise_enabled / set_noise_gain on the melange preamp (engine.rs:394-400; gen_preamp.rs:3433-3461): the 11 resistor
     noise currents are integer-exact xoshiro256++ streams shaped by Marsaglia polar (log, sqrt), so with a fixed seed
