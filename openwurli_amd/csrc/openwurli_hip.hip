@@ -191,6 +191,7 @@ struct Switches {
     bool mel_rank1 = false, mel_lds = false, mel_generic = false;
     int mel_eng = 0;                           // OW_MEL_ENG=1: lane = engine melange kernel (k_preamp_mel_eng; measured -3 % at 131 072 engines, 2x slower at 65 536)
     int pa_sort = 1;                           // OW_PA_SORT: 0 never, 1 when the block exceeds the chip, 2 always
+    int eout_attn = -1;                        // OW_EOUT_ATTN=0/1: status summary instead of the status blocks (k_eout_attention); -1: ranges of >= 8 192 engines
     int pipe = 0;                              // OW_PIPE=n stages
     bool pipe_overlap = false;
     bool host_profile = false;
@@ -208,6 +209,7 @@ struct Switches {
         w.trem_traj = flag("OW_TREM_TRAJ", 1) != 0;
         w.mel_rank1 = flag("OW_MEL_RANK1", 0) == 1; w.mel_lds = flag("OW_MEL_LDS", 0) == 1; w.mel_generic = flag("OW_MEL_GENERIC", 0) == 1;
         w.mel_eng = flag("OW_MEL_ENG", 0) == 1;
+        w.eout_attn = flag("OW_EOUT_ATTN", -1); if (w.eout_attn > 1 || w.eout_attn < -1) w.eout_attn = -1;
         w.pa_sort = flag("OW_PA_SORT", 1); if (w.pa_sort < 0 || w.pa_sort > 2) w.pa_sort = 1;
         if (const char* e = std::getenv("OW_PIPE")) { const int v = std::atoi(e); w.pipe = (v >= 1 && v <= 8) ? v : 0; }
         w.pipe_overlap = flag("OW_PIPE_OVERLAP", 0) == 1;
@@ -260,14 +262,16 @@ struct ow_engine {
     uint64_t main_mask = 0, steal_mask = 0;
     double sr = 0.0;            // host sample rate (steal crossfade length, engine.rs:318)
     uint8_t* dirty = nullptr;   // -> pool->dirty[index]: engine has pending ops / setter targets / changed masks
+    uint8_t* dirty_any = nullptr;   // -> pool->dirty_any: some engine of the pool is dirty (lets a steady block skip the per-engine scans)
+    void mark() { if (dirty) { *dirty = 1; __atomic_store_n(dirty_any, (uint8_t)1, __ATOMIC_RELAXED); } }
     void sync_masks(int s) {
         const Slot& sl = slots[s];
         const uint64_t b = 1ull << s;
         if (sl.has_voice && !(st_mask[OW_VOICE_FREE] & b)) main_mask |= b; else main_mask &= ~b;
         if (sl.has_steal) steal_mask |= b; else steal_mask &= ~b;
-        if (dirty) *dirty = 1;
+        mark();
     }
-    void touch() { if (dirty) *dirty = 1; }
+    void touch() { mark(); }
 };
 
 struct ow_pool {
@@ -314,6 +318,19 @@ struct ow_pool {
     size_t ops_cap = 0;
     OwEngineArgs* h_args = nullptr;   // pinned
     OwEngineOut* h_eout = nullptr;    // pinned
+    // Status summary of a block (big pools): k_eout_attention marks the engines whose status block the host has to look at (a voice
+    // fell silent, a steal fade is running, a guard fired, the transient flag changed); the host copies one bit per engine and fetches
+    // the status blocks themselves only when a bit is set -- a steady block of 131 072 engines then costs the host 16 KB instead of a
+    // 5 MB copy and a 131 072-entry scan.
+    uint64_t* d_attn = nullptr;       // [ceil(I / 64)]
+    uint64_t* h_attn = nullptr;       // pinned
+    uint8_t* d_prev_tr = nullptr;     // [I] transient flag the host knows (p->transient)
+    bool attn_pending = false;        // the block just rendered left its summary in h_attn instead of its status blocks in h_eout
+    bool attn_resync = true;          // d_prev_tr has to be refreshed from p->transient before the next summary
+    bool eout_all_live = true;        // a block went through the status-block path: any h_eout entry may hold something
+    std::vector<uint32_t> eout_live;  // engines whose h_eout entry holds something other than "nothing happened" (cleared next block)
+    uint8_t dirty_any = 1;            // some dirty[] entry may be set (engines set it; a whole-pool render clears it)
+    bool any_cache_valid = false, any_main_c = false, any_steal_c = false;   // any_main / any_steal of the last whole-pool render
     OwEngineOut* d_eout_packed = nullptr;   // [I] status blocks of a list of engines, packed (voice-sum NaN guard's second pass)
     OwEngineOut* h_eout_packed = nullptr;   // pinned
     OwOp* h_ops = nullptr;            // pinned
@@ -998,6 +1015,7 @@ size_t Workers::host_threads() { return std::min<size_t>(effective_cpus(), OW_MA
 // reference (ow_melange_col.h).  OW_MEL_RANK1=1 selects the rank-one (Sherman-Morrison) kernel instead: mathematically the same, but
 // without the LU's rounding noise, i.e. up to 1.8e-7 V away from the reference while R_ldr moves fast (DESIGN.md deviation 6);
 // OW_MEL_LDS=1 the round-2 literal kernel (S of every engine in LDS); OW_MEL_GENERIC=1 the literal kernels without their fast path.
+static inline bool eout_attention(const ow_pool* p, int ne) { return p->d_attn && (p->sw.eout_attn < 0 ? ne >= 8192 : p->sw.eout_attn != 0); }
 static inline bool melange_rank_one(const ow_pool* p) { return p->sw.mel_rank1; }
 static inline bool melange_lds_matrix(const ow_pool* p) { return p->sw.mel_lds; }
 static inline bool melange_generic_only(const ow_pool* p) { return p->sw.mel_generic; }
@@ -1150,8 +1168,11 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
     // uploaded args; a steady-state step of a large pool does no per-engine host work here)
     // Large pools split the range over host threads: slice t counts its pending ops, a prefix sum places the slices in h_ops,
     // then every slice packs its own engines (a 65536-engine re-strike moves ~8 M ops; one thread took ~100 ms for it).
+    // A steady block of the whole pool -- no engine touched since the last one -- skips the per-engine scans below (0.2 ms at 131 072)
+    const bool untouched = whole && !__atomic_load_n(&p->dirty_any, __ATOMIC_RELAXED) && !p->args_stale && p->any_cache_valid;
+    if (whole) __atomic_store_n(&p->dirty_any, (uint8_t)0, __ATOMIC_RELAXED);   // engines touched from here on belong to the next block
     size_t n_dirty = 0;
-    for (int k = 0; k < ne; ++k) n_dirty += p->dirty[e0 + k];     // dirty[] holds 0/1
+    if (!untouched) for (int k = 0; k < ne; ++k) n_dirty += p->dirty[e0 + k];     // dirty[] holds 0/1
     size_t T = (n_dirty >= 4096) ? std::min<size_t>(effective_cpus(), 32) : 1;
     const int per = (int)((ne + T - 1) / T);
     size_t cnt[OW_MAX_SLICES + 1] = {0};
@@ -1166,7 +1187,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         }
         cnt[t + 1] = c; dirty_t[t] = d;
     };
-    Workers::get().each(T, count_slice);
+    if (!untouched) Workers::get().each(T, count_slice);
     bool any_dirty = false;
     for (size_t t = 0; t < T; ++t) { any_dirty = any_dirty || dirty_t[t]; cnt[t + 1] += cnt[t]; }
     const size_t n_ops = cnt[T];
@@ -1200,8 +1221,12 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         };
         Workers::get().each(T, pack_slice);
     }
-    bool any_main = false, any_steal = false;
-    for (int k = 0; k < ne; ++k) { any_main |= p->h_args[e0 + k].main_mask != 0; any_steal |= p->h_args[e0 + k].steal_mask != 0; }
+    bool any_main = p->any_main_c, any_steal = p->any_steal_c;
+    if (!untouched) {
+        any_main = false; any_steal = false;
+        for (int k = 0; k < ne; ++k) { any_main |= p->h_args[e0 + k].main_mask != 0; any_steal |= p->h_args[e0 + k].steal_mask != 0; }
+        if (whole) { p->any_main_c = any_main; p->any_steal_c = any_steal; p->any_cache_valid = true; }
+    }
     // args carry one-shot fields (ops, setter targets): upload when anything changed, and once more afterwards to clear them
     if (any_dirty || p->args_stale) {
         HIP_OK(hipMemcpyAsync(p->d_args + e0, p->h_args + e0, sizeof(OwEngineArgs) * ne, hipMemcpyHostToDevice, st));
@@ -1329,7 +1354,19 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
     }
     p->last_n_os = n_os;
     HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(p->h_eout + e0, p->d_eout + e0, sizeof(OwEngineOut) * ne, hipMemcpyDeviceToHost, st));
+    if (eout_attention(p, ne)) {
+        if (p->attn_resync) {
+            HIP_OK(hipMemcpyAsync(p->d_prev_tr, p->transient.data(), p->I, hipMemcpyHostToDevice, st));
+            p->attn_resync = false;
+        }
+        owdev::k_eout_attention<<<dim3((ne + 255) / 256), dim3(256), 0, st>>>(p->d_eout, p->d_args, p->d_prev_tr, e0, ne, p->d_attn);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpyAsync(p->h_attn, p->d_attn, sizeof(uint64_t) * ((ne + 63) / 64), hipMemcpyDeviceToHost, st));
+        p->attn_pending = true;
+    } else {
+        HIP_OK(hipMemcpyAsync(p->h_eout + e0, p->d_eout + e0, sizeof(OwEngineOut) * ne, hipMemcpyDeviceToHost, st));
+        p->attn_pending = false;
+    }
 }
 
 // host bookkeeping of ONE engine after a block: steal-fade countdown (engine.rs:490-493), NaN-guard frees (engine.rs:499-521,
@@ -1425,27 +1462,65 @@ void guard_second_pass(ow_pool* p, const uint32_t* engs, size_t n_eng, size_t le
 // host bookkeeping after the block has been rendered (needs h_eout; call after stream sync)
 void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
     const uint32_t l32 = (uint32_t)std::min<size_t>(len, 0xFFFFFFFFull);
+    // what one engine's status block asks of the host; returns bit 0 = the voice lists changed, bit 1 = misdispatch, bit 2 = voice-sum guard
+    auto one = [&](int e) -> uint8_t {
+        const OwEngineOut& o = p->h_eout[e];
+        const OwEngineArgs& a = p->h_args[e];
+        uint8_t r = 0;
+        if (o.transient == 2u) r |= 2;
+        const uint8_t tr = o.transient != 0u;
+        if (tr != p->transient[e]) { p->transient[e] = tr; r |= 1; }
+        // fast path on the contiguous status/args arrays: nothing to book-keep for this engine
+        if (!a.steal_mask && !(o.silent_mask & a.main_mask) && !o.sum_nonfinite && !o.out_nonfinite) return r;
+        if (o.sum_nonfinite) r |= 4;
+        engine_post_render(p->engines[e], l32, o);
+        return r;
+    };
+    auto second_pass = [&] {   // voice-sum NaN guard fired somewhere: the reference's second render pass for those engines
+        uint32_t* engs = p->h_op_engines;     // pinned scratch of I entries, free between renders
+        size_t n = 0;
+        for (int k = 0; k < ne; ++k) if (p->h_eout[e0 + k].sum_nonfinite) engs[n++] = (uint32_t)(e0 + k);
+        guard_second_pass(p, engs, n, len);
+    };
+    if (p->attn_pending) {
+        // the block left one bit per engine (k_eout_attention): nothing set = nothing to do, the usual case of a big pool
+        p->attn_pending = false;
+        const int words = (ne + 63) / 64;
+        size_t count = 0;
+        for (int w = 0; w < words; ++w) count += (size_t)__builtin_popcountll(p->h_attn[w]);
+        if (p->eout_all_live) { std::memset(p->h_eout, 0, sizeof(OwEngineOut) * p->I); p->eout_all_live = false; }
+        else for (uint32_t e : p->eout_live) std::memset(&p->h_eout[e], 0, sizeof(OwEngineOut));
+        p->eout_live.clear();
+        if (count == 0) return;
+        HIP_OK(hipMemcpyAsync(p->h_eout + e0, p->d_eout + e0, sizeof(OwEngineOut) * ne, hipMemcpyDeviceToHost, p->stream));
+        HIP_OK(hipStreamSynchronize(p->stream));
+        if (count * 8 <= (size_t)ne) {
+            uint8_t r = 0;
+            for (int w = 0; w < words; ++w)
+                for (uint64_t m = p->h_attn[w]; m; m &= m - 1) {
+                    const int e = e0 + w * 64 + __builtin_ctzll(m);
+                    r |= one(e);
+                    p->eout_live.push_back((uint32_t)e);
+                }
+            if (r & 1) p->lists_valid = false;
+            if (r & 2) set_err("voice dispatch: an engine in a transient phase was sent to the steady kernel");
+            if (r & 4) { second_pass(); p->attn_resync = true; }
+            return;
+        }
+        p->eout_all_live = true;               // many engines (a whole-pool re-strike): the sliced scan below
+    } else if (p->d_attn) {
+        p->eout_all_live = true;
+    }
     // engines are independent: after a whole-pool re-strike every engine has 64 steal fades to count down and 64 masks to
     // update (40 ms on one thread for 65 536 engines), so large ranges are cut into slices like the MIDI and op packing are
     const size_t T = ne >= 16384 ? std::min<size_t>(effective_cpus(), 32) : 1;
     const int per = (int)((ne + T - 1) / T);
-    uint8_t lists_changed[OW_MAX_SLICES] = {0}, misdispatch[OW_MAX_SLICES] = {0}, guard_t[OW_MAX_SLICES] = {0};
-    bool any_guard = false;
+    uint8_t res[OW_MAX_SLICES] = {0};
     auto slice = [&](size_t t) {
         const int k1 = std::min(ne, (int)(t + 1) * per);
-        uint8_t changed = 0, bad = 0, grd = 0;
-        for (int k = (int)t * per; k < k1; ++k) {
-            const OwEngineOut& o = p->h_eout[e0 + k];
-            const OwEngineArgs& a = p->h_args[e0 + k];
-            if (o.transient == 2u) bad = 1;
-            const uint8_t tr = o.transient != 0u;
-            if (tr != p->transient[e0 + k]) { p->transient[e0 + k] = tr; changed = 1; }
-            // fast path on the contiguous status/args arrays: nothing to book-keep for this engine
-            if (!a.steal_mask && !(o.silent_mask & a.main_mask) && !o.sum_nonfinite && !o.out_nonfinite) continue;
-            if (o.sum_nonfinite) grd = 1;
-            engine_post_render(p->engines[e0 + k], l32, o);
-        }
-        lists_changed[t] = changed; misdispatch[t] = bad; guard_t[t] = grd;
+        uint8_t r = 0;
+        for (int k = (int)t * per; k < k1; ++k) r |= one(e0 + k);
+        res[t] = r;
     };
     // a steady block of a big pool has (almost) nothing to do per engine, which is not worth starting threads for (~0.1 ms): estimate
     // the engines with steal fades / silent voices from every 64th one and go parallel from ~8 000 of them
@@ -1459,17 +1534,11 @@ void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
     } else {
         Workers::get().each(T, slice);
     }
-    for (size_t t = 0; t < T; ++t) {
-        if (lists_changed[t]) p->lists_valid = false;
-        if (misdispatch[t]) set_err("voice dispatch: an engine in a transient phase was sent to the steady kernel");
-        any_guard = any_guard || guard_t[t];
-    }
-    if (any_guard) {      // voice-sum NaN guard fired somewhere: the reference's second render pass for those engines
-        uint32_t* engs = p->h_op_engines;     // pinned scratch of I entries, free between renders
-        size_t n = 0;
-        for (int k = 0; k < ne; ++k) if (p->h_eout[e0 + k].sum_nonfinite) engs[n++] = (uint32_t)(e0 + k);
-        guard_second_pass(p, engs, n, len);
-    }
+    uint8_t r = 0;
+    for (size_t t = 0; t < T; ++t) r |= res[t];
+    if (r & 1) { p->lists_valid = false; if (p->d_prev_tr) p->attn_resync = true; }    // p->transient moved without the device's copy
+    if (r & 2) set_err("voice dispatch: an engine in a transient phase was sent to the steady kernel");
+    if (r & 4) { second_pass(); if (p->d_prev_tr) p->attn_resync = true; }
 }
 
 void collect_profile(ow_pool* p) {
@@ -1583,6 +1652,12 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     HIP_OK(hipHostMalloc(&p->h_eout, sizeof(OwEngineOut) * n_engines));
     HIP_OK(hipMalloc(&p->d_eout_packed, sizeof(OwEngineOut) * n_engines));
     HIP_OK(hipHostMalloc(&p->h_eout_packed, sizeof(OwEngineOut) * n_engines));
+    if (n_engines >= 64) {      // status summary of big ranges (k_eout_attention)
+        HIP_OK(hipMalloc(&p->d_attn, sizeof(uint64_t) * ((n_engines + 63) / 64)));
+        HIP_OK(hipHostMalloc(&p->h_attn, sizeof(uint64_t) * ((n_engines + 63) / 64)));
+        HIP_OK(hipMalloc(&p->d_prev_tr, n_engines));
+        HIP_OK(hipMemset(p->d_prev_tr, 0, n_engines));
+    }
     for (ow_pool::VoiceList* vl : {&p->vl_steady, &p->vl_general, &p->vl_steal}) {   // worst case: one block per engine
         HIP_OK(hipMalloc(&vl->d, sizeof(uint32_t) * 64 * n_engines));
         HIP_OK(hipHostMalloc(&vl->h, sizeof(uint32_t) * 64 * n_engines));
@@ -1642,7 +1717,7 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
         ow_engine* en = new ow_engine();
         en->pool = p;
         en->index = i;
-        en->dirty = &p->dirty[i];
+        en->dirty = &p->dirty[i]; en->dirty_any = &p->dirty_any;
         en->sr = sample_rate;
         // Room for a whole-keyboard re-strike (damper + move-to-steal + note-on per key) from the start: growing 65 536 op lists
         // from 64 to 192 entries inside the first re-strike cost 180 ms of reallocation and page faults on the MIDI threads
@@ -1709,6 +1784,9 @@ void pool_destroy(ow_pool* p) {
     hipHostFree(p->h_args); hipHostFree(p->h_eout);
     if (p->d_eout_packed) hipFree(p->d_eout_packed);
     if (p->h_eout_packed) hipHostFree(p->h_eout_packed);
+    if (p->d_attn) hipFree(p->d_attn);
+    if (p->h_attn) hipHostFree(p->h_attn);
+    if (p->d_prev_tr) hipFree(p->d_prev_tr);
     for (auto& e : p->ev) if (e) hipEventDestroy(e);
     for (int k = 1; k < OW_MAX_STAGES; ++k) if (p->pipe_stream[k]) { hipStreamSynchronize(p->pipe_stream[k]); hipStreamDestroy(p->pipe_stream[k]); }
     if (p->ev_ready) hipEventDestroy(p->ev_ready);
@@ -2414,6 +2492,7 @@ int ow_test_pool_set_switch(ow_pool* p, const char* name, int value) {
     else if (n == "mel_rank1") w.mel_rank1 = value != 0;
     else if (n == "mel_lds") w.mel_lds = value != 0;
     else if (n == "mel_eng") w.mel_eng = value != 0;
+    else if (n == "eout_attn") w.eout_attn = value < 0 ? -1 : (value != 0);
     else if (n == "pa_sort") { if (value < 0 || value > 2) return -1; w.pa_sort = value; }
     else if (n == "host_profile") w.host_profile = value != 0;
     else return -1;                                       // (trem_traj / trem_cache / pipe shape the pool at creation: environment only)
@@ -2431,6 +2510,7 @@ int ow_test_pool_get_switch(const ow_pool* p, const char* name) {
     if (n == "mel_rank1") return w.mel_rank1;
     if (n == "mel_lds") return w.mel_lds;
     if (n == "mel_eng") return w.mel_eng;
+    if (n == "eout_attn") return w.eout_attn;
     if (n == "pa_sort") return w.pa_sort;
     if (n == "trem_traj") return p->traj ? 1 : 0;
     if (n == "trem_cache") return w.trem_cache;

@@ -520,6 +520,25 @@ __global__ void k_eout_gather_list(const OwEngineOut* __restrict__ eout, const u
     if (i < n) packed[i] = eout[engs[i]];
 }
 
+// One bit per engine of [e0, e0 + ne): does the host have to look at the engine's status block after this block?  (a voice of the
+// engine fell silent, a steal fade is running, a NaN guard fired, the transient flag is not the one the host knows, a misdispatch.)
+// prev_tr mirrors the host's p->transient; the kernel moves it along.  attn[k / 64] = the flags of engines e0 + 64 (k / 64) + 0..63.
+__global__ __launch_bounds__(256) void k_eout_attention(const OwEngineOut* __restrict__ eout, const OwEngineArgs* __restrict__ args,
+                                                        uint8_t* __restrict__ prev_tr, int e0, int ne, uint64_t* __restrict__ attn) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    bool flag = false;
+    if (k < ne) {
+        const int e = e0 + k;
+        const OwEngineOut o = eout[e];
+        const uint8_t tr = o.transient != 0u ? 1 : 0;
+        flag = args[e].steal_mask != 0ull || (o.silent_mask & args[e].main_mask) != 0ull || o.bad_main != 0ull || o.bad_steal != 0ull ||
+               o.sum_nonfinite != 0u || o.out_nonfinite != 0u || o.transient == 2u || tr != prev_tr[e];
+        prev_tr[e] = tr;
+    }
+    const uint64_t b = __builtin_amdgcn_ballot_w64(flag);
+    if ((threadIdx.x & 63) == 0 && k < ne) attn[k >> 6] = b;
+}
+
 // ------------------------------------------------------------------ where an engine's CdS resistance R[n] comes from
 // Tremolo::process takes no audio and no depth into the oscillator, the LED envelope or r_ldr (tremolo.rs:121-146; depth only enters
 // shunt_impedance, :152-167), and new() / reset() start from the same settled state (:83-102, :192-216): r_ldr[t] is ONE deterministic
