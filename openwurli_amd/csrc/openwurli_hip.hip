@@ -325,6 +325,7 @@ struct ow_pool {
     uint64_t* d_attn = nullptr;       // [ceil(I / 64)]
     uint64_t* h_attn = nullptr;       // pinned
     uint8_t* d_prev_tr = nullptr;     // [I] transient flag the host knows (p->transient)
+    uint8_t* h_prev_tr = nullptr;     // pinned staging of p->transient for a resync
     bool attn_pending = false;        // the block just rendered left its summary in h_attn instead of its status blocks in h_eout
     bool attn_resync = true;          // d_prev_tr has to be refreshed from p->transient before the next summary
     bool eout_all_live = true;        // a block went through the status-block path: any h_eout entry may hold something
@@ -1356,7 +1357,8 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
     HIP_OK(hipGetLastError());
     if (eout_attention(p, ne)) {
         if (p->attn_resync) {
-            HIP_OK(hipMemcpyAsync(p->d_prev_tr, p->transient.data(), p->I, hipMemcpyHostToDevice, st));
+            std::memcpy(p->h_prev_tr, p->transient.data(), p->I);
+            HIP_OK(hipMemcpyAsync(p->d_prev_tr, p->h_prev_tr, p->I, hipMemcpyHostToDevice, st));
             p->attn_resync = false;
         }
         owdev::k_eout_attention<<<dim3((ne + 255) / 256), dim3(256), 0, st>>>(p->d_eout, p->d_args, p->d_prev_tr, e0, ne, p->d_attn);
@@ -1657,6 +1659,8 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
         HIP_OK(hipHostMalloc(&p->h_attn, sizeof(uint64_t) * ((n_engines + 63) / 64)));
         HIP_OK(hipMalloc(&p->d_prev_tr, n_engines));
         HIP_OK(hipMemset(p->d_prev_tr, 0, n_engines));
+        HIP_OK(hipHostMalloc(&p->h_prev_tr, n_engines));
+        p->eout_live.reserve(n_engines / 8 + 64);       // the summary path lists at most ne / 8 engines: nothing grows on the render path
     }
     for (ow_pool::VoiceList* vl : {&p->vl_steady, &p->vl_general, &p->vl_steal}) {   // worst case: one block per engine
         HIP_OK(hipMalloc(&vl->d, sizeof(uint32_t) * 64 * n_engines));
@@ -1787,6 +1791,7 @@ void pool_destroy(ow_pool* p) {
     if (p->d_attn) hipFree(p->d_attn);
     if (p->h_attn) hipHostFree(p->h_attn);
     if (p->d_prev_tr) hipFree(p->d_prev_tr);
+    if (p->h_prev_tr) hipHostFree(p->h_prev_tr);
     for (auto& e : p->ev) if (e) hipEventDestroy(e);
     for (int k = 1; k < OW_MAX_STAGES; ++k) if (p->pipe_stream[k]) { hipStreamSynchronize(p->pipe_stream[k]); hipStreamDestroy(p->pipe_stream[k]); }
     if (p->ev_ready) hipEventDestroy(p->ev_ready);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Register / LDS / scratch use of every gfx950 kernel of the library (compiler view).  usage: tools/kernel_resources.sh [filter]
 cd "$(dirname "$0")/.."
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value -Wno-macro-redefined ${OW_HIPCC_EXTRA} \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value -Wno-macro-redefined ${OW_SCHED--mllvm -amdgpu-sched-strategy=max-memory-clause} ${OW_HIPCC_EXTRA} \
   -Rpass-analysis=kernel-resource-usage --cuda-device-only -c -o /dev/null openwurli_amd/csrc/openwurli_hip.hip 2>&1 |
 python3 -c '
 import re,sys
