@@ -190,6 +190,7 @@ struct Switches {
     bool trem_traj = true;                     // OW_TREM_TRAJ=0: no shared trajectory, one oscillator per phase group (rounds 1-3)
     bool mel_rank1 = false, mel_lds = false, mel_generic = false;
     int mel_eng = 0;                           // OW_MEL_ENG=1: lane = engine melange kernel (k_preamp_mel_eng; measured -3 % at 131 072 engines, 2x slower at 65 536)
+    bool voice_skew = true;                    // OW_VOICE_SKEW=0: the steady voice kernel without skewed lane clocks (one jitter grid per wavefront assumed)
     int pa_sort = 1;                           // OW_PA_SORT: 0 never, 1 when the block exceeds the chip, 2 always
     int eout_attn = -1;                        // OW_EOUT_ATTN=0/1: status summary instead of the status blocks (k_eout_attention); -1: ranges of >= 8 192 engines
     int pipe = 0;                              // OW_PIPE=n stages
@@ -210,6 +211,7 @@ struct Switches {
         w.mel_rank1 = flag("OW_MEL_RANK1", 0) == 1; w.mel_lds = flag("OW_MEL_LDS", 0) == 1; w.mel_generic = flag("OW_MEL_GENERIC", 0) == 1;
         w.mel_eng = flag("OW_MEL_ENG", 0) == 1;
         w.eout_attn = flag("OW_EOUT_ATTN", -1); if (w.eout_attn > 1 || w.eout_attn < -1) w.eout_attn = -1;
+        w.voice_skew = flag("OW_VOICE_SKEW", 1) != 0;
         w.pa_sort = flag("OW_PA_SORT", 1); if (w.pa_sort < 0 || w.pa_sort > 2) w.pa_sort = 1;
         if (const char* e = std::getenv("OW_PIPE")) { const int v = std::atoi(e); w.pipe = (v >= 1 && v <= 8) ? v : 0; }
         w.pipe_overlap = flag("OW_PIPE_OVERLAP", 0) == 1;
@@ -324,6 +326,9 @@ struct ow_pool {
     // fell silent, a steal fade is running, a guard fired, the transient flag changed); the host copies one bit per engine and fetches
     // the status blocks themselves only when a bit is set -- a steady block of 131 072 engines then costs the host 16 KB instead of a
     // 5 MB copy and a 131 072-entry scan.
+    uint32_t* d_skew_seen = nullptr;  // k_voice_steady: some wavefront of the launch held voices on more than one 16-sample jitter grid
+    uint32_t* h_skew_seen = nullptr;  // pinned
+    bool skew_next = false, skew_pending = false;   // variant of the next steady launch; a report is on its way
     uint64_t* d_attn = nullptr;       // [ceil(I / 64)]
     uint64_t* h_attn = nullptr;       // pinned
     uint8_t* d_prev_tr = nullptr;     // [I] transient flag the host knows (p->transient)
@@ -1256,6 +1261,8 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
     const int NP = voices ? std::min(pipeline_stages(p, ne), p->slice_T) : 1;
     const bool overlap = pipeline_overlap(p);
     p->last_np = NP;
+    bool steady_launched = false;
+    if (voices && p->vl_steady.n_blocks) HIP_OK(hipMemsetAsync(p->d_skew_seen, 0, sizeof(uint32_t), st));
     if (NP > 1) HIP_OK(hipEventRecord(p->ev_ready, st));      // args, ops and voice lists are in place
     const bool tabs = (size_t)p->vl_general.n_blocks * 4 < (size_t)ne;   // sparse general list (played input): tabulated phase gains
     for (int k = 0; k < NP; ++k) {
@@ -1274,7 +1281,14 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
             const ow_pool::SliceStart& a1 = p->slice_start[NP == 1 ? p->slice_T : t1];
             const unsigned bs = (a1.s - a0.s) / 64, bg = (a1.g - a0.g) / 64, bt = (a1.t - a0.t) / 64;
             if (bs)
-                owdev::k_voice_steady<<<dim3(bs), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_steady.d + a0.s, p->d_sum, p->d_eout, I, L, Lcap);
+                {
+                // voices on more than one jitter grid in some wavefront of the previous steady launch: the skewed variant (same samples)
+                if (p->sw.voice_skew && p->skew_next)
+                    owdev::k_voice_steady<true><<<dim3(bs), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_steady.d + a0.s, p->d_sum, p->d_eout, I, L, Lcap, p->d_skew_seen);
+                else
+                    owdev::k_voice_steady<false><<<dim3(bs), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_steady.d + a0.s, p->d_sum, p->d_eout, I, L, Lcap, p->d_skew_seen);
+                steady_launched = true;
+            }
             if (bg) {
                 if (tabs) owdev::k_voice<true><<<dim3(bg), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_general.d + a0.g, p->d_sum, p->d_eout, I, L, Lcap, 0);
                 else owdev::k_voice<false><<<dim3(bg), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_general.d + a0.g, p->d_sum, p->d_eout, I, L, Lcap, 0);
@@ -1357,6 +1371,10 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
     }
     p->last_n_os = n_os;
     HIP_OK(hipGetLastError());
+    if (steady_launched) {
+        HIP_OK(hipMemcpyAsync(p->h_skew_seen, p->d_skew_seen, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        p->skew_pending = true;
+    }
     if (eout_attention(p, ne)) {
         if (p->attn_resync) {
             std::memcpy(p->h_prev_tr, p->transient.data(), p->I);
@@ -1465,6 +1483,7 @@ void guard_second_pass(ow_pool* p, const uint32_t* engs, size_t n_eng, size_t le
 
 // host bookkeeping after the block has been rendered (needs h_eout; call after stream sync)
 void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
+    if (p->skew_pending) { p->skew_pending = false; p->skew_next = *p->h_skew_seen != 0u; }
     const uint32_t l32 = (uint32_t)std::min<size_t>(len, 0xFFFFFFFFull);
     // what one engine's status block asks of the host; returns bit 0 = the voice lists changed, bit 1 = misdispatch, bit 2 = voice-sum guard
     auto one = [&](int e) -> uint8_t {
@@ -1656,6 +1675,10 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     HIP_OK(hipHostMalloc(&p->h_eout, sizeof(OwEngineOut) * n_engines));
     HIP_OK(hipMalloc(&p->d_eout_packed, sizeof(OwEngineOut) * n_engines));
     HIP_OK(hipHostMalloc(&p->h_eout_packed, sizeof(OwEngineOut) * n_engines));
+    HIP_OK(hipMalloc(&p->d_skew_seen, sizeof(uint32_t)));
+    HIP_OK(hipMemset(p->d_skew_seen, 0, sizeof(uint32_t)));
+    HIP_OK(hipHostMalloc(&p->h_skew_seen, sizeof(uint32_t)));
+    *p->h_skew_seen = 0u;
     if (n_engines >= 64) {      // status summary of big ranges (k_eout_attention)
         HIP_OK(hipMalloc(&p->d_attn, sizeof(uint64_t) * ((n_engines + 63) / 64)));
         HIP_OK(hipHostMalloc(&p->h_attn, sizeof(uint64_t) * ((n_engines + 63) / 64)));
@@ -1790,6 +1813,8 @@ void pool_destroy(ow_pool* p) {
     hipHostFree(p->h_args); hipHostFree(p->h_eout);
     if (p->d_eout_packed) hipFree(p->d_eout_packed);
     if (p->h_eout_packed) hipHostFree(p->h_eout_packed);
+    if (p->d_skew_seen) hipFree(p->d_skew_seen);
+    if (p->h_skew_seen) hipHostFree(p->h_skew_seen);
     if (p->d_attn) hipFree(p->d_attn);
     if (p->h_attn) hipHostFree(p->h_attn);
     if (p->d_prev_tr) hipFree(p->d_prev_tr);
@@ -2500,6 +2525,7 @@ int ow_test_pool_set_switch(ow_pool* p, const char* name, int value) {
     else if (n == "mel_lds") w.mel_lds = value != 0;
     else if (n == "mel_eng") w.mel_eng = value != 0;
     else if (n == "eout_attn") w.eout_attn = value < 0 ? -1 : (value != 0);
+    else if (n == "voice_skew") w.voice_skew = value != 0;
     else if (n == "pa_sort") { if (value < 0 || value > 2) return -1; w.pa_sort = value; }
     else if (n == "host_profile") w.host_profile = value != 0;
     else return -1;                                       // (trem_traj / trem_cache / pipe shape the pool at creation: environment only)
@@ -2518,6 +2544,8 @@ int ow_test_pool_get_switch(const ow_pool* p, const char* name) {
     if (n == "mel_lds") return w.mel_lds;
     if (n == "mel_eng") return w.mel_eng;
     if (n == "eout_attn") return w.eout_attn;
+    if (n == "voice_skew") return w.voice_skew;
+    if (n == "voice_skew_active") return p->skew_next ? 1 : 0;   // the next steady launch takes the skewed variant
     if (n == "pa_sort") return w.pa_sort;
     if (n == "trem_traj") return p->traj ? 1 : 0;
     if (n == "trem_cache") return w.trem_cache;

@@ -138,7 +138,7 @@ OW_DEV VoiceLanes voice_lanes(const uint32_t* __restrict__ entries, int* __restr
     return w;
 }
 // Sum the voices of each engine of the block in slot order for sample (base + lane) and write its row of sum[pass][engine][.].
-template <int CH = OW_VCHUNK>
+template <int CH = OW_VCHUNK, int RS = CH + 1>
 OW_DEV void voice_reduce(const double* __restrict__ tile, const int* __restrict__ eng_l, const VoiceLanes& w, int cn, int base, int pass,
                          double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int Lcap) {
     const int lane = threadIdx.x;
@@ -147,10 +147,10 @@ OW_DEV void voice_reduce(const double* __restrict__ tile, const int* __restrict_
             double acc = 0.0;
             if (w.nvalid == 64) {
 #pragma unroll 16
-                for (int l = 0; l < 64; ++l) acc += tile[l * (CH + 1) + lane];
+                for (int l = 0; l < 64; ++l) acc += tile[l * RS + lane];
             } else {
 #pragma unroll 4
-                for (int l = 0; l < w.nvalid; ++l) acc += tile[l * (CH + 1) + lane];
+                for (int l = 0; l < w.nvalid; ++l) acc += tile[l * RS + lane];
             }
             const int e = eng_l[0];
             if (!isfinite(acc)) atomicOr(&eout[e].sum_nonfinite, 1u);
@@ -159,7 +159,7 @@ OW_DEV void voice_reduce(const double* __restrict__ tile, const int* __restrict_
         }
         double acc = 0.0;
         for (int l = 0; l < w.nvalid; ++l) {
-            acc += tile[l * (CH + 1) + lane];
+            acc += tile[l * RS + lane];
             if ((w.seg_end >> l) & 1ull) {
                 const int e = eng_l[l];
                 if (!isfinite(acc)) atomicOr(&eout[e].sum_nonfinite, 1u);
@@ -336,7 +336,13 @@ struct VoiceSteady {
 #ifndef OW_STRICT_FP
 #pragma clang fp contract(fast)
 #endif
-        if (cd == 0u) {
+        if (cd == 0u) jitter_due();
+    }
+    OW_DEV void jitter_due() {                               // the update itself (the caller knows this voice's sample counter is at a multiple of 16)
+#ifndef OW_STRICT_FP
+#pragma clang fp contract(fast)
+#endif
+        {
             cd = 16u;
             const uint64_t sample = next_evt;
             next_evt += 16ull;
@@ -394,9 +400,33 @@ struct VoiceSteady {
     }
 };
 
-__global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict__ K, double* __restrict__ vrec, const uint32_t* __restrict__ entries,
-                                                     double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int L, int Lcap) {
-    __shared__ double tile[64 * (OW_VCHUNK + 1)];
+// Skewed clocks (round 4).  Every voice updates its jitter when ITS sample counter is a multiple of 16 (reed.rs:262).  Voices struck at
+// one sample share that grid, and the wavefront takes the update branch once in 16 samples; the voices of played input do not, some lane
+// is due at almost every sample, and the whole wavefront walks through the ~85-instruction update almost every sample (measured: 1.7 x the
+// kernel time).  The update needs nothing but the lane's own state, so the lanes may run on shifted clocks: lane l works on its sample
+// n = i - d_l in loop trip i, with d_l in 0..15 chosen so that all updates of the wavefront fall on the trips with i % 16 == g -- a
+// uniform branch taken once in 16 trips again.  The block then takes L + max d trips (the first and last max d of them with part of the
+// lanes masked), the voice-sum tile becomes a ring of two 16-sample chunks whose reduction runs one chunk behind, and every voice sees
+// exactly the operations it saw before: bit-identical (tests/test_gpu_parity.py::test_skewed_voice_clocks_are_bit_identical).
+// A wavefront whose voices already share a grid (d = 0 for all: the all-keys chord of the benchmark) keeps the plain loop.
+#define OW_SKEW_CH 16
+#define OW_SKEW_RING 32
+// Row stride of the ring.  A lane writes column (i - d_l) & 31 of its row: the LDS bank is 2 ((RS l + i - d_l) mod 32), so lanes l, l' of a
+// half-wavefront collide when RS (l - l') = d_l - d_l' (mod 32).  With RS = 33 a chord rolled one sample per key (d_l = l mod 16) puts
+// sixteen lanes on one bank (measured: 1.4 x the kernel time); with RS = 35 that pattern is a two-way conflict, uniform columns (the plain
+// loop, the reduction's reads) stay conflict-free (3 is odd), and 64 x 35 doubles x 8 wavefronts still fit the CU's LDS.
+#define OW_SKEW_RS 35
+// Two instantiations, so that each loop gets its own register allocation (one kernel holding both took 322 registers, or spilled inside
+// the plain loop when capped): SKEW = false is the plain loop, which also REPORTS whether some wavefront of the launch held more than one
+// jitter grid (skew_seen); the host launches the skewed variant for the next block then -- both give the same samples, so a stale choice
+// only costs time, and the phases of sounding voices relative to each other never change between note events.
+template <bool SKEW>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_voice_steady(const OwConsts* __restrict__ K, double* __restrict__ vrec, const uint32_t* __restrict__ entries,
+                                                     double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int L, int Lcap, uint32_t* __restrict__ skew_seen) {
+    constexpr int TILE_DOUBLES = SKEW ? 64 * OW_SKEW_RS : 64 * (OW_VCHUNK + 1);    // (the skewed variant's short blocks use the plain loop with a 16-sample chunk)
+    constexpr int PCH = SKEW ? OW_SKEW_RING : OW_VCHUNK;      // chunk of the plain loop
+    constexpr int PRS = SKEW ? OW_SKEW_RS : OW_VCHUNK + 1;    // ... and its row stride
+    __shared__ double tile[TILE_DOUBLES];
     __shared__ int eng_l[64];
     const int lane = threadIdx.x;
     const VoiceLanes w = voice_lanes(entries, eng_l);
@@ -425,10 +455,87 @@ __global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict_
         v.update_rotation();
     }
     __syncthreads();                     // eng_l
-    for (int base = 0; base < L; base += OW_VCHUNK) {
-        const int cn = min(OW_VCHUNK, L - base);
+    // ---- which trips carry the jitter updates: g minimising the longest delay over the phases present in this wavefront
+    int g = 0, D = 0, d = 0;
+    {
+        const uint32_t cd0 = v.cd;                                  // samples until this voice's next update (0 = its first sample here)
+        uint32_t present = 0;                                       // bit b: some voice has cd0 == b
+        for (int b = 0; b < 16; ++b) present |= (__ballot(active && cd0 == (uint32_t)b) != 0ull ? 1u : 0u) << b;
+        if (!SKEW) {
+            if (lane == 0 && (present & (present - 1u)) != 0u && L >= 2 * OW_SKEW_CH) atomicOr(skew_seen, 1u);
+        } else if (L >= 2 * OW_SKEW_CH) {
+        int best = 16;
+        for (int gg = 0; gg < 16; ++gg) {
+            int mx = 0;
+            for (int b = 0; b < 16; ++b) if ((present >> b) & 1u) mx = max(mx, (gg - b) & 15);
+            if (mx < best) { best = mx; g = gg; }
+        }
+        D = best;
+        d = (int)((uint32_t)(g - (int)cd0) & 15u);
+        if (lane == 0 && D > 0) atomicOr(skew_seen, 1u);
+        }
+    }
+    if (SKEW && D > 0) {
+        constexpr int RS = OW_SKEW_RS;
+        double* trow = tile + lane * RS;
+        const int n_trips = L + D;
+        int wcol = 0;                                               // ring column of this lane's next sample (n & 31)
+        int red = 0;                                                // next chunk to reduce
+        const int n_chunks = (L + OW_SKEW_CH - 1) / OW_SKEW_CH;
+        for (int i0 = 0; i0 < n_trips; i0 += OW_SKEW_CH) {
+            const int i1 = min(i0 + OW_SKEW_CH, n_trips);
+            if (active) {
+                // One copy of the masked step and one of the pipelined loop: segment 0 = the trips of this chunk before every lane has
+                // started, then the trips in which every lane works, segment 1 = the trips after the first lanes have finished.
+                int i = i0;
+                int nseg = 2;
+                asm volatile("" : "+s"(nseg));                      // keeps the segment loop rolled (one masked body, not two)
+#pragma unroll 1
+                for (int seg = 0; seg < nseg; ++seg) {
+                    if (seg == 1) {
+                        const int f1 = min(i1, L);
+                        if (i < f1) {
+                            if ((i & 15) == g) v.jitter_due();
+                            double y = v.advance();
+                            ++i;
+#pragma unroll 2
+                            for (; i < f1; ++i) {
+                                if ((i & 15) == g) v.jitter_due();
+                                trow[wcol] = v.pickup(y);
+                                wcol = (wcol + 1) & (OW_SKEW_RING - 1);
+                                y = v.advance();
+                            }
+                            trow[wcol] = v.pickup(y);
+                            wcol = (wcol + 1) & (OW_SKEW_RING - 1);
+                        }
+                    }
+                    const int m1 = seg ? i1 : min(i1, D);
+#pragma unroll 1
+                    for (; i < m1; ++i) {
+                        if (i >= d && i - d < L) {
+                            if ((i & 15) == g) v.jitter_due();
+                            const double y = v.advance();
+                            trow[wcol] = v.pickup(y);
+                            wcol = (wcol + 1) & (OW_SKEW_RING - 1);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // chunks every lane has finished: chunk r is complete after trip 16 r + (its length - 1) + D
+            while (red < n_chunks) {
+                const int cn = min(OW_SKEW_CH, L - red * OW_SKEW_CH);
+                if (red * OW_SKEW_CH + cn - 1 + D > i1 - 1) break;
+                voice_reduce<OW_SKEW_RING, OW_SKEW_RS>(tile + ((red * OW_SKEW_CH) & (OW_SKEW_RING - 1)), eng_l, w, cn, red * OW_SKEW_CH, 0, sum, eout, I, Lcap);
+                ++red;
+            }
+            __syncthreads();
+        }
+    } else
+    for (int base = 0; base < L; base += PCH) {
+        const int cn = min(PCH, L - base);
         if (active) {
-            double* trow = tile + lane * (OW_VCHUNK + 1);
+            double* trow = tile + lane * PRS;
             v.jitter();
             double y = v.advance();
 #pragma unroll 2   // two samples per trip: the compiler renames the pipelined state instead of copying it back (7 v_mov_b64 per sample)
@@ -440,7 +547,7 @@ __global__ __launch_bounds__(64) void k_voice_steady(const OwConsts* __restrict_
             trow[cn - 1] = v.pickup(y);
         }
         __syncthreads();
-        voice_reduce(tile, eng_l, w, cn, base, 0, sum, eout, I, Lcap);
+        voice_reduce<PCH, PRS>(tile, eng_l, w, cn, base, 0, sum, eout, I, Lcap);
         __syncthreads();
     }
     if (active) {

@@ -977,3 +977,52 @@ def test_chain_fused_is_bit_identical(hiplib, oracle):
         rep = oracle.parity_report(g.render(length), c.render(length), abs_floor=oracle.ABS_FLOOR_OUTPUT)
         assert rep["n_bad"] == 0, (length, rep)
     g.close(); c.close()
+
+
+def test_skewed_voice_clocks_are_bit_identical(hiplib, oracle):
+    """k_voice_steady<true> (ow_kernels.h): voices struck at different samples update their jitter on different 16-sample grids; the skewed
+    variant delays each lane by 0..15 loop trips so that all updates of a wavefront share trips.  Every voice performs the operations it
+    performed before, so voice sums and output are bit-identical to the plain loop (OW_VOICE_SKEW=0) -- keys struck one sample apart, a
+    sparse engine and a dense one sharing wavefronts, ragged block lengths incl. some below the 32-sample limit of the skewed loop --
+    and both follow the oracle."""
+    import openwurli_amd as ow
+    sr, n = 48000.0, 5
+    res = {}
+    for skew in (1, 0):
+        p = ow.EnginePool(sr, n)
+        p.set_switch("voice_skew", skew)
+        p.set_sample_rate(sr)
+        cs = [oracle.OracleEngine(sr) for _ in range(n)] if skew else None
+        if cs:
+            for c in cs:
+                c.set_sample_rate(sr)
+        outs, sums = [], []
+        def both(f):
+            for k in range(n):
+                f(k, p[k])
+                if cs:
+                    f(k, cs[k])
+        def render(length):
+            o = p.render(length); outs.append(o.copy()); sums.append(p.voice_sum(length).copy())
+            if cs:
+                for k in range(n):
+                    co, cv, _, _ = cs[k].render_taps(length)
+                    rep = oracle.parity_report(o[k], co, abs_floor=oracle.ABS_FLOOR_OUTPUT)
+                    assert rep["n_bad"] == 0, (k, length, rep)
+        keys = {0: list(range(40, 90)), 1: [45, 52], 2: list(range(33, 97)), 3: [60], 4: [36, 48, 60, 72, 84, 96]}
+        for step in range(64):                                   # one key per sample where the engine still has keys left
+            both(lambda k, e: e.note_on(keys[k][step], 0.7) if step < len(keys[k]) else None)
+            render(1)
+        for b in range(30):                                      # past onset ramps and attack noise, then long enough for several renormalisations
+            render((512, 300, 31, 512, 33, 777, 64, 512)[b % 8])
+        for k in range(n):
+            assert p[k].active_voice_count() == len(keys[k])
+        assert p.get_switch("voice_skew_active") == 1          # the plain loop reported more than one grid per wavefront; skew=0 only ignores it
+        p.close()
+        if cs:
+            for c in cs:
+                c.close()
+        res[skew] = (np.concatenate(outs, axis=1), np.concatenate(sums, axis=1))
+    assert np.array_equal(res[1][1], res[0][1])
+    assert np.array_equal(res[1][0], res[0][0])
+    assert np.max(np.abs(res[1][0])) > 1e-3
