@@ -671,9 +671,26 @@ static inline bool chain_wide(size_t n_jobs) {
     if (const char* env = std::getenv("OW_CHAIN_WIDE")) return env[0] == '1';
     return n_jobs <= 8192;
 }
+// OW_JOB_FUSED=0: the quad job chain as one wavefront (k_job_chain_wide) instead of preamp | output stage on two (k_job_chain_fused)
+// (two wavefronts of 400+ registers per eight jobs: 512 workgroups fill the chip, more of them take a second round -- 8 192 jobs measured
+// 319 against 191 ms -- so the fused form is for up to 4 096 jobs)
+static inline bool job_chain_fused(size_t n_jobs) {
+    if (const char* env = std::getenv("OW_JOB_FUSED")) return env[0] != '0';
+    return n_jobs <= 4096;
+}
+// The batch render may run the voices of its jobs BESIDE this chain (ow_batch_render: k_job_voice on a second stream publishes its
+// progress, k_job_chain_fused waits chunk by chunk): only while the chain's workgroups leave SIMDs free for the voice kernel -- 2 048 jobs
+// are 256 workgroups of two one-per-SIMD wavefronts, half the chip -- so that the producer can always be scheduled.
+static inline bool job_voice_overlap(size_t n_jobs) {
+    if (const char* env = std::getenv("OW_JOB_OVERLAP")) { if (env[0] == '0') return false; }
+    return chain_wide(n_jobs) && job_chain_fused(n_jobs) && n_jobs <= 2048;
+}
 static void launch_job_chain_legacy(const OwConsts* dK, const owdev::OwJobDev* d_jobs, const double* d_in, double* d_out, size_t n_jobs, long long n,
-                                    long long stride, hipStream_t st) {
-    if (chain_wide(n_jobs))
+                                    long long stride, hipStream_t st, const int* voice_prog = nullptr) {
+    if (voice_prog && !(chain_wide(n_jobs) && job_chain_fused(n_jobs))) throw std::runtime_error("job chain: overlap with the voices needs the fused chain");
+    if (chain_wide(n_jobs) && job_chain_fused(n_jobs))
+        owdev::k_job_chain_fused<<<dim3((unsigned)((n_jobs + 7) / 8)), dim3(128), 0, st>>>(dK, d_jobs, d_in, d_out, (int)n_jobs, n, stride, voice_prog);
+    else if (chain_wide(n_jobs))
         owdev::k_job_chain_wide<<<dim3((unsigned)((n_jobs + 7) / 8)), dim3(64), 0, st>>>(dK, d_jobs, d_in, d_out, (int)n_jobs, n, stride);
     else
         owdev::k_job_chain<false><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_in, d_out, nullptr, (int)n_jobs, n, stride);
@@ -693,8 +710,18 @@ void pa_settled_to_device(int device, double* d_dst, hipStream_t st);
 //     rate is (power_amp.rs:321-323), it runs at the BASE rate on preamp x volume^2 -- as its own launch (eight lanes per job,
 //     k_mpa_debug) between the chain kernel and the speaker stage.
 struct JobChainCfg { double sample_rate; int device, preamp_kind, power_amp_kind, no_rail_sag; };
+// true when run_job_chain will take the plain legacy chain (launch_job_chain_legacy) for these jobs
+static bool job_chain_is_plain_legacy(const JobChainCfg& cfg, const std::vector<owdev::OwJobDev>& hj) {
+    if (cfg.preamp_kind != OW_PREAMP_LEGACY8) return false;
+    bool any_pa = false;
+    for (const auto& j : hj) {
+        if ((j.tremolo_depth > 0.0 && !j.no_preamp) || j.no_preamp) return false;
+        any_pa = any_pa || j.poweramp;
+    }
+    return !(cfg.power_amp_kind == OW_POWER_AMP_MELANGE && any_pa);
+}
 void run_job_chain(const JobChainCfg& cfg, const OwConsts* dK, const std::vector<owdev::OwJobDev>& hj, const owdev::OwJobDev* d_jobs, const double* d_in,
-                   double* d_out, size_t n_jobs, long long n, long long stride, hipStream_t st) {
+                   double* d_out, size_t n_jobs, long long n, long long stride, hipStream_t st, const int* voice_prog = nullptr) {
     if (cfg.preamp_kind != OW_PREAMP_LEGACY8 && cfg.preamp_kind != OW_PREAMP_MELANGE12) throw std::runtime_error("unknown preamp_kind");
     if (cfg.power_amp_kind != OW_POWER_AMP_BEHAVIORAL && cfg.power_amp_kind != OW_POWER_AMP_MELANGE) throw std::runtime_error("unknown power_amp_kind");
     bool any_trem = false, any_special = false, any_pa = false;
@@ -748,7 +775,7 @@ void run_job_chain(const JobChainCfg& cfg, const OwConsts* dK, const std::vector
         owdev::k_job_chain<true><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_in, chain_out, d_settled.as<double>(), (int)n_jobs, n, stride,
                                                                                             trem, out_mode);
     } else if (!any_trem && !any_special && !mpa) {
-        launch_job_chain_legacy(dK, d_jobs, d_in, chain_out, n_jobs, n, stride, st);
+        launch_job_chain_legacy(dK, d_jobs, d_in, chain_out, n_jobs, n, stride, st, voice_prog);
     } else {
         owdev::k_job_chain<false><<<dim3((unsigned)((n_jobs + 31) / 32)), dim3(64), 0, st>>>(dK, d_jobs, d_in, chain_out, nullptr, (int)n_jobs, n, stride, trem, out_mode);
     }
@@ -2748,10 +2775,33 @@ long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg*
         HIP_OK(hipMemcpyAsync(dK, &hc, sizeof(OwConsts), hipMemcpyHostToDevice, st));
         HIP_OK(hipMemcpyAsync(d_jobs, hj.data(), sizeof(owdev::OwJobDev) * n_jobs, hipMemcpyHostToDevice, st));
         owdev::k_note_table<<<dim3(1), dim3(64), 0, st>>>(d_nt);
-        owdev::k_job_voice<<<dim3((unsigned)vblocks), dim3(64), 0, st>>>(dK, d_nt, d_vrec, d_jobs, d_reed, (int)n_jobs, (long long)n, (long long)stride);
-        HIP_OK(hipGetLastError());
         const JobChainCfg cc{cfg->sample_rate, cfg->device, cfg->preamp_kind, cfg->power_amp_kind, cfg->no_rail_sag};
-        run_job_chain(cc, dK, hj, d_jobs, d_reed, d_out, n_jobs, (long long)n, (long long)stride, st);
+        // Voices and chain side by side when the chain is the plain legacy one and leaves room on the chip: a job's run time is serial
+        // latency in both kernels, so the 13 % the voices take are hidden behind the chain instead of in front of it.
+        const bool overlap = job_chain_is_plain_legacy(cc, hj) && job_voice_overlap(n_jobs);
+        DevMem m_prog;
+        StreamOwner so2;
+        hipEvent_t ev_ready = nullptr, ev_voice = nullptr;
+        struct EvGuard { hipEvent_t* a; hipEvent_t* b; ~EvGuard() { if (*a) hipEventDestroy(*a); if (*b) hipEventDestroy(*b); } } evg{&ev_ready, &ev_voice};
+        int* d_prog = nullptr;
+        if (overlap) {
+            m_prog.alloc(sizeof(int) * vblocks);
+            d_prog = m_prog.as<int>();
+            HIP_OK(hipMemsetAsync(d_prog, 0, sizeof(int) * vblocks, st));
+            HIP_OK(hipStreamCreateWithFlags(&so2.s, hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&ev_voice, hipEventDisableTiming));
+            HIP_OK(hipEventRecord(ev_ready, st));
+            HIP_OK(hipStreamWaitEvent(so2.s, ev_ready, 0));
+            owdev::k_job_voice<<<dim3((unsigned)vblocks), dim3(64), 0, so2.s>>>(dK, d_nt, d_vrec, d_jobs, d_reed, (int)n_jobs, (long long)n, (long long)stride, d_prog);
+            HIP_OK(hipGetLastError());
+            HIP_OK(hipEventRecord(ev_voice, so2.s));
+        } else {
+            owdev::k_job_voice<<<dim3((unsigned)vblocks), dim3(64), 0, st>>>(dK, d_nt, d_vrec, d_jobs, d_reed, (int)n_jobs, (long long)n, (long long)stride);
+            HIP_OK(hipGetLastError());
+        }
+        run_job_chain(cc, dK, hj, d_jobs, d_reed, d_out, n_jobs, (long long)n, (long long)stride, st, d_prog);
+        if (overlap) HIP_OK(hipStreamWaitEvent(st, ev_voice, 0));
         if (!out_is_device) HIP_OK(hipMemcpyAsync(out, d_out, sizeof(double) * n_jobs * stride, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         return (long long)n;

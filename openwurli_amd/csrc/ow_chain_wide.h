@@ -570,4 +570,119 @@ __global__ __launch_bounds__(128) void k_chain_fused(const OwConsts* __restrict_
     smoother_store(sv, cs, I, e, CS_SM_VOL);
 }
 
+
+// k_job_chain_wide as two wavefronts (round 4): a job's run time is the chain's serial latency, and half-band decimation, volume taper,
+// behavioural power amp and speaker (main.rs:445-496) hang behind the preamp in the same lane.  Here wavefront 0 runs the up-sampler and
+// the two preamp steps of a sample (k_job_chain_wide's lanes and state) and hands the pair of chain-rate outputs over through a
+// two-slot LDS ring; wavefront 1 -- one lane per job -- follows a chunk behind with the rest.  Same statements per job in the same
+// order: bit-identical to k_job_chain_wide (tests/test_gpu_render_flags.py, OW_JOB_FUSED=0/1).
+__global__ __launch_bounds__(128) void k_job_chain_fused(const OwConsts* __restrict__ K, const OwJobDev* __restrict__ jobs, const double* __restrict__ reed,
+                                                         double* __restrict__ out, int n_jobs, long long n, long long stride, const int* __restrict__ voice_prog) {
+    __shared__ double tin[8 * (OW_FCHUNK + 1)];
+    __shared__ double ring[2][OW_FCHUNK * 2][8];               // preamp out at the chain rate: [slot][sample x phase][job of the block]
+    __shared__ double tout[8 * (OW_FCHUNK + 1)];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = lane & 3, role = lane >> 5;
+    const int jl = wv == 0 ? (lane & 31) >> 2 : (lane & 7);      // wavefront 1: lanes 0..7 own a job each, the others shadow them
+    const int jb = blockIdx.x * 8;
+    const int j = jb + jl;
+    const bool valid = j < n_jobs;
+    const OwJobDev jd = jobs[valid ? j : n_jobs - 1];
+    const int osr = K->oversample ? 2 : 1;
+    const double sr = K->sr;
+    const long long n_chunks = (n + OW_FCHUNK - 1) / OW_FCHUNK;
+
+    DkWideRows R;
+    DkSt st;
+    double r_ldr = 1000000.0, g_ldr = 1.0 / 1000000.0, g_prev = g_ldr;
+    double ua[3] = {0, 0, 0}, ub[3] = {0, 0, 0}, da[3] = {0, 0, 0}, db[3] = {0, 0, 0}, dd = 0.0;
+    SpeakerSt sp;
+    if (wv == 0) {
+        dk_wide_rows_load(R, K, q);
+        dk_dc_reset(K, r_ldr, st);                               // DkPreamp::new(preamp_sr); reset(); set_ldr_resistance(r_ldr)  (main.rs:432-441)
+        const double r_new = fmax(jd.r_ldr, 1000.0);
+        if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = 1.0 / r_new; }
+    } else {
+        sp.character = 1.0; sp.ts = 0.0;                         // Speaker::new(sr); set_character(c)  (main.rs:483-484)
+        sp.hpf.s1 = sp.hpf.s2 = sp.lpf.s1 = sp.lpf.s2 = 0.0;
+        speaker_update(sp, sr);
+        speaker_set_character(sp, jd.speaker, sr);
+    }
+    const double vol2_a = jd.volume;
+    auto preamp_step = [&](double x) -> double {
+        const double o = dk_step_wide(st, R, q, x, g_ldr, g_prev, K);
+        g_prev = g_ldr;
+        const double other = xor32(o);
+        double res = role ? (other - o) : (o - other);
+        if (!isfinite(res)) {
+            dk_dc_reset(K, r_ldr, st); g_ldr = 1.0 / r_ldr; g_prev = g_ldr;
+            res = 0.0;
+        }
+        return res;
+    };
+    for (long long c = 0; c <= n_chunks; ++c) {
+        if (wv == 0 && c < n_chunks) {
+            const long long base = c * OW_FCHUNK;
+            const int cn = (int)((n - base) < OW_FCHUNK ? (n - base) : OW_FCHUNK);
+            if (voice_prog) {   // the voices of these eight jobs (one block of k_job_voice) are being rendered beside this kernel: wait for the chunk
+                const int need = (int)(base + cn);
+                while (__hip_atomic_load(&voice_prog[jb >> 6], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(32);
+            }
+#pragma unroll
+            for (int u = 0; u < 8 * OW_FCHUNK / 64; ++u) {
+                const int k = lane + 64 * u;
+                const int r = k / OW_FCHUNK, sm = k % OW_FCHUNK;
+                double x = 0.0;
+                if (jb + r < n_jobs && sm < cn) x = reed[(size_t)(jb + r) * stride + base + sm];
+                tin[r * (OW_FCHUNK + 1) + sm] = x;
+            }
+            OW_WAVE_SYNC();
+            double (*slot)[8] = ring[c & 1];
+            for (int sidx = 0; sidx < cn; ++sidx) {
+                const double x = tin[jl * (OW_FCHUNK + 1) + sidx];
+                if (osr == 2) {                                  // main.rs:445-466: per-sample up(1) -> 2x process (-> down(1) on wavefront 1)
+                    const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, ua, x);
+                    const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, ub, x);
+                    const double in[2] = {role ? 0.0 : a, role ? 0.0 : b};
+                    for (int k = 0; k < 2; ++k) {
+                        const double pk = preamp_step(in[k]);
+                        if (role == 0 && q == 0) slot[sidx * 2 + k][jl] = pk;
+                    }
+                } else {
+                    const double pk = preamp_step(role ? 0.0 : x);
+                    if (role == 0 && q == 0) slot[sidx * 2][jl] = pk;
+                }
+            }
+        }
+        if (wv == 1 && c >= 1) {
+            const long long base = (c - 1) * OW_FCHUNK;
+            const int cn = (int)((n - base) < OW_FCHUNK ? (n - base) : OW_FCHUNK);
+            const double (*slot)[8] = ring[(c - 1) & 1];
+            for (int sidx = 0; sidx < cn; ++sidx) {
+                double pre;
+                if (osr == 2) {
+                    const double fa = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, slot[sidx * 2][jl]);
+                    const double fb = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, slot[sidx * 2 + 1][jl]);
+                    pre = (fa + dd) * 0.5;
+                    dd = fb;
+                } else {
+                    pre = slot[sidx * 2][jl];
+                }
+                // main.rs:487-496: volume^2 (audio taper) -> optional power amp at base rate -> speaker -> PSG
+                const double att = pre * vol2_a * vol2_a;
+                const double amp = jd.poweramp ? power_amp(att) : att;
+                const double y = speaker_process(sp, amp, K->spk_thermal_alpha) * 7.498942093324558;
+                if (lane < 8) tout[jl * (OW_FCHUNK + 1) + sidx] = y;
+            }
+            OW_WAVE_SYNC();
+            for (int k = lane; k < 8 * OW_FCHUNK; k += 64) {
+                const int r = k / OW_FCHUNK, sm = k - r * OW_FCHUNK;
+                if (jb + r < n_jobs && sm < cn) out[(size_t)(jb + r) * stride + base + sm] = tout[r * (OW_FCHUNK + 1) + sm];
+            }
+            OW_WAVE_SYNC();
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace owdev

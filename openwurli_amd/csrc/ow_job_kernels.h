@@ -27,7 +27,7 @@ enum { JOB_OUT_FINAL = 0, JOB_OUT_PA_INPUT = 1 };
 // Voice::note_on + Voice::render for n samples, lane = job.  reed[job][n] (row stride `stride`).
 __global__ __launch_bounds__(64) void k_job_voice(const OwConsts* __restrict__ K, const double* __restrict__ nt, double* __restrict__ vrec,
                                                   const OwJobDev* __restrict__ jobs, double* __restrict__ reed, int n_jobs, long long n,
-                                                  long long stride) {
+                                                  long long stride, int* __restrict__ prog = nullptr) {
     __shared__ double tile[64 * (OW_VCHUNK + 1)];
     const int lane = threadIdx.x;
     const int jb = blockIdx.x * 64;
@@ -59,6 +59,12 @@ __global__ __launch_bounds__(64) void k_job_voice(const OwConsts* __restrict__ K
             if (jb + r < n_jobs && s < cn) reed[(size_t)(jb + r) * stride + base + s] = tile[r * (OW_VCHUNK + 1) + s];
         }
         __syncthreads();
+        // prog != nullptr: the chain kernel of these jobs runs BESIDE this one (k_job_chain_fused on another stream) and waits, chunk by
+        // chunk, for the samples to exist: publish how far the block's 64 rows are written
+        if (prog) {
+            __threadfence();
+            if (lane == 0) __hip_atomic_store(&prog[blockIdx.x], (int)(base + cn), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

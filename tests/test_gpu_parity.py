@@ -304,13 +304,21 @@ def test_chain_wide_is_bit_identical(hiplib, oracle):
                                            (40, 90, 1e6), (55, 35, 7e5), (67, 80, 1e6), (79, 127, 1e6)])]
     for sr in (44100.0, 96000.0):
         outs = {}
-        for wide in ("0", "1"):
-            os.environ["OW_CHAIN_WIDE"] = wide
+        # "1": the quad chain as preamp | output stage on two wavefronts (k_job_chain_fused) with the voices rendered BESIDE it on a second
+        # stream (k_job_voice publishes its progress, the chain waits chunk by chunk); "1-after-voices": the same chain behind the voices
+        for wide in ("0", "1", "1-one-wavefront", "1-after-voices"):
+            os.environ["OW_CHAIN_WIDE"] = wide[0]
+            if wide in ("0", "1-one-wavefront"):
+                os.environ["OW_JOB_FUSED"] = "0"
+            if wide == "1-after-voices":
+                os.environ["OW_JOB_OVERLAP"] = "0"
             try:
                 outs[wide] = ow.batch_render(jobs, sr, 0.35)
             finally:
                 del os.environ["OW_CHAIN_WIDE"]
-        assert np.array_equal(outs["0"], outs["1"]), (sr, np.max(np.abs(outs["0"] - outs["1"])))
+                os.environ.pop("OW_JOB_FUSED", None); os.environ.pop("OW_JOB_OVERLAP", None)
+        for other in ("0", "1-one-wavefront", "1-after-voices"):
+            assert np.array_equal(outs[other], outs["1"]), (sr, other, np.max(np.abs(outs[other] - outs["1"])))
         for k in (0, 2, 4, 10):
             j = jobs[k]
             c = oracle.batch_render_job(j["note"], j["velocity"], 0.35, sr, volume=j["volume"], speaker=j["speaker"], r_ldr=j["r_ldr"],
