@@ -462,9 +462,9 @@ def main(argv=None):
                            "parallelism": f"{world} rank(s), static job deal, no data-path collective besides the final gather"},
                 "batch": b,
                 "dry_run": bool(dryrun),
-                "roofline": {"bound": "valu_f64", "kernel": "k_job_chain_wide", "achieved": lit["valu_frac"] * PEAK_FP64_VALU_TFLOPS, "peak": PEAK_FP64_VALU_TFLOPS,
+                "roofline": {"bound": "valu_f64", "kernel": "k_job_chain_fused", "achieved": lit["valu_frac"] * PEAK_FP64_VALU_TFLOPS, "peak": PEAK_FP64_VALU_TFLOPS,
                              "unit": "TFLOP/s", "frac": lit["valu_frac"], "traffic": None,
-                             "note": "512 jobs = 64 quad-lane wavefronts on 1 024 SIMDs: bounded by the serial latency of one preamp stream, not by issue or HBM"},
+                             "note": "512 jobs = 64 workgroups of two quad-lane wavefronts (preamp | output stage) on 1 024 SIMDs, the voices rendered beside them: bounded by the serial latency of one preamp stream, not by issue or HBM"},
                 "cpu_baseline": None,
             }
     else:
