@@ -689,7 +689,8 @@ static void launch_job_chain_legacy(const OwConsts* dK, const owdev::OwJobDev* d
                                     long long stride, hipStream_t st, const int* voice_prog = nullptr) {
     if (voice_prog && !(chain_wide(n_jobs) && job_chain_fused(n_jobs))) throw std::runtime_error("job chain: overlap with the voices needs the fused chain");
     if (chain_wide(n_jobs) && job_chain_fused(n_jobs))
-        owdev::k_job_chain_fused<<<dim3((unsigned)((n_jobs + 7) / 8)), dim3(128), 0, st>>>(dK, d_jobs, d_in, d_out, (int)n_jobs, n, stride, voice_prog);
+        owdev::k_job_chain_fused<<<dim3((unsigned)((n_jobs + 7) / 8)), dim3(128), 0, st>>>(dK, d_jobs, d_in, d_out, (int)n_jobs, n, stride, voice_prog,
+                                                                                           voice_prog ? const_cast<int*>(voice_prog) + (n_jobs + 63) / 64 : nullptr);
     else if (chain_wide(n_jobs))
         owdev::k_job_chain_wide<<<dim3((unsigned)((n_jobs + 7) / 8)), dim3(64), 0, st>>>(dK, d_jobs, d_in, d_out, (int)n_jobs, n, stride);
     else
@@ -2785,9 +2786,9 @@ long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg*
         struct EvGuard { hipEvent_t* a; hipEvent_t* b; ~EvGuard() { if (*a) hipEventDestroy(*a); if (*b) hipEventDestroy(*b); } } evg{&ev_ready, &ev_voice};
         int* d_prog = nullptr;
         if (overlap) {
-            m_prog.alloc(sizeof(int) * vblocks);
+            m_prog.alloc(sizeof(int) * (vblocks + 1));                 // progress of every voice block + the chain's "gave up waiting" flag
             d_prog = m_prog.as<int>();
-            HIP_OK(hipMemsetAsync(d_prog, 0, sizeof(int) * vblocks, st));
+            HIP_OK(hipMemsetAsync(d_prog, 0, sizeof(int) * (vblocks + 1), st));
             HIP_OK(hipStreamCreateWithFlags(&so2.s, hipStreamNonBlocking));
             HIP_OK(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
             HIP_OK(hipEventCreateWithFlags(&ev_voice, hipEventDisableTiming));
@@ -2801,7 +2802,13 @@ long long ow_batch_render(const ow_job* jobs, size_t n_jobs, const ow_batch_cfg*
             HIP_OK(hipGetLastError());
         }
         run_job_chain(cc, dK, hj, d_jobs, d_reed, d_out, n_jobs, (long long)n, (long long)stride, st, d_prog);
-        if (overlap) HIP_OK(hipStreamWaitEvent(st, ev_voice, 0));
+        if (overlap) {
+            HIP_OK(hipStreamWaitEvent(st, ev_voice, 0));
+            int gave_up = 0;
+            HIP_OK(hipMemcpyAsync(&gave_up, d_prog + vblocks, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            if (gave_up) run_job_chain(cc, dK, hj, d_jobs, d_reed, d_out, n_jobs, (long long)n, (long long)stride, st);   // the voices are complete now
+        }
         if (!out_is_device) HIP_OK(hipMemcpyAsync(out, d_out, sizeof(double) * n_jobs * stride, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         return (long long)n;

@@ -577,7 +577,8 @@ __global__ __launch_bounds__(128) void k_chain_fused(const OwConsts* __restrict_
 // two-slot LDS ring; wavefront 1 -- one lane per job -- follows a chunk behind with the rest.  Same statements per job in the same
 // order: bit-identical to k_job_chain_wide (tests/test_gpu_render_flags.py, OW_JOB_FUSED=0/1).
 __global__ __launch_bounds__(128) void k_job_chain_fused(const OwConsts* __restrict__ K, const OwJobDev* __restrict__ jobs, const double* __restrict__ reed,
-                                                         double* __restrict__ out, int n_jobs, long long n, long long stride, const int* __restrict__ voice_prog) {
+                                                         double* __restrict__ out, int n_jobs, long long n, long long stride, const int* __restrict__ voice_prog,
+                                                         int* __restrict__ voice_err) {
     __shared__ double tin[8 * (OW_FCHUNK + 1)];
     __shared__ double ring[2][OW_FCHUNK * 2][8];               // preamp out at the chain rate: [slot][sample x phase][job of the block]
     __shared__ double tout[8 * (OW_FCHUNK + 1)];
@@ -591,6 +592,7 @@ __global__ __launch_bounds__(128) void k_job_chain_fused(const OwConsts* __restr
     const int osr = K->oversample ? 2 : 1;
     const double sr = K->sr;
     const long long n_chunks = (n + OW_FCHUNK - 1) / OW_FCHUNK;
+    bool gave_up = false;
 
     DkWideRows R;
     DkSt st;
@@ -624,9 +626,15 @@ __global__ __launch_bounds__(128) void k_job_chain_fused(const OwConsts* __restr
         if (wv == 0 && c < n_chunks) {
             const long long base = c * OW_FCHUNK;
             const int cn = (int)((n - base) < OW_FCHUNK ? (n - base) : OW_FCHUNK);
-            if (voice_prog) {   // the voices of these eight jobs (one block of k_job_voice) are being rendered beside this kernel: wait for the chunk
+            if (voice_prog && !gave_up) {   // the voices of these eight jobs (one block of k_job_voice) are being rendered beside this kernel: wait for the chunk
                 const int need = (int)(base + cn);
-                while (__hip_atomic_load(&voice_prog[jb >> 6], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(32);
+                // bounded: a producer that never gets scheduled (a chip filled by other work) must not hang the device -- after ~5 s the
+                // kernel raises the flag behind the progress words and runs on without waiting; the host then repeats the chain alone
+                long spins = 0;
+                while (__hip_atomic_load(&voice_prog[jb >> 6], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                    __builtin_amdgcn_s_sleep(32);
+                    if (++spins > 5000000L) { gave_up = true; if (lane == 0) atomicOr(voice_err, 1); break; }
+                }
             }
 #pragma unroll
             for (int u = 0; u < 8 * OW_FCHUNK / 64; ++u) {
