@@ -54,10 +54,11 @@ NOTES = list(range(33, 97))
 # deviation 9) + jitter 3 + pickup 13 + gain/sum 2 per voice-sample: the algorithm AS BUILT.  (SURVEY 8d counts 130 for the reference.)
 FLOPS_VOICE_SAMPLE = 123
 FLOPS_VOICES = 64 * FLOPS_VOICE_SAMPLE
-# f64 flops the steady voice kernel EXECUTES per voice-sample by its PMC instruction mix (9.2 add + 27.5 mul + 2 x 35.5 fma,
-# profiles/r02c_voice_steady_pmc.md): below the algorithmic count because the jitter-corrected rotation coefficients (4 flops per
-# mode, reed.rs:281-283 evaluates them every sample) only change with the drift, every 16th sample, and are hoisted there
-FLOPS_VOICE_SAMPLE_EXECUTED = 107.7
+# f64 flops the steady voice kernel EXECUTES per voice-sample by its PMC instruction mix (8.4 add + 27.5 mul + 2 x 35.5 fma + 1.2
+# transcendental, profiles/r04_pmc_per_sample.md; 83.8 VALU instructions in all): below the algorithmic count because the
+# jitter-corrected rotation coefficients (4 flops per mode, reed.rs:281-283 evaluates them every sample) only change with the drift,
+# every 16th sample, and are hoisted there
+FLOPS_VOICE_SAMPLE_EXECUTED = 8.4 + 27.5 + 2 * 35.5 + 1.2
 FLOPS_TREMOLO = 2 * (1000 + 25)    # Twin-T NR step + LDR law per OS sample, 2 OS samples -- per tremolo PHASE GROUP, not per engine
 FLOPS_PREAMP = 2 * 1400 + 24       # main+shadow dk_step per OS sample + half-band up
 # melange 12-node preamp as the kernel EXECUTES it (rank-one update of the inverse, no per-sample LU): per state and chain-rate
@@ -374,6 +375,9 @@ def main(argv=None):
                     help="engines = configs[1] replicated per configs[4] (the metric's config); batch = configs[3] sharded over the ranks")
     ap.add_argument("--instances", type=int, default=int(os.environ.get("OW_BENCH_INSTANCES", "131072")), help="engine instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--deliver", choices=["hbm", "host"], default="hbm",
+                    help="hbm (default, the contract's `value`): every block stays in HBM; host: every block of the timed region is delivered into a "
+                         "pinned host block, as render(&mut [f32]) hands it back (engine.rs:425-462) -- the 10 s run in this mode IS the API-faithful figure")
     ap.add_argument("--no-extras", action="store_true", help="skip pcie_inclusive / config4_literal / single_instance / batch objects")
     ap.add_argument("--preamp", choices=["legacy", "melange"], default="legacy",
                     help="legacy = the 8-node DK solver of the reference's default build (the metric's config); melange = the generated "
@@ -550,7 +554,8 @@ def main(argv=None):
                         "active_voices": voices, "nan_guard_and_reset_counters": counters}
 
         pool = make_pool(n_inst, n_phases=phases)
-        script = Script(pool, n_inst)
+        main_host = pool.alloc_host_block(BUF) if (args.deliver == "host" and not dryrun) else None
+        script = Script(pool, n_inst, host_out=main_host)
         for _ in range(args.warmup):
             script.step()
         pool.set_profiling(True)
@@ -560,28 +565,43 @@ def main(argv=None):
         pool.set_profiling(False)
         verified, verify_details = verify(pool, n_inst)
         on_traj = pool.trajectory_info()[0]
+        failed_ranks = [] if verified else [rank]
         if dist is not None:
-            t_ = torch.tensor([1.0 if verified else 0.0], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t_, op=dist.ReduceOp.MIN)
-            verified = bool(t_.item() > 0.5)
+            t_ = torch.zeros(world, dtype=torch.float64, device=red_dev)     # one slot per rank: which ranks failed, not just whether one did
+            t_[rank] = 0.0 if verified else 1.0
+            dist.all_reduce(t_, op=dist.ReduceOp.SUM)
+            failed_ranks = [r for r, x in enumerate(t_.tolist()) if x > 0.5]
+            verified = not failed_ranks
 
         extras = {}
         if not args.no_extras and not dryrun:
-            # (a) PCIe-inclusive: the same steps with every block copied into a pinned host buffer (what render(&mut [f32]) hands back)
+            # (a) PCIe-inclusive: the same steps with every block delivered into a pinned host buffer (what render(&mut [f32]) hands back,
+            # engine.rs:425-462): big pools store the rows from the chain kernel itself (k_chain_stream), nothing is copied afterwards
             host = pool.alloc_host_block(BUF)
             sp = Script(pool, n_inst, host_out=host)
             sp.pos = script.pos
             k_steps = max(5, min(args.steps, 20))
+            for _ in range(2):
+                sp.step()
             el = timed_steps(sp, k_steps)
             extras["pcie_inclusive"] = {"value": k_steps * BUF * n_inst * world / el, "unit": "samples/s", "ms_per_step": 1e3 * el / k_steps, "steps": k_steps,
-                                        "bytes_per_step_per_gpu": 4 * BUF * n_inst, "host_memory": "pinned (ow_host_alloc)"}
-            pool.free_host_block(host)
+                                        "bytes_per_step_per_gpu": 4 * BUF * n_inst, "host_memory": "pinned (ow_host_alloc), mapped: rows stored by the output stage itself",
+                                        "restrikes_in_timed_region": int((sp.pos // EPOCH) - ((sp.pos - k_steps * BUF) // EPOCH))}
             # (a1) ten steps that straddle a re-strike epoch (note_off + note_on of all 64 keys of every instance: 5 ms steal crossfades,
-            # onset ramps and attack noise in the general voice kernel, host MIDI + op upload) -- the default timed region may hold none
+            # onset ramps and attack noise in the general voice kernel, host MIDI + op upload) -- the default timed region may hold none;
+            # once with the audio left in HBM, once delivered to the host block
             r = side_run(pool, n_inst, 0, 10, pos=EPOCH - 3 * BUF)
             r["restrikes_in_timed_region"] = 1
             r["note"] = "steps [epoch - 3 buffers, epoch + 7 buffers): one whole-keyboard re-strike of every instance inside"
             extras["with_restrike"] = r
+            sh = Script(pool, n_inst, host_out=host)
+            sh.pos = EPOCH - 3 * BUF
+            el = timed_steps(sh, 10)
+            extras["with_restrike_host"] = {"value": 10 * BUF * n_inst * world / el, "unit": "samples/s", "ms_per_step": 1e3 * el / 10, "steps": 10,
+                                            "restrikes_in_timed_region": 1, "note": "the same ten steps delivered to the pinned host block"}
+            pool.free_host_block(host)
+        if main_host is not None:
+            pool.free_host_block(main_host)
         pool.close()
 
         if not args.no_extras and not dryrun and phases * 4 >= n_inst:
@@ -782,13 +802,21 @@ def main(argv=None):
             solver = "melange 12-node DK" if preamp_kind else "legacy DK"
             amp = "melange 7-BJT power amp + rail sag" if pa_kind else "behavioural power amp"
             pcie = extras.get("pcie_inclusive", {}).get("value")
+
+            def epoch_weighted(steady_ms, restrike_ms):
+                """samples/s over one config-2 epoch (48 000 samples = 93.75 buffers): 83.75 steady buffers + the 10 around the re-strike"""
+                if not steady_ms or not restrike_ms:
+                    return None
+                per_epoch_ms = (EPOCH / BUF - 10) * steady_ms + 10 * restrike_ms
+                return {"value": EPOCH * n_inst * world / (per_epoch_ms * 1e-3), "unit": "samples/s", "ms_per_step": per_epoch_ms / (EPOCH / BUF),
+                        "steady_ms_per_step": steady_ms, "restrike_window_ms_per_step": restrike_ms}
             line = {
                 "metric": f"audio samples/s, 64-voice full chain (x real-time @{SR / 1000:.0f} kHz = value / {SR:.0f})",
                 "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f64",
                 "data": "synthetic" if not dryrun else "DRY RUN (gloo, stand-in pool): launcher, barriers and aggregation only, nothing measured",
-                "verified": verified, "verify": verify_details, "ranks_seen": ranks_seen, "dry_run": bool(dryrun),
+                "verified": verified, "verify": verify_details, "verify_failed_ranks": failed_ranks, "ranks_seen": ranks_seen, "dry_run": bool(dryrun),
                 "config": {
                     "workload": (f"cfg2: 64-voice all-keys-sustained (1.0 s re-strike), 48 kHz host / 96 kHz chain, full chain "
                                  f"(tremolo+{solver} preamp+{amp}+speaker), MLP on, buffers of 512") if SR == 48000.0 else
@@ -802,9 +830,14 @@ def main(argv=None):
                                       "figure is the `tremolo_per_instance` extra; the oscillator's flops are not in any numerator") if shared else
                                      f"{phases} tremolo phase groups, one Twin-T oscillator each (its flops are in whole_chain_frac)"),
                     "restrikes_in_timed_region": int((script.pos // EPOCH) - ((script.pos - args.steps * BUF) // EPOCH)),
-                    "audio_left_in_hbm": True,
+                    "audio_left_in_hbm": args.deliver != "host",
                     "pcie_inclusive_samples_per_s": pcie,
-                    "pcie_note": "`value` leaves every block in HBM; pcie_inclusive copies each block into a pinned host buffer -- the render(&mut [f32]) equivalent",
+                    "pcie_note": "`value` leaves every block in HBM; pcie_inclusive delivers each block into a pinned host buffer -- the render(&mut [f32]) equivalent",
+                    # SURVEY 8d config 2 as defined: all 64 keys re-struck every 48 000 samples.  One epoch = 93.75 buffers of 512; the ten
+                    # buffers around the re-strike are the `with_restrike` window, the other 83.75 run at the steady rate of the timed region
+                    "config2_epoch_weighted": epoch_weighted(1e3 * elapsed / args.steps, extras.get("with_restrike", {}).get("ms_per_step")),
+                    # ... and with every block delivered to the caller's host buffer (engine.rs:425-462): what a caller of render(&mut [f32]) gets
+                    "api_faithful": epoch_weighted(extras.get("pcie_inclusive", {}).get("ms_per_step"), extras.get("with_restrike_host", {}).get("ms_per_step")),
                 },
                 "x_realtime_aggregate": value / SR,
                 "host_midi_s": script.t_midi, "render_calls_s": script.t_render, "elapsed_s": elapsed,

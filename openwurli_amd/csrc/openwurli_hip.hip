@@ -31,6 +31,7 @@
 #include "ow_audit.h"
 #include "ow_midi_kernels.h"
 #include "ow_chain_wide.h"
+#include "ow_chain_stream.h"
 #include <condition_variable>
 #include <map>
 #include <memory>
@@ -59,6 +60,25 @@ uint64_t process_noise_seed() {
         hipError_t _e = (expr);                                                                        \
         if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
+
+// Pinned host blocks handed out by ow_host_alloc: mapped into the device's address space, so the output stage of a big pool can store a
+// rendered block straight into the caller's buffer (no d_out -> host copy trailing the last kernel).  render looks a target up here;
+// anything else (pageable memory, blocks pinned by somebody else) takes the staged copy.
+std::mutex g_host_mu;
+struct HostBlock { size_t bytes; void* dptr; };
+std::map<uintptr_t, HostBlock> g_host_blocks;
+void host_block_register(void* ptr, size_t bytes, void* dptr) { std::lock_guard<std::mutex> lk(g_host_mu); g_host_blocks[(uintptr_t)ptr] = HostBlock{bytes, dptr}; }
+void host_block_forget(void* ptr) { std::lock_guard<std::mutex> lk(g_host_mu); g_host_blocks.erase((uintptr_t)ptr); }
+// device address of [ptr, ptr + bytes) when it lies inside one registered block, else nullptr
+void* host_block_device_ptr(const void* ptr, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    auto it = g_host_blocks.upper_bound((uintptr_t)ptr);
+    if (it == g_host_blocks.begin()) return nullptr;
+    --it;
+    const uintptr_t off = (uintptr_t)ptr - it->first;
+    if (!it->second.dptr || off > it->second.bytes || bytes > it->second.bytes - off) return nullptr;
+    return (char*)it->second.dptr + off;
+}
 
 struct DevMem {   // device buffer released on every exit path
     void* p = nullptr;
@@ -194,6 +214,8 @@ struct Switches {
     int pa_sort = 1;                           // OW_PA_SORT: 0 never, 1 when the block exceeds the chip, 2 always
     int eout_attn = -1;                        // OW_EOUT_ATTN=0/1: status summary instead of the status blocks (k_eout_attention); -1: ranges of >= 8 192 engines
     int pipe = 0;                              // OW_PIPE=n stages
+    int chain_stream = -1;                     // OW_CHAIN_STREAM=0/1: preamp + output stage of a big oversampled pool as one launch (k_chain_stream); -1: when the block goes to a pinned host block
+    int out_direct = -1;                       // OW_OUT_DIRECT=0/1: output stage stores straight into a pinned host block (ow_host_alloc) instead of d_out + copy; -1: default
     bool pipe_overlap = false;
     bool host_profile = false;
     int midi_threads = 0;                      // OW_MIDI_THREADS
@@ -215,6 +237,8 @@ struct Switches {
         w.pa_sort = flag("OW_PA_SORT", 1); if (w.pa_sort < 0 || w.pa_sort > 2) w.pa_sort = 1;
         if (const char* e = std::getenv("OW_PIPE")) { const int v = std::atoi(e); w.pipe = (v >= 1 && v <= 8) ? v : 0; }
         w.pipe_overlap = flag("OW_PIPE_OVERLAP", 0) == 1;
+        w.chain_stream = flag("OW_CHAIN_STREAM", -1); if (w.chain_stream > 1 || w.chain_stream < -1) w.chain_stream = -1;
+        w.out_direct = flag("OW_OUT_DIRECT", -1); if (w.out_direct > 1 || w.out_direct < -1) w.out_direct = -1;
         w.host_profile = std::getenv("OW_HOST_PROFILE") != nullptr;
         if (const char* e = std::getenv("OW_MIDI_THREADS")) { const long v = std::atol(e); if (v >= 1 && v <= 64) w.midi_threads = (int)v; }
         return w;
@@ -1293,7 +1317,12 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
     if (voices && p->vl_steady.n_blocks) HIP_OK(hipMemsetAsync(p->d_skew_seen, 0, sizeof(uint32_t), st));
     if (NP > 1) HIP_OK(hipEventRecord(p->ev_ready, st));      // args, ops and voice lists are in place
     const bool tabs = (size_t)p->vl_general.n_blocks * 4 < (size_t)ne;   // sparse general list (played input): tabulated phase gains
+    // A target inside a pinned block of ow_host_alloc is written by the output stage itself (it is mapped into the device's address space)
+    float* out_direct = nullptr;
+    if (out_host && p->sw.out_direct != 0 && out_stride >= len && ne > 0)
+        out_direct = (float*)host_block_device_ptr(out_host, sizeof(float) * ((size_t)(ne - 1) * out_stride + len));
     for (int k = 0; k < NP; ++k) {
+        bool direct_done = false;
         hipStream_t s = p->pipe_stream[k];                    // [0] == st
         const int t0 = k * p->slice_T / NP, t1 = (k + 1) * p->slice_T / NP;
         const int se0 = NP == 1 ? e0 : e0 + std::min(ne, t0 * p->slice_per);
@@ -1330,11 +1359,19 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         if (traj_ready) HIP_OK(hipStreamWaitEvent(s, traj_ready, 0));
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][2], s));
         const bool fused = chain && sne > 0 && chain_fused(p, sne);
+        // k_chain_stream (ow_chain_stream.h): legacy preamp + behavioural amp, oversampled chain, pools too big for the quad kernels.
+        // Default: when the block goes to a pinned host block (the point of it: no copy trails the launch); OW_CHAIN_STREAM=1 always.
+        const bool streamed = chain && !fused && sne > 0 && p->hc.oversample && p->hc.preamp_kind == OW_PREAMP_LEGACY8 && p->power_amp_kind == OW_POWER_AMP_BEHAVIORAL &&
+                              !preamp_wide(p, sne) && (p->sw.chain_stream < 0 ? out_direct != nullptr : p->sw.chain_stream == 1);
         if (fused) {           // small pool: preamp and output stage as two wavefronts of one workgroup (ow_chain_wide.h)
             if (p->hc.oversample)
                 owdev::k_chain_fused<true><<<dim3((sne + 7) / 8), dim3(128), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, tsrc, p->d_pre, p->d_out, I, L, Lcap, L, se0, sne);
             else
                 owdev::k_chain_fused<false><<<dim3((sne + 7) / 8), dim3(128), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, tsrc, p->d_pre, p->d_out, I, L, Lcap, L, se0, sne);
+        } else if (sne > 0 && chain && streamed) {   // big oversampled pool: preamp and output stage alternate per 64-sample chunk in one launch, rows stored
+            float* o2 = out_direct ? out_direct + (size_t)(se0 - e0) * out_stride : nullptr;      // straight into the caller's pinned block
+            owdev::k_chain_stream<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, tsrc, p->d_pre, p->d_out, I, L, Lcap, L, se0, sne, o2, out_stride);
+            direct_done = o2 != nullptr;
         } else if (sne > 0 && chain) {
             if (p->hc.preamp_kind == OW_PREAMP_MELANGE12 && !melange_rank_one(p) && p->hc.ml_sparse_ok && !melange_lds_matrix(p) && melange_lane_engine(p, sne))
                 owdev::k_preamp_mel_eng<<<dim3((sne + 63) / 64), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_mel_settled, p->d_args, p->d_eout, p->d_sum, tsrc,
@@ -1356,8 +1393,8 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
                 owdev::k_preamp<<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, tsrc, p->d_pre, I, L, Lcap, se0, sne);
         }
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][3], s));
-        if (!chain || fused) {
-            // voice sums only / the output stage ran inside k_chain_fused
+        if (!chain || fused || streamed) {
+            // voice sums only / the output stage ran inside k_chain_fused or k_chain_stream
         } else if (sne > 0 && p->power_amp_kind == OW_POWER_AMP_MELANGE) {
             // more engines than one workgroup: dispatch them by falling demand of their last block (see k_post_mpa)
             // -- when the block has more engines than the chip holds at once (two workgroups of 32 per CU); below that every wavefront
@@ -1374,14 +1411,16 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
             owdev::k_post_mpa<<<dim3((sne + PA_EPB - 1) / PA_EPB), dim3(PA_WPB * 64), 0, s>>>(p->dK, p->dPa, p->d_pa_settled, p->d_cs, p->d_pa, p->d_args, p->d_eout, p->d_pre, p->d_out,
                                                                           p->d_pa_tap, I, L, L, se0, sne, ordered ? p->d_pa_order : nullptr, p->d_pa_demand);
         } else if (sne > 0) {
+            float* o2 = out_direct ? out_direct + (size_t)(se0 - e0) * out_stride : nullptr;
             if (p->hc.oversample)
-                owdev::k_post<true><<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, L, se0, sne);
+                owdev::k_post<true><<<dim3((sne + 31) / 32), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, L, se0, sne, o2, out_stride);
             else
-                owdev::k_post<false><<<dim3((sne + 63) / 64), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, L, se0, sne);
+                owdev::k_post<false><<<dim3((sne + 63) / 64), dim3(64), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_pre, p->d_out, I, L, L, se0, sne, o2, out_stride);
+            direct_done = o2 != nullptr;
         }
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][4], s));
         if (!overlap && k + 1 < NP) HIP_OK(hipEventRecord(p->ev_voice_done[k], s));   // the next stage computes while this one's rows are copied
-        if (out_host && sne > 0) {        // the stage's rows go out while the later stages still compute
+        if (out_host && sne > 0 && !direct_done) {        // the stage's rows go out while the later stages still compute
             float* dst = out_host + (size_t)(se0 - e0) * out_stride;
             const float* src = p->d_out + (size_t)se0 * len;
             if (out_stride == len) HIP_OK(hipMemcpyAsync(dst, src, sizeof(float) * len * (size_t)sne, hipMemcpyDeviceToHost, s));
@@ -1964,6 +2003,9 @@ void ow_pool_render(ow_pool* p, float* out_host, size_t out_stride, size_t len) 
         p->last_len = len;
     });
     if (!ok) {
+        // queued note events / setter targets of engines the failed render did not get to pack must survive: the next block scans again
+        __atomic_store_n(&p->dirty_any, (uint8_t)1, __ATOMIC_RELAXED);
+        p->args_stale = true; p->lists_valid = false;
         // "never fails, degrades to silence" (engine.rs:450-458 does the same for numeric failure): every row of the
         // caller's block is written.  Drain the stream first so that an output copy already queued cannot land after the zeros.
         for (int k = 0; k < OW_MAX_STAGES; ++k) if (p->pipe_stream[k]) hipStreamSynchronize(p->pipe_stream[k]);
@@ -2556,6 +2598,8 @@ int ow_test_pool_set_switch(ow_pool* p, const char* name, int value) {
     else if (n == "voice_skew") w.voice_skew = value != 0;
     else if (n == "pa_sort") { if (value < 0 || value > 2) return -1; w.pa_sort = value; }
     else if (n == "host_profile") w.host_profile = value != 0;
+    else if (n == "out_direct") w.out_direct = value < 0 ? -1 : (value != 0);
+    else if (n == "chain_stream") w.chain_stream = value < 0 ? -1 : (value != 0);
     else return -1;                                       // (trem_traj / trem_cache / pipe shape the pool at creation: environment only)
     return 0;
 }
@@ -2577,6 +2621,8 @@ int ow_test_pool_get_switch(const ow_pool* p, const char* name) {
     if (n == "pa_sort") return w.pa_sort;
     if (n == "trem_traj") return p->traj ? 1 : 0;
     if (n == "trem_cache") return w.trem_cache;
+    if (n == "out_direct") return w.out_direct;
+    if (n == "chain_stream") return w.chain_stream;
     return -2;
 }
 // Engines of the pool that read the shared trajectory / samples the store of the pool's rate holds (produced or enqueued) / its capacity.
@@ -2669,7 +2715,7 @@ int ow_debug_div_forms(int mode, const double* a, const double* b, const double*
 
 int ow_debug_unary(int which, const double* x, size_t n, double* fast, double* lib, int device) {
     try {
-        if (!x || !fast || !lib || which < 0 || which > 4) throw std::runtime_error("null argument or unknown function");
+        if (!x || !fast || !lib || which < 0 || which > 5) throw std::runtime_error("null argument or unknown function");
         if (n == 0) return 0;
         HIP_OK(hipSetDevice(device));
         DevMem dx, df, dl;
@@ -2826,11 +2872,16 @@ void ow_device_free(void* ptr, int device) {
 
 void* ow_host_alloc(size_t bytes, int device) {
     void* ptr = nullptr;
-    if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&ptr, bytes ? bytes : 1) != hipSuccess) { set_err("ow_host_alloc: hipHostMalloc failed"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&ptr, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { set_err("ow_host_alloc: hipHostMalloc failed"); return nullptr; }
+    void* dptr = nullptr;
+    if (hipHostGetDevicePointer(&dptr, ptr, 0) != hipSuccess) dptr = nullptr;
+    try { host_block_register(ptr, bytes ? bytes : 1, dptr); } catch (...) {}
     return ptr;
 }
 void ow_host_free(void* ptr, int device) {
-    if (ptr && hipSetDevice(device) == hipSuccess) hipHostFree(ptr);
+    if (!ptr) return;
+    host_block_forget(ptr);
+    if (hipSetDevice(device) == hipSuccess) hipHostFree(ptr);
 }
 
 // ---- ML-pipeline stage after the batch render ---------------------------------------------------------------

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64) OW_VOICE_GENERAL_ATTR void k_voice(const OwCons
                 for (int q = lane; q < cn * 7; q += 64) {
                     const int i = q / 7, md = q - 7 * i;
                     const double t = d0 + (double)(i + 1);      // dcount after this sample's increment (exact: a sample count)
-                    dtab[(r * CH + i) * 7 + md] = exp_neg(lcoef[(5 + md) * 64 + l] * t / dr);
+                    dtab[(r * CH + i) * 7 + md] = exp_neg_small(lcoef[(5 + md) * 64 + l] * damper_ramp_pos(t, dr));
                 }
             }
         }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64) OW_VOICE_GENERAL_ATTR void k_voice(const OwCons
                 if (pass) {  // 5 ms linear crossfade, engine.rs:483-489
                     const uint32_t i = (uint32_t)(base + n);
                     const uint32_t remaining = steal_fade > i ? steal_fade - i : 0u;
-                    o = o * ((double)remaining / (double)steal_len);
+                    o = o * ow_div((double)remaining, (double)steal_len);       // (= the IEEE quotient, tests/test_gpu_division.py)
                 }
             }
             tile[lane * (CH + 1) + n] = o;
@@ -1003,7 +1003,9 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
 template <bool SPLIT>
 __global__ __launch_bounds__(64) void k_post(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args,
                                              OwEngineOut* __restrict__ eout, const double* __restrict__ pre, float* __restrict__ out, int I, int L,
-                                             int Lcap, int e0, int ne) {
+                                             int Lcap, int e0, int ne, float* __restrict__ out2 = nullptr, size_t ld2 = 0) {
+    // out2 / ld2: a second copy of the block, rows at stride ld2 with row 0 = engine e0 -- the caller's pinned host block, mapped into the
+    // device's address space (render_range), so that no device-to-host copy trails the kernel
     constexpr int NROWS = SPLIT ? 32 : 64;
     __shared__ float tile[NROWS * (OW_OCHUNK + 1)];
     const int lane = threadIdx.x;
@@ -1067,7 +1069,11 @@ __global__ __launch_bounds__(64) void k_post(const OwConsts* __restrict__ K, dou
         __syncthreads();
         for (int r = 0; r < NROWS; ++r) {
             const int er = eb + r;
-            if (er < e0 + ne && lane < cn) out[(size_t)er * Lcap + base + lane] = tile[r * (OW_OCHUNK + 1) + lane];
+            if (er < e0 + ne && lane < cn) {
+                const float f = tile[r * (OW_OCHUNK + 1) + lane];
+                out[(size_t)er * Lcap + base + lane] = f;
+                if (out2) out2[(size_t)(er - e0) * ld2 + base + lane] = f;
+            }
         }
         __syncthreads();
     }

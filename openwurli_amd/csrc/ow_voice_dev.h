@@ -461,6 +461,32 @@ __device__ __noinline__ __attribute__((const)) double onset_gain(double n, doubl
 #endif
 }
 __device__ __noinline__ __attribute__((const)) double exp_neg(double x) { return exp(-x); }                         // reed.rs:238
+// exp(-x) for the damper ramp's per-sample factors (reed.rs:236-239): x = damper_rate * t / ramp <= damper_rate = min(55 * 2^((n-60)/24)
+// * 3^m, 2000) / sr (reed.rs:198-201), i.e. 0 <= x <= 0.0454 at 44.1 kHz.  On [0, 1/8] no range reduction is needed: the degree-11 Taylor
+// polynomial in Horner form (fused steps) has a truncation error of x^12 / 12! <= 3e-20 and ends in fma(y, p, 1.0), one rounding of a
+// value in (0.88, 1]: within 0.52 ulp of exp(-x), where the library's exp (the same kind of polynomial behind a reduction by ln 2, an
+// ldexp and overflow / underflow selects: ~45 instructions behind a call, seven times per sample of every released voice for the 8-50 ms
+// of its ramp -- the cost of a whole-keyboard re-strike's steal pass) is specified to 1 ulp, like the reference's f64::exp (glibc).
+// Larger arguments (host rates below 16 kHz) take the library.  tests/test_gpu_division.py::test_damper_ramp_exp_accuracy.
+OW_DEV double exp_neg_poly(double x) {          // 0 <= x <= 1/8
+    const double y = -x;
+    double p = __builtin_fma(y, 2.50521083854417187751e-08, 2.75573192239858906526e-07);       // 1/11!, 1/10!
+    p = __builtin_fma(y, p, 2.75573192239858906526e-06);                                        // 1/9!
+    p = __builtin_fma(y, p, 2.48015873015873015873e-05);                                        // 1/8!
+    p = __builtin_fma(y, p, 1.98412698412698412698e-04);                                        // 1/7!
+    p = __builtin_fma(y, p, 1.38888888888888888889e-03);                                        // 1/6!
+    p = __builtin_fma(y, p, 8.33333333333333333333e-03);                                        // 1/5!
+    p = __builtin_fma(y, p, 4.16666666666666666667e-02);                                        // 1/4!
+    p = __builtin_fma(y, p, 1.66666666666666666667e-01);                                        // 1/3!
+    p = __builtin_fma(y, p, 0.5);
+    p = __builtin_fma(y, p, 1.0);
+    return __builtin_fma(y, p, 1.0);
+}
+OW_DEV double exp_neg_small(double x) { return __builtin_expect(!(x <= 0.125), 0) ? exp_neg(x) : exp_neg_poly(x); }
+// The instantaneous damper rate of reed.rs:237, `damper_rate * t / ramp`, as damper_rate * (t / ramp): ONE division per sample for the
+// seven modes instead of seven.  The two roundings swap places (<= 1 ulp of an x <= 0.045: 6e-18 relative on exp(-x), a twentieth of
+// that function's own half-ulp).
+OW_DEV double damper_ramp_pos(double t, double ramp) { return ow_div(t, ramp); }
 __device__ __noinline__ __attribute__((const)) double noise_fade_env(double t) { return 0.5 * (1.0 - cos(3.14159265358979323846 * t)); }  // hammer.rs:165
 // (one argument: with |y| passed in, the caller materialises it -- two instructions -- on every sample, ahead of the branch that is
 // taken once in a blue moon)
@@ -567,10 +593,13 @@ struct VoiceRegs {
 #pragma unroll
                         for (int m = 0; m < 7; ++m) env[m] *= damp_tab[m];
                     } else {
+                        const double tr = damper_ramp_pos(t, dramp);
+                        // damper_rate rises with the mode number (reed.rs:198-201) and t <= ramp: mode 6 decides for all seven
+                        if (__builtin_expect(!(lcoef[11 * 64] <= 0.125), 0)) {
+                            for (int m = 0; m < 7; ++m) env[m] *= exp_neg(lcoef[(5 + m) * 64] * tr);
+                        } else {
 #pragma unroll
-                        for (int m = 0; m < 7; ++m) {
-                            const double inst_rate = lcoef[(5 + m) * 64] * t / dramp;
-                            env[m] *= exp_neg(inst_rate);
+                            for (int m = 0; m < 7; ++m) env[m] *= exp_neg_poly(lcoef[(5 + m) * 64] * tr);
                         }
                     }
                 }
@@ -604,13 +633,19 @@ struct VoiceRegs {
             c[m] = c_new;
             env[m] *= decay[m];
         }
-        if ((lo & 1023u) == 0u && sample > 0ull) {
+        // (a real branch: written as a plain `if` the compiler predicates the seven square roots and divisions -- ~130 instructions -- into
+        // every sample of the general loop; one lane in 1 024 is due)
+        const bool renorm_due = (lo & 1023u) == 0u && sample > 0ull;
+        if (__builtin_amdgcn_ballot_w64(renorm_due) != 0ull) {
+            asm volatile("" ::: "memory");       // not speculated
+            if (renorm_due) {
 #pragma unroll
-            for (int m = 0; m < 7; ++m) {
-                const double r_sq = s[m] * s[m] + c[m] * c[m];
-                const double r_inv = 1.0 / sqrt(r_sq);
-                s[m] *= r_inv;
-                c[m] *= r_inv;
+                for (int m = 0; m < 7; ++m) {
+                    const double r_sq = s[m] * s[m] + c[m] * c[m];
+                    const double r_inv = 1.0 / sqrt(r_sq);
+                    s[m] *= r_inv;
+                    c[m] *= r_inv;
+                }
             }
         }
         sample += 1ull;

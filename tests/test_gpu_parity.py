@@ -987,6 +987,65 @@ def test_chain_fused_is_bit_identical(hiplib, oracle):
     g.close(); c.close()
 
 
+def test_chain_stream_is_bit_identical(hiplib, oracle):
+    """Big oversampled pools whose block goes to a pinned host block run preamp and output stage as ONE launch (k_chain_stream,
+    ow_chain_stream.h: one wavefront per 32 engines alternates between the two per 64-sample chunk and stores the f32 rows straight into
+    the caller's mapped block) instead of k_preamp, k_post and a device-to-host copy behind them.  Same bits at the preamp tap and at the
+    output as the two launches -- tremolo, depth / volume / speaker-character ramps, a reset, the steal pass, ragged block lengths incl.
+    1 and lengths that are no multiple of the chunk, an output NaN guard event and the blocks after it; 70 engines = two full workgroups
+    and a ragged third.  The host block (row stride larger than the block) equals the block left in HBM."""
+    import ctypes
+    import openwurli_amd as ow
+    lengths = (512, 300, 1, 17, 64, 65, 15, 777, 512, 33)
+    sr, n = 48000.0, 70
+    res = {}
+    stride = 800
+    for streamed in (0, 1):
+        g = ow.EnginePool(sr, n)
+        g.set_sample_rate(sr)
+        g.ensure_buffer_capacity(1024)
+        g.set_switch("preamp_wide", 0); g.set_switch("chain_fused", 0)
+        g.set_switch("chain_stream", streamed); g.set_switch("out_direct", streamed)
+        assert g.get_switch("chain_stream") == streamed
+        host = g.alloc_host_block(stride)
+        hview = np.ctypeslib.as_array((ctypes.c_float * (n * stride)).from_address(host[0])).reshape(n, stride)
+        for k in range(n):
+            g[k].set_tremolo_depth(0.013 * k); g[k].set_volume(0.3 + 0.005 * k); g[k].set_speaker_character(0.014 * k)
+            for note in (40 + k % 30, 60 + k % 11, 72):
+                g[k].note_on(note, 0.5 + 0.006 * k)
+        outs, pres, diags = [], [], []
+        for b, length in enumerate(lengths):
+            if b == 3:
+                g[4].set_tremolo_depth(1.0); g[37].note_on(60 + 7, 1.0); g[65].set_speaker_character(1.0)
+                for note in range(33, 97):
+                    g[33].note_on(note, 0.6)
+            if b == 4:
+                for note in range(33, 97):                  # the steal pass
+                    g[33].note_off(note); g[33].note_on(note, 0.7)
+            if b == 5:
+                g[69].set_volume(1e308)                     # a non-finite output -> NaN guard
+            if b == 6:
+                g[2].reset(); g[2].note_on(55, 0.9); g[69].set_volume(0.5)
+            hview[:] = -7.0
+            g.render_into(host[0], stride, length)
+            blk = g.last_block()[:, :length].copy()
+            assert np.array_equal(hview[:, :length], blk), (streamed, b, "host block")
+            assert np.all(hview[:, length:] == -7.0)
+            outs.append(blk)
+            pres.append(g.preamp_out(length * 2).copy())
+            diags.append([(g[k].diag().output_nan_resets, g[k].diag().preamp_nan_resets) for k in (2, 69)])
+        res[streamed] = (outs, pres, diags)
+        g.free_host_block(host)
+        g.close()
+    for b in range(len(lengths)):
+        assert np.array_equal(res[0][1][b], res[1][1][b]), (b, "preamp tap")
+        assert np.array_equal(res[0][0][b], res[1][0][b]), (b, "output")
+        assert res[0][2][b] == res[1][2][b], (b, "diag")
+    assert res[1][2][-1][1][0] >= 1                                # the guard did fire on engine 69
+    assert all(np.all(np.isfinite(o)) for o in res[1][0])
+    assert max(float(np.max(np.abs(o))) for o in res[1][0]) > 1e-3
+
+
 def test_skewed_voice_clocks_are_bit_identical(hiplib, oracle):
     """k_voice_steady<true> (ow_kernels.h): voices struck at different samples update their jitter on different 16-sample grids; the skewed
     variant delays each lane by 0..15 loop trips so that all updates of a wavefront share trips.  Every voice performs the operations it
