@@ -106,10 +106,18 @@ int ow_pool_read_tremolo_r(ow_pool*, double* out_host, size_t out_stride, size_t
  * state (:83-102,:192-216), so its resistance r_ldr[t] is one sequence per chain rate.  The library computes it once per (device, chain
  * rate) into HBM -- the engine with the largest t extends it with a single oscillator, every engine of every pool of the process reads it
  * at its own t -- instead of one oscillator per engine.  Bit-identical to per-engine oscillators (tests/test_gpu_trajectory.py).
- * OW_TREM_TRAJ_SECONDS (default 1800) sizes the store when it is first used; an engine that runs longer without reset continues on an
- * oscillator of its own.  OW_TREM_TRAJ=0 when a pool is created: no trajectory for that pool.
- * ow_tremolo_prefetch: make the first `seconds` of the trajectory for host rate `sample_rate` exist now (blocking; a host would call it
- * where it instantiates the plugin).  Returns the samples the store holds, <0 on error. */
+ * The store runs ahead of its oldest reader in the background from the moment it exists (Tremolo::new settles inside the constructor,
+ * tremolo.rs:83-102: nothing for the host to call), a lead of 60 s of audio by default, on its own stream, one wavefront.  Its buffers
+ * start at 150 s of audio (115 MB at 96 kHz; pools of >= 4 096 engines take the whole capacity at once) and double on a helper thread
+ * long before a reader gets to their end; an engine older than the capacity (default 1 800 s since its new / reset / set_sample_rate)
+ * continues on an oscillator of its own -- same samples, one oscillator per such engine.  OW_TREM_TRAJ=0 when a pool is created: no
+ * trajectory for that pool.
+ * ow_tremolo_configure: capacity and lead, in seconds of audio, of the stores of `device` (<= 0 / < 0: back to the defaults, which
+ * OW_TREM_TRAJ_SECONDS / OW_TREM_TRAJ_LEAD_SECONDS override).  Applies to stores created afterwards and re-limits the existing ones
+ * (never below what they hold).  Nothing is reserved by this call.  0 on success.
+ * ow_tremolo_prefetch: make the first `seconds` of the trajectory for host rate `sample_rate` exist now (blocking; optional -- a host
+ * that wants its first block after instantiation to find everything in place).  Returns the samples known complete, <0 on error. */
+int ow_tremolo_configure(int device, double capacity_seconds, double lead_seconds);
 long long ow_tremolo_prefetch(double sample_rate, int device, double seconds);
 /* HIP stream the pool launches on (hipStream_t as void*), for event timing by the caller. */
 void* ow_pool_stream(ow_pool*);

@@ -122,6 +122,9 @@ int ow_test_pool_get_switch(const ow_pool*, const char* name);
 /* out[0] = engines of the pool reading the shared tremolo trajectory, out[1] = samples its store holds (produced or enqueued),
  * out[2] = the store's capacity in samples. */
 int ow_test_pool_trajectory_info(const ow_pool*, uint64_t out[3]);
+/* The store behind the pool, in samples: [0] produced or enqueued, [1] known complete, [2] held by its buffers now, [3] configured capacity,
+ * [4] t of the pool's oldest engine on it. */
+int ow_test_pool_trajectory_state(const ow_pool*, uint64_t out[5]);
 
 /* ---- fault injection ------------------------------------------------------------------------ */
 /* The next n_renders calls of ow_pool_render / ow_engine_render on this pool fail before their first launch, exactly as a HIP

@@ -107,6 +107,7 @@ SYMBOLS = {
     "ow_pool_read_preamp_out": (C.c_int, [_VP, _VP, C.c_size_t, C.c_size_t]),
     "ow_pool_read_tremolo_r": (C.c_int, [_VP, _VP, C.c_size_t, C.c_size_t]),
     "ow_tremolo_prefetch": (C.c_longlong, [C.c_double, C.c_int, C.c_double]),
+    "ow_tremolo_configure": (C.c_int, [C.c_int, C.c_double, C.c_double]),
     "ow_pool_stream": (_VP, [_VP]),
     "ow_pool_set_profiling": (None, [_VP, C.c_int]),
     "ow_pool_last_kernel_ms": (None, [_VP, C.POINTER(C.c_float)]),
@@ -179,6 +180,7 @@ TEST_SYMBOLS = {
     "ow_test_pool_set_switch": (C.c_int, [_VP, C.c_char_p, C.c_int]),
     "ow_test_pool_get_switch": (C.c_int, [_VP, C.c_char_p]),
     "ow_test_pool_trajectory_info": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
+    "ow_test_pool_trajectory_state": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "ow_test_host_melange_paths": (C.c_int, [C.c_double]),
     "ow_test_device_read": (C.c_int, [_VP, _VP, C.c_size_t, C.c_int]),
     "ow_test_engine_poke_voice": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_double]),

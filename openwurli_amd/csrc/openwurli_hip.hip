@@ -214,6 +214,7 @@ struct Switches {
     int pa_sort = 1;                           // OW_PA_SORT: 0 never, 1 when the block exceeds the chip, 2 always
     int eout_attn = -1;                        // OW_EOUT_ATTN=0/1: status summary instead of the status blocks (k_eout_attention); -1: ranges of >= 8 192 engines
     int pipe = 0;                              // OW_PIPE=n stages
+    bool force_general = false;                // test / probe hook: every engine's slot voices go to the general voice kernel (what it costs without any phase active)
     int chain_stream = -1;                     // OW_CHAIN_STREAM=0/1: preamp + output stage of a big oversampled pool as one launch (k_chain_stream); -1: when the block goes to a pinned host block
     int out_direct = -1;                       // OW_OUT_DIRECT=0/1: output stage stores straight into a pinned host block (ow_host_alloc) instead of d_out + copy; -1: default
     bool pipe_overlap = false;
@@ -414,6 +415,7 @@ struct ow_pool {
     size_t n_on_traj = 0;
     std::vector<long long> h_birth;   // [I]
     long long* d_birth = nullptr;
+    unsigned long long* d_evict = nullptr;   // [3][I] scratch of trem_evict (engine list, positions, fallback counts): render never allocates
     long long last_n_os = 0;          // chain-rate samples of the last rendered block (ow_pool_read_tremolo_r)
     Switches sw;                      // latched at creation
     bool voices_only = false;         // ow_render_note: the pool renders voice sums only -- no chain state, no tremolo / preamp / output kernels
@@ -574,27 +576,63 @@ TremSettled trem_settled_rows(int device, double os_sr, const OwConsts* dK, cons
 struct TremTraj {
     int device = 0;
     double os_sr = 0.0;
-    std::mutex mu;                    // guards len / marks / enqueues on `stream`; held for host-side enqueue work only
+    std::mutex mu;                    // guards len / cap / buffers / marks / enqueues on `stream`; held for host-side enqueue work only
     OwConsts* dK = nullptr;           // constants at the chain rate (the tremolo fields are all the kernels read)
     double* d_r = nullptr;            // [cap + 64]
     double* d_state = nullptr;        // [18] oscillator rows at sample `len`
     double* d_ckpt = nullptr;         // [cap / OW_TRAJ_CK + 2][OW_TRAJ_CKD]
     unsigned long long* d_be = nullptr;   // [1 + OW_TRAJ_BE_CAP]
     uint32_t* d_zero = nullptr;       // leaders = {0} for the settle kernels
-    size_t cap = 0, len = 0;          // len: samples produced or enqueued for production
+    size_t cap = 0, len = 0;          // cap: samples the buffers hold; len: samples produced or enqueued for production
+    size_t cap_max = 0;               // configured capacity (ow_tremolo_configure / OW_TREM_TRAJ_SECONDS): the buffers grow up to it, an engine
+                                      // older than this leaves the store (trem_evict)
+    size_t lead = 0;                  // samples the store is kept ahead of a fast reader (a small pool) by the feeder thread
+    size_t target = 0;                // where the feeder is taking the store (<= cap)
+    size_t reader_end = 0, reader_block = 1024;   // furthest sample a fast reader asked for, and its block (feeder back-off)
+    std::chrono::steady_clock::time_point reader_seen{};
     size_t done = 0;                  // samples known to be complete (a recorded mark was seen finished)
     uint64_t be_settle = 0;           // fallbacks the settle itself counted (what a fresh CircuitState carries after Tremolo::new)
     hipStream_t stream = nullptr;
     static constexpr int NMARK = 16;
     struct Mark { size_t end = 0; hipEvent_t ev = nullptr; } mark[NMARK];
     int head = 0;
+    bool grow_requested = false;      // the helper thread has been asked to double the buffers
+    std::vector<void*> retired;       // buffers a growth replaced: kernels launched before the swap may still read them, so they are only
+                                      // freed at the NEXT growth (minutes of audio later) or with the store
     ~TremTraj() {
         hipSetDevice(device);
         if (stream) hipStreamSynchronize(stream);
         for (auto& m : mark) if (m.ev) hipEventDestroy(m.ev);
         if (dK) hipFree(dK); if (d_r) hipFree(d_r); if (d_state) hipFree(d_state); if (d_ckpt) hipFree(d_ckpt);
+        for (void* q : retired) hipFree(q);
         if (d_be) hipFree(d_be); if (d_zero) hipFree(d_zero);
         if (stream) hipStreamDestroy(stream);
+    }
+    static size_t ckpt_doubles(size_t c) { return (size_t)OW_TRAJ_CKD * (c / OW_TRAJ_CK + 2); }
+    // Buffers for `new_cap` samples: allocate (no lock held: hipMalloc may take milliseconds), then under the lock copy what exists on the
+    // store's stream -- behind every extension already enqueued -- and swap.  Readers that fetch the new pointer wait for the copy's mark.
+    void grow_to(size_t new_cap) {
+        new_cap = std::min((new_cap + OW_TRAJ_CK - 1) / OW_TRAJ_CK * OW_TRAJ_CK, cap_max);
+        { std::lock_guard<std::mutex> lk(mu); if (new_cap <= cap) { grow_requested = false; return; } }
+        HIP_OK(hipSetDevice(device));
+        double* nr = nullptr; double* nc = nullptr;
+        HIP_OK(hipMalloc(&nr, sizeof(double) * (new_cap + 64)));
+        if (hipMalloc(&nc, sizeof(double) * ckpt_doubles(new_cap)) != hipSuccess) { hipFree(nr); throw std::runtime_error("trajectory store: out of memory"); }
+        std::lock_guard<std::mutex> lk(mu);
+        if (new_cap <= cap) { hipFree(nr); hipFree(nc); grow_requested = false; return; }
+        for (void* q : retired) hipFree(q);            // replaced one growth ago
+        retired.clear();
+        HIP_OK(hipMemcpyAsync(nr, d_r, sizeof(double) * (len + 64 <= cap + 64 ? len + 64 : cap + 64), hipMemcpyDeviceToDevice, stream));
+        HIP_OK(hipMemcpyAsync(nc, d_ckpt, sizeof(double) * ckpt_doubles(cap), hipMemcpyDeviceToDevice, stream));
+        Mark& m = mark[head];
+        head = (head + 1) % NMARK;
+        HIP_OK(hipEventRecord(m.ev, stream));
+        m.end = len;
+        retired.push_back(d_r); retired.push_back(d_ckpt);
+        d_r = nr; d_ckpt = nc; cap = new_cap;
+        done = 0;                                      // everything has to be waited for again (the copy)
+        for (Mark& o : mark) if (&o != &m && o.end <= len) o.end = 0;     // older marks stand for data in the old buffer
+        grow_requested = false;
     }
     // callers hold mu
     void extend_to(size_t end) {
@@ -608,10 +646,21 @@ struct TremTraj {
         m.end = end;
         len = end;
     }
-    // Make samples [0, end) exist (enqueue what is missing on the store's stream), then keep the store `ahead` samples further.  Returns
-    // the event a consumer stream has to wait for before it reads them, or nullptr when they are known to be complete.  (The event may
-    // be re-recorded by a later extension before the consumer waits on it: it then stands for a longer prefix -- still sufficient.)
-    hipEvent_t cover(size_t end, size_t ahead) {
+    // extension launches not known to have finished (their marks)
+    int in_flight() {
+        int n = 0;
+        for (Mark& m : mark) if (m.end > done) { if (hipEventQuery(m.ev) == hipSuccess) done = std::max(done, m.end); else ++n; }
+        return n;
+    }
+    // Make samples [0, end) exist (enqueue what is missing on the store's stream), then keep the store `ahead` samples further (one block:
+    // what the next render will ask for).  lead_for > 0: the caller is a reader that can outrun real time (a small pool): the store's
+    // target moves to end + lead_for and the feeder thread (TrajGrower) keeps the oscillator running towards it -- two short launches in
+    // flight at a time, whether or not anybody renders meanwhile.  (Deep queues do not work here: a consumer stream that waits for a mark
+    // of this stream was measured to resume only when everything enqueued on it had finished -- with a second of oscillator steps queued,
+    // every block of a pool at the frontier waited 0.4 s.)  Returns true in *feed when the feeder has something new to do.
+    // Returns the event a consumer stream has to wait for before it reads [0, end), or nullptr when they are known to be complete.  (The
+    // event may be re-recorded by a later extension before the consumer waits on it: it then stands for a longer prefix -- still sufficient.)
+    hipEvent_t cover(size_t end, size_t ahead, size_t lead_for = 0, bool* feed = nullptr) {
         end = std::min(end, cap);
         extend_to(end);
         hipEvent_t wait = nullptr;
@@ -624,12 +673,37 @@ struct TremTraj {
             }
         }
         if (ahead) extend_to(end + ahead);
+        if (lead_for) {
+            const size_t t = std::min(end + lead_for, cap);
+            if (t > target) { target = t; if (feed && len < target) *feed = true; }
+            reader_end = std::max(reader_end, end);
+            if (ahead) reader_block = ahead;
+            reader_seen = std::chrono::steady_clock::now();
+        }
         return wait;
     }
+    // Feeder thread: one more short launch towards `target` when fewer than two are in flight; true while there is more to do.
+    // It stands back while a reader renders right behind the frontier (a pool that outruns the oscillator): such a reader enqueues exactly
+    // the block ahead it needs (`ahead` above), and anything the feeder put in front of that would only be more for it to wait for.  The
+    // lead is built whenever readers are further back or idle -- between a host's instantiation and its first block, between blocks of
+    // a host paced at real time.
+    bool feed_step() {
+        std::lock_guard<std::mutex> lk(mu);
+        const size_t t = std::min(target, cap);
+        if (len >= t) return false;
+        const bool reader_active = reader_end > 0 && std::chrono::steady_clock::now() - reader_seen < std::chrono::milliseconds(20);
+        if (reader_active && len < reader_end + 8 * reader_block) return true;
+        if (in_flight() < 2) extend_to(std::min(len + 2048, t));
+        return len < t;
+    }
+    // the store should soon be longer than its buffers are (callers hold mu)
+    bool wants_growth(size_t end) const { return cap < cap_max && !grow_requested && std::max(end, target) + (size_t)(30.0 * os_sr) > cap; }
     // the recorded fallback events ([0] = count, [1 + k] = sample index), one transfer however many engines ask
+    // No wait for the store's stream (the background extension keeps it busy for seconds at a time): whoever asks stands at a t whose
+    // samples a FINISHED launch produced, so the events below t are in memory; entries a running launch has counted but not yet written
+    // read as ~0 (the list is initialised to all ones) and lie above every t.
     std::vector<unsigned long long> be_events() {
         std::vector<unsigned long long> h(1 + OW_TRAJ_BE_CAP, 0ull);
-        if (hipStreamSynchronize(stream) != hipSuccess) return h;      // (no lock: a render on another thread must not wait behind an inspection call)
         if (hipMemcpy(h.data(), d_be, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost) != hipSuccess) std::fill(h.begin(), h.end(), 0ull);
         return h;
     }
@@ -637,7 +711,7 @@ struct TremTraj {
     uint64_t be_count_at(long long t, const std::vector<unsigned long long>& h) const {
         uint64_t n = be_settle;
         const size_t k = (size_t)std::min<unsigned long long>(h[0], OW_TRAJ_BE_CAP);
-        for (size_t i = 0; i < k; ++i) n += (long long)h[1 + i] < t;
+        for (size_t i = 0; i < k; ++i) n += h[1 + i] < (unsigned long long)std::max<long long>(t, 0);
         if (h[0] > OW_TRAJ_BE_CAP) n += h[0] - OW_TRAJ_BE_CAP;     // beyond the list: counted, not placed
         return n;
     }
@@ -650,29 +724,127 @@ std::mutex g_traj_mu;
 using TrajMap = std::map<std::pair<int, uint64_t>, std::shared_ptr<TremTraj>>;
 TrajMap& traj_registry() { static TrajMap* m = new TrajMap(); return *m; }
 
-// the store of (device, hc.os_sr), created (and settled) on first use
-std::shared_ptr<TremTraj> traj_acquire(int device, const OwConsts& hc, const OwConsts& k48, bool use_settle_cache) {
+// ow_tremolo_configure: capacity / lead of the stores of a device (seconds of audio at the chain rate); what is not configured comes from
+// OW_TREM_TRAJ_SECONDS / OW_TREM_TRAJ_LEAD_SECONDS, then the defaults.
+struct TrajConfig { double seconds = 0.0, lead = -1.0; };
+std::map<int, TrajConfig> g_traj_cfg;      // guarded by g_traj_mu
+constexpr double OW_TRAJ_DEFAULT_SECONDS = 1800.0, OW_TRAJ_DEFAULT_LEAD = 60.0, OW_TRAJ_FIRST_SECONDS = 150.0;
+
+// Buffers grow on a helper thread (hipMalloc is no work for a thread that renders): cover() asks when the store comes within lead + 30 s
+// of the end of its buffers, the helper doubles them.  One thread per process, started with the first store, parked on a condition
+// variable; leaked like the registry (it must not touch the runtime while the process exits).
+struct TrajGrower {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::weak_ptr<TremTraj>> todo;      // stores whose buffers should double
+    std::vector<std::weak_ptr<TremTraj>> fed;       // stores on their way to their target
+    void ask(const std::shared_ptr<TremTraj>& t) { { std::lock_guard<std::mutex> lk(mu); todo.push_back(t); } cv.notify_one(); }
+    void feed(const std::shared_ptr<TremTraj>& t) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto& w : fed) if (!w.owner_before(t) && !std::weak_ptr<TremTraj>(t).owner_before(w)) return;    // already on the list
+            fed.push_back(t);
+        }
+        cv.notify_one();
+    }
+    bool stopping = false, parked = false;
+    void stop() {       // from the exit handler: the thread makes no further runtime call once this returns (or after 2 s)
+        std::unique_lock<std::mutex> lk(mu);
+        stopping = true;
+        cv.notify_all();
+        cv.wait_for(lk, std::chrono::seconds(2), [&] { return parked; });
+    }
+    void run() {
+        for (;;) {
+            std::vector<std::weak_ptr<TremTraj>> grow, feeding;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (stopping) { parked = true; cv.notify_all(); for (;;) cv.wait(lk); }
+                if (fed.empty()) cv.wait(lk, [&] { return stopping || !todo.empty() || !fed.empty(); });
+                else cv.wait_for(lk, std::chrono::milliseconds(1));      // a launch of 2 048 steps lasts ~5 ms: look again soon
+                if (stopping) { parked = true; cv.notify_all(); for (;;) cv.wait(lk); }
+                grow.swap(todo);
+                feeding = fed;
+            }
+            for (auto& w : grow)
+                if (std::shared_ptr<TremTraj> t = w.lock()) {
+                    try { size_t c; { std::lock_guard<std::mutex> lk(t->mu); c = t->cap; } t->grow_to(c * 2); }
+                    catch (const std::exception& ex) { (void)hipGetLastError(); std::lock_guard<std::mutex> lk(t->mu); t->cap_max = t->cap; t->grow_requested = false;
+                                                       std::fprintf(stderr, "openwurli-hip: tremolo trajectory store stays at %zu samples (%s)\n", t->cap, ex.what()); }
+                }
+            std::vector<std::weak_ptr<TremTraj>> keep;
+            for (auto& w : feeding)
+                if (std::shared_ptr<TremTraj> t = w.lock()) {
+                    bool more = false;
+                    try {
+                        if (hipSetDevice(t->device) == hipSuccess) more = t->feed_step();
+                        bool ask_grow = false;
+                        { std::lock_guard<std::mutex> lk(t->mu); if (t->wants_growth(t->len)) { t->grow_requested = true; ask_grow = true; } }
+                        if (ask_grow) { std::lock_guard<std::mutex> lk(mu); todo.push_back(t); }
+                    } catch (const std::exception&) { (void)hipGetLastError(); more = false; }
+                    if (more) keep.push_back(w);
+                }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                // stores that were added while this round ran stay; the ones this round finished go
+                std::vector<std::weak_ptr<TremTraj>> next;
+                for (auto& w : fed) {
+                    bool was = false, stays = false;
+                    for (auto& f : feeding) if (!w.owner_before(f) && !f.owner_before(w)) was = true;
+                    for (auto& k : keep) if (!w.owner_before(k) && !k.owner_before(w)) stays = true;
+                    if (!was || stays) next.push_back(w);
+                }
+                fed.swap(next);
+            }
+        }
+    }
+};
+TrajGrower& traj_grower() {
+    static TrajGrower* g = [] {
+        TrajGrower* x = new TrajGrower();
+        std::thread([x] { x->run(); }).detach();
+        // exit(): handlers run in reverse order of registration, so this one -- registered long after the HIP runtime's own -- parks the
+        // thread before the runtime starts to come down (a launch or an event query during teardown crashes the process)
+        std::atexit([] { traj_grower().stop(); });
+        return x;
+    }();
+    return *g;
+}
+
+// the store of (device, hc.os_sr), created (and settled) on first use.  n_engines: size of the pool that asks -- a big pool reserves the
+// whole configured capacity at once (render never waits for a growth), a small one starts with 150 s (115 MB at 96 kHz) and grows.
+std::shared_ptr<TremTraj> traj_acquire(int device, const OwConsts& hc, const OwConsts& k48, bool use_settle_cache, size_t n_engines = 1) {
     uint64_t rate_bits; std::memcpy(&rate_bits, &hc.os_sr, 8);
     const std::pair<int, uint64_t> key(device, rate_bits);
+    std::shared_ptr<TremTraj> t;
+    {
     std::lock_guard<std::mutex> lk(g_traj_mu);
     TrajMap& g_traj = traj_registry();
     auto it = g_traj.find(key);
-    if (it != g_traj.end()) return it->second;
-    auto t = std::make_shared<TremTraj>();
+    if (it != g_traj.end()) t = it->second;
+    else {
+    t = std::make_shared<TremTraj>();
     t->device = device; t->os_sr = hc.os_sr;
-    double seconds = 1800.0;
-    if (const char* env = std::getenv("OW_TREM_TRAJ_SECONDS")) { const double v = std::atof(env); if (v > 0.0) seconds = v; }
+    TrajConfig cfg;
+    { auto c = g_traj_cfg.find(device); if (c != g_traj_cfg.end()) cfg = c->second; }
+    double seconds = cfg.seconds > 0.0 ? cfg.seconds : OW_TRAJ_DEFAULT_SECONDS, lead = cfg.lead >= 0.0 ? cfg.lead : OW_TRAJ_DEFAULT_LEAD;
+    if (!(cfg.seconds > 0.0)) if (const char* env = std::getenv("OW_TREM_TRAJ_SECONDS")) { const double v = std::atof(env); if (v > 0.0) seconds = v; }
+    if (!(cfg.lead >= 0.0)) if (const char* env = std::getenv("OW_TREM_TRAJ_LEAD_SECONDS")) { const double v = std::atof(env); if (v >= 0.0) lead = v; }
     const double want = std::min(seconds * hc.os_sr, 4.0e9);
-    t->cap = ((size_t)want + OW_TRAJ_CK - 1) / OW_TRAJ_CK * OW_TRAJ_CK;
+    t->cap_max = ((size_t)want + OW_TRAJ_CK - 1) / OW_TRAJ_CK * OW_TRAJ_CK;
+    t->lead = (size_t)std::min(lead * hc.os_sr, (double)t->cap_max);
+    const size_t first = n_engines >= 4096 ? t->cap_max : std::min(t->cap_max, ((size_t)(OW_TRAJ_FIRST_SECONDS * hc.os_sr) + OW_TRAJ_CK - 1) / OW_TRAJ_CK * OW_TRAJ_CK);
+    t->cap = first;
     HIP_OK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     for (auto& m : t->mark) HIP_OK(hipEventCreateWithFlags(&m.ev, hipEventDisableTiming));
     HIP_OK(hipMalloc(&t->dK, sizeof(OwConsts)));
     HIP_OK(hipMalloc(&t->d_r, sizeof(double) * (t->cap + 64)));
     HIP_OK(hipMalloc(&t->d_state, sizeof(double) * 18));
-    HIP_OK(hipMalloc(&t->d_ckpt, sizeof(double) * OW_TRAJ_CKD * (t->cap / OW_TRAJ_CK + 2)));
+    HIP_OK(hipMalloc(&t->d_ckpt, sizeof(double) * TremTraj::ckpt_doubles(t->cap)));
     HIP_OK(hipMalloc(&t->d_be, sizeof(unsigned long long) * (1 + OW_TRAJ_BE_CAP)));
     HIP_OK(hipMalloc(&t->d_zero, sizeof(uint32_t)));
-    HIP_OK(hipMemsetAsync(t->d_be, 0, sizeof(unsigned long long) * (1 + OW_TRAJ_BE_CAP), t->stream));
+    HIP_OK(hipMemsetAsync(t->d_be, 0xFF, sizeof(unsigned long long) * (1 + OW_TRAJ_BE_CAP), t->stream));
+    HIP_OK(hipMemsetAsync(t->d_be, 0, sizeof(unsigned long long), t->stream));
     HIP_OK(hipMemsetAsync(t->d_zero, 0, sizeof(uint32_t), t->stream));
     HIP_OK(hipMemcpyAsync(t->dK, &hc, sizeof(OwConsts), hipMemcpyHostToDevice, t->stream));
     DevMem dk48;
@@ -683,6 +855,19 @@ std::shared_ptr<TremTraj> traj_acquire(int device, const OwConsts& hc, const OwC
     HIP_OK(hipMemsetAsync(t->d_state + 17, 0, sizeof(double), t->stream));   // the trajectory's own events go to d_be
     HIP_OK(hipStreamSynchronize(t->stream));
     g_traj[key] = t;
+    traj_grower();                                                        // the helper thread exists before any render could need it
+    }
+    }
+    // (outside the registry lock) a big pool on a store that was created small: all of it now, where allocating is allowed
+    if (n_engines >= 4096) t->grow_to(t->cap_max);
+    // a small pool can outrun the one oscillator: it starts to run ahead right away, fed by the helper thread, so that a host that never
+    // calls ow_tremolo_prefetch finds its first blocks' samples waiting.  (A big pool renders far slower than the oscillator steps and
+    // only ever needs the block ahead that its own renders enqueue.)
+    if (n_engines < 4096) {
+        bool feed = false;
+        { std::lock_guard<std::mutex> lk(t->mu); t->cover(0, 0, t->lead, &feed); }
+        if (feed) traj_grower().feed(t);
+    }
     return t;
 }
 
@@ -769,11 +954,11 @@ void run_job_chain(const JobChainCfg& cfg, const OwConsts* dK, const std::vector
             owhip::build_consts(*hc, cfg.sample_rate, OW_PREAMP_LEGACY8);
             owhip::build_consts(*k48, 24000.0, OW_PREAMP_LEGACY8);
             traj = traj_acquire(cfg.device, *hc, *k48, sw.trem_cache);
-            if ((size_t)n_os <= traj->cap) {
+            if ((size_t)n_os <= traj->cap_max) {
+                traj->grow_to((size_t)n_os);                 // (offline entry point: allocating here is fine; no-op when the buffers reach that far)
                 hipEvent_t ev;
-                { std::lock_guard<std::mutex> lk(traj->mu); ev = traj->cover((size_t)n_os, 0); }
+                { std::lock_guard<std::mutex> lk(traj->mu); ev = traj->cover((size_t)n_os, 0); trem = traj->d_r; }
                 if (ev) HIP_OK(hipStreamWaitEvent(st, ev, 0));
-                trem = traj->d_r;
             }
         }
         if (!trem) {                                        // longer than the store: one oscillator for this call, from a pool of one
@@ -927,7 +1112,7 @@ void trem_evict(ow_pool* p, int e0, int ne, int n_os) {
     long long tmax = 0;
     for (int k = 0; k < ne; ++k) {
         const long long b = p->h_birth[e0 + k];
-        if (b == OW_OFF_TRAJ || (size_t)(p->trem_clock - b) + (size_t)n_os <= T->cap) continue;
+        if (b == OW_OFF_TRAJ || (size_t)(p->trem_clock - b) + (size_t)n_os <= T->cap_max) continue;
         eng.push_back((uint32_t)(e0 + k)); tp.push_back(p->trem_clock - b); tmax = std::max(tmax, p->trem_clock - b);
     }
     if (eng.empty()) return;
@@ -941,13 +1126,14 @@ void trem_evict(ow_pool* p, int e0, int ne, int n_os) {
         const std::vector<unsigned long long> events = T->be_events();
         for (size_t i = 0; i < eng.size(); ++i) be[i] = T->be_count_at(tp[i], events);
     }
-    DevMem de, dt, db;
-    de.alloc(sizeof(uint32_t) * eng.size()); dt.alloc(sizeof(long long) * eng.size()); db.alloc(sizeof(unsigned long long) * eng.size());
-    HIP_OK(hipMemcpy(de.p, eng.data(), sizeof(uint32_t) * eng.size(), hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(dt.p, tp.data(), sizeof(long long) * eng.size(), hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(db.p, be.data(), sizeof(unsigned long long) * eng.size(), hipMemcpyHostToDevice));
-    owdev::k_trem_from_ckpt<<<dim3((unsigned)((eng.size() + 63) / 64)), dim3(64), 0, p->stream>>>(p->dK, T->d_r, T->d_ckpt, p->d_cs, (int)p->I, de.as<uint32_t>(),
-                                                                                                    dt.as<long long>(), db.as<unsigned long long>(), (int)eng.size());
+    // scratch reserved at pool creation (d_evict: [I] engines as u64 | [I] t | [I] fallback counts): no allocation on this path
+    uint32_t* de = (uint32_t*)p->d_evict; long long* dt = (long long*)(p->d_evict + p->I); unsigned long long* db = p->d_evict + 2 * p->I;
+    HIP_OK(hipMemcpy(de, eng.data(), sizeof(uint32_t) * eng.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dt, tp.data(), sizeof(long long) * eng.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(db, be.data(), sizeof(unsigned long long) * eng.size(), hipMemcpyHostToDevice));
+    const double* tr; const double* tc;
+    { std::lock_guard<std::mutex> lk(T->mu); tr = T->d_r; tc = T->d_ckpt; }
+    owdev::k_trem_from_ckpt<<<dim3((unsigned)((eng.size() + 63) / 64)), dim3(64), 0, p->stream>>>(p->dK, tr, tc, p->d_cs, (int)p->I, de, dt, db, (int)eng.size());
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(p->stream));
     for (uint32_t e : eng) { p->h_birth[e] = OW_OFF_TRAJ; p->h_lead[e] = e; }
@@ -1033,7 +1219,7 @@ void upload_consts(ow_pool* p, double sr, int preamp_kind) {
     if (!p->voices_only && p->tremolo_kind == OW_TREMOLO_TWIN_T && p->sw.trem_traj) {
         // a store that cannot be had (no room for it on a crowded device) is not an error: the pool runs one oscillator per phase
         // group, as under OW_TREM_TRAJ=0 -- the same samples
-        try { p->traj = traj_acquire(p->device, p->hc, k48, p->sw.trem_cache); }
+        try { p->traj = traj_acquire(p->device, p->hc, k48, p->sw.trem_cache, p->I); }
         catch (const std::exception& ex) { p->traj.reset(); (void)hipGetLastError(); std::fprintf(stderr, "openwurli-hip: no tremolo trajectory store (%s): per-group oscillators\n", ex.what()); }
     }
     if (!p->traj) { std::fill(p->h_birth.begin(), p->h_birth.end(), OW_OFF_TRAJ); if (p->d_birth) traj_upload_births(p, 0, (int)p->I); p->n_on_traj = 0; }
@@ -1125,7 +1311,7 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
             const uint32_t e = (uint32_t)(e0 + k);
             const OwEngineArgs& a = p->h_args[e];
             if (a.main_mask) {
-                if (p->transient[e] || a.op_count) put(G, f.g, e, a.main_mask, false);
+                if (p->transient[e] || a.op_count || p->sw.force_general) put(G, f.g, e, a.main_mask, false);
                 else put(S, f.s, e, a.main_mask, false);
             }
             if (a.steal_mask) put(Tl, f.t, e, a.steal_mask, true);   // one engine per block: the crossfade early-out is per engine
@@ -1177,13 +1363,22 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
     if (chain && p->traj) {
         long long mn = p->min_birth;
         if (!whole) { mn = p->trem_clock; for (int k = 0; k < ne; ++k) if (p->h_birth[e0 + k] != OW_OFF_TRAJ) mn = std::min(mn, p->h_birth[e0 + k]); }
-        if ((size_t)(p->trem_clock - mn) + (size_t)n_os > p->traj->cap) { trem_evict(p, e0, ne, n_os); mn = p->trem_clock; for (int k = 0; k < ne; ++k) if (p->h_birth[e0 + k] != OW_OFF_TRAJ) mn = std::min(mn, p->h_birth[e0 + k]); }
+        if ((size_t)(p->trem_clock - mn) + (size_t)n_os > p->traj->cap_max) { trem_evict(p, e0, ne, n_os); mn = p->trem_clock; for (int k = 0; k < ne; ++k) if (p->h_birth[e0 + k] != OW_OFF_TRAJ) mn = std::min(mn, p->h_birth[e0 + k]); }
         const size_t need = (size_t)(p->trem_clock - mn) + (size_t)n_os;
+        bool ask = false, must = false, feed = false;
         {
             std::lock_guard<std::mutex> lk(p->traj->mu);
-            traj_ready = p->traj->cover(need, (size_t)n_os);
+            must = need > p->traj->cap;                        // the helper did not get there in time (it is asked a lead + 30 s before)
+            if (!must && p->traj->wants_growth(need)) { p->traj->grow_requested = true; ask = true; }
         }
-        tsrc.traj = p->traj->d_r + p->trem_clock;
+        if (must) p->traj->grow_to(std::max(need, p->traj->cap * 2));       // cold: allocates on this thread, like the reference's buffer auto-grow
+        if (ask) traj_grower().ask(p->traj);
+        {
+            std::lock_guard<std::mutex> lk(p->traj->mu);
+            traj_ready = p->traj->cover(need, (size_t)n_os, p->I < 4096 ? p->traj->lead : 0, &feed);
+            tsrc.traj = p->traj->d_r + p->trem_clock;         // (under the lock: a growth swaps the buffer)
+        }
+        if (feed) traj_grower().feed(p->traj);
     }
     // (b) engines with an oscillator of their own (phase groups): already there if the block-ahead speculation hit
     const bool hit = chain && p->spec.valid && p->spec.e0 == e0 && p->spec.ne == ne && p->spec.n_os == n_os;
@@ -1728,6 +1923,7 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     HIP_OK(hipMalloc(&p->d_zero, sizeof(uint32_t)));
     HIP_OK(hipMemsetAsync(p->d_zero, 0, sizeof(uint32_t), p->stream));
     HIP_OK(hipMalloc(&p->d_birth, sizeof(long long) * n_engines));
+    HIP_OK(hipMalloc(&p->d_evict, sizeof(unsigned long long) * 3 * n_engines));
     p->h_birth.assign(n_engines, OW_OFF_TRAJ);
     p->sw = Switches::from_env();
     if (no_traj) p->sw.trem_traj = false;
@@ -1899,6 +2095,7 @@ void pool_destroy(ow_pool* p) {
     if (p->d_trem_settled) hipFree(p->d_trem_settled);
     if (p->d_zero) hipFree(p->d_zero);
     if (p->d_birth) hipFree(p->d_birth);
+    if (p->d_evict) hipFree(p->d_evict);
     if (p->stream_trem) hipStreamDestroy(p->stream_trem);
     if (p->stream) hipStreamDestroy(p->stream);
     for (ow_engine* en : p->engines) delete en;
@@ -2033,12 +2230,41 @@ long long ow_tremolo_prefetch(double sample_rate, int device, double seconds) {
         owhip::build_consts(*k48, 24000.0, OW_PREAMP_LEGACY8);
         const Switches sw = Switches::from_env();
         std::shared_ptr<TremTraj> t = traj_acquire(device, *hc, *k48, sw.trem_cache);
+        const size_t want = (size_t)std::min(seconds * hc->os_sr, (double)t->cap_max);
+        t->grow_to(want);                                    // instantiation time: the place to allocate
         hipEvent_t ev;
-        { std::lock_guard<std::mutex> lk(t->mu); ev = t->cover((size_t)std::min(seconds * hc->os_sr, (double)t->cap), 0); }
+        { std::lock_guard<std::mutex> lk(t->mu); ev = t->cover(want, 0); }
         if (ev) HIP_OK(hipEventSynchronize(ev));
         std::lock_guard<std::mutex> lk(t->mu);
-        return (long long)t->len;
+        return (long long)std::max(t->done, std::min(want, t->len));     // (the store may hold more: the background lead)
     } catch (const std::exception& ex) { set_err(std::string("ow_tremolo_prefetch: ") + ex.what()); return -1; }
+}
+
+// Capacity and lead of the trajectory stores of `device` (seconds of audio): capacity_seconds = how old an engine may grow (time since
+// new / reset / set_sample_rate) before it leaves the shared trajectory for an oscillator of its own (default 1 800; <= 0 restores it);
+// lead_seconds = how far the store is kept ahead of its oldest reader in the background (default 60; 0 = only the block ahead; < 0
+// restores the default).  The buffers are NOT reserved at that size: a store starts at 150 s (115 MB at 96 kHz; all of it for pools of
+// >= 4 096 engines) and doubles on a helper thread well before a reader gets there.  Applies to stores created afterwards (a store is
+// created by the first engine of its device and chain rate) and raises / lowers the limits of the existing ones.  0 on success.
+int ow_tremolo_configure(int device, double capacity_seconds, double lead_seconds) {
+    try {
+        std::vector<std::shared_ptr<TremTraj>> live;
+        {
+            std::lock_guard<std::mutex> lk(g_traj_mu);
+            TrajConfig& c = g_traj_cfg[device];
+            c.seconds = capacity_seconds > 0.0 ? capacity_seconds : 0.0;
+            c.lead = lead_seconds >= 0.0 ? lead_seconds : -1.0;
+            for (auto& kv : traj_registry()) if (kv.first.first == device) live.push_back(kv.second);
+        }
+        for (auto& t : live) {
+            std::lock_guard<std::mutex> lk(t->mu);
+            const double secs = capacity_seconds > 0.0 ? capacity_seconds : OW_TRAJ_DEFAULT_SECONDS, lead = lead_seconds >= 0.0 ? lead_seconds : OW_TRAJ_DEFAULT_LEAD;
+            const size_t want = ((size_t)std::min(secs * t->os_sr, 4.0e9) + OW_TRAJ_CK - 1) / OW_TRAJ_CK * OW_TRAJ_CK;
+            t->cap_max = std::max(want, t->cap);             // never below what is already allocated (engines may stand there)
+            t->lead = (size_t)std::min(lead * t->os_sr, (double)t->cap_max);
+        }
+        return 0;
+    } catch (const std::exception& ex) { set_err(std::string("ow_tremolo_configure: ") + ex.what()); return -1; }
 }
 
 int ow_pool_read_voice_sum(ow_pool* p, double* out_host, size_t out_stride, size_t len) {
@@ -2088,13 +2314,16 @@ int ow_pool_read_tremolo_r(ow_pool* p, double* out_host, size_t out_stride, size
         std::vector<double> tr;
         if (p->traj && p->n_on_traj) {     // engines on the shared trajectory: the n_os samples below their present t
             if ((long long)n_os > p->last_n_os) throw std::runtime_error("more samples than the last block consumed");
-            { std::lock_guard<std::mutex> lk(p->traj->mu); HIP_OK(hipStreamSynchronize(p->traj->stream)); }
+            // (the samples the last block consumed are complete -- its kernels waited for them; no wait for the store's stream, which
+            // the background extension keeps busy)
             HIP_OK(hipStreamSynchronize(p->stream));
             DevMem g;
             g.alloc(sizeof(double) * I * n_os);
+            const double* base;
+            { std::lock_guard<std::mutex> lk(p->traj->mu); base = p->traj->d_r; }
             // the block consumed [t_end - last_n_os, t_end); its first n_os samples are asked for
             owdev::k_trem_traj_gather<<<dim3((unsigned)((I * n_os + 255) / 256)), dim3(256), 0, p->stream>>>(
-                p->traj->d_r + p->trem_clock - (p->last_n_os - (long long)n_os), p->d_birth, (int)I, (long long)n_os, g.as<double>());
+                base + p->trem_clock - (p->last_n_os - (long long)n_os), p->d_birth, (int)I, (long long)n_os, g.as<double>());
             HIP_OK(hipGetLastError());
             tr.resize(I * n_os);
             HIP_OK(hipMemcpyAsync(tr.data(), g.p, sizeof(double) * I * n_os, hipMemcpyDeviceToHost, p->stream));
@@ -2536,9 +2765,12 @@ int ow_test_host_matrices(int solver, double rate, int force_rebuild, double* s,
 // Forget the process-wide settled states (Twin-T per chain rate; melange preamp and power amp per device): the next pool settles
 // afresh on the device.  Returns the number of cached Twin-T states that were dropped.
 int ow_test_clear_settle_caches(void) {
-    std::lock_guard<std::mutex> lk(g_mel_mu);
-    const int n = (int)g_trem_settled.size();
-    g_trem_settled.clear(); g_mel_settled.clear(); g_pa_settled.clear();
+    int n;
+    {   // one lock at a time: traj_acquire holds g_traj_mu while its settle takes g_mel_mu (trem_settled_rows)
+        std::lock_guard<std::mutex> lk(g_mel_mu);
+        n = (int)g_trem_settled.size();
+        g_trem_settled.clear(); g_mel_settled.clear(); g_pa_settled.clear();
+    }
     { std::lock_guard<std::mutex> lt(g_traj_mu); traj_registry().clear(); }     // pools that hold a store keep it alive; new pools start a new one
     return n;
 }
@@ -2599,6 +2831,7 @@ int ow_test_pool_set_switch(ow_pool* p, const char* name, int value) {
     else if (n == "pa_sort") { if (value < 0 || value > 2) return -1; w.pa_sort = value; }
     else if (n == "host_profile") w.host_profile = value != 0;
     else if (n == "out_direct") w.out_direct = value < 0 ? -1 : (value != 0);
+    else if (n == "force_general") { w.force_general = value != 0; p->lists_valid = false; }
     else if (n == "chain_stream") w.chain_stream = value < 0 ? -1 : (value != 0);
     else return -1;                                       // (trem_traj / trem_cache / pipe shape the pool at creation: environment only)
     return 0;
@@ -2629,7 +2862,19 @@ int ow_test_pool_get_switch(const ow_pool* p, const char* name) {
 int ow_test_pool_trajectory_info(const ow_pool* p, uint64_t out[3]) {
     if (!p || !out) return -1;
     out[0] = p->traj ? p->n_on_traj : 0; out[1] = 0; out[2] = 0;
-    if (p->traj) { std::lock_guard<std::mutex> lk(p->traj->mu); out[1] = p->traj->len; out[2] = p->traj->cap; }
+    if (p->traj) { std::lock_guard<std::mutex> lk(p->traj->mu); out[1] = p->traj->len; out[2] = p->traj->cap_max; }
+    return 0;
+}
+// The store behind the pool, in samples: [0] produced or enqueued, [1] known complete (finished launches), [2] what its buffers hold now,
+// [3] its configured capacity, [4] t of the pool's oldest engine on it (what the next block needs is [4] + its chain-rate samples).
+int ow_test_pool_trajectory_state(const ow_pool* p, uint64_t out[5]) {
+    if (!p || !out) return -1;
+    for (int i = 0; i < 5; ++i) out[i] = 0;
+    if (!p->traj) return 0;
+    std::lock_guard<std::mutex> lk(p->traj->mu);
+    p->traj->in_flight();                                  // looks at the marks: refreshes `done`
+    out[0] = p->traj->len; out[1] = p->traj->done; out[2] = p->traj->cap; out[3] = p->traj->cap_max;
+    out[4] = (uint64_t)std::max<long long>(p->trem_clock - p->min_birth, 0);
     return 0;
 }
 

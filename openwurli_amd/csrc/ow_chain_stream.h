@@ -22,7 +22,7 @@ namespace owdev {
 #define OW_SCHUNK 64
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_chain_stream(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args, OwEngineOut* __restrict__ eout,
-                    const double* __restrict__ sum, const OwTremSrc tsrc, double* pre, float* __restrict__ out, int I, int L, int Lcap, int Lout,
+                    const double* __restrict__ sum, const OwTremSrc tsrc, double* __restrict__ pre, float* __restrict__ out, int I, int L, int Lcap, int Lout,
                     int e0, int ne, float* __restrict__ out2, size_t ld2) {
     __shared__ double tile[32 * (OW_SCHUNK + 1)];            // preamp phase: voice sums of the chunk; output phase: its f32 rows
     float* otile = reinterpret_cast<float*>(tile);

@@ -576,9 +576,11 @@ __global__ __launch_bounds__(128) void k_chain_fused(const OwConsts* __restrict_
 // the two preamp steps of a sample (k_job_chain_wide's lanes and state) and hands the pair of chain-rate outputs over through a
 // two-slot LDS ring; wavefront 1 -- one lane per job -- follows a chunk behind with the rest.  Same statements per job in the same
 // order: bit-identical to k_job_chain_wide (tests/test_gpu_render_flags.py, OW_JOB_FUSED=0/1).
-__global__ __launch_bounds__(128) void k_job_chain_fused(const OwConsts* __restrict__ K, const OwJobDev* __restrict__ jobs, const double* __restrict__ reed,
-                                                         double* __restrict__ out, int n_jobs, long long n, long long stride, const int* __restrict__ voice_prog,
-                                                         int* __restrict__ voice_err) {
+// (`reed` and `voice_prog` are NOT __restrict__ / read-only to the compiler: in the overlapped form k_job_voice writes both while this
+// kernel runs, and the acquire load of the progress word is what orders the chunk's loads behind the producer's stores.)
+__global__ __launch_bounds__(128) void k_job_chain_fused(const OwConsts* __restrict__ K, const OwJobDev* __restrict__ jobs, const volatile double* reed,
+                                                         double* __restrict__ out, int n_jobs, long long n, long long stride, const int* voice_prog,
+                                                         int* voice_err) {
     __shared__ double tin[8 * (OW_FCHUNK + 1)];
     __shared__ double ring[2][OW_FCHUNK * 2][8];               // preamp out at the chain rate: [slot][sample x phase][job of the block]
     __shared__ double tout[8 * (OW_FCHUNK + 1)];

@@ -254,6 +254,12 @@ class EnginePool:
         self._lib.ow_test_pool_trajectory_info(self._h, out)
         return int(out[0]), int(out[1]), int(out[2])
 
+    def trajectory_state(self):
+        """Test hook: the store behind the pool, in samples -- dict(enqueued, complete, buffers, capacity, oldest_t)."""
+        out = (C.c_uint64 * 5)()
+        self._lib.ow_test_pool_trajectory_state(self._h, out)
+        return dict(zip(("enqueued", "complete", "buffers", "capacity", "oldest_t"), (int(x) for x in out)))
+
     def midi(self, events):
         """Apply a numpy structured array of events (dtype binding.MIDI_DTYPE) in order."""
         ev = np.ascontiguousarray(events, dtype=np.dtype(binding.MIDI_DTYPE))
@@ -326,6 +332,14 @@ def tremolo_prefetch(sample_rate, seconds, device=0):
     if n < 0:
         raise OwError(binding.take_error(lib))
     return int(n)
+
+
+def tremolo_configure(capacity_seconds=0.0, lead_seconds=-1.0, device=0):
+    """``ow_tremolo_configure``: how old an engine may grow on the shared trajectory (seconds since its new / reset; <= 0: the default,
+    1 800) and how far the store runs ahead of its oldest reader in the background (seconds; < 0: the default, 60)."""
+    lib = binding.load_library()
+    if lib.ow_tremolo_configure(int(device), float(capacity_seconds), float(lead_seconds)) != 0:
+        raise OwError(binding.take_error(lib))
 
 
 def render_note(midi_note, velocity, duration_secs, sample_rate, device=0, displacement_scale=None):

@@ -218,3 +218,90 @@ def test_latched_switches(hiplib):
     with pytest.raises(ow.OwError):
         p.set_switch("trem_traj", 0)
     p.close()
+
+
+_FRESH = r"""
+import json, sys, time
+import numpy as np
+import openwurli_amd as ow
+sr, n = 48000.0, 256
+p = ow.EnginePool(sr, n)              # no ow_tremolo_prefetch anywhere in this process
+p.set_sample_rate(sr)                 # initialize(): chain build + 0.6 s warm-up, as the plugin does
+p.stagger_tremolo(n)
+for k in range(n):
+    for note in range(33, 97):
+        p[k].note_on(note, (40 + (37 * k) % 88) / 127.0)
+time.sleep(0.5)                       # a host instantiates its plugins some time before the transport starts
+rows = []
+for b in range(40):
+    st = p.trajectory_state()
+    t0 = time.perf_counter()
+    out = p.render(512)
+    rows.append((st["complete"], st["oldest_t"], st["enqueued"], st["buffers"], st["capacity"], time.perf_counter() - t0))
+print(json.dumps({"rows": rows, "finite": bool(np.all(np.isfinite(out))), "peak": float(np.max(np.abs(out)))}))
+p.close()
+"""
+
+
+def test_fresh_process_never_waits_for_the_oscillator(hiplib):
+    """A host that never calls ow_tremolo_prefetch (the reference has nothing to call: Tremolo::new settles inside the constructor,
+    tremolo.rs:83-102): a FRESH process creates 256 instances with 256 tremolo phases and renders back to back (configs[4] literally).
+    The store starts to run ahead when it is created (a helper thread feeds the oscillator whether or not anybody renders), so every
+    sample a block needs is already complete when the block is asked for -- no block waits for the single oscillator -- and its buffers
+    are the small first allocation (150 s), not the 1 800 s capacity.  (A pool that renders back to back outruns one oscillator --
+    5.7 against 4 x real time -- so the lead shrinks while it does; 40 blocks stay far inside it.)"""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("OW_TREM_TRAJ_SECONDS", "OW_TREM_TRAJ_LEAD_SECONDS", "OW_TREM_TRAJ"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", _FRESH], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["finite"] and d["peak"] > 1e-3
+    rows = d["rows"]
+    n_os = 1024
+    for b, (complete, oldest, enq, buffers, capacity, dt) in enumerate(rows):
+        if b >= 3:
+            assert complete >= oldest + n_os, (b, complete, oldest)          # everything the block reads was there before it was asked for
+        assert enq <= buffers <= capacity
+    up = lambda x: (x + 4095) // 4096 * 4096
+    assert rows[0][3] == up(150 * 96000) and rows[0][4] == up(1800 * 96000)
+    assert rows[0][2] - rows[0][1] > 64 * n_os                                # the feeder thread ran the oscillator ahead while the host was busy elsewhere
+
+
+def test_store_grows_and_configures(hiplib, oracle):
+    """ow_tremolo_configure + growth: a store limited to 3 s with a 0.5 s lead starts with buffers of ... 3 s (below the first allocation,
+    nothing to grow); one limited to 400 s starts at 150 s and doubles when a reader comes within lead + 30 s of the end -- here forced
+    by ow_tremolo_prefetch(200 s), which allocates where allocating is allowed.  Engines keep reading the same samples through the swap:
+    the pool's output is bit-identical to a pool on per-group oscillators."""
+    import openwurli_amd as ow
+    sr = 44100.0                      # a chain rate no other test's store uses (88.2 kHz)
+    ow.load_library().ow_test_clear_settle_caches()
+    ow.tremolo_configure(400.0, 2.0)
+    try:
+        res = {}
+        for traj in (True, False):
+            p = _pool(ow, sr, 6, traj)
+            p.set_sample_rate(sr)
+            p.stagger_tremolo(3)
+            for k in range(6):
+                p[k].set_tremolo_depth(1.0); p[k].note_on(50 + k, 0.8)
+            outs = []
+            for b in range(8):
+                if traj and b == 3:
+                    st = p.trajectory_state()
+                    assert st["buffers"] == 150 * 88200 // 4096 * 4096 + 4096 and st["capacity"] >= 400 * 88200
+                    assert ow.tremolo_prefetch(sr, 200.0) >= 200 * 88200          # grows the buffers (150 s -> 200 s worth) and fills them
+                    st = p.trajectory_state()
+                    assert st["buffers"] >= 200 * 88200 and st["complete"] >= 200 * 88200
+                outs.append(p.render(300).copy())
+            res[traj] = outs
+            p.close()
+        for b in range(8):
+            assert np.array_equal(res[True][b], res[False][b]), b
+    finally:
+        ow.tremolo_configure(0.0, -1.0)
+        ow.load_library().ow_test_clear_settle_caches()

@@ -18,11 +18,17 @@ for _ in range(12):
     sc.step()
 host = p.alloc_host_block(bench.BUF)
 res = {}
-for name, sw in (("hbm", None), ("staged", 0), ("direct", 1), ("staged2", 0), ("direct2", 1)):
-    s2 = bench.Script(p, n, host_out=None if sw is None else host)
+# (name, deliver to the host block?, chain_stream switch, out_direct switch)
+modes = (("hbm_two_launches", False, 0, 0), ("hbm_stream_kernel", False, 1, 0), ("host_staged_copy", True, 0, 0), ("host_k_post_direct", True, 0, 1),
+         ("host_stream_kernel", True, 1, 1), ("hbm_two_launches_again", False, 0, 0), ("host_stream_kernel_again", True, 1, 1))
+if len(sys.argv) > 2 and sys.argv[2] == "general":
+    modes = (("steady_kernel", False, 0, 0), ("general_kernel_no_phase_active", False, 0, 0))
+for name, to_host, cs, od in modes:
+    s2 = bench.Script(p, n, host_out=host if to_host else None)
     s2.pos = sc.pos
-    if sw is not None:
-        p.set_switch("out_direct", sw)
+    p.set_switch("chain_stream", cs); p.set_switch("out_direct", od)
+    if name.startswith("general"):
+        p.set_switch("force_general", 1)
     p.set_profiling(True)
     for _ in range(3):
         s2.step()
@@ -36,9 +42,9 @@ for name, sw in (("hbm", None), ("staged", 0), ("direct", 1), ("staged2", 0), ("
     el = time.perf_counter() - t0
     p.set_profiling(False)
     km = s2.kernel_ms / max(s2.kernel_launches, 1)
-    res[name] = {"ms_per_step": 1e3 * el / K, "samples_per_s": K * bench.BUF * n / el, "kernel_ms": [float(x) for x in km]}
+    res[name] = {"ms_per_step": 1e3 * el / K, "samples_per_s": K * bench.BUF * n / el, "kernel_ms": dict(zip(("ops", "voices", "tremolo", "preamp", "post"), (float(x) for x in km)))}
     sc.pos = s2.pos
-    if sw == 1:      # the block the host received equals the block left in HBM
+    if to_host:      # the block the host received equals the block left in HBM
         a = np.ctypeslib.as_array((__import__("ctypes").c_float * (n * bench.BUF)).from_address(host[0])).reshape(n, bench.BUF)
         res[name]["host_equals_hbm"] = bool(np.array_equal(a, p.last_block()))
 print(json.dumps(res, indent=1))
