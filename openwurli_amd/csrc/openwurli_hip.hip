@@ -734,20 +734,30 @@ constexpr double OW_TRAJ_DEFAULT_SECONDS = 1800.0, OW_TRAJ_DEFAULT_LEAD = 60.0, 
 // of the end of its buffers, the helper doubles them.  One thread per process, started with the first store, parked on a condition
 // variable; leaked like the registry (it must not touch the runtime while the process exits).
 struct TrajGrower {
+    // fixed tables: feed() / ask() are called from render, and the thread's own rounds run while hosts audit allocations -- nothing here
+    // touches the heap (weak_ptr copies only count references)
+    static constexpr int CAP = 16;
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<std::weak_ptr<TremTraj>> todo;      // stores whose buffers should double
-    std::vector<std::weak_ptr<TremTraj>> fed;       // stores on their way to their target
-    void ask(const std::shared_ptr<TremTraj>& t) { { std::lock_guard<std::mutex> lk(mu); todo.push_back(t); } cv.notify_one(); }
+    std::weak_ptr<TremTraj> todo[CAP];     // stores whose buffers should double
+    std::weak_ptr<TremTraj> fed[CAP];      // stores on their way to their target
+    int n_todo = 0, n_fed = 0;
+    bool stopping = false, parked = false;
+    static bool same(const std::weak_ptr<TremTraj>& a, const std::weak_ptr<TremTraj>& b) { return !a.owner_before(b) && !b.owner_before(a); }
+    void ask(const std::shared_ptr<TremTraj>& t) {
+        { std::lock_guard<std::mutex> lk(mu); if (n_todo < CAP) todo[n_todo++] = t; }
+        cv.notify_one();
+    }
     void feed(const std::shared_ptr<TremTraj>& t) {
         {
             std::lock_guard<std::mutex> lk(mu);
-            for (auto& w : fed) if (!w.owner_before(t) && !std::weak_ptr<TremTraj>(t).owner_before(w)) return;    // already on the list
-            fed.push_back(t);
+            const std::weak_ptr<TremTraj> w(t);
+            for (int i = 0; i < n_fed; ++i) if (same(fed[i], w)) return;          // already on the list
+            if (n_fed == CAP) return;                                            // (sixteen chain rates x devices being fed at once: the renders' own block ahead remains)
+            fed[n_fed++] = w;
         }
         cv.notify_one();
     }
-    bool stopping = false, parked = false;
     void stop() {       // from the exit handler: the thread makes no further runtime call once this returns (or after 2 s)
         std::unique_lock<std::mutex> lk(mu);
         stopping = true;
@@ -756,45 +766,45 @@ struct TrajGrower {
     }
     void run() {
         for (;;) {
-            std::vector<std::weak_ptr<TremTraj>> grow, feeding;
+            std::weak_ptr<TremTraj> grow[CAP], feeding[CAP];
+            int n_grow = 0, n_feeding = 0;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 if (stopping) { parked = true; cv.notify_all(); for (;;) cv.wait(lk); }
-                if (fed.empty()) cv.wait(lk, [&] { return stopping || !todo.empty() || !fed.empty(); });
+                if (n_fed == 0) cv.wait(lk, [&] { return stopping || n_todo > 0 || n_fed > 0; });
                 else cv.wait_for(lk, std::chrono::milliseconds(1));      // a launch of 2 048 steps lasts ~5 ms: look again soon
                 if (stopping) { parked = true; cv.notify_all(); for (;;) cv.wait(lk); }
-                grow.swap(todo);
-                feeding = fed;
+                for (int i = 0; i < n_todo; ++i) { grow[n_grow++] = todo[i]; todo[i].reset(); }
+                n_todo = 0;
+                for (int i = 0; i < n_fed; ++i) feeding[n_feeding++] = fed[i];
             }
-            for (auto& w : grow)
-                if (std::shared_ptr<TremTraj> t = w.lock()) {
+            for (int i = 0; i < n_grow; ++i)
+                if (std::shared_ptr<TremTraj> t = grow[i].lock()) {
                     try { size_t c; { std::lock_guard<std::mutex> lk(t->mu); c = t->cap; } t->grow_to(c * 2); }
                     catch (const std::exception& ex) { (void)hipGetLastError(); std::lock_guard<std::mutex> lk(t->mu); t->cap_max = t->cap; t->grow_requested = false;
                                                        std::fprintf(stderr, "openwurli-hip: tremolo trajectory store stays at %zu samples (%s)\n", t->cap, ex.what()); }
                 }
-            std::vector<std::weak_ptr<TremTraj>> keep;
-            for (auto& w : feeding)
-                if (std::shared_ptr<TremTraj> t = w.lock()) {
-                    bool more = false;
+            bool more[CAP] = {false};
+            for (int i = 0; i < n_feeding; ++i)
+                if (std::shared_ptr<TremTraj> t = feeding[i].lock()) {
                     try {
-                        if (hipSetDevice(t->device) == hipSuccess) more = t->feed_step();
+                        if (hipSetDevice(t->device) == hipSuccess) more[i] = t->feed_step();
                         bool ask_grow = false;
                         { std::lock_guard<std::mutex> lk(t->mu); if (t->wants_growth(t->len)) { t->grow_requested = true; ask_grow = true; } }
-                        if (ask_grow) { std::lock_guard<std::mutex> lk(mu); todo.push_back(t); }
-                    } catch (const std::exception&) { (void)hipGetLastError(); more = false; }
-                    if (more) keep.push_back(w);
+                        if (ask_grow) { std::lock_guard<std::mutex> lk(mu); if (n_todo < CAP) todo[n_todo++] = t; }
+                    } catch (const std::exception&) { (void)hipGetLastError(); more[i] = false; }
                 }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 // stores that were added while this round ran stay; the ones this round finished go
-                std::vector<std::weak_ptr<TremTraj>> next;
-                for (auto& w : fed) {
+                int k = 0;
+                for (int i = 0; i < n_fed; ++i) {
                     bool was = false, stays = false;
-                    for (auto& f : feeding) if (!w.owner_before(f) && !f.owner_before(w)) was = true;
-                    for (auto& k : keep) if (!w.owner_before(k) && !k.owner_before(w)) stays = true;
-                    if (!was || stays) next.push_back(w);
+                    for (int j = 0; j < n_feeding; ++j) if (same(fed[i], feeding[j])) { was = true; stays = more[j]; }
+                    if (!was || stays) { if (k != i) fed[k] = fed[i]; ++k; }
                 }
-                fed.swap(next);
+                for (int i = k; i < n_fed; ++i) fed[i].reset();
+                n_fed = k;
             }
         }
     }
@@ -1511,7 +1521,6 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
     bool steady_launched = false;
     if (voices && p->vl_steady.n_blocks) HIP_OK(hipMemsetAsync(p->d_skew_seen, 0, sizeof(uint32_t), st));
     if (NP > 1) HIP_OK(hipEventRecord(p->ev_ready, st));      // args, ops and voice lists are in place
-    const bool tabs = (size_t)p->vl_general.n_blocks * 4 < (size_t)ne;   // sparse general list (played input): tabulated phase gains
     // A target inside a pinned block of ow_host_alloc is written by the output stage itself (it is mapped into the device's address space)
     float* out_direct = nullptr;
     if (out_host && p->sw.out_direct != 0 && out_stride >= len && ne > 0)
@@ -1542,11 +1551,10 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
                 steady_launched = true;
             }
             if (bg) {
-                if (tabs) owdev::k_voice<true><<<dim3(bg), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_general.d + a0.g, p->d_sum, p->d_eout, I, L, Lcap, 0);
-                else owdev::k_voice<false><<<dim3(bg), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_general.d + a0.g, p->d_sum, p->d_eout, I, L, Lcap, 0);
+                owdev::k_voice<<<dim3(bg), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_general.d + a0.g, p->d_sum, p->d_eout, I, L, Lcap, 0);
             }
             if (bt)
-                owdev::k_voice<false><<<dim3(bt), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_steal.d + a0.t, p->d_sum, p->d_eout, I, L, Lcap, 1);
+                owdev::k_voice<<<dim3(bt), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_steal.d + a0.t, p->d_sum, p->d_eout, I, L, Lcap, 1);
         }
         if (overlap && k + 1 < NP) HIP_OK(hipEventRecord(p->ev_voice_done[k], s));
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][1], s));
@@ -1724,11 +1732,11 @@ void guard_second_pass(ow_pool* p, const uint32_t* engs, size_t n_eng, size_t le
     const int I = (int)p->I, L = (int)len, Lcap = (int)p->Lcap;
     if (nm) {
         HIP_OK(hipMemcpyAsync(p->vl_general.d, p->vl_general.h, sizeof(uint32_t) * nm, hipMemcpyHostToDevice, st));
-        owdev::k_voice<false><<<dim3(nm / 64), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_general.d, p->d_sum, p->d_eout, I, L, Lcap, 2);
+        owdev::k_voice<<<dim3(nm / 64), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_general.d, p->d_sum, p->d_eout, I, L, Lcap, 2);
     }
     if (ns) {
         HIP_OK(hipMemcpyAsync(p->vl_steal.d, p->vl_steal.h, sizeof(uint32_t) * ns, hipMemcpyHostToDevice, st));
-        owdev::k_voice<false><<<dim3(ns / 64), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_steal.d, p->d_sum, p->d_eout, I, L, Lcap, 3);
+        owdev::k_voice<<<dim3(ns / 64), dim3(64), 0, st>>>(p->dK, p->d_vrec, p->vl_steal.d, p->d_sum, p->d_eout, I, L, Lcap, 3);
     }
     owdev::k_eout_gather_list<<<dim3(nb), dim3(256), 0, st>>>(p->d_eout, p->d_op_engines, (int)n_eng, p->d_eout_packed);
     HIP_OK(hipGetLastError());

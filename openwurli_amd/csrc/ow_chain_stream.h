@@ -20,6 +20,67 @@
 namespace owdev {
 
 #define OW_SCHUNK 64
+// Output stage of one chunk (the body of k_post<true>), out of line: its own register allocation -- inlined, the scalar values of the
+// preamp phase stayed live across it and the compiler spilled ~120 SGPRs per sample to vector lanes inside this loop (+12 % on the
+// launch).  State comes from and goes back to the chain-state rows; the f32 samples of the chunk go to the tile (`otile`, LDS).
+typedef __attribute__((address_space(3))) float* OwLdsFloatPtr;
+__device__ __noinline__ bool chain_stream_post_chunk(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args,
+                                                     const double* __restrict__ pre, OwLdsFloatPtr otile, int I, int e, int el, int phase, bool valid,
+                                                     int base, int cn, uint32_t set_flags) {
+    const double sr = K->sr;
+    const double thermal_alpha = K->spk_thermal_alpha;
+    bool nan_fired = false;
+    double da[3], db[3], dd;
+    for (int i = 0; i < 3; ++i) { da[i] = CSF(CS_OS_DA + i); db[i] = CSF(CS_OS_DB + i); }
+    dd = CSF(CS_OS_DD);
+    SpeakerSt sp;
+    {
+        double* hp = &sp.hpf.b0; double* lp = &sp.lpf.b0;
+        for (int i = 0; i < 7; ++i) { hp[i] = CSF(CS_SPK_HPF + i); lp[i] = CSF(CS_SPK_LPF + i); }
+        sp.character = CSF(CS_SPK_CHAR); sp.a2 = CSF(CS_SPK_A2); sp.a3 = CSF(CS_SPK_A3); sp.tc = CSF(CS_SPK_TC); sp.ts = CSF(CS_SPK_TS);
+    }
+    Smoother ss, sv;
+    smoother_load(ss, cs, I, e, CS_SM_SPK);
+    smoother_load(sv, cs, I, e, CS_SM_VOL);
+    if (base == 0) {
+        if (set_flags & 2u) ss.retarget(args[e].spk_target, K->ramp_samples);
+        if (set_flags & 4u) sv.retarget(args[e].vol_target, K->ramp_samples);
+    }
+    double pn = pre[((size_t)base * 2 + phase) * I + e];
+    for (int n = 0; n < cn; ++n) {
+        const double pc = pn;
+        pn = pre[((size_t)(base + min(n + 1, cn - 1)) * 2 + phase) * I + e];     // one sample ahead, inside the chunk
+        const double y = power_amp(pc * 0.25);
+        const double yo = __shfl_xor(y, 32);                                // engine.rs:536-553
+        const double y0 = phase ? yo : y, y1 = phase ? y : yo;
+        const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, y0);
+        const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, y1);
+        const double o = (a + dd) * 0.5;
+        dd = b;
+        speaker_set_character(sp, ss.next(), sr);                           // engine.rs:437-438
+        const double shaped = speaker_process(sp, o, thermal_alpha);
+        const double post = shaped * 7.498942093324558 * sv.next();         // POST_SPEAKER_GAIN x user volume
+        float f = (float)post;
+        if (!isfinite(f)) {                                                 // engine.rs:450-458
+            f = 0.0f;
+            sp.hpf.s1 = sp.hpf.s2 = sp.lpf.s1 = sp.lpf.s2 = 0.0;
+            sp.ts = 0.0;
+            nan_fired = true;
+        }
+        if (phase == 0) otile[el * (OW_SCHUNK + 1) + n] = f;
+    }
+    if (valid && phase == 0) {
+        for (int i = 0; i < 3; ++i) { CSF(CS_OS_DA + i) = da[i]; CSF(CS_OS_DB + i) = db[i]; }
+        CSF(CS_OS_DD) = dd;
+        const double* hp = &sp.hpf.b0; const double* lp = &sp.lpf.b0;
+        for (int i = 0; i < 7; ++i) { CSF(CS_SPK_HPF + i) = hp[i]; CSF(CS_SPK_LPF + i) = lp[i]; }
+        CSF(CS_SPK_CHAR) = sp.character; CSF(CS_SPK_A2) = sp.a2; CSF(CS_SPK_A3) = sp.a3; CSF(CS_SPK_TC) = sp.tc; CSF(CS_SPK_TS) = sp.ts;
+        smoother_store(ss, cs, I, e, CS_SM_SPK);
+        smoother_store(sv, cs, I, e, CS_SM_VOL);
+    }
+    return nan_fired;
+}
+
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_chain_stream(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args, OwEngineOut* __restrict__ eout,
                     const double* __restrict__ sum, const OwTremSrc tsrc, double* __restrict__ pre, float* __restrict__ out, int I, int L, int Lcap, int Lout,
@@ -33,8 +94,6 @@ void k_chain_stream(const OwConsts* __restrict__ K, double* __restrict__ cs, con
     const bool valid = e_raw < e0 + ne;
     const int e = valid ? e_raw : (e0 + ne - 1);             // clamp so every lane runs the same (harmless) work
     const int e_last = e0 + ne - 1;
-    const double sr = K->sr;
-    const double thermal_alpha = K->spk_thermal_alpha;
 
     // ---- preamp state (k_preamp), in registers for the whole launch
     DkSt st;
@@ -117,57 +176,7 @@ void k_chain_stream(const OwConsts* __restrict__ K, double* __restrict__ cs, con
         }
         __syncthreads();      // (a workgroup-scope release / acquire: the chunk of `pre` written above is read by other lanes below)
         // ================================================================ output stage of the chunk (k_post<true>)
-        {
-            const int phase = role;
-            double da[3], db[3], dd;
-            for (int i = 0; i < 3; ++i) { da[i] = CSF(CS_OS_DA + i); db[i] = CSF(CS_OS_DB + i); }
-            dd = CSF(CS_OS_DD);
-            SpeakerSt sp;
-            {
-                double* hp = &sp.hpf.b0; double* lp = &sp.lpf.b0;
-                for (int i = 0; i < 7; ++i) { hp[i] = CSF(CS_SPK_HPF + i); lp[i] = CSF(CS_SPK_LPF + i); }
-                sp.character = CSF(CS_SPK_CHAR); sp.a2 = CSF(CS_SPK_A2); sp.a3 = CSF(CS_SPK_A3); sp.tc = CSF(CS_SPK_TC); sp.ts = CSF(CS_SPK_TS);
-            }
-            Smoother ss, sv;
-            smoother_load(ss, cs, I, e, CS_SM_SPK);
-            smoother_load(sv, cs, I, e, CS_SM_VOL);
-            if (base == 0) {
-                if (set_flags & 2u) ss.retarget(args[e].spk_target, K->ramp_samples);
-                if (set_flags & 4u) sv.retarget(args[e].vol_target, K->ramp_samples);
-            }
-            double pn = pre[((size_t)base * 2 + phase) * I + e];
-            for (int n = 0; n < cn; ++n) {
-                const double pc = pn;
-                pn = pre[((size_t)(base + min(n + 1, cn - 1)) * 2 + phase) * I + e];     // one sample ahead, inside the chunk
-                const double y = power_amp(pc * 0.25);
-                const double yo = __shfl_xor(y, 32);                                // engine.rs:536-553
-                const double y0 = phase ? yo : y, y1 = phase ? y : yo;
-                const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, y0);
-                const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, y1);
-                const double o = (a + dd) * 0.5;
-                dd = b;
-                speaker_set_character(sp, ss.next(), sr);                           // engine.rs:437-438
-                const double shaped = speaker_process(sp, o, thermal_alpha);
-                const double post = shaped * 7.498942093324558 * sv.next();         // POST_SPEAKER_GAIN x user volume
-                float f = (float)post;
-                if (!isfinite(f)) {                                                 // engine.rs:450-458
-                    f = 0.0f;
-                    sp.hpf.s1 = sp.hpf.s2 = sp.lpf.s1 = sp.lpf.s2 = 0.0;
-                    sp.ts = 0.0;
-                    nan_fired = true;
-                }
-                if (phase == 0) otile[el * (OW_SCHUNK + 1) + n] = f;
-            }
-            if (valid && phase == 0) {
-                for (int i = 0; i < 3; ++i) { CSF(CS_OS_DA + i) = da[i]; CSF(CS_OS_DB + i) = db[i]; }
-                CSF(CS_OS_DD) = dd;
-                const double* hp = &sp.hpf.b0; const double* lp = &sp.lpf.b0;
-                for (int i = 0; i < 7; ++i) { CSF(CS_SPK_HPF + i) = hp[i]; CSF(CS_SPK_LPF + i) = lp[i]; }
-                CSF(CS_SPK_CHAR) = sp.character; CSF(CS_SPK_A2) = sp.a2; CSF(CS_SPK_A3) = sp.a3; CSF(CS_SPK_TC) = sp.tc; CSF(CS_SPK_TS) = sp.ts;
-                smoother_store(ss, cs, I, e, CS_SM_SPK);
-                smoother_store(sv, cs, I, e, CS_SM_VOL);
-            }
-        }
+        if (chain_stream_post_chunk(K, cs, args, pre, (OwLdsFloatPtr)otile, I, e, el, role, valid, base, cn, set_flags)) nan_fired = true;
         __syncthreads();
         for (int r = 0; r < 32; ++r) {
             const int er = eb + r;

@@ -149,8 +149,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #endif
 #define OW_VCHUNK 24   // 64 voices x 24 samples x f64 = 12.8 KB tile: 8 voice blocks + 4 tremolo blocks fit the 160 KB LDS of a CU
 #define OW_NO_VOICE 0xFFFFFFFFu
-#define OW_GT_MAX 16      // lanes in an onset ramp / damper ramp up to which their gain curves are tabulated per chunk (k_voice)
-#define OW_DT_MAX 8
 
 struct VoiceLanes {           // per-lane view of one packed block
     int e, slot;
@@ -210,16 +208,22 @@ OW_DEV void voice_reduce(const double* __restrict__ tile, const int* __restrict_
 // renders every remaining voice of the engine AGAIN to find the culprit, which advances the survivors by another `L` samples.  The same
 // stepping runs here with nothing summed or written but the voice records and the status bits; a steal voice's crossfade counter is
 // not touched (the reference decrements it in the first pass only).
-// TABS: tabulate phase gain curves per chunk (below).  The tables cost 14 KB of LDS (4 instead of 7 blocks per CU), so the host uses
-// this variant when the general list is sparse (played input) and the plain one when most engines are in it (a re-strike of everything).
-template <bool TABS>
+//
+// Onset gains (reed.rs:251-264: a cosine, and for mid velocities a power -- ~200 instructions) are never evaluated inside the sample
+// loop: evaluated there they cost EVERY sample of the wavefront that price for as long as one lane is inside its ramp (the bass keys of
+// a re-struck engine: 1 200 samples with a dozen lanes left in it).  They depend on the voice's own sample counter only, so each chunk
+// starts with a tabulation pass that is lane-parallel over (voice, sample): four voices x 16 samples per pass, ceil(k / 4) passes for k
+// lanes in their ramp -- the in-loop price when all 64 are (the first 2 ms after a whole-keyboard strike), a sixteenth of it for the
+// last few.  The table needs no LDS of its own: the gains of lane l's chunk are parked in lane l's row of the voice-sum tile, which that
+// lane reads (gain of sample n) just before it overwrites the slot (output of sample n).  Same function, same arguments: same bits.
+#ifndef OW_KCHUNK
+#define OW_KCHUNK 24      // 64 voices x 24 samples: 12.8 KB tile, seven workgroups per CU with the 9.7 KB coefficient table (16: +28 % with no phase active -- the chunk edge costs more than the tabulation saves)
+#endif
 __global__ __launch_bounds__(64) OW_VOICE_GENERAL_ATTR void k_voice(const OwConsts* __restrict__ K, double* __restrict__ vrec, const uint32_t* __restrict__ entries,
                                               double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int L, int Lcap, int pass) {
-    constexpr int CH = OW_VCHUNK;       // (a 16-sample tile for the dense variant -- eight workgroups per CU instead of six -- measured no different)
+    constexpr int CH = OW_KCHUNK;
     __shared__ double tile[64 * (CH + 1)];
     __shared__ double lcoef[OW_LCOEF_ROWS * 64];
-    __shared__ double gtab[TABS ? OW_GT_MAX * CH : 1];       // onset gains of this chunk, one row per lane inside its onset ramp
-    __shared__ double dtab[TABS ? OW_DT_MAX * CH * 7 : 1];   // damper-ramp factors of this chunk, [lane in its ramp][sample][mode]
     __shared__ int eng_l[64];
     const int lane = threadIdx.x;
     const VoiceLanes w = voice_lanes(entries, eng_l);
@@ -251,42 +255,33 @@ __global__ __launch_bounds__(64) OW_VOICE_GENERAL_ATTR void k_voice(const OwCons
             for (int i = base + lane; i < L; i += 64) row[i] = 0.0;
             break;
         }
-        // Phase gain curves of the chunk, lane-parallel over its samples.  The onset gain (cos, pow) and the damper-ramp factors
-        // (seven exp) depend on the voice's own sample counters only; evaluated inside the sample loop they cost every sample of
-        // the wavefront ~500 instructions as soon as ONE lane is in such a phase (a packed block mixes voices of many engines and
-        // phases).  Here each voice in a phase costs one pass of those functions per chunk, spread over the lanes.  With many lanes
-        // in the phase at once (a re-strike of all keys) the in-loop evaluation serves them all together and stays cheaper.
+        // ---- onset gains of the chunk into the tile rows of the lanes inside their ramp, four voices per pass
         const uint64_t m_on = __ballot(active && v.sample < v.onset_n);
-        const uint64_t m_rp = __ballot(active && (v.flags & 1u) && !(v.flags & 2u));
-        const bool tab_on = TABS && m_on != 0ull && __popcll(m_on) <= OW_GT_MAX;
-        const bool tab_rp = TABS && m_rp != 0ull && __popcll(m_rp) <= OW_DT_MAX;
-        if (tab_on) {
-            int r = 0;
-            for (uint64_t m = m_on; m; m &= m - 1, ++r) {
-                const int l = __builtin_ctzll(m);
-                const unsigned long long s0 = __shfl((unsigned long long)v.sample, l), on = __shfl((unsigned long long)v.onset_n, l);
-                const double inc = __shfl(v.onset_inc, l), ex = __shfl(v.onset_exp, l);
-                if (lane < cn) gtab[r * CH + lane] = (s0 + lane < on) ? onset_gain((double)(s0 + lane), inc, ex) : 1.0;
-            }
-        }
-        if (tab_rp) {
-            int r = 0;
-            for (uint64_t m = m_rp; m; m &= m - 1, ++r) {
-                const int l = __builtin_ctzll(m);
-                const double d0 = __shfl(v.dcount, l), dr = __shfl(v.dramp, l);
-                for (int q = lane; q < cn * 7; q += 64) {
-                    const int i = q / 7, md = q - 7 * i;
-                    const double t = d0 + (double)(i + 1);      // dcount after this sample's increment (exact: a sample count)
-                    dtab[(r * CH + i) * 7 + md] = exp_neg_small(lcoef[(5 + md) * 64 + l] * damper_ramp_pos(t, dr));
+        {
+            constexpr int SLOT = CH <= 16 ? 16 : 32, VP = 64 / SLOT;              // lanes per voice of a pass, voices per pass
+            const int sub = lane / SLOT, j = lane % SLOT;
+            for (uint64_t m = m_on; m; ) {
+                // the sub-th of the next (up to) VP set bits of m for this lane's part of the wavefront
+                int l = -1;
+                uint64_t mm = m;
+                for (int k = 0; k < VP; ++k) {
+                    const int b = mm ? __builtin_ctzll(mm) : -1;
+                    if (k == sub) l = b;
+                    mm &= mm - 1ull;
                 }
+                m = mm;                                                          // wave-uniform: the VP lowest bits are consumed
+                const int src = l < 0 ? 0 : l;
+                const unsigned long long s0 = __shfl((unsigned long long)v.sample, src), on = __shfl((unsigned long long)v.onset_n, src);
+                const double inc = __shfl(v.onset_inc, src), ex = __shfl(v.onset_exp, src);
+                if (l >= 0 && j < cn) tile[l * (CH + 1) + j] = (s0 + (unsigned long long)j < on) ? onset_gain((double)(s0 + (unsigned long long)j), inc, ex) : 1.0;
             }
         }
-        const double* my_gt = (tab_on && ((m_on >> lane) & 1ull)) ? gtab + __popcll(m_on & ((1ull << lane) - 1ull)) * CH : nullptr;
-        const double* my_dt = (tab_rp && ((m_rp >> lane) & 1ull)) ? dtab + __popcll(m_rp & ((1ull << lane) - 1ull)) * CH * 7 : nullptr;
+        __syncthreads();
+        const double* my_gt = tile + lane * (CH + 1);
         for (int n = 0; n < cn; ++n) {
             double o = 0.0;
             if (active) {
-                o = v.step<false>(lcoef + lane, my_gt ? my_gt + n : nullptr, my_dt ? my_dt + 7 * n : nullptr);
+                o = v.step<false, true>(lcoef + lane, my_gt + n, nullptr);      // (my_gt is only dereferenced inside the ramp)
                 if (pass) {  // 5 ms linear crossfade, engine.rs:483-489
                     const uint32_t i = (uint32_t)(base + n);
                     const uint32_t remaining = steal_fade > i ? steal_fade - i : 0u;

@@ -464,7 +464,7 @@ __device__ __noinline__ __attribute__((const)) double exp_neg(double x) { return
 // exp(-x) for the damper ramp's per-sample factors (reed.rs:236-239): x = damper_rate * t / ramp <= damper_rate = min(55 * 2^((n-60)/24)
 // * 3^m, 2000) / sr (reed.rs:198-201), i.e. 0 <= x <= 0.0454 at 44.1 kHz.  On [0, 1/8] no range reduction is needed: the degree-11 Taylor
 // polynomial in Horner form (fused steps) has a truncation error of x^12 / 12! <= 3e-20 and ends in fma(y, p, 1.0), one rounding of a
-// value in (0.88, 1]: within 0.52 ulp of exp(-x), where the library's exp (the same kind of polynomial behind a reduction by ln 2, an
+// value in (0.88, 1]: within 0.57 ulp of exp(-x) (measured, 2^23 arguments), where the library's exp (the same kind of polynomial behind a reduction by ln 2, an
 // ldexp and overflow / underflow selects: ~45 instructions behind a call, seven times per sample of every released voice for the 8-50 ms
 // of its ramp -- the cost of a whole-keyboard re-strike's steal pass) is specified to 1 ulp, like the reference's f64::exp (glibc).
 // Larger arguments (host rates below 16 kHz) take the library.  tests/test_gpu_division.py::test_damper_ramp_exp_accuracy.
@@ -570,7 +570,7 @@ struct VoiceRegs {
     // FMA contraction is enabled for this function (OW_STRICT_FP restores the reference's unfused a*b+c):
     // the kernel is VALU-issue bound and the rotation / pickup are mul-add chains.  Fused results differ from the
     // unfused reference by <= 1e-12 of peak over the parity renders (tests/test_gpu_parity.py voice-sum tap).
-    template <bool STEADY>
+    template <bool STEADY, bool ONSET_FROM_TABLE = false>
     // lcoef: LDS copy of the lane's phase-only coefficients, lcoef[i * 64]: i = 0..4 attack-noise BPF b0, b1, b2, a1, a2
     // (VF_NB0..VF_NA2, first 15 ms of a note), i = 5..11 damper_rate, i = 12..18 damper_mult (VF_DRATE / VF_DMULT, while the key is
     // released).  In registers they would cost 38 VGPRs for the whole kernel; read from the voice record in HBM they cost a
@@ -608,7 +608,8 @@ struct VoiceRegs {
                     for (int m = 0; m < 7; ++m) env[m] *= lcoef[(12 + m) * 64];
                 }
             }
-            if (sample < onset_n) onset = onset_tab ? *onset_tab : onset_gain((double)sample, onset_inc, onset_exp);
+            // (ONSET_FROM_TABLE: k_voice tabulates the gains of every lane inside its ramp ahead of the chunk -- no call in its sample loop)
+            if (sample < onset_n) onset = (ONSET_FROM_TABLE || onset_tab) ? *onset_tab : onset_gain((double)sample, onset_inc, onset_exp);
         }
         const uint32_t lo = (uint32_t)sample;
         if ((lo & 15u) == 0u) {

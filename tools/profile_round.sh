@@ -3,7 +3,7 @@
 # rocprofv3 gets the program itself after `--` (python3 ...), never a shell or env wrapper (the profiler's preloaded library has
 # initialised the GPU before the program starts: any exec hop in between takes the box down).  Counter passes are separate runs with
 # --kernel-trace only.
-R=${1:-r04}
+R=${1:-r05}
 PART=${2:-ABC}      # A = traces + default counters, B = non-default kernels, C = bench lines (one gpurun call each: a hung command then costs one part)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
@@ -75,6 +75,12 @@ timeout 900 python bench.py --power-amp melange --steps 4 --warmup 3 --no-extras
 timeout 900 python bench.py --power-amp melange --instances 16384 --steps 4 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_power_amp_melange_16384.log 2>&1
 timeout 900 python bench.py --workload batch > $O/bench_batch.log 2>&1
 timeout 900 python bench.py --instances 256 --steps 100 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_p256.log 2>&1
+# round 5: config 2 as the API delivers it (every block into the caller's pinned host block, ten re-strikes inside), the 8-rank host
+# share priced on one GPU (two host threads: what LOCAL_WORLD_SIZE = 8 leaves a rank of a 16-CPU quota), a fresh 256-instance process
+timeout 900 python bench.py --steps 938 --warmup 5 --no-extras --no-cpu-baseline --deliver host > $O/bench_10s_host.log 2>&1
+OW_HOST_THREADS=2 timeout 900 python bench.py --steps 938 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_10s_2threads.log 2>&1
+OW_HOST_THREADS=2 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_like_2threads.log 2>&1
+timeout 900 python bench.py --instances 256 --steps 30 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_p256_fresh.log 2>&1
 timeout 900 python tools/probe_fused.py > $O/probe_fused.log 2>&1
 timeout 900 python tools/probe_power_amp_waves.py 16384 > $O/probe_power_amp_waves.log 2>&1
 tail -1 $O/bench_default.log | cut -c1-700
