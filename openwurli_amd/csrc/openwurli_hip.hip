@@ -18,6 +18,7 @@
 #include "../../include/openwurli_hip.h"
 #include "../../include/openwurli_hip_test.h"
 #include "ow_consts_host.hpp"
+#include "ow_vm.h"
 #include "ow_kernels.h"
 #include "ow_job_kernels.h"
 #include "ow_mlp_mfma.h"
@@ -32,6 +33,7 @@
 #include "ow_midi_kernels.h"
 #include "ow_chain_wide.h"
 #include "ow_chain_stream.h"
+#include "ow_vm_kernels.h"
 #include <condition_variable>
 #include <map>
 #include <memory>
@@ -180,13 +182,6 @@ thread_local bool Workers::in_slice_ = false;
 #define OW_MAX_STAGES 8
 #define OW_MAX_SLICES 64   // upper bound of the slices one dispatch is cut into (scratch arrays live on the stack)
 
-struct Slot {  // VoiceSlot, engine.rs:39-62 (the Voice objects themselves live in HBM); state and note live in ow_engine's
-               // st_mask[] / midi_of[] so the per-event searches are mask operations, not 64-slot walks
-    uint64_t age = 0;
-    bool has_voice = false, has_steal = false;
-    uint32_t steal_fade = 0, steal_fade_len = 0;
-};
-
 struct HostSmoother {  // host mirror of LinearSmoother::target only (the 1e-9 acceptance test, engine.rs:86-89)
     double target;
     bool pending = false;
@@ -214,6 +209,7 @@ struct Switches {
     int pa_sort = 1;                           // OW_PA_SORT: 0 never, 1 when the block exceeds the chip, 2 always
     int eout_attn = -1;                        // OW_EOUT_ATTN=0/1: status summary instead of the status blocks (k_eout_attention); -1: ranges of >= 8 192 engines
     int pipe = 0;                              // OW_PIPE=n stages
+    int midi_device = -1;                      // OW_MIDI_DEVICE=0/1: bursts of ow_pool_midi applied on the device (k_vm_events) never / whenever the list allows; -1: pools of >= 8 192 engines, >= 65 536 events
     bool force_general = false;                // test / probe hook: every engine's slot voices go to the general voice kernel (what it costs without any phase active)
     int chain_stream = -1;                     // OW_CHAIN_STREAM=0/1: preamp + output stage of a big oversampled pool as one launch (k_chain_stream); -1: when the block goes to a pinned host block
     int out_direct = -1;                       // OW_OUT_DIRECT=0/1: output stage stores straight into a pinned host block (ow_host_alloc) instead of d_out + copy; -1: default
@@ -238,6 +234,7 @@ struct Switches {
         w.pa_sort = flag("OW_PA_SORT", 1); if (w.pa_sort < 0 || w.pa_sort > 2) w.pa_sort = 1;
         if (const char* e = std::getenv("OW_PIPE")) { const int v = std::atoi(e); w.pipe = (v >= 1 && v <= 8) ? v : 0; }
         w.pipe_overlap = flag("OW_PIPE_OVERLAP", 0) == 1;
+        w.midi_device = flag("OW_MIDI_DEVICE", -1); if (w.midi_device > 1 || w.midi_device < -1) w.midi_device = -1;
         w.chain_stream = flag("OW_CHAIN_STREAM", -1); if (w.chain_stream > 1 || w.chain_stream < -1) w.chain_stream = -1;
         w.out_direct = flag("OW_OUT_DIRECT", -1); if (w.out_direct > 1 || w.out_direct < -1) w.out_direct = -1;
         w.host_profile = std::getenv("OW_HOST_PROFILE") != nullptr;
@@ -254,53 +251,36 @@ struct ow_engine {
     ow_pool* pool = nullptr;
     size_t index = 0;
     bool owns_pool = false;
-    Slot slots[OW_MAX_VOICES];
-    // slot state as four disjoint bitmasks indexed by OW_VOICE_* (exactly one bit set per slot) and the slot notes as 64 bytes:
-    // note_on / note_off / allocate_voice become ctz / SSE2 byte-compare instead of scans over 2 KB of slots
-    uint64_t st_mask[4] = {~0ull, 0, 0, 0};
-    alignas(16) uint8_t midi_of[OW_MAX_VOICES] = {0};
-    int state_of(int s) const {
-        const uint64_t b = 1ull << s;
-        return (st_mask[1] & b) ? 1 : (st_mask[2] & b) ? 2 : (st_mask[3] & b) ? 3 : 0;
-    }
-    void set_state(int s, int st) {
-        const uint64_t b = 1ull << s;
-        st_mask[0] &= ~b; st_mask[1] &= ~b; st_mask[2] &= ~b; st_mask[3] &= ~b;
-        st_mask[st] |= b;
-    }
-    uint64_t note_match(uint8_t note) const {   // bit s set <=> midi_of[s] == note
-        const __m128i n = _mm_set1_epi8((char)note);
-        uint64_t m = 0;
-        for (int k = 0; k < 4; ++k) {
-            const __m128i v = _mm_load_si128((const __m128i*)(midi_of + 16 * k));
-            m |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(v, n)) << (16 * k);
-        }
-        return m;
-    }
-    uint64_t age_counter = 0;
-    bool sustain_held = false, mlp_enabled = true;
+    // VoiceSlot[64] + pool counters (engine.rs:39-62): plain data shared with the device (ow_vm.h).  An engine of a pool points into the
+    // pool's pinned array (a burst of events applied on the device is copied back into it wholesale); a device-less test engine owns one.
+    OwVm* vm = nullptr;
+    OwVm own_vm;
+    ow_engine() { vm_init(own_vm); vm = &own_vm; }
+    int state_of(int s) const { return vm_state_of(*vm, s); }
+    void set_state(int s, int st) { vm_set_state(*vm, s, st); }
     bool rail_sag = true;           // melange power amp: rail sag (PowerAmp::new_at_sample_rate starts with it on, power_amp.rs:335-346)
     bool noise_on = false;          // melange preamp thermal noise (engine.rs:394-400); DkPreamp::new starts with off / 1.0
     double thermal_gain = 1.0;
     HostSmoother volume{0.5}, depth{0.5}, spk{0.0};
     uint64_t nan_guard_fires = 0, output_nan_resets = 0;
-    std::vector<OwOp> ops;  // pending slot ops, applied at the start of the next render
-    // bit s set <=> slot s renders a voice / a steal voice (engine.rs:471-493); kept incrementally
-    uint64_t main_mask = 0, steal_mask = 0;
+    std::vector<OwOp> ops;  // pending slot ops queued on the host, applied at the start of the next render (behind the device-queued ones)
     double sr = 0.0;            // host sample rate (steal crossfade length, engine.rs:318)
     uint8_t* dirty = nullptr;   // -> pool->dirty[index]: engine has pending ops / setter targets / changed masks
     uint8_t* dirty_any = nullptr;   // -> pool->dirty_any: some engine of the pool is dirty (lets a steady block skip the per-engine scans)
+    uint8_t* host_ops_any = nullptr; // -> pool->host_ops_any: some engine holds host-queued ops (a burst then stays on the host: queue order)
     // (test before set: sixteen MIDI threads storing to the one shared byte on every event bounce its cache line -- 520 ms instead of 40 for
     // a 16.7 M-event re-strike; a read of an already-set flag stays shared)
     void mark() { if (dirty) { *dirty = 1; if (!__atomic_load_n(dirty_any, __ATOMIC_RELAXED)) __atomic_store_n(dirty_any, (uint8_t)1, __ATOMIC_RELAXED); } }
-    void sync_masks(int s) {
-        const Slot& sl = slots[s];
-        const uint64_t b = 1ull << s;
-        if (sl.has_voice && !(st_mask[OW_VOICE_FREE] & b)) main_mask |= b; else main_mask &= ~b;
-        if (sl.has_steal) steal_mask |= b; else steal_mask &= ~b;
+    void sync_masks(int s) { vm_sync_masks(*vm, s); mark(); }
+    void touch() { mark(); }
+    // Sink of the shared state machine on the host: the engine's own op list
+    void push(uint8_t type, int slot, uint8_t note, bool mlp, uint32_t seed, double vel) {
+        OwOp op;
+        op.type = type; op.slot = (uint8_t)slot; op.note = note; op.mlp = mlp ? 1 : 0; op.seed = seed; op.velocity = vel;
+        ops.push_back(op);
+        if (host_ops_any && !__atomic_load_n(host_ops_any, __ATOMIC_RELAXED)) __atomic_store_n(host_ops_any, (uint8_t)1, __ATOMIC_RELAXED);
         mark();
     }
-    void touch() { mark(); }
 };
 
 struct ow_pool {
@@ -367,6 +347,26 @@ struct ow_pool {
     OwEngineOut* d_eout_packed = nullptr;   // [I] status blocks of a list of engines, packed (voice-sum NaN guard's second pass)
     OwEngineOut* h_eout_packed = nullptr;   // pinned
     OwOp* h_ops = nullptr;            // pinned
+    // Voice-pool states (ow_vm.h): h_vm is what the engines' host state machine works on; a burst of events (ow_pool_midi on a big pool) is
+    // applied to d_vm by k_vm_events and copied back.  vm_host_dirty: the host changed some state since d_vm was last written.
+    OwVm* h_vm = nullptr;             // pinned [I]
+    OwVm* d_vm = nullptr;             // [I], allocated with the first burst
+    OwOp* d_ops_fix = nullptr;        // [I][OW_VM_OPS_MAX] op queues written by the device
+    ow_midi_event* h_ev = nullptr;    // pinned staging of a burst's events (lists that are not in a pinned block themselves)
+    ow_midi_event* d_ev = nullptr;
+    size_t ev_cap = 0;
+    uint32_t* d_ev_begin = nullptr;   // [2][I] slice of every engine in the burst's list
+    uint8_t vm_host_dirty = 1;
+    uint8_t host_ops_any = 0;         // some engine holds host-queued ops since the last whole-pool render
+    uint32_t* d_vm_ovf = nullptr;     // a device queue overflowed during the burst (the burst is then replayed on the host)
+    uint32_t* h_vm_ovf = nullptr;     // pinned
+    bool vm_download_pending = false; // d_vm -> h_vm is in flight (ev_vm)
+    hipEvent_t ev_vm = nullptr;
+    bool dev_ops_pending = false;     // some engine's next ops sit in d_ops_fix
+    uint64_t vm_bursts = 0;           // bursts that went through the device (test hook)
+    struct OpTail { uint32_t src, dst, n; };   // host-queued ops of an engine that also has device-queued ones: appended on the device
+    std::vector<OpTail> op_tails;
+    std::mutex op_tails_mu;
     // Packed voice dispatch (ow_kernels.h): lane = sounding voice.  Three block lists of (engine << 6 | slot) entries, rebuilt when a
     // mask, a pending op or a transient flag changed: steady slot voices, slot voices of engines in a transient phase, steal voices.
     struct VoiceList { uint32_t* h = nullptr; uint32_t* d = nullptr; uint32_t n_blocks = 0; };
@@ -429,6 +429,14 @@ struct ow_pool {
 };
 
 namespace {
+
+// The host mirror of the voice-pool states is current (a burst applied on the device is copied back asynchronously: wait for it), and
+// the host is about to change / has changed one of them (the device copy is stale until the next burst uploads them again).
+void vm_wait_download(ow_pool* p) {
+    if (p && p->vm_download_pending) { hipEventSynchronize(p->ev_vm); p->vm_download_pending = false; }
+}
+void vm_host_current(const ow_engine* e) { if (e && e->pool) vm_wait_download(e->pool); }
+void vm_host_changed(ow_engine* e) { if (e && e->pool && !__atomic_load_n(&e->pool->vm_host_dirty, __ATOMIC_RELAXED)) __atomic_store_n(&e->pool->vm_host_dirty, (uint8_t)1, __ATOMIC_RELAXED); }
 
 // Drop a pending block-ahead tremolo result: restore the oscillator rows it advanced and drain the tremolo stream.
 void invalidate_spec(ow_pool* p) {
@@ -1361,6 +1369,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
     const int L = (int)len, Lcap = (int)p->Lcap;
     p->out_ld = len;
     hipStream_t st = p->stream, tt = p->stream_trem;
+    vm_wait_download(p);                     // a burst applied on the device: the host's copy of the voice-pool states is complete from here on
     // ---- tremolo: CdS cell resistance of this block
     const int n_os = L * (p->hc.oversample ? 2 : 1);
     const size_t rb_half = (size_t)2 * p->Lcap * p->I;
@@ -1469,12 +1478,25 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
                 }
                 ow_engine* en = p->engines[e0 + k];
                 // engine.rs:471-473: a Free slot renders nothing unless it still carries a steal voice
-                a.main_mask = en->main_mask; a.steal_mask = en->steal_mask;
+                a.main_mask = en->vm->main_mask; a.steal_mask = en->vm->steal_mask;
                 a.noise_on = en->noise_on ? 1u : 0u; a.thermal_gain = en->thermal_gain;
                 a.pa_flags = en->rail_sag ? 1u : 0u;
                 a.op_begin = (uint32_t)op_pos;
                 a.op_count = (uint32_t)en->ops.size();
                 if (!en->ops.empty()) std::memcpy(p->h_ops + op_pos, en->ops.data(), sizeof(OwOp) * en->ops.size());
+                if (const uint32_t nd = en->vm->n_dev_ops) {
+                    // the engine's queue was (also) written on the device (k_vm_events): it stays where it is; ops the host queued
+                    // behind it are appended there after the upload (rare: single events between a burst and the render)
+                    if (!en->ops.empty()) {
+                        const uint32_t room = OW_VM_OPS_MAX - nd, nh = (uint32_t)std::min<size_t>(en->ops.size(), room);
+                        std::lock_guard<std::mutex> lk(p->op_tails_mu);
+                        p->op_tails.push_back({(uint32_t)op_pos, (uint32_t)((e0 + k) * OW_VM_OPS_MAX) + nd, nh});
+                        a.op_count = nd + nh;
+                    } else a.op_count = nd;
+                    a.op_begin = 0x80000000u | (uint32_t)((e0 + k) * OW_VM_OPS_MAX);
+                    en->vm->n_dev_ops = 0;
+                    if (!p->vm_host_dirty) p->vm_host_dirty = 1;
+                }
                 op_pos += en->ops.size();
                 en->ops.clear();
                 a.set_flags = 0;
@@ -1499,14 +1521,21 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
     }
     HIP_OK(hipMemsetAsync(p->d_eout + e0, 0, sizeof(OwEngineOut) * ne, st));
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[0], st));
-    if (n_ops) {
-        HIP_OK(hipMemcpyAsync(p->d_ops, p->h_ops, sizeof(OwOp) * n_ops, hipMemcpyHostToDevice, st));
+    if (n_ops || p->dev_ops_pending) {
+        if (n_ops) HIP_OK(hipMemcpyAsync(p->d_ops, p->h_ops, sizeof(OwOp) * n_ops, hipMemcpyHostToDevice, st));
+        for (const ow_pool::OpTail& t : p->op_tails)
+            HIP_OK(hipMemcpyAsync(p->d_ops_fix + t.dst, p->d_ops + t.src, sizeof(OwOp) * t.n, hipMemcpyDeviceToDevice, st));
+        p->op_tails.clear();
         // one block per engine that has ops
         uint32_t n_act = 0;
         for (int k = 0; k < ne; ++k) if (p->h_args[e0 + k].op_count) p->h_op_engines[n_act++] = (uint32_t)(e0 + k);
-        HIP_OK(hipMemcpyAsync(p->d_op_engines, p->h_op_engines, sizeof(uint32_t) * n_act, hipMemcpyHostToDevice, st));
-        owdev::k_apply_ops<<<dim3(n_act), dim3(64), 0, st>>>(p->dK, p->d_nt, p->d_vrec, p->d_args, p->d_ops, p->d_op_engines);
+        if (n_act) {
+            HIP_OK(hipMemcpyAsync(p->d_op_engines, p->h_op_engines, sizeof(uint32_t) * n_act, hipMemcpyHostToDevice, st));
+            owdev::k_apply_ops<<<dim3(n_act), dim3(64), 0, st>>>(p->dK, p->d_nt, p->d_vrec, p->d_args, p->d_ops, p->d_op_engines, p->d_ops_fix);
+        }
+        if (whole) p->dev_ops_pending = false;
     }
+    if (whole) __atomic_store_n(&p->host_ops_any, (uint8_t)0, __ATOMIC_RELAXED);
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[1], st));
     const bool voices = with_voices && (any_main || any_steal);
     if (voices) {
@@ -1664,28 +1693,28 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
 // host bookkeeping of ONE engine after a block: steal-fade countdown (engine.rs:490-493), NaN-guard frees (engine.rs:499-521,
 // culprits identified in the same pass) and cleanup_voices (engine.rs:592-602)
 void engine_post_render(ow_engine* en, uint32_t l32, const OwEngineOut& o) {
-    if (en->steal_mask) {
-        for (uint64_t m = en->steal_mask; m; m &= m - 1) {
+    OwVm& v = *en->vm;
+    vm_host_changed(en);
+    if (v.steal_mask) {
+        for (uint64_t m = v.steal_mask; m; m &= m - 1) {
             const int s = __builtin_ctzll(m);
-            Slot& sl = en->slots[s];
-            sl.steal_fade = sl.steal_fade > l32 ? sl.steal_fade - l32 : 0u;
-            if (sl.steal_fade == 0) { sl.has_steal = false; en->sync_masks(s); }
+            v.steal_fade[s] = v.steal_fade[s] > l32 ? v.steal_fade[s] - l32 : 0u;
+            if (v.steal_fade[s] == 0) { v.has_steal &= ~(1ull << s); en->sync_masks(s); }
         }
     }
     if (o.sum_nonfinite) {
         en->nan_guard_fires += 1;
         for (int s = 0; s < OW_MAX_VOICES; ++s) {
-            Slot& sl = en->slots[s];
-            if ((o.bad_main >> s) & 1ull) { en->set_state(s, OW_VOICE_FREE); sl.has_voice = false; }
-            if ((o.bad_steal >> s) & 1ull) { sl.has_steal = false; sl.steal_fade = 0; }
+            const uint64_t b = 1ull << s;
+            if ((o.bad_main >> s) & 1ull) { en->set_state(s, OW_VOICE_FREE); v.has_voice &= ~b; }
+            if ((o.bad_steal >> s) & 1ull) { v.has_steal &= ~b; v.steal_fade[s] = 0; }
             en->sync_masks(s);
         }
     }
     if (o.out_nonfinite) en->output_nan_resets += 1;
-    for (uint64_t m = o.silent_mask & en->main_mask; m; m &= m - 1) {
+    for (uint64_t m = o.silent_mask & v.main_mask; m; m &= m - 1) {
         const int s = __builtin_ctzll(m);
-        Slot& sl = en->slots[s];
-        if (en->state_of(s) != OW_VOICE_FREE && sl.has_voice) { en->set_state(s, OW_VOICE_FREE); sl.has_voice = false; en->sync_masks(s); }
+        if (en->state_of(s) != OW_VOICE_FREE && ((v.has_voice >> s) & 1ull)) { en->set_state(s, OW_VOICE_FREE); v.has_voice &= ~(1ull << s); en->sync_masks(s); }
     }
 }
 
@@ -1696,17 +1725,18 @@ void engine_post_render(ow_engine* en, uint32_t l32, const OwEngineOut& o) {
 // another `len` samples (k_voice in guard mode: same stepping, nothing summed), voices that turn non-finite in that second pass are freed
 // too, and the status the block leaves behind (silent voices, transient phases) is the status after the second pass.  Cold path.
 void engine_guard_second_pass_result(ow_engine* en, const OwEngineOut& o) {
+    OwVm& v = *en->vm;
+    vm_host_changed(en);
     for (int s = 0; s < OW_MAX_VOICES; ++s) {
-        Slot& sl = en->slots[s];
+        const uint64_t b = 1ull << s;
         bool touched = false;
-        if ((o.bad_main >> s) & 1ull) { en->set_state(s, OW_VOICE_FREE); sl.has_voice = false; touched = true; }
-        if ((o.bad_steal >> s) & 1ull) { sl.has_steal = false; sl.steal_fade = 0; touched = true; }
+        if ((o.bad_main >> s) & 1ull) { en->set_state(s, OW_VOICE_FREE); v.has_voice &= ~b; touched = true; }
+        if ((o.bad_steal >> s) & 1ull) { v.has_steal &= ~b; v.steal_fade[s] = 0; touched = true; }
         if (touched) en->sync_masks(s);
     }
-    for (uint64_t m = o.silent_mask & en->main_mask; m; m &= m - 1) {     // cleanup_voices sees the twice-advanced voices (engine.rs:461)
+    for (uint64_t m = o.silent_mask & v.main_mask; m; m &= m - 1) {     // cleanup_voices sees the twice-advanced voices (engine.rs:461)
         const int s = __builtin_ctzll(m);
-        Slot& sl = en->slots[s];
-        if (en->state_of(s) != OW_VOICE_FREE && sl.has_voice) { en->set_state(s, OW_VOICE_FREE); sl.has_voice = false; en->sync_masks(s); }
+        if (en->state_of(s) != OW_VOICE_FREE && ((v.has_voice >> s) & 1ull)) { en->set_state(s, OW_VOICE_FREE); v.has_voice &= ~(1ull << s); en->sync_masks(s); }
     }
 }
 void guard_second_pass(ow_pool* p, const uint32_t* engs, size_t n_eng, size_t len) {
@@ -1719,8 +1749,8 @@ void guard_second_pass(ow_pool* p, const uint32_t* engs, size_t n_eng, size_t le
             for (uint64_t m = mask; m; m &= m - 1) a[n++] = (engs[i] << 6) | (uint32_t)__builtin_ctzll(m);
             while (n & 63u) a[n++] = 0xFFFFFFFFu;
         };
-        put(p->vl_general.h, nm, en->main_mask);
-        put(p->vl_steal.h, ns, en->steal_mask);
+        put(p->vl_general.h, nm, en->vm->main_mask);
+        put(p->vl_steal.h, ns, en->vm->steal_mask);
     }
     p->lists_valid = false;           // the list buffers were borrowed
     // the guarded engines' status blocks: ONE clear, ONE gather and ONE transfer for the whole set (a bad parameter broadcast to a big
@@ -1865,38 +1895,17 @@ void warm_up_range(ow_pool* p, int e0, int ne) {
 }
 
 void engine_host_reset(ow_engine* en) {  // host half of WurliEngine::reset (engine.rs:231-244)
-    for (auto& s : en->slots) { s.has_voice = false; s.has_steal = false; s.steal_fade = 0; }
-    en->st_mask[0] = ~0ull; en->st_mask[1] = en->st_mask[2] = en->st_mask[3] = 0;
-    en->main_mask = 0; en->steal_mask = 0;
+    vm_host_current(en); vm_host_changed(en);
+    const uint8_t mlp = en->vm->mlp_enabled;
+    vm_init(*en->vm);                          // every slot Free, no voices, age counter 0, sustain up; nothing queued on the device either
+    en->vm->mlp_enabled = mlp;                 // (a parameter, not state: reset() does not touch it)
     en->touch();
-    en->age_counter = 0;
-    en->sustain_held = false;
     en->ops.clear();
     // snap_to(target): a pending retarget would ramp; the device snaps current := target, so drop the ramp request
     en->volume.pending = en->depth.pending = en->spk.pending = false;
 }
 
-int allocate_voice(const ow_engine* en) {  // engine.rs:569-590
-    // first free slot, else the oldest voice of the lowest-priority non-empty class (releasing < sustained < held); ages are
-    // unique, so this is the slot the reference's min_by_key over (class, age) returns
-    if (en->st_mask[OW_VOICE_FREE]) return __builtin_ctzll(en->st_mask[OW_VOICE_FREE]);
-    const uint64_t cls = en->st_mask[OW_VOICE_RELEASING] ? en->st_mask[OW_VOICE_RELEASING]
-                       : en->st_mask[OW_VOICE_SUSTAINED] ? en->st_mask[OW_VOICE_SUSTAINED] : en->st_mask[OW_VOICE_HELD];
-    int best_idx = 0;
-    uint64_t best = ~0ull;
-    for (uint64_t m = cls; m; m &= m - 1) {
-        const int i = __builtin_ctzll(m);
-        if (en->slots[i].age < best) { best = en->slots[i].age; best_idx = i; }
-    }
-    return best_idx;
-}
-
-void push_op(ow_engine* en, uint8_t type, int slot, uint8_t note, bool mlp, uint32_t seed, double vel) {
-    OwOp op;
-    op.type = type; op.slot = (uint8_t)slot; op.note = note; op.mlp = mlp ? 1 : 0; op.seed = seed; op.velocity = vel;
-    en->ops.push_back(op);
-    en->touch();
-}
+void push_op(ow_engine* en, uint8_t type, int slot, uint8_t note, bool mlp, uint32_t seed, double vel) { en->push(type, slot, note, mlp, seed, vel); }
 
 ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int preamp_kind, int power_amp_kind = OW_POWER_AMP_BEHAVIORAL,
                      int tremolo_kind = OW_TREMOLO_TWIN_T, bool voices_only = false, bool no_traj) {
@@ -1943,6 +1952,8 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     HIP_OK(hipMalloc(&p->d_args, sizeof(OwEngineArgs) * n_engines));
     HIP_OK(hipMalloc(&p->d_eout, sizeof(OwEngineOut) * n_engines));
     HIP_OK(hipHostMalloc(&p->h_args, sizeof(OwEngineArgs) * n_engines));
+    HIP_OK(hipHostMalloc(&p->h_vm, sizeof(OwVm) * n_engines));
+    HIP_OK(hipEventCreateWithFlags(&p->ev_vm, hipEventDisableTiming));
     HIP_OK(hipHostMalloc(&p->h_eout, sizeof(OwEngineOut) * n_engines));
     HIP_OK(hipMalloc(&p->d_eout_packed, sizeof(OwEngineOut) * n_engines));
     HIP_OK(hipHostMalloc(&p->h_eout_packed, sizeof(OwEngineOut) * n_engines));
@@ -2018,6 +2029,9 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
         en->pool = p;
         en->index = i;
         en->dirty = &p->dirty[i]; en->dirty_any = &p->dirty_any;
+        en->vm = &p->h_vm[i];
+        vm_init(*en->vm);
+        en->host_ops_any = &p->host_ops_any;
         en->sr = sample_rate;
         // Room for a whole-keyboard re-strike (damper + move-to-steal + note-on per key) from the start: growing 65 536 op lists
         // from 64 to 192 entries inside the first re-strike cost 180 ms of reallocation and page faults on the MIDI threads
@@ -2082,6 +2096,15 @@ void pool_destroy(ow_pool* p) {
     if (p->d_snap) hipFree(p->d_snap);
     if (p->h_snap) hipHostFree(p->h_snap);
     hipHostFree(p->h_args); hipHostFree(p->h_eout);
+    if (p->h_vm) hipHostFree(p->h_vm);
+    if (p->d_vm) hipFree(p->d_vm);
+    if (p->d_ops_fix) hipFree(p->d_ops_fix);
+    if (p->h_ev) hipHostFree(p->h_ev);
+    if (p->d_ev) hipFree(p->d_ev);
+    if (p->d_ev_begin) hipFree(p->d_ev_begin);
+    if (p->d_vm_ovf) hipFree(p->d_vm_ovf);
+    if (p->h_vm_ovf) hipHostFree(p->h_vm_ovf);
+    if (p->ev_vm) hipEventDestroy(p->ev_vm);
     if (p->d_eout_packed) hipFree(p->d_eout_packed);
     if (p->h_eout_packed) hipHostFree(p->h_eout_packed);
     if (p->d_skew_seen) hipFree(p->d_skew_seen);
@@ -2411,73 +2434,28 @@ void ow_engine_warm_up(ow_engine* e) {
 
 void ow_engine_ensure_buffer_capacity(ow_engine* e, size_t n) { if (e) ow_pool_ensure_buffer_capacity(e->pool, n); }
 
+// (the state machine itself: ow_vm.h -- the same functions run on the device for bursts, k_vm_events)
 void ow_engine_note_on(ow_engine* e, uint8_t note_in, float velocity) {  // engine.rs:299-338
     if (!e) return;
-    const uint8_t note = std::min<uint8_t>(std::max<uint8_t>(note_in, OW_MIDI_LO), OW_MIDI_HI);
-    if (e->st_mask[OW_VOICE_SUSTAINED]) {
-        for (uint64_t m = e->st_mask[OW_VOICE_SUSTAINED] & e->note_match(note); m; m &= m - 1) {
-            const int i = __builtin_ctzll(m);
-            e->set_state(i, OW_VOICE_RELEASING);
-            if (e->slots[i].has_voice) push_op(e, OP_DAMPER, i, note, false, 0, 0.0);
-        }
-    }
-    const int idx = allocate_voice(e);
-    Slot& slot = e->slots[idx];
-    if (e->state_of(idx) != OW_VOICE_FREE) {
-        const uint32_t fade = owhip::sat_u32(e->sr * 0.005);
-        if (slot.has_voice) {
-            push_op(e, OP_MOVE_STEAL, idx, note, false, fade, 0.0);
-            slot.has_steal = true;
-        } else {
-            slot.has_steal = false;  // Option::take() of an empty voice
-        }
-        slot.has_voice = false;
-        slot.steal_fade = fade;
-        slot.steal_fade_len = fade;
-    }
-    e->age_counter += 1;
-    const uint32_t seed = (uint32_t)note * 2654435761u + (uint32_t)e->age_counter;
-    push_op(e, OP_NOTE_ON, idx, note, e->mlp_enabled, seed, (double)velocity);
-    slot.has_voice = true;
-    e->set_state(idx, OW_VOICE_HELD);
-    e->midi_of[idx] = note;
-    slot.age = e->age_counter;
-    e->sync_masks(idx);
+    vm_host_current(e); vm_host_changed(e);
+    vm_note_on(*e->vm, *e, note_in, velocity, owhip::sat_u32(e->sr * 0.005));
+    e->mark();
 }
-
 void ow_engine_note_off(ow_engine* e, uint8_t note_in) {  // engine.rs:340-359
     if (!e) return;
-    const uint8_t note = std::min<uint8_t>(std::max<uint8_t>(note_in, OW_MIDI_LO), OW_MIDI_HI);
-    int oldest = -1;
-    if (!e->st_mask[OW_VOICE_HELD]) return;
-    for (uint64_t m = e->st_mask[OW_VOICE_HELD] & e->note_match(note); m; m &= m - 1) {
-        const int i = __builtin_ctzll(m);
-        if (oldest < 0 || e->slots[i].age < e->slots[oldest].age) oldest = i;
-    }
-    if (oldest < 0) return;
-    if (e->sustain_held) e->set_state(oldest, OW_VOICE_SUSTAINED);
-    else {
-        e->set_state(oldest, OW_VOICE_RELEASING);
-        if (e->slots[oldest].has_voice) push_op(e, OP_DAMPER, oldest, note, false, 0, 0.0);
-    }
+    vm_host_current(e); vm_host_changed(e);
+    vm_note_off(*e->vm, *e, note_in);
 }
-
 void ow_engine_set_sustain(ow_engine* e, int held) {  // engine.rs:361-374
     if (!e) return;
-    if (e->sustain_held && !held) {
-        for (uint64_t m = e->st_mask[OW_VOICE_SUSTAINED]; m; m &= m - 1) {   // ascending slot order, as the reference iterates
-            const int i = __builtin_ctzll(m);
-            e->set_state(i, OW_VOICE_RELEASING);
-            if (e->slots[i].has_voice) push_op(e, OP_DAMPER, i, e->midi_of[i], false, 0, 0.0);
-        }
-    }
-    e->sustain_held = held != 0;
+    vm_host_current(e); vm_host_changed(e);
+    vm_set_sustain(*e->vm, *e, held != 0);
 }
 
 void ow_engine_set_volume(ow_engine* e, double v) { if (e) { e->volume.set_target(v); if (e->volume.pending) e->touch(); } }
 void ow_engine_set_tremolo_depth(ow_engine* e, double d) { if (e) { e->depth.set_target(d); if (e->depth.pending) e->touch(); } }
 void ow_engine_set_speaker_character(ow_engine* e, double c) { if (e) { e->spk.set_target(c); if (e->spk.pending) e->touch(); } }
-void ow_engine_set_mlp_enabled(ow_engine* e, int on) { if (e) e->mlp_enabled = on != 0; }
+void ow_engine_set_mlp_enabled(ow_engine* e, int on) { if (e) { vm_host_current(e); e->vm->mlp_enabled = on != 0 ? 1 : 0; vm_host_changed(e); } }
 // Thermal noise of the melange preamp's main state; no-ops on the legacy solver (dk_preamp_legacy.rs:262-265)
 void ow_engine_set_noise_enabled(ow_engine* e, int on) {
     if (!e || !e->pool || e->pool->hc.preamp_kind != OW_PREAMP_MELANGE12) return;
@@ -2508,12 +2486,14 @@ void ow_engine_render(ow_engine* e, float* out, size_t len) {
 void ow_engine_get_diag(const ow_engine* e, ow_diag* d) {
     if (!e || !d) return;
     std::memset(d, 0, sizeof *d);
-    d->active_voices = (uint32_t)__builtin_popcountll(~e->st_mask[OW_VOICE_FREE]);
-    d->held_voices = (uint32_t)__builtin_popcountll(e->st_mask[OW_VOICE_HELD]);
-    d->sustained_voices = (uint32_t)__builtin_popcountll(e->st_mask[OW_VOICE_SUSTAINED]);
-    d->releasing_voices = (uint32_t)__builtin_popcountll(e->st_mask[OW_VOICE_RELEASING]);
-    for (const Slot& s : e->slots) if (s.has_steal) d->steal_voices++;
-    d->sustain_held = e->sustain_held ? 1 : 0;
+    vm_host_current(e);
+    const OwVm& v = *e->vm;
+    d->active_voices = (uint32_t)__builtin_popcountll(~v.st_mask[OW_VOICE_FREE]);
+    d->held_voices = (uint32_t)__builtin_popcountll(v.st_mask[OW_VOICE_HELD]);
+    d->sustained_voices = (uint32_t)__builtin_popcountll(v.st_mask[OW_VOICE_SUSTAINED]);
+    d->releasing_voices = (uint32_t)__builtin_popcountll(v.st_mask[OW_VOICE_RELEASING]);
+    d->steal_voices = (uint32_t)__builtin_popcountll(v.has_steal);
+    d->sustain_held = v.sustain_held ? 1 : 0;
     d->nan_guard_fires = e->nan_guard_fires;
     d->output_nan_resets = e->output_nan_resets;
     ow_pool* p = e->pool;
@@ -2532,11 +2512,12 @@ void ow_engine_get_diag(const ow_engine* e, ow_diag* d) {
         }
     }
 }
-int ow_engine_slot_state(const ow_engine* e, int slot) { return (e && slot >= 0 && slot < OW_MAX_VOICES) ? e->state_of(slot) : -1; }
-int ow_engine_slot_note(const ow_engine* e, int slot) { return (e && slot >= 0 && slot < OW_MAX_VOICES) ? e->midi_of[slot] : -1; }
+int ow_engine_slot_state(const ow_engine* e, int slot) { vm_host_current(e); return (e && slot >= 0 && slot < OW_MAX_VOICES) ? e->state_of(slot) : -1; }
+int ow_engine_slot_note(const ow_engine* e, int slot) { vm_host_current(e); return (e && slot >= 0 && slot < OW_MAX_VOICES) ? e->vm->midi_of[slot] : -1; }
 int ow_engine_has_steal_voice_for(const ow_engine* e, uint8_t note) {
     if (!e) return 0;
-    for (int i = 0; i < OW_MAX_VOICES; ++i) if (e->midi_of[i] == note && e->slots[i].has_steal) return 1;
+    vm_host_current(e);
+    for (int i = 0; i < OW_MAX_VOICES; ++i) if (e->vm->midi_of[i] == note && ((e->vm->has_steal >> i) & 1ull)) return 1;
     return 0;
 }
 
@@ -2550,6 +2531,67 @@ static void midi_apply_one(ow_pool* p, const ow_midi_event& ev) {
     }
 }
 
+// A burst on the device (ow_vm.h / ow_vm_kernels.h).  The list must be grouped by engine (the usual layout of a batched script; verified
+// by the caller) and the ops it queues must fit the engines' fixed queues; false = not taken (the host path does it).
+static bool midi_burst_on_device(ow_pool* p, const ow_midi_event* ev, size_t n) {
+    const size_t I = p->I;
+    HIP_OK(hipSetDevice(p->device));
+    hipStream_t st = p->stream;
+    if (!p->d_vm) {                                                // first burst: the device side of the state machine (instantiation-class work)
+        HIP_OK(hipMalloc(&p->d_vm, sizeof(OwVm) * I));
+        HIP_OK(hipMalloc(&p->d_ops_fix, sizeof(OwOp) * OW_VM_OPS_MAX * I));
+        HIP_OK(hipMalloc(&p->d_ev_begin, sizeof(uint32_t) * 2 * I));
+        HIP_OK(hipMalloc(&p->d_vm_ovf, sizeof(uint32_t)));
+        HIP_OK(hipHostMalloc(&p->h_vm_ovf, sizeof(uint32_t)));
+        p->vm_host_dirty = 1;
+    }
+    if (__atomic_load_n(&p->host_ops_any, __ATOMIC_RELAXED)) return false;   // ops queued on the host come first in their engines' queues: host path
+    // the events: straight from the caller's block when it is pinned (ow_host_alloc), else through a pinned staging copy made by the workers
+    const ow_midi_event* src = (const ow_midi_event*)host_block_device_ptr(ev, sizeof(ow_midi_event) * n) ? ev : nullptr;
+    if (n > p->ev_cap) {
+        if (p->d_ev) hipFree(p->d_ev);
+        if (p->h_ev) hipHostFree(p->h_ev);
+        p->d_ev = nullptr; p->h_ev = nullptr; p->ev_cap = 0;
+        const size_t cap = std::max<size_t>(n, (size_t)2 * OW_MAX_VOICES * I);      // a whole-keyboard re-strike of every engine
+        HIP_OK(hipMalloc(&p->d_ev, sizeof(ow_midi_event) * cap));
+        HIP_OK(hipHostMalloc(&p->h_ev, sizeof(ow_midi_event) * cap));
+        p->ev_cap = cap;
+    }
+    if (!src) {
+        const size_t T = std::min<size_t>(effective_cpus(), OW_MAX_SLICES);
+        auto copy = [&](size_t t) { const size_t a = n * t / T, b = n * (t + 1) / T; std::memcpy(p->h_ev + a, ev + a, sizeof(ow_midi_event) * (b - a)); };
+        Workers::get().each(T, copy);
+        src = p->h_ev;
+    }
+    vm_wait_download(p);
+    const uint32_t e_lo = std::min<uint32_t>(ev[0].engine, (uint32_t)I), e_hi = std::min<uint32_t>(ev[n - 1].engine + 1u, (uint32_t)I);
+    if (e_lo >= e_hi) return true;                                 // nothing addressed to this pool
+    if (p->vm_host_dirty) {
+        HIP_OK(hipMemcpyAsync(p->d_vm, p->h_vm, sizeof(OwVm) * I, hipMemcpyHostToDevice, st));
+        p->vm_host_dirty = 0;
+    }
+    HIP_OK(hipMemcpyAsync(p->d_ev, src, sizeof(ow_midi_event) * n, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(p->d_ev_begin, 0, sizeof(uint32_t) * 2 * I, st));
+    owdev::k_vm_index<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(p->d_ev, n, p->d_ev_begin, p->d_ev_begin + I, (uint32_t)I);
+    const uint32_t fade = owhip::sat_u32(p->engines[0]->sr * 0.005);
+    HIP_OK(hipMemsetAsync(p->d_vm_ovf, 0, sizeof(uint32_t), st));
+    owdev::k_vm_events<<<dim3((e_hi - e_lo + 63) / 64), dim3(64), 0, st>>>(p->d_vm, p->d_ev, p->d_ev_begin, p->d_ev_begin + I, p->d_ops_fix, e_lo, e_hi, fade, p->d_vm_ovf);
+    HIP_OK(hipGetLastError());
+    // a queue that overflowed (more than OW_VM_OPS_MAX slot ops for one engine between two renders) lost ops: nothing of this burst is
+    // kept -- the host's copy of the states is still the one from before it -- and the host path replays it
+    HIP_OK(hipMemcpyAsync(p->h_vm_ovf, p->d_vm_ovf, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (*p->h_vm_ovf) { p->vm_host_dirty = 1; return false; }
+    HIP_OK(hipMemcpyAsync(p->h_vm + e_lo, p->d_vm + e_lo, sizeof(OwVm) * (e_hi - e_lo), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipEventRecord(p->ev_vm, st));
+    p->vm_download_pending = true;
+    std::memset(p->dirty.data() + e_lo, 1, e_hi - e_lo);           // masks / queues of these engines changed: the next render packs them
+    __atomic_store_n(&p->dirty_any, (uint8_t)1, __ATOMIC_RELAXED);
+    p->dev_ops_pending = true;
+    p->vm_bursts += 1;
+    return true;
+}
+
 void ow_pool_midi(ow_pool* p, const ow_midi_event* ev, size_t n) {
     if (!p || !ev) return;
     // Engines are independent state machines: large event lists are applied by the persistent host workers, each slice owning a
@@ -2557,7 +2599,16 @@ void ow_pool_midi(ow_pool* p, const ow_midi_event* ev, size_t n) {
     size_t T = std::min<size_t>(effective_cpus(), OW_MAX_SLICES);
     if (p->sw.midi_threads) T = (size_t)p->sw.midi_threads;
     if (n < 4096 || p->I < 2 * T) T = 1;
+    vm_wait_download(p);
+    const bool want_device = n > 0 && !p->voices_only && (p->sw.midi_device == 1 || (p->sw.midi_device < 0 && p->I >= 8192 && n >= 65536));
     if (T == 1) {
+        if (want_device) {
+            bool grouped1 = true;
+            for (size_t i = 1; i < n && grouped1; ++i) grouped1 = ev[i].engine >= ev[i - 1].engine;
+            bool done = false;
+            if (grouped1) guarded("ow_pool_midi (device burst)", [&] { done = midi_burst_on_device(p, ev, n); });
+            if (done) return;
+        }
         for (size_t i = 0; i < n; ++i) if (ev[i].engine < p->I) midi_apply_one(p, ev[i]);
         return;
     }
@@ -2574,6 +2625,11 @@ void ow_pool_midi(ow_pool* p, const ow_midi_event* ev, size_t n) {
     Workers::get().each(T, verify);
     bool grouped = true;
     for (size_t t = 0; t < T; ++t) grouped = grouped && ok[t];
+    if (grouped && want_device) {
+        bool done = false;
+        guarded("ow_pool_midi (device burst)", [&] { done = midi_burst_on_device(p, ev, n); });
+        if (done) return;
+    }
     if (grouped) {
         size_t cut[OW_MAX_SLICES + 1];
         cut[0] = 0; cut[T] = n;
@@ -2621,7 +2677,7 @@ void ow_test_engine_after_render(ow_engine* e, size_t len, uint64_t silent_mask)
     o.silent_mask = silent_mask;
     engine_post_render(e, (uint32_t)std::min<size_t>(len, 0xFFFFFFFFull), o);
 }
-uint64_t ow_test_engine_masks(const ow_engine* e, int which) { return e ? (which ? e->steal_mask : e->main_mask) : 0; }
+uint64_t ow_test_engine_masks(const ow_engine* e, int which) { return e ? (which ? e->vm->steal_mask : e->vm->main_mask) : 0; }
 int ow_test_pool_stagger_tremolo(ow_pool* p, size_t n_groups) {
     if (!p || n_groups == 0 || n_groups > p->I) return -1;
     try {
@@ -2839,6 +2895,7 @@ int ow_test_pool_set_switch(ow_pool* p, const char* name, int value) {
     else if (n == "pa_sort") { if (value < 0 || value > 2) return -1; w.pa_sort = value; }
     else if (n == "host_profile") w.host_profile = value != 0;
     else if (n == "out_direct") w.out_direct = value < 0 ? -1 : (value != 0);
+    else if (n == "midi_device") w.midi_device = value < 0 ? -1 : (value != 0);
     else if (n == "force_general") { w.force_general = value != 0; p->lists_valid = false; }
     else if (n == "chain_stream") w.chain_stream = value < 0 ? -1 : (value != 0);
     else return -1;                                       // (trem_traj / trem_cache / pipe shape the pool at creation: environment only)
@@ -2863,6 +2920,8 @@ int ow_test_pool_get_switch(const ow_pool* p, const char* name) {
     if (n == "trem_traj") return p->traj ? 1 : 0;
     if (n == "trem_cache") return w.trem_cache;
     if (n == "out_direct") return w.out_direct;
+    if (n == "midi_device") return w.midi_device;
+    if (n == "midi_device_bursts") return (int)std::min<uint64_t>(p->vm_bursts, 0x7FFFFFFF);
     if (n == "chain_stream") return w.chain_stream;
     return -2;
 }
@@ -3005,7 +3064,7 @@ static long long render_note_impl(uint8_t midi, double velocity, double dur_s, d
         ow_engine* e = p->engines[0];
         // Voice::render_note: seed = midi * 2654435761, MLP off, no note clamping beyond the table range (voice.rs:206-207)
         const uint8_t note = std::min<uint8_t>(std::max<uint8_t>(midi, OW_MIDI_LO), OW_MIDI_HI);
-        e->slots[0].has_voice = true; e->set_state(0, OW_VOICE_HELD); e->midi_of[0] = note;
+        e->vm->has_voice |= 1ull; e->set_state(0, OW_VOICE_HELD); e->vm->midi_of[0] = note;
         e->sync_masks(0);
         push_op(e, OP_NOTE_ON, 0, note, false, (uint32_t)midi * 2654435761u, velocity);
         if (ds) push_op(e, OP_SET_DS, 0, note, false, 0, *ds);      // voice.set_displacement_scale(scale) right after note_on (voice.rs:210-212)

@@ -60,13 +60,16 @@ __device__ inline void mlp_raw_mfma(double* __restrict__ h, double in0, double i
 // Capped at 256 registers (it would take ~500 to keep the MLP weights resident): a wavefront of this kernel then fits beside a
 // tremolo wavefront on a SIMD, so the block-ahead oscillator can be launched before the host has prepared the ops.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_apply_ops(const OwConsts* __restrict__ K, const double* __restrict__ nt, double* __restrict__ vrec,
-                                                  const OwEngineArgs* __restrict__ args, const OwOp* __restrict__ ops,
-                                                  const uint32_t* __restrict__ engines) {
+                                                  const OwEngineArgs* __restrict__ args, const OwOp* __restrict__ ops_packed,
+                                                  const uint32_t* __restrict__ engines, const OwOp* __restrict__ ops_fixed = nullptr) {
     __shared__ double h[64 * 17];
     const int e = (int)engines[blockIdx.x];
     const int lane = threadIdx.x;
-    const OwEngineArgs a = args[e];
+    OwEngineArgs a = args[e];
     if (a.op_count == 0) return;
+    // bit 31 of op_begin: the queue was written on the device (k_vm_events) at the engine's fixed place, not packed and uploaded by the host
+    const OwOp* __restrict__ ops = (a.op_begin & 0x80000000u) ? ops_fixed : ops_packed;
+    a.op_begin &= 0x7FFFFFFFu;
     double* main_rec = vrec + ((size_t)e * 2 + 0) * OW_VREC_DOUBLES + lane;
     double* steal_rec = vrec + ((size_t)e * 2 + 1) * OW_VREC_DOUBLES + lane;
     // Which ops are addressed to this lane's slot: the queue is read once, 64 entries at a time (lane l holds entry 64 t + l), and one

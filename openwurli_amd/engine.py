@@ -105,6 +105,10 @@ class _EngineHandle:
         """VoiceSlot.state of one of the 64 slots (VoiceState value)."""
         return self._lib.ow_engine_slot_state(self._h, int(slot))
 
+    def slot_note(self, slot):
+        """VoiceSlot.midi_note of one of the 64 slots."""
+        return self._lib.ow_engine_slot_note(self._h, int(slot))
+
     def count_voices_in_state(self, state):
         return sum(1 for s in range(64) if self._lib.ow_engine_slot_state(self._h, s) == int(state))
 
@@ -228,6 +232,24 @@ class EnginePool:
         if not ptr:
             raise OwError(binding.take_error(self._lib))
         return (ptr, int(length))
+
+    def alloc_host_events(self, n_events, device=0):
+        """Page-locked event list for ``midi``: a numpy structured array (dtype binding.MIDI_DTYPE) over an ``ow_host_alloc`` block.  A burst
+        that a big pool applies on the device is uploaded straight from it (no staging copy).  Free with ``free_host_events``."""
+        dt = np.dtype(binding.MIDI_DTYPE)
+        ptr = self._lib.ow_host_alloc(dt.itemsize * max(int(n_events), 1), int(device))
+        if not ptr:
+            raise OwError(binding.take_error(self._lib))
+        buf = (C.c_char * (dt.itemsize * int(n_events))).from_address(ptr)
+        arr = np.frombuffer(buf, dtype=dt)
+        self._host_events = getattr(self, "_host_events", {})
+        self._host_events[arr.ctypes.data] = ptr
+        return arr
+
+    def free_host_events(self, arr, device=0):
+        ptr = getattr(self, "_host_events", {}).pop(arr.ctypes.data, None)
+        if ptr:
+            self._lib.ow_host_free(C.c_void_p(ptr), int(device))
 
     def free_host_block(self, block, device=0):
         self._lib.ow_host_free(C.c_void_p(block[0]), int(device))

@@ -294,3 +294,81 @@ def test_voice_sum_nan_guard_second_pass(hiplib, oracle, scenario):
             e.note_off(64 + k); e.note_on(64 + k, 0.8)
     compare("after the guard, new notes", 5)
     g.close()
+
+
+def test_midi_burst_on_device_equals_the_host_state_machine(hiplib):
+    """ow_pool_midi on a big pool applies a burst of events ON THE DEVICE (k_vm_events: the state machine of ow_vm.h, the code the host runs,
+    one lane per engine; the states are copied back) instead of event by event on the host threads.  Forced here on a pool of 96 engines
+    and compared with the host path under a script that goes through every branch of engine.rs:299-374 / 569-590: whole-keyboard strikes
+    and re-strikes, repeated keys, out-of-range keys, more notes than slots (steals of releasing, sustained and held voices), the pedal down
+    / up with sustained voices to damp, single events between a burst and its render (their ops queue behind the device's), single
+    events BEFORE a burst (the burst then stays on the host: queue order), two bursts before one render, a burst whose ops overflow an
+    engine's fixed queue (replayed on the host), reset of one engine.  Slot states, notes, steal voices, voice counts and every rendered
+    sample are identical."""
+    import openwurli_amd as ow
+    from openwurli_amd import binding
+    n = 96
+    rng0 = np.random.default_rng(7)
+
+    def burst(engines, kind, seed):
+        rng = np.random.default_rng(seed)
+        rows = []
+        for e in engines:
+            if kind == "strike":
+                ev = [(0, k, 0.3 + 0.6 * ((e + k) % 7) / 7.0) for k in range(33, 97)]
+            elif kind == "restrike":
+                ev = [x for k in range(33, 97) for x in ((1, k, 0.0), (0, k, 0.4 + 0.5 * ((e * 3 + k) % 5) / 5.0))]
+            elif kind == "play":
+                ev = []
+                for _ in range(int(rng.integers(5, 40))):
+                    t = int(rng.choice([0, 0, 0, 1, 1, 2]))
+                    ev.append((t, int(rng.integers(20, 110)), float(rng.random())))
+            elif kind == "pedal_down":
+                ev = [(2, 0, 1.0)] + [(1, k, 0.0) for k in range(40, 70)]
+            elif kind == "pedal_up":
+                ev = [(0, 50, 0.7), (2, 0, 0.0), (0, 61, 0.5)]
+            elif kind == "overflow":
+                ev = [x for _ in range(3) for k in range(33, 97) for x in ((1, k, 0.0), (0, k, 0.6))]
+            rows += [(e, t, k, 0, v) for t, k, v in ev]
+        return np.array(rows, dtype=np.dtype(binding.MIDI_DTYPE))
+
+    def run(device):
+        g = ow.EnginePool(48000.0, n)
+        g.set_sample_rate(48000.0)
+        g.set_switch("midi_device", device)
+        outs, states = [], []
+
+        def snap():
+            st = []
+            for k in (0, 1, 17, 50, 95):
+                e = g[k]
+                d = e.diag()
+                st.append(([e.slot_state(s) for s in range(64)], [e.slot_note(s) for s in range(64)], [bool(e.has_steal_voice_for(q)) for q in (40, 50, 60, 70)],
+                           d.active_voices, d.held_voices, d.sustained_voices, d.releasing_voices, d.steal_voices, d.sustain_held))
+            return st
+        allk = list(range(n))
+        g.midi(burst(allk, "strike", 1)); outs.append(g.render(256).copy()); states.append(snap())
+        g.midi(burst(allk, "play", 2)); outs.append(g.render(300).copy()); states.append(snap())
+        g.midi(burst(allk, "pedal_down", 3)); outs.append(g.render(128).copy()); states.append(snap())
+        g.midi(burst(allk, "play", 4)); g[17].note_on(77, 0.9); g[17].note_off(77); g[50].set_sustain(False)      # single events BEHIND a burst
+        outs.append(g.render(200).copy()); states.append(snap())
+        g.midi(burst(allk, "pedal_up", 5)); outs.append(g.render(256).copy()); states.append(snap())
+        g[1].note_on(45, 0.6)                                              # a single event BEFORE a burst: queue order keeps the burst on the host
+        g.midi(burst(allk, "restrike", 6)); outs.append(g.render(512).copy()); states.append(snap())
+        g.midi(burst(allk[: n // 2], "play", 7)); g.midi(burst(allk, "play", 8))                                     # two bursts, one render
+        outs.append(g.render(100).copy()); states.append(snap())
+        g[95].reset(); g[95].note_on(60, 0.8)
+        g.midi(burst(allk, "restrike", 9)); outs.append(g.render(512).copy()); states.append(snap())
+        g.midi(burst(allk, "overflow", 10)); outs.append(g.render(256).copy()); states.append(snap())               # 576 ops per engine: host replay
+        g.midi(burst(allk, "play", 11)); outs.append(g.render(256).copy()); states.append(snap())
+        bursts = g.get_switch("midi_device_bursts")
+        g.close()
+        return outs, states, bursts
+    o_dev, s_dev, b_dev = run(1)
+    o_host, s_host, b_host = run(0)
+    assert b_host == 0 and b_dev >= 8, (b_host, b_dev)                     # the device path really ran (all but the ordered / overflowing bursts)
+    for i, (a, b) in enumerate(zip(s_dev, s_host)):
+        assert a == b, (i, "slot states")
+    for i, (a, b) in enumerate(zip(o_dev, o_host)):
+        assert np.array_equal(a, b), (i, float(np.max(np.abs(a - b))))
+    assert max(float(np.max(np.abs(o))) for o in o_dev) > 1e-3
