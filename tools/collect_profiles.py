@@ -78,6 +78,14 @@ def main():
     if t:
         run([os.path.join(ROOT, "tools", "summarize_profile.py"), t, os.path.join(dst, f"{r}_kernel_trace_serial.md")])
         made.append(os.path.join(dst, f"{r}_kernel_trace_serial.md"))
+    t = find(f"{src}/trace_host/**/t_kernel_trace.csv")
+    if t:       # round 5: the same command with --deliver host (k_chain_stream instead of k_preamp + k_post)
+        run([os.path.join(ROOT, "tools", "summarize_profile.py"), t, os.path.join(dst, f"{r}_kernel_trace_host_delivery.md")])
+        made.append(os.path.join(dst, f"{r}_kernel_trace_host_delivery.md"))
+    for name, out in (("restrike_hbm.txt", "restrike_trace.txt"), ("restrike_host.txt", "restrike_trace_host_delivery.txt"), ("smoke.txt", "smoke.txt")):
+        if os.path.exists(os.path.join(src, name)):
+            open(os.path.join(dst, f"{r}_{out}"), "w").write(open(os.path.join(src, name)).read())
+            made.append(os.path.join(dst, f"{r}_{out}"))
     # default kernels: counters
     files = [f for f in sorted(glob.glob(f"{src}/pmc_*/**/p_counter_collection.csv", recursive=True))
              if not any(f"pmc_{tag}_" in f for tag in ("melange", "mpa", "batch", "p256"))]

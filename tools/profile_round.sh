@@ -20,6 +20,8 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o 
 export OW_TREM_TRAJ=0
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_serial -o t -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/trace_serial.log 2>&1
 unset OW_TREM_TRAJ
+# ... and with every block delivered into a pinned host block (k_chain_stream instead of k_preamp + k_post, round 5)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_host -o t -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-extras --deliver host > $O/trace_host.log 2>&1
 
 # ---- 2. counters of the default kernels: 4 096-engine pool; the big-pool preamp / output kernels forced (a 4 096-engine pool would pick
 # the quad-per-engine preamp and the fused chain on its own)
