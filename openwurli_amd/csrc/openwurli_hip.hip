@@ -210,6 +210,7 @@ struct Switches {
     int eout_attn = -1;                        // OW_EOUT_ATTN=0/1: status summary instead of the status blocks (k_eout_attention); -1: ranges of >= 8 192 engines
     int pipe = 0;                              // OW_PIPE=n stages
     int midi_device = -1;                      // OW_MIDI_DEVICE=0/1: bursts of ow_pool_midi applied on the device (k_vm_events) never / whenever the list allows; -1: pools of >= 8 192 engines, >= 65 536 events
+    int voice_attack = 1;                      // OW_VOICE_ATTACK=0: no attack variant of the steady voice kernel (engines in onset / noise phases go to the general kernel)
     bool force_general = false;                // test / probe hook: every engine's slot voices go to the general voice kernel (what it costs without any phase active)
     int chain_stream = -1;                     // OW_CHAIN_STREAM=0/1: preamp + output stage of a big oversampled pool as one launch (k_chain_stream); -1: when the block goes to a pinned host block
     int out_direct = -1;                       // OW_OUT_DIRECT=0/1: output stage stores straight into a pinned host block (ow_host_alloc) instead of d_out + copy; -1: default
@@ -234,6 +235,7 @@ struct Switches {
         w.pa_sort = flag("OW_PA_SORT", 1); if (w.pa_sort < 0 || w.pa_sort > 2) w.pa_sort = 1;
         if (const char* e = std::getenv("OW_PIPE")) { const int v = std::atoi(e); w.pipe = (v >= 1 && v <= 8) ? v : 0; }
         w.pipe_overlap = flag("OW_PIPE_OVERLAP", 0) == 1;
+        w.voice_attack = flag("OW_VOICE_ATTACK", 1) != 0;
         w.midi_device = flag("OW_MIDI_DEVICE", -1); if (w.midi_device > 1 || w.midi_device < -1) w.midi_device = -1;
         w.chain_stream = flag("OW_CHAIN_STREAM", -1); if (w.chain_stream > 1 || w.chain_stream < -1) w.chain_stream = -1;
         w.out_direct = flag("OW_OUT_DIRECT", -1); if (w.out_direct > 1 || w.out_direct < -1) w.out_direct = -1;
@@ -370,7 +372,7 @@ struct ow_pool {
     // Packed voice dispatch (ow_kernels.h): lane = sounding voice.  Three block lists of (engine << 6 | slot) entries, rebuilt when a
     // mask, a pending op or a transient flag changed: steady slot voices, slot voices of engines in a transient phase, steal voices.
     struct VoiceList { uint32_t* h = nullptr; uint32_t* d = nullptr; uint32_t n_blocks = 0; };
-    VoiceList vl_steady, vl_general, vl_steal;
+    VoiceList vl_steady, vl_general, vl_steal, vl_attack;     // vl_attack: engines inside onset ramps / attack noise whose slot voices are not damping (k_voice_steady<false, true>)
     std::vector<uint8_t> transient;   // per engine: device status after the previous block (OwEngineOut::transient)
     bool lists_valid = false;
     int lists_e0 = -1, lists_ne = -1;
@@ -378,7 +380,7 @@ struct ow_pool {
     // on its own stream; the kernels of stage k start when those of stage k-1 have finished, so the device-to-host copy of stage k-1
     // (copy engine) runs beside the kernels of stage k.  Stage boundaries are slice boundaries of the packed voice lists.
     int slice_T = 1, slice_per = 0;                             // slices the lists were packed in, engines per slice
-    struct SliceStart { uint32_t s = 0, g = 0, t = 0; } slice_start[OW_MAX_SLICES + 1];   // entry offsets of every slice in the three lists
+    struct SliceStart { uint32_t s = 0, g = 0, t = 0, a = 0; } slice_start[OW_MAX_SLICES + 1];   // entry offsets of every slice in the three lists
     hipStream_t pipe_stream[OW_MAX_STAGES] = {};               // [0] == stream
     hipEvent_t ev_ready = nullptr, ev_voice_done[OW_MAX_STAGES] = {}, ev_stage_done[OW_MAX_STAGES] = {};
     hipEvent_t ev_stage[OW_MAX_STAGES][5] = {};                // profiling: before voices, after voices, before preamp, after preamp, after post
@@ -1316,7 +1318,7 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
     Fill* start = p->slice_start;                              // T <= 32; kept: stage k launches the blocks of its slices
     start[0] = Fill();
     p->slice_T = (int)T; p->slice_per = per;
-    auto pack = [&](size_t t, uint32_t* S, uint32_t* G, uint32_t* Tl, Fill& f) {   // S == nullptr: count only
+    auto pack = [&](size_t t, uint32_t* S, uint32_t* G, uint32_t* Tl, uint32_t* A, Fill& f) {   // S == nullptr: count only
         auto pad = [](uint32_t* a, uint32_t& n) { while (n & 63u) { if (a) a[n] = 0xFFFFFFFFu; ++n; } };
         auto put = [&](uint32_t* a, uint32_t& n, uint32_t e, uint64_t mask, bool own_block) {
             const uint32_t pc = (uint32_t)__builtin_popcountll(mask);
@@ -1329,27 +1331,35 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
             const uint32_t e = (uint32_t)(e0 + k);
             const OwEngineArgs& a = p->h_args[e];
             if (a.main_mask) {
-                if (p->transient[e] || a.op_count || p->sw.force_general) put(G, f.g, e, a.main_mask, false);
-                else put(S, f.s, e, a.main_mask, false);
+                if (p->sw.force_general) put(G, f.g, e, a.main_mask, false);
+                else if (p->transient[e] || a.op_count) {
+                    // in a transient phase, or about to be (ops pending).  A slot voice only damps while its slot is Releasing (the damper
+                    // starts with the release, engine.rs:340-374): an engine without releasing slot voices is inside onset ramps / attack
+                    // noise at most -- the attack variant of the steady kernel, 1.2-1.7 x its price instead of the general kernel's 2.6 x
+                    const bool damping = (p->h_vm[e].st_mask[OW_VOICE_RELEASING] & a.main_mask) != 0ull;
+                    if (!damping && p->sw.voice_attack) put(A, f.a, e, a.main_mask, false);
+                    else put(G, f.g, e, a.main_mask, false);
+                } else put(S, f.s, e, a.main_mask, false);
             }
             if (a.steal_mask) put(Tl, f.t, e, a.steal_mask, true);   // one engine per block: the crossfade early-out is per engine
         }
-        pad(S, f.s); pad(G, f.g); pad(Tl, f.t);
+        pad(S, f.s); pad(G, f.g); pad(Tl, f.t); pad(A, f.a);
     };
-    auto pass1 = [&](size_t t) { pack(t, nullptr, nullptr, nullptr, size[t]); };
+    auto pass1 = [&](size_t t) { pack(t, nullptr, nullptr, nullptr, nullptr, size[t]); };
     Workers::get().each(T, pass1);
-    for (size_t t = 0; t < T; ++t) { start[t + 1].s = start[t].s + size[t].s; start[t + 1].g = start[t].g + size[t].g; start[t + 1].t = start[t].t + size[t].t; }
+    for (size_t t = 0; t < T; ++t) { start[t + 1].s = start[t].s + size[t].s; start[t + 1].g = start[t].g + size[t].g; start[t + 1].t = start[t].t + size[t].t; start[t + 1].a = start[t].a + size[t].a; }
     auto pass2 = [&](size_t t) {
         Fill f;   // slice-local counters: the slice regions start on block boundaries, so padding decisions match pass 1
-        pack(t, p->vl_steady.h + start[t].s, p->vl_general.h + start[t].g, p->vl_steal.h + start[t].t, f);
+        pack(t, p->vl_steady.h + start[t].s, p->vl_general.h + start[t].g, p->vl_steal.h + start[t].t, p->vl_attack.h + start[t].a, f);
     };
     Workers::get().each(T, pass2);
-    const uint32_t fs = start[T].s, fg = start[T].g, fl = start[T].t;
-    p->vl_steady.n_blocks = fs / 64; p->vl_general.n_blocks = fg / 64; p->vl_steal.n_blocks = fl / 64;
+    const uint32_t fs = start[T].s, fg = start[T].g, fl = start[T].t, fa = start[T].a;
+    p->vl_steady.n_blocks = fs / 64; p->vl_general.n_blocks = fg / 64; p->vl_steal.n_blocks = fl / 64; p->vl_attack.n_blocks = fa / 64;
     hipStream_t st = p->stream;
     if (fs) HIP_OK(hipMemcpyAsync(p->vl_steady.d, p->vl_steady.h, sizeof(uint32_t) * fs, hipMemcpyHostToDevice, st));
     if (fg) HIP_OK(hipMemcpyAsync(p->vl_general.d, p->vl_general.h, sizeof(uint32_t) * fg, hipMemcpyHostToDevice, st));
     if (fl) HIP_OK(hipMemcpyAsync(p->vl_steal.d, p->vl_steal.h, sizeof(uint32_t) * fl, hipMemcpyHostToDevice, st));
+    if (fa) HIP_OK(hipMemcpyAsync(p->vl_attack.d, p->vl_attack.h, sizeof(uint32_t) * fa, hipMemcpyHostToDevice, st));
     p->lists_e0 = e0; p->lists_ne = ne;
 }
 
@@ -1569,7 +1579,8 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         if (voices) {
             const ow_pool::SliceStart& a0 = p->slice_start[NP == 1 ? 0 : t0];
             const ow_pool::SliceStart& a1 = p->slice_start[NP == 1 ? p->slice_T : t1];
-            const unsigned bs = (a1.s - a0.s) / 64, bg = (a1.g - a0.g) / 64, bt = (a1.t - a0.t) / 64;
+            const unsigned bs = (a1.s - a0.s) / 64, bg = (a1.g - a0.g) / 64, bt = (a1.t - a0.t) / 64, ba = (a1.a - a0.a) / 64;
+            if (ba) owdev::k_voice_steady<false, true><<<dim3(ba), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_attack.d + a0.a, p->d_sum, p->d_eout, I, L, Lcap, nullptr);
             if (bs)
                 {
                 // voices on more than one jitter grid in some wavefront of the previous steady launch: the skewed variant (same samples)
@@ -1969,7 +1980,7 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
         HIP_OK(hipHostMalloc(&p->h_prev_tr, n_engines));
         p->eout_live.reserve(n_engines / 8 + 64);       // the summary path lists at most ne / 8 engines: nothing grows on the render path
     }
-    for (ow_pool::VoiceList* vl : {&p->vl_steady, &p->vl_general, &p->vl_steal}) {   // worst case: one block per engine
+    for (ow_pool::VoiceList* vl : {&p->vl_steady, &p->vl_general, &p->vl_steal, &p->vl_attack}) {   // worst case: one block per engine
         HIP_OK(hipMalloc(&vl->d, sizeof(uint32_t) * 64 * n_engines));
         HIP_OK(hipHostMalloc(&vl->h, sizeof(uint32_t) * 64 * n_engines));
     }
@@ -2084,7 +2095,7 @@ void pool_destroy(ow_pool* p) {
     hipFree(p->d_args); hipFree(p->d_eout);
     if (p->d_ops) hipFree(p->d_ops);
     if (p->h_ops) hipHostFree(p->h_ops);
-    for (ow_pool::VoiceList* vl : {&p->vl_steady, &p->vl_general, &p->vl_steal}) { if (vl->d) hipFree(vl->d); if (vl->h) hipHostFree(vl->h); }
+    for (ow_pool::VoiceList* vl : {&p->vl_steady, &p->vl_general, &p->vl_steal, &p->vl_attack}) { if (vl->d) hipFree(vl->d); if (vl->h) hipHostFree(vl->h); }
     if (p->d_op_engines) hipFree(p->d_op_engines);
     if (p->h_op_engines) hipHostFree(p->h_op_engines);
     if (p->d_lead) hipFree(p->d_lead);
@@ -2896,6 +2907,7 @@ int ow_test_pool_set_switch(ow_pool* p, const char* name, int value) {
     else if (n == "host_profile") w.host_profile = value != 0;
     else if (n == "out_direct") w.out_direct = value < 0 ? -1 : (value != 0);
     else if (n == "midi_device") w.midi_device = value < 0 ? -1 : (value != 0);
+    else if (n == "voice_attack") { w.voice_attack = value != 0; p->lists_valid = false; }
     else if (n == "force_general") { w.force_general = value != 0; p->lists_valid = false; }
     else if (n == "chain_stream") w.chain_stream = value < 0 ? -1 : (value != 0);
     else return -1;                                       // (trem_traj / trem_cache / pipe shape the pool at creation: environment only)
@@ -2921,6 +2933,11 @@ int ow_test_pool_get_switch(const ow_pool* p, const char* name) {
     if (n == "trem_cache") return w.trem_cache;
     if (n == "out_direct") return w.out_direct;
     if (n == "midi_device") return w.midi_device;
+    if (n == "voice_attack") return w.voice_attack;
+    if (n == "blocks_steady") return (int)p->vl_steady.n_blocks;   // wavefront blocks of the voice lists the last render launched
+    if (n == "blocks_general") return (int)p->vl_general.n_blocks;
+    if (n == "blocks_attack") return (int)p->vl_attack.n_blocks;
+    if (n == "blocks_steal") return (int)p->vl_steal.n_blocks;
     if (n == "midi_device_bursts") return (int)std::min<uint64_t>(p->vm_bursts, 0x7FFFFFFF);
     if (n == "chain_stream") return w.chain_stream;
     return -2;

@@ -342,6 +342,11 @@ struct VoiceSteady {
     uint32_t cd;              // samples until it (0: this sample)
     uint32_t renorm;          // this sample is also a renormalisation point
     uint32_t jitter_state;
+    // ATTACK variant only (k_voice_steady<false, true>: engines inside onset ramps / attack-noise bursts, no voice damping): samples left of
+    // the onset ramp (reed.rs:251-264; the gains themselves are tabulated per chunk into the lane's tile row) and the noise burst's state
+    // (hammer.rs:150-179)
+    uint32_t on_rem, noise_rem, noise_fade, noise_rng;
+    double namp, ns1, ns2, ndecay;
 
     OW_DEV void set_sample(uint64_t sample) {
         cd = (16u - ((uint32_t)sample & 15u)) & 15u;
@@ -389,7 +394,10 @@ struct VoiceSteady {
             update_rotation();
         }
     }
-    OW_DEV double advance() {                                // modal sum + rotation; returns the pickup displacement y
+    // gain: this sample's slot of the lane's tile row (ATTACK: the onset gain sits there while the ramp lasts); nco: the lane's column of
+    // the attack-noise BPF coefficients b0, b1, b2, a1, a2 in LDS (nco[i * 64]); fade16: the sixteen fade-in values of hammer.rs:165
+    template <bool ATTACK = false>
+    OW_DEV double advance(const double* __restrict__ gain = nullptr, const double* __restrict__ nco = nullptr, const double* __restrict__ fade16 = nullptr) {
 #ifndef OW_STRICT_FP
 #pragma clang fp contract(fast)
 #endif
@@ -403,7 +411,23 @@ struct VoiceSteady {
             c[m] = c_new;
             ae[m] *= decay[m];
         }
-        const double x = 0.0 + sum;
+        if (ATTACK && on_rem > 0u) {                         // reed.rs:276: every term carries the onset gain -- here the sum does (one
+            sum *= *gain;                                    // multiply instead of seven: the products round differently, <= 1 ulp of the sum)
+            on_rem -= 1u;
+        }
+        double x = 0.0 + sum;
+        if (ATTACK && noise_rem > 0u) {                      // hammer.rs:150-179, as VoiceRegs::step
+            double e = 1.0;
+            if (noise_fade > 0u) { e = fade16[16u - noise_fade]; noise_fade -= 1u; }
+            noise_rng = lcg(noise_rng);
+            const double nz = (double)(int32_t)noise_rng / 2147483647.0;
+            const double yb = nco[0] * nz + ns1;
+            ns1 = nco[64] * nz - nco[192] * yb + ns2;
+            ns2 = nco[128] * nz - nco[256] * yb;
+            x += namp * e * yb;
+            namp *= ndecay;
+            noise_rem -= 1u;
+        }
         double y = x * ds;
         const double ay = fabs(y);
         if (renorm) {
@@ -452,13 +476,21 @@ struct VoiceSteady {
 // the plain loop when capped): SKEW = false is the plain loop, which also REPORTS whether some wavefront of the launch held more than one
 // jitter grid (skew_seen); the host launches the skewed variant for the next block then -- both give the same samples, so a stale choice
 // only costs time, and the phases of sounding voices relative to each other never change between note events.
-template <bool SKEW>
+// ATTACK (round 5): the plain loop for engines whose slot voices are inside onset ramps and attack-noise bursts but NOT damping (what a
+// note-on leaves behind; a release puts the engine in k_voice).  Same pipelined loop with two per-lane additions -- the onset gain,
+// tabulated ahead of every 32-sample chunk into the lane's tile row (two voices per pass, lane-parallel over samples; read just before the
+// slot is overwritten), and the noise burst -- at 1.2-1.7 x the steady price instead of the general kernel's 2.6 x: the four blocks
+// after a whole-keyboard re-strike were 19 + 47 + 37 + 17 ms there.  Values differ from k_voice's in the last bit (fused steps, the
+// onset gain on the sum): the same class as deviation 9, inside the voice-sum bar.
+template <bool SKEW, bool ATTACK = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_voice_steady(const OwConsts* __restrict__ K, double* __restrict__ vrec, const uint32_t* __restrict__ entries,
                                                      double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int L, int Lcap, uint32_t* __restrict__ skew_seen) {
     constexpr int TILE_DOUBLES = SKEW ? 64 * OW_SKEW_RS : 64 * (32 + 1);    // (the skewed variant's short blocks and aligned wavefronts use the plain loop in the ring's tile)
     constexpr int PCH = 32;                                   // chunk of the plain loop (24 -> 32: a 512-sample block is sixteen whole chunks; 12.9 against 13.05 ms)
     constexpr int PRS = SKEW ? OW_SKEW_RS : PCH + 1;          // ... and its row stride
+    static_assert(!(SKEW && ATTACK), "the attack variant is the plain loop");
     __shared__ double tile[TILE_DOUBLES];
+    __shared__ double nco[ATTACK ? 5 * 64 + 16 : 1];          // attack-noise BPF coefficients per lane, then the sixteen fade-in values
     __shared__ int eng_l[64];
     const int lane = threadIdx.x;
     const VoiceLanes w = voice_lanes(entries, eng_l);
@@ -466,13 +498,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     double* rec = vrec + ((size_t)(active ? w.e : 0) * 2) * OW_VREC_DOUBLES + w.slot;
     VoiceSteady v;
     uint32_t noise_rng = 0;
+    v.on_rem = 0u; v.noise_rem = 0u; v.noise_fade = 0u; v.noise_rng = 0u; v.namp = 0.0; v.ns1 = 0.0; v.ns2 = 0.0; v.ndecay = 0.0;
+    if (ATTACK && lane < 16) nco[5 * 64 + lane] = noise_fade_env((double)lane / 16.0);      // the values k_voice forms per sample (hammer.rs:165)
     if (active) {
         // The host sends an engine here only if its status after the previous block said "no transient phase" and no note event
         // arrived since; those phases never start by themselves.  A voice found inside one means that bookkeeping is wrong.
         const uint32_t flags = (uint32_t)dbits(rec[VF_FLAGS * 64]);
         const uint64_t smp = dbits(rec[VF_SAMPLE * 64]), onset_n = dbits(rec[VF_ONSET_N * 64]);
         const uint32_t noise_rem = (uint32_t)dbits(rec[VF_NCNT * 64]);
-        if ((flags & 1u) || smp < onset_n || noise_rem > 0u) eout[w.e].transient = 2u;
+        if (ATTACK) {
+            if (flags & 1u) eout[w.e].transient = 2u;      // a damping voice: the host's classification is wrong
+            v.on_rem = smp < onset_n ? (uint32_t)min((unsigned long long)(onset_n - smp), 0xFFFFFFFFull) : 0u;
+            const uint64_t nc = dbits(rec[VF_NCNT * 64]);
+            v.noise_rem = (uint32_t)nc; v.noise_fade = (uint32_t)(nc >> 32);
+            v.namp = rec[VF_NAMP * 64]; v.ns1 = rec[VF_NS1 * 64]; v.ns2 = rec[VF_NS2 * 64]; v.ndecay = rec[VF_NDECAY * 64];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) nco[i * 64 + lane] = rec[(VF_NB0 + i) * 64];
+        } else if ((flags & 1u) || smp < onset_n || noise_rem > 0u) eout[w.e].transient = 2u;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             v.s[i] = rec[(VF_S + i) * 64]; v.c[i] = rec[(VF_C + i) * 64]; v.ae[i] = rec[(VF_AMP + i) * 64] * rec[(VF_ENV + i) * 64];
@@ -484,9 +526,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         v.set_sample(dbits(rec[VF_SAMPLE * 64]));
         const uint64_t r = dbits(rec[VF_RNG * 64]);
         v.jitter_state = (uint32_t)r; noise_rng = (uint32_t)(r >> 32);
+        v.noise_rng = noise_rng;
         v.update_rotation();
     }
-    __syncthreads();                     // eng_l
+    __syncthreads();                     // eng_l, nco
     // ---- which trips carry the jitter updates: g minimising the longest delay over the phases present in this wavefront
     int g = 0, D = 0, d = 0;
     {
@@ -494,7 +537,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         uint32_t present = 0;                                       // bit b: some voice has cd0 == b
         for (int b = 0; b < 16; ++b) present |= (__ballot(active && cd0 == (uint32_t)b) != 0ull ? 1u : 0u) << b;
         if (!SKEW) {
-            if (lane == 0 && (present & (present - 1u)) != 0u && L >= 2 * OW_SKEW_CH) atomicOr(skew_seen, 1u);
+            if (!ATTACK && lane == 0 && (present & (present - 1u)) != 0u && L >= 2 * OW_SKEW_CH) atomicOr(skew_seen, 1u);
         } else if (L >= 2 * OW_SKEW_CH) {
         int best = 16;
         for (int gg = 0; gg < 16; ++gg) {
@@ -566,15 +609,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     } else
     for (int base = 0; base < L; base += PCH) {
         const int cn = min(PCH, L - base);
+        if (ATTACK) {
+            // onset gains of the chunk into the tile rows of the lanes inside their ramp: two voices per pass, 32 samples each
+            const uint64_t m_on = __ballot(active && v.on_rem > 0u);
+            const int sub = lane >> 5, j = lane & 31;
+            for (uint64_t m = m_on; m; ) {
+                const int l0 = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const int l1 = m ? __builtin_ctzll(m) : -1;
+                if (l1 >= 0) m &= m - 1ull;
+                const int l = sub ? l1 : l0;
+                const int src = l < 0 ? 0 : l;
+                const int e_l = __shfl(w.e, src), slot_l = __shfl(w.slot, src);
+                const uint32_t rem_l = (uint32_t)__shfl((int)v.on_rem, src);
+                if (l >= 0 && j < cn && (uint32_t)j < rem_l) {
+                    const double* r = vrec + ((size_t)e_l * 2) * OW_VREC_DOUBLES + slot_l;
+                    const uint64_t on = dbits(r[VF_ONSET_N * 64]);
+                    tile[l * PRS + j] = onset_gain((double)(on - (uint64_t)rem_l + (uint64_t)j), r[VF_ONSET_INC * 64], r[VF_ONSET_EXP * 64]);
+                }
+            }
+            __syncthreads();
+        }
         if (active) {
             double* trow = tile + lane * PRS;
             v.jitter();
-            double y = v.advance();
+            double y = v.advance<ATTACK>(trow, nco + lane, nco + 5 * 64);
 #pragma unroll 2   // two samples per trip: the compiler renames the pipelined state instead of copying it back (7 v_mov_b64 per sample)
             for (int n = 1; n < cn; ++n) {
                 v.jitter();
                 trow[n - 1] = v.pickup(y);
-                y = v.advance();
+                y = v.advance<ATTACK>(trow + n, nco + lane, nco + 5 * 64);
             }
             trow[cn - 1] = v.pickup(y);
         }
@@ -597,6 +661,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         rec[VF_Q * 64] = v.q;
         rec[VF_SAMPLE * 64] = bitsd(dbits(rec[VF_SAMPLE * 64]) + (uint64_t)L);
+        if (ATTACK) {
+            noise_rng = v.noise_rng;
+            rec[VF_NAMP * 64] = v.namp; rec[VF_NS1 * 64] = v.ns1; rec[VF_NS2 * 64] = v.ns2;
+            rec[VF_NCNT * 64] = bitsd((uint64_t)v.noise_rem | ((uint64_t)v.noise_fade << 32));
+            if (v.on_rem > 0u || v.noise_rem > 0u) eout[w.e].transient = 1u;      // still inside a phase: this variant again next block
+        }
         rec[VF_RNG * 64] = bitsd((uint64_t)v.jitter_state | ((uint64_t)noise_rng << 32));
         const unsigned long long bit = 1ull << w.slot;
         if (all_quiet) atomicOr((unsigned long long*)&eout[w.e].silent_mask, bit);   // damper inactive here: only the -80 dB test of Voice::is_silent

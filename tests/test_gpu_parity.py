@@ -1093,3 +1093,72 @@ def test_skewed_voice_clocks_are_bit_identical(hiplib, oracle):
     assert np.array_equal(res[1][1], res[0][1])
     assert np.array_equal(res[1][0], res[0][0])
     assert np.max(np.abs(res[1][0])) > 1e-3
+
+
+def test_attack_variant_follows_the_oracle_and_the_general_kernel(hiplib, oracle):
+    """k_voice_steady<false, true> (ow_kernels.h): engines inside onset ramps / attack noise whose slot voices are not damping render on the
+    steady loop with the onset gain tabulated per chunk and the noise burst beside it, instead of on the general kernel.  Scenarios: one
+    note; the whole keyboard at once; a key per block over ragged block lengths (incl. lengths below the chunk); a key released while
+    others are still in their onset (-> the engine moves to the general kernel and stays there while the voice damps); pedal down + note
+    off (Sustained: not damping, stays on the attack variant) and pedal up (-> general); a re-struck key (steal pass beside the attack).
+    Every block follows the oracle; against OW_VOICE_ATTACK=0 (general kernel for every phase) voice sums differ by rounding only; the
+    lists of the two runs show where the engines went; no misdispatch is reported (the render would fail)."""
+    import openwurli_amd as ow
+    sr, n = 48000.0, 6
+    lengths = (512, 64, 7, 300, 1, 33, 777, 512, 24, 25, 512, 512, 512, 512, 512, 512)
+    res, blocks = {}, {}
+    for attack in (1, 0):
+        p = ow.EnginePool(sr, n)
+        p.set_switch("voice_attack", attack)
+        p.set_sample_rate(sr)
+        cs = [oracle.OracleEngine(sr) for _ in range(n)] if attack else None
+        if cs:
+            for c in cs:
+                c.set_sample_rate(sr)
+        def both(k, f):
+            f(p[k])
+            if cs:
+                f(cs[k])
+        sums, outs, blk = [], [], []
+        both(0, lambda e: e.note_on(60, 0.8))
+        for note in range(33, 97):
+            both(1, lambda e: e.note_on(note, 0.3 + 0.01 * (note - 33)))
+        both(3, lambda e: (e.note_on(48, 0.9), e.note_on(55, 0.6)))
+        both(4, lambda e: (e.set_sustain(True), e.note_on(50, 0.7), e.note_on(62, 0.7)))
+        both(5, lambda e: e.note_on(70, 1.0))
+        for b, length in enumerate(lengths):
+            if b < 12:
+                both(2, lambda e: e.note_on(36 + 5 * b, 0.4 + 0.05 * b))
+            if b == 1:
+                both(3, lambda e: (e.note_off(48), e.note_on(67, 0.5)))      # a damper phase beside a fresh onset
+            if b == 2:
+                both(4, lambda e: e.note_off(50))                            # pedal down: Sustained, no damper
+            if b == 5:
+                both(4, lambda e: e.set_sustain(False))                      # the damper starts now
+            if b in (1, 3):
+                both(5, lambda e: (e.note_off(70), e.note_on(70, 0.9)))      # re-struck: the old voice damps in its slot
+            o = p.render(length)
+            outs.append(o.copy()); sums.append(p.voice_sum(length).copy())
+            blk.append((p.get_switch("blocks_attack"), p.get_switch("blocks_general"), p.get_switch("blocks_steady")))
+            if cs:
+                for k in range(n):
+                    co, cv, _, _ = cs[k].render_taps(length)
+                    floor = oracle.ABS_FLOOR_DENSE if k == 1 else oracle.ABS_FLOOR_OUTPUT
+                    rep = oracle.parity_report(o[k], co, abs_floor=floor)
+                    assert rep["n_bad"] == 0, (k, b, length, rep)
+                    vs = sums[-1][k]
+                    assert np.max(np.abs(vs - cv)) <= 2e-9 * max(1.0, float(np.max(np.abs(cv)))), (k, b, float(np.max(np.abs(vs - cv))))
+        p.close()
+        if cs:
+            for c in cs:
+                c.close()
+        res[attack] = (np.concatenate(outs, axis=1), np.concatenate(sums, axis=1))
+        blocks[attack] = blk
+    assert all(a == 0 for a, _, _ in blocks[0])
+    assert blocks[1][0][0] >= 2 and blocks[1][0][1] == 0            # first block: every engine on the attack variant (the keyboard fills a block of its own)
+    assert blocks[1][1][1] >= 1 and blocks[1][1][0] >= 1            # engines 3 and 5 moved to the general kernel, the others did not
+    assert blocks[1][-1][0] == 0 and blocks[1][-1][2] >= 1          # phases over: steady (damping voices of 3 / 4 / 5 may still sound)
+    scale = max(1.0, float(np.max(np.abs(res[0][1]))))
+    assert np.max(np.abs(res[1][1] - res[0][1])) <= 1e-10 * scale, float(np.max(np.abs(res[1][1] - res[0][1])))
+    assert np.max(np.abs(res[1][0] - res[0][0])) <= 1e-6
+    assert np.max(np.abs(res[1][0])) > 1e-3

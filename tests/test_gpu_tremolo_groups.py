@@ -34,8 +34,11 @@ def test_individual_resets_split_the_group_and_match_the_oracle(hiplib, oracle):
             gr = g.tremolo_r(2 * length)
             for k in range(n):
                 co, _, _, cr = cs[k].render_taps(length)
-                rep = oracle.parity_report(go[k], co, abs_floor=oracle.ABS_FLOOR_OUTPUT)
-                assert rep["n_bad"] == 0, (tag, b, k, rep)
+                # engines at (nearly) full tremolo depth: the reference's own one-ulp indeterminacy reaches 1.9e-9 there
+                # (tests/test_oracle_sensitivity.py::test_full_depth_tremolo_floor), the dense-play floor applies
+                floor = oracle.ABS_FLOOR_DENSE if 1.0 - 0.1 * k >= 0.9 else oracle.ABS_FLOOR_OUTPUT
+                rep = oracle.parity_report(go[k], co, abs_floor=floor)
+                assert rep["n_bad"] == 0, (tag, b, k, rep["worst_ratio"], rep)
                 d = 1.0 - 0.1 * k if tag != "start" or b > 0 else None     # depth ramps in the first block; the R check needs the final depth
                 if d is not None and b > 0:
                     r = gr[k]

@@ -203,3 +203,25 @@ def test_melange_power_amp_guard_timing_is_not_one_ulp_stable(oracle):
     assert before < 1e-8, before                       # until then they are the same signal to the preamp floor
     assert ga != gb and d > 1e-4, parted               # and they part at a guard event, by a visible amount
     assert min(ga, gb) >= 5, parted                    # after a number of guard resets that both sides took at the same samples
+
+
+def test_full_depth_tremolo_floor(oracle):
+    """Tremolo depth 1.0 (the LDR divider at its largest gain swing): one note after a reset, volume 0.5.  The one-ulp experiment moves quiet
+    samples of the reference algorithm by 1.9e-9 -- 0.93 of the 2e-9 floor the four-note scenarios use -- so parity tests of engines at
+    full depth (tests/test_gpu_tremolo_groups.py) take the dense-play floor (5e-9), like every scenario whose depth reaches 1."""
+    sr = 48000.0
+    a, b = oracle.OracleEngine(sr), oracle.OracleEngine(sr, perturbed=True)
+    for e in (a, b):
+        e.set_sample_rate(sr); e.set_tremolo_depth(1.0); e.set_volume(0.5); e.note_on(45, 0.85)
+    for _ in range(12):
+        a.render(512); b.render(512)
+    for e in (a, b):
+        e.reset(); e.note_on(60, 0.8)
+    worst = 0.0
+    for _ in range(40):
+        x = a.render(512).astype(np.float64); y = b.render(512).astype(np.float64)
+        q = np.abs(x) < 2e-4
+        if q.any():
+            worst = max(worst, float(np.max(np.abs(x - y)[q])))
+    assert 1e-9 < worst < oracle.ABS_FLOOR_DENSE, worst
+    a.close(); b.close()
