@@ -2997,14 +2997,15 @@ int ow_debug_div(const double* a, const double* b, size_t n, double* fast, doubl
 
 int ow_debug_div_const(int which, const double* a, size_t n, double* fast, double* ieee, uint64_t* mismatches, int device) {
     try {
-        if (which < 0 || which > 5) throw std::runtime_error("unknown constant");
+        if (which < 0 || which > 6) throw std::runtime_error("unknown constant");
         HIP_OK(hipSetDevice(device));
         if (!a) {
             if (!mismatches) throw std::runtime_error("null argument");
+            if (which != 0 && which != 6) throw std::runtime_error("no exhaustive numerator set for this constant");
             DevMem dm;
             dm.alloc(sizeof(unsigned long long));
             HIP_OK(hipMemset(dm.p, 0, sizeof(unsigned long long)));
-            owdev::k_debug_div_jitter_all<<<dim3(4096), dim3(256)>>>(dm.as<unsigned long long>());
+            owdev::k_debug_div_draw_all<<<dim3(4096), dim3(256)>>>(which, dm.as<unsigned long long>());
             HIP_OK(hipGetLastError());
             unsigned long long h = 0;
             HIP_OK(hipMemcpy(&h, dm.p, sizeof h, hipMemcpyDeviceToHost));

@@ -416,11 +416,13 @@ struct VoiceSteady {
             on_rem -= 1u;
         }
         double x = 0.0 + sum;
+        // (both additions as lane-dependent branches: written branch-free -- selects, one loop copy per phase set picked per chunk -- the
+        // loop spilled and the block after a re-strike took 38.7 instead of 27.3 ms)
         if (ATTACK && noise_rem > 0u) {                      // hammer.rs:150-179, as VoiceRegs::step
             double e = 1.0;
             if (noise_fade > 0u) { e = fade16[16u - noise_fade]; noise_fade -= 1u; }
             noise_rng = lcg(noise_rng);
-            const double nz = (double)(int32_t)noise_rng / 2147483647.0;
+            const double nz = OW_DIV_C((double)(int32_t)noise_rng, 2147483647.0);   // (= the IEEE quotient for all 2^32 draws, tests/test_gpu_division.py)
             const double yb = nco[0] * nz + ns1;
             ns1 = nco[64] * nz - nco[192] * yb + ns2;
             ns2 = nco[128] * nz - nco[256] * yb;
@@ -610,8 +612,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int base = 0; base < L; base += PCH) {
         const int cn = min(PCH, L - base);
         if (ATTACK) {
-            // onset gains of the chunk into the tile rows of the lanes inside their ramp: two voices per pass, 32 samples each
-            const uint64_t m_on = __ballot(active && v.on_rem > 0u);
+            // onset gains of the chunk into the tile rows of the lanes inside their ramp: two voices per pass, 32 samples each.  The
+            // ramp's parameters travel from the owning lane by cross-lane reads (fetched from the voice record in every pass -- three
+            // dependent global loads behind two shuffles -- the passes cost 5 % more)
+            const bool ramp = active && v.on_rem > 0u;
+            const uint64_t m_on = __ballot(ramp);
+            uint32_t my_on = 0u;
+            double my_inc = 0.0, my_exp = 0.0;
+            if (ramp) { my_on = (uint32_t)dbits(rec[VF_ONSET_N * 64]); my_inc = rec[VF_ONSET_INC * 64]; my_exp = rec[VF_ONSET_EXP * 64]; }
             const int sub = lane >> 5, j = lane & 31;
             for (uint64_t m = m_on; m; ) {
                 const int l0 = __builtin_ctzll(m);
@@ -620,13 +628,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 if (l1 >= 0) m &= m - 1ull;
                 const int l = sub ? l1 : l0;
                 const int src = l < 0 ? 0 : l;
-                const int e_l = __shfl(w.e, src), slot_l = __shfl(w.slot, src);
-                const uint32_t rem_l = (uint32_t)__shfl((int)v.on_rem, src);
-                if (l >= 0 && j < cn && (uint32_t)j < rem_l) {
-                    const double* r = vrec + ((size_t)e_l * 2) * OW_VREC_DOUBLES + slot_l;
-                    const uint64_t on = dbits(r[VF_ONSET_N * 64]);
-                    tile[l * PRS + j] = onset_gain((double)(on - (uint64_t)rem_l + (uint64_t)j), r[VF_ONSET_INC * 64], r[VF_ONSET_EXP * 64]);
-                }
+                const uint32_t rem_l = (uint32_t)__shfl((int)v.on_rem, src), on_l = (uint32_t)__shfl((int)my_on, src);
+                const double inc_l = __shfl(my_inc, src), exp_l = __shfl(my_exp, src);
+                if (l >= 0 && j < cn && (uint32_t)j < rem_l)
+                    tile[l * PRS + j] = onset_gain((double)((uint64_t)on_l - (uint64_t)rem_l + (uint64_t)j), inc_l, exp_l);
             }
             __syncthreads();
         }

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64) void k_debug_mlp(const uint8_t* __restrict__ no
 }
 
 // OW_DIV_C against the compiler's division, for the constants the kernels divide by (tests/test_gpu_division.py)
-#define OW_DIVC_CASES(X) X(0, OW_JITTER_DIV) X(1, 1.0 * OW_T_VT) X(2, 10.95 - 0.70) X(3, OW_P_VT) X(4, 0.013 * 0.013) X(5, 22.0)
+#define OW_DIVC_CASES(X) X(0, OW_JITTER_DIV) X(1, 1.0 * OW_T_VT) X(2, 10.95 - 0.70) X(3, OW_P_VT) X(4, 0.013 * 0.013) X(5, 22.0) X(6, 2147483647.0)
 __device__ inline void divc_pair(int which, double a, double& fast, double& ieee) {
     fast = ieee = 0.0;
 #define OW_DIVC_ONE(i, B) if (which == i) { fast = OW_DIV_C(a, B); ieee = a / (B); }
@@ -95,12 +95,14 @@ __global__ __launch_bounds__(256) void k_debug_div_const(int which, const double
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) divc_pair(which, a[i], fast[i], ieee[i]);
 }
-// every numerator the jitter draw can produce: (jitter_state >> 1) for all 2^31 values; counts quotients whose bits differ
-__global__ __launch_bounds__(256) void k_debug_div_jitter_all(unsigned long long* __restrict__ mismatches) {
+// every numerator a draw can produce, counting quotients whose bits differ.  which = 0: the jitter draw, (jitter_state >> 1) for all 2^31
+// values over 2147483647.5 (reed.rs:267-272); which = 6: the attack-noise draw, every int32 over 2147483647.0 (hammer.rs:192-195)
+__global__ __launch_bounds__(256) void k_debug_div_draw_all(int which, unsigned long long* __restrict__ mismatches) {
     unsigned long long bad = 0;
-    for (unsigned long long v = (unsigned long long)blockIdx.x * 256 + threadIdx.x; v < (1ull << 31); v += (unsigned long long)gridDim.x * 256) {
+    const unsigned long long n = which == 0 ? (1ull << 31) : (1ull << 32);
+    for (unsigned long long v = (unsigned long long)blockIdx.x * 256 + threadIdx.x; v < n; v += (unsigned long long)gridDim.x * 256) {
         double f, e;
-        divc_pair(0, (double)(uint32_t)v, f, e);
+        divc_pair(which, which == 0 ? (double)(uint32_t)v : (double)(int32_t)(uint32_t)v, f, e);
         bad += __double_as_longlong(f) != __double_as_longlong(e);
     }
     if (bad) atomicAdd(mismatches, bad);

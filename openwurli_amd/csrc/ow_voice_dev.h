@@ -402,25 +402,34 @@ __device__ inline void start_damper_lane(double* __restrict__ rec, const OwConst
 // cos on [0, pi] (the onset ramp's phase n * pi / N, n < N): quadrant by Cody-Waite with the first 33 bits of pi/2 (k <= 2: the product is
 // exact) and the fdlibm kernels (k_cos.c / k_sin.c polynomials) with explicit fused steps; <= 1.5 ulp.  The library's cos carries a
 // Payne-Hanek path for huge arguments and costs ~150 instructions per lane and sample of an onset ramp; this is ~35.
+// fma(a, b, k) with the CONSTANT k read from a scalar register pair (v_fma_f64's third operand).  Left to itself the compiler turns a
+// Horner step with a literal coefficient into two v_mov_b32 (the literal into the destination) + v_fmac_f64: three vector issue slots per
+// step instead of one -- a third of onset_gain's 150 vector instructions were such moves.  The s_mov pair that fills the scalar
+// register issues beside the other wavefront's vector work.  Same operation, same bits.
+OW_DEV double fma_k(double a, double b, double k) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
 OW_DEV double cos_0_pi(double x) {
     const double kf = floor(x * 6.36619772367581382433e-01 + 0.5);                      // 0, 1 or 2
     const double r = __builtin_fma(-kf, 6.07710050650619224932e-11, __builtin_fma(-kf, 1.57079632673412561417e+00, x));
     const double z = r * r;
     // cos(r)
     double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    pc = fma_k(z, pc, -2.75573143513906633035e-07);
+    pc = fma_k(z, pc, 2.48015872894767294178e-05);
+    pc = fma_k(z, pc, -1.38888888888741095749e-03);
+    pc = fma_k(z, pc, 4.16666666666666019037e-02);
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
     const double cr = w + (((1.0 - w) - hz) + z * (z * pc));                              // 1 - z/2 + z^2 pc with the rounding error of 1 - z/2 fed back
     // sin(r)
     double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-    const double sr = __builtin_fma(z * r, __builtin_fma(z, ps, -1.66666666666666324348e-01), r);
+    ps = fma_k(z, ps, 2.75573137070700676789e-06);
+    ps = fma_k(z, ps, -1.98412698298579493134e-04);
+    ps = fma_k(z, ps, 8.33333333332248946124e-03);
+    const double sr = __builtin_fma(z * r, fma_k(z, ps, -1.66666666666666324348e-01), r);
     return kf == 0.0 ? cr : (kf == 1.0 ? -sr : -cr);
 }
 // ln on (0, 1] (fdlibm e_log.c: x = 2^k (1 + f), s = f / (2 + f), the Lg1..Lg7 series, k ln2 split in hi / lo); <= 1 ulp.  Normal
@@ -432,13 +441,33 @@ OW_DEV double log_unit(double x) {
     const double f = m - 1.0;
     const double s = ow_div(f, 2.0 + f);
     const double z = s * s, w = z * z;
-    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
-                                        6.666666666666735130e-01);
+    const double t1 = w * fma_k(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma_k(w, fma_k(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                                6.666666666666735130e-01);
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     const double dk = (double)k;
     return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+// The library's exp (ocml: n = rint(x log2 e), two-step reduction by ln 2, degree-11 polynomial, ldexp -- the constants and operations of
+// exp_bounded, ow_chain_dev.h) for -700 < x <= 0 -- the onset ramp's p ln(cosine) >= -75 -- without the overflow / underflow
+// selects, which cannot fire there, and with the coefficients in scalar registers (fma_k).  Bit-identical to exp() on that range.
+OW_DEV double exp_nonpos(double x) {
+    const double n = rint(x * __longlong_as_double(0x3ff71547652b82feLL));
+    double r = __builtin_fma(__longlong_as_double((long long)0xbfe62e42fefa39efULL), n, x);
+    r = __builtin_fma(__longlong_as_double((long long)0xbc7abc9e3b39803fULL), n, r);
+    double p = __builtin_fma(__longlong_as_double(0x3e5ade156a5dcb37LL), r, __longlong_as_double(0x3e928af3fca7ab0cLL));
+    p = fma_k(r, p, __longlong_as_double(0x3ec71dee623fde64LL));
+    p = fma_k(r, p, __longlong_as_double(0x3efa01997c89e6b0LL));
+    p = fma_k(r, p, __longlong_as_double(0x3f2a01a014761f6eLL));
+    p = fma_k(r, p, __longlong_as_double(0x3f56c16c1852b7b0LL));
+    p = fma_k(r, p, __longlong_as_double(0x3f81111111122322LL));
+    p = fma_k(r, p, __longlong_as_double(0x3fa55555555502a1LL));
+    p = fma_k(r, p, __longlong_as_double(0x3fc5555555555511LL));
+    p = fma_k(r, p, __longlong_as_double(0x3fe000000000000bLL));
+    p = __builtin_fma(r, p, 1.0);
+    p = __builtin_fma(r, p, 1.0);
+    return ldexp(p, (int)n);
 }
 __device__ __noinline__ __attribute__((const)) double onset_gain(double n, double onset_inc, double onset_exp) {  // reed.rs:251-264
 #ifdef OW_LIB_POW
@@ -457,7 +486,7 @@ __device__ __noinline__ __attribute__((const)) double onset_gain(double n, doubl
     // whose maximum over c is eps / e = 4e-17 -- below half an ulp of the gains near 1 that carry the signal, and the reference's own
     // f64::powf (glibc) is only specified to 1 ulp.  pow(0, p) = 0.  (tests/test_gpu_division.py::test_onset_gain_accuracy)
     if (!(cosine > 0.0)) return 0.0;
-    return exp(onset_exp * log_unit(cosine));
+    return exp_nonpos(onset_exp * log_unit(cosine));   // cosine = (1 - cos) / 2 is 0 or >= 2^-54: p ln(cosine) >= -75
 #endif
 }
 __device__ __noinline__ __attribute__((const)) double exp_neg(double x) { return exp(-x); }                         // reed.rs:238
@@ -659,7 +688,7 @@ struct VoiceRegs {
                 e = noise_fade_env((double)pos / 16.0);
             }
             noise_rng = lcg(noise_rng);
-            const double nz = (double)(int32_t)noise_rng / 2147483647.0;
+            const double nz = OW_DIV_C((double)(int32_t)noise_rng, 2147483647.0);     // (= the IEEE quotient for all 2^32 draws, tests/test_gpu_division.py)
             const double y = lcoef[0] * nz + ns1;
             ns1 = lcoef[64] * nz - lcoef[192] * y + ns2;
             ns2 = lcoef[128] * nz - lcoef[256] * y;

@@ -72,10 +72,10 @@ def test_outside_the_promise_is_reported_not_hidden(hiplib):
     assert np.max(np.abs(fast - ieee)) <= ulp
 
 
-CONSTANTS = [2147483647.5, 1.0 * 2.58519910000000012e-2, 10.95 - 0.70, 0.026, 0.013 * 0.013, 22.0]
+CONSTANTS = [2147483647.5, 1.0 * 2.58519910000000012e-2, 10.95 - 0.70, 0.026, 0.013 * 0.013, 22.0, 2147483647.0]
 
 
-@pytest.mark.parametrize("which", range(6))
+@pytest.mark.parametrize("which", range(7))
 def test_constant_divisors_bit_identical(hiplib, which):
     """OW_DIV_C(a, B): reciprocal folded at compile time, product, exact residual, one correction.  Numerators: what the call site
     can produce and several decades around it, rounding-boundary neighbours of multiples of B, zeros, infinities, NaN."""
@@ -98,6 +98,13 @@ def test_jitter_draw_exhaustive(hiplib):
     """u = (jitter_state >> 1) / 2147483647.5 (reed.rs:267-272): every one of the 2^31 possible numerators, on the device."""
     bad = C.c_uint64(123)
     assert hiplib.ow_debug_div_const(0, None, 0, None, None, C.byref(bad), 0) == 0
+    assert bad.value == 0
+
+
+def test_noise_draw_exhaustive(hiplib):
+    """noise = (rng as i32) / 2147483647.0 (hammer.rs:192-195, the attack-noise burst): every one of the 2^32 numerators, on the device."""
+    bad = C.c_uint64(123)
+    assert hiplib.ow_debug_div_const(6, None, 0, None, None, C.byref(bad), 0) == 0
     assert bad.value == 0
 
 
