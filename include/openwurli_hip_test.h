@@ -36,7 +36,7 @@ int ow_debug_mlp_raw(const uint8_t* notes, const double* velocities, size_t n, d
  * fast[i], ieee[i] for n operand pairs.  Returns 0, <0 on device error. */
 int ow_debug_div(const double* a, const double* b, size_t n, double* fast, double* ieee, int device);
 /* The same for the constant-divisor form (OW_DIV_C): which = 0 jitter draw 2147483647.5, 1 Twin-T V_T, 2 LED span 10.25,
- * 3 preamp V_T 0.026, 4 power-amp 0.013^2, 5 power-amp headroom 22, 6 attack-noise draw 2147483647.  a == NULL (which = 0 or 6) runs
+ * 3 preamp V_T 0.026, 4 power-amp 0.013^2, 5 power-amp headroom 22, 6 attack-noise draw 2147483647, 7 pickup soft-limit range 0.04.  a == NULL (which = 0 or 6) runs
  * every numerator of that draw (all 2^31 integers / every int32) on the device and stores the number of quotients that differ from
  * `a / B` in *mismatches. */
 int ow_debug_div_const(int which, const double* a, size_t n, double* fast, double* ieee, uint64_t* mismatches, int device);

@@ -2997,7 +2997,7 @@ int ow_debug_div(const double* a, const double* b, size_t n, double* fast, doubl
 
 int ow_debug_div_const(int which, const double* a, size_t n, double* fast, double* ieee, uint64_t* mismatches, int device) {
     try {
-        if (which < 0 || which > 6) throw std::runtime_error("unknown constant");
+        if (which < 0 || which > 7) throw std::runtime_error("unknown constant");
         HIP_OK(hipSetDevice(device));
         if (!a) {
             if (!mismatches) throw std::runtime_error("null argument");

@@ -718,52 +718,7 @@ OW_DEV double allpass3(const double c0, const double c1, const double c2, double
 #define OW_OS_B1 0.420399304190880
 #define OW_OS_B2 0.854640112701920
 
-// tanh for the power amp's Newton loop and the speaker.  The device library's f64 tanh is a < 1 ulp routine built on
-// extended-precision (double-double) exponentials: ~130 instructions, 100 of them adds, twice or three times per output sample
-// and lane.  The reference calls libm tanh, itself good to 1-2 ulp; this one is tanh(x) = z / (z + 2), z = expm1(2|x|) from the
-// same ln 2 reduction as exp_bounded and a degree-13 series: ~45 instructions, <= 2 ulp (measured on the device against an 80-bit
-// reference over the whole domain, tests/test_gpu_division.py::test_tanh_fast_accuracy; glibc's own tanh measures 1.2 there).  OW_LIB_TANH restores the library call.
-OW_DEV double tanh_fast(double x) {
-#ifdef OW_LIB_TANH
-    return tanh(x);
-#else
-    double ax = fabs(x);
-    ax = ax > 20.0 ? 20.0 : ax;                       // tanh(20) rounds to 1.0; NaN stays NaN
-    const double y = ax + ax;
-    const double n = rint(y * __longlong_as_double(0x3ff71547652b82feLL));
-    double r = __builtin_fma(__longlong_as_double((long long)0xbfe62e42fefa39efULL), n, y);
-    r = __builtin_fma(__longlong_as_double((long long)0xbc7abc9e3b39803fULL), n, r);
-    double q = 1.0 / 6227020800.0;                     // 1/13!
-    q = __builtin_fma(q, r, 1.0 / 479001600.0);
-    q = __builtin_fma(q, r, 1.0 / 39916800.0);
-    q = __builtin_fma(q, r, 1.0 / 3628800.0);
-    q = __builtin_fma(q, r, 1.0 / 362880.0);
-    q = __builtin_fma(q, r, 1.0 / 40320.0);
-    q = __builtin_fma(q, r, 1.0 / 5040.0);
-    q = __builtin_fma(q, r, 1.0 / 720.0);
-    q = __builtin_fma(q, r, 1.0 / 120.0);
-    q = __builtin_fma(q, r, 1.0 / 24.0);
-    q = __builtin_fma(q, r, 1.0 / 6.0);
-    q = __builtin_fma(q, r, 0.5);
-    const double em1 = __builtin_fma(r * r, q, r);     // expm1(r), |r| <= ln2 / 2
-    const double s = __longlong_as_double((long long)(1023 + (int)n) << 52);   // 2^n, 0 <= n <= 58
-    const double z = __builtin_fma(s, em1, s - 1.0);   // expm1(2|x|) = 2^n expm1(r) + (2^n - 1)
-    // z / (z + 2) with the rounding error of the sum fed back into the quotient's residual (Fast2Sum is exact while z <= 2, which is
-    // where it matters: for larger z the quotient is insensitive to it)
-    const double d = z + 2.0;
-    const double d_lo = z <= 2.0 ? z - (d - 2.0) : 0.0;
-    double rc = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, rc, 1.0);
-    rc = __builtin_fma(rc, e, rc);
-    e = __builtin_fma(-d, rc, 1.0);
-    rc = __builtin_fma(rc, e, rc);
-    const double q0 = z * rc;
-    double res = __builtin_fma(-d, q0, z);
-    res = __builtin_fma(-d_lo, q0, res);
-    const double t = __builtin_fma(res, rc, q0);        // d >= 2: no special cases (NaN propagates)
-    return copysign(t, x);
-#endif
-}
+// (tanh_fast: ow_voice_dev.h)
 
 // ------------------------------------------------------------------ power amp (power_amp.rs:206-240)
 __device__ inline double power_amp(double input) {

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64) void k_debug_mlp(const uint8_t* __restrict__ no
 }
 
 // OW_DIV_C against the compiler's division, for the constants the kernels divide by (tests/test_gpu_division.py)
-#define OW_DIVC_CASES(X) X(0, OW_JITTER_DIV) X(1, 1.0 * OW_T_VT) X(2, 10.95 - 0.70) X(3, OW_P_VT) X(4, 0.013 * 0.013) X(5, 22.0) X(6, 2147483647.0)
+#define OW_DIVC_CASES(X) X(0, OW_JITTER_DIV) X(1, 1.0 * OW_T_VT) X(2, 10.95 - 0.70) X(3, OW_P_VT) X(4, 0.013 * 0.013) X(5, 22.0) X(6, 2147483647.0) X(7, 0.98 - 0.94)
 __device__ inline void divc_pair(int which, double a, double& fast, double& ieee) {
     fast = ieee = 0.0;
 #define OW_DIVC_ONE(i, B) if (which == i) { fast = OW_DIV_C(a, B); ieee = a / (B); }

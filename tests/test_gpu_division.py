@@ -72,10 +72,10 @@ def test_outside_the_promise_is_reported_not_hidden(hiplib):
     assert np.max(np.abs(fast - ieee)) <= ulp
 
 
-CONSTANTS = [2147483647.5, 1.0 * 2.58519910000000012e-2, 10.95 - 0.70, 0.026, 0.013 * 0.013, 22.0, 2147483647.0]
+CONSTANTS = [2147483647.5, 1.0 * 2.58519910000000012e-2, 10.95 - 0.70, 0.026, 0.013 * 0.013, 22.0, 2147483647.0, 0.98 - 0.94]
 
 
-@pytest.mark.parametrize("which", range(7))
+@pytest.mark.parametrize("which", range(8))
 def test_constant_divisors_bit_identical(hiplib, which):
     """OW_DIV_C(a, B): reciprocal folded at compile time, product, exact residual, one correction.  Numerators: what the call site
     can produce and several decades around it, rounding-boundary neighbours of multiples of B, zeros, infinities, NaN."""
