@@ -210,6 +210,7 @@ struct Switches {
     int eout_attn = -1;                        // OW_EOUT_ATTN=0/1: status summary instead of the status blocks (k_eout_attention); -1: ranges of >= 8 192 engines
     int pipe = 0;                              // OW_PIPE=n stages
     int midi_device = -1;                      // OW_MIDI_DEVICE=0/1: bursts of ow_pool_midi applied on the device (k_vm_events) never / whenever the list allows; -1: pools of >= 8 192 engines, >= 65 536 events
+    int voice_steal = 1;                       // OW_VOICE_STEAL=0: no steal variant of the steady voice kernel (k_voice renders every crossfade)
     int voice_attack = 1;                      // OW_VOICE_ATTACK=0: no attack variant of the steady voice kernel (engines in onset / noise phases go to the general kernel)
     bool force_general = false;                // test / probe hook: every engine's slot voices go to the general voice kernel (what it costs without any phase active)
     int chain_stream = -1;                     // OW_CHAIN_STREAM=0/1: preamp + output stage of a big oversampled pool as one launch (k_chain_stream); -1: when the block goes to a pinned host block
@@ -236,6 +237,7 @@ struct Switches {
         if (const char* e = std::getenv("OW_PIPE")) { const int v = std::atoi(e); w.pipe = (v >= 1 && v <= 8) ? v : 0; }
         w.pipe_overlap = flag("OW_PIPE_OVERLAP", 0) == 1;
         w.voice_attack = flag("OW_VOICE_ATTACK", 1) != 0;
+        w.voice_steal = flag("OW_VOICE_STEAL", 1) != 0;
         w.midi_device = flag("OW_MIDI_DEVICE", -1); if (w.midi_device > 1 || w.midi_device < -1) w.midi_device = -1;
         w.chain_stream = flag("OW_CHAIN_STREAM", -1); if (w.chain_stream > 1 || w.chain_stream < -1) w.chain_stream = -1;
         w.out_direct = flag("OW_OUT_DIRECT", -1); if (w.out_direct > 1 || w.out_direct < -1) w.out_direct = -1;
@@ -372,7 +374,7 @@ struct ow_pool {
     // Packed voice dispatch (ow_kernels.h): lane = sounding voice.  Three block lists of (engine << 6 | slot) entries, rebuilt when a
     // mask, a pending op or a transient flag changed: steady slot voices, slot voices of engines in a transient phase, steal voices.
     struct VoiceList { uint32_t* h = nullptr; uint32_t* d = nullptr; uint32_t n_blocks = 0; };
-    VoiceList vl_steady, vl_general, vl_steal, vl_attack;     // vl_attack: engines inside onset ramps / attack noise whose slot voices are not damping (k_voice_steady<false, true>)
+    VoiceList vl_steady, vl_general, vl_steal, vl_attack;     // vl_attack: engines inside onset ramps / attack noise whose slot voices are not damping (k_voice_steady<false, 1>)
     std::vector<uint8_t> transient;   // per engine: device status after the previous block (OwEngineOut::transient)
     bool lists_valid = false;
     int lists_e0 = -1, lists_ne = -1;
@@ -1580,7 +1582,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
             const ow_pool::SliceStart& a0 = p->slice_start[NP == 1 ? 0 : t0];
             const ow_pool::SliceStart& a1 = p->slice_start[NP == 1 ? p->slice_T : t1];
             const unsigned bs = (a1.s - a0.s) / 64, bg = (a1.g - a0.g) / 64, bt = (a1.t - a0.t) / 64, ba = (a1.a - a0.a) / 64;
-            if (ba) owdev::k_voice_steady<false, true><<<dim3(ba), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_attack.d + a0.a, p->d_sum, p->d_eout, I, L, Lcap, nullptr);
+            if (ba) owdev::k_voice_steady<false, 1><<<dim3(ba), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_attack.d + a0.a, p->d_sum, p->d_eout, I, L, Lcap, nullptr);
             if (bs)
                 {
                 // voices on more than one jitter grid in some wavefront of the previous steady launch: the skewed variant (same samples)
@@ -1593,8 +1595,12 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
             if (bg) {
                 owdev::k_voice<<<dim3(bg), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_general.d + a0.g, p->d_sum, p->d_eout, I, L, Lcap, 0);
             }
-            if (bt)
-                owdev::k_voice<<<dim3(bt), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_steal.d + a0.t, p->d_sum, p->d_eout, I, L, Lcap, 1);
+            if (bt) {
+                // the steal variant of the steady kernel takes the engines whose steal voices are past onset and noise (each block decides
+                // by itself, voice_steal_takes); k_voice (pass | 4) renders the others
+                if (p->sw.voice_steal) owdev::k_voice_steady<false, 2><<<dim3(bt), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_steal.d + a0.t, p->d_sum, p->d_eout, I, L, Lcap, nullptr);
+                owdev::k_voice<<<dim3(bt), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_steal.d + a0.t, p->d_sum, p->d_eout, I, L, Lcap, p->sw.voice_steal ? 5 : 1);
+            }
         }
         if (overlap && k + 1 < NP) HIP_OK(hipEventRecord(p->ev_voice_done[k], s));
         if (p->profiling) HIP_OK(hipEventRecord(p->ev_stage[k][1], s));
@@ -2908,6 +2914,7 @@ int ow_test_pool_set_switch(ow_pool* p, const char* name, int value) {
     else if (n == "out_direct") w.out_direct = value < 0 ? -1 : (value != 0);
     else if (n == "midi_device") w.midi_device = value < 0 ? -1 : (value != 0);
     else if (n == "voice_attack") { w.voice_attack = value != 0; p->lists_valid = false; }
+    else if (n == "voice_steal") w.voice_steal = value != 0;
     else if (n == "force_general") { w.force_general = value != 0; p->lists_valid = false; }
     else if (n == "chain_stream") w.chain_stream = value < 0 ? -1 : (value != 0);
     else return -1;                                       // (trem_traj / trem_cache / pipe shape the pool at creation: environment only)
@@ -2934,6 +2941,7 @@ int ow_test_pool_get_switch(const ow_pool* p, const char* name) {
     if (n == "out_direct") return w.out_direct;
     if (n == "midi_device") return w.midi_device;
     if (n == "voice_attack") return w.voice_attack;
+    if (n == "voice_steal") return w.voice_steal;
     if (n == "blocks_steady") return (int)p->vl_steady.n_blocks;   // wavefront blocks of the voice lists the last render launched
     if (n == "blocks_general") return (int)p->vl_general.n_blocks;
     if (n == "blocks_attack") return (int)p->vl_attack.n_blocks;

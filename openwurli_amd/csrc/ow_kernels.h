@@ -205,6 +205,12 @@ OW_DEV void voice_reduce(const double* __restrict__ tile, const int* __restrict_
     }
 }
 
+// Does the steal variant of the steady kernel (k_voice_steady<false, 2>, below) render this block's engine?  One test for both kernels.
+OW_DEV bool voice_steal_takes(bool active, uint64_t sample, uint64_t onset_n, uint32_t noise_rem, uint32_t flags, double rate6) {
+    const bool other_phase = active && (sample < onset_n || noise_rem > 0u || ((flags & 1u) && !(rate6 <= 0.125)));
+    return __ballot(other_phase) == 0ull;
+}
+
 // General step (any phase).  pass 0 = slot voices of the engines the host classified as "in a transient phase", pass 1 = steal voices
 // (one engine per block there, so the crossfade early-out below is per engine).
 // pass | 2 = the voice-sum NaN guard's second render (engine.rs:496-521): after a block whose voice sum was non-finite the reference
@@ -232,9 +238,20 @@ __global__ __launch_bounds__(64) OW_VOICE_GENERAL_ATTR void k_voice(const OwCons
     const VoiceLanes w = voice_lanes(entries, eng_l);
     const bool active = w.active;
     const bool guard = (pass & 2) != 0;
+    const bool skip_taken = (pass & 4) != 0;                   // pass | 4: engines the steal variant of the steady kernel renders are skipped
     pass &= 1;
     double* rec = vrec + ((size_t)(active ? w.e : 0) * 2 + pass) * OW_VREC_DOUBLES + w.slot;
 
+    if (skip_taken) {                    // (ahead of the record: the blocks that leave here are most of a re-strike's launch)
+        uint64_t smp = 0ull, on_n = 0ull;
+        uint32_t nrem = 0u, fl = 0u;
+        double rate6 = 0.0;
+        if (active) {
+            smp = dbits(rec[VF_SAMPLE * 64]); on_n = dbits(rec[VF_ONSET_N * 64]); nrem = (uint32_t)dbits(rec[VF_NCNT * 64]);
+            fl = (uint32_t)dbits(rec[VF_FLAGS * 64]); rate6 = rec[(VF_DRATE + 6) * 64];
+        }
+        if (voice_steal_takes(active, smp, on_n, nrem, fl, rate6)) return;
+    }
     VoiceRegs v;
     uint32_t steal_fade = 0, steal_len = 1;
     if (active) {
@@ -347,21 +364,43 @@ struct VoiceSteady {
     // (hammer.rs:150-179)
     uint32_t on_rem, noise_rem, noise_fade, noise_rng;
     double namp, ns1, ns2, ndecay;
+    // STEAL variant only (k_voice_steady<false, 2>: the steal voices of an engine during their 5 ms crossfade, usually damping): the damper's
+    // clock and ramp length (reed.rs:228-247; the seven rates -- the seven multipliers once the ramp is over -- sit in the lane's LDS column)
+    double dt, dramp, dramp_y;   // (dramp_y = ow_rcp_refined(dramp): the per-sample quotient t / ramp is ow_div instruction for instruction)
+    uint32_t dflags;          // bit 0 damper active, bit 1 ramp done (VF_FLAGS)
 
     OW_DEV void set_sample(uint64_t sample) {
         cd = (16u - ((uint32_t)sample & 15u)) & 15u;
         next_evt = sample + (uint64_t)cd;
         renorm = 0u;
     }
-    OW_DEV void update_rotation() {
+    // MEM (the STEAL variant): cos_inc / sin_inc / phase_inc are read from the voice record `rc` at every update (once in 16 samples)
+    // instead of living in 42 registers -- the registers the seven damper polynomials need; with them resident that loop spilled on
+    // every sample.
+    template <bool MEM = false>
+    OW_DEV void update_rotation(const double* __restrict__ rc = nullptr, const volatile int* zero = nullptr) {
 #ifndef OW_STRICT_FP
 #pragma clang fp contract(fast)
 #endif
+        if constexpr (MEM) {
+            // (the record's address behind a zero the compiler cannot see through -- a volatile LDS word -- so that the loads stay here:
+            // left alone they are hoisted out of the sample loop, back into registers; volatile global reads bypass the caches; an opaque
+            // zero from inline asm counts as a convergent operation and the loop is then no longer unrolled by two)
+            rc += *zero;
 #pragma unroll
-        for (int m = 0; m < 7; ++m) {
-            const double delta_phase = drift[m] * phase_inc[m];
-            ci[m] = cos_inc[m] - delta_phase * sin_inc[m];
-            si[m] = sin_inc[m] + delta_phase * cos_inc[m];
+            for (int m = 0; m < 7; ++m) {
+                const double cinc = rc[(VF_COS_INC + m) * 64], sinc = rc[(VF_SIN_INC + m) * 64], pinc = rc[(VF_PHASE_INC + m) * 64];
+                const double delta_phase = drift[m] * pinc;
+                ci[m] = cinc - delta_phase * sinc;
+                si[m] = sinc + delta_phase * cinc;
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                const double delta_phase = drift[m] * phase_inc[m];
+                ci[m] = cos_inc[m] - delta_phase * sin_inc[m];
+                si[m] = sin_inc[m] + delta_phase * cos_inc[m];
+            }
         }
     }
 
@@ -369,13 +408,15 @@ struct VoiceSteady {
     // (pickup(), ~25 dependent f64 ops) is emitted in the same basic block as the 7 independent rotations of sample n
     // (advance()), with the rare branches (jitter / renormalise / saturate) at the block edges.  Same arithmetic, same order
     // per value as VoiceRegs::step<true>; only the instruction interleaving changes.
-    OW_DEV void jitter() {                                   // reed.rs:262-283, every 16th sample of this voice
+    template <bool MEM = false>
+    OW_DEV void jitter(const double* __restrict__ rc = nullptr, const volatile int* zero = nullptr) {   // reed.rs:262-283, every 16th sample of this voice
 #ifndef OW_STRICT_FP
 #pragma clang fp contract(fast)
 #endif
-        if (cd == 0u) jitter_due();
+        if (cd == 0u) jitter_due<MEM>(rc, zero);
     }
-    OW_DEV void jitter_due() {                               // the update itself (the caller knows this voice's sample counter is at a multiple of 16)
+    template <bool MEM = false>
+    OW_DEV void jitter_due(const double* __restrict__ rc = nullptr, const volatile int* zero = nullptr) {   // the update itself (the caller knows this voice's sample counter is at a multiple of 16)
 #ifndef OW_STRICT_FP
 #pragma clang fp contract(fast)
 #endif
@@ -391,16 +432,39 @@ struct VoiceSteady {
                 const double noise = (u * 2.0 - 1.0) * 1.7320508080;
                 drift[m] = revert * drift[m] + diffusion * noise;
             }
-            update_rotation();
+            update_rotation<MEM>(rc, zero);
         }
     }
     // gain: this sample's slot of the lane's tile row (ATTACK: the onset gain sits there while the ramp lasts); nco: the lane's column of
     // the attack-noise BPF coefficients b0, b1, b2, a1, a2 in LDS (nco[i * 64]); fade16: the sixteen fade-in values of hammer.rs:165
-    template <bool ATTACK = false>
-    OW_DEV double advance(const double* __restrict__ gain = nullptr, const double* __restrict__ nco = nullptr, const double* __restrict__ fade16 = nullptr) {
+    // DAMP: dtab = the lane's column of damper rates (dtab[m * 64]; the multipliers once the ramp is done), rec = its voice record
+    template <bool ATTACK = false, bool DAMP = false>
+    OW_DEV double advance(const double* __restrict__ gain = nullptr, const double* __restrict__ nco = nullptr, const double* __restrict__ fade16 = nullptr,
+                          double* __restrict__ dtab = nullptr, const double* __restrict__ rec = nullptr) {
 #ifndef OW_STRICT_FP
 #pragma clang fp contract(fast)
 #endif
+        if (DAMP) {                                          // reed.rs:228-247, ahead of the modal sum; the factors land on ae = amplitude * envelope
+            // Branch-free but for the (wave-uniform, once per voice) end of a ramp: every lane evaluates the seven polynomials and a
+            // select picks polynomial / multiplier / 1 -- lane-dependent branches here cut the loop's scheduling region in pieces.
+            const bool damp = (dflags & 1u) != 0u;
+            dt += damp ? 1.0 : 0.0;
+            if (__builtin_amdgcn_ballot_w64(damp && !(dflags & 2u) && dt > dramp) != 0ull) {
+                if (damp && !(dflags & 2u) && dt > dramp) {
+                    dflags |= 2u;
+#pragma unroll
+                    for (int m = 0; m < 7; ++m) dtab[m * 64] = rec[(VF_DMULT + m) * 64];
+                }
+            }
+            const bool in_ramp = damp && !(dflags & 2u);
+            const double tr = ow_div_y(dt, dramp, dramp_y);   // damper_ramp_pos: ow_div(t, ramp) with the ramp's reciprocal refined once (unused garbage outside a ramp)
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                const double k = dtab[m * 64];               // rate inside the ramp (<= 1/8: the kernel's entry test), multiplier after it
+                const double pf = exp_neg_poly(k * tr);
+                ae[m] *= in_ramp ? pf : (damp ? k : 1.0);    // (x * 1.0 == x)
+            }
+        }
         double sum = 0.0;
 #pragma unroll
         for (int m = 0; m < 7; ++m) {
@@ -484,23 +548,47 @@ struct VoiceSteady {
 // slot is overwritten), and the noise burst -- at 1.2-1.7 x the steady price instead of the general kernel's 2.6 x: the four blocks
 // after a whole-keyboard re-strike were 19 + 47 + 37 + 17 ms there.  Values differ from k_voice's in the last bit (fused steps, the
 // onset gain on the sum): the same class as deviation 9, inside the voice-sum bar.
-template <bool SKEW, bool ATTACK = false>
+// STEAL (PHASE = 2, round 5): the steal voices of one engine per block (the host's steal list) for the 5 ms of their crossfade
+// (engine.rs:483-490) -- released voices inside or past their damper ramp, as a re-struck key leaves them behind.  The loop adds the
+// damper's factors (seven exp_neg_poly per sample during the ramp, rates in the lane's LDS column) and the crossfade gain; 24-sample
+// chunks, so that the rate table fits beside the tile at eight workgroups per CU.  A block decides by itself whether it may: an engine
+// with a steal voice still inside its onset ramp or noise burst (stolen within 40 ms of its strike), or with a damper rate above 1/8
+// (host rates below 16 kHz), returns at once and is rendered by k_voice, which skips the others (voice_steal_takes: one test, both
+// kernels).  The general kernel spent 14.0 + 13.0 ms on the two sub-blocks of a whole-pool re-strike's crossfade.
+template <bool SKEW, int PHASE = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_voice_steady(const OwConsts* __restrict__ K, double* __restrict__ vrec, const uint32_t* __restrict__ entries,
                                                      double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int L, int Lcap, uint32_t* __restrict__ skew_seen) {
-    constexpr int TILE_DOUBLES = SKEW ? 64 * OW_SKEW_RS : 64 * (32 + 1);    // (the skewed variant's short blocks and aligned wavefronts use the plain loop in the ring's tile)
-    constexpr int PCH = 32;                                   // chunk of the plain loop (24 -> 32: a 512-sample block is sixteen whole chunks; 12.9 against 13.05 ms)
+    constexpr bool ATTACK = PHASE == 1, STEAL = PHASE == 2;
+    constexpr int PCH = STEAL ? 24 : 32;                      // chunk of the plain loop (24 -> 32: a 512-sample block is sixteen whole chunks; 12.9 against 13.05 ms)
+    constexpr int TILE_DOUBLES = SKEW ? 64 * OW_SKEW_RS : 64 * (PCH + 1);   // (the skewed variant's short blocks and aligned wavefronts use the plain loop in the ring's tile)
     constexpr int PRS = SKEW ? OW_SKEW_RS : PCH + 1;          // ... and its row stride
-    static_assert(!(SKEW && ATTACK), "the attack variant is the plain loop");
+    constexpr int PASS = STEAL ? 1 : 0;                       // which record of the slot and which row of the sums
+    static_assert(!(SKEW && PHASE != 0), "the attack / steal variants are the plain loop");
     __shared__ double tile[TILE_DOUBLES];
-    __shared__ double nco[ATTACK ? 5 * 64 + 16 : 1];          // attack-noise BPF coefficients per lane, then the sixteen fade-in values
+    __shared__ double nco[ATTACK ? 5 * 64 + 16 : (STEAL ? 7 * 64 : 1)];   // attack-noise BPF coefficients per lane, then the sixteen fade-in values / damper rates per lane
     __shared__ int eng_l[64];
+    __shared__ int zero_l[1];                                 // (STEAL: update_rotation<true>)
     const int lane = threadIdx.x;
+    if (STEAL && lane == 0) zero_l[0] = 0;
     const VoiceLanes w = voice_lanes(entries, eng_l);
     const bool active = w.active;
-    double* rec = vrec + ((size_t)(active ? w.e : 0) * 2) * OW_VREC_DOUBLES + w.slot;
+    double* rec = vrec + ((size_t)(active ? w.e : 0) * 2 + PASS) * OW_VREC_DOUBLES + w.slot;
     VoiceSteady v;
     uint32_t noise_rng = 0;
     v.on_rem = 0u; v.noise_rem = 0u; v.noise_fade = 0u; v.noise_rng = 0u; v.namp = 0.0; v.ns1 = 0.0; v.ns2 = 0.0; v.ndecay = 0.0;
+    v.dt = 0.0; v.dramp = 0.0; v.dramp_y = 0.0; v.dflags = 0u;
+    uint32_t steal_fade = 0u, steal_len = 1u;
+    double steal_len_d = 1.0, steal_len_y = 1.0;
+    if (STEAL) {
+        uint64_t smp = 0ull, on_n = 0ull;
+        uint32_t nrem = 0u, fl = 0u;
+        double rate6 = 0.0;
+        if (active) {
+            smp = dbits(rec[VF_SAMPLE * 64]); on_n = dbits(rec[VF_ONSET_N * 64]); nrem = (uint32_t)dbits(rec[VF_NCNT * 64]);
+            fl = (uint32_t)dbits(rec[VF_FLAGS * 64]); rate6 = rec[(VF_DRATE + 6) * 64];
+        }
+        if (!voice_steal_takes(active, smp, on_n, nrem, fl, rate6)) return;      // k_voice renders this engine
+    }
     if (ATTACK && lane < 16) nco[5 * 64 + lane] = noise_fade_env((double)lane / 16.0);      // the values k_voice forms per sample (hammer.rs:165)
     if (active) {
         // The host sends an engine here only if its status after the previous block said "no transient phase" and no note event
@@ -516,12 +604,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             v.namp = rec[VF_NAMP * 64]; v.ns1 = rec[VF_NS1 * 64]; v.ns2 = rec[VF_NS2 * 64]; v.ndecay = rec[VF_NDECAY * 64];
 #pragma unroll
             for (int i = 0; i < 5; ++i) nco[i * 64 + lane] = rec[(VF_NB0 + i) * 64];
+        } else if (STEAL) {
+            v.dflags = flags & 3u; v.dt = rec[VF_DCOUNT * 64]; v.dramp = rec[VF_DRAMP * 64]; v.dramp_y = ow_rcp_refined(v.dramp);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) nco[i * 64 + lane] = rec[(((flags & 2u) ? VF_DMULT : VF_DRATE) + i) * 64];
+            const uint64_t sf = dbits(rec[VF_STEAL * 64]);
+            steal_fade = (uint32_t)sf; steal_len = (uint32_t)(sf >> 32);
+            steal_len_d = (double)steal_len; steal_len_y = ow_rcp_refined(steal_len_d);
         } else if ((flags & 1u) || smp < onset_n || noise_rem > 0u) eout[w.e].transient = 2u;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             v.s[i] = rec[(VF_S + i) * 64]; v.c[i] = rec[(VF_C + i) * 64]; v.ae[i] = rec[(VF_AMP + i) * 64] * rec[(VF_ENV + i) * 64];
-            v.drift[i] = rec[(VF_DRIFT + i) * 64]; v.cos_inc[i] = rec[(VF_COS_INC + i) * 64]; v.sin_inc[i] = rec[(VF_SIN_INC + i) * 64];
-            v.phase_inc[i] = rec[(VF_PHASE_INC + i) * 64]; v.decay[i] = rec[(VF_DECAY + i) * 64];
+            v.drift[i] = rec[(VF_DRIFT + i) * 64]; v.decay[i] = rec[(VF_DECAY + i) * 64];
+            if (!STEAL) { v.cos_inc[i] = rec[(VF_COS_INC + i) * 64]; v.sin_inc[i] = rec[(VF_SIN_INC + i) * 64]; v.phase_inc[i] = rec[(VF_PHASE_INC + i) * 64]; }
         }
         v.q = rec[VF_Q * 64]; v.ds = rec[VF_DS * 64]; v.gain = rec[VF_GAIN * 64];
         v.beta = rec[VF_BETA * 64]; v.revert = rec[VF_JREV * 64]; v.diffusion = rec[VF_JDIFF * 64];
@@ -529,7 +624,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const uint64_t r = dbits(rec[VF_RNG * 64]);
         v.jitter_state = (uint32_t)r; noise_rng = (uint32_t)(r >> 32);
         v.noise_rng = noise_rng;
-        v.update_rotation();
+        v.template update_rotation<STEAL>(rec, zero_l);
     }
     __syncthreads();                     // eng_l, nco
     // ---- which trips carry the jitter updates: g minimising the longest delay over the phases present in this wavefront
@@ -539,7 +634,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         uint32_t present = 0;                                       // bit b: some voice has cd0 == b
         for (int b = 0; b < 16; ++b) present |= (__ballot(active && cd0 == (uint32_t)b) != 0ull ? 1u : 0u) << b;
         if (!SKEW) {
-            if (!ATTACK && lane == 0 && (present & (present - 1u)) != 0u && L >= 2 * OW_SKEW_CH) atomicOr(skew_seen, 1u);
+            if (PHASE == 0 && lane == 0 && (present & (present - 1u)) != 0u && L >= 2 * OW_SKEW_CH) atomicOr(skew_seen, 1u);
         } else if (L >= 2 * OW_SKEW_CH) {
         int best = 16;
         for (int gg = 0; gg < 16; ++gg) {
@@ -611,6 +706,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     } else
     for (int base = 0; base < L; base += PCH) {
         const int cn = min(PCH, L - base);
+        if (STEAL && __all(!active || steal_fade <= (uint32_t)base)) {   // every crossfade of the engine has run out (as k_voice, pass 1)
+            double* row = sum + ((size_t)PASS * I + eng_l[0]) * Lcap;
+            for (int i = base + lane; i < L; i += 64) row[i] = 0.0;
+            break;
+        }
         if (ATTACK) {
             // onset gains of the chunk into the tile rows of the lanes inside their ramp: two voices per pass, 32 samples each.  The
             // ramp's parameters travel from the owning lane by cross-lane reads (fetched from the voice record in every pass -- three
@@ -637,18 +737,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         if (active) {
             double* trow = tile + lane * PRS;
-            v.jitter();
-            double y = v.advance<ATTACK>(trow, nco + lane, nco + 5 * 64);
-#pragma unroll 2   // two samples per trip: the compiler renames the pipelined state instead of copying it back (7 v_mov_b64 per sample)
-            for (int n = 1; n < cn; ++n) {
-                v.jitter();
-                trow[n - 1] = v.pickup(y);
-                y = v.advance<ATTACK>(trow + n, nco + lane, nco + 5 * 64);
+            // 5 ms linear crossfade of a steal voice, engine.rs:483-489 (as k_voice, pass 1)
+            auto faded = [&](double o, int n) {
+                if (!STEAL) return o;
+                const uint32_t i = (uint32_t)(base + n);
+                const uint32_t remaining = steal_fade > i ? steal_fade - i : 0u;
+                return o * ow_div_y((double)remaining, steal_len_d, steal_len_y);     // ow_div(remaining, len), the divisor's reciprocal refined once
+            };
+            v.template jitter<STEAL>(rec, zero_l);
+            double y = v.advance<ATTACK, STEAL>(trow, nco + lane, nco + 5 * 64, nco + lane, rec);
+            auto one = [&](int n) {
+                v.template jitter<STEAL>(rec, zero_l);
+                trow[n - 1] = faded(v.pickup(y), n - 1);
+                y = v.advance<ATTACK, STEAL>(trow + n, nco + lane, nco + 5 * 64, nco + lane, rec);
+            };
+            // two samples per trip: the compiler renames the pipelined state instead of copying it back (7 v_mov_b64 per sample)
+            if (STEAL) {          // (by hand: the ballot in its damper step is a convergent operation, which the unroller leaves alone)
+                int n = 1;
+                for (; n + 1 < cn; n += 2) { one(n); one(n + 1); }
+                if (n < cn) one(n);
+            } else {
+#pragma unroll 2
+                for (int n = 1; n < cn; ++n) one(n);
             }
-            trow[cn - 1] = v.pickup(y);
+            trow[cn - 1] = faded(v.pickup(y), cn - 1);
         }
         __syncthreads();
-        voice_reduce<PCH, PRS>(tile, eng_l, w, cn, base, 0, sum, eout, I, Lcap);
+        voice_reduce<PCH, PRS>(tile, eng_l, w, cn, base, PASS, sum, eout, I, Lcap);
         __syncthreads();
     }
     if (active) {
@@ -674,8 +789,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         rec[VF_RNG * 64] = bitsd((uint64_t)v.jitter_state | ((uint64_t)noise_rng << 32));
         const unsigned long long bit = 1ull << w.slot;
-        if (all_quiet) atomicOr((unsigned long long*)&eout[w.e].silent_mask, bit);   // damper inactive here: only the -80 dB test of Voice::is_silent
-        if (!fin) atomicOr((unsigned long long*)&eout[w.e].bad_main, bit);
+        if (STEAL) {
+            rec[VF_DCOUNT * 64] = v.dt;
+            const uint64_t fl = dbits(rec[VF_FLAGS * 64]);
+            rec[VF_FLAGS * 64] = bitsd((fl & ~3ull) | (uint64_t)v.dflags);
+            const uint32_t l32 = (uint32_t)L;                                      // slot.steal_fade.saturating_sub(len) (engine.rs:490)
+            steal_fade = steal_fade > l32 ? steal_fade - l32 : 0u;
+            rec[VF_STEAL * 64] = bitsd((uint64_t)steal_fade | ((uint64_t)steal_len << 32));
+            if (!fin) atomicOr((unsigned long long*)&eout[w.e].bad_steal, bit);
+        } else {
+            if (all_quiet) atomicOr((unsigned long long*)&eout[w.e].silent_mask, bit);   // damper inactive here: only the -80 dB test of Voice::is_silent
+            if (!fin) atomicOr((unsigned long long*)&eout[w.e].bad_main, bit);
+        }
     }
 }
 

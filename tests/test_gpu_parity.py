@@ -1162,3 +1162,74 @@ def test_attack_variant_follows_the_oracle_and_the_general_kernel(hiplib, oracle
     assert np.max(np.abs(res[1][1] - res[0][1])) <= 1e-10 * scale, float(np.max(np.abs(res[1][1] - res[0][1])))
     assert np.max(np.abs(res[1][0] - res[0][0])) <= 1e-6
     assert np.max(np.abs(res[1][0])) > 1e-3
+
+
+def test_steal_variant_follows_the_oracle_and_the_general_kernel(hiplib, oracle):
+    """k_voice_steady<false, 2> (ow_kernels.h): the steal voices of an engine during their 5 ms crossfade render on the steady loop with the
+    damper's factors and the crossfade gain beside it, instead of on the general kernel; each block decides by itself (voice_steal_takes).
+    Engines: 0 the whole keyboard re-struck (every steal voice inside its damper ramp); 1 three more keys on a full keyboard (held voices
+    stolen: no damper); 2 two more keys in the block of the first strike (voices stolen inside their onset ramp: the general kernel's);
+    3 the top keys (no damper at all) released and re-struck with the rest; 4 released 64 ms before the re-strike (past every damper ramp:
+    the multipliers); 5 released 42 ms before (bass ramps end inside the crossfade).  Ragged block lengths incl. some below the chunk.
+    Every block follows the oracle; against OW_VOICE_STEAL=0 voice sums differ by rounding only."""
+    import openwurli_amd as ow
+    sr, n = 48000.0, 6
+    lengths = (512, 512, 512, 512, 512, 100, 7, 133, 24, 25, 512, 1, 512, 512, 512, 300, 512)
+    res = {}
+    keys = list(range(33, 97))
+    for steal in (1, 0):
+        p = ow.EnginePool(sr, n)
+        p.set_switch("voice_steal", steal)
+        assert p.get_switch("voice_steal") == steal
+        p.set_sample_rate(sr)
+        cs = [oracle.OracleEngine(sr) for _ in range(n)] if steal else None
+        if cs:
+            for c in cs:
+                c.set_sample_rate(sr)
+        def both(k, f):
+            f(p[k])
+            if cs:
+                f(cs[k])
+        def chord(vel):
+            return lambda e: [e.note_on(note, vel + 0.004 * (note - 33)) for note in keys]
+        def release(e):
+            for note in keys:
+                e.note_off(note)
+        sums, outs = [], []
+        for k in range(n):
+            both(k, chord(0.45 + 0.05 * k))
+        both(2, lambda e: (e.note_on(50, 0.9), e.note_on(51, 0.8)))            # 65th and 66th voice in the block of the strike
+        for b, length in enumerate(lengths):
+            if b == 5:
+                both(0, release); both(0, chord(0.7))                          # the benchmark's re-strike
+                both(1, lambda e: [e.note_on(note, 0.8) for note in (40, 60, 80)])
+                both(3, release); both(3, chord(0.6))
+                both(4, release)
+            if b == 7:
+                both(5, release)
+            if b == 11:
+                both(4, chord(0.65))                                           # 64.6 ms after the release
+                both(5, chord(0.75))                                           # 42.5 ms after the release
+            o = p.render(length)
+            outs.append(o.copy()); sums.append(p.voice_sum(length).copy())
+            if cs:
+                for k in range(n):
+                    co, cv, _, _ = cs[k].render_taps(length)
+                    rep = oracle.parity_report(o[k], co, abs_floor=oracle.ABS_FLOOR_DENSE)
+                    assert rep["n_bad"] == 0, (k, b, length, rep)
+                    vs = sums[-1][k]
+                    assert np.max(np.abs(vs - cv)) <= 2e-9 * max(1.0, float(np.max(np.abs(cv)))), (k, b, float(np.max(np.abs(vs - cv))))
+        for k in range(n):
+            assert p[k].active_voice_count() == 64
+        p.close()
+        if cs:
+            for c in cs:
+                c.close()
+        res[steal] = (np.concatenate(outs, axis=1), np.concatenate(sums, axis=1))
+    scale = max(1.0, float(np.max(np.abs(res[0][1]))))
+    d = np.abs(res[1][1] - res[0][1])
+    assert np.max(d) <= 1e-10 * scale, float(np.max(d))
+    assert np.array_equal(res[1][1][2, :512], res[0][1][2, :512])              # engine 2's crossfade stayed on the general kernel
+    assert np.max(d[0]) > 0.0                                                  # ... and engine 0's did not
+    assert np.max(np.abs(res[1][0] - res[0][0])) <= 1e-6
+    assert np.max(np.abs(res[1][0])) > 1e-3
