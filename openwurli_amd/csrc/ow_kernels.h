@@ -480,8 +480,9 @@ struct VoiceSteady {
             on_rem -= 1u;
         }
         double x = 0.0 + sum;
-        // (both additions as lane-dependent branches: written branch-free -- selects, one loop copy per phase set picked per chunk -- the
-        // loop spilled and the block after a re-strike took 38.7 instead of 27.3 ms)
+        // (both additions as lane-dependent branches.  Written branch-free -- selects, one loop copy per phase set picked per chunk, as
+        // the steal variant's damper step is -- this loop spills: the block after a re-strike took 38.7 instead of 27.3 ms, and 68 ms
+        // with the rotation constants read from the record as well)
         if (ATTACK && noise_rem > 0u) {                      // hammer.rs:150-179, as VoiceRegs::step
             double e = 1.0;
             if (noise_fade > 0u) { e = fade16[16u - noise_fade]; noise_fade -= 1u; }
