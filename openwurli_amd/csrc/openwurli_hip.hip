@@ -1520,10 +1520,34 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         };
         Workers::get().each(T, pack_slice);
     }
+    // One parallel pass over the args of the range (13 MB at 131 072 engines: ~1 ms per walk on one thread, and the blocks after a
+    // whole-pool re-strike used to take two): does any engine sound, and which engines have ops (slice t lists its own into its part of
+    // h_op_engines; the parts are closed up below).
     bool any_main = p->any_main_c, any_steal = p->any_steal_c;
+    uint32_t n_act = 0;
     if (!untouched) {
+        const size_t TA = ne >= 16384 ? std::min<size_t>(effective_cpus(), 32) : 1;
+        const int per_a = (int)((ne + TA - 1) / TA);
+        uint32_t act_n[OW_MAX_SLICES] = {0};
+        uint8_t any_m[OW_MAX_SLICES] = {0}, any_s[OW_MAX_SLICES] = {0};
+        auto scan_slice = [&](size_t t) {
+            const int k0 = (int)t * per_a, k1 = std::min(ne, (int)(t + 1) * per_a);
+            uint32_t n = 0; uint8_t m = 0, sl = 0;
+            uint32_t* dst = p->h_op_engines + k0;
+            for (int k = k0; k < k1; ++k) {
+                const OwEngineArgs& a = p->h_args[e0 + k];
+                m |= a.main_mask != 0; sl |= a.steal_mask != 0;
+                if (a.op_count) dst[n++] = (uint32_t)(e0 + k);
+            }
+            act_n[t] = n; any_m[t] = m; any_s[t] = sl;
+        };
+        Workers::get().each(TA, scan_slice);
         any_main = false; any_steal = false;
-        for (int k = 0; k < ne; ++k) { any_main |= p->h_args[e0 + k].main_mask != 0; any_steal |= p->h_args[e0 + k].steal_mask != 0; }
+        for (size_t t = 0; t < TA; ++t) {
+            any_main |= any_m[t] != 0; any_steal |= any_s[t] != 0;
+            if (act_n[t] && n_act != (uint32_t)(t * per_a)) std::memmove(p->h_op_engines + n_act, p->h_op_engines + t * per_a, sizeof(uint32_t) * act_n[t]);
+            n_act += act_n[t];
+        }
         if (whole) { p->any_main_c = any_main; p->any_steal_c = any_steal; p->any_cache_valid = true; }
     }
     // args carry one-shot fields (ops, setter targets): upload when anything changed, and once more afterwards to clear them
@@ -1538,9 +1562,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         for (const ow_pool::OpTail& t : p->op_tails)
             HIP_OK(hipMemcpyAsync(p->d_ops_fix + t.dst, p->d_ops + t.src, sizeof(OwOp) * t.n, hipMemcpyDeviceToDevice, st));
         p->op_tails.clear();
-        // one block per engine that has ops
-        uint32_t n_act = 0;
-        for (int k = 0; k < ne; ++k) if (p->h_args[e0 + k].op_count) p->h_op_engines[n_act++] = (uint32_t)(e0 + k);
+        // one block per engine that has ops (listed by the scan above; an untouched range has none)
         if (n_act) {
             HIP_OK(hipMemcpyAsync(p->d_op_engines, p->h_op_engines, sizeof(uint32_t) * n_act, hipMemcpyHostToDevice, st));
             owdev::k_apply_ops<<<dim3(n_act), dim3(64), 0, st>>>(p->dK, p->d_nt, p->d_vrec, p->d_args, p->d_ops, p->d_op_engines, p->d_ops_fix);
@@ -2243,6 +2265,8 @@ void ow_pool_render(ow_pool* p, float* out_host, size_t out_stride, size_t len) 
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
             double* acc = p->hostprof_acc;
             acc[0] += ms(t0, t1); acc[1] += ms(t1, t2); acc[2] += ms(t2, t3); acc[3] += ms(t3, t4);
+            if (ms(t0, t1) > 2.0 || ms(t2, t3) > 1.0)      // the blocks around a re-strike: where the host time between the kernels goes
+                std::fprintf(stderr, "hostprof block %ld len %zu: launch %.3f wait %.3f post %.3f ms\n", p->hostprof_cnt, len, ms(t0, t1), ms(t1, t2), ms(t2, t3));
             if (++p->hostprof_cnt % 50 == 0) { std::fprintf(stderr, "hostprof I=%zu: launch %.3f wait %.3f post %.3f profile %.3f ms (mean of 50)\n", p->I, acc[0] / 50, acc[1] / 50, acc[2] / 50, acc[3] / 50); acc[0] = acc[1] = acc[2] = acc[3] = 0; }
         }
         p->last_len = len;
