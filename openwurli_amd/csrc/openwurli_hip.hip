@@ -373,7 +373,9 @@ struct ow_pool {
     std::mutex op_tails_mu;
     // Packed voice dispatch (ow_kernels.h): lane = sounding voice.  Three block lists of (engine << 6 | slot) entries, rebuilt when a
     // mask, a pending op or a transient flag changed: steady slot voices, slot voices of engines in a transient phase, steal voices.
-    struct VoiceList { uint32_t* h = nullptr; uint32_t* d = nullptr; uint32_t n_blocks = 0; };
+    // sig: signature of the (engine, mask) sequence the device copy was packed from (two independent 64-bit hashes + layout); a rebuild that
+    // arrives at the same signature leaves the list alone (the blocks after a whole-pool re-strike repack 33 MB per list otherwise)
+    struct VoiceList { uint32_t* h = nullptr; uint32_t* d = nullptr; uint32_t n_blocks = 0; uint64_t sig[3] = {0, 0, 0}; bool sig_valid = false; };
     VoiceList vl_steady, vl_general, vl_steal, vl_attack;     // vl_attack: engines inside onset ramps / attack noise whose slot voices are not damping (k_voice_steady<false, 1>)
     std::vector<uint8_t> transient;   // per engine: device status after the previous block (OwEngineOut::transient)
     bool lists_valid = false;
@@ -382,7 +384,7 @@ struct ow_pool {
     // on its own stream; the kernels of stage k start when those of stage k-1 have finished, so the device-to-host copy of stage k-1
     // (copy engine) runs beside the kernels of stage k.  Stage boundaries are slice boundaries of the packed voice lists.
     int slice_T = 1, slice_per = 0;                             // slices the lists were packed in, engines per slice
-    struct SliceStart { uint32_t s = 0, g = 0, t = 0, a = 0; } slice_start[OW_MAX_SLICES + 1];   // entry offsets of every slice in the three lists
+    struct SliceStart { uint32_t s = 0, g = 0, t = 0, a = 0; uint64_t h[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}; } slice_start[OW_MAX_SLICES + 1];   // entry offsets of every slice in the four lists (h: pass-1 hashes of a slice, unused in the stored copy)
     hipStream_t pipe_stream[OW_MAX_STAGES] = {};               // [0] == stream
     hipEvent_t ev_ready = nullptr, ev_voice_done[OW_MAX_STAGES] = {}, ev_stage_done[OW_MAX_STAGES] = {};
     hipEvent_t ev_stage[OW_MAX_STAGES][5] = {};                // profiling: before voices, after voices, before preamp, after preamp, after post
@@ -424,6 +426,7 @@ struct ow_pool {
     Switches sw;                      // latched at creation
     bool voices_only = false;         // ow_render_note: the pool renders voice sums only -- no chain state, no tremolo / preamp / output kernels
     int inject_faults = 0;            // test hook (openwurli_hip_test.h): the next n renders fail before their first launch
+    bool steal_counted = false;       // the block in flight had its steal fades counted down while its kernels ran (steal_countdown_early)
     double hostprof_acc[4] = {0, 0, 0, 0};
     long hostprof_cnt = 0;
     bool profiling = false;
@@ -1320,13 +1323,21 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
     Fill* start = p->slice_start;                              // T <= 32; kept: stage k launches the blocks of its slices
     start[0] = Fill();
     p->slice_T = (int)T; p->slice_per = per;
-    auto pack = [&](size_t t, uint32_t* S, uint32_t* G, uint32_t* Tl, uint32_t* A, Fill& f) {   // S == nullptr: count only
+    auto pack = [&](size_t t, uint32_t* S, uint32_t* G, uint32_t* Tl, uint32_t* A, Fill& f) {   // a null list: count (and hash) only
         auto pad = [](uint32_t* a, uint32_t& n) { while (n & 63u) { if (a) a[n] = 0xFFFFFFFFu; ++n; } };
-        auto put = [&](uint32_t* a, uint32_t& n, uint32_t e, uint64_t mask, bool own_block) {
+        auto put_l = [&](int list, uint32_t* a, uint32_t& n, uint32_t e, uint64_t mask, bool own_block) {
             const uint32_t pc = (uint32_t)__builtin_popcountll(mask);
             if (own_block || (n & 63u) + pc > 64u) pad(a, n);
             if (a) for (uint64_t m = mask; m; m &= m - 1) a[n++] = (e << 6) | (uint32_t)__builtin_ctzll(m);
-            else n += pc;
+            else {
+                n += pc;
+                uint64_t* h = f.h[list];
+                h[0] = (h[0] ^ ((uint64_t)e * 0x9E3779B97F4A7C15ull + mask)) * 0xFF51AFD7ED558CCDull;
+                h[1] = (h[1] + mask * 0xC2B2AE3D27D4EB4Full + e) * 0x9FB21C651E98DF25ull + (h[1] >> 29);
+            }
+        };
+        auto put = [&](uint32_t* a, uint32_t& n, uint32_t e, uint64_t mask, bool own_block) {
+            put_l(&n == &f.s ? 0 : (&n == &f.g ? 1 : (&n == &f.t ? 2 : 3)), a, n, e, mask, own_block);
         };
         const int k1 = std::min(ne, (int)(t + 1) * per);
         for (int k = (int)t * per; k < k1; ++k) {
@@ -1350,18 +1361,33 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
     auto pass1 = [&](size_t t) { pack(t, nullptr, nullptr, nullptr, nullptr, size[t]); };
     Workers::get().each(T, pass1);
     for (size_t t = 0; t < T; ++t) { start[t + 1].s = start[t].s + size[t].s; start[t + 1].g = start[t].g + size[t].g; start[t + 1].t = start[t].t + size[t].t; start[t + 1].a = start[t].a + size[t].a; }
+    const uint32_t fs = start[T].s, fg = start[T].g, fl = start[T].t, fa = start[T].a;
+    // a list whose (engine, mask) sequence, slices and range are the ones its device copy was packed from is left alone: after a
+    // whole-pool re-strike the attack and steal lists of the 128-sample sub-block serve the next block(s) as they are
+    ow_pool::VoiceList* const vls[4] = {&p->vl_steady, &p->vl_general, &p->vl_steal, &p->vl_attack};
+    const uint32_t fill[4] = {fs, fg, fl, fa};
+    bool keep[4];
+    for (int l = 0; l < 4; ++l) {
+        uint64_t sig[3] = {0x243F6A8885A308D3ull ^ (uint64_t)T, 0x13198A2E03707344ull ^ (uint64_t)per, ((uint64_t)(uint32_t)e0 << 32) | (uint32_t)ne};
+        for (size_t t = 0; t < T; ++t) {
+            const uint32_t n_t = l == 0 ? size[t].s : (l == 1 ? size[t].g : (l == 2 ? size[t].t : size[t].a));
+            sig[0] = (sig[0] * 0x100000001B3ull) ^ size[t].h[l][0] ^ ((uint64_t)n_t << 17);
+            sig[1] = (sig[1] * 0xD6E8FEB86659FD93ull) + size[t].h[l][1] + n_t;
+        }
+        ow_pool::VoiceList& vl = *vls[l];
+        keep[l] = fill[l] != 0 && vl.sig_valid && vl.n_blocks == fill[l] / 64 && vl.sig[0] == sig[0] && vl.sig[1] == sig[1] && vl.sig[2] == sig[2];
+        vl.sig[0] = sig[0]; vl.sig[1] = sig[1]; vl.sig[2] = sig[2]; vl.sig_valid = fill[l] != 0;
+        vl.n_blocks = fill[l] / 64;
+    }
     auto pass2 = [&](size_t t) {
         Fill f;   // slice-local counters: the slice regions start on block boundaries, so padding decisions match pass 1
-        pack(t, p->vl_steady.h + start[t].s, p->vl_general.h + start[t].g, p->vl_steal.h + start[t].t, p->vl_attack.h + start[t].a, f);
+        pack(t, keep[0] ? nullptr : p->vl_steady.h + start[t].s, keep[1] ? nullptr : p->vl_general.h + start[t].g,
+             keep[2] ? nullptr : p->vl_steal.h + start[t].t, keep[3] ? nullptr : p->vl_attack.h + start[t].a, f);
     };
-    Workers::get().each(T, pass2);
-    const uint32_t fs = start[T].s, fg = start[T].g, fl = start[T].t, fa = start[T].a;
-    p->vl_steady.n_blocks = fs / 64; p->vl_general.n_blocks = fg / 64; p->vl_steal.n_blocks = fl / 64; p->vl_attack.n_blocks = fa / 64;
+    if (!((keep[0] || !fs) && (keep[1] || !fg) && (keep[2] || !fl) && (keep[3] || !fa))) Workers::get().each(T, pass2);
     hipStream_t st = p->stream;
-    if (fs) HIP_OK(hipMemcpyAsync(p->vl_steady.d, p->vl_steady.h, sizeof(uint32_t) * fs, hipMemcpyHostToDevice, st));
-    if (fg) HIP_OK(hipMemcpyAsync(p->vl_general.d, p->vl_general.h, sizeof(uint32_t) * fg, hipMemcpyHostToDevice, st));
-    if (fl) HIP_OK(hipMemcpyAsync(p->vl_steal.d, p->vl_steal.h, sizeof(uint32_t) * fl, hipMemcpyHostToDevice, st));
-    if (fa) HIP_OK(hipMemcpyAsync(p->vl_attack.d, p->vl_attack.h, sizeof(uint32_t) * fa, hipMemcpyHostToDevice, st));
+    for (int l = 0; l < 4; ++l)
+        if (fill[l] && !keep[l]) HIP_OK(hipMemcpyAsync(vls[l]->d, vls[l]->h, sizeof(uint32_t) * fill[l], hipMemcpyHostToDevice, st));
     p->lists_e0 = e0; p->lists_ne = ne;
 }
 
@@ -1731,16 +1757,22 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
 
 // host bookkeeping of ONE engine after a block: steal-fade countdown (engine.rs:490-493), NaN-guard frees (engine.rs:499-521,
 // culprits identified in the same pass) and cleanup_voices (engine.rs:592-602)
-void engine_post_render(ow_engine* en, uint32_t l32, const OwEngineOut& o) {
+// slot.steal_fade.saturating_sub(len) and the drop of a steal voice whose crossfade has ended (engine.rs:490-493): needs nothing from the
+// block's status, so a whole-pool render does it for every engine while the kernels run (steal_countdown_early) instead of after them
+void engine_steal_countdown(ow_engine* en, uint32_t l32) {
+    OwVm& v = *en->vm;
+    if (!v.steal_mask) return;
+    vm_host_changed(en);
+    for (uint64_t m = v.steal_mask; m; m &= m - 1) {
+        const int s = __builtin_ctzll(m);
+        v.steal_fade[s] = v.steal_fade[s] > l32 ? v.steal_fade[s] - l32 : 0u;
+        if (v.steal_fade[s] == 0) { v.has_steal &= ~(1ull << s); en->sync_masks(s); }
+    }
+}
+void engine_post_render(ow_engine* en, uint32_t l32, const OwEngineOut& o, bool steal_counted = false) {
     OwVm& v = *en->vm;
     vm_host_changed(en);
-    if (v.steal_mask) {
-        for (uint64_t m = v.steal_mask; m; m &= m - 1) {
-            const int s = __builtin_ctzll(m);
-            v.steal_fade[s] = v.steal_fade[s] > l32 ? v.steal_fade[s] - l32 : 0u;
-            if (v.steal_fade[s] == 0) { v.has_steal &= ~(1ull << s); en->sync_masks(s); }
-        }
-    }
+    if (!steal_counted) engine_steal_countdown(en, l32);
     if (o.sum_nonfinite) {
         en->nan_guard_fires += 1;
         for (int s = 0; s < OW_MAX_VOICES; ++s) {
@@ -1792,6 +1824,7 @@ void guard_second_pass(ow_pool* p, const uint32_t* engs, size_t n_eng, size_t le
         put(p->vl_steal.h, ns, en->vm->steal_mask);
     }
     p->lists_valid = false;           // the list buffers were borrowed
+    p->vl_general.sig_valid = false; p->vl_steal.sig_valid = false;
     // the guarded engines' status blocks: ONE clear, ONE gather and ONE transfer for the whole set (a bad parameter broadcast to a big
     // pool can put every engine here: 131 072 engines used to mean 262 144 runtime calls on the audio thread).  engs is pinned
     // (h_op_engines) and d_op_engines is free between renders.
@@ -1821,9 +1854,30 @@ void guard_second_pass(ow_pool* p, const uint32_t* engs, size_t n_eng, size_t le
 }
 
 // host bookkeeping after the block has been rendered (needs h_eout; call after stream sync)
+// The steal-fade countdown of a whole-pool block while its kernels run (ow_pool_render, between the launches and the stream sync).
+// After a whole-pool re-strike that is 64 counters and masks per engine over 120 MB of state: 2-3 ms on sixteen threads, GPU idle, when
+// done after the block.  post_render_host then skips it (p->steal_counted).
+void steal_countdown_early(ow_pool* p, size_t len) {
+    p->steal_counted = false;
+    const int ne = (int)p->I;
+    if (!p->any_steal_c || !p->any_cache_valid || ne < 16384) return;
+    const uint32_t l32 = (uint32_t)std::min<size_t>(len, 0xFFFFFFFFull);
+    const size_t T = std::min<size_t>(effective_cpus(), 32);
+    const int per = (int)((ne + T - 1) / T);
+    auto slice = [&](size_t t) {
+        const int k1 = std::min(ne, (int)(t + 1) * per);
+        for (int k = (int)t * per; k < k1; ++k)
+            if (p->h_args[k].steal_mask) engine_steal_countdown(p->engines[k], l32);
+    };
+    Workers::get().each(T, slice);
+    p->steal_counted = true;
+}
+
 void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
     if (p->skew_pending) { p->skew_pending = false; p->skew_next = *p->h_skew_seen != 0u; }
     const uint32_t l32 = (uint32_t)std::min<size_t>(len, 0xFFFFFFFFull);
+    const bool steal_counted = p->steal_counted;
+    p->steal_counted = false;
     // what one engine's status block asks of the host; returns bit 0 = the voice lists changed, bit 1 = misdispatch, bit 2 = voice-sum guard
     auto one = [&](int e) -> uint8_t {
         const OwEngineOut& o = p->h_eout[e];
@@ -1833,9 +1887,9 @@ void post_render_host(ow_pool* p, int e0, int ne, size_t len) {
         const uint8_t tr = o.transient != 0u;
         if (tr != p->transient[e]) { p->transient[e] = tr; r |= 1; }
         // fast path on the contiguous status/args arrays: nothing to book-keep for this engine
-        if (!a.steal_mask && !(o.silent_mask & a.main_mask) && !o.sum_nonfinite && !o.out_nonfinite) return r;
+        if ((steal_counted || !a.steal_mask) && !(o.silent_mask & a.main_mask) && !o.sum_nonfinite && !o.out_nonfinite) return r;
         if (o.sum_nonfinite) r |= 4;
-        engine_post_render(p->engines[e], l32, o);
+        engine_post_render(p->engines[e], l32, o, steal_counted);
         return r;
     };
     auto second_pass = [&] {   // voice-sum NaN guard fired somewhere: the reference's second render pass for those engines
@@ -2254,6 +2308,7 @@ void ow_pool_render(ow_pool* p, float* out_host, size_t out_stride, size_t len) 
         const bool hostprof = p->sw.host_profile;
         auto t0 = std::chrono::steady_clock::now();
         render_range(p, 0, (int)p->I, len, true, out_host, out_stride);
+        steal_countdown_early(p, len);
         auto t1 = std::chrono::steady_clock::now();
         HIP_OK(hipStreamSynchronize(p->stream));
         auto t2 = std::chrono::steady_clock::now();
@@ -2274,7 +2329,7 @@ void ow_pool_render(ow_pool* p, float* out_host, size_t out_stride, size_t len) 
     if (!ok) {
         // queued note events / setter targets of engines the failed render did not get to pack must survive: the next block scans again
         __atomic_store_n(&p->dirty_any, (uint8_t)1, __ATOMIC_RELAXED);
-        p->args_stale = true; p->lists_valid = false;
+        p->args_stale = true; p->lists_valid = false; p->steal_counted = false;
         // "never fails, degrades to silence" (engine.rs:450-458 does the same for numeric failure): every row of the
         // caller's block is written.  Drain the stream first so that an output copy already queued cannot land after the zeros.
         for (int k = 0; k < OW_MAX_STAGES; ++k) if (p->pipe_stream[k]) hipStreamSynchronize(p->pipe_stream[k]);
