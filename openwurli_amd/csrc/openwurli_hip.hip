@@ -210,6 +210,7 @@ struct Switches {
     int eout_attn = -1;                        // OW_EOUT_ATTN=0/1: status summary instead of the status blocks (k_eout_attention); -1: ranges of >= 8 192 engines
     int pipe = 0;                              // OW_PIPE=n stages
     int midi_device = -1;                      // OW_MIDI_DEVICE=0/1: bursts of ow_pool_midi applied on the device (k_vm_events) never / whenever the list allows; -1: pools of >= 8 192 engines, >= 65 536 events
+    int midi_apply_early = 1;                  // OW_MIDI_APPLY_EARLY=0: the queues of a device burst wait for the next render's k_apply_ops
     int voice_steal = 1;                       // OW_VOICE_STEAL=0: no steal variant of the steady voice kernel (k_voice renders every crossfade)
     int voice_attack = 1;                      // OW_VOICE_ATTACK=0: no attack variant of the steady voice kernel (engines in onset / noise phases go to the general kernel)
     bool force_general = false;                // test / probe hook: every engine's slot voices go to the general voice kernel (what it costs without any phase active)
@@ -238,6 +239,7 @@ struct Switches {
         w.pipe_overlap = flag("OW_PIPE_OVERLAP", 0) == 1;
         w.voice_attack = flag("OW_VOICE_ATTACK", 1) != 0;
         w.voice_steal = flag("OW_VOICE_STEAL", 1) != 0;
+        w.midi_apply_early = flag("OW_MIDI_APPLY_EARLY", 1) != 0;
         w.midi_device = flag("OW_MIDI_DEVICE", -1); if (w.midi_device > 1 || w.midi_device < -1) w.midi_device = -1;
         w.chain_stream = flag("OW_CHAIN_STREAM", -1); if (w.chain_stream > 1 || w.chain_stream < -1) w.chain_stream = -1;
         w.out_direct = flag("OW_OUT_DIRECT", -1); if (w.out_direct > 1 || w.out_direct < -1) w.out_direct = -1;
@@ -366,6 +368,12 @@ struct ow_pool {
     uint32_t* h_vm_ovf = nullptr;     // pinned
     bool vm_download_pending = false; // d_vm -> h_vm is in flight (ev_vm)
     hipEvent_t ev_vm = nullptr;
+    hipEvent_t ev_vm_events = nullptr;   // k_vm_events of the last burst has finished (the download waits for it on its own stream)
+    // The last burst's queues were applied at once (k_apply_ops launched by ow_pool_midi, beside the download of the states): the engines
+    // of [applied_lo, applied_hi) whose downloaded state still says "n_dev_ops queued" have nothing queued any more -- vm_wait_download
+    // settles that on the host's copy and marks them as inside a note-on's phases for the next block's dispatch.
+    bool dev_ops_applied = false;
+    uint32_t applied_lo = 0, applied_hi = 0;
     bool dev_ops_pending = false;     // some engine's next ops sit in d_ops_fix
     uint64_t vm_bursts = 0;           // bursts that went through the device (test hook)
     struct OpTail { uint32_t src, dst, n; };   // host-queued ops of an engine that also has device-queued ones: appended on the device
@@ -439,8 +447,9 @@ namespace {
 
 // The host mirror of the voice-pool states is current (a burst applied on the device is copied back asynchronously: wait for it), and
 // the host is about to change / has changed one of them (the device copy is stale until the next burst uploads them again).
+void vm_settle_applied(ow_pool* p);
 void vm_wait_download(ow_pool* p) {
-    if (p && p->vm_download_pending) { hipEventSynchronize(p->ev_vm); p->vm_download_pending = false; }
+    if (p && p->vm_download_pending) { hipEventSynchronize(p->ev_vm); p->vm_download_pending = false; if (p->dev_ops_applied) vm_settle_applied(p); }
 }
 void vm_host_current(const ow_engine* e) { if (e && e->pool) vm_wait_download(e->pool); }
 void vm_host_changed(ow_engine* e) { if (e && e->pool && !__atomic_load_n(&e->pool->vm_host_dirty, __ATOMIC_RELAXED)) __atomic_store_n(&e->pool->vm_host_dirty, (uint8_t)1, __ATOMIC_RELAXED); }
@@ -1282,6 +1291,22 @@ static size_t effective_cpus() {
 }
 size_t Workers::host_threads() { return std::min<size_t>(effective_cpus(), OW_MAX_SLICES); }
 
+// see ow_pool::dev_ops_applied
+void vm_settle_applied(ow_pool* p) {
+    p->dev_ops_applied = false;
+    const uint32_t lo = p->applied_lo, hi = p->applied_hi;
+    const size_t T = hi - lo >= 16384 ? std::min<size_t>(effective_cpus(), 32) : 1;
+    const uint32_t per = (uint32_t)((hi - lo + T - 1) / T);
+    auto slice = [&](size_t t) {
+        const uint32_t k1 = std::min(hi, lo + (uint32_t)(t + 1) * per);
+        for (uint32_t e = lo + (uint32_t)t * per; e < k1; ++e)
+            if (p->h_vm[e].n_dev_ops) { p->h_vm[e].n_dev_ops = 0u; p->transient[e] = 1; }
+    };
+    Workers::get().each(T, slice);
+    p->lists_valid = false;
+    if (p->d_prev_tr) p->attn_resync = true;      // p->transient moved without the device's copy
+}
+
 // Melange preamp: the default kernel re-factors the 12x12 system for every sample whose R_ldr moved, operation for operation like the
 // reference (ow_melange_col.h).  OW_MEL_RANK1=1 selects the rank-one (Sherman-Morrison) kernel instead: mathematically the same, but
 // without the LU's rounding noise, i.e. up to 1.8e-7 V away from the reference while R_ldr moves fast (DESIGN.md deviation 6);
@@ -2047,6 +2072,7 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     HIP_OK(hipHostMalloc(&p->h_args, sizeof(OwEngineArgs) * n_engines));
     HIP_OK(hipHostMalloc(&p->h_vm, sizeof(OwVm) * n_engines));
     HIP_OK(hipEventCreateWithFlags(&p->ev_vm, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&p->ev_vm_events, hipEventDisableTiming));
     HIP_OK(hipHostMalloc(&p->h_eout, sizeof(OwEngineOut) * n_engines));
     HIP_OK(hipMalloc(&p->d_eout_packed, sizeof(OwEngineOut) * n_engines));
     HIP_OK(hipHostMalloc(&p->h_eout_packed, sizeof(OwEngineOut) * n_engines));
@@ -2198,6 +2224,7 @@ void pool_destroy(ow_pool* p) {
     if (p->d_vm_ovf) hipFree(p->d_vm_ovf);
     if (p->h_vm_ovf) hipHostFree(p->h_vm_ovf);
     if (p->ev_vm) hipEventDestroy(p->ev_vm);
+    if (p->ev_vm_events) hipEventDestroy(p->ev_vm_events);
     if (p->d_eout_packed) hipFree(p->d_eout_packed);
     if (p->h_eout_packed) hipHostFree(p->h_eout_packed);
     if (p->d_skew_seen) hipFree(p->d_skew_seen);
@@ -2661,29 +2688,43 @@ static bool midi_burst_on_device(ow_pool* p, const ow_midi_event* ev, size_t n) 
     }
     vm_wait_download(p);
     const uint32_t e_lo = std::min<uint32_t>(ev[0].engine, (uint32_t)I), e_hi = std::min<uint32_t>(ev[n - 1].engine + 1u, (uint32_t)I);
-    if (e_lo >= e_hi) return true;                                 // nothing addressed to this pool
+    if (e_lo >= e_hi) return false;                                // nothing addressed to this pool -- if the list is grouped, which only the host path checks here
     if (p->vm_host_dirty) {
         HIP_OK(hipMemcpyAsync(p->d_vm, p->h_vm, sizeof(OwVm) * I, hipMemcpyHostToDevice, st));
         p->vm_host_dirty = 0;
     }
     HIP_OK(hipMemcpyAsync(p->d_ev, src, sizeof(ow_midi_event) * n, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemsetAsync(p->d_ev_begin, 0, sizeof(uint32_t) * 2 * I, st));
-    owdev::k_vm_index<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(p->d_ev, n, p->d_ev_begin, p->d_ev_begin + I, (uint32_t)I);
-    const uint32_t fade = owhip::sat_u32(p->engines[0]->sr * 0.005);
     HIP_OK(hipMemsetAsync(p->d_vm_ovf, 0, sizeof(uint32_t), st));
+    owdev::k_vm_index<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(p->d_ev, n, p->d_ev_begin, p->d_ev_begin + I, (uint32_t)I, p->d_vm_ovf);
+    const uint32_t fade = owhip::sat_u32(p->engines[0]->sr * 0.005);
     owdev::k_vm_events<<<dim3((e_hi - e_lo + 63) / 64), dim3(64), 0, st>>>(p->d_vm, p->d_ev, p->d_ev_begin, p->d_ev_begin + I, p->d_ops_fix, e_lo, e_hi, fade, p->d_vm_ovf);
     HIP_OK(hipGetLastError());
-    // a queue that overflowed (more than OW_VM_OPS_MAX slot ops for one engine between two renders) lost ops: nothing of this burst is
-    // kept -- the host's copy of the states is still the one from before it -- and the host path replays it
+    // a queue that overflowed (more than OW_VM_OPS_MAX slot ops for one engine between two renders) lost ops, a list that is not grouped
+    // by engine (bit 1, k_vm_index) was cut into meaningless slices: nothing of this burst is kept -- the host's copy of the states is
+    // still the one from before it -- and the host path replays it
     HIP_OK(hipMemcpyAsync(p->h_vm_ovf, p->d_vm_ovf, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipEventRecord(p->ev_vm_events, st));
     HIP_OK(hipStreamSynchronize(st));
     if (*p->h_vm_ovf) { p->vm_host_dirty = 1; return false; }
-    HIP_OK(hipMemcpyAsync(p->h_vm + e_lo, p->d_vm + e_lo, sizeof(OwVm) * (e_hi - e_lo), hipMemcpyDeviceToHost, st));
-    HIP_OK(hipEventRecord(p->ev_vm, st));
+    // the states come back on a stream of their own (126 MB for 131 072 engines, 2.3 ms), and the queues are applied AT ONCE beside that
+    // (Voice::note_on builds its voice when it is called, voice.rs:28-110; the next render used to start with this launch): the 14.5 ms
+    // of a whole-pool re-strike's k_apply_ops now cover the download and the host's packing, scanning and list building for the block
+    // that follows.  Ops the host had queued before the burst keep it off this path altogether (above); ops it queues afterwards are
+    // applied by the next render, behind these, as before.
+    hipStream_t sc = p->pipe_stream[1] ? p->pipe_stream[1] : st;
+    if (sc != st) HIP_OK(hipStreamWaitEvent(sc, p->ev_vm_events, 0));
+    HIP_OK(hipMemcpyAsync(p->h_vm + e_lo, p->d_vm + e_lo, sizeof(OwVm) * (e_hi - e_lo), hipMemcpyDeviceToHost, sc));
+    HIP_OK(hipEventRecord(p->ev_vm, sc));
     p->vm_download_pending = true;
     std::memset(p->dirty.data() + e_lo, 1, e_hi - e_lo);           // masks / queues of these engines changed: the next render packs them
     __atomic_store_n(&p->dirty_any, (uint8_t)1, __ATOMIC_RELAXED);
-    p->dev_ops_pending = true;
+    if (p->sw.midi_apply_early && sc != st) {
+        owdev::k_apply_ops<<<dim3(e_hi - e_lo), dim3(64), 0, st>>>(p->dK, p->d_nt, p->d_vrec, nullptr, nullptr, nullptr, p->d_ops_fix, p->d_vm, (int)e_lo);
+        owdev::k_vm_clear_dev_ops<<<dim3((e_hi - e_lo + 255) / 256), dim3(256), 0, st>>>(p->d_vm, e_lo, e_hi);
+        HIP_OK(hipGetLastError());
+        p->dev_ops_applied = true; p->applied_lo = e_lo; p->applied_hi = e_hi;
+    } else p->dev_ops_pending = true;
     p->vm_bursts += 1;
     return true;
 }
@@ -2697,14 +2738,12 @@ void ow_pool_midi(ow_pool* p, const ow_midi_event* ev, size_t n) {
     if (n < 4096 || p->I < 2 * T) T = 1;
     vm_wait_download(p);
     const bool want_device = n > 0 && !p->voices_only && (p->sw.midi_device == 1 || (p->sw.midi_device < 0 && p->I >= 8192 && n >= 65536));
+    if (want_device) {     // (whether the list is grouped by engine is checked on the device too: no walk over 200 MB of events here)
+        bool done = false;
+        guarded("ow_pool_midi (device burst)", [&] { done = midi_burst_on_device(p, ev, n); });
+        if (done) return;
+    }
     if (T == 1) {
-        if (want_device) {
-            bool grouped1 = true;
-            for (size_t i = 1; i < n && grouped1; ++i) grouped1 = ev[i].engine >= ev[i - 1].engine;
-            bool done = false;
-            if (grouped1) guarded("ow_pool_midi (device burst)", [&] { done = midi_burst_on_device(p, ev, n); });
-            if (done) return;
-        }
         for (size_t i = 0; i < n; ++i) if (ev[i].engine < p->I) midi_apply_one(p, ev[i]);
         return;
     }
@@ -2721,11 +2760,6 @@ void ow_pool_midi(ow_pool* p, const ow_midi_event* ev, size_t n) {
     Workers::get().each(T, verify);
     bool grouped = true;
     for (size_t t = 0; t < T; ++t) grouped = grouped && ok[t];
-    if (grouped && want_device) {
-        bool done = false;
-        guarded("ow_pool_midi (device burst)", [&] { done = midi_burst_on_device(p, ev, n); });
-        if (done) return;
-    }
     if (grouped) {
         size_t cut[OW_MAX_SLICES + 1];
         cut[0] = 0; cut[T] = n;
@@ -2994,6 +3028,7 @@ int ow_test_pool_set_switch(ow_pool* p, const char* name, int value) {
     else if (n == "midi_device") w.midi_device = value < 0 ? -1 : (value != 0);
     else if (n == "voice_attack") { w.voice_attack = value != 0; p->lists_valid = false; }
     else if (n == "voice_steal") w.voice_steal = value != 0;
+    else if (n == "midi_apply_early") w.midi_apply_early = value != 0;
     else if (n == "force_general") { w.force_general = value != 0; p->lists_valid = false; }
     else if (n == "chain_stream") w.chain_stream = value < 0 ? -1 : (value != 0);
     else return -1;                                       // (trem_traj / trem_cache / pipe shape the pool at creation: environment only)
@@ -3021,6 +3056,7 @@ int ow_test_pool_get_switch(const ow_pool* p, const char* name) {
     if (n == "midi_device") return w.midi_device;
     if (n == "voice_attack") return w.voice_attack;
     if (n == "voice_steal") return w.voice_steal;
+    if (n == "midi_apply_early") return w.midi_apply_early;
     if (n == "blocks_steady") return (int)p->vl_steady.n_blocks;   // wavefront blocks of the voice lists the last render launched
     if (n == "blocks_general") return (int)p->vl_general.n_blocks;
     if (n == "blocks_attack") return (int)p->vl_attack.n_blocks;

@@ -9,6 +9,7 @@
 // All global traffic is coalesced: voice records are field-major [field][64 slots], chain state and the
 // R / preamp streams are engine-minor [..][I]; engine-major audio rows are transposed through LDS tiles.
 #pragma once
+#include "ow_vm.h"
 #include "ow_chain_dev.h"
 
 namespace owdev {
@@ -61,11 +62,16 @@ __device__ inline void mlp_raw_mfma(double* __restrict__ h, double in0, double i
 // tremolo wavefront on a SIMD, so the block-ahead oscillator can be launched before the host has prepared the ops.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_apply_ops(const OwConsts* __restrict__ K, const double* __restrict__ nt, double* __restrict__ vrec,
                                                   const OwEngineArgs* __restrict__ args, const OwOp* __restrict__ ops_packed,
-                                                  const uint32_t* __restrict__ engines, const OwOp* __restrict__ ops_fixed = nullptr) {
+                                                  const uint32_t* __restrict__ engines, const OwOp* __restrict__ ops_fixed = nullptr,
+                                                  const OwVm* __restrict__ vm = nullptr, int e_base = 0) {
     __shared__ double h[64 * 17];
-    const int e = (int)engines[blockIdx.x];
+    // vm != nullptr: the launch of ow_pool_midi's device burst itself -- block b is engine e_base + b, its queue is the one k_vm_events
+    // just wrote at the engine's fixed place (vm[e].n_dev_ops entries); no args, no engine list
+    const int e = vm ? e_base + (int)blockIdx.x : (int)engines[blockIdx.x];
     const int lane = threadIdx.x;
-    OwEngineArgs a = args[e];
+    OwEngineArgs a;
+    if (vm) { a.op_count = vm[e].n_dev_ops; a.op_begin = 0x80000000u | (uint32_t)(e * OW_VM_OPS_MAX); }
+    else a = args[e];
     if (a.op_count == 0) return;
     // bit 31 of op_begin: the queue was written on the device (k_vm_events) at the engine's fixed place, not packed and uploaded by the host
     const OwOp* __restrict__ ops = (a.op_begin & 0x80000000u) ? ops_fixed : ops_packed;

@@ -7,10 +7,14 @@
 namespace owdev {
 
 // begin[e] / end[e]: slice of engine e in the list (both 0 for an engine without events; the arrays are cleared before the launch)
-__global__ void k_vm_index(const ow_midi_event* __restrict__ ev, size_t n, uint32_t* __restrict__ begin, uint32_t* __restrict__ end, uint32_t I) {
+// flags |= 2 when the list is not grouped by engine (an event whose engine index is below its predecessor's): the slices are then
+// meaningless and the host drops the burst (it checks the word together with the queue-overflow bit)
+__global__ void k_vm_index(const ow_midi_event* __restrict__ ev, size_t n, uint32_t* __restrict__ begin, uint32_t* __restrict__ end, uint32_t I,
+                           uint32_t* __restrict__ flags) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t e = ev[i].engine;
+    if (i > 0 && ev[i - 1].engine > e) atomicOr(flags, 2u);
     if (e >= I) return;                                            // events for engines the pool does not have are ignored (as on the host)
     if (i == 0 || ev[i - 1].engine != e) begin[e] = (uint32_t)i;
     if (i + 1 == n || ev[i + 1].engine != e) end[e] = (uint32_t)(i + 1);
@@ -46,6 +50,12 @@ __global__ __launch_bounds__(64) void k_vm_events(OwVm* __restrict__ vm, const o
     }
     v.n_dev_ops = sink.n;
     if (sink.overflow) { v.dev_overflow = 1; atomicOr(overflow, 1u); }
+}
+
+// after the queues of a burst have been applied right away (k_apply_ops launched by ow_pool_midi itself): they are empty again
+__global__ void k_vm_clear_dev_ops(OwVm* __restrict__ vm, uint32_t e_lo, uint32_t e_hi) {
+    const uint32_t e = e_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < e_hi) vm[e].n_dev_ops = 0u;
 }
 
 }  // namespace owdev
