@@ -369,6 +369,12 @@ struct ow_pool {
     bool vm_download_pending = false; // d_vm -> h_vm is in flight (ev_vm)
     hipEvent_t ev_vm = nullptr;
     hipEvent_t ev_vm_events = nullptr;   // k_vm_events of the last burst has finished (the download waits for it on its own stream)
+    // Once a pool has taken a burst on the device, the host's copy of the states goes up again in the BACKGROUND whenever a block's
+    // book-keeping has changed it (end of ow_pool_render, copy stream, beside the next block's kernels): the next burst then finds the
+    // device's copy current instead of starting with 126 MB of upload.  A host change while that copy is in flight sets vm_host_dirty
+    // again (vm_host_changed comes first), and the burst uploads as before.
+    hipEvent_t ev_vm_up = nullptr;
+    bool vm_upload_inflight = false;
     // The last burst's queues were applied at once (k_apply_ops launched by ow_pool_midi, beside the download of the states): the engines
     // of [applied_lo, applied_hi) whose downloaded state still says "n_dev_ops queued" have nothing queued any more -- vm_wait_download
     // settles that on the host's copy and marks them as inside a note-on's phases for the next block's dispatch.
@@ -2073,6 +2079,7 @@ ow_pool* pool_create(double sample_rate, size_t n_engines, int device, int pream
     HIP_OK(hipHostMalloc(&p->h_vm, sizeof(OwVm) * n_engines));
     HIP_OK(hipEventCreateWithFlags(&p->ev_vm, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&p->ev_vm_events, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&p->ev_vm_up, hipEventDisableTiming));
     HIP_OK(hipHostMalloc(&p->h_eout, sizeof(OwEngineOut) * n_engines));
     HIP_OK(hipMalloc(&p->d_eout_packed, sizeof(OwEngineOut) * n_engines));
     HIP_OK(hipHostMalloc(&p->h_eout_packed, sizeof(OwEngineOut) * n_engines));
@@ -2225,6 +2232,7 @@ void pool_destroy(ow_pool* p) {
     if (p->h_vm_ovf) hipHostFree(p->h_vm_ovf);
     if (p->ev_vm) hipEventDestroy(p->ev_vm);
     if (p->ev_vm_events) hipEventDestroy(p->ev_vm_events);
+    if (p->ev_vm_up) hipEventDestroy(p->ev_vm_up);
     if (p->d_eout_packed) hipFree(p->d_eout_packed);
     if (p->h_eout_packed) hipHostFree(p->h_eout_packed);
     if (p->d_skew_seen) hipFree(p->d_skew_seen);
@@ -2342,6 +2350,13 @@ void ow_pool_render(ow_pool* p, float* out_host, size_t out_stride, size_t len) 
         post_render_host(p, 0, (int)p->I, len);
         auto t3 = std::chrono::steady_clock::now();
         collect_profile(p);
+        if (p->d_vm && p->vm_bursts && p->vm_host_dirty && p->pipe_stream[1] && !p->vm_download_pending) {   // see ow_pool::ev_vm_up
+            if (p->vm_upload_inflight) HIP_OK(hipStreamWaitEvent(p->pipe_stream[1], p->ev_vm_up, 0));
+            __atomic_store_n(&p->vm_host_dirty, (uint8_t)0, __ATOMIC_RELAXED);
+            HIP_OK(hipMemcpyAsync(p->d_vm, p->h_vm, sizeof(OwVm) * p->I, hipMemcpyHostToDevice, p->pipe_stream[1]));
+            HIP_OK(hipEventRecord(p->ev_vm_up, p->pipe_stream[1]));
+            p->vm_upload_inflight = true;
+        }
         auto t4 = std::chrono::steady_clock::now();
         if (hostprof) {
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -2689,6 +2704,7 @@ static bool midi_burst_on_device(ow_pool* p, const ow_midi_event* ev, size_t n) 
     vm_wait_download(p);
     const uint32_t e_lo = std::min<uint32_t>(ev[0].engine, (uint32_t)I), e_hi = std::min<uint32_t>(ev[n - 1].engine + 1u, (uint32_t)I);
     if (e_lo >= e_hi) return false;                                // nothing addressed to this pool -- if the list is grouped, which only the host path checks here
+    if (p->vm_upload_inflight) { HIP_OK(hipStreamWaitEvent(st, p->ev_vm_up, 0)); p->vm_upload_inflight = false; }
     if (p->vm_host_dirty) {
         HIP_OK(hipMemcpyAsync(p->d_vm, p->h_vm, sizeof(OwVm) * I, hipMemcpyHostToDevice, st));
         p->vm_host_dirty = 0;

@@ -303,8 +303,10 @@ def test_midi_burst_on_device_equals_the_host_state_machine(hiplib):
     and re-strikes, repeated keys, out-of-range keys, more notes than slots (steals of releasing, sustained and held voices), the pedal down
     / up with sustained voices to damp, single events between a burst and its render (their ops queue behind the device's), single
     events BEFORE a burst (the burst then stays on the host: queue order), two bursts before one render, a burst whose ops overflow an
-    engine's fixed queue (replayed on the host), reset of one engine.  Slot states, notes, steal voices, voice counts and every rendered
-    sample are identical."""
+    engine's fixed queue (replayed on the host), reset of one engine, a list that is NOT grouped by engine (found out on the device, replayed
+    on the host).  The device applies a burst's queues at once, beside the download of the states (`midi_apply_early`); with that off they
+    wait for the next render's k_apply_ops.  Slot states, notes, steal voices, voice counts and every rendered sample are identical in
+    all three."""
     import openwurli_amd as ow
     from openwurli_amd import binding
     n = 96
@@ -332,10 +334,10 @@ def test_midi_burst_on_device_equals_the_host_state_machine(hiplib):
             rows += [(e, t, k, 0, v) for t, k, v in ev]
         return np.array(rows, dtype=np.dtype(binding.MIDI_DTYPE))
 
-    def run(device):
+    def run(device, early=1):
         g = ow.EnginePool(48000.0, n)
         g.set_sample_rate(48000.0)
-        g.set_switch("midi_device", device)
+        g.set_switch("midi_device", device); g.set_switch("midi_apply_early", early)
         outs, states = [], []
 
         def snap():
@@ -361,14 +363,19 @@ def test_midi_burst_on_device_equals_the_host_state_machine(hiplib):
         g.midi(burst(allk, "restrike", 9)); outs.append(g.render(512).copy()); states.append(snap())
         g.midi(burst(allk, "overflow", 10)); outs.append(g.render(256).copy()); states.append(snap())               # 576 ops per engine: host replay
         g.midi(burst(allk, "play", 11)); outs.append(g.render(256).copy()); states.append(snap())
+        g.midi(burst(allk[::-1], "play", 12)); outs.append(g.render(256).copy()); states.append(snap())             # engines in falling order: not grouped
+        g.midi(burst(allk, "restrike", 13)); outs.append(g.render(64).copy()); states.append(snap())
+        outs.append(g.render(512).copy()); states.append(snap())
         bursts = g.get_switch("midi_device_bursts")
         g.close()
         return outs, states, bursts
     o_dev, s_dev, b_dev = run(1)
+    o_late, s_late, b_late = run(1, early=0)
     o_host, s_host, b_host = run(0)
-    assert b_host == 0 and b_dev >= 8, (b_host, b_dev)                     # the device path really ran (all but the ordered / overflowing bursts)
-    for i, (a, b) in enumerate(zip(s_dev, s_host)):
-        assert a == b, (i, "slot states")
-    for i, (a, b) in enumerate(zip(o_dev, o_host)):
+    assert b_host == 0 and b_dev >= 9 and b_late == b_dev, (b_host, b_dev, b_late)   # the device path really ran (all but the ordered / overflowing / ungrouped bursts)
+    for i, (a, b, c) in enumerate(zip(s_dev, s_host, s_late)):
+        assert a == b and c == b, (i, "slot states")
+    for i, (a, b, c) in enumerate(zip(o_dev, o_host, o_late)):
         assert np.array_equal(a, b), (i, float(np.max(np.abs(a - b))))
+        assert np.array_equal(c, b), (i, "late", float(np.max(np.abs(c - b))))
     assert max(float(np.max(np.abs(o))) for o in o_dev) > 1e-3
