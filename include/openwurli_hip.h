@@ -84,7 +84,11 @@ void ow_pool_render(ow_pool*, float* out_host, size_t out_stride, size_t len);
 /* Sample-accurate MIDI for many engines in one call: the plugin's handle_event (plugin/src/lib.rs:49-62)
  * applied in array order.  type 0 = NoteOn(note, value=velocity 0..1), 1 = NoteOff(note), 2 = sustain (value >= 0.5 = held).
  * Only the order of the events of one engine matters.  Large lists are applied by several host threads; a list grouped by engine
- * (non-decreasing `engine`) is cut into per-thread slices, any other order makes every thread scan the whole list. */
+ * (non-decreasing `engine`) is cut into per-thread slices, any other order makes every thread scan the whole list.
+ * A grouped list of >= 65 536 events on a pool of >= 8 192 engines is applied ON THE DEVICE (the voice-pool state machine of
+ * engine.rs:299-374 / 569-590 one lane per engine; a list in a block of ow_host_alloc is read where it lies), and its note-ons build
+ * their voices before the call returns, as Voice::note_on does (voice.rs:28-110); every other list queues its slot ops for the next
+ * render.  Same states, same samples either way (OW_MIDI_DEVICE=0 / OW_MIDI_APPLY_EARLY=0 switch the two steps off). */
 typedef struct ow_midi_event {
     uint32_t engine;
     uint8_t type;
