@@ -3184,7 +3184,7 @@ int ow_debug_div_forms(int mode, const double* a, const double* b, const double*
 
 int ow_debug_unary(int which, const double* x, size_t n, double* fast, double* lib, int device) {
     try {
-        if (!x || !fast || !lib || which < 0 || which > 5) throw std::runtime_error("null argument or unknown function");
+        if (!x || !fast || !lib || which < 0 || which > 6) throw std::runtime_error("null argument or unknown function");
         if (n == 0) return 0;
         HIP_OK(hipSetDevice(device));
         DevMem dx, df, dl;

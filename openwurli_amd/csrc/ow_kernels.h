@@ -347,7 +347,18 @@ __global__ __launch_bounds__(64) OW_VOICE_GENERAL_ATTR void k_voice(const OwCons
 // conditions are monotone between events, so one test at block start covers the whole block.  The kernel carries
 // only the fields that path needs (fewer registers) and has no phase tests in its sample loop; engines that fail the
 // test are left to k_voice.  Arithmetic per block is the same as VoiceRegs::step<true>.
-struct VoiceSteady {
+// (the envelope k samples into a block in the folded form: env0 * d^k by the library's pow -- correctly rounded to an ulp where the
+// reference's k-fold product carries ~sqrt(k) ulp of its own; binary powers of d would carry k / 2.  Out of line: once per 1 024 samples.)
+__device__ __noinline__ __attribute__((const)) double env_after(double env0, double d, uint32_t k) {
+    return env0 * pow(d, (double)k);
+}
+// FOLD (the steady kernel proper, round 5): the envelope is not a recurrence of its own but the RADIUS of the quadrature pair -- the
+// rotation coefficients carry decay_mult (folded in where they are formed, every 16th sample), `ae` holds the constant amplitude, and
+// the seven `ae *= decay` of every sample are gone (78 -> 72 vector instructions per voice-sample).  (s, c) enter the block multiplied
+// by the record's envelope and leave it divided by env0 * d^L; the renormalisation every 1 024 samples (reed.rs:292-299) resets the
+// radius to env0 * d^k instead of 1.  Same mathematics; roundings move by ~1e-16 per step, as with deviation 9.
+template <bool FOLD>
+struct VoiceSteadyT {
     // ae = amplitude * envelope carried as ONE recurrence (ae *= decay_mult): the modal sum is then one FMA per mode, where
     // reed.rs:276 multiplies amplitude * s * onset * envelope (two multiplies + add with onset == 1).  The product is reassociated and
     // rounded once per sample instead of twice: a relative random walk of ~1e-16 per sample against the reference's envelope, 3e-14
@@ -406,6 +417,7 @@ struct VoiceSteady {
                 const double delta_phase = drift[m] * phase_inc[m];
                 ci[m] = cos_inc[m] - delta_phase * sin_inc[m];
                 si[m] = sin_inc[m] + delta_phase * cos_inc[m];
+                if (FOLD) { ci[m] *= decay[m]; si[m] *= decay[m]; }
             }
         }
     }
@@ -479,7 +491,7 @@ struct VoiceSteady {
             const double c_new = c[m] * ci[m] - s[m] * si[m];
             s[m] = s_new;
             c[m] = c_new;
-            ae[m] *= decay[m];
+            if (!FOLD) ae[m] *= decay[m];
         }
         if (ATTACK && on_rem > 0u) {                         // reed.rs:276: every term carries the onset gain -- here the sum does (one
             sum *= *gain;                                    // multiply instead of seven: the products round differently, <= 1 ulp of the sum)
@@ -505,12 +517,27 @@ struct VoiceSteady {
         const double ay = fabs(y);
         if (renorm) {
             renorm = 0u;
+            // FOLD: the radius this pair should have now = the envelope after this sample: env0 * d^k, k = samples into the block
+            // including this one (jitter_due has just moved next_evt 16 past this sample's index)
+            const uint32_t k = FOLD ? (uint32_t)(next_evt - 15ull - dbits(rec[VF_SAMPLE * 64])) : 0u;
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
-                const double r_sq = s[m] * s[m] + c[m] * c[m];
-                const double r_inv = 1.0 / sqrt(r_sq);
-                s[m] *= r_inv;
-                c[m] *= r_inv;
+                if (FOLD) {
+                    // (on the pair divided by its target radius: the squares of a fast-decaying upper mode's 1e-160 would underflow.
+                    // A mode whose envelope has left the normal range is left alone: it adds nothing to any sum ever again.)
+                    const double env_t = env_after(rec[(VF_ENV + m) * 64], decay[m], k);
+                    if (env_t > 1e-290) {
+                        const double u = ow_div(s[m], env_t), w = ow_div(c[m], env_t);
+                        const double r_inv = 1.0 / sqrt(u * u + w * w);
+                        s[m] = (u * r_inv) * env_t;
+                        c[m] = (w * r_inv) * env_t;
+                    }
+                } else {
+                    const double r_sq = s[m] * s[m] + c[m] * c[m];
+                    const double r_inv = 1.0 / sqrt(r_sq);
+                    s[m] *= r_inv;
+                    c[m] *= r_inv;
+                }
             }
         }
         cd -= 1u;
@@ -580,7 +607,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const VoiceLanes w = voice_lanes(entries, eng_l);
     const bool active = w.active;
     double* rec = vrec + ((size_t)(active ? w.e : 0) * 2 + PASS) * OW_VREC_DOUBLES + w.slot;
-    VoiceSteady v;
+    VoiceSteadyT<PHASE == 0> v;
+    constexpr bool FOLD = PHASE == 0;
     uint32_t noise_rng = 0;
     v.on_rem = 0u; v.noise_rem = 0u; v.noise_fade = 0u; v.noise_rng = 0u; v.namp = 0.0; v.ns1 = 0.0; v.ns2 = 0.0; v.ndecay = 0.0;
     v.dt = 0.0; v.dramp = 0.0; v.dramp_y = 0.0; v.dflags = 0u;
@@ -621,7 +649,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         } else if ((flags & 1u) || smp < onset_n || noise_rem > 0u) eout[w.e].transient = 2u;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-            v.s[i] = rec[(VF_S + i) * 64]; v.c[i] = rec[(VF_C + i) * 64]; v.ae[i] = rec[(VF_AMP + i) * 64] * rec[(VF_ENV + i) * 64];
+            if (FOLD) { const double env0 = rec[(VF_ENV + i) * 64]; v.s[i] = rec[(VF_S + i) * 64] * env0; v.c[i] = rec[(VF_C + i) * 64] * env0; v.ae[i] = rec[(VF_AMP + i) * 64]; }
+            else { v.s[i] = rec[(VF_S + i) * 64]; v.c[i] = rec[(VF_C + i) * 64]; v.ae[i] = rec[(VF_AMP + i) * 64] * rec[(VF_ENV + i) * 64]; }
             v.drift[i] = rec[(VF_DRIFT + i) * 64]; v.decay[i] = rec[(VF_DECAY + i) * 64];
             if (!STEAL) { v.cos_inc[i] = rec[(VF_COS_INC + i) * 64]; v.sin_inc[i] = rec[(VF_SIN_INC + i) * 64]; v.phase_inc[i] = rec[(VF_PHASE_INC + i) * 64]; }
         }
@@ -675,14 +704,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         const int f1 = min(i1, L);
                         if (i < f1) {
                             if ((i & 15) == g) v.jitter_due();
-                            double y = v.advance();
+                            double y = v.template advance<false, false>(nullptr, nullptr, nullptr, nullptr, rec);
                             ++i;
 #pragma unroll 2
                             for (; i < f1; ++i) {
                                 if ((i & 15) == g) v.jitter_due();
                                 trow[wcol] = v.pickup(y);
                                 wcol = (wcol + 1) & (OW_SKEW_RING - 1);
-                                y = v.advance();
+                                y = v.template advance<false, false>(nullptr, nullptr, nullptr, nullptr, rec);
                             }
                             trow[wcol] = v.pickup(y);
                             wcol = (wcol + 1) & (OW_SKEW_RING - 1);
@@ -693,7 +722,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     for (; i < m1; ++i) {
                         if (i >= d && i - d < L) {
                             if ((i & 15) == g) v.jitter_due();
-                            const double y = v.advance();
+                            const double y = v.template advance<false, false>(nullptr, nullptr, nullptr, nullptr, rec);
                             trow[wcol] = v.pickup(y);
                             wcol = (wcol + 1) & (OW_SKEW_RING - 1);
                         }
@@ -752,11 +781,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 return o * ow_div_y((double)remaining, steal_len_d, steal_len_y);     // ow_div(remaining, len), the divisor's reciprocal refined once
             };
             v.template jitter<STEAL>(rec, zero_l);
-            double y = v.advance<ATTACK, STEAL>(trow, nco + lane, nco + 5 * 64, nco + lane, rec);
+            double y = v.template advance<ATTACK, STEAL>(trow, nco + lane, nco + 5 * 64, nco + lane, rec);
             auto one = [&](int n) {
                 v.template jitter<STEAL>(rec, zero_l);
                 trow[n - 1] = faded(v.pickup(y), n - 1);
-                y = v.advance<ATTACK, STEAL>(trow + n, nco + lane, nco + 5 * 64, nco + lane, rec);
+                y = v.template advance<ATTACK, STEAL>(trow + n, nco + lane, nco + 5 * 64, nco + lane, rec);
             };
             // two samples per trip: the compiler renames the pipelined state instead of copying it back (7 v_mov_b64 per sample)
             if (STEAL) {          // (by hand: the ballot in its damper step is a convergent operation, which the unroller leaves alone)
@@ -781,10 +810,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // envelope = ae / amplitude (amplitude read again here rather than held in 14 registers across the block); a mode without
             // amplitude contributes nothing whatever its envelope is: it keeps decaying by the closed form
             const double amp = rec[(VF_AMP + i) * 64];
+            if (FOLD) {
+                // back to the record's form: envelope env0 * d^L, (s, c) divided by it.  An envelope that has left the normal range (a
+                // fast-decaying upper mode of a long-held key, 1e-290 and falling) cannot give the pair back: it keeps its direction at
+                // unit length (or (0, 1) once the pair itself has underflowed) -- a mode at that level adds nothing to any sum ever again.
+                const double env = env_after(rec[(VF_ENV + i) * 64], v.decay[i], (uint32_t)L);
+                double so = v.s[i], co = v.c[i];
+                if (env > 1e-290) { so = ow_div(so, env); co = ow_div(co, env); }
+                else {
+                    const double r = sqrt(so * so + co * co);
+                    if (r > 0.0) { so = so / r; co = co / r; } else { so = 0.0; co = 1.0; }
+                }
+                fin = fin && isfinite(v.s[i]) && isfinite(v.c[i]);
+                rec[(VF_S + i) * 64] = so; rec[(VF_C + i) * 64] = co; rec[(VF_ENV + i) * 64] = env; rec[(VF_DRIFT + i) * 64] = v.drift[i];
+                all_quiet = all_quiet && (fabs(amp * env) <= 1e-4);
+            } else {
             const double env = amp != 0.0 ? v.ae[i] / amp : rec[(VF_ENV + i) * 64] * pow(v.decay[i], (double)L);
             rec[(VF_S + i) * 64] = v.s[i]; rec[(VF_C + i) * 64] = v.c[i]; rec[(VF_ENV + i) * 64] = env; rec[(VF_DRIFT + i) * 64] = v.drift[i];
             fin = fin && isfinite(v.s[i]) && isfinite(v.c[i]) && isfinite(v.ae[i]);
             all_quiet = all_quiet && (fabs(v.ae[i]) <= 1e-4);
+            }
         }
         rec[VF_Q * 64] = v.q;
         rec[VF_SAMPLE * 64] = bitsd(dbits(rec[VF_SAMPLE * 64]) + (uint64_t)L);

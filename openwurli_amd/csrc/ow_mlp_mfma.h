@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) void k_debug_exp(int which, const double* __re
     if (which == 0) { fast[i] = exp_bounded(x[i]); lib[i] = exp(x[i]); }
     else if (which == 1) { fast[i] = tanh_fast(x[i]);   lib[i] = tanh(x[i]); }
     else if (which == 5) { fast[i] = exp_neg_small(x[i]); lib[i] = exp(-x[i]); }       // damper-ramp factor (ow_voice_dev.h)
+    else if (which == 6) { fast[i] = env_after(1.0, x[i], 512u + (uint32_t)(i & 1023u)); lib[i] = pow(x[i], (double)(512u + (uint32_t)(i & 1023u))); }   // the folded steady kernel's envelope (ow_kernels.h)
     else {               // 2, 3, 4: the onset gain at phase x with shape exponent 1.25 / 1.5 / 1.9, next to the library's pow
         const double p = which == 2 ? 1.25 : (which == 3 ? 1.5 : 1.9);
         fast[i] = onset_gain(x[i], 1.0, p);
