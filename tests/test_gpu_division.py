@@ -253,3 +253,24 @@ def test_damper_ramp_exp_accuracy(hiplib):
     assert np.array_equal(f[~small], l[~small])              # the library beyond 1/8
     assert f[x == 0.0][0] == 1.0
     assert np.max(lib_err) <= 1.0
+
+
+def test_folded_envelope_is_the_power_of_the_decay(hiplib):
+    """env_after (ow_kernels.h): the envelope k samples into a block of the steady voice kernel, which carries it on the radius of its
+    quadrature pairs (DESIGN deviation 15), is env0 * decay^k by the device library's pow: within an ulp of numpy's, where the
+    reference's k-fold product carries ~sqrt(k) ulp of rounding of its own (checked here: the two differ by less than k / 4 ulp)."""
+    rng = np.random.default_rng(15)
+    d = np.concatenate([1.0 - 10.0 ** rng.uniform(-6.0, -1.5, 1 << 16), np.array([1.0, 0.5, 0.999999999])])
+    f = np.zeros_like(d); l = np.zeros_like(d)
+    assert hiplib.ow_debug_unary(6, d.ctypes.data_as(C.c_void_p), d.size, f.ctypes.data_as(C.c_void_p), l.ctypes.data_as(C.c_void_p), 0) == 0
+    k = 512 + (np.arange(d.size) & 1023)
+    want = np.power(d, k.astype(np.float64))
+    ok = want > 1e-300
+    assert _same_bits(f, l)
+    assert np.max(np.abs(f[ok] - want[ok]) / np.spacing(want[ok])) <= 1.0
+    # the reference's recurrence: k multiplications
+    i = int(np.argmin(np.abs(d - 0.9995)))
+    e = 1.0
+    for _ in range(int(k[i])):
+        e *= float(d[i])
+    assert abs(e - f[i]) / np.spacing(f[i]) < k[i] / 4
