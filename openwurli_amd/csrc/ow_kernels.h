@@ -552,7 +552,7 @@ struct VoiceSteadyT {
         const double alpha = beta * omy;
         const double q_next = ow_div(q * (1.0 - alpha) + 2.0 * beta, 1.0 + alpha);
         q = q_next;
-        return ((q_next * omy - 1.0) * 1.8375) * gain;
+        return (q_next * omy - 1.0) * gain;                    // gain = 1.8375 * post_pickup_gain, formed once per block (deviation 9's class: <= 1 ulp of the sample)
     }
 };
 
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             v.drift[i] = rec[(VF_DRIFT + i) * 64]; v.decay[i] = rec[(VF_DECAY + i) * 64];
             if (!STEAL) { v.cos_inc[i] = rec[(VF_COS_INC + i) * 64]; v.sin_inc[i] = rec[(VF_SIN_INC + i) * 64]; v.phase_inc[i] = rec[(VF_PHASE_INC + i) * 64]; }
         }
-        v.q = rec[VF_Q * 64]; v.ds = rec[VF_DS * 64]; v.gain = rec[VF_GAIN * 64];
+        v.q = rec[VF_Q * 64]; v.ds = rec[VF_DS * 64]; v.gain = 1.8375 * rec[VF_GAIN * 64];
         v.beta = rec[VF_BETA * 64]; v.revert = rec[VF_JREV * 64]; v.diffusion = rec[VF_JDIFF * 64];
         v.set_sample(dbits(rec[VF_SAMPLE * 64]));
         const uint64_t r = dbits(rec[VF_RNG * 64]);
