@@ -497,7 +497,9 @@ struct VoiceSteadyT {
             sum *= *gain;                                    // multiply instead of seven: the products round differently, <= 1 ulp of the sum)
             on_rem -= 1u;
         }
-        double x = 0.0 + sum;
+        // (reed.rs adds the modal sum to a buffer of zeros, and the noise burst on top: `0.0 + sum` only turns a -0.0 sum into +0.0, which
+        // nothing downstream of a noiseless sample can tell -- 1 - y, |y| and the products are the same)
+        double x = ATTACK ? 0.0 + sum : sum;
         // (both additions as lane-dependent branches.  Written branch-free -- selects, one loop copy per phase set picked per chunk, as
         // the steal variant's damper step is -- this loop spills: the block after a re-strike took 38.7 instead of 27.3 ms, and 68 ms
         // with the rotation constants read from the record as well)
@@ -607,8 +609,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const VoiceLanes w = voice_lanes(entries, eng_l);
     const bool active = w.active;
     double* rec = vrec + ((size_t)(active ? w.e : 0) * 2 + PASS) * OW_VREC_DOUBLES + w.slot;
-    VoiceSteadyT<PHASE == 0> v;
-    constexpr bool FOLD = PHASE == 0;
+    VoiceSteadyT<PHASE != 2> v;                               // (the steal variant's damper multiplies the envelope every sample: it keeps the recurrence)
+    constexpr bool FOLD = PHASE != 2;
     uint32_t noise_rng = 0;
     v.on_rem = 0u; v.noise_rem = 0u; v.noise_fade = 0u; v.noise_rng = 0u; v.namp = 0.0; v.ns1 = 0.0; v.ns2 = 0.0; v.ndecay = 0.0;
     v.dt = 0.0; v.dramp = 0.0; v.dramp_y = 0.0; v.dflags = 0u;
