@@ -211,6 +211,7 @@ struct Switches {
     int pipe = 0;                              // OW_PIPE=n stages
     int midi_device = -1;                      // OW_MIDI_DEVICE=0/1: bursts of ow_pool_midi applied on the device (k_vm_events) never / whenever the list allows; -1: pools of >= 8 192 engines, >= 65 536 events
     int midi_apply_early = 1;                  // OW_MIDI_APPLY_EARLY=0: the queues of a device burst wait for the next render's k_apply_ops
+    int voice_release = 1;                     // OW_VOICE_RELEASE=0: no release variant of the steady voice kernel (k_voice renders every engine with a damping voice)
     int voice_steal = 1;                       // OW_VOICE_STEAL=0: no steal variant of the steady voice kernel (k_voice renders every crossfade)
     int voice_attack = 1;                      // OW_VOICE_ATTACK=0: no attack variant of the steady voice kernel (engines in onset / noise phases go to the general kernel)
     bool force_general = false;                // test / probe hook: every engine's slot voices go to the general voice kernel (what it costs without any phase active)
@@ -239,6 +240,7 @@ struct Switches {
         w.pipe_overlap = flag("OW_PIPE_OVERLAP", 0) == 1;
         w.voice_attack = flag("OW_VOICE_ATTACK", 1) != 0;
         w.voice_steal = flag("OW_VOICE_STEAL", 1) != 0;
+        w.voice_release = flag("OW_VOICE_RELEASE", 1) != 0;
         w.midi_apply_early = flag("OW_MIDI_APPLY_EARLY", 1) != 0;
         w.midi_device = flag("OW_MIDI_DEVICE", -1); if (w.midi_device > 1 || w.midi_device < -1) w.midi_device = -1;
         w.chain_stream = flag("OW_CHAIN_STREAM", -1); if (w.chain_stream > 1 || w.chain_stream < -1) w.chain_stream = -1;
@@ -1672,7 +1674,11 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
                 steady_launched = true;
             }
             if (bg) {
-                owdev::k_voice<<<dim3(bg), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_general.d + a0.g, p->d_sum, p->d_eout, I, L, Lcap, 0);
+                // the release variant of the steady kernel takes the blocks whose voices are all past onset and noise (each block decides by
+                // itself, voice_steal_takes: what is left in this list are engines with a damping voice); k_voice (pass | 4) renders the others
+                const bool rel = p->sw.voice_release && !p->sw.force_general;      // (force_general measures k_voice itself)
+                if (rel) owdev::k_voice_steady<false, 3><<<dim3(bg), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_general.d + a0.g, p->d_sum, p->d_eout, I, L, Lcap, nullptr);
+                owdev::k_voice<<<dim3(bg), dim3(64), 0, s>>>(p->dK, p->d_vrec, p->vl_general.d + a0.g, p->d_sum, p->d_eout, I, L, Lcap, rel ? 4 : 0);
             }
             if (bt) {
                 // the steal variant of the steady kernel takes the engines whose steal voices are past onset and noise (each block decides
@@ -2737,6 +2743,9 @@ static bool midi_burst_on_device(ow_pool* p, const ow_midi_event* ev, size_t n) 
     __atomic_store_n(&p->dirty_any, (uint8_t)1, __ATOMIC_RELAXED);
     if (p->sw.midi_apply_early && sc != st) {
         owdev::k_apply_ops<<<dim3(e_hi - e_lo), dim3(64), 0, st>>>(p->dK, p->d_nt, p->d_vrec, nullptr, nullptr, nullptr, p->d_ops_fix, p->d_vm, (int)e_lo);
+        // the queue lengths go back to zero only when the download has them: the host recognises the engines of this burst by them
+        // (vm_settle_applied); a short k_apply_ops -- a burst of note-offs -- would otherwise finish, and clear, under the copy
+        HIP_OK(hipStreamWaitEvent(st, p->ev_vm, 0));
         owdev::k_vm_clear_dev_ops<<<dim3((e_hi - e_lo + 255) / 256), dim3(256), 0, st>>>(p->d_vm, e_lo, e_hi);
         HIP_OK(hipGetLastError());
         p->dev_ops_applied = true; p->applied_lo = e_lo; p->applied_hi = e_hi;
@@ -3044,6 +3053,7 @@ int ow_test_pool_set_switch(ow_pool* p, const char* name, int value) {
     else if (n == "midi_device") w.midi_device = value < 0 ? -1 : (value != 0);
     else if (n == "voice_attack") { w.voice_attack = value != 0; p->lists_valid = false; }
     else if (n == "voice_steal") w.voice_steal = value != 0;
+    else if (n == "voice_release") w.voice_release = value != 0;
     else if (n == "midi_apply_early") w.midi_apply_early = value != 0;
     else if (n == "force_general") { w.force_general = value != 0; p->lists_valid = false; }
     else if (n == "chain_stream") w.chain_stream = value < 0 ? -1 : (value != 0);
@@ -3072,6 +3082,7 @@ int ow_test_pool_get_switch(const ow_pool* p, const char* name) {
     if (n == "midi_device") return w.midi_device;
     if (n == "voice_attack") return w.voice_attack;
     if (n == "voice_steal") return w.voice_steal;
+    if (n == "voice_release") return w.voice_release;
     if (n == "midi_apply_early") return w.midi_apply_early;
     if (n == "blocks_steady") return (int)p->vl_steady.n_blocks;   // wavefront blocks of the voice lists the last render launched
     if (n == "blocks_general") return (int)p->vl_general.n_blocks;

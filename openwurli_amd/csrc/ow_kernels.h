@@ -591,32 +591,36 @@ struct VoiceSteadyT {
 // with a steal voice still inside its onset ramp or noise burst (stolen within 40 ms of its strike), or with a damper rate above 1/8
 // (host rates below 16 kHz), returns at once and is rendered by k_voice, which skips the others (voice_steal_takes: one test, both
 // kernels).  The general kernel spent 14.0 + 13.0 ms on the two sub-blocks of a whole-pool re-strike's crossfade.
+// RELEASE (PHASE = 3): the same damper step for the SLOT voices of the general list -- engines with a released key that still sounds
+// (engine.rs:340-374: what note-off and pedal-up leave behind for the ~170 ms until the voice is freed) -- packed like every slot list,
+// several engines per block; the same test decides per BLOCK (any voice of it inside an onset ramp or noise burst: k_voice's).
 template <bool SKEW, int PHASE = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_voice_steady(const OwConsts* __restrict__ K, double* __restrict__ vrec, const uint32_t* __restrict__ entries,
                                                      double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int L, int Lcap, uint32_t* __restrict__ skew_seen) {
-    constexpr bool ATTACK = PHASE == 1, STEAL = PHASE == 2;
-    constexpr int PCH = STEAL ? 24 : 32;                      // chunk of the plain loop (24 -> 32: a 512-sample block is sixteen whole chunks; 12.9 against 13.05 ms)
+    constexpr bool ATTACK = PHASE == 1, STEAL = PHASE == 2, RELEASE = PHASE == 3;
+    constexpr bool DAMPV = STEAL || RELEASE;                  // the variants with the damper step
+    constexpr int PCH = DAMPV ? 24 : 32;                      // chunk of the plain loop (24 -> 32: a 512-sample block is sixteen whole chunks; 12.9 against 13.05 ms)
     constexpr int TILE_DOUBLES = SKEW ? 64 * OW_SKEW_RS : 64 * (PCH + 1);   // (the skewed variant's short blocks and aligned wavefronts use the plain loop in the ring's tile)
     constexpr int PRS = SKEW ? OW_SKEW_RS : PCH + 1;          // ... and its row stride
     constexpr int PASS = STEAL ? 1 : 0;                       // which record of the slot and which row of the sums
-    static_assert(!(SKEW && PHASE != 0), "the attack / steal variants are the plain loop");
+    static_assert(!(SKEW && PHASE != 0), "the attack / steal / release variants are the plain loop");
     __shared__ double tile[TILE_DOUBLES];
-    __shared__ double nco[ATTACK ? 5 * 64 + 16 : (STEAL ? 7 * 64 : 1)];   // attack-noise BPF coefficients per lane, then the sixteen fade-in values / damper rates per lane
+    __shared__ double nco[ATTACK ? 5 * 64 + 16 : (DAMPV ? 7 * 64 : 1)];   // attack-noise BPF coefficients per lane, then the sixteen fade-in values / damper rates per lane
     __shared__ int eng_l[64];
-    __shared__ int zero_l[1];                                 // (STEAL: update_rotation<true>)
+    __shared__ int zero_l[1];                                 // (DAMPV: update_rotation<true>)
     const int lane = threadIdx.x;
-    if (STEAL && lane == 0) zero_l[0] = 0;
+    if (DAMPV && lane == 0) zero_l[0] = 0;
     const VoiceLanes w = voice_lanes(entries, eng_l);
     const bool active = w.active;
     double* rec = vrec + ((size_t)(active ? w.e : 0) * 2 + PASS) * OW_VREC_DOUBLES + w.slot;
-    VoiceSteadyT<PHASE != 2> v;                               // (the steal variant's damper multiplies the envelope every sample: it keeps the recurrence)
-    constexpr bool FOLD = PHASE != 2;
+    VoiceSteadyT<!DAMPV> v;                                   // (a damper multiplies the envelope every sample: those variants keep the recurrence)
+    constexpr bool FOLD = !DAMPV;
     uint32_t noise_rng = 0;
     v.on_rem = 0u; v.noise_rem = 0u; v.noise_fade = 0u; v.noise_rng = 0u; v.namp = 0.0; v.ns1 = 0.0; v.ns2 = 0.0; v.ndecay = 0.0;
     v.dt = 0.0; v.dramp = 0.0; v.dramp_y = 0.0; v.dflags = 0u;
     uint32_t steal_fade = 0u, steal_len = 1u;
     double steal_len_d = 1.0, steal_len_y = 1.0;
-    if (STEAL) {
+    if (DAMPV) {
         uint64_t smp = 0ull, on_n = 0ull;
         uint32_t nrem = 0u, fl = 0u;
         double rate6 = 0.0;
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             smp = dbits(rec[VF_SAMPLE * 64]); on_n = dbits(rec[VF_ONSET_N * 64]); nrem = (uint32_t)dbits(rec[VF_NCNT * 64]);
             fl = (uint32_t)dbits(rec[VF_FLAGS * 64]); rate6 = rec[(VF_DRATE + 6) * 64];
         }
-        if (!voice_steal_takes(active, smp, on_n, nrem, fl, rate6)) return;      // k_voice renders this engine
+        if (!voice_steal_takes(active, smp, on_n, nrem, fl, rate6)) return;      // k_voice renders this block
     }
     if (ATTACK && lane < 16) nco[5 * 64 + lane] = noise_fade_env((double)lane / 16.0);      // the values k_voice forms per sample (hammer.rs:165)
     if (active) {
@@ -641,20 +645,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             v.namp = rec[VF_NAMP * 64]; v.ns1 = rec[VF_NS1 * 64]; v.ns2 = rec[VF_NS2 * 64]; v.ndecay = rec[VF_NDECAY * 64];
 #pragma unroll
             for (int i = 0; i < 5; ++i) nco[i * 64 + lane] = rec[(VF_NB0 + i) * 64];
-        } else if (STEAL) {
+        } else if (DAMPV) {
             v.dflags = flags & 3u; v.dt = rec[VF_DCOUNT * 64]; v.dramp = rec[VF_DRAMP * 64]; v.dramp_y = ow_rcp_refined(v.dramp);
 #pragma unroll
             for (int i = 0; i < 7; ++i) nco[i * 64 + lane] = rec[(((flags & 2u) ? VF_DMULT : VF_DRATE) + i) * 64];
-            const uint64_t sf = dbits(rec[VF_STEAL * 64]);
-            steal_fade = (uint32_t)sf; steal_len = (uint32_t)(sf >> 32);
-            steal_len_d = (double)steal_len; steal_len_y = ow_rcp_refined(steal_len_d);
+            if (STEAL) {
+                const uint64_t sf = dbits(rec[VF_STEAL * 64]);
+                steal_fade = (uint32_t)sf; steal_len = (uint32_t)(sf >> 32);
+                steal_len_d = (double)steal_len; steal_len_y = ow_rcp_refined(steal_len_d);
+            }
         } else if ((flags & 1u) || smp < onset_n || noise_rem > 0u) eout[w.e].transient = 2u;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             if (FOLD) { const double env0 = rec[(VF_ENV + i) * 64]; v.s[i] = rec[(VF_S + i) * 64] * env0; v.c[i] = rec[(VF_C + i) * 64] * env0; v.ae[i] = rec[(VF_AMP + i) * 64]; }
             else { v.s[i] = rec[(VF_S + i) * 64]; v.c[i] = rec[(VF_C + i) * 64]; v.ae[i] = rec[(VF_AMP + i) * 64] * rec[(VF_ENV + i) * 64]; }
             v.drift[i] = rec[(VF_DRIFT + i) * 64]; v.decay[i] = rec[(VF_DECAY + i) * 64];
-            if (!STEAL) { v.cos_inc[i] = rec[(VF_COS_INC + i) * 64]; v.sin_inc[i] = rec[(VF_SIN_INC + i) * 64]; v.phase_inc[i] = rec[(VF_PHASE_INC + i) * 64]; }
+            if (!DAMPV) { v.cos_inc[i] = rec[(VF_COS_INC + i) * 64]; v.sin_inc[i] = rec[(VF_SIN_INC + i) * 64]; v.phase_inc[i] = rec[(VF_PHASE_INC + i) * 64]; }
         }
         v.q = rec[VF_Q * 64]; v.ds = rec[VF_DS * 64]; v.gain = 1.8375 * rec[VF_GAIN * 64];
         v.beta = rec[VF_BETA * 64]; v.revert = rec[VF_JREV * 64]; v.diffusion = rec[VF_JDIFF * 64];
@@ -662,7 +668,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const uint64_t r = dbits(rec[VF_RNG * 64]);
         v.jitter_state = (uint32_t)r; noise_rng = (uint32_t)(r >> 32);
         v.noise_rng = noise_rng;
-        v.template update_rotation<STEAL>(rec, zero_l);
+        v.template update_rotation<DAMPV>(rec, zero_l);
     }
     __syncthreads();                     // eng_l, nco
     // ---- which trips carry the jitter updates: g minimising the longest delay over the phases present in this wavefront
@@ -782,15 +788,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const uint32_t remaining = steal_fade > i ? steal_fade - i : 0u;
                 return o * ow_div_y((double)remaining, steal_len_d, steal_len_y);     // ow_div(remaining, len), the divisor's reciprocal refined once
             };
-            v.template jitter<STEAL>(rec, zero_l);
-            double y = v.template advance<ATTACK, STEAL>(trow, nco + lane, nco + 5 * 64, nco + lane, rec);
+            v.template jitter<DAMPV>(rec, zero_l);
+            double y = v.template advance<ATTACK, DAMPV>(trow, nco + lane, nco + 5 * 64, nco + lane, rec);
             auto one = [&](int n) {
-                v.template jitter<STEAL>(rec, zero_l);
+                v.template jitter<DAMPV>(rec, zero_l);
                 trow[n - 1] = faded(v.pickup(y), n - 1);
-                y = v.template advance<ATTACK, STEAL>(trow + n, nco + lane, nco + 5 * 64, nco + lane, rec);
+                y = v.template advance<ATTACK, DAMPV>(trow + n, nco + lane, nco + 5 * 64, nco + lane, rec);
             };
             // two samples per trip: the compiler renames the pipelined state instead of copying it back (7 v_mov_b64 per sample)
-            if (STEAL) {          // (by hand: the ballot in its damper step is a convergent operation, which the unroller leaves alone)
+            if (DAMPV) {          // (by hand: the ballot in the damper step is a convergent operation, which the unroller leaves alone)
                 int n = 1;
                 for (; n + 1 < cn; n += 2) { one(n); one(n + 1); }
                 if (n < cn) one(n);
@@ -843,14 +849,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         rec[VF_RNG * 64] = bitsd((uint64_t)v.jitter_state | ((uint64_t)noise_rng << 32));
         const unsigned long long bit = 1ull << w.slot;
-        if (STEAL) {
+        if (DAMPV) {
             rec[VF_DCOUNT * 64] = v.dt;
             const uint64_t fl = dbits(rec[VF_FLAGS * 64]);
             rec[VF_FLAGS * 64] = bitsd((fl & ~3ull) | (uint64_t)v.dflags);
+        }
+        if (STEAL) {
             const uint32_t l32 = (uint32_t)L;                                      // slot.steal_fade.saturating_sub(len) (engine.rs:490)
             steal_fade = steal_fade > l32 ? steal_fade - l32 : 0u;
             rec[VF_STEAL * 64] = bitsd((uint64_t)steal_fade | ((uint64_t)steal_len << 32));
             if (!fin) atomicOr((unsigned long long*)&eout[w.e].bad_steal, bit);
+        } else if (RELEASE) {
+            // Voice::is_silent (voice.rs:183-188): -80 dB on every mode, or ten seconds under the damper; a voice that still damps keeps its
+            // engine in the transient class (as k_voice reports it)
+            const bool timed_out = (v.dflags & 1u) && ow_div(v.dt, rec[VF_VSR * 64]) > 10.0;
+            if (all_quiet || timed_out) atomicOr((unsigned long long*)&eout[w.e].silent_mask, bit);
+            if (!fin) atomicOr((unsigned long long*)&eout[w.e].bad_main, bit);
+            if (v.dflags & 1u) eout[w.e].transient = 1u;
         } else {
             if (all_quiet) atomicOr((unsigned long long*)&eout[w.e].silent_mask, bit);   // damper inactive here: only the -80 dB test of Voice::is_silent
             if (!fin) atomicOr((unsigned long long*)&eout[w.e].bad_main, bit);

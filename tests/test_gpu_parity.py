@@ -1233,3 +1233,75 @@ def test_steal_variant_follows_the_oracle_and_the_general_kernel(hiplib, oracle)
     assert np.max(d[0]) > 0.0                                                  # ... and engine 0's did not
     assert np.max(np.abs(res[1][0] - res[0][0])) <= 1e-6
     assert np.max(np.abs(res[1][0])) > 1e-3
+
+
+def test_release_variant_follows_the_oracle_and_the_general_kernel(hiplib, oracle):
+    """k_voice_steady<false, 3> (ow_kernels.h): the slot voices of engines with a released key that still sounds render on the steady loop
+    with the damper step beside it (ramp, then multipliers) instead of on the general kernel; each packed block decides by itself
+    (voice_steal_takes: a voice inside an onset ramp or noise burst anywhere in it leaves the block to k_voice).  Engines: 0 a chord, some
+    keys released; 1 the whole keyboard released at once (bass ramps of 50 ms, treble of 8 ms, the top keys without a damper); 2 pedal
+    down, keys up (Sustained: nothing damps), pedal up (everything damps at once); 3 released and re-struck at once (damping steal voices
+    beside fresh onsets: general, then the variants take over); 4 a key released inside its own onset ramp; 5 sparse: one held note, one
+    released (shares its packed block with its neighbours).  Ragged block lengths incl. some below the chunk; long enough for voices to
+    be freed at -80 dB (slot states follow the oracle).  Every block follows the oracle; against OW_VOICE_RELEASE=0 voice sums differ by
+    rounding only, and the two runs free their voices in the same blocks."""
+    import openwurli_amd as ow
+    sr, n = 48000.0, 6
+    lengths = (512, 512, 512, 512, 512, 512, 100, 7, 133, 24, 25, 512, 1, 512, 300) + (512,) * 30
+    res = {}
+    keys = list(range(33, 97))
+    for release in (1, 0):
+        p = ow.EnginePool(sr, n)
+        p.set_switch("voice_release", release)
+        assert p.get_switch("voice_release") == release
+        p.set_sample_rate(sr)
+        cs = [oracle.OracleEngine(sr) for _ in range(n)] if release else None
+        if cs:
+            for c in cs:
+                c.set_sample_rate(sr)
+        def both(k, f):
+            f(p[k])
+            if cs:
+                f(cs[k])
+        sums, outs, counts = [], [], []
+        both(0, lambda e: [e.note_on(k, 0.7) for k in (40, 47, 52, 60, 64, 67, 72, 88)])
+        both(1, lambda e: [e.note_on(k, 0.5 + 0.004 * (k - 33)) for k in keys])
+        both(2, lambda e: (e.set_sustain(True), [e.note_on(k, 0.6) for k in (36, 48, 55, 62, 70, 81)]))
+        both(3, lambda e: [e.note_on(k, 0.65) for k in keys[::2]])
+        both(5, lambda e: (e.note_on(45, 0.8), e.note_on(69, 0.8)))
+        for b, length in enumerate(lengths):
+            if b == 6:
+                both(0, lambda e: [e.note_off(k) for k in (40, 52, 64, 88)])
+                both(1, lambda e: [e.note_off(k) for k in keys])
+                both(2, lambda e: [e.note_off(k) for k in (36, 48, 55, 62, 70, 81)])
+                both(3, lambda e: [(e.note_off(k), e.note_on(k, 0.8)) for k in keys[::2]])
+                both(4, lambda e: e.note_on(38, 0.3))                           # a slow onset (bass, soft) ...
+                both(5, lambda e: e.note_off(69))
+            if b == 7:
+                both(4, lambda e: e.note_off(38))                               # ... released 100 samples into it
+            if b == 12:
+                both(2, lambda e: e.set_sustain(False))
+            o = p.render(length)
+            outs.append(o.copy()); sums.append(p.voice_sum(length).copy())
+            counts.append([p[k].active_voice_count() for k in range(n)])
+            if cs:
+                for k in range(n):
+                    co, cv, _, _ = cs[k].render_taps(length)
+                    rep = oracle.parity_report(o[k], co, abs_floor=oracle.ABS_FLOOR_DENSE)
+                    assert rep["n_bad"] == 0, (k, b, length, rep)
+                    vs = sums[-1][k]
+                    assert np.max(np.abs(vs - cv)) <= 2e-9 * max(1.0, float(np.max(np.abs(cv)))), (k, b, float(np.max(np.abs(vs - cv))))
+                    assert counts[-1][k] == cs[k].active_voice_count(), (k, b, counts[-1][k], cs[k].active_voice_count())
+        p.close()
+        if cs:
+            for c in cs:
+                c.close()
+        res[release] = (np.concatenate(outs, axis=1), np.concatenate(sums, axis=1), counts)
+    assert res[1][2] == res[0][2]
+    assert res[1][2][-1][1] <= 8 and res[1][2][6][1] == 64                      # the released keyboard has been freed (all but the undamped top keys and the slowest bass)
+    scale = max(1.0, float(np.max(np.abs(res[0][1]))))
+    d = np.abs(res[1][1] - res[0][1])
+    assert np.max(d) <= 1e-10 * scale, float(np.max(d))
+    assert np.max(d[1]) > 0.0                                                  # engine 1's release did run on the variant
+    assert np.max(np.abs(res[1][0] - res[0][0])) <= 1e-6
+    assert np.max(np.abs(res[1][0])) > 1e-3
