@@ -83,7 +83,7 @@ def main():
         run([os.path.join(ROOT, "tools", "summarize_profile.py"), t, os.path.join(dst, f"{r}_kernel_trace_host_delivery.md")])
         made.append(os.path.join(dst, f"{r}_kernel_trace_host_delivery.md"))
     for name, out in (("restrike_hbm.txt", "restrike_trace.txt"), ("restrike_host.txt", "restrike_trace_host_delivery.txt"), ("smoke.txt", "smoke.txt"),
-                      ("pmc_restrike.txt", "pmc_restrike_voice_kernels.txt")):
+                      ("pmc_restrike.txt", "pmc_restrike_voice_kernels.txt"), ("probe_release.txt", "probe_release.txt"), ("soak.txt", "soak.txt")):
         if os.path.exists(os.path.join(src, name)):
             open(os.path.join(dst, f"{r}_{out}"), "w").write(open(os.path.join(src, name)).read())
             made.append(os.path.join(dst, f"{r}_{out}"))
