@@ -179,10 +179,30 @@ OW_DEV VoiceLanes voice_lanes(const uint32_t* __restrict__ entries, int* __restr
     return w;
 }
 // Sum the voices of each engine of the block in slot order for sample (base + lane) and write its row of sum[pass][engine][.].
-template <int CH = OW_VCHUNK, int RS = CH + 1>
+// HALVES (the steady kernel and its variants): a block that is one engine with all 64 voices is summed as (v0 + ... + v31) + (v32 + ... +
+// v63), both halves of the wavefront at work on 32 voices each, instead of 64 dependent additions on half of its lanes -- the chain
+// the wavefront waits for at every chunk edge is half as long.  One rounding of the engine.rs:469-479 order moves (the class of
+// deviation 9; k_voice keeps the strict order).
+template <int CH = OW_VCHUNK, int RS = CH + 1, bool HALVES = false>
 OW_DEV void voice_reduce(const double* __restrict__ tile, const int* __restrict__ eng_l, const VoiceLanes& w, int cn, int base, int pass,
                          double* __restrict__ sum, OwEngineOut* __restrict__ eout, int I, int Lcap) {
     const int lane = threadIdx.x;
+    if (HALVES && CH <= 32 && w.nvalid == 64 && w.seg_end == (1ull << 63)) {      // (wave-uniform)
+        const int j = lane & 31, h = lane >> 5;
+        double acc = 0.0;
+        if (j < cn) {
+#pragma unroll 16
+            for (int l = 0; l < 32; ++l) acc += tile[(32 * h + l) * RS + j];
+        }
+        const double hi = __shfl(acc, j + 32);
+        if (h == 0 && j < cn) {
+            acc += hi;
+            const int e = eng_l[0];
+            if (!isfinite(acc)) atomicOr(&eout[e].sum_nonfinite, 1u);
+            sum[((size_t)pass * I + e) * Lcap + base + j] = acc;
+        }
+        return;
+    }
     if (lane < cn) {
         if (w.seg_end == (1ull << (w.nvalid - 1))) {   // one engine in the block (every block when all keys are down): no segment tests
             double acc = 0.0;
@@ -742,7 +762,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             while (red < n_chunks) {
                 const int cn = min(OW_SKEW_CH, L - red * OW_SKEW_CH);
                 if (red * OW_SKEW_CH + cn - 1 + D > i1 - 1) break;
-                voice_reduce<OW_SKEW_RING, OW_SKEW_RS>(tile + ((red * OW_SKEW_CH) & (OW_SKEW_RING - 1)), eng_l, w, cn, red * OW_SKEW_CH, 0, sum, eout, I, Lcap);
+                voice_reduce<OW_SKEW_RING, OW_SKEW_RS, true>(tile + ((red * OW_SKEW_CH) & (OW_SKEW_RING - 1)), eng_l, w, cn, red * OW_SKEW_CH, 0, sum, eout, I, Lcap);
                 ++red;
             }
             __syncthreads();
@@ -807,7 +827,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             trow[cn - 1] = faded(v.pickup(y), cn - 1);
         }
         __syncthreads();
-        voice_reduce<PCH, PRS>(tile, eng_l, w, cn, base, PASS, sum, eout, I, Lcap);
+        voice_reduce<PCH, PRS, true>(tile, eng_l, w, cn, base, PASS, sum, eout, I, Lcap);
         __syncthreads();
     }
     if (active) {
