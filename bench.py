@@ -54,12 +54,12 @@ NOTES = list(range(33, 97))
 # deviation 9) + jitter 3 + pickup 13 + gain/sum 2 per voice-sample: the algorithm AS BUILT.  (SURVEY 8d counts 130 for the reference.)
 FLOPS_VOICE_SAMPLE = 123
 FLOPS_VOICES = 64 * FLOPS_VOICE_SAMPLE
-# f64 flops the steady voice kernel EXECUTES per voice-sample by its PMC instruction mix (4.8 add + 20.3 mul + 2 x 35.9 fma + 1.1
-# transcendental, profiles/r05_pmc_per_sample.md; 75.0 VALU instructions in all -- 8.4 / 27.5 / 35.5 / 1.2 and 83.8 until the pickup's soft
+# f64 flops the steady voice kernel EXECUTES per voice-sample by its PMC instruction mix (3.8 add + 20.3 mul + 2 x 35.9 fma + 1.1
+# transcendental, profiles/r05_pmc_per_sample.md; 74.2 VALU instructions in all -- 8.4 / 27.5 / 35.5 / 1.2 and 83.8 until the pickup's soft
 # limit stopped calling the library's tanh and the envelope moved onto the quadrature pair's radius, round 5): below the algorithmic
 # count because the jitter-corrected rotation coefficients (4 flops per mode, reed.rs:281-283 evaluates them every sample) only change
 # with the drift, every 16th sample, and are hoisted there, and because the folded form has no `envelope *= decay` per mode and sample
-FLOPS_VOICE_SAMPLE_EXECUTED = 4.8 + 20.3 + 2 * 35.9 + 1.1
+FLOPS_VOICE_SAMPLE_EXECUTED = 3.8 + 20.3 + 2 * 35.9 + 1.1
 FLOPS_TREMOLO = 2 * (1000 + 25)    # Twin-T NR step + LDR law per OS sample, 2 OS samples -- per tremolo PHASE GROUP, not per engine
 FLOPS_PREAMP = 2 * 1400 + 24       # main+shadow dk_step per OS sample + half-band up
 # melange 12-node preamp as the kernel EXECUTES it (rank-one update of the inverse, no per-sample LU): per state and chain-rate
