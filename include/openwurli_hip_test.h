@@ -97,6 +97,15 @@ int ow_test_host_matrices(int solver, double rate, int force_rebuild, double* s,
  * Twin-T states dropped. */
 int ow_test_clear_settle_caches(void);
 
+/* ---- the trajectory's oscillator kernels on their own --------------------------------------------- */
+/* CircuitState at DC_OP, n_settle oscillator steps without the cell, then n steps of the shared trajectory (r_ldr[0 .. n)) in launches of
+ * `chunk` steps, with the quad-lane kernels (row = 0: ow_trem_wide.h) or the one-system-per-wavefront kernels (row = 1: ow_trem_row.h).
+ * No store and no pool are touched.  r_out[n]; state_out[18] = the oscillator rows after the last step; ckpt_out[(n / 4096 + 2) * 16] and
+ * be_out[1024] may be NULL; *ms_out = device time of the trajectory launches.  The two must agree bit for bit
+ * (tests/test_gpu_trajectory.py); the time per step is the figure every small pool waits for.  Returns 0, <0 on error. */
+int ow_debug_trem_trajectory(double sample_rate, long long n_settle, long long n, long long chunk, int row, double* r_out, double* state_out,
+                             double* ckpt_out, unsigned long long* be_out, double* ms_out, int device);
+
 /* ---- voice-sum NaN guard ----------------------------------------------------------------------- */
 /* Overwrite one double of a voice record on the device before the next block (slot 0..63; steal != 0 selects the slot's steal voice;
  * field = a VF_* index of openwurli_amd/csrc/ow_types.h: OW_TEST_VF_Q is the pickup charge, OW_TEST_VF_S0 mode 0's sine state).  A

@@ -29,6 +29,7 @@
 #include "ow_power_amp_dev.h"
 #include "ow_features.h"
 #include "ow_trem_wide.h"
+#include "ow_trem_row.h"
 #include "ow_audit.h"
 #include "ow_midi_kernels.h"
 #include "ow_chain_wide.h"
@@ -567,6 +568,9 @@ void pa_settled_to_device(int device, double* d_dst, hipStream_t st) {
 // expensive settles the same way (OnceLock: melange_adapter.rs:12-29, power_amp.rs:283-299).  Keyed by (device, chain rate); the cached
 // rows are what the product kernels produced on the first use, so a hit is bit-identical to a fresh settle
 // (tests/test_gpu_boundary.py::test_settled_tremolo_cache_is_bit_identical).  OW_TREM_CACHE=0 disables it.
+// OW_TREM_ROW=0: the quad-lane oscillator step (ow_trem_wide.h) for the settle and the shared trajectory instead of the row step
+// (ow_trem_row.h).  Same samples either way (tests/test_gpu_trajectory.py); read once per process.
+bool trem_row_enabled() { static const bool on = Switches::flag("OW_TREM_ROW", 1) != 0; return on; }
 struct TremSettled { double rows[18]; };       // rows 0..16 after the settle; [17] = BE fallbacks the settle itself counted (u64 bits)
 std::map<std::pair<int, uint64_t>, TremSettled> g_trem_settled;
 
@@ -589,8 +593,13 @@ TremSettled trem_settled_rows(int device, double os_sr, const OwConsts* dK, cons
     }
     const long long n_settle = (long long)owhip::sat_u32(os_sr * 2.0);
     owdev::k_trem_state_dc<<<dim3(1), dim3(64), 0, st>>>(d_state);
-    owdev::k_tremolo_wide<true><<<dim3(1), dim3(64), 0, st>>>(dK48, d_state, nullptr, 1, 50LL, d_zero, 1);
-    owdev::k_tremolo_wide<true><<<dim3(1), dim3(64), 0, st>>>(dK, d_state, nullptr, 1, n_settle, d_zero, 1);
+    if (trem_row_enabled()) {      // one system per wavefront (ow_trem_row.h): bit-identical, ~0.55 x the time
+        owdev::k_trem_settle_row<<<dim3(1), dim3(64), 0, st>>>(dK48, d_state, 50LL);
+        owdev::k_trem_settle_row<<<dim3(1), dim3(64), 0, st>>>(dK, d_state, n_settle);
+    } else {
+        owdev::k_tremolo_wide<true><<<dim3(1), dim3(64), 0, st>>>(dK48, d_state, nullptr, 1, 50LL, d_zero, 1);
+        owdev::k_tremolo_wide<true><<<dim3(1), dim3(64), 0, st>>>(dK, d_state, nullptr, 1, n_settle, d_zero, 1);
+    }
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(t.rows, d_state, sizeof(double) * 18, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
@@ -670,7 +679,8 @@ struct TremTraj {
     void extend_to(size_t end) {
         end = std::min(end, cap);
         if (end <= len) return;
-        owdev::k_trem_traj_extend<<<dim3(1), dim3(64), 0, stream>>>(dK, d_state, d_r + len, (long long)len, (long long)(end - len), d_ckpt, d_be);
+        if (trem_row_enabled()) owdev::k_trem_traj_extend_row<<<dim3(1), dim3(64), 0, stream>>>(dK, d_state, d_r + len, (long long)len, (long long)(end - len), d_ckpt, d_be);
+        else owdev::k_trem_traj_extend<<<dim3(1), dim3(64), 0, stream>>>(dK, d_state, d_r + len, (long long)len, (long long)(end - len), d_ckpt, d_be);
         HIP_OK(hipGetLastError());
         Mark& m = mark[head];
         head = (head + 1) % NMARK;
@@ -3018,6 +3028,55 @@ extern "C" int ow_debug_counters(unsigned long long* out8, int device) {
     return hipMemcpyToSymbol(HIP_SYMBOL(owdev::g_ow_dbg), z, sizeof z) == hipSuccess ? 0 : -1;
 }
 #endif
+// The two oscillator kernels of the shared trajectory on their own (no store, no pool): CircuitState at DC_OP, n_settle steps without
+// the cell (Tremolo::new's settle), then n steps with it through a trajectory kernel in launches of `chunk` steps.  row = 0: the quad-lane
+// kernels (k_tremolo_wide<true>, k_trem_traj_extend), 1: the row kernels (ow_trem_row.h).  r_out[n], state_out[18], ckpt_out[(n / 4096 + 2)
+// * 16] (or NULL), be_out[1 + 1023] (or NULL); *ms_out = device time of the trajectory launches (HIP events).
+int ow_debug_trem_trajectory(double sample_rate, long long n_settle, long long n, long long chunk, int row, double* r_out, double* state_out,
+                             double* ckpt_out, unsigned long long* be_out, double* ms_out, int device) {
+    try {
+        if (!r_out || !state_out || n <= 0 || n_settle < 0 || chunk <= 0) throw std::runtime_error("bad arguments");
+        HIP_OK(hipSetDevice(device));
+        std::unique_ptr<OwConsts> hc(new OwConsts());
+        owhip::build_consts(*hc, sample_rate, OW_PREAMP_LEGACY8);
+        DevMem dk, dstate, dr, dck, dbe, dzero;
+        dk.alloc(sizeof(OwConsts)); dstate.alloc(sizeof(double) * 18); dr.alloc(sizeof(double) * (size_t)(n + 64));
+        const size_t nck = TremTraj::ckpt_doubles((size_t)n);
+        dck.alloc(sizeof(double) * nck); dbe.alloc(sizeof(unsigned long long) * (1 + OW_TRAJ_BE_CAP)); dzero.alloc(sizeof(uint32_t));
+        StreamOwner so;
+        HIP_OK(hipStreamCreate(&so.s));
+        HIP_OK(hipMemcpyAsync(dk.p, hc.get(), sizeof(OwConsts), hipMemcpyHostToDevice, so.s));
+        HIP_OK(hipMemsetAsync(dck.p, 0, sizeof(double) * nck, so.s));
+        HIP_OK(hipMemsetAsync(dbe.p, 0xFF, sizeof(unsigned long long) * (1 + OW_TRAJ_BE_CAP), so.s));
+        HIP_OK(hipMemsetAsync(dbe.p, 0, sizeof(unsigned long long), so.s));
+        HIP_OK(hipMemsetAsync(dzero.p, 0, sizeof(uint32_t), so.s));
+        owdev::k_trem_state_dc<<<dim3(1), dim3(64), 0, so.s>>>(dstate.as<double>());
+        if (n_settle > 0) {
+            if (row) owdev::k_trem_settle_row<<<dim3(1), dim3(64), 0, so.s>>>(dk.as<OwConsts>(), dstate.as<double>(), n_settle);
+            else owdev::k_tremolo_wide<true><<<dim3(1), dim3(64), 0, so.s>>>(dk.as<OwConsts>(), dstate.as<double>(), nullptr, 1, n_settle, dzero.as<uint32_t>(), 1);
+        }
+        hipEvent_t e0, e1;
+        HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+        HIP_OK(hipEventRecord(e0, so.s));
+        for (long long t = 0; t < n; t += chunk) {
+            const long long m = std::min(chunk, n - t);
+            if (row) owdev::k_trem_traj_extend_row<<<dim3(1), dim3(64), 0, so.s>>>(dk.as<OwConsts>(), dstate.as<double>(), dr.as<double>() + t, t, m, dck.as<double>(), dbe.as<unsigned long long>());
+            else owdev::k_trem_traj_extend<<<dim3(1), dim3(64), 0, so.s>>>(dk.as<OwConsts>(), dstate.as<double>(), dr.as<double>() + t, t, m, dck.as<double>(), dbe.as<unsigned long long>());
+        }
+        HIP_OK(hipEventRecord(e1, so.s));
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(so.s));
+        float ms = 0.0f;
+        HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        if (ms_out) *ms_out = ms;
+        HIP_OK(hipMemcpy(r_out, dr.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(state_out, dstate.p, sizeof(double) * 18, hipMemcpyDeviceToHost));
+        if (ckpt_out) HIP_OK(hipMemcpy(ckpt_out, dck.p, sizeof(double) * nck, hipMemcpyDeviceToHost));
+        if (be_out) HIP_OK(hipMemcpy(be_out, dbe.p, sizeof(unsigned long long) * (1 + OW_TRAJ_BE_CAP), hipMemcpyDeviceToHost));
+        return 0;
+    } catch (const std::exception& ex) { (void)hipGetLastError(); set_err(std::string("ow_debug_trem_trajectory: ") + ex.what()); return -1; }
+}
 // Which literal-rebuild fast paths the host found usable for the melange preamp at chain rate `rate` (no device): bit 0 = the
 // R-independent leading block could be replayed (ml_ok), bit 1 = the factors have the sparsity pattern ow_melange_col.h compiles in.
 int ow_test_host_melange_paths(double rate) {

@@ -173,9 +173,10 @@ struct TremState {   // register-resident part; v / i_prev / i_pp live in TremPa
 // BE fallback (dense v_d, :2798-2817).  Returns true when converged within MAX_ITER (=50).
 // SK: kk0 points into the constant block (wave-uniform): the kernel is re-read per sweep through an opaque SCALAR zero, i.e. by two
 // s_load_dwordx16 into SGPRs, instead of 48 LDS reads per sweep through an opaque vector zero.
+// One sweep: i_nl is advanced, true = this sweep met the convergence test.
 template <bool BE, bool SK = false>
-__device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk0)[4], double i_nl[4]) {
-    for (int iter = 0; iter < 50; ++iter) {
+OW_DEV bool trem_nr_sweep(const double p[4], const double (*__restrict__ kk0)[4], double i_nl[4]) {
+    {
         int z = 0, zs = 0;
         asm volatile("" : "+v"(z));   // opaque zero: K is re-read from LDS every sweep instead of held in 32 VGPRs
         asm volatile("" : "+s"(zs));
@@ -292,6 +293,12 @@ __device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk
             }
         }
     }
+    return false;
+}
+template <bool BE, bool SK = false>
+__device__ inline bool trem_nr(const double p[4], const double (*__restrict__ kk0)[4], double i_nl[4]) {
+    for (int iter = 0; iter < 50; ++iter)
+        if (trem_nr_sweep<BE, SK>(p, kk0, i_nl)) return true;
     return false;
 }
 

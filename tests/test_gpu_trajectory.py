@@ -305,3 +305,41 @@ def test_store_grows_and_configures(hiplib, oracle):
     finally:
         ow.tremolo_configure(0.0, -1.0)
         ow.load_library().ow_test_clear_settle_caches()
+
+
+def _traj_kernels(hiplib, sr, n_settle, n, chunk, row):
+    import ctypes as C
+    r = np.zeros(n, np.float64); st = np.zeros(18, np.float64)
+    ck = np.zeros((n // 4096 + 2) * 16, np.float64); be = np.zeros(1024, np.uint64)
+    ms = C.c_double(0.0)
+    rc = hiplib.ow_debug_trem_trajectory(C.c_double(sr), n_settle, n, chunk, row, r.ctypes.data, st.ctypes.data, ck.ctypes.data, be.ctypes.data,
+                                         C.addressof(ms), 0)
+    assert rc == 0, hiplib.ow_last_error()
+    return r, st, ck, be, ms.value
+
+
+@pytest.mark.parametrize("sr", [48000.0, 44100.0, 96000.0])
+def test_row_oscillator_kernels_equal_the_quad_lane_kernels(hiplib, sr):
+    """ow_trem_row.h (one system per wavefront: lanes = matrix rows, zero coefficients for the emitted sparsity, the usual pivot order as a
+    lane assignment, one branch per Newton sweep) against ow_trem_wide.h (the quad-lane step, itself bit-identical to the lane = engine
+    step and to the oracle): from DC_OP through the start-up transient -- where the junction limiter, the step cap and off-diagonal pivots
+    fire, i.e. the sweeps the row step hands to the generic sweep -- into the settled oscillation.  R, the state rows, every checkpoint
+    and the fallback list must be the same bits, for any cut into launches."""
+    n = 3 * 4096 + 1234
+    a = _traj_kernels(hiplib, sr, 0, n, 4096, 0)
+    b = _traj_kernels(hiplib, sr, 0, n, 4096, 1)
+    c = _traj_kernels(hiplib, sr, 0, n, 1000, 1)
+    for x in (b, c):
+        assert np.array_equal(a[0].view(np.uint64), x[0].view(np.uint64)), int(np.argmax(a[0] != x[0]))
+        assert np.array_equal(a[1].view(np.uint64), x[1].view(np.uint64)), (a[1], x[1])
+        assert np.array_equal(a[2].view(np.uint64), x[2].view(np.uint64))
+        assert np.array_equal(a[3], x[3])
+    # settled regime (the regime the store extends in): 2 s of settle with either kernel, then one launch each
+    n_settle = int(2 * (sr * 2 if sr < 88200.0 else sr))
+    d = _traj_kernels(hiplib, sr, n_settle, 8192, 8192, 0)
+    e = _traj_kernels(hiplib, sr, n_settle, 8192, 8192, 1)
+    assert np.array_equal(d[0].view(np.uint64), e[0].view(np.uint64))
+    assert np.array_equal(d[1].view(np.uint64), e[1].view(np.uint64))
+    assert np.array_equal(d[2].view(np.uint64), e[2].view(np.uint64))
+    assert d[0].min() > 10.0 and d[0].max() <= 1.0e6 and d[0].max() / d[0].min() > 3.0      # the cell swings (tremolo.rs:128-146)
+    print(f"\n[oscillator step at {sr:.0f} Hz] quad-lane {d[4] * 1e3 / 8192:.3f} us, row {e[4] * 1e3 / 8192:.3f} us")
