@@ -30,6 +30,7 @@
 #include "ow_features.h"
 #include "ow_trem_wide.h"
 #include "ow_trem_row.h"
+#include "ow_chain_row.h"
 #include "ow_audit.h"
 #include "ow_midi_kernels.h"
 #include "ow_chain_wide.h"
@@ -216,6 +217,7 @@ struct Switches {
     int voice_steal = 1;                       // OW_VOICE_STEAL=0: no steal variant of the steady voice kernel (k_voice renders every crossfade)
     int voice_attack = 1;                      // OW_VOICE_ATTACK=0: no attack variant of the steady voice kernel (engines in onset / noise phases go to the general kernel)
     bool force_general = false;                // test / probe hook: every engine's slot voices go to the general voice kernel (what it costs without any phase active)
+    int chain_row = -1;                        // OW_CHAIN_ROW=0/1: the fused chain launch with one solver state per row of sixteen lanes (k_chain_row) never / whenever the chain is fused; -1: ranges of <= 1 024 engines
     int chain_stream = -1;                     // OW_CHAIN_STREAM=0/1: preamp + output stage of a big oversampled pool as one launch (k_chain_stream); -1: when the block goes to a pinned host block
     int out_direct = -1;                       // OW_OUT_DIRECT=0/1: output stage stores straight into a pinned host block (ow_host_alloc) instead of d_out + copy; -1: default
     bool pipe_overlap = false;
@@ -244,6 +246,7 @@ struct Switches {
         w.voice_release = flag("OW_VOICE_RELEASE", 1) != 0;
         w.midi_apply_early = flag("OW_MIDI_APPLY_EARLY", 1) != 0;
         w.midi_device = flag("OW_MIDI_DEVICE", -1); if (w.midi_device > 1 || w.midi_device < -1) w.midi_device = -1;
+        w.chain_row = flag("OW_CHAIN_ROW", -1); if (w.chain_row > 1 || w.chain_row < -1) w.chain_row = -1;
         w.chain_stream = flag("OW_CHAIN_STREAM", -1); if (w.chain_stream > 1 || w.chain_stream < -1) w.chain_stream = -1;
         w.out_direct = flag("OW_OUT_DIRECT", -1); if (w.out_direct > 1 || w.out_direct < -1) w.out_direct = -1;
         w.host_profile = std::getenv("OW_HOST_PROFILE") != nullptr;
@@ -1085,6 +1088,8 @@ static inline bool chain_fused(const ow_pool* p, int ne) {
     if (p->hc.preamp_kind != OW_PREAMP_LEGACY8 || p->power_amp_kind != OW_POWER_AMP_BEHAVIORAL) return false;
     return p->sw.chain_fused >= 0 ? p->sw.chain_fused == 1 : preamp_wide(p, ne);
 }
+// ... with the row step (k_chain_row): while every preamp wavefront (two engines) has a SIMD of its own
+static inline bool chain_row(const ow_pool* p, int ne) { return p->sw.chain_row >= 0 ? p->sw.chain_row == 1 : ne <= 1024; }
 // ---- tremolo phase groups (see ow_pool) ---------------------------------------------------------------------------------
 void trem_groups_changed(ow_pool* p) {
     HIP_OK(hipMemcpyAsync(p->d_lead, p->h_lead, sizeof(uint32_t) * p->I, hipMemcpyHostToDevice, p->stream));
@@ -1707,7 +1712,12 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         // Default: when the block goes to a pinned host block (the point of it: no copy trails the launch); OW_CHAIN_STREAM=1 always.
         const bool streamed = chain && !fused && sne > 0 && p->hc.oversample && p->hc.preamp_kind == OW_PREAMP_LEGACY8 && p->power_amp_kind == OW_POWER_AMP_BEHAVIORAL &&
                               !preamp_wide(p, sne) && (p->sw.chain_stream < 0 ? out_direct != nullptr : p->sw.chain_stream == 1);
-        if (fused) {           // small pool: preamp and output stage as two wavefronts of one workgroup (ow_chain_wide.h)
+        if (fused && chain_row(p, sne)) {      // ... with one solver state per row of sixteen lanes (ow_chain_row.h): four preamp wavefronts + the output-stage one per eight engines
+            if (p->hc.oversample)
+                owdev::k_chain_row<true><<<dim3((sne + 7) / 8), dim3(320), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, tsrc, p->d_pre, p->d_out, I, L, Lcap, L, se0, sne);
+            else
+                owdev::k_chain_row<false><<<dim3((sne + 7) / 8), dim3(320), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, tsrc, p->d_pre, p->d_out, I, L, Lcap, L, se0, sne);
+        } else if (fused) {    // small pool: preamp and output stage as two wavefronts of one workgroup (ow_chain_wide.h)
             if (p->hc.oversample)
                 owdev::k_chain_fused<true><<<dim3((sne + 7) / 8), dim3(128), 0, s>>>(p->dK, p->d_cs, p->d_args, p->d_eout, p->d_sum, tsrc, p->d_pre, p->d_out, I, L, Lcap, L, se0, sne);
             else
@@ -3116,6 +3126,7 @@ int ow_test_pool_set_switch(ow_pool* p, const char* name, int value) {
     else if (n == "midi_apply_early") w.midi_apply_early = value != 0;
     else if (n == "force_general") { w.force_general = value != 0; p->lists_valid = false; }
     else if (n == "chain_stream") w.chain_stream = value < 0 ? -1 : (value != 0);
+    else if (n == "chain_row") w.chain_row = value < 0 ? -1 : (value != 0);
     else return -1;                                       // (trem_traj / trem_cache / pipe shape the pool at creation: environment only)
     return 0;
 }
@@ -3127,6 +3138,7 @@ int ow_test_pool_get_switch(const ow_pool* p, const char* name) {
     if (n == "trem_wide") return w.trem_wide;
     if (n == "preamp_wide") return w.preamp_wide;
     if (n == "chain_fused") return w.chain_fused;
+    if (n == "chain_row") return w.chain_row;
     if (n == "mel_generic") return w.mel_generic;
     if (n == "mel_rank1") return w.mel_rank1;
     if (n == "mel_lds") return w.mel_lds;

@@ -153,7 +153,7 @@ OW_DEV double xor32(double x) {
     const int lo = __double2loint(x), hi = __double2hiint(x);
     const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
     const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    const bool low_half = threadIdx.x < 32;
+    const bool low_half = (threadIdx.x & 63) < 32;      // (lane of the wavefront: k_chain_row's preamp wavefronts are not wavefront 0 of their block)
     return __hiloint2double(low_half ? b[1] : b[0], low_half ? a[1] : a[0]);
 }
 

@@ -987,6 +987,61 @@ def test_chain_fused_is_bit_identical(hiplib, oracle):
     g.close(); c.close()
 
 
+def test_chain_row_is_bit_identical(hiplib, oracle):
+    """The smallest pools run the fused chain launch with ONE preamp state per row of sixteen lanes (k_chain_row, ow_chain_row.h: lane r =
+    matrix row r, one v_mov_b64_dpp per value that crosses lanes, the Newton sweeps of a wavefront's four states in one uniform loop, four
+    preamp wavefronts + the output-stage wavefront per eight engines) instead of the quad-lane k_chain_fused.  Same bits at the preamp
+    tap and at the output as k_chain_fused AND as the two-launch path -- tremolo at every depth incl. 0 (the LDR hysteresis never fires)
+    and 1, depth / volume / speaker-character ramps, reset of one engine, the steal pass, ragged block lengths incl. 1 and lengths that
+    are no multiple of the 16-sample chunk, an output NaN guard event and the blocks after it (the deferred preamp reset), at both rates;
+    pools of 11 (one full workgroup and a ragged one with an odd engine count: a preamp wavefront with one engine) and of 1."""
+    import openwurli_amd as ow
+    lengths = (512, 300, 1, 17, 64, 16, 15, 777, 512, 33)
+    for sr, n_eng in ((48000.0, 11), (96000.0, 11), (48000.0, 1)):
+        osr = 2 if sr < 88200.0 else 1
+        res = {}
+        for mode in ("two_launches", "quad", "row"):
+            g = ow.EnginePool(sr, n_eng)
+            g.set_sample_rate(sr)
+            g.set_switch("chain_fused", 0 if mode == "two_launches" else 1)
+            g.set_switch("chain_row", 1 if mode == "row" else 0)
+            for k in range(n_eng):
+                g[k].set_tremolo_depth(0.1 * k); g[k].set_volume(0.3 + 0.05 * k); g[k].set_speaker_character(0.08 * k)
+                for note in (40 + 3 * k, 60 + k, 72):
+                    g[k].note_on(note, 0.5 + 0.04 * k)
+            outs, pres, diags = [], [], []
+            hot = min(9, n_eng - 1)
+            for b, length in enumerate(lengths):
+                if b == 3:
+                    g[min(4, n_eng - 1)].set_tremolo_depth(1.0); g[min(7, n_eng - 1)].note_on(60 + 7, 1.0); g[min(5, n_eng - 1)].set_speaker_character(1.0)
+                if b == 5:
+                    g[hot].set_volume(1e308)                   # a non-finite output -> NaN guard -> deferred preamp / oversampler reset
+                if b == 6:
+                    g[min(2, n_eng - 1)].reset(); g[min(2, n_eng - 1)].note_on(55, 0.9); g[hot].set_volume(0.5)
+                outs.append(g.render(length).copy())
+                pres.append(g.preamp_out(length * osr).copy())
+                diags.append([(g[k].diag().output_nan_resets, g[k].diag().preamp_nan_resets) for k in sorted({min(2, n_eng - 1), hot})])
+            res[mode] = (outs, pres, diags)
+            g.close()
+        for mode in ("quad", "row"):
+            for b in range(len(lengths)):
+                assert np.array_equal(res["two_launches"][1][b], res[mode][1][b]), (sr, n_eng, mode, b, "preamp tap")
+                assert np.array_equal(res["two_launches"][0][b], res[mode][0][b]), (sr, n_eng, mode, b, "output")
+                assert res["two_launches"][2][b] == res[mode][2][b], (sr, n_eng, mode, b, "diag")
+        assert res["row"][2][-1][-1][0] >= 1                           # the guard did fire
+        assert max(float(np.abs(o).max()) for o in res["row"][0]) > 1e-3
+    # the default for a pool of one is the row kernel: against the oracle
+    g, c = ow.WurliEngine(48000.0), oracle.OracleEngine(48000.0)
+    for e in (g, c):
+        e.set_tremolo_depth(0.8); e.set_speaker_character(0.4)
+        for n in (45, 60, 64, 79):
+            e.note_on(n, 0.8)
+    for length in (64, 64, 128, 7, 512):
+        rep = oracle.parity_report(g.render(length), c.render(length), abs_floor=oracle.ABS_FLOOR_OUTPUT)
+        assert rep["n_bad"] == 0, (length, rep)
+    g.close(); c.close()
+
+
 def test_chain_stream_is_bit_identical(hiplib, oracle):
     """Big oversampled pools whose block goes to a pinned host block run preamp and output stage as ONE launch (k_chain_stream,
     ow_chain_stream.h: one wavefront per 32 engines alternates between the two per 64-sample chunk and stores the f32 rows straight into

@@ -3,11 +3,11 @@ import numpy as np
 sys.path.insert(0, os.getcwd())
 import openwurli_amd as ow
 sr = 48000.0
-for fused in (0, 1):
+for fused, row in ((0, 0), (1, 0), (1, 1)):
     for n_eng, buf in ((1, 64), (1, 512), (256, 512)):
         p = ow.EnginePool(sr, n_eng)
         p.set_sample_rate(sr)
-        p.set_switch("chain_fused", fused)
+        p.set_switch("chain_fused", fused); p.set_switch("chain_row", row)
         p.ensure_buffer_capacity(buf)
         if n_eng > 1: p.stagger_tremolo(n_eng)
         ow.tremolo_prefetch(sr, 8.0)
@@ -24,5 +24,5 @@ for fused in (0, 1):
             p.render(buf, to_host=(n_eng == 1)); ms.append(list(p.last_kernel_ms().values()))
         p.set_profiling(False)
         ms = np.mean(np.array(ms), axis=0)
-        print(f"fused {fused} engines {n_eng} buffer {buf}: wall/buffer {1e6*np.mean(lat):.0f} us (p50 {1e6*np.median(lat):.0f}); x real time {n_eng*buf/np.mean(lat)/sr:.1f}; kernels ms ops/voices/tremolo/preamp/post = {np.round(ms,3).tolist()}")
+        print(f"fused {fused} row {row} engines {n_eng} buffer {buf}: wall/buffer {1e6*np.mean(lat):.0f} us (p50 {1e6*np.median(lat):.0f}); x real time {n_eng*buf/np.mean(lat)/sr:.1f}; kernels ms ops/voices/tremolo/preamp/post = {np.round(ms,3).tolist()}")
         p.close()
