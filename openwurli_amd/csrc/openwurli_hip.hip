@@ -949,10 +949,19 @@ static inline bool job_voice_overlap(size_t n_jobs) {
     if (const char* env = std::getenv("OW_JOB_OVERLAP")) { if (env[0] == '0') return false; }
     return chain_wide(n_jobs) && job_chain_fused(n_jobs) && n_jobs <= 2048;
 }
+// OW_JOB_ROW=0: the fused job chain with a quad per solver state (k_job_chain_fused) instead of a row of sixteen lanes (k_job_chain_row:
+// five wavefronts per eight jobs -- while they all find a SIMD of their own beside the voice kernel)
+static inline bool job_chain_row(size_t n_jobs) {
+    if (const char* env = std::getenv("OW_JOB_ROW")) return env[0] != '0';
+    return n_jobs <= 1024;
+}
 static void launch_job_chain_legacy(const OwConsts* dK, const owdev::OwJobDev* d_jobs, const double* d_in, double* d_out, size_t n_jobs, long long n,
                                     long long stride, hipStream_t st, const int* voice_prog = nullptr) {
     if (voice_prog && !(chain_wide(n_jobs) && job_chain_fused(n_jobs))) throw std::runtime_error("job chain: overlap with the voices needs the fused chain");
-    if (chain_wide(n_jobs) && job_chain_fused(n_jobs))
+    if (chain_wide(n_jobs) && job_chain_fused(n_jobs) && job_chain_row(n_jobs))
+        owdev::k_job_chain_row<<<dim3((unsigned)((n_jobs + 7) / 8)), dim3(320), 0, st>>>(dK, d_jobs, d_in, d_out, (int)n_jobs, n, stride, voice_prog,
+                                                                                         voice_prog ? const_cast<int*>(voice_prog) + (n_jobs + 63) / 64 : nullptr);
+    else if (chain_wide(n_jobs) && job_chain_fused(n_jobs))
         owdev::k_job_chain_fused<<<dim3((unsigned)((n_jobs + 7) / 8)), dim3(128), 0, st>>>(dK, d_jobs, d_in, d_out, (int)n_jobs, n, stride, voice_prog,
                                                                                            voice_prog ? const_cast<int*>(voice_prog) + (n_jobs + 63) / 64 : nullptr);
     else if (chain_wide(n_jobs))

@@ -369,3 +369,136 @@ __global__ __launch_bounds__(320) void k_chain_row(const OwConsts* __restrict__ 
 }
 
 }  // namespace owdev
+
+namespace owdev {
+
+// k_job_chain_fused (ow_chain_wide.h) with the row step: eight jobs per workgroup, wavefronts 0-3 = up-sampler + the two preamp steps of
+// a sample for two jobs each (rows 0-1 main, rows 2-3 shadow), wavefront 4 = the rest of main.rs:445-496 one lane per job, a chunk behind.
+// Same arguments, same statements per job in the same order: bit-identical (tests/test_gpu_render_flags.py, OW_JOB_ROW=0/1).
+__global__ __launch_bounds__(320) void k_job_chain_row(const OwConsts* __restrict__ K, const OwJobDev* __restrict__ jobs, const volatile double* reed,
+                                                       double* __restrict__ out, int n_jobs, long long n, long long stride, const int* voice_prog,
+                                                       int* voice_err) {
+    __shared__ double tin[8 * (OW_FCHUNK + 1)];
+    __shared__ double ring[2][OW_FCHUNK * 2][8];               // preamp out at the chain rate: [slot][sample x phase][job of the block]
+    __shared__ double tout[8 * (OW_FCHUNK + 1)];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int jb = blockIdx.x * 8;
+    const int osr = K->oversample ? 2 : 1;
+    const long long n_chunks = (n + OW_FCHUNK - 1) / OW_FCHUNK;
+
+    if (wv < 4) {
+        const int row = lane >> 4, role = row >> 1;
+        const int jl = 2 * wv + (row & 1);
+        const int j = jb + jl;
+        const bool valid = j < n_jobs;
+        const OwJobDev jd = jobs[valid ? j : n_jobs - 1];
+        DkRowK R;
+        dk_row_consts(R, K, lane);
+        DkSt st;
+        double r_ldr = 1000000.0, g_ldr = 1.0 / 1000000.0, g_prev = g_ldr;
+        double us[3] = {0, 0, 0};
+        dk_dc_reset(K, r_ldr, st);                               // DkPreamp::new(preamp_sr); reset(); set_ldr_resistance(r_ldr)  (main.rs:432-441)
+        {
+            const double r_new = fmax(jd.r_ldr, 1000.0);
+            if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = 1.0 / r_new; }
+        }
+        const double sgn = role ? -1.0 : 1.0;
+        bool gave_up = false;
+        auto preamp_step = [&](double x) -> double {
+            const double o = dk_step_row(st, R, lane, x, g_ldr, g_prev);
+            g_prev = g_ldr;
+            const double other = xor32(o);
+            double res = (o - other) * sgn;
+            if (!isfinite(res)) {
+                dk_dc_reset(K, r_ldr, st); g_ldr = 1.0 / r_ldr; g_prev = g_ldr;
+                res = 0.0;
+            }
+            return res;
+        };
+        const int f_jl = 2 * wv + ((lane >> 4) & 1), f_n = lane & 15;
+        for (long long c = 0; c <= n_chunks; ++c) {
+            if (c < n_chunks) {
+                const long long base = c * OW_FCHUNK;
+                const int cn = (int)((n - base) < OW_FCHUNK ? (n - base) : OW_FCHUNK);
+                if (voice_prog && !gave_up) {   // the voices of these jobs are being rendered beside this kernel: wait for the chunk (see k_job_chain_fused)
+                    const int need = (int)(base + cn);
+                    long spins = 0;
+                    while (__hip_atomic_load(&voice_prog[jb >> 6], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                        __builtin_amdgcn_s_sleep(32);
+                        if (++spins > 5000000L) { gave_up = true; if (lane == 0) atomicOr(voice_err, 1); break; }
+                    }
+                }
+                if (lane < 32) {
+                    double x = 0.0;
+                    if (jb + f_jl < n_jobs && f_n < cn) x = reed[(size_t)(jb + f_jl) * stride + base + f_n];
+                    tin[f_jl * (OW_FCHUNK + 1) + f_n] = x;
+                }
+                OW_WAVE_SYNC();
+                double (*slot)[8] = ring[c & 1];
+                for (int sidx = 0; sidx < cn; ++sidx) {
+                    const double x = tin[jl * (OW_FCHUNK + 1) + sidx];
+                    if (osr == 2) {                                  // main.rs:445-466: per-sample up(1) -> 2x process (-> down(1) on the output wavefront)
+                        const double y = allpass3(R.oc0, R.oc1, R.oc2, us, x);      // branch A on even lanes, B on odd ones
+                        const double in[2] = {role ? 0.0 : rowb<0>(y), role ? 0.0 : rowb<1>(y)};
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const double pk = preamp_step(in[k]);
+                            if (role == 0 && (lane & 15) == 0) slot[sidx * 2 + k][jl] = pk;
+                        }
+                    } else {
+                        const double pk = preamp_step(role ? 0.0 : x);
+                        if (role == 0 && (lane & 15) == 0) slot[sidx * 2][jl] = pk;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- the output-stage wavefront: lanes 0..7 own a job each, the others shadow them
+    const int jl = lane & 7;
+    const int j = jb + jl;
+    const bool valid = j < n_jobs;
+    const OwJobDev jd = jobs[valid ? j : n_jobs - 1];
+    const double sr = K->sr;
+    double da[3] = {0, 0, 0}, db[3] = {0, 0, 0}, dd = 0.0;
+    SpeakerSt sp;
+    sp.character = 1.0; sp.ts = 0.0;                         // Speaker::new(sr); set_character(c)  (main.rs:483-484)
+    sp.hpf.s1 = sp.hpf.s2 = sp.lpf.s1 = sp.lpf.s2 = 0.0;
+    speaker_update(sp, sr);
+    speaker_set_character(sp, jd.speaker, sr);
+    const double vol2_a = jd.volume;
+    for (long long c = 0; c <= n_chunks; ++c) {
+        if (c >= 1) {
+            const long long base = (c - 1) * OW_FCHUNK;
+            const int cn = (int)((n - base) < OW_FCHUNK ? (n - base) : OW_FCHUNK);
+            const double (*slot)[8] = ring[(c - 1) & 1];
+            for (int sidx = 0; sidx < cn; ++sidx) {
+                double pre;
+                if (osr == 2) {
+                    const double fa = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, slot[sidx * 2][jl]);
+                    const double fb = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, slot[sidx * 2 + 1][jl]);
+                    pre = (fa + dd) * 0.5;
+                    dd = fb;
+                } else {
+                    pre = slot[sidx * 2][jl];
+                }
+                // main.rs:487-496: volume^2 (audio taper) -> optional power amp at base rate -> speaker -> PSG
+                const double att = pre * vol2_a * vol2_a;
+                const double amp = jd.poweramp ? power_amp(att) : att;
+                const double y = speaker_process(sp, amp, K->spk_thermal_alpha) * 7.498942093324558;
+                if (lane < 8) tout[jl * (OW_FCHUNK + 1) + sidx] = y;
+            }
+            OW_WAVE_SYNC();
+            for (int k = lane; k < 8 * OW_FCHUNK; k += 64) {
+                const int r = k / OW_FCHUNK, sm = k - r * OW_FCHUNK;
+                if (jb + r < n_jobs && sm < cn) out[(size_t)(jb + r) * stride + base + sm] = tout[r * (OW_FCHUNK + 1) + sm];
+            }
+            OW_WAVE_SYNC();
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace owdev

@@ -306,18 +306,22 @@ def test_chain_wide_is_bit_identical(hiplib, oracle):
         outs = {}
         # "1": the quad chain as preamp | output stage on two wavefronts (k_job_chain_fused) with the voices rendered BESIDE it on a second
         # stream (k_job_voice publishes its progress, the chain waits chunk by chunk); "1-after-voices": the same chain behind the voices
-        for wide in ("0", "1", "1-one-wavefront", "1-after-voices"):
+        # ("1" with few jobs is k_job_chain_row -- one solver state per row of sixteen lanes, four preamp wavefronts + the output-stage one per
+        # eight jobs, ow_chain_row.h; "1-quad" (OW_JOB_ROW=0) is the quad-lane k_job_chain_fused)
+        for wide in ("0", "1", "1-quad", "1-one-wavefront", "1-after-voices"):
             os.environ["OW_CHAIN_WIDE"] = wide[0]
             if wide in ("0", "1-one-wavefront"):
                 os.environ["OW_JOB_FUSED"] = "0"
             if wide == "1-after-voices":
                 os.environ["OW_JOB_OVERLAP"] = "0"
+            if wide == "1-quad":
+                os.environ["OW_JOB_ROW"] = "0"
             try:
                 outs[wide] = ow.batch_render(jobs, sr, 0.35)
             finally:
                 del os.environ["OW_CHAIN_WIDE"]
-                os.environ.pop("OW_JOB_FUSED", None); os.environ.pop("OW_JOB_OVERLAP", None)
-        for other in ("0", "1-one-wavefront", "1-after-voices"):
+                os.environ.pop("OW_JOB_FUSED", None); os.environ.pop("OW_JOB_OVERLAP", None); os.environ.pop("OW_JOB_ROW", None)
+        for other in ("0", "1-quad", "1-one-wavefront", "1-after-voices"):
             assert np.array_equal(outs[other], outs["1"]), (sr, other, np.max(np.abs(outs[other] - outs["1"])))
         for k in (0, 2, 4, 10):
             j = jobs[k]
