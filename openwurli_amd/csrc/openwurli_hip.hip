@@ -256,6 +256,7 @@ struct Switches {
 };
 
 struct TremTraj;   // shared Twin-T / CdS trajectory of one (device, chain rate), below
+std::atomic<uint64_t> g_ops_dropped{0};      // slot ops that found no room behind a device-side burst (render_range; OW_MIDI_APPLY_EARLY=0 only)
 
 }  // namespace
 
@@ -279,7 +280,7 @@ struct ow_engine {
     double sr = 0.0;            // host sample rate (steal crossfade length, engine.rs:318)
     uint8_t* dirty = nullptr;   // -> pool->dirty[index]: engine has pending ops / setter targets / changed masks
     uint8_t* dirty_any = nullptr;   // -> pool->dirty_any: some engine of the pool is dirty (lets a steady block skip the per-engine scans)
-    uint8_t* host_ops_any = nullptr; // -> pool->host_ops_any: some engine holds host-queued ops (a burst then stays on the host: queue order)
+    uint32_t* host_ops_any = nullptr; // -> pool->host_ops_any: NUMBER of engines that hold host-queued ops (a burst then stays on the host: queue order)
     // (test before set: sixteen MIDI threads storing to the one shared byte on every event bounce its cache line -- 520 ms instead of 40 for
     // a 16.7 M-event re-strike; a read of an already-set flag stays shared)
     void mark() { if (dirty) { *dirty = 1; if (!__atomic_load_n(dirty_any, __ATOMIC_RELAXED)) __atomic_store_n(dirty_any, (uint8_t)1, __ATOMIC_RELAXED); } }
@@ -290,7 +291,7 @@ struct ow_engine {
         OwOp op;
         op.type = type; op.slot = (uint8_t)slot; op.note = note; op.mlp = mlp ? 1 : 0; op.seed = seed; op.velocity = vel;
         ops.push_back(op);
-        if (host_ops_any && !__atomic_load_n(host_ops_any, __ATOMIC_RELAXED)) __atomic_store_n(host_ops_any, (uint8_t)1, __ATOMIC_RELAXED);
+        if (host_ops_any && ops.size() == 1) __atomic_fetch_add(host_ops_any, 1u, __ATOMIC_RELAXED);     // once per engine and block, not per event
         mark();
     }
 };
@@ -369,7 +370,8 @@ struct ow_pool {
     size_t ev_cap = 0;
     uint32_t* d_ev_begin = nullptr;   // [2][I] slice of every engine in the burst's list
     uint8_t vm_host_dirty = 1;
-    uint8_t host_ops_any = 0;         // some engine holds host-queued ops since the last whole-pool render
+    uint32_t host_ops_any = 0;        // engines that hold host-queued ops (counted where a queue becomes non-empty / is drained: a host that mixes
+                                      // single-engine events with partial renders gets the device bursts back as soon as the queues are empty)
     uint32_t* d_vm_ovf = nullptr;     // a device queue overflowed during the burst (the burst is then replayed on the host)
     uint32_t* h_vm_ovf = nullptr;     // pinned
     bool vm_download_pending = false; // d_vm -> h_vm is in flight (ev_vm)
@@ -659,24 +661,28 @@ struct TremTraj {
         new_cap = std::min((new_cap + OW_TRAJ_CK - 1) / OW_TRAJ_CK * OW_TRAJ_CK, cap_max);
         { std::lock_guard<std::mutex> lk(mu); if (new_cap <= cap) { grow_requested = false; return; } }
         HIP_OK(hipSetDevice(device));
-        double* nr = nullptr; double* nc = nullptr;
-        HIP_OK(hipMalloc(&nr, sizeof(double) * (new_cap + 64)));
-        if (hipMalloc(&nc, sizeof(double) * ckpt_doubles(new_cap)) != hipSuccess) { hipFree(nr); throw std::runtime_error("trajectory store: out of memory"); }
-        std::lock_guard<std::mutex> lk(mu);
-        if (new_cap <= cap) { hipFree(nr); hipFree(nc); grow_requested = false; return; }
-        for (void* q : retired) hipFree(q);            // replaced one growth ago
-        retired.clear();
-        HIP_OK(hipMemcpyAsync(nr, d_r, sizeof(double) * (len + 64 <= cap + 64 ? len + 64 : cap + 64), hipMemcpyDeviceToDevice, stream));
-        HIP_OK(hipMemcpyAsync(nc, d_ckpt, sizeof(double) * ckpt_doubles(cap), hipMemcpyDeviceToDevice, stream));
-        Mark& m = mark[head];
-        head = (head + 1) % NMARK;
-        HIP_OK(hipEventRecord(m.ev, stream));
-        m.end = len;
-        retired.push_back(d_r); retired.push_back(d_ckpt);
-        d_r = nr; d_ckpt = nc; cap = new_cap;
-        done = 0;                                      // everything has to be waited for again (the copy)
-        for (Mark& o : mark) if (&o != &m && o.end <= len) o.end = 0;     // older marks stand for data in the old buffer
-        grow_requested = false;
+        DevMem nr, nc;                                     // released on every exit path until the swap below takes them over
+        nr.alloc(sizeof(double) * (new_cap + 64));
+        nc.alloc(sizeof(double) * ckpt_doubles(new_cap));
+        std::vector<void*> to_free;                        // hipFree drains the whole device: never under `mu` (a render thread in cover() would wait for it)
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (new_cap <= cap) { grow_requested = false; return; }
+            to_free.swap(retired);                         // replaced one growth ago
+            HIP_OK(hipMemcpyAsync(nr.p, d_r, sizeof(double) * (len + 64 <= cap + 64 ? len + 64 : cap + 64), hipMemcpyDeviceToDevice, stream));
+            HIP_OK(hipMemcpyAsync(nc.p, d_ckpt, sizeof(double) * ckpt_doubles(cap), hipMemcpyDeviceToDevice, stream));
+            Mark& m = mark[head];
+            head = (head + 1) % NMARK;
+            HIP_OK(hipEventRecord(m.ev, stream));
+            m.end = len;
+            retired.push_back(d_r); retired.push_back(d_ckpt);
+            d_r = nr.as<double>(); d_ckpt = nc.as<double>(); cap = new_cap;
+            nr.p = nullptr; nc.p = nullptr;
+            done = 0;                                      // everything has to be waited for again (the copy)
+            for (Mark& o : mark) if (&o != &m && o.end <= len) o.end = 0;     // older marks stand for data in the old buffer
+            grow_requested = false;
+        }
+        for (void* q : to_free) hipFree(q);
     }
     // callers hold mu
     void extend_to(size_t end) {
@@ -1433,7 +1439,9 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
         }
         ow_pool::VoiceList& vl = *vls[l];
         keep[l] = fill[l] != 0 && vl.sig_valid && vl.n_blocks == fill[l] / 64 && vl.sig[0] == sig[0] && vl.sig[1] == sig[1] && vl.sig[2] == sig[2];
-        vl.sig[0] = sig[0]; vl.sig[1] = sig[1]; vl.sig[2] = sig[2]; vl.sig_valid = fill[l] != 0;
+        // the signature only stands for the DEVICE copy once that copy has been enqueued (below): if anything throws in between, no list keeps
+        // a signature whose upload never happened
+        vl.sig[0] = sig[0]; vl.sig[1] = sig[1]; vl.sig[2] = sig[2]; vl.sig_valid = keep[l];
         vl.n_blocks = fill[l] / 64;
     }
     auto pass2 = [&](size_t t) {
@@ -1444,7 +1452,10 @@ void build_voice_lists(ow_pool* p, int e0, int ne) {
     if (!((keep[0] || !fs) && (keep[1] || !fg) && (keep[2] || !fl) && (keep[3] || !fa))) Workers::get().each(T, pass2);
     hipStream_t st = p->stream;
     for (int l = 0; l < 4; ++l)
-        if (fill[l] && !keep[l]) HIP_OK(hipMemcpyAsync(vls[l]->d, vls[l]->h, sizeof(uint32_t) * fill[l], hipMemcpyHostToDevice, st));
+        if (fill[l] && !keep[l]) {
+            HIP_OK(hipMemcpyAsync(vls[l]->d, vls[l]->h, sizeof(uint32_t) * fill[l], hipMemcpyHostToDevice, st));
+            vls[l]->sig_valid = true;
+        }
     p->lists_e0 = e0; p->lists_ne = ne;
 }
 
@@ -1478,14 +1489,27 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         long long mn = p->min_birth;
         if (!whole) { mn = p->trem_clock; for (int k = 0; k < ne; ++k) if (p->h_birth[e0 + k] != OW_OFF_TRAJ) mn = std::min(mn, p->h_birth[e0 + k]); }
         if ((size_t)(p->trem_clock - mn) + (size_t)n_os > p->traj->cap_max) { trem_evict(p, e0, ne, n_os); mn = p->trem_clock; for (int k = 0; k < ne; ++k) if (p->h_birth[e0 + k] != OW_OFF_TRAJ) mn = std::min(mn, p->h_birth[e0 + k]); }
-        const size_t need = (size_t)(p->trem_clock - mn) + (size_t)n_os;
+        size_t need = (size_t)(p->trem_clock - mn) + (size_t)n_os;
         bool ask = false, must = false, feed = false;
         {
             std::lock_guard<std::mutex> lk(p->traj->mu);
             must = need > p->traj->cap;                        // the helper did not get there in time (it is asked a lead + 30 s before)
             if (!must && p->traj->wants_growth(need)) { p->traj->grow_requested = true; ask = true; }
         }
-        if (must) p->traj->grow_to(std::max(need, p->traj->cap * 2));       // cold: allocates on this thread, like the reference's buffer auto-grow
+        if (must) {                                            // cold: allocates on this thread, like the reference's buffer auto-grow
+            try { p->traj->grow_to(std::max(need, p->traj->cap * 2)); }
+            catch (const std::exception& ex) {
+                // no memory for a longer store (a crowded device): it stays as long as it is -- as the helper thread's failure path decides --
+                // and the engines that have outgrown it continue on oscillators of their own instead of retrying the allocation every block
+                (void)hipGetLastError();
+                { std::lock_guard<std::mutex> lk(p->traj->mu); p->traj->cap_max = p->traj->cap; p->traj->grow_requested = false; }
+                std::fprintf(stderr, "openwurli-hip: tremolo trajectory store stays at %zu samples (%s)\n", p->traj->cap, ex.what());
+                trem_evict(p, e0, ne, n_os);
+                mn = p->trem_clock;
+                for (int k = 0; k < ne; ++k) if (p->h_birth[e0 + k] != OW_OFF_TRAJ) mn = std::min(mn, p->h_birth[e0 + k]);
+                need = (size_t)(p->trem_clock - mn) + (size_t)n_os;
+            }
+        }
         if (ask) traj_grower().ask(p->traj);
         {
             std::lock_guard<std::mutex> lk(p->traj->mu);
@@ -1584,6 +1608,15 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
                     // behind it are appended there after the upload (rare: single events between a burst and the render)
                     if (!en->ops.empty()) {
                         const uint32_t room = OW_VM_OPS_MAX - nd, nh = (uint32_t)std::min<size_t>(en->ops.size(), room);
+                        if (nh < en->ops.size()) {
+                            // Only with OW_MIDI_APPLY_EARLY=0 (a burst's queue left for this render), a burst that filled the engine's 192
+                            // entries and single events behind it: the tail does not fit the device queue.  Counted and reported -- the
+                            // default schedule applies a burst's queue inside ow_pool_midi and never gets here with nd != 0.
+                            const uint64_t lost = g_ops_dropped.fetch_add(en->ops.size() - nh) + (en->ops.size() - nh);
+                            if (lost == en->ops.size() - nh)
+                                std::fprintf(stderr, "openwurli-hip: engine %zu: %zu queued slot ops do not fit behind a device-side MIDI burst (OW_MIDI_APPLY_EARLY=0) and are dropped\n",
+                                             (size_t)(e0 + k), en->ops.size() - nh);
+                        }
                         std::lock_guard<std::mutex> lk(p->op_tails_mu);
                         p->op_tails.push_back({(uint32_t)op_pos, (uint32_t)((e0 + k) * OW_VM_OPS_MAX) + nd, nh});
                         a.op_count = nd + nh;
@@ -1593,7 +1626,7 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
                     if (!p->vm_host_dirty) p->vm_host_dirty = 1;
                 }
                 op_pos += en->ops.size();
-                en->ops.clear();
+                if (!en->ops.empty()) { en->ops.clear(); __atomic_fetch_sub(&p->host_ops_any, 1u, __ATOMIC_RELAXED); }
                 a.set_flags = 0;
                 if (en->depth.pending) { a.set_flags |= 1u; a.depth_target = en->depth.pending_value; en->depth.pending = false; }
                 if (en->spk.pending)   { a.set_flags |= 2u; a.spk_target = en->spk.pending_value;     en->spk.pending = false; }
@@ -1652,7 +1685,6 @@ void render_range(ow_pool* p, int e0, int ne, size_t len, bool with_voices, floa
         }
         if (whole) p->dev_ops_pending = false;
     }
-    if (whole) __atomic_store_n(&p->host_ops_any, (uint8_t)0, __ATOMIC_RELAXED);
     if (p->profiling) HIP_OK(hipEventRecord(p->ev[1], st));
     const bool voices = with_voices && (any_main || any_steal);
     if (voices) {
@@ -2059,7 +2091,7 @@ void engine_host_reset(ow_engine* en) {  // host half of WurliEngine::reset (eng
     vm_init(*en->vm);                          // every slot Free, no voices, age counter 0, sustain up; nothing queued on the device either
     en->vm->mlp_enabled = mlp;                 // (a parameter, not state: reset() does not touch it)
     en->touch();
-    en->ops.clear();
+    if (!en->ops.empty()) { en->ops.clear(); if (en->host_ops_any) __atomic_fetch_sub(en->host_ops_any, 1u, __ATOMIC_RELAXED); }
     // snap_to(target): a pending retarget would ramp; the device snaps current := target, so drop the ramp request
     en->volume.pending = en->depth.pending = en->spk.pending = false;
 }
@@ -2770,15 +2802,27 @@ static bool midi_burst_on_device(ow_pool* p, const ow_midi_event* ev, size_t n) 
     p->vm_download_pending = true;
     std::memset(p->dirty.data() + e_lo, 1, e_hi - e_lo);           // masks / queues of these engines changed: the next render packs them
     __atomic_store_n(&p->dirty_any, (uint8_t)1, __ATOMIC_RELAXED);
+    // From here on the burst IS applied to the states (the download will overwrite the host's copy): whatever fails below, the caller must
+    // not replay the list on the host.  A failed early application leaves the queues to the next render, as OW_MIDI_APPLY_EARLY=0 does.
+    bool early = false, launched = false;
     if (p->sw.midi_apply_early && sc != st) {
-        owdev::k_apply_ops<<<dim3(e_hi - e_lo), dim3(64), 0, st>>>(p->dK, p->d_nt, p->d_vrec, nullptr, nullptr, nullptr, p->d_ops_fix, p->d_vm, (int)e_lo);
-        // the queue lengths go back to zero only when the download has them: the host recognises the engines of this burst by them
-        // (vm_settle_applied); a short k_apply_ops -- a burst of note-offs -- would otherwise finish, and clear, under the copy
-        HIP_OK(hipStreamWaitEvent(st, p->ev_vm, 0));
-        owdev::k_vm_clear_dev_ops<<<dim3((e_hi - e_lo + 255) / 256), dim3(256), 0, st>>>(p->d_vm, e_lo, e_hi);
-        HIP_OK(hipGetLastError());
-        p->dev_ops_applied = true; p->applied_lo = e_lo; p->applied_hi = e_hi;
-    } else p->dev_ops_pending = true;
+        try {
+            owdev::k_apply_ops<<<dim3(e_hi - e_lo), dim3(64), 0, st>>>(p->dK, p->d_nt, p->d_vrec, nullptr, nullptr, nullptr, p->d_ops_fix, p->d_vm, (int)e_lo);
+            HIP_OK(hipGetLastError());
+            launched = true;
+            // the queue lengths go back to zero only when the download has them: the host recognises the engines of this burst by them
+            // (vm_settle_applied); a short k_apply_ops -- a burst of note-offs -- would otherwise finish, and clear, under the copy
+            HIP_OK(hipStreamWaitEvent(st, p->ev_vm, 0));
+            owdev::k_vm_clear_dev_ops<<<dim3((e_hi - e_lo + 255) / 256), dim3(256), 0, st>>>(p->d_vm, e_lo, e_hi);
+            HIP_OK(hipGetLastError());
+            early = true;
+        } catch (const std::exception& ex) {
+            (void)hipGetLastError();
+            set_err(std::string("ow_pool_midi (device burst, early application): ") + ex.what());
+        }
+    }
+    if (early || launched) { p->dev_ops_applied = true; p->applied_lo = e_lo; p->applied_hi = e_hi; }
+    else p->dev_ops_pending = true;
     p->vm_bursts += 1;
     return true;
 }
