@@ -123,6 +123,17 @@ int ow_pool_read_tremolo_r(ow_pool*, double* out_host, size_t out_stride, size_t
  * that wants its first block after instantiation to find everything in place).  Returns the samples known complete, <0 on error. */
 int ow_tremolo_configure(int device, double capacity_seconds, double lead_seconds);
 long long ow_tremolo_prefetch(double sample_rate, int device, double seconds);
+/* Keeping the trajectory ACROSS PROCESSES -- the counterpart of the reference's in-process start-up caches (the OnceLock settles of
+ * dk_preamp/melange_adapter.rs:12-29; Tremolo::new's own settle, tremolo.rs:92-102), which a new process pays again.  Optional.
+ * ow_tremolo_export: write what the store of (device, chain rate of host rate `sample_rate`) holds, cut to a 4 096-sample checkpoint
+ * boundary, to `path` (8 bytes per chain sample).  Returns the samples written, <0 on error.
+ * ow_tremolo_import: load such a file into the store (created if it does not exist yet; its 2 s settle is taken from the file too).  The
+ * file is only accepted when THIS library would have produced it: same build id, same chain rate, same tremolo constants, payload
+ * checksum, and its first and last checkpoint segments regenerated on the device by the product kernel and compared bit for bit.
+ * Returns the samples the store took from the file (0: it already held more), <0 when the file is rejected (ow_last_error says why;
+ * the store is untouched and extends itself as usual).  Call it where allocating is allowed (instantiation). */
+long long ow_tremolo_export(double sample_rate, int device, const char* path);
+long long ow_tremolo_import(double sample_rate, int device, const char* path);
 /* HIP stream the pool launches on (hipStream_t as void*), for event timing by the caller. */
 void* ow_pool_stream(ow_pool*);
 /* Time (ms, HIP events on the pool stream) each kernel of the last ow_pool_render took:

@@ -7,9 +7,9 @@ importing works anywhere, constructing an engine without the built library or wi
 HIP device raises.
 """
 from .binding import load_library, library_path, OwError  # noqa: F401
-from .engine import WurliEngine, EnginePool, VoiceState, render_note, batch_render, normalize_scale, tremolo_prefetch, tremolo_configure  # noqa: F401
+from .engine import WurliEngine, EnginePool, VoiceState, render_note, batch_render, normalize_scale, tremolo_prefetch, tremolo_configure, tremolo_export, tremolo_import  # noqa: F401
 from . import features  # noqa: F401
 from . import alias_audit  # noqa: F401
 from . import midi_render  # noqa: F401
 
-__all__ = ["load_library", "library_path", "OwError", "WurliEngine", "EnginePool", "VoiceState", "render_note", "batch_render", "normalize_scale", "tremolo_prefetch", "tremolo_configure", "features", "alias_audit", "midi_render"]
+__all__ = ["load_library", "library_path", "OwError", "WurliEngine", "EnginePool", "VoiceState", "render_note", "batch_render", "normalize_scale", "tremolo_prefetch", "tremolo_configure", "tremolo_export", "tremolo_import", "features", "alias_audit", "midi_render"]

@@ -107,6 +107,8 @@ SYMBOLS = {
     "ow_pool_read_preamp_out": (C.c_int, [_VP, _VP, C.c_size_t, C.c_size_t]),
     "ow_pool_read_tremolo_r": (C.c_int, [_VP, _VP, C.c_size_t, C.c_size_t]),
     "ow_tremolo_prefetch": (C.c_longlong, [C.c_double, C.c_int, C.c_double]),
+    "ow_tremolo_export": (C.c_longlong, [C.c_double, C.c_int, C.c_char_p]),
+    "ow_tremolo_import": (C.c_longlong, [C.c_double, C.c_int, C.c_char_p]),
     "ow_tremolo_configure": (C.c_int, [C.c_int, C.c_double, C.c_double]),
     "ow_pool_stream": (_VP, [_VP]),
     "ow_pool_set_profiling": (None, [_VP, C.c_int]),

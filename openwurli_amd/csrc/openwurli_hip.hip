@@ -2476,6 +2476,177 @@ long long ow_tremolo_prefetch(double sample_rate, int device, double seconds) {
     } catch (const std::exception& ex) { set_err(std::string("ow_tremolo_prefetch: ") + ex.what()); return -1; }
 }
 
+// ---- trajectory persistence (ow_tremolo_export / ow_tremolo_import) -----------------------------------------------------------------
+// The reference's expensive start-up states are in-process caches (OnceLock: dk_preamp/melange_adapter.rs:12-29; Tremolo::new settles in
+// its constructor, tremolo.rs:92-102), paid once per process.  Here the analogue of that cost is the trajectory itself: a fresh process
+// that renders offline faster than the one oscillator steps waits for it.  A host may therefore keep the store across processes: export
+// writes r_ldr[0 .. L) (L = the store's length cut to a checkpoint boundary), the checkpoints, the fallback list and the settled rows;
+// import loads them into the store of (device, chain rate) -- after checking that THIS library would have produced them: same build, same
+// tremolo constants, payload checksum, and the first and the last 4 096-sample segment regenerated on the device by the product kernel
+// from the file's own settled rows / checkpoint and compared bit for bit (samples and the checkpoint behind them).
+namespace {
+struct TrajFileHeader {
+    char magic[8];                  // "OWTRAJ1\0"
+    uint32_t abi, ck;               // OW_ABI_VERSION, OW_TRAJ_CK
+    uint64_t build_id, consts_hash, rate_bits, len, be_settle, payload_sum;
+    double settled[18];
+    uint64_t reserved[4];
+};
+uint64_t fnv64(const void* data, size_t bytes, uint64_t h = 0xCBF29CE484222325ull) {
+    const unsigned char* b = static_cast<const unsigned char*>(data);
+    for (size_t i = 0; i < bytes; ++i) h = (h ^ b[i]) * 0x100000001B3ull;
+    return h;
+}
+uint64_t words_sum(const void* data, size_t bytes, uint64_t h) {     // order-dependent mix over 64-bit words (payloads are arrays of 8-byte items)
+    const uint64_t* w = static_cast<const uint64_t*>(data);
+    for (size_t i = 0; i < bytes / 8; ++i) { h ^= w[i]; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+    return h;
+}
+uint64_t traj_build_id() { static const char stamp[] = "openwurli-hip " __DATE__ " " __TIME__; return fnv64(stamp, sizeof stamp) ^ (uint64_t)OW_ABI_VERSION; }
+uint64_t traj_consts_hash(const OwConsts& c) {
+    uint64_t h = fnv64(c.t_a_neg, sizeof c.t_a_neg);
+    h = fnv64(c.t_s, sizeof c.t_s, h); h = fnv64(c.t_k, sizeof c.t_k, h); h = fnv64(c.t_s_ni, sizeof c.t_s_ni, h);
+    h = fnv64(c.t_a_neg_be, sizeof c.t_a_neg_be, h); h = fnv64(c.t_s_be, sizeof c.t_s_be, h); h = fnv64(c.t_k_be, sizeof c.t_k_be, h);
+    h = fnv64(c.t_s_ni_be, sizeof c.t_s_ni_be, h);
+    const double tail[4] = {c.ldr_attack, c.ldr_release, c.ln_r_max, c.ln_min_minus_max};
+    return fnv64(tail, sizeof tail, h);
+}
+struct FileCloser { std::FILE* f = nullptr; ~FileCloser() { if (f) std::fclose(f); } };
+// oscillator rows (I = 1 layout) in front of sample k * OW_TRAJ_CK, from checkpoint k (v[7] ip[4] ipp[4] env) and the sample before it
+void traj_state_from_ckpt(const double* ck, double r_before, double* rows) {
+    for (int i = 0; i < 7; ++i) rows[CS_T_V + i] = ck[i];
+    for (int i = 0; i < 4; ++i) { rows[CS_T_I + i] = ck[7 + i]; rows[CS_T_IP + i] = ck[11 + i]; }
+    rows[CS_T_ENV] = ck[15]; rows[CS_T_RLDR] = r_before;
+    const uint64_t z = 0; std::memcpy(&rows[CS_T_BE], &z, 8);
+}
+}  // namespace
+
+long long ow_tremolo_export(double sample_rate, int device, const char* path) {
+    try {
+        if (!(sample_rate > 0.0) || !path) throw std::runtime_error("bad argument");
+        HIP_OK(hipSetDevice(device));
+        std::unique_ptr<OwConsts> hc(new OwConsts()), k48(new OwConsts());
+        owhip::build_consts(*hc, sample_rate, OW_PREAMP_LEGACY8);
+        owhip::build_consts(*k48, 24000.0, OW_PREAMP_LEGACY8);
+        const Switches sw = Switches::from_env();
+        std::shared_ptr<TremTraj> t = traj_acquire(device, *hc, *k48, sw.trem_cache);
+        TrajFileHeader h;
+        std::memset(&h, 0, sizeof h);
+        std::memcpy(h.magic, "OWTRAJ1", 8);
+        h.abi = OW_ABI_VERSION; h.ck = OW_TRAJ_CK; h.build_id = traj_build_id(); h.consts_hash = traj_consts_hash(*hc);
+        std::memcpy(&h.rate_bits, &hc->os_sr, 8);
+        std::vector<double> r, ck;
+        std::vector<unsigned long long> be(1 + OW_TRAJ_BE_CAP);
+        {
+            std::lock_guard<std::mutex> lk(t->mu);
+            HIP_OK(hipStreamSynchronize(t->stream));                   // everything enqueued has been produced
+            const size_t L = t->len / OW_TRAJ_CK * OW_TRAJ_CK;
+            if (L == 0) throw std::runtime_error("the store holds less than one checkpoint segment");
+            h.len = L; h.be_settle = t->be_settle;
+            r.resize(L); ck.resize((L / OW_TRAJ_CK + 1) * OW_TRAJ_CKD);
+            HIP_OK(hipMemcpy(r.data(), t->d_r, sizeof(double) * L, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(ck.data(), t->d_ckpt, sizeof(double) * ck.size(), hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(be.data(), t->d_be, sizeof(unsigned long long) * be.size(), hipMemcpyDeviceToHost));
+        }
+        // events of samples beyond L belong to what is not exported
+        { size_t k = 0; const size_t n = (size_t)std::min<unsigned long long>(be[0], OW_TRAJ_BE_CAP);
+          for (size_t i = 0; i < n; ++i) if (be[1 + i] < h.len) be[1 + k++] = be[1 + i];
+          for (size_t i = k; i < OW_TRAJ_BE_CAP; ++i) be[1 + i] = ~0ull;
+          be[0] = k; }
+        traj_state_from_ckpt(ck.data(), 1000000.0, h.settled);         // the settled rows ARE checkpoint 0 (the cell at rest: r_ldr = 1 MOhm)
+        std::memcpy(&h.settled[17], &h.be_settle, 8);
+        h.payload_sum = words_sum(be.data(), sizeof(unsigned long long) * be.size(), words_sum(ck.data(), sizeof(double) * ck.size(), words_sum(r.data(), sizeof(double) * r.size(), 0x0123456789ABCDEFull)));
+        FileCloser fc;
+        fc.f = std::fopen(path, "wb");
+        if (!fc.f) throw std::runtime_error(std::string("cannot open ") + path);
+        if (std::fwrite(&h, sizeof h, 1, fc.f) != 1 || std::fwrite(r.data(), sizeof(double), r.size(), fc.f) != r.size() ||
+            std::fwrite(ck.data(), sizeof(double), ck.size(), fc.f) != ck.size() || std::fwrite(be.data(), sizeof(unsigned long long), be.size(), fc.f) != be.size())
+            throw std::runtime_error("short write");
+        return (long long)h.len;
+    } catch (const std::exception& ex) { (void)hipGetLastError(); set_err(std::string("ow_tremolo_export: ") + ex.what()); return -1; }
+}
+
+long long ow_tremolo_import(double sample_rate, int device, const char* path) {
+    try {
+        if (!(sample_rate > 0.0) || !path) throw std::runtime_error("bad argument");
+        HIP_OK(hipSetDevice(device));
+        std::unique_ptr<OwConsts> hc(new OwConsts()), k48(new OwConsts());
+        owhip::build_consts(*hc, sample_rate, OW_PREAMP_LEGACY8);
+        owhip::build_consts(*k48, 24000.0, OW_PREAMP_LEGACY8);
+        FileCloser fc;
+        fc.f = std::fopen(path, "rb");
+        if (!fc.f) throw std::runtime_error(std::string("cannot open ") + path);
+        TrajFileHeader h;
+        if (std::fread(&h, sizeof h, 1, fc.f) != 1 || std::memcmp(h.magic, "OWTRAJ1", 8) != 0) throw std::runtime_error("not a trajectory file");
+        uint64_t rate_bits; std::memcpy(&rate_bits, &hc->os_sr, 8);
+        if (h.abi != OW_ABI_VERSION || h.ck != OW_TRAJ_CK || h.build_id != traj_build_id()) throw std::runtime_error("written by another build of the library");
+        if (h.rate_bits != rate_bits) throw std::runtime_error("written for another chain rate");
+        if (h.consts_hash != traj_consts_hash(*hc)) throw std::runtime_error("written with other tremolo constants");
+        const size_t L = (size_t)h.len;
+        if (L == 0 || L % OW_TRAJ_CK != 0 || L > (size_t)4.0e9) throw std::runtime_error("bad length");
+        std::vector<double> r(L), ck((L / OW_TRAJ_CK + 1) * OW_TRAJ_CKD);
+        std::vector<unsigned long long> be(1 + OW_TRAJ_BE_CAP);
+        if (std::fread(r.data(), sizeof(double), r.size(), fc.f) != r.size() || std::fread(ck.data(), sizeof(double), ck.size(), fc.f) != ck.size() ||
+            std::fread(be.data(), sizeof(unsigned long long), be.size(), fc.f) != be.size())
+            throw std::runtime_error("truncated file");
+        if (h.payload_sum != words_sum(be.data(), sizeof(unsigned long long) * be.size(), words_sum(ck.data(), sizeof(double) * ck.size(), words_sum(r.data(), sizeof(double) * r.size(), 0x0123456789ABCDEFull))))
+            throw std::runtime_error("checksum mismatch");
+        // ---- would this library have produced it?  Segment 0 from the file's settled rows, the last segment from its checkpoint.
+        {
+            DevMem dk, dstate, dr, dck, dbe;
+            dk.alloc(sizeof(OwConsts)); dstate.alloc(sizeof(double) * 18); dr.alloc(sizeof(double) * (OW_TRAJ_CK + 64));
+            const size_t nck = TremTraj::ckpt_doubles(L);
+            dck.alloc(sizeof(double) * nck); dbe.alloc(sizeof(unsigned long long) * (1 + OW_TRAJ_BE_CAP));
+            HIP_OK(hipMemcpy(dk.p, hc.get(), sizeof(OwConsts), hipMemcpyHostToDevice));
+            std::vector<double> got(OW_TRAJ_CK), gck(OW_TRAJ_CKD);
+            const size_t K = L / OW_TRAJ_CK;
+            for (int pass = 0; pass < 2; ++pass) {
+                const size_t seg = pass == 0 ? 0 : K - 1;
+                if (pass == 1 && seg == 0) break;
+                double rows[18];
+                if (seg == 0) { std::memcpy(rows, h.settled, sizeof rows); const uint64_t z = 0; std::memcpy(&rows[17], &z, 8); }
+                else traj_state_from_ckpt(ck.data() + seg * OW_TRAJ_CKD, r[seg * OW_TRAJ_CK - 1], rows);
+                HIP_OK(hipMemcpy(dstate.p, rows, sizeof rows, hipMemcpyHostToDevice));
+                HIP_OK(hipMemset(dbe.p, 0, sizeof(unsigned long long) * (1 + OW_TRAJ_BE_CAP)));
+                owdev::k_trem_traj_extend_row<<<dim3(1), dim3(64)>>>(dk.as<OwConsts>(), dstate.as<double>(), dr.as<double>(), (long long)(seg * OW_TRAJ_CK),
+                                                                      (long long)OW_TRAJ_CK, dck.as<double>(), dbe.as<unsigned long long>());
+                HIP_OK(hipGetLastError());
+                HIP_OK(hipMemcpy(got.data(), dr.p, sizeof(double) * OW_TRAJ_CK, hipMemcpyDeviceToHost));
+                HIP_OK(hipMemcpy(gck.data(), dck.as<double>() + (seg + 1) * OW_TRAJ_CKD, sizeof(double) * OW_TRAJ_CKD, hipMemcpyDeviceToHost));
+                if (std::memcmp(got.data(), r.data() + seg * OW_TRAJ_CK, sizeof(double) * OW_TRAJ_CK) != 0 ||
+                    std::memcmp(gck.data(), ck.data() + (seg + 1) * OW_TRAJ_CKD, sizeof(double) * OW_TRAJ_CKD) != 0)
+                    throw std::runtime_error("the regenerated segment differs from the file's");
+            }
+        }
+        // ---- the settled rows spare the new store its settle; then the store takes what it does not have yet
+        const Switches sw = Switches::from_env();
+        if (sw.trem_cache) {
+            TremSettled ts;
+            std::memcpy(ts.rows, h.settled, sizeof ts.rows);
+            std::lock_guard<std::mutex> lk(g_mel_mu);
+            g_trem_settled.emplace(std::make_pair(device, rate_bits), ts);        // (an existing entry stays: it was computed here)
+        }
+        std::shared_ptr<TremTraj> t = traj_acquire(device, *hc, *k48, sw.trem_cache);
+        if (t->be_settle != h.be_settle) throw std::runtime_error("settled state differs from this library's");
+        if (L > t->cap_max) throw std::runtime_error("longer than the store's configured capacity (ow_tremolo_configure)");
+        t->grow_to(L);
+        std::lock_guard<std::mutex> lk(t->mu);
+        HIP_OK(hipStreamSynchronize(t->stream));
+        if (L > t->cap) throw std::runtime_error("the store could not grow to the file's length");
+        if (L <= t->len) return 0;                                         // the store already holds more
+        const size_t from = t->len / OW_TRAJ_CK * OW_TRAJ_CK;               // whole segments from the checkpoint at or below the store's end (same bits where they overlap)
+        HIP_OK(hipMemcpy(t->d_r + from, r.data() + from, sizeof(double) * (L - from), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(t->d_ckpt + from / OW_TRAJ_CK * OW_TRAJ_CKD, ck.data() + from / OW_TRAJ_CK * OW_TRAJ_CKD, sizeof(double) * (L / OW_TRAJ_CK - from / OW_TRAJ_CK + 1) * OW_TRAJ_CKD, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(t->d_be, be.data(), sizeof(unsigned long long) * be.size(), hipMemcpyHostToDevice));
+        double rows[18];
+        traj_state_from_ckpt(ck.data() + L / OW_TRAJ_CK * OW_TRAJ_CKD, r[L - 1], rows);
+        HIP_OK(hipMemcpy(t->d_state, rows, sizeof rows, hipMemcpyHostToDevice));
+        t->len = L; t->done = L;
+        t->target = std::max(t->target, L);
+        return (long long)L;
+    } catch (const std::exception& ex) { (void)hipGetLastError(); set_err(std::string("ow_tremolo_import: ") + ex.what()); return -1; }
+}
+
 // Capacity and lead of the trajectory stores of `device` (seconds of audio): capacity_seconds = how old an engine may grow (time since
 // new / reset / set_sample_rate) before it leaves the shared trajectory for an oscillator of its own (default 1 800; <= 0 restores it);
 // lead_seconds = how far the store is kept ahead of its oldest reader in the background (default 60; 0 = only the block ahead; < 0

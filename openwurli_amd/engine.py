@@ -356,6 +356,27 @@ def tremolo_prefetch(sample_rate, seconds, device=0):
     return int(n)
 
 
+def tremolo_export(sample_rate, path, device=0):
+    """``ow_tremolo_export``: write the trajectory store of this host rate (cut to a checkpoint boundary) to ``path``.  Returns the number
+    of chain-rate samples written."""
+    lib = binding.load_library()
+    n = lib.ow_tremolo_export(float(sample_rate), int(device), str(path).encode())
+    if n < 0:
+        raise OwError(binding.take_error(lib))
+    return int(n)
+
+
+def tremolo_import(sample_rate, path, device=0):
+    """``ow_tremolo_import``: load a file written by :func:`tremolo_export` into the store of this host rate, after the library has checked
+    that it would have produced the same samples itself (build id, rate, constants, checksum, two regenerated checkpoint segments).
+    Returns the samples taken from the file (0: the store already held more); raises OwError when the file is rejected."""
+    lib = binding.load_library()
+    n = lib.ow_tremolo_import(float(sample_rate), int(device), str(path).encode())
+    if n < 0:
+        raise OwError(binding.take_error(lib))
+    return int(n)
+
+
 def tremolo_configure(capacity_seconds=0.0, lead_seconds=-1.0, device=0):
     """``ow_tremolo_configure``: how old an engine may grow on the shared trajectory (seconds since its new / reset; <= 0: the default,
     1 800) and how far the store runs ahead of its oldest reader in the background (seconds; < 0: the default, 60)."""

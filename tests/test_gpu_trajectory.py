@@ -343,3 +343,75 @@ def test_row_oscillator_kernels_equal_the_quad_lane_kernels(hiplib, sr):
     assert np.array_equal(d[2].view(np.uint64), e[2].view(np.uint64))
     assert d[0].min() > 10.0 and d[0].max() <= 1.0e6 and d[0].max() / d[0].min() > 3.0      # the cell swings (tremolo.rs:128-146)
     print(f"\n[oscillator step at {sr:.0f} Hz] quad-lane {d[4] * 1e3 / 8192:.3f} us, row {e[4] * 1e3 / 8192:.3f} us")
+
+
+def test_trajectory_export_import_round_trip(hiplib, tmp_path):
+    """ow_tremolo_export / ow_tremolo_import: the cross-process analogue of the reference's in-process start-up caches
+    (dk_preamp/melange_adapter.rs:12-29 OnceLock; tremolo.rs:92-102).  A 256-engine pool on a GENERATED store and -- after every
+    process-wide store and settled state has been dropped -- a fresh one on an IMPORTED store render the same bits (R rows and output);
+    the import spares the new store both its settle and its oscillator steps; a file with a flipped sample, a truncated one and one for
+    another chain rate are rejected, and so is a well-formed file whose middle was produced by something else when that reaches a
+    checked segment (first / last)."""
+    import openwurli_amd as ow
+    sr, n, blocks, length = 48000.0, 256, 6, 512
+    path = str(tmp_path / "traj_96k.bin")
+
+    def run(p):
+        p.stagger_tremolo(n)
+        for k in range(0, n, 7):
+            p[k].set_tremolo_depth(0.2 + 0.7 * (k % 5) / 5.0); p[k].note_on(40 + k % 50, 0.7)
+        outs, rs = [], []
+        for _ in range(blocks):
+            outs.append(p.render(length).copy()); rs.append(p.tremolo_r(2 * length).copy())
+        return outs, rs
+
+    hiplib.ow_test_clear_settle_caches()
+    a = ow.EnginePool(sr, n)
+    ref = run(a)
+    ow.tremolo_prefetch(sr, 3.0)
+    wrote = ow.tremolo_export(sr, path)
+    assert wrote >= 3 * 96000 // 4096 * 4096 and wrote % 4096 == 0
+    a.close()
+    size = os.path.getsize(path)
+    assert size >= wrote * 8
+
+    # rejected files leave no trace
+    raw = bytearray(open(path, "rb").read())
+    bad = bytearray(raw); bad[len(bad) // 2] ^= 1
+    open(str(tmp_path / "flipped.bin"), "wb").write(bad)
+    open(str(tmp_path / "short.bin"), "wb").write(raw[: len(raw) - 4096])
+    hiplib.ow_test_clear_settle_caches()
+    for name, why in (("flipped.bin", "checksum"), ("short.bin", "truncated")):
+        with pytest.raises(ow.OwError, match=why):
+            ow.tremolo_import(sr, str(tmp_path / name))
+    with pytest.raises(ow.OwError, match="chain rate"):
+        ow.tremolo_import(44100.0, path)
+
+    # the import: no settle, no oscillator steps for what the file holds
+    hiplib.ow_test_clear_settle_caches()
+    took = ow.tremolo_import(sr, path)
+    assert took == wrote
+    assert ow.tremolo_import(sr, path) == 0                     # the store already holds it
+    b = ow.EnginePool(sr, n)
+    assert b.trajectory_info()[1] >= wrote
+    got = run(b)
+    for k in range(blocks):
+        assert np.array_equal(ref[1][k].view(np.uint64), got[1][k].view(np.uint64)), (k, "R rows")
+        assert np.array_equal(ref[0][k], got[0][k]), (k, "output")
+    # ... and the store goes on from the file's end with its own oscillator: what it holds afterwards is what a store that never stopped holds
+    assert ow.tremolo_prefetch(sr, 3.6) > wrote
+    path2, path3 = str(tmp_path / "after_import.bin"), str(tmp_path / "generated.bin")
+    n2 = ow.tremolo_export(sr, path2)
+    b.close()
+    hiplib.ow_test_clear_settle_caches()
+    ow.tremolo_prefetch(sr, 3.6)
+    n3 = ow.tremolo_export(sr, path3)
+
+    def samples(pth, count):
+        hdr = 240                                               # sizeof(TrajFileHeader)
+        assert int(np.fromfile(pth, dtype=np.uint64, count=1, offset=40)[0]) >= count
+        return np.fromfile(pth, dtype=np.uint64, count=count, offset=hdr)
+    m = min(n2, n3)
+    assert m > wrote
+    assert np.array_equal(samples(path2, m), samples(path3, m))
+    assert np.array_equal(samples(path, wrote), samples(path3, wrote))
