@@ -477,11 +477,18 @@ def main(argv=None):
                 "data": "synthetic" if not dryrun else "DRY RUN (gloo, stand-in renderer): launcher and gather plumbing only, nothing measured",
                 "config": {"workload": "cfg4: 512 jobs (64 notes x 8 velocities) x 5 s at 48 kHz, job j -> rank j mod G, one RCCL gather of f32 slabs to rank 0",
                            "parallelism": f"{world} rank(s), static job deal, no data-path collective besides the final gather"},
+                # what scales and what cannot: the literal grid is STRONG scaling of a latency-bound job -- 512 jobs leave 7/8 of one chip idle and
+                # a serial stream does not get shorter on more chips, so its N-GPU figure cannot exceed ~1 x the 1-GPU one; the scaled grid
+                # (the same jobs repeated until every GPU holds 8 192) is the weak-scaling figure of this path
+                "scaling_figure": {"grid": "scaled", "scaling": "weak", "samples_per_s": b["scaled"]["samples_per_s"], "jobs": b["scaled"]["jobs"],
+                                   "pass_ms": b["scaled"]["pass_ms"], "gather_ms": b["scaled"]["gather_ms"]},
+                "scaling_note": ("`value` is the LITERAL grid (512 jobs x 5 s): strong scaling of a latency-bound job, by construction <= ~1 x at any N; "
+                                 "`scaling_figure` (the scaled grid, 8 192 jobs per GPU) is the number to compare across N"),
                 "batch": b,
                 "dry_run": bool(dryrun),
-                "roofline": {"bound": "valu_f64", "kernel": "k_job_chain_fused", "achieved": lit["valu_frac"] * PEAK_FP64_VALU_TFLOPS, "peak": PEAK_FP64_VALU_TFLOPS,
+                "roofline": {"bound": "valu_f64", "kernel": "k_job_chain_row", "achieved": lit["valu_frac"] * PEAK_FP64_VALU_TFLOPS, "peak": PEAK_FP64_VALU_TFLOPS,
                              "unit": "TFLOP/s", "frac": lit["valu_frac"], "traffic": None,
-                             "note": "512 jobs = 64 workgroups of two quad-lane wavefronts (preamp | output stage) on 1 024 SIMDs, the voices rendered beside them: bounded by the serial latency of one preamp stream, not by issue or HBM"},
+                             "note": "512 jobs = 64 workgroups of five wavefronts (four row-of-sixteen preamp wavefronts | output stage) on 1 024 SIMDs, the voices rendered beside them: bounded by the serial instruction stream of one preamp state, not by chip-wide issue or HBM"},
                 "cpu_baseline": None,
             }
     else:
@@ -886,6 +893,16 @@ def main(argv=None):
                 "cpu_baseline": cpu,
             }
             line.update(extras)
+            # the contract-faithful figures where a reader of the first keys finds them (they also stay inside `config` / the extras)
+            front = {"config2_epoch_weighted": line["config"].get("config2_epoch_weighted"), "api_faithful": line["config"].get("api_faithful"),
+                     "configs4_fresh": ({"instances": 256, "x_realtime_aggregate": extras["config4_literal"]["cold"]["x_realtime_aggregate"],
+                                         "ms_per_step": extras["config4_literal"]["cold"]["ms_per_step"],
+                                         "warm_x_realtime_aggregate": extras["config4_literal"]["x_realtime_aggregate"],
+                                         "note": "BASELINE configs[4] literally: ONE pool of 256 instances, 30 steps right after every process-wide store was dropped "
+                                                 "(no import, no prefetch: the pool's oldest instance extends the trajectory as it renders); warm = the store already in HBM"}
+                                        if "cold" in extras.get("config4_literal", {}) else None)}
+            head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+            line = {**{k: line[k] for k in head}, **front, **{k: v for k, v in line.items() if k not in head}}
     rc = 0
     if line is not None and line.get("verified") is False:
         print("bench.py: the rendered block failed verification: " + json.dumps(line.get("verify")), file=sys.stderr)

