@@ -16,6 +16,11 @@
 #include "ow_tables.hpp"
 #include <vector>
 
+#ifdef OW_ORACLE_VOICE_PERTURB
+#define OW_VOICE_LIBM(x) ((x) * (1.0 + 2.2e-16))
+#else
+#define OW_VOICE_LIBM(x) (x)
+#endif
 namespace owo {
 
 constexpr double PI_ = 3.14159265358979323846;   // std::f64::consts::PI
@@ -93,9 +98,11 @@ struct ModalReed {
             const double decay_per_sample = alpha_nepers / sr;
             Mode& m = modes[i];
             m.s = 0.0; m.c = 1.0;
-            m.cos_inc = std::cos(phase_inc); m.sin_inc = std::sin(phase_inc);
+            // OW_ORACLE_VOICE_PERTURB builds a second sensitivity variant: the three library calls behind a mode's rotation and decay return
+            // their neighbour in the last place -- the reference under a different libm, seen from the voice path (tools/soak_parity.py --ulp-voice)
+            m.cos_inc = OW_VOICE_LIBM(std::cos(phase_inc)); m.sin_inc = OW_VOICE_LIBM(std::sin(phase_inc));
             m.phase_inc = phase_inc; m.amplitude = amps[i];
-            m.decay_mult = std::exp(-decay_per_sample);
+            m.decay_mult = OW_VOICE_LIBM(std::exp(-decay_per_sample));
             m.envelope = 1.0; m.jitter_drift = drift[i];
             m.damper_rate = 0.0; m.damper_mult = 1.0;
         }

@@ -60,6 +60,20 @@ def lib_perturbed():
     return _LIB_P
 
 
+_PATH_VOICE_PERTURBED = os.path.join(_ROOT, "oracle", "_build", "libow_oracle_voice_perturbed.so")
+_LIB_V = None
+
+
+def lib_voice_perturbed():
+    """Second sensitivity variant: the voice path's rotation / decay library calls off by one ulp (oracle/ow_voice.hpp)."""
+    global _LIB_V
+    if _LIB_V is None:
+        if not os.path.exists(_PATH_VOICE_PERTURBED):
+            build()
+        _LIB_V = _configure(C.CDLL(_PATH_VOICE_PERTURBED))
+    return _LIB_V
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -68,7 +82,7 @@ class OracleEngine:
     """CPU restatement of WurliEngine with the reference's method names."""
 
     def __init__(self, sr, perturbed=False, preamp_kind=0, power_amp_kind=0, tremolo_kind=0):
-        self.L = lib_perturbed() if perturbed else lib()
+        self.L = lib_voice_perturbed() if perturbed == "voice" else (lib_perturbed() if perturbed else lib())
         self.h = C.c_void_p(self.L.owo_engine_new_kinds3(C.c_double(sr), int(preamp_kind), int(power_amp_kind), int(tremolo_kind)))
 
     def close(self):
@@ -237,8 +251,9 @@ def alias_audit_run(note, velocity, preamp_kind=0):
 ABS_FLOOR_OUTPUT = 2e-9
 ABS_FLOOR_PREAMP = 2e-9
 # batch jobs (`preamp-bench render`): output = preamp x volume^2 x 7.5 with a static LDR, so the same indeterminacy
-# shows up ~10x larger (8.9e-9 on the samples the floor governs, 1.1e-8 anywhere: test_oracle_sensitivity.py; 3e-8 until round 6)
-ABS_FLOOR_BATCH = 2.2e-8
+# shows up ~10x larger: 8.9e-9 on short bass / mid jobs, 2.6e-8 on the 5 s render of note 96 at velocity 50 -- the job on which the GPU's own
+# worst batch error (2.5e-8) falls (test_oracle_sensitivity.py::test_batch_job_floor)
+ABS_FLOOR_BATCH = 3e-8
 # alias-audit stimulus (tremolo depth 0, i.e. the LDR dark and the preamp at its lowest loop gain): the same one-ulp experiment
 # moves quiet samples by up to 2.5e-9 (tests/test_oracle_sensitivity.py::test_alias_audit_stimulus_floor)
 ABS_FLOOR_AUDIT = 4e-9

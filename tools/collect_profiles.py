@@ -83,7 +83,8 @@ def main():
         run([os.path.join(ROOT, "tools", "summarize_profile.py"), t, os.path.join(dst, f"{r}_kernel_trace_host_delivery.md")])
         made.append(os.path.join(dst, f"{r}_kernel_trace_host_delivery.md"))
     for name, out in (("restrike_hbm.txt", "restrike_trace.txt"), ("restrike_host.txt", "restrike_trace_host_delivery.txt"), ("smoke.txt", "smoke.txt"),
-                      ("pmc_restrike.txt", "pmc_restrike_voice_kernels.txt"), ("probe_release.txt", "probe_release.txt"), ("soak.txt", "soak.txt")):
+                      ("pmc_restrike.txt", "pmc_restrike_voice_kernels.txt"), ("probe_release.txt", "probe_release.txt"), ("soak.txt", "soak.txt"), ("soak_gpu.txt", "soak_gpu.txt"),
+                      ("probe_soak_variants.txt", "probe_soak_variants.txt"), ("probe_fused.txt", "probe_fused.txt")):
         if os.path.exists(os.path.join(src, name)):
             open(os.path.join(dst, f"{r}_{out}"), "w").write(open(os.path.join(src, name)).read())
             made.append(os.path.join(dst, f"{r}_{out}"))
@@ -127,6 +128,21 @@ def main():
         open(out, "w").write(json.dumps(json.loads(line[-1]), indent=1) + "\n")
         made.append(out)
     print("\n".join(os.path.relpath(m, ROOT) for m in made))
+    # a collected file that is a stack trace (or empty) is not evidence: fail, so that the round's README cannot list it as a measurement
+    bad = []
+    for m in made:
+        try:
+            txt = open(m, errors="replace").read()
+        except OSError:
+            bad.append((m, "missing")); continue
+        if "Traceback (most recent call last)" in txt:
+            bad.append((m, "contains a Python traceback"))
+        elif not txt.strip():
+            bad.append((m, "empty"))
+    if bad:
+        for m, why in bad:
+            print("NOT EVIDENCE: %s %s" % (os.path.relpath(m, ROOT), why), file=sys.stderr)
+        sys.exit(2)
 
 
 if __name__ == "__main__":

@@ -84,6 +84,10 @@ OW_HOST_THREADS=2 timeout 900 python bench.py --steps 938 --warmup 5 --no-extras
 OW_HOST_THREADS=2 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_like_2threads.log 2>&1
 timeout 900 python bench.py --instances 256 --steps 30 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_p256_fresh.log 2>&1
 timeout 900 python tools/probe_fused.py > $O/probe_fused.log 2>&1
+# the wave-level counters need the library built with -DOW_DBG_COUNTERS: rebuilt HERE from the round's sources (round 5 ran a stale one
+# that lacked a symbol and recorded a traceback)
+timeout 600 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value -Wno-macro-redefined \
+    -mllvm -amdgpu-sched-strategy=max-memory-clause -DOW_DBG_COUNTERS -o openwurli_amd/lib/libow_dbg.so openwurli_amd/csrc/openwurli_hip.hip > $O/build_dbg.log 2>&1
 timeout 900 python tools/probe_power_amp_waves.py 16384 > $O/probe_power_amp_waves.log 2>&1
 tail -1 $O/bench_default.log | cut -c1-700
 fi

@@ -3,8 +3,10 @@ within the parity bar, voice counts equal).
 Usage: python tools/soak_parity.py [seconds] [engines] [preamp_kind] [power_amp_kind] [tremolo_kind] [--seed S] [--seeds S0,S1,...] [--ulp]
   (kinds as in include/openwurli_hip.h)
   --seed / --seeds   seed(s) of the random script (default 99, the script of rounds 3-5); several seeds print one line each and a summary
-  --ulp              no GPU: the oracle against ITS OWN one-ulp build (exp() off by one ulp) on the same script(s) -- what the reference
-                     algorithm itself does under a different libm, the yardstick for the GPU's ratio
+  --ulp              no GPU: the oracle against ITS OWN one-ulp build (the preamp's exp() off by one ulp) on the same script(s) -- what the
+                     reference algorithm itself does under a different libm, the yardstick for the GPU's ratio
+  --no-stop          do not stop at the first block outside the bar: the worst ratio over the whole length is what is wanted
+  --ulp-voice        the same with the VOICE path's libm off by one ulp (cos / sin / exp behind every mode's rotation and decay)
 Exit codes: 0 ran its length inside the bar; 1 mismatch; 3 (melange power amp only) ended at a divergence-guard event only one side took.
 
 Absolute floor: ABS_FLOOR_DENSE (tests/oracle_binding.py; DESIGN.md section 2 has its row).  The suites' four-note scenarios use 2e-9; under
@@ -26,7 +28,7 @@ class Parted(Exception):
     """melange power amp: the soak ended at a guard event only one side took (the reference's documented instability)"""
 
 
-def soak(seconds=60.0, n=4, pk=0, pak=0, tk=0, seed=99, ulp=False, verbose=True):
+def soak(seconds=60.0, n=4, pk=0, pak=0, tk=0, seed=99, ulp=False, verbose=True, switches=None, stop_on_mismatch=True):
     """Returns dict(worst, branch, block, engine, blocks, wall).  Raises AssertionError on a mismatch, Parted for the melange power amp's
     unshared guard event."""
     import oracle_binding as ob
@@ -36,7 +38,7 @@ def soak(seconds=60.0, n=4, pk=0, pak=0, tk=0, seed=99, ulp=False, verbose=True)
     if ulp:
         class _Pool:        # the oracle's one-ulp build behind the pool's interface
             def __init__(self):
-                self.e = [ob.OracleEngine(sr, perturbed=True, preamp_kind=pk, power_amp_kind=pak, tremolo_kind=tk) for _ in range(n)]
+                self.e = [ob.OracleEngine(sr, perturbed=ulp, preamp_kind=pk, power_amp_kind=pak, tremolo_kind=tk) for _ in range(n)]
             def __getitem__(self, k): return self.e[k]
             def render(self, L): return np.stack([x.render(L) for x in self.e])
             def set_sample_rate(self, r):
@@ -47,6 +49,8 @@ def soak(seconds=60.0, n=4, pk=0, pak=0, tk=0, seed=99, ulp=False, verbose=True)
     else:
         import openwurli_amd as ow
         g = ow.EnginePool(sr, n, preamp_kind=pk, power_amp_kind=pak, tremolo_kind=tk)
+        for name, val in (switches or {}).items():      # probes: the same script under one of the pool's latched switches
+            g.set_switch(name, val)
     g.set_sample_rate(sr)
     for c in cs:
         c.set_sample_rate(sr)
@@ -84,7 +88,7 @@ def soak(seconds=60.0, n=4, pk=0, pak=0, tk=0, seed=99, ulp=False, verbose=True)
             if rep["worst_ratio"] > worst["worst"]:
                 worst = dict(worst=rep["worst_ratio"], branch=rep["worst_branch"], block=b, engine=k)
             voices_differ = (not ulp) and g[k].active_voice_count() != c.active_voice_count()
-            if (rep["n_bad"] and not ulp) or voices_differ:
+            if ((rep["n_bad"] and not ulp) or voices_differ) and (stop_on_mismatch or voices_differ):
                 gr_now = (g[k].power_amp_diag().guard_resets, c.power_amp_diag()[3]) if pak else (0, 0)
                 # Only a mismatch that BEGINS at an unshared guard event is the reference's own instability: the counts were equal after
                 # the previous block (everything before was inside the bar) and differ after this one.  Anything else -- counts that were
@@ -106,7 +110,7 @@ def soak(seconds=60.0, n=4, pk=0, pak=0, tk=0, seed=99, ulp=False, verbose=True)
     if verbose:
         print("soak %s (preamp %d, power amp %d, tremolo %d, seed %d): %.0f s x %d engines, %d blocks, worst error / tolerance %.3f (the worst sample's "
               "tolerance was the %s term; block %d, engine %d), %.0f s wall%s"
-              % ("of the oracle's one-ulp build" if ulp else "ok", pk, pak, tk, seed, seconds, n, blocks, worst["worst"], worst["branch"], worst["block"],
+              % (("of the oracle's one-ulp build" + (" (voice path)" if ulp == "voice" else "")) if ulp else "ok", pk, pak, tk, seed, seconds, n, blocks, worst["worst"], worst["branch"], worst["block"],
                  worst["engine"], worst["wall"], ("; power-amp guard resets per engine: %r" % worst["guard_resets"]) if "guard_resets" in worst else ""), flush=True)
     return worst
 
@@ -116,6 +120,11 @@ def main():
     seeds, ulp = [99], False
     if "--ulp" in argv:
         ulp = True; argv.remove("--ulp")
+    if "--ulp-voice" in argv:
+        ulp = "voice"; argv.remove("--ulp-voice")
+    stop = True
+    if "--no-stop" in argv:           # run the length whatever the bar says (voice counts still have to agree): the worst ratio per seed on record
+        stop = False; argv.remove("--no-stop")
     for flag in ("--seed", "--seeds"):
         if flag in argv:
             i = argv.index(flag)
@@ -129,7 +138,7 @@ def main():
     rows = []
     for s in seeds:
         try:
-            rows.append(soak(seconds, n, pk, pak, tk, seed=s, ulp=ulp))
+            rows.append(soak(seconds, n, pk, pak, tk, seed=s, ulp=ulp, stop_on_mismatch=stop))
         except Parted as ex:
             print(ex)
             sys.exit(3)
@@ -137,7 +146,7 @@ def main():
             print(ex)
             sys.exit(1)
     if len(rows) > 1:
-        print("summary (%s): seeds %r worst error / tolerance %r max %.3f" % ("one-ulp build" if ulp else "GPU", [r["seed"] for r in rows],
+        print("summary (%s): seeds %r worst error / tolerance %r max %.3f" % (("one-ulp build" + (" (voice path)" if ulp == "voice" else "")) if ulp else "GPU", [r["seed"] for r in rows],
                                                                                     [round(r["worst"], 3) for r in rows], max(r["worst"] for r in rows)))
 
 
