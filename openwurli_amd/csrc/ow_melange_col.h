@@ -482,7 +482,10 @@ __device__ inline double mel_process_col(MelSt& st, double input_in, double pot,
 
 // Preamp stream, literal rebuild, column-streamed.  Same interface as k_preamp_mel_lit; lu_scratch: [144][2 * ceil(I / 32) * 32] doubles,
 // lane-minor, touched by the generic fallback only.
-__global__ __launch_bounds__(64, 2) void k_preamp_mel_col(const OwConsts* __restrict__ K, double* __restrict__ cs,
+#ifndef OW_MEL_COL_WAVES
+#define OW_MEL_COL_WAVES 2     // wavefronts per SIMD the register budget is set for (experiment, profiles/r06_melange_experiments.md: 1 = no spills, half the occupancy)
+#endif
+__global__ __launch_bounds__(64, OW_MEL_COL_WAVES) void k_preamp_mel_col(const OwConsts* __restrict__ K, double* __restrict__ cs,
                                                           const double* __restrict__ settled, const OwEngineArgs* __restrict__ args,
                                                           const OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const OwTremSrc tsrc,
                                                           double* __restrict__ pre, double* __restrict__ noise, int I, int L,

@@ -184,7 +184,12 @@ OW_DEV double pa_pnjlim(double vnew, double vold, double vt, double vcrit) {   /
 // Every sum keeps the reference's operand order and the library is built without FMA contraction: the solver follows the CPU
 // restatement bit for bit (pnjlim's logarithm excepted), which keeps the divergence guard firing on the same sample on both sides.
 #define PA_EPW 8              // engines per wavefront
+#ifndef PA_WPB
 #define PA_WPB 4              // wavefronts per workgroup
+#endif
+#ifndef PA_MIN_BLOCKS
+#define PA_MIN_BLOCKS 2       // workgroups per CU the register budget is set for (__launch_bounds__)
+#endif
 #define PA_EPB (PA_EPW * PA_WPB)
 #define PA_LS 9               // LDS row stride in doubles
 enum {
@@ -335,10 +340,21 @@ __device__ __forceinline__ bool pa_newton_pass(double* __restrict__ W, const dou
         PL(PL_CAND + posA) = fabs(A[0]);
         PL(PL_CAND + posB) = fabs(B[0]);
         PA_SYNC();
+#ifdef OW_PA_TIERS8      // experiment (round 6, profiles/r06_mpa_experiments.md): eight tiers of two columns -- 7 % fewer update operations, twice the code
+        PA_ELIM_TIER(0, 2, 15)
+        PA_ELIM_TIER(2, 4, 13)
+        PA_ELIM_TIER(4, 6, 11)
+        PA_ELIM_TIER(6, 8, 9)
+        PA_ELIM_TIER(8, 10, 7)
+        PA_ELIM_TIER(10, 12, 5)
+        PA_ELIM_TIER(12, 14, 3)
+        PA_ELIM_TIER(14, 16, 1)
+#else
         PA_ELIM_TIER(0, 4, 15)
         PA_ELIM_TIER(4, 8, 11)
         PA_ELIM_TIER(8, 12, 7)
         PA_ELIM_TIER(12, 16, 3)
+#endif
 #undef PA_ELIM_TIER
         if (singular) {
             const double i0 = PL(PL_INL + r0), i1 = PL(PL_INL + r1);
@@ -712,7 +728,7 @@ __global__ __launch_bounds__(64) void k_mpa_settle(const OwPaConsts* __restrict_
 
 // The amp alone on given input (debug hook ow_debug_power_amp): engine slot s of block b processes row b * 32 + s of `in`.  taps
 // [row][n][3]: outer Newton iterations of the sample (70 = exhausted), guard resets so far, positive rail after the sample.
-__global__ __launch_bounds__(PA_WPB * 64, 2) void k_mpa_debug(const OwPaConsts* __restrict__ C, const double* __restrict__ settled, const double* __restrict__ in,
+__global__ __launch_bounds__(PA_WPB * 64, PA_MIN_BLOCKS) void k_mpa_debug(const OwPaConsts* __restrict__ C, const double* __restrict__ settled, const double* __restrict__ in,
                                                            double* __restrict__ out, double* __restrict__ taps, long long n, int n_rows, int rail_sag,
                                                            const long long* __restrict__ poke_at, const int* __restrict__ poke_node, const double* __restrict__ poke_val,
                                                            long long ld = 0) {
@@ -811,7 +827,7 @@ __global__ void k_pa_order_scatter(const uint32_t* __restrict__ demand, int e0, 
 // f32 as k_post.  That cheap tail runs on the role-0 lane of the engine with its state (filters, smoothers) in LDS between samples:
 // in registers it would sit on top of the solver's ~430 and spill to scratch.
 struct PaTail { SpeakerSt sp; Smoother ss, sv; double da[3], db[3], dd; };
-__global__ __launch_bounds__(PA_WPB * 64, 2) void k_post_mpa(const OwConsts* __restrict__ K, const OwPaConsts* __restrict__ C, const double* __restrict__ settled,
+__global__ __launch_bounds__(PA_WPB * 64, PA_MIN_BLOCKS) void k_post_mpa(const OwConsts* __restrict__ K, const OwPaConsts* __restrict__ C, const double* __restrict__ settled,
                                                           double* __restrict__ cs, double* __restrict__ pa, const OwEngineArgs* __restrict__ args,
                                                           OwEngineOut* __restrict__ eout, const double* __restrict__ pre, float* __restrict__ out,
                                                           double* __restrict__ pa_tap, int I, int L, int Lout, int e0, int ne,
