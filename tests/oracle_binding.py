@@ -261,6 +261,12 @@ ABS_FLOOR_AUDIT = 4e-9
 # reaches the output scales with volume^2 and the tremolo's gain swing; the one-ulp experiment on such a script moves quiet samples by
 # up to 3.1e-9 (tests/test_oracle_sensitivity.py::test_dense_play_floor, tools/soak_parity.py)
 ABS_FLOOR_DENSE = 5e-9
+# long dense soaks (tools/soak_parity.py: 120 s x 6 engines per seed, tests/test_gpu_soak.py): over minutes of random play the reference
+# algorithm passes through states -- an engine at tremolo depth 0 under a dense chord, mostly -- in which the SAME one-ulp experiment moves a
+# quiet sample by up to 3.4e-8 (seed 5, block 691, engine 0; seeds 3 and 4: 9e-9 and 1.4e-8), at the very blocks and engines where the GPU's
+# own worst samples sit (1.5e-8 / 1.0e-8 / 9.5e-9: profiles/r06_soak.md has the eight seeds side by side).  The dense-play floor above
+# stays what the suites' short scenarios use; a soak is held to 2e-8 = 0.6 x the reference's own movement on the worst seed.
+ABS_FLOOR_SOAK = 2e-8
 # melange 12-node solver.  The reference (and the oracle) re-invert the 12x12 MNA matrix by LU for every sample whose R_ldr
 # moved; the GPU applies the mathematically identical rank-one (Sherman-Morrison) update of the inverse at the nominal pot.
 # While R_ldr is steady the two agree to 4-7e-10 at the preamp node.  While R_ldr moves fast (depth-knob ramp, tremolo trough)
@@ -284,7 +290,7 @@ ABS_FLOOR_MELANGE_LIT_OUTPUT = 3.4e-8
 # used for).  No floor changes without its row.
 FLOORS = {
     "ABS_FLOOR_OUTPUT": ABS_FLOOR_OUTPUT, "ABS_FLOOR_PREAMP": ABS_FLOOR_PREAMP, "ABS_FLOOR_BATCH": ABS_FLOOR_BATCH,
-    "ABS_FLOOR_AUDIT": ABS_FLOOR_AUDIT, "ABS_FLOOR_DENSE": ABS_FLOOR_DENSE,
+    "ABS_FLOOR_AUDIT": ABS_FLOOR_AUDIT, "ABS_FLOOR_DENSE": ABS_FLOOR_DENSE, "ABS_FLOOR_SOAK": ABS_FLOOR_SOAK,
     "ABS_FLOOR_MELANGE_LIT_PREAMP": ABS_FLOOR_MELANGE_LIT_PREAMP, "ABS_FLOOR_MELANGE_LIT_OUTPUT": ABS_FLOOR_MELANGE_LIT_OUTPUT,
 }
 FLOOR_RULE = 2.5

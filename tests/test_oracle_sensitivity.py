@@ -266,3 +266,20 @@ def test_full_depth_tremolo_floor(oracle):
             worst = max(worst, float(np.max(np.abs(x - y)[q])))
     assert 1e-9 < worst < oracle.ABS_FLOOR_DENSE, worst
     a.close(); b.close()
+
+
+def test_soak_floor_governing_measurement(oracle):
+    """The soak's floor (ABS_FLOOR_SOAK, tools/soak_parity.py, tests/test_gpu_soak.py): the first 8 s of the soak script under seed 5 -- six
+    engines scripted, engine 0 (tremolo depth 0, volume 0.35) rendered -- carry the spot where the reference algorithm itself moves most
+    over the eight seeds x 120 s of profiles/r06_soak.md: at block 691 a quiet sample of the oracle's one-ulp build lies 3.4e-8 from the
+    oracle's.  The GPU's own worst sample of those 16 minutes sits in the same block of the same engine, at 1.5e-8."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import soak_parity
+    r = soak_parity.soak(8.0, 6, seed=5, ulp=True, only=[0], verbose=False, floor=oracle.ABS_FLOOR_SOAK)
+    assert r["branch"] == "floor" and r["block"] == 691 and r["engine"] == 0, r
+    moved = r["worst"] * oracle.ABS_FLOOR_SOAK
+    print(f"\n[floor table] ABS_FLOOR_SOAK {oracle.ABS_FLOOR_SOAK:.1e}: one-ulp {moved:.2e} (seed 5, block 691, engine 0), ratio {oracle.ABS_FLOOR_SOAK / moved:.2f}")
+    assert 2e-8 < moved < 6e-8, moved
+    assert oracle.ABS_FLOOR_SOAK <= oracle.FLOOR_RULE * moved
