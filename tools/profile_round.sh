@@ -3,7 +3,7 @@
 # rocprofv3 gets the program itself after `--` (python3 ...), never a shell or env wrapper (the profiler's preloaded library has
 # initialised the GPU before the program starts: any exec hop in between takes the box down).  Counter passes are separate runs with
 # --kernel-trace only.
-R=${1:-r05}
+R=${1:-r06}
 PART=${2:-ABC}      # A = traces + default counters, B = non-default kernels, C = bench lines (one gpurun call each: a hung command then costs one part)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
@@ -89,6 +89,14 @@ timeout 900 python tools/probe_fused.py > $O/probe_fused.log 2>&1
 timeout 600 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value -Wno-macro-redefined \
     -mllvm -amdgpu-sched-strategy=max-memory-clause -DOW_DBG_COUNTERS -o openwurli_amd/lib/libow_dbg.so openwurli_amd/csrc/openwurli_hip.hip > $O/build_dbg.log 2>&1
 timeout 900 python tools/probe_power_amp_waves.py 16384 > $O/probe_power_amp_waves.log 2>&1
+# round 6: the serial steps -- the trajectory's oscillator kernels alone (quad-lane vs row), the small-pool chain by pool size, a lone
+# instance / 256 instances under the three chain kernels, the batch path under the row and the quad chain
+timeout 900 python -m pytest tests/test_gpu_trajectory.py -q -s -k "row_oscillator" > $O/probe_oscillator_step.log 2>&1
+timeout 900 python tools/probe_row_crossover.py > $O/probe_row_crossover.log 2>&1
+timeout 900 python tools/bench_batch.py > $O/probe_batch_row.log 2>&1
+OW_JOB_ROW=0 timeout 900 python tools/bench_batch.py > $O/probe_batch_quad.log 2>&1
+OW_TREM_ROW=0 timeout 900 python bench.py --instances 256 --steps 30 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_p256_fresh_quad_oscillator.log 2>&1
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 tail -1 $O/bench_default.log | cut -c1-700
 fi
 ls $O
