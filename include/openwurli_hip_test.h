@@ -101,10 +101,12 @@ int ow_test_clear_settle_caches(void);
 /* CircuitState at DC_OP, n_settle oscillator steps without the cell, then n steps of the shared trajectory (r_ldr[0 .. n)) in launches of
  * `chunk` steps, with the quad-lane kernels (row = 0: ow_trem_wide.h) or the one-system-per-wavefront kernels (row = 1: ow_trem_row.h).
  * No store and no pool are touched.  r_out[n]; state_out[18] = the oscillator rows after the last step; ckpt_out[(n / 4096 + 2) * 16] and
- * be_out[1024] may be NULL; *ms_out = device time of the trajectory launches.  The two must agree bit for bit
+ * be_out[1024] may be NULL; *ms_out = device time of the trajectory launches; cold_out[2] (or NULL, row kernels only) = Newton sweeps the row
+ * step handed to the generic sweep / steps that took the backward-Euler retry during those launches; kick18 (or NULL): added to the
+ * DC_OP state rows (v[7], i_prev[4], i_pp[4]) before anything runs -- a circuit pushed off its operating point.  The two must agree bit for bit
  * (tests/test_gpu_trajectory.py); the time per step is the figure every small pool waits for.  Returns 0, <0 on error. */
 int ow_debug_trem_trajectory(double sample_rate, long long n_settle, long long n, long long chunk, int row, double* r_out, double* state_out,
-                             double* ckpt_out, unsigned long long* be_out, double* ms_out, int device);
+                             double* ckpt_out, unsigned long long* be_out, double* ms_out, int device, unsigned long long* cold_out, const double* kick18);
 
 /* ---- voice-sum NaN guard ----------------------------------------------------------------------- */
 /* Overwrite one double of a voice record on the device before the next block (slot 0..63; steal != 0 selects the slot's steal voice;
@@ -114,6 +116,10 @@ int ow_debug_trem_trajectory(double sample_rate, long long n_settle, long long n
 #define OW_TEST_VF_S0 0
 #define OW_TEST_VF_Q 81
 int ow_test_engine_poke_voice(ow_engine*, int slot, int steal, int field, double value);
+
+/* The same for the legacy preamp: overwrite node voltage `node` (0..7) of engine e's main (shadow = 0) or shadow solver state before the next
+ * block.  A non-finite value provokes the preamp's own NaN reset (dk_preamp_legacy.rs:610-615).  Returns 0, <0 on error. */
+int ow_test_engine_poke_preamp_node(ow_engine*, int shadow, int node, double volts);
 
 /* Plain device-to-host copy, for reading a block that ow_pool_render(pool, NULL, ...) left in HBM (ow_pool_device_output). */
 int ow_test_device_read(void* dst_host, const void* src_device, size_t bytes, int device);

@@ -71,6 +71,9 @@ OW_DEV void trem_row_consts(TremRowK& c, const OwConsts* __restrict__ K, int lan
     c.g2 = base ? (is / beta_r) : -(is / beta_r);                                        // + ib_rev | - ib_rev
 }
 
+// sweeps the row step handed to the generic sweep / steps that took the backward-Euler retry, since the library was loaded (one atomic in
+// a cold block; read by ow_debug_trem_trajectory: the bit-identity test wants to know that its scenario exercises those paths)
+__device__ unsigned long long g_trem_row_cold[2] = {0ull, 0ull};
 struct TremRow {
     double vf[7], ipf[4], ipp[4];   // wave-uniform: v and i_prev after the denormal flush (what the step reads), i_pp
     double ip[4];                   // wave-uniform: i_prev as the state holds it (before the flush)
@@ -217,6 +220,7 @@ __device__ __forceinline__ double trem_osc_step_row(TremRow& st, const TremRowK&
         // pnjlim acts when v_trial > vcrit and |dv| > 2 vt (which is > 1e-4); the step cap when some |dv| > 3.5
         bad |= __builtin_amdgcn_ballot_w64((v_trial > OW_T_VCRIT && fabs(dv) > OW_T_VT + OW_T_VT) || fabs(dv) > 3.5);
         if (__builtin_expect(bad != 0ull, 0)) {
+            if (lane == 0) atomicAdd(&g_trem_row_cold[0], 1ull);
             double tv[7], ti[4];      // copies: the callee takes addresses, and only this cold block may put anything in memory
 #pragma unroll
             for (int j = 0; j < 7; ++j) tv[j] = vp[j];
@@ -241,6 +245,7 @@ __device__ __forceinline__ double trem_osc_step_row(TremRow& st, const TremRowK&
     for (int j = 0; j < 4; ++j) xa += c.sni[j] * i_nl[j];
     if (__builtin_expect(!converged, 0)) {
         st.be_fallbacks += 1u;
+        if (lane == 0) atomicAdd(&g_trem_row_cold[1], 1ull);
         double v[7], tv[7], ta[4], tb[4], ti[4];
 #pragma unroll
         for (int j = 0; j < 7; ++j) tv[j] = st.vf[j];

@@ -78,6 +78,10 @@ class _EngineHandle:
         """Test hook (openwurli_hip_test.h): overwrite one double of a voice record on the device."""
         return self._lib.ow_test_engine_poke_voice(self._h, int(slot), 1 if steal else 0, int(field), float(value))
 
+    def poke_preamp_node(self, node, volts, shadow=False):
+        """Test hook (openwurli_hip_test.h): overwrite a node voltage of the legacy preamp's main / shadow solver state."""
+        return self._lib.ow_test_engine_poke_preamp_node(self._h, 1 if shadow else 0, int(node), float(volts))
+
     def reset(self):
         self._lib.ow_engine_reset(self._h)
         binding.raise_if_error(self._lib)

@@ -59,6 +59,11 @@ void owo_engine_advance_tremolo(void* e, size_t n) {
     WurliEngine* w = (WurliEngine*)e;
     for (size_t i = 0; i < n; ++i) (void)w->tremolo.process();
 }
+// test poke (mirror of the product's ow_test_engine_poke_preamp_node): node voltage of the legacy preamp's main / shadow solver state
+void owo_engine_poke_preamp_node(void* e, int shadow, int node, double v) {
+    WurliEngine* w = (WurliEngine*)e;
+    (shadow ? w->preamp.shadow : w->preamp.main).v[node] = v;
+}
 void owo_engine_poke_pa_node(void* e, int node, double v) { ((WurliEngine*)e)->mel_pa.state.v_prev[node] = v; }
 // render with the power-amp tap (chain rate) besides the output
 void owo_engine_render_pa_tap(void* e, float* out, double* pa, size_t n) {

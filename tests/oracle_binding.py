@@ -148,6 +148,10 @@ class OracleEngine:
         """test poke: field 81 = pickup charge q, 0 = mode 0's sine state (the product's ow_test_engine_poke_voice)"""
         return self.L.owo_engine_poke_voice(self.h, int(slot), 1 if steal else 0, int(field), C.c_double(value))
 
+    def poke_preamp_node(self, node, volts, shadow=False):
+        """test poke: a node voltage of the legacy preamp's solver state (the product's ow_test_engine_poke_preamp_node)"""
+        self.L.owo_engine_poke_preamp_node(self.h, 1 if shadow else 0, int(node), C.c_double(volts))
+
     def poke_power_amp_node(self, node, volts): self.L.owo_engine_poke_pa_node(self.h, int(node), C.c_double(volts))
 
     def count_voices_in_state(self, st): return self.L.owo_engine_count_state(self.h, int(st))

@@ -1046,6 +1046,63 @@ def test_chain_row_is_bit_identical(hiplib, oracle):
     g.close(); c.close()
 
 
+def test_preamp_nan_reset_in_every_chain_kernel(hiplib, oracle):
+    """The preamp's OWN NaN reset (dk_preamp_legacy.rs:610-615: `main - shadow` non-finite -> both solver states back to the DC solution at the
+    current R_ldr, this sample's output 0.0, the block goes on) cannot be reached through the API; a test hook overwrites a node voltage
+    of a solver state with NaN (main of engine 1, shadow of engine 3) or infinity (engine 4, a block later) before a block.  Every chain kernel -- two launches
+    with the lane-pair and the quad-lane preamp, the fused quad chain, the row chain, the stream chain -- must count the same resets and
+    produce the same bits at the preamp tap and the output, in that block and after it; and they are the oracle's (same poke, same block)."""
+    import openwurli_amd as ow
+    sr, n_eng, length = 48000.0, 5, 96
+    modes = {"lane pairs": {"chain_fused": 0, "preamp_wide": 0, "chain_stream": 0}, "quad, two launches": {"chain_fused": 0, "preamp_wide": 1},
+             "quad, fused": {"chain_fused": 1, "chain_row": 0}, "row": {"chain_fused": 1, "chain_row": 1},
+             "stream": {"chain_fused": 0, "preamp_wide": 0, "chain_stream": 1}}
+    res = {}
+    cs = [oracle.OracleEngine(sr) for _ in range(n_eng)]
+    for name in list(modes) + ["oracle"]:
+        g = None
+        if name != "oracle":
+            g = ow.EnginePool(sr, n_eng); g.set_sample_rate(sr)
+            for k, v in modes[name].items():
+                g.set_switch(k, v)
+        es = [g[k] for k in range(n_eng)] if g is not None else cs
+        for k, e in enumerate(es):
+            if g is None:
+                e.set_sample_rate(sr)
+            e.set_tremolo_depth(0.2 * k); e.set_volume(0.5)
+            for note in (45 + k, 60, 67 + k):
+                e.note_on(note, 0.8)
+        outs, pres = [], []
+        for b in range(5):
+            if b == 2:
+                es[1].poke_preamp_node(6, float("nan")); es[3].poke_preamp_node(2, float("nan"), shadow=True)
+            if b == 3:
+                es[4].poke_preamp_node(0, float("inf"))                    # an infinite node voltage: inf - inf inside the step
+            if g is not None:
+                outs.append(g.render(length).copy()); pres.append(g.preamp_out(2 * length).copy())
+            else:
+                taps = [e.render_taps(length) for e in es]
+                outs.append(np.stack([t[0] for t in taps])); pres.append(np.stack([t[2] for t in taps]))
+        resets = [es[k].diag().preamp_nan_resets for k in range(n_eng)] if g is not None else None      # (the reference keeps no counter of them)
+        res[name] = (outs, pres, resets)
+        if g is not None:
+            g.close()
+    ref = res["lane pairs"]
+    assert ref[2][1] >= 1 and ref[2][3] >= 1 and ref[2][4] >= 1 and ref[2][0] == 0 and ref[2][2] == 0, ref[2]
+    for name in modes:
+        assert res[name][2] == ref[2], (name, res[name][2], ref[2])
+        for b in range(5):
+            assert np.array_equal(res[name][1][b], ref[1][b]), (name, b, "preamp tap")
+            assert np.array_equal(res[name][0][b], ref[0][b]), (name, b, "output")
+            assert np.all(np.isfinite(res[name][0][b]))
+    for b in range(5):
+        for k in range(n_eng):
+            rep = oracle.parity_report(ref[0][b][k], res["oracle"][0][b][k], abs_floor=oracle.ABS_FLOOR_OUTPUT)
+            assert rep["n_bad"] == 0, (b, k, rep)
+    for c in cs:
+        c.close()
+
+
 def test_chain_stream_is_bit_identical(hiplib, oracle):
     """Big oversampled pools whose block goes to a pinned host block run preamp and output stage as ONE launch (k_chain_stream,
     ow_chain_stream.h: one wavefront per 32 engines alternates between the two per 64-sample chunk and stores the f32 rows straight into

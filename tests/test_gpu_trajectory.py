@@ -307,14 +307,16 @@ def test_store_grows_and_configures(hiplib, oracle):
         ow.load_library().ow_test_clear_settle_caches()
 
 
-def _traj_kernels(hiplib, sr, n_settle, n, chunk, row):
+def _traj_kernels(hiplib, sr, n_settle, n, chunk, row, kick=None):
     import ctypes as C
     r = np.zeros(n, np.float64); st = np.zeros(18, np.float64)
     ck = np.zeros((n // 4096 + 2) * 16, np.float64); be = np.zeros(1024, np.uint64)
     ms = C.c_double(0.0)
+    cold = np.zeros(2, np.uint64)
     rc = hiplib.ow_debug_trem_trajectory(C.c_double(sr), n_settle, n, chunk, row, r.ctypes.data, st.ctypes.data, ck.ctypes.data, be.ctypes.data,
-                                         C.addressof(ms), 0)
+                                         C.addressof(ms), 0, cold.ctypes.data, None if kick is None else np.ascontiguousarray(kick, np.float64).ctypes.data)
     assert rc == 0, hiplib.ow_last_error()
+    _traj_kernels.cold = (int(cold[0]), int(cold[1]))      # generic sweeps / backward-Euler retries of this run (row kernels)
     return r, st, ck, be, ms.value
 
 
@@ -322,9 +324,9 @@ def _traj_kernels(hiplib, sr, n_settle, n, chunk, row):
 def test_row_oscillator_kernels_equal_the_quad_lane_kernels(hiplib, sr):
     """ow_trem_row.h (one system per wavefront: lanes = matrix rows, zero coefficients for the emitted sparsity, the usual pivot order as a
     lane assignment, one branch per Newton sweep) against ow_trem_wide.h (the quad-lane step, itself bit-identical to the lane = engine
-    step and to the oracle): from DC_OP through the start-up transient -- where the junction limiter, the step cap and off-diagonal pivots
-    fire, i.e. the sweeps the row step hands to the generic sweep -- into the settled oscillation.  R, the state rows, every checkpoint
-    and the fallback list must be the same bits, for any cut into launches."""
+    step and to the oracle): from DC_OP through the growth of the oscillation into its settled regime (every sweep on the row step's fast
+    path), and from states kicked off the operating point (the sweeps the row step hands to the generic sweep, the backward-Euler retry:
+    below).  R, the state rows, every checkpoint and the fallback list must be the same bits, for any cut into launches."""
     n = 3 * 4096 + 1234
     a = _traj_kernels(hiplib, sr, 0, n, 4096, 0)
     b = _traj_kernels(hiplib, sr, 0, n, 4096, 1)
@@ -338,11 +340,29 @@ def test_row_oscillator_kernels_equal_the_quad_lane_kernels(hiplib, sr):
     n_settle = int(2 * (sr * 2 if sr < 88200.0 else sr))
     d = _traj_kernels(hiplib, sr, n_settle, 8192, 8192, 0)
     e = _traj_kernels(hiplib, sr, n_settle, 8192, 8192, 1)
+    cold_settled = _traj_kernels.cold
     assert np.array_equal(d[0].view(np.uint64), e[0].view(np.uint64))
     assert np.array_equal(d[1].view(np.uint64), e[1].view(np.uint64))
     assert np.array_equal(d[2].view(np.uint64), e[2].view(np.uint64))
     assert d[0].min() > 10.0 and d[0].max() <= 1.0e6 and d[0].max() / d[0].min() > 3.0      # the cell swings (tremolo.rs:128-146)
-    print(f"\n[oscillator step at {sr:.0f} Hz] quad-lane {d[4] * 1e3 / 8192:.3f} us, row {e[4] * 1e3 / 8192:.3f} us")
+    # From DC_OP the oscillation grows gently: no sweep ever needs the generic path (the counters say so).  A circuit KICKED off its
+    # operating point does -- node voltages and junction currents moved by volts / milliamps: junction limiting, the 3.5 V cap, pivots off the
+    # usual order, singular sweeps, backward-Euler retries -- and must still follow the quad-lane kernel bit for bit, through the recovery.
+    worst = (0, 0)
+    for k, kick in enumerate((np.array([0, 0, 2.0, 0, -1.5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0]),
+                              np.array([-6.0, 3.0, 0, 4.0, 5.0, 0, 0.5, 1e-3, -1e-3, 2e-3, 1e-3, 0, 0, 0, 0, 0, 0, 0.0]),
+                              np.array([9.0, -9.0, 9.0, -9.0, 9.0, 0, 1.0, 5e-3, 5e-3, -5e-3, 5e-3, -1e-3, 1e-3, 1e-3, -1e-3, 0, 0, 0.0]))):
+        qa = _traj_kernels(hiplib, sr, 0, 6000, 4096, 0, kick=kick)
+        ra = _traj_kernels(hiplib, sr, 0, 6000, 4096, 1, kick=kick)
+        cold = _traj_kernels.cold
+        worst = (max(worst[0], cold[0]), max(worst[1], cold[1]))
+        assert np.array_equal(qa[0].view(np.uint64), ra[0].view(np.uint64)), (k, int(np.argmax(qa[0] != ra[0])), cold)
+        assert np.array_equal(qa[1].view(np.uint64), ra[1].view(np.uint64)), (k, cold)
+        assert np.array_equal(qa[2].view(np.uint64), ra[2].view(np.uint64)), (k, cold)
+        assert np.array_equal(qa[3], ra[3]), (k, cold)
+    assert worst[0] > 0, worst                                  # the kicks did hand sweeps to the generic sweep
+    print(f"\n[oscillator step at {sr:.0f} Hz] quad-lane {d[4] * 1e3 / 8192:.3f} us, row {e[4] * 1e3 / 8192:.3f} us; generic sweeps / BE retries: "
+          f"{cold_settled} in 8 192 settled steps, up to {worst} in 6 000 steps after a kick")
 
 
 def test_trajectory_export_import_round_trip(hiplib, tmp_path):
