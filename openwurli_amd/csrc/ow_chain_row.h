@@ -157,17 +157,20 @@ __device__ __forceinline__ double dk_step_row(DkSt& st, const DkRowK& R, int lan
 
 // k_chain_fused (ow_chain_wide.h) with the row step: eight engines per workgroup, wavefronts 0-3 = the preamps of two engines each
 // (rows 0-1 main, rows 2-3 shadow), wavefront 4 = k_post<SPLIT>'s lanes for the eight.  Same arguments, same results.
-template <bool SPLIT>
+// CH: host samples per hand-over chunk.  The output stage follows the preamps one chunk behind, so a block ends with one chunk of
+// output-stage time (1.2 us per sample) that nothing overlaps: 16 for long blocks (a barrier per 16 samples), 8 for blocks of <= 128
+// samples, where those 10 us are 4 % of a lone instance's 64-sample buffer.
+template <bool SPLIT, int CH>
 __global__ __launch_bounds__(320) void k_chain_row(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args,
                                                    OwEngineOut* __restrict__ eout, const double* __restrict__ sum, const OwTremSrc tsrc,
                                                    double* __restrict__ pre, float* __restrict__ out, int I, int L, int Lcap, int Lout, int e0, int ne) {
     constexpr int OSR = SPLIT ? 2 : 1;
-    __shared__ double tin[8 * (OW_FCHUNK + 1)];                 // voice sums of the chunk: [engine of the block][sample]
-    __shared__ double ring[2][OW_FCHUNK * OSR][8];              // preamp out, chain rate: [slot][sample][engine of the block]
-    __shared__ float tout[8 * (OW_FCHUNK + 1)];                 // finished samples of the chunk (output wavefront only)
+    __shared__ double tin[8 * (CH + 1)];                 // voice sums of the chunk: [engine of the block][sample]
+    __shared__ double ring[2][CH * OSR][8];              // preamp out, chain rate: [slot][sample][engine of the block]
+    __shared__ float tout[8 * (CH + 1)];                 // finished samples of the chunk (output wavefront only)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int eb = e0 + blockIdx.x * 8;
-    const int n_chunks = (L + OW_FCHUNK - 1) / OW_FCHUNK;
+    const int n_chunks = (L + CH - 1) / CH;
 
     if (wv < 4) {
         // ---- a preamp wavefront: rows (0, 1) = main of engines el0, el0 + 1; rows (2, 3) = their shadows
@@ -196,16 +199,17 @@ __global__ __launch_bounds__(320) void k_chain_row(const OwConsts* __restrict__ 
             }
         }
         uint32_t nan_resets = 0;
+        double sh_depth = __longlong_as_double(0x7FF8000000000000LL), sh_top = 0.0, sh_lower = 0.0;      // (NaN: nothing formed yet)
         const TremCol rc = trem_col(tsrc, I, e);
         double rnx[2];                                           // R one host sample ahead (registers): the global load is off the serial path
         rnx[0] = trem_col_at(rc, 0u);
         rnx[1] = OSR == 2 ? trem_col_at(rc, 1u) : 0.0;
         // voice sums of the next chunk, fetched while this one is solved: lanes 0-31 = (engine of this wavefront, sample)
-        const int f_el = 2 * wv + ((lane >> 4) & 1), f_n = lane & 15;
+        const int f_el = 2 * wv + (lane >= CH ? 1 : 0), f_n = lane >= CH ? lane - CH : lane;      // lanes 0 .. 2 CH - 1 = (engine of this wavefront, sample of the chunk)
         auto fetch_sum = [&](int chunk) -> double {
-            const int er = eb + f_el, b0 = chunk * OW_FCHUNK;
+            const int er = eb + f_el, b0 = chunk * CH;
             double x = 0.0;
-            if (lane < 32 && er < e0 + ne && b0 + f_n < L && !eout[er].sum_nonfinite) {
+            if (lane < 2 * CH && er < e0 + ne && b0 + f_n < L && !eout[er].sum_nonfinite) {
                 if (args[er].main_mask) x = sum[((size_t)0 * I + er) * Lcap + b0 + f_n];
                 if (args[er].steal_mask) x += sum[((size_t)1 * I + er) * Lcap + b0 + f_n];
             }
@@ -215,14 +219,14 @@ __global__ __launch_bounds__(320) void k_chain_row(const OwConsts* __restrict__ 
         const double sgn = role ? -1.0 : 1.0;
         for (int c = 0; c <= n_chunks; ++c) {
             if (c < n_chunks) {
-                const int base = c * OW_FCHUNK;
-                const int cn = min(OW_FCHUNK, L - base);
-                if (lane < 32) tin[f_el * (OW_FCHUNK + 1) + f_n] = nxt;
+                const int base = c * CH;
+                const int cn = min(CH, L - base);
+                if (lane < 2 * CH) tin[f_el * (CH + 1) + f_n] = nxt;
                 OW_WAVE_SYNC();
                 if (c + 1 < n_chunks) nxt = fetch_sum(c + 1);
                 double (*slot)[8] = ring[c & 1];
                 for (int n = 0; n < cn; ++n) {
-                    const double x = tin[el * (OW_FCHUNK + 1) + n];
+                    const double x = tin[el * (CH + 1) + n];
                     const double rcur[2] = {rnx[0], rnx[1]};            // R of this sample, fetched one host sample ago
                     {
                         const uint32_t nx = (uint32_t)(min(base + n + 1, L - 1) * OSR);
@@ -230,6 +234,15 @@ __global__ __launch_bounds__(320) void k_chain_row(const OwConsts* __restrict__ 
                         if (OSR == 2) rnx[1] = trem_col_at(rc, nx + 1u);
                     }
                     const double depth = clampd(sd.next(), 0.0, 1.0);   // engine.rs:533-534, tremolo.rs:117-119
+                    // Tremolo::shunt_impedance (tremolo.rs:152-167; trem_shunt): the pot's upper leg and r_lower depend on the depth alone, and
+                    // the depth only moves while its smoother ramps -- they are formed again (the same operations: the same bits) when some
+                    // state of the wavefront sees another depth than the one they were formed from, i.e. on a few blocks per knob movement
+                    if (__builtin_amdgcn_ballot_w64(!(depth == sh_depth)) != 0ull) {
+                        sh_depth = depth;
+                        const double r_upper = 50000.0 * (1.0 - depth);
+                        sh_lower = 50000.0 * depth;
+                        sh_top = r_upper > 0.0 ? ow_div(r_upper * 18000.0, r_upper + 18000.0) : 0.0;
+                    }
                     double in[2];
                     if (OSR == 2) {
                         const double y = allpass3(R.oc0, R.oc1, R.oc2, us, x);      // branch A on even lanes, B on odd ones
@@ -242,7 +255,9 @@ __global__ __launch_bounds__(320) void k_chain_row(const OwConsts* __restrict__ 
 #pragma unroll
                     for (int j = 0; j < OSR; ++j) {
                         const size_t idx = (size_t)((base + n) * OSR + j);
-                        const double r_new = fmax(trem_shunt(depth, rcur[j]), 1000.0);   // tremolo.rs:152-167; set_ldr_resistance
+                        const double branch = 680.0 + rcur[j];
+                        const double low = sh_lower > 0.0 ? ow_div(sh_lower * branch, sh_lower + branch) : 0.0;
+                        const double r_new = fmax(sh_top + low, 1000.0);                 // set_ldr_resistance
                         if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = ow_div(1.0, r_new); }
                         const double o = dk_step_row(st, R, lane, in[j], g_ldr, g_prev);
                         g_prev = g_ldr;
@@ -308,8 +323,8 @@ __global__ __launch_bounds__(320) void k_chain_row(const OwConsts* __restrict__ 
     const double sr = K->sr, thermal_alpha = K->spk_thermal_alpha;
     for (int c = 0; c <= n_chunks; ++c) {
         if (c >= 1) {
-            const int base = (c - 1) * OW_FCHUNK;
-            const int cn = min(OW_FCHUNK, L - base);
+            const int base = (c - 1) * CH;
+            const int cn = min(CH, L - base);
             const double (*slot)[8] = ring[(c - 1) & 1];
             const int pe = pel < 8 ? pel : 7;
             for (int n = 0; n < cn; ++n) {
@@ -336,13 +351,13 @@ __global__ __launch_bounds__(320) void k_chain_row(const OwConsts* __restrict__ 
                     sp.ts = 0.0;
                     nan_fired = true;
                 }
-                if (phase == 0 && pel < 8) tout[pel * (OW_FCHUNK + 1) + n] = f;
+                if (phase == 0 && pel < 8) tout[pel * (CH + 1) + n] = f;
             }
             OW_WAVE_SYNC();
-            for (int k = lane; k < 8 * OW_FCHUNK; k += 64) {
-                const int r = k / OW_FCHUNK, n = k - r * OW_FCHUNK;
+            for (int k = lane; k < 8 * CH; k += 64) {
+                const int r = k / CH, n = k - r * CH;
                 const int er = eb + r;
-                if (er < e0 + ne && n < cn) out[(size_t)er * Lout + base + n] = tout[r * (OW_FCHUNK + 1) + n];
+                if (er < e0 + ne && n < cn) out[(size_t)er * Lout + base + n] = tout[r * (CH + 1) + n];
             }
             OW_WAVE_SYNC();
         }
