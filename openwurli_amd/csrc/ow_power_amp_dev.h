@@ -113,6 +113,26 @@ __device__ inline PaBjt pa_bjt_with_parasitics(double vbe_ext, double vbc_ext, c
         held = e;
         const double f1 = vbe_int - vbe_ext + e.ib * D.rb + (e.ic + e.ib) * D.re;
         const double f2 = vbc_int - vbc_ext + e.ib * D.rb - e.ic * D.rc;
+#ifdef OW_PA_UNIFORM_INNER
+        // experiment (profiles/r06_mpa_experiments.md): the lanes' loops as one wave-uniform loop, a finished lane holds its voltages
+        // (its re-evaluation is at the same voltages: the same `held`, the same f1/f2)
+        fresh = fresh || (fabs(f1) < 1e-10 && fabs(f2) < 1e-10);
+        if (__builtin_amdgcn_ballot_w64(!fresh) == 0ull) break;
+        const double j11 = 1.0 + held.j2 * D.rb + (held.j0 + held.j2) * D.re;
+        const double j12 = held.j3 * D.rb + (held.j1 + held.j3) * D.re;
+        const double j21 = held.j2 * D.rb - held.j0 * D.rc;
+        const double j22 = 1.0 + held.j3 * D.rb - held.j1 * D.rc;
+        const double det = j11 * j22 - j12 * j21;
+        fresh = fresh || fabs(det) < 1e-30;
+        const double inv_det = ow_div(1.0, det);
+        double dvbe = (j22 * f1 - j12 * f2) * inv_det;
+        double dvbc = (j11 * f2 - j21 * f1) * inv_det;
+        dvbe = clampd(dvbe, -D.max_step, D.max_step);
+        dvbc = clampd(dvbc, -D.max_step, D.max_step);
+        vbe_int = fresh ? vbe_int : vbe_int - dvbe;
+        vbc_int = fresh ? vbc_int : vbc_int - dvbc;
+    }
+#else
         if (fabs(f1) < 1e-10 && fabs(f2) < 1e-10) { fresh = true; break; }
         const double j11 = 1.0 + e.j2 * D.rb + (e.j0 + e.j2) * D.re;
         const double j12 = e.j3 * D.rb + (e.j1 + e.j3) * D.re;
@@ -128,6 +148,7 @@ __device__ inline PaBjt pa_bjt_with_parasitics(double vbe_ext, double vbc_ext, c
         vbe_int -= dvbe;
         vbc_int -= dvbc;
     }
+#endif
     PaBjt e = held;
     if (__builtin_amdgcn_ballot_w64(!fresh) != 0ull) {
         OW_DBG_WAVE(3);
