@@ -491,7 +491,12 @@ struct Smoother {
 // ------------------------------------------------------------------ legacy DK preamp
 #define OW_P_IS 3.03e-14
 #define OW_P_VT 0.026
-struct DkSt { double j_cin, cin_prev, v[8], i_nl[2], v_nl[2]; };
+// gm[]: the junctions' transconductances AT v_nl, beside i_nl (their currents at v_nl): the evaluation the reference's Newton loop opens
+// every step with (bjt_ic_gm(state.v_nl), dk_preamp_legacy.rs:508-509) is a pure function of state.v_nl, and state.i_nl is by
+// construction bjt_ic(state.v_nl) (at_dc :247, step 9 :548-549) -- so the step's last evaluation is carried into the next one instead of
+// being repeated: one exponential pair per Newton UPDATE, none for the opening residual.  gm lives in registers only: dk_load derives it
+// from v_nl once per block, the state rows in HBM are the reference's fields.
+struct DkSt { double j_cin, cin_prev, v[8], i_nl[2], v_nl[2], gm[2]; };
 
 // exp() for the junction laws below, whose argument is clamped to [-1 V, 0.85 V] / V_T = [-38.5, 32.7]: the device library's f64 exp
 // (x * log2(e) rounded to n, two-step reduction by ln 2, degree-11 polynomial, ldexp) without its overflow / underflow selects
@@ -518,13 +523,26 @@ OW_DEV double exp_bounded(double x) {
     return ldexp(p, (int)n);
 #endif
 }
+// vbe.clamp(-1.0, VBE_MAX) as v_max_f64 + v_min_f64 (the compare-and-select form is two compares and four v_cndmask per junction).  The
+// two differ for a NaN only: f64::clamp hands it on, this gives -1 V.  A junction voltage can only turn NaN in a step whose v_pred is
+// already non-finite (the residuals and the 2x2 are built from p = N_v v_pred and sm_k, and sm_k is in every v_pred too; |det| < 1e-30
+// leaves before 1 / det), every node voltage v = v_pred + ... of that step is then non-finite, the caller's guard (:610-615) sees a
+// non-finite output and replaces the whole state by the DC solve: the currents of such a step are never used
+// (tests/test_gpu_parity.py::test_preamp_nan_reset_in_every_chain_kernel).
+OW_DEV double dk_clamp_vbe(double vbe) { return __builtin_fmin(__builtin_fmax(vbe, -1.0), 0.85); }
 OW_DEV double dk_ic(double vbe) {  // dk_preamp_legacy.rs:663-666
-    return OW_P_IS * (exp_bounded(OW_DIV_C(clampd(vbe, -1.0, 0.85), OW_P_VT)) - 1.0);
+    return OW_P_IS * (exp_bounded(OW_DIV_C(dk_clamp_vbe(vbe), OW_P_VT)) - 1.0);
 }
 OW_DEV void dk_ic_gm(double vbe, double& ic, double& gm) {  // :686-690
-    const double e = exp_bounded(OW_DIV_C(clampd(vbe, -1.0, 0.85), OW_P_VT));
+    const double e = exp_bounded(OW_DIV_C(dk_clamp_vbe(vbe), OW_P_VT));
     ic = OW_P_IS * (e - 1.0);
     gm = (OW_P_IS / OW_P_VT) * e;
+}
+// gm at the state's v_nl (block start, DC solve): see DkSt
+OW_DEV void dk_refresh_gm(DkSt& st) {
+    double ic;
+    dk_ic_gm(st.v_nl[0], ic, st.gm[0]);
+    dk_ic_gm(st.v_nl[1], ic, st.gm[1]);
 }
 
 // dk_step, dk_preamp_legacy.rs:447-554.  Node order BASE1,EMIT1,COLL1,EMIT2,EMIT2B,COLL2,OUT,FB.
@@ -594,54 +612,30 @@ __device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_
     const double k10 = K->p_k[1][0] - sm_k * K->p_nv_sfb[1] * K->p_sfb_ni[0];
     const double k11 = K->p_k[1][1] - sm_k * K->p_nv_sfb[1] * K->p_sfb_ni[1];
     double vn0 = st.v_nl[0], vn1 = st.v_nl[1];
-    // The reference evaluates the collector currents once more after the loop (:519-520) at the final junction voltages.  A lane that
-    // left the loop at one of its two `break`s has not moved them since the loop's last evaluation: bjt_ic is the same expression as the
-    // ic half of bjt_ic_gm (:663-666, :686-690), so that evaluation IS the one after the loop and is kept; only a lane that ran all six
-    // updates evaluates again (two exponentials per sample and state saved when no lane of the wavefront did).
-    double ic0 = 0.0, ic1 = 0.0;
-    bool at_eval = false;
-#ifndef OW_DK_DIVERGENT_NEWTON
-    // Round 6: the sweeps of the wavefront's lanes in ONE wave-uniform loop (as dk_step_row).  A lane that has left the reference's loop at
-    // one of its two `break`s (at_eval) is no longer moved -- the evaluations it still takes part in repeat its last one bit for bit -- and
-    // the loop ends when every lane has, or after the six updates: the same values lane by lane as the per-lane loop below (which a SIMD
-    // runs for as long as its slowest lane anyway), without a divergent loop's execution-mask bookkeeping: k_preamp 6.76 -> 6.46 ms per
-    // 131 072-engine block.  -DOW_DK_DIVERGENT_NEWTON restores the per-lane loop.
+    // Newton on the two junctions (:505-532).  (ic, gm) always hold the evaluation AT (vn0, vn1): the state's own on entry (DkSt), a fresh
+    // one after every update -- so the residual of a sweep needs no exponential, and the evaluation the reference makes after its loop
+    // (:535, bjt_ic is the ic half of bjt_ic_gm) is the one already held, whichever way a lane left: converged, singular 2x2, six updates.
+    // The sweeps of the wavefront's lanes run in ONE wave-uniform loop: a lane that has left the reference's loop at one of its two
+    // `break`s (`done`) is no longer moved -- the evaluations it still takes part in repeat its last one bit for bit -- and the loop ends
+    // when every lane has, or after the six updates: the same values lane by lane as a per-lane loop (which a SIMD runs for as long as
+    // its slowest lane anyway) without a divergent loop's execution-mask bookkeeping.
+    double ic0 = st.i_nl[0], ic1 = st.i_nl[1], gm0 = st.gm[0], gm1 = st.gm[1];
+    bool done = false;
     for (int iter = 0; iter < 6; ++iter) {
-        double gm0, gm1;
-        dk_ic_gm(vn0, ic0, gm0);
-        dk_ic_gm(vn1, ic1, gm1);
         const double f0 = vn0 - p0 - k00 * ic0 - k01 * ic1;
         const double f1 = vn1 - p1 - k10 * ic0 - k11 * ic1;
-        at_eval = at_eval || (fabs(f0) < 1e-9 && fabs(f1) < 1e-9);
-        if (__builtin_amdgcn_ballot_w64(!at_eval) == 0ull) break;
+        done = done || (fabs(f0) < 1e-9 && fabs(f1) < 1e-9);
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
         const double j00 = 1.0 - k00 * gm0, j01 = -k01 * gm1, j10 = -k10 * gm0, j11 = 1.0 - k11 * gm1;
         const double det = j00 * j11 - j01 * j10;
-        at_eval = at_eval || fabs(det) < 1e-30;
+        done = done || fabs(det) < 1e-30;
         const double inv_det = ow_div(1.0, det);
         const double n0 = vn0 - inv_det * (j11 * f0 - j01 * f1);
         const double n1 = vn1 - inv_det * (j00 * f1 - j10 * f0);
-        vn0 = at_eval ? vn0 : n0;
-        vn1 = at_eval ? vn1 : n1;
-    }
-#else
-    for (int iter = 0; iter < 6; ++iter) {
-        double gm0, gm1;
+        vn0 = done ? vn0 : n0;
+        vn1 = done ? vn1 : n1;
         dk_ic_gm(vn0, ic0, gm0);
         dk_ic_gm(vn1, ic1, gm1);
-        const double f0 = vn0 - p0 - k00 * ic0 - k01 * ic1;
-        const double f1 = vn1 - p1 - k10 * ic0 - k11 * ic1;
-        if (fabs(f0) < 1e-9 && fabs(f1) < 1e-9) { at_eval = true; break; }
-        const double j00 = 1.0 - k00 * gm0, j01 = -k01 * gm1, j10 = -k10 * gm0, j11 = 1.0 - k11 * gm1;
-        const double det = j00 * j11 - j01 * j10;
-        if (fabs(det) < 1e-30) { at_eval = true; break; }
-        const double inv_det = ow_div(1.0, det);
-        vn0 -= inv_det * (j11 * f0 - j01 * f1);
-        vn1 -= inv_det * (j00 * f1 - j10 * f0);
-    }
-#endif
-    if (__builtin_amdgcn_ballot_w64(!at_eval) != 0ull) {
-        const double a = dk_ic(vn0), b = dk_ic(vn1);
-        if (!at_eval) { ic0 = a; ic1 = b; }
     }
     K = k_reload(K0);
     const double dot = K->p_sfb_ni[0] * ic0 + K->p_sfb_ni[1] * ic1;
@@ -655,6 +649,7 @@ __device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_
     st.j_cin = -K->p_gc_1pc * dv_cin - K->p_c_cin * st.j_cin;
     st.i_nl[0] = ic0; st.i_nl[1] = ic1;
     st.v_nl[0] = vn0; st.v_nl[1] = vn1;
+    st.gm[0] = gm0; st.gm[1] = gm1;
     return st.v[6];
 }
 
@@ -731,6 +726,7 @@ __device__ inline void dk_dc_reset(const OwConsts* __restrict__ K, double r_ldr,
     DkSt tmp;
     dk_dc_state(K, r_ldr, &tmp);
     st = tmp;
+    dk_refresh_gm(st);
 }
 
 // ------------------------------------------------------------------ oversampler (oversampler.rs:17-45)

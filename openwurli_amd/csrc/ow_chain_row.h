@@ -80,11 +80,8 @@ OW_DEV double exp_bounded_row(double x) {
     return ldexp(p, (int)n);
 #endif
 }
-OW_DEV double dk_ic_row(double vbe) {  // dk_ic
-    return OW_P_IS * (exp_bounded_row(OW_DIV_C(clampd(vbe, -1.0, 0.85), OW_P_VT)) - 1.0);
-}
 OW_DEV void dk_ic_gm_row(double vbe, double& ic, double& gm) {  // dk_ic_gm
-    const double e = exp_bounded_row(OW_DIV_C(clampd(vbe, -1.0, 0.85), OW_P_VT));
+    const double e = exp_bounded_row(OW_DIV_C(dk_clamp_vbe(vbe), OW_P_VT));
     ic = OW_P_IS * (e - 1.0);
     gm = (OW_P_IS / OW_P_VT) * e;
 }
@@ -115,18 +112,14 @@ __device__ __forceinline__ double dk_step_row(DkSt& st, const DkRowK& R, int lan
     const double k10 = R.k[2] - sm_k * R.nv_sfb[1] * R.sfb_ni[0];
     const double k11 = R.k[3] - sm_k * R.nv_sfb[1] * R.sfb_ni[1];
     double vn0 = st.v_nl[0], vn1 = st.v_nl[1];
-    // The sweeps of dk_step's Newton loop (:488-517) for the four states of the wavefront in ONE wave-uniform loop: a state that has left
-    // the reference's loop at one of its two `break`s (`done`) stays where it is -- its junction voltages are no longer moved, so the
-    // evaluations it still takes part in repeat its last one bit for bit -- until every state of the wavefront has; the row moves always
-    // run with every lane active and the loop costs two scalar branches per sweep instead of a divergent loop's mask bookkeeping.
-    double ic0 = 0.0, ic1 = 0.0;
-    bool done = false;                 // left the loop at a `break`: the loop's last evaluation is the one the reference makes after it (dk_step)
+    // dk_step's Newton loop (ow_chain_dev.h): (ic, gm) hold the evaluation at (vn0, vn1) -- the state's own on entry, a fresh one after
+    // every update (even lanes evaluate junction 0, odd lanes junction 1) -- and the four states of the wavefront sweep in ONE wave-uniform
+    // loop: a state that has left the reference's loop at one of its two `break`s (`done`) stays where it is until every state of the
+    // wavefront has; the row moves always run with every lane active and the loop costs two scalar branches per sweep.
+    double ic0 = st.i_nl[0], ic1 = st.i_nl[1], gm0 = st.gm[0], gm1 = st.gm[1];
+    bool done = false;
     const bool odd = (lane & 1) != 0;
     for (int iter = 0; iter < 6; ++iter) {
-        double ic, gm;
-        dk_ic_gm_row(odd ? vn1 : vn0, ic, gm);
-        ic0 = rowb<0>(ic); ic1 = rowb<1>(ic);
-        const double gm0 = rowb<0>(gm), gm1 = rowb<1>(gm);
         const double f0 = vn0 - p0 - k00 * ic0 - k01 * ic1;
         const double f1 = vn1 - p1 - k10 * ic0 - k11 * ic1;
         const double j00 = 1.0 - k00 * gm0, j01 = -k01 * gm1, j10 = -k10 * gm0, j11 = 1.0 - k11 * gm1;
@@ -138,11 +131,10 @@ __device__ __forceinline__ double dk_step_row(DkSt& st, const DkRowK& R, int lan
         const double n1 = vn1 - inv_det * (j00 * f1 - j10 * f0);
         vn0 = done ? vn0 : n0;
         vn1 = done ? vn1 : n1;
-    }
-    if (__builtin_amdgcn_ballot_w64(!done) != 0ull) {          // some state took all six updates: the reference evaluates once more (:519-520)
-        const double ic = dk_ic_row(odd ? vn1 : vn0);
-        const double a = rowb<0>(ic), b = rowb<1>(ic);
-        if (!done) { ic0 = a; ic1 = b; }
+        double ic, gm;
+        dk_ic_gm_row(odd ? vn1 : vn0, ic, gm);
+        ic0 = rowb<0>(ic); ic1 = rowb<1>(ic);
+        gm0 = rowb<0>(gm); gm1 = rowb<1>(gm);
     }
     const double dot = R.sfb_ni[0] * ic0 + R.sfb_ni[1] * ic1;
     const double v_me = vp + (ic0 * R.c1 + ic1 * R.c2) - sm_k * dot * R.fb;
@@ -152,6 +144,7 @@ __device__ __forceinline__ double dk_step_row(DkSt& st, const DkRowK& R, int lan
     st.j_cin = -R.gc_1pc * dv_cin - R.c_cin * st.j_cin;
     st.i_nl[0] = ic0; st.i_nl[1] = ic1;
     st.v_nl[0] = vn0; st.v_nl[1] = vn1;
+    st.gm[0] = gm0; st.gm[1] = gm1;
     return st.v[6];
 }
 

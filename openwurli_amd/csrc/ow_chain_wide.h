@@ -61,11 +61,6 @@ OW_DEV void dk_ic_gm_pair(int q, double vn0, double vn1, double& ic0, double& gm
     ic0 = qperm<0xA0>(ic); gm0 = qperm<0xA0>(gm);   // lanes (0,1,2,3) read lanes (0,0,2,2)
     ic1 = qperm<0xF5>(ic); gm1 = qperm<0xF5>(gm);   // lanes (0,1,2,3) read lanes (1,1,3,3)
 }
-OW_DEV void dk_ic_pair(int q, double vn0, double vn1, double& ic0, double& ic1) {
-    const double ic = dk_ic((q & 1) ? vn1 : vn0);
-    ic0 = qperm<0xA0>(ic);
-    ic1 = qperm<0xF5>(ic);
-}
 
 // dk_step (dk_preamp_legacy.rs:447-554), quad-parallel.  `st` is replicated in the four lanes.
 __device__ inline double dk_step_wide(DkSt& st, const DkWideRows& R, int q, double input, double g_ldr, double g_ldr_prev,
@@ -110,27 +105,25 @@ __device__ inline double dk_step_wide(DkSt& st, const DkWideRows& R, int q, doub
     const double k10 = R.k[2] - sm_k * R.nv_sfb[1] * R.sfb_ni[0];
     const double k11 = R.k[3] - sm_k * R.nv_sfb[1] * R.sfb_ni[1];
     double vn0 = st.v_nl[0], vn1 = st.v_nl[1];
-    // The trip count is the same in the four lanes of a quad (replicated values), so the quad moves inside the loop always find
-    // their source lanes active.
-    double ic0 = 0.0, ic1 = 0.0;
-    bool at_eval = false;              // left the loop at a `break`: the loop's last evaluation is the one the reference makes after it (dk_step)
+    // dk_step's loop (ow_chain_dev.h): (ic, gm) hold the evaluation at (vn0, vn1) -- the state's own on entry, a fresh one after every
+    // update -- and the quads of the wavefront sweep in one wave-uniform loop (a finished quad is no longer moved), so the quad moves
+    // inside dk_ic_gm_pair always find their source lanes active.  `done` is the same in the four lanes of a quad (replicated values).
+    double ic0 = st.i_nl[0], ic1 = st.i_nl[1], gm0 = st.gm[0], gm1 = st.gm[1];
+    bool done = false;
     for (int iter = 0; iter < 6; ++iter) {
-        double gm0, gm1;
-        dk_ic_gm_pair(q, vn0, vn1, ic0, gm0, ic1, gm1);
         const double f0 = vn0 - p0 - k00 * ic0 - k01 * ic1;
         const double f1 = vn1 - p1 - k10 * ic0 - k11 * ic1;
-        if (fabs(f0) < 1e-9 && fabs(f1) < 1e-9) { at_eval = true; break; }
+        done = done || (fabs(f0) < 1e-9 && fabs(f1) < 1e-9);
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
         const double j00 = 1.0 - k00 * gm0, j01 = -k01 * gm1, j10 = -k10 * gm0, j11 = 1.0 - k11 * gm1;
         const double det = j00 * j11 - j01 * j10;
-        if (fabs(det) < 1e-30) { at_eval = true; break; }
+        done = done || fabs(det) < 1e-30;
         const double inv_det = ow_div(1.0, det);
-        vn0 -= inv_det * (j11 * f0 - j01 * f1);
-        vn1 -= inv_det * (j00 * f1 - j10 * f0);
-    }
-    if (__builtin_amdgcn_ballot_w64(!at_eval) != 0ull) {       // wave-uniform: the quad moves inside dk_ic_pair run with every lane active
-        double a, b;
-        dk_ic_pair(q, vn0, vn1, a, b);
-        if (!at_eval) { ic0 = a; ic1 = b; }
+        const double n0 = vn0 - inv_det * (j11 * f0 - j01 * f1);
+        const double n1 = vn1 - inv_det * (j00 * f1 - j10 * f0);
+        vn0 = done ? vn0 : n0;
+        vn1 = done ? vn1 : n1;
+        dk_ic_gm_pair(q, vn0, vn1, ic0, gm0, ic1, gm1);
     }
     const double dot = R.sfb_ni[0] * ic0 + R.sfb_ni[1] * ic1;
     // v = v_pred + S N_i i_c - sm_k (s_fb N_i . i_c) s_fb_col: the same expression for every row with the row's constants -- each
@@ -143,6 +136,7 @@ __device__ inline double dk_step_wide(DkSt& st, const DkWideRows& R, int q, doub
     st.j_cin = -R.gc_1pc * dv_cin - R.c_cin * st.j_cin;
     st.i_nl[0] = ic0; st.i_nl[1] = ic1;
     st.v_nl[0] = vn0; st.v_nl[1] = vn1;
+    st.gm[0] = gm0; st.gm[1] = gm1;
     return st.v[6];
 }
 

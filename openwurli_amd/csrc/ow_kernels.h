@@ -926,6 +926,7 @@ OW_DEV void dk_load(DkSt& s, const double* __restrict__ cs, int I, int e, int ba
 #pragma unroll
     for (int i = 0; i < 8; ++i) s.v[i] = CSF(base + 2 + i);
     s.i_nl[0] = CSF(base + 10); s.i_nl[1] = CSF(base + 11); s.v_nl[0] = CSF(base + 12); s.v_nl[1] = CSF(base + 13);
+    dk_refresh_gm(s);
 }
 OW_DEV void dk_store(const DkSt& s, double* __restrict__ cs, int I, int e, int base) {
     CSF(base) = s.j_cin; CSF(base + 1) = s.cin_prev;
