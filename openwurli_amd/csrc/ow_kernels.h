@@ -54,13 +54,16 @@ __device__ inline void mlp_raw_scalar(double in0, double in1, double raw[11]) {
 }
 
 // ------------------------------------------------------------------ slot ops
+#ifndef OW_APPLY_OPS_ATTR
+#define OW_APPLY_OPS_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 __device__ inline void mlp_raw_mfma(double* __restrict__ h, double in0, double in1, double raw[11]);   // ow_mlp_mfma.h
 
 // Ops of one engine are applied in queue order per slot.  The wavefront advances in rounds: every lane takes its next
 // pending op; the note-ons of a round share ONE batched MLP evaluation on the f64 matrix cores (ow_mlp_mfma.h).
 // Capped at 256 registers (it would take ~500 to keep the MLP weights resident): a wavefront of this kernel then fits beside a
 // tremolo wavefront on a SIMD, so the block-ahead oscillator can be launched before the host has prepared the ops.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_apply_ops(const OwConsts* __restrict__ K, const double* __restrict__ nt, double* __restrict__ vrec,
+__global__ __launch_bounds__(64) OW_APPLY_OPS_ATTR void k_apply_ops(const OwConsts* __restrict__ K, const double* __restrict__ nt, double* __restrict__ vrec,
                                                   const OwEngineArgs* __restrict__ args, const OwOp* __restrict__ ops_packed,
                                                   const uint32_t* __restrict__ engines, const OwOp* __restrict__ ops_fixed = nullptr,
                                                   const OwVm* __restrict__ vm = nullptr, int e_base = 0) {
@@ -101,6 +104,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     uint32_t cursor = 0;
     for (;;) {
+        // The record pointers pass through an opaque move once per round: left visible, the address of every field the round may touch
+        // (rec + 512 f, beyond the 4 KB a load's immediate offset spans) is a loop-invariant 64-bit value the compiler forms AHEAD of the
+        // loop -- ~200 register pairs, 430 registers spilled at this kernel's cap of 256, and a wavefront spent 0.55 ms of a
+        // whole-keyboard re-strike waiting for its own scratch memory (131 072 engines: 18 ms).
+        asm volatile("" : "+v"(main_rec), "+v"(steal_rec));
         OwOp op;
         op.type = 0;
         if (tiled) {                                               // next op addressed to this slot: lowest set bit of the lowest non-empty tile
@@ -139,7 +147,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         } else if (op.type == OP_SET_DS) {
             main_rec[VF_DS * 64] = op.velocity;
         } else if (op.type == OP_MOVE_STEAL) {  // slot.steal_voice = slot.voice.take() (engine.rs:316-321)
-            for (int f = 0; f < VF_COUNT; ++f) steal_rec[f * 64] = main_rec[f * 64];
+            // sixteen loads in flight, then their stores (field by field the copy is 103 dependent load -> store round trips per
+            // wavefront: the two records may alias as far as the compiler knows)
+            constexpr int CP = 16;
+            for (int f0 = 0; f0 < VF_COUNT; f0 += CP) {
+                double t[CP];
+#pragma unroll
+                for (int k = 0; k < CP; ++k) t[k] = f0 + k < VF_COUNT ? main_rec[(f0 + k) * 64] : 0.0;
+#pragma unroll
+                for (int k = 0; k < CP; ++k) if (f0 + k < VF_COUNT) steal_rec[(f0 + k) * 64] = t[k];
+            }
             steal_rec[VF_STEAL * 64] = bitsd((uint64_t)op.seed | ((uint64_t)op.seed << 32));
         }
     }

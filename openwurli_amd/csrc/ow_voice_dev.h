@@ -269,55 +269,52 @@ __device__ inline void note_on_lane(double* __restrict__ rec, const double* __re
     const int ni = note - OW_MIDI_LO;
     const double sr = K->sr;
     const double f0d = nt[NT_F0D * 64 + ni];
-    double ratios[7], amps[7], decay[7];
-    for (int i = 0; i < 7; ++i) { ratios[i] = nt[(NT_RATIO + i) * 64 + ni]; decay[i] = nt[(NT_DECAY + i) * 64 + ni]; }
     // dwell filter (hammer.rs:26-29, 69-90) on the uncorrected ratios
     const double t_dwell = clampd((0.75 + 0.25 * (1.0 - vel)) / f0d, 0.0003, 0.020);
-    double att[7];
-    for (int i = 0; i < 7; ++i) {
-        const double ft = f0d * ratios[i] * t_dwell;
-        att[i] = exp(-ft * ft / (2.0 * (8.0 * 8.0)));
+    double a0;
+    {
+        const double ft = f0d * nt[NT_RATIO * 64 + ni] * t_dwell;
+        a0 = exp(-ft * ft / (2.0 * (8.0 * 8.0)));
     }
-    const double a0 = att[0];
-    if (a0 > 1e-30)
-        for (int i = 0; i < 7; ++i) att[i] /= a0;
     const double onset_time = fmax((1.0 + 1.0 * (1.0 - vel)) * (1.0 / f0d), 0.002);  // hammer.rs:53-57
     const double scurve = velocity_scurve(vel);
     const double vel_scale = pow(scurve, nt[NT_VEL_EXP * 64 + ni]);
-    for (int i = 0; i < 7; ++i) {
-        amps[i] = nt[(NT_AMP + i) * 64 + ni] * att[i] * nt[(NT_AOFF + i) * 64 + ni];
-        amps[i] *= vel_scale;
-    }
-    for (int h = 0; h < 5; ++h) {                                                   // voice.rs:68-84
-        ratios[1 + h] *= pow(2.0, corr.cents[h] / 1200.0);
-        decay[1 + h] /= corr.decay[h];
-    }
     const double base_ds = nt[NT_DS * 64 + ni];
     const double corrected_ds = base_ds * corr.ds;
-
-    // ModalReed::new (reed.rs:108-182)
+    // One ROLLED loop over the seven modes (dwell attenuation, MLP corrections voice.rs:68-84, ModalReed::new reed.rs:108-182): every
+    // value is the expression it was when the steps were seven-wide loops of their own, but the exponentials, powers, logarithms and
+    // sines of a mode are in the code once instead of seven times side by side -- unrolled, k_apply_ops wanted > 512 registers, spilled
+    // 430 of them at its cap of 256 and a wavefront spent 0.55 ms waiting for its own scratch memory (a whole-pool re-strike: 18 ms).
     uint32_t js = seed > 1u ? seed : 1u;
-    double drift[7];
+#pragma unroll 1
     for (int i = 0; i < 7; ++i) {
+        double ratio = nt[(NT_RATIO + i) * 64 + ni], dec = nt[(NT_DECAY + i) * 64 + ni];
+        const double ft = f0d * ratio * t_dwell;
+        double att = exp(-ft * ft / (2.0 * (8.0 * 8.0)));
+        if (a0 > 1e-30) att /= a0;
+        double amp = nt[(NT_AMP + i) * 64 + ni] * att * nt[(NT_AOFF + i) * 64 + ni];
+        amp *= vel_scale;
+        if (i >= 1 && i <= 5) {                                                     // voice.rs:68-84
+            ratio *= pow(2.0, corr.cents[i - 1] / 1200.0);
+            dec /= corr.decay[i - 1];
+        }
         js = lcg(js);
         const double u1 = (double)(js >> 1) / 2147483647.5;
         js = lcg(js);
         const double u2 = (double)(js >> 1) / 2147483647.5;
         const double r = sqrt(-2.0 * log(fmax(u1, 1e-30)));
-        drift[i] = 0.0004 * r * cos(6.28318530717958647692 * u2);
-    }
-    for (int i = 0; i < 7; ++i) {
-        const double freq = f0d * ratios[i];
+        const double drift = 0.0004 * r * cos(6.28318530717958647692 * u2);
+        const double freq = f0d * ratio;
         const double phase_inc = 6.28318530717958647692 * freq / sr;
-        const double decay_per_sample = (decay[i] / 8.686) / sr;
+        const double decay_per_sample = (dec / 8.686) / sr;
         rec[(VF_S + i) * 64] = 0.0;
         rec[(VF_C + i) * 64] = 1.0;
         rec[(VF_ENV + i) * 64] = 1.0;
-        rec[(VF_DRIFT + i) * 64] = drift[i];
+        rec[(VF_DRIFT + i) * 64] = drift;
         rec[(VF_COS_INC + i) * 64] = cos(phase_inc);
         rec[(VF_SIN_INC + i) * 64] = sin(phase_inc);
         rec[(VF_PHASE_INC + i) * 64] = phase_inc;
-        rec[(VF_AMP + i) * 64] = amps[i];
+        rec[(VF_AMP + i) * 64] = amp;
         rec[(VF_DECAY + i) * 64] = exp(-decay_per_sample);
         rec[(VF_DRATE + i) * 64] = 0.0;
         rec[(VF_DMULT + i) * 64] = 1.0;
