@@ -488,6 +488,17 @@ struct Smoother {
     }
 };
 
+// Value of lane ^ 32 (main <-> shadow) without the LDS crossbar: v_permlane32_swap exchanges the upper half of its first operand
+// with the lower half of its second; with both = x the first result holds x[lane - 32] in lanes 32-63 and the second x[lane + 32]
+// in lanes 0-31.
+OW_DEV double xor32(double x) {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const bool low_half = (threadIdx.x & 63) < 32;      // (lane of the wavefront: k_chain_row's preamp wavefronts are not wavefront 0 of their block)
+    return __hiloint2double(low_half ? b[1] : b[0], low_half ? a[1] : a[0]);
+}
+
 // ------------------------------------------------------------------ legacy DK preamp
 #define OW_P_IS 3.03e-14
 #define OW_P_VT 0.026
@@ -560,18 +571,20 @@ __device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_
     const OwConsts* __restrict__ K = k_reload(K0);
     // rhs = A_neg v (dk_preamp_legacy.rs:466).  A_neg = 2C/T - G has 20 structural non-zeros (resistor/capacitor stamps,
     // :283-309); the reference multiplies the zeros too, which adds exact +-0.0 terms, so skipping them is bit-identical
-    // for finite v (a non-finite v still propagates through its node's own diagonal entry).
+    // for finite v (a non-finite v still propagates through its node's own diagonal entry).  The sums also start at their first product
+    // instead of the reference's 0.0: `0.0 + x` is x except for x = -0.0, and a row that is +-0.0 at this point gets 2w[i] added below,
+    // which is non-zero or +0.0 (ow_consts_host.hpp) -- the row ends as the same bits either way.
     const double (*__restrict__ an)[8] = K->p_a_neg;
     const double* v = st.v;
     double rhs[8];
-    rhs[0] = 0.0 + an[0][0] * v[0] + an[0][2] * v[2];
-    rhs[1] = 0.0 + an[1][1] * v[1] + an[1][7] * v[7];
-    rhs[2] = 0.0 + an[2][0] * v[0] + an[2][2] * v[2] + an[2][5] * v[5];
-    rhs[3] = 0.0 + an[3][3] * v[3] + an[3][4] * v[4];
-    rhs[4] = 0.0 + an[4][3] * v[3] + an[4][4] * v[4];
-    rhs[5] = 0.0 + an[5][2] * v[2] + an[5][5] * v[5] + an[5][6] * v[6];
-    rhs[6] = 0.0 + an[6][5] * v[5] + an[6][6] * v[6] + an[6][7] * v[7];
-    rhs[7] = 0.0 + an[7][1] * v[1] + an[7][6] * v[6] + an[7][7] * v[7];
+    rhs[0] = an[0][0] * v[0] + an[0][2] * v[2];
+    rhs[1] = an[1][1] * v[1] + an[1][7] * v[7];
+    rhs[2] = an[2][0] * v[0] + an[2][2] * v[2] + an[2][5] * v[5];
+    rhs[3] = an[3][3] * v[3] + an[3][4] * v[4];
+    rhs[4] = an[4][3] * v[3] + an[4][4] * v[4];
+    rhs[5] = an[5][2] * v[2] + an[5][5] * v[5] + an[5][6] * v[6];
+    rhs[6] = an[6][5] * v[5] + an[6][6] * v[6] + an[6][7] * v[7];
+    rhs[7] = an[7][1] * v[1] + an[7][6] * v[6] + an[7][7] * v[7];
     rhs[7] -= g_ldr_prev * st.v[7];
     const double cin_now = K->p_g_cin * input + st.j_cin;
     rhs[0] += cin_now + st.cin_prev;

@@ -68,14 +68,14 @@ __device__ inline double dk_step_wide(DkSt& st, const DkWideRows& R, int q, doub
     const double* an = R.an;
     const double* v = st.v;
     double rhs[8];
-    rhs[0] = 0.0 + an[0] * v[0] + an[1] * v[2];
-    rhs[1] = 0.0 + an[2] * v[1] + an[3] * v[7];
-    rhs[2] = 0.0 + an[4] * v[0] + an[5] * v[2] + an[6] * v[5];
-    rhs[3] = 0.0 + an[7] * v[3] + an[8] * v[4];
-    rhs[4] = 0.0 + an[9] * v[3] + an[10] * v[4];
-    rhs[5] = 0.0 + an[11] * v[2] + an[12] * v[5] + an[13] * v[6];
-    rhs[6] = 0.0 + an[14] * v[5] + an[15] * v[6] + an[16] * v[7];
-    rhs[7] = 0.0 + an[17] * v[1] + an[18] * v[6] + an[19] * v[7];
+    rhs[0] = an[0] * v[0] + an[1] * v[2];
+    rhs[1] = an[2] * v[1] + an[3] * v[7];
+    rhs[2] = an[4] * v[0] + an[5] * v[2] + an[6] * v[5];
+    rhs[3] = an[7] * v[3] + an[8] * v[4];
+    rhs[4] = an[9] * v[3] + an[10] * v[4];
+    rhs[5] = an[11] * v[2] + an[12] * v[5] + an[13] * v[6];
+    rhs[6] = an[14] * v[5] + an[15] * v[6] + an[16] * v[7];
+    rhs[7] = an[17] * v[1] + an[18] * v[6] + an[19] * v[7];
     rhs[7] -= g_ldr_prev * st.v[7];
     const double cin_now = R.g_cin * input + st.j_cin;
     rhs[0] += cin_now + st.cin_prev;
@@ -138,17 +138,6 @@ __device__ inline double dk_step_wide(DkSt& st, const DkWideRows& R, int q, doub
     st.v_nl[0] = vn0; st.v_nl[1] = vn1;
     st.gm[0] = gm0; st.gm[1] = gm1;
     return st.v[6];
-}
-
-// Value of lane ^ 32 (main <-> shadow) without the LDS crossbar: v_permlane32_swap exchanges the upper half of its first operand
-// with the lower half of its second; with both = x the first result holds x[lane - 32] in lanes 32-63 and the second x[lane + 32]
-// in lanes 0-31.
-OW_DEV double xor32(double x) {
-    const int lo = __double2loint(x), hi = __double2hiint(x);
-    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    const bool low_half = (threadIdx.x & 63) < 32;      // (lane of the wavefront: k_chain_row's preamp wavefronts are not wavefront 0 of their block)
-    return __hiloint2double(low_half ? b[1] : b[0], low_half ? a[1] : a[0]);
 }
 
 // k_job_chain<false> with a quad per solver state: 8 jobs per wavefront (main quads in lanes 0-31, shadow quads in lanes 32-63).

@@ -204,7 +204,7 @@ static void build_preamp_consts(OwConsts& c) {
             a[i][j] = tc + g[i][j];
             c.p_a_neg[i][j] = tc - g[i][j];
         }
-    for (int i = 0; i < 8; ++i) c.p_two_w[i] = 2.0 * w[i];
+    for (int i = 0; i < 8; ++i) c.p_two_w[i] = 2.0 * w[i] + 0.0;      // (never -0.0: dk_step's rhs rows rely on it, see there)
     gauss_jordan8(a, c.p_s);
     const double (*s)[8] = c.p_s;
     c.p_k[0][0] = s[BASE1][EMIT1] - s[BASE1][COLL1] - s[EMIT1][EMIT1] + s[EMIT1][COLL1];

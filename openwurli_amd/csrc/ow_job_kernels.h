@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64) void k_job_chain(const OwConsts* __restrict__ K
             o = dk_step(st, x, g_ldr, g_prev, K);
             g_prev = g_ldr;
         }
-        const double other = __shfl_xor(o, 32);
+        const double other = xor32(o);
         double res = role ? (other - o) : (o - other);
         if (!isfinite(res)) {
             if (MEL) { mel_init_state(ms, settled); }

@@ -1216,6 +1216,7 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
         }
     }
     uint32_t nan_resets = 0;
+    double sh_depth = __longlong_as_double(0x7FF8000000000000LL), sh_top = 0.0, sh_lower = 0.0;      // trem_shunt's depth-only part (NaN: nothing formed yet)
     // per-lane staging flags of engine row (lane & 31): bit0 = slot pass present, bit1 = steal pass present; 0 when the row is
     // past the range or its block is non-finite (engine.rs:499-501 zeroes it).  Broadcast per row with v_readlane below, so the
     // staging loop has no scalar loads and no branches and the row loads of a group are all in flight together.
@@ -1254,6 +1255,15 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
                 if (osr == 2) rn[1] = trem_col_at(tcol, nx + 1u);
             }
             const double depth = clampd(sd.next(), 0.0, 1.0);   // engine.rs:533-534, tremolo.rs:117-119
+            // Tremolo::shunt_impedance (tremolo.rs:152-167; trem_shunt): the pot's upper leg and r_lower depend on the depth alone, and the
+            // depth only moves while its smoother ramps -- formed again (the same operations: the same bits) when some lane of the wavefront
+            // sees another depth than the one they were formed from (k_chain_row's form)
+            if (__builtin_amdgcn_ballot_w64(!(depth == sh_depth)) != 0ull) {
+                sh_depth = depth;
+                const double r_upper = 50000.0 * (1.0 - depth);
+                sh_lower = 50000.0 * depth;
+                sh_top = r_upper > 0.0 ? ow_div(r_upper * 18000.0, r_upper + 18000.0) : 0.0;
+            }
             double in[2];
             if (osr == 2) {  // Oversampler::upsample_2x (oversampler.rs:108-121); shadow input is 0.0 (dk_preamp_legacy.rs:599)
                 const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, ua, x);
@@ -1266,11 +1276,13 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
             }
             for (int j = 0; j < osr; ++j) {
                 const size_t idx = (size_t)((base + n) * osr + j);
-                const double r_new = fmax(trem_shunt(depth, rc[j]), 1000.0);   // tremolo.rs:152-167; set_ldr_resistance, :620-626
+                const double branch = 680.0 + rc[j];
+                const double low = sh_lower > 0.0 ? ow_div(sh_lower * branch, sh_lower + branch) : 0.0;
+                const double r_new = fmax(sh_top + low, 1000.0);               // tremolo.rs:152-167; set_ldr_resistance, :620-626
                 if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = ow_div(1.0, r_new); }
                 const double o = dk_step(st, in[j], g_ldr, g_prev, K);
                 g_prev = g_ldr;                                                   // :604
-                const double other = __shfl_xor(o, 32);
+                const double other = xor32(o);
                 double result = role ? (other - o) : (o - other);                 // main - pump, :608
                 if (!isfinite(result)) {                                          // :610-615
                     dk_dc_reset(K, r_ldr, st);
@@ -1350,7 +1362,7 @@ __global__ __launch_bounds__(64) void k_post(const OwConsts* __restrict__ K, dou
             const double y = power_amp(pc * 0.25);
             double o;
             if (SPLIT) {  // engine.rs:536-553
-                const double yo = __shfl_xor(y, 32);
+                const double yo = xor32(y);
                 const double y0 = phase ? yo : y, y1 = phase ? y : yo;
                 const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, y0);
                 const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, y1);
