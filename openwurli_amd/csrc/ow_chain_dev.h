@@ -491,6 +491,16 @@ struct Smoother {
 // Value of lane ^ 32 (main <-> shadow) without the LDS crossbar: v_permlane32_swap exchanges the upper half of its first operand
 // with the lower half of its second; with both = x the first result holds x[lane - 32] in lanes 32-63 and the second x[lane + 32]
 // in lanes 0-31.
+// xor32_t: the same exchange for the pool-sized kernels (two wavefronts per SIMD, vector-issue bound): OW_XOR32_SWAP picks the swap form
+// there too, the default is the LDS crossbar's ds_bpermute, which costs them no vector issue slots
+OW_DEV double xor32(double x);
+OW_DEV double xor32_t(double x) {
+#ifdef OW_XOR32_SWAP
+    return xor32(x);
+#else
+    return __shfl_xor(x, 32);
+#endif
+}
 OW_DEV double xor32(double x) {
     const int lo = __double2loint(x), hi = __double2hiint(x);
     const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);

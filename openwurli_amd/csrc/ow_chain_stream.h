@@ -51,7 +51,7 @@ __device__ __noinline__ bool chain_stream_post_chunk(const OwConsts* __restrict_
         const double pc = pn;
         pn = pre[((size_t)(base + min(n + 1, cn - 1)) * 2 + phase) * I + e];     // one sample ahead, inside the chunk
         const double y = power_amp(pc * 0.25);
-        const double yo = xor32(y);                                // engine.rs:536-553
+        const double yo = xor32_t(y);                                // engine.rs:536-553
         const double y0 = phase ? yo : y, y1 = phase ? y : yo;
         const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, y0);
         const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, y1);
@@ -163,7 +163,7 @@ void k_chain_stream(const OwConsts* __restrict__ K, double* __restrict__ cs, con
                 if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = ow_div(1.0, r_new); }
                 const double o = dk_step(st, in[j], g_ldr, g_prev, K);
                 g_prev = g_ldr;                                                   // :604
-                const double other = xor32(o);
+                const double other = xor32_t(o);
                 double result = role ? (other - o) : (o - other);                 // main - pump, :608
                 if (!isfinite(result)) {                                          // :610-615
                     dk_dc_reset(K, r_ldr, st);

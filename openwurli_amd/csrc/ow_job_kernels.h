@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64) void k_job_chain(const OwConsts* __restrict__ K
             o = dk_step(st, x, g_ldr, g_prev, K);
             g_prev = g_ldr;
         }
-        const double other = xor32(o);
+        const double other = xor32_t(o);
         double res = role ? (other - o) : (o - other);
         if (!isfinite(res)) {
             if (MEL) { mel_init_state(ms, settled); }

@@ -1282,7 +1282,7 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
                 if (fabs(r_new - r_ldr) > 0.01) { r_ldr = r_new; g_ldr = ow_div(1.0, r_new); }
                 const double o = dk_step(st, in[j], g_ldr, g_prev, K);
                 g_prev = g_ldr;                                                   // :604
-                const double other = xor32(o);
+                const double other = xor32_t(o);
                 double result = role ? (other - o) : (o - other);                 // main - pump, :608
                 if (!isfinite(result)) {                                          // :610-615
                     dk_dc_reset(K, r_ldr, st);
@@ -1362,7 +1362,7 @@ __global__ __launch_bounds__(64) void k_post(const OwConsts* __restrict__ K, dou
             const double y = power_amp(pc * 0.25);
             double o;
             if (SPLIT) {  // engine.rs:536-553
-                const double yo = xor32(y);
+                const double yo = xor32_t(y);
                 const double y0 = phase ? yo : y, y1 = phase ? y : yo;
                 const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, y0);
                 const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, y1);
