@@ -120,6 +120,9 @@ int ow_test_engine_poke_voice(ow_engine*, int slot, int steal, int field, double
 /* The same for the legacy preamp: overwrite node voltage `node` (0..7) of engine e's main (shadow = 0) or shadow solver state before the next
  * block.  A non-finite value provokes the preamp's own NaN reset (dk_preamp_legacy.rs:610-615).  Returns 0, <0 on error. */
 int ow_test_engine_poke_preamp_node(ow_engine*, int shadow, int node, double volts);
+/* ... and read that state back after the blocks rendered so far: out14 = j_cin, cin_rhs_prev, v[8], i_nl[2], v_nl[2] (DkState,
+ * dk_preamp_legacy.rs:231-239).  Returns 0, <0 on error. */
+int ow_test_engine_read_preamp_state(ow_engine*, int shadow, double* out14);
 
 /* Plain device-to-host copy, for reading a block that ow_pool_render(pool, NULL, ...) left in HBM (ow_pool_device_output). */
 int ow_test_device_read(void* dst_host, const void* src_device, size_t bytes, int device);

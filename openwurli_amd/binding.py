@@ -187,6 +187,7 @@ TEST_SYMBOLS = {
     "ow_test_device_read": (C.c_int, [_VP, _VP, C.c_size_t, C.c_int]),
     "ow_test_engine_poke_voice": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_double]),
     "ow_test_engine_poke_preamp_node": (C.c_int, [_VP, C.c_int, C.c_int, C.c_double]),
+    "ow_test_engine_read_preamp_state": (C.c_int, [_VP, C.c_int, _VP]),
     "ow_test_host_matrices": (C.c_int, [C.c_int, C.c_double, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "ow_debug_trem_trajectory": (C.c_int, [C.c_double, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int, _VP, _VP, _VP, _VP, _VP, C.c_int, _VP, _VP]),
 }

@@ -82,6 +82,15 @@ class _EngineHandle:
         """Test hook (openwurli_hip_test.h): overwrite a node voltage of the legacy preamp's main / shadow solver state."""
         return self._lib.ow_test_engine_poke_preamp_node(self._h, 1 if shadow else 0, int(node), float(volts))
 
+    def read_preamp_state(self, shadow=False):
+        """Test hook (openwurli_hip_test.h): the legacy preamp's solver state after the blocks rendered so far -- j_cin, cin_rhs_prev, v[8],
+        i_nl[2], v_nl[2] (DkState, dk_preamp_legacy.rs:231-239)."""
+        import numpy as np
+        out = np.zeros(14, dtype=np.float64)
+        if self._lib.ow_test_engine_read_preamp_state(self._h, 1 if shadow else 0, out.ctypes.data) != 0:
+            raise RuntimeError("ow_test_engine_read_preamp_state failed")
+        return out
+
     def reset(self):
         self._lib.ow_engine_reset(self._h)
         binding.raise_if_error(self._lib)

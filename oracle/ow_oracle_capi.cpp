@@ -64,6 +64,16 @@ void owo_engine_poke_preamp_node(void* e, int shadow, int node, double v) {
     WurliEngine* w = (WurliEngine*)e;
     (shadow ? w->preamp.shadow : w->preamp.main).v[node] = v;
 }
+// the legacy preamp's solver state (main / shadow) as stored: j_cin, cin_rhs_prev, v[8], i_nl[2], v_nl[2], then bjt_ic(v_nl[0..1]) evaluated
+// NOW -- tests/test_oracle_sensitivity.py pins the invariant i_nl == bjt_ic(v_nl) the product's carried evaluation rests on
+void owo_engine_preamp_state(void* e, int shadow, double* out16) {
+    WurliEngine* w = (WurliEngine*)e;
+    const DkState& s = shadow ? w->preamp.shadow : w->preamp.main;
+    out16[0] = s.j_cin; out16[1] = s.cin_rhs_prev;
+    for (int i = 0; i < 8; ++i) out16[2 + i] = s.v[i];
+    out16[10] = s.i_nl[0]; out16[11] = s.i_nl[1]; out16[12] = s.v_nl[0]; out16[13] = s.v_nl[1];
+    out16[14] = dk::bjt_ic(s.v_nl[0]); out16[15] = dk::bjt_ic(s.v_nl[1]);
+}
 void owo_engine_poke_pa_node(void* e, int node, double v) { ((WurliEngine*)e)->mel_pa.state.v_prev[node] = v; }
 // render with the power-amp tap (chain rate) besides the output
 void owo_engine_render_pa_tap(void* e, float* out, double* pa, size_t n) {

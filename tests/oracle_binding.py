@@ -152,6 +152,12 @@ class OracleEngine:
         """test poke: a node voltage of the legacy preamp's solver state (the product's ow_test_engine_poke_preamp_node)"""
         self.L.owo_engine_poke_preamp_node(self.h, 1 if shadow else 0, int(node), C.c_double(volts))
 
+    def preamp_state(self, shadow=False):
+        """the legacy preamp's solver state as stored (j_cin, cin_rhs_prev, v[8], i_nl[2], v_nl[2]) + bjt_ic(v_nl[0..1]) evaluated now"""
+        out = np.zeros(16, dtype=np.float64)
+        self.L.owo_engine_preamp_state(self.h, 1 if shadow else 0, out.ctypes.data_as(C.c_void_p))
+        return out
+
     def poke_power_amp_node(self, node, volts): self.L.owo_engine_poke_pa_node(self.h, int(node), C.c_double(volts))
 
     def count_voices_in_state(self, st): return self.L.owo_engine_count_state(self.h, int(st))

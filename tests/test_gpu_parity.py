@@ -1103,6 +1103,66 @@ def test_preamp_nan_reset_in_every_chain_kernel(hiplib, oracle):
         c.close()
 
 
+def test_preamp_state_rows_are_the_references_fields_in_every_chain_kernel(hiplib, oracle):
+    """dk_step carries the junction evaluation from one step into the next (i_nl beside a register-only gm: DESIGN.md section 4.1) -- the
+    state rows in HBM stay the reference's DkState (dk_preamp_legacy.rs:231-239).  After every block of a scenario with notes, a depth
+    ramp, a release and a reset, under every chain kernel: the fourteen fields of main and shadow are the same bits in every kernel, and
+    the oracle's within the preamp bar (volts: 1e-5 relative + the preamp floor; currents and the capacitor's companion source, which
+    are ~1e-4 A and ~1e-6 A: the same relative bar + 1e-12)."""
+    import openwurli_amd as ow
+    sr, n_eng = 48000.0, 3
+    modes = {"lane pairs": {"chain_fused": 0, "preamp_wide": 0}, "quad, two launches": {"chain_fused": 0, "preamp_wide": 1},
+             "quad, fused": {"chain_fused": 1, "chain_row": 0}, "row": {"chain_fused": 1, "chain_row": 1}}
+    lens = [64, 97, 512, 1, 33, 256, 128, 512]
+    states = {}
+    for name in list(modes) + ["oracle"]:
+        g = None
+        if name != "oracle":
+            g = ow.EnginePool(sr, n_eng); g.set_sample_rate(sr)
+            for k, v in modes[name].items():
+                g.set_switch(k, v)
+            es = [g[k] for k in range(n_eng)]
+        else:
+            es = [oracle.OracleEngine(sr) for _ in range(n_eng)]
+            for e in es:
+                e.set_sample_rate(sr)
+        for k, e in enumerate(es):
+            e.set_tremolo_depth(0.4 * k); e.set_volume(0.5)
+            for note in (43 + 2 * k, 60, 72 + k):
+                e.note_on(note, 0.85)
+        rows = []
+        for b, n in enumerate(lens):
+            if b == 2:
+                es[1].set_tremolo_depth(1.0)
+            if b == 4:
+                es[0].note_off(60)
+            if b == 6:
+                es[2].reset()
+            if g is not None:
+                g.render(n)
+                rows.append(np.stack([np.stack([e.read_preamp_state(False), e.read_preamp_state(True)]) for e in es]))
+            else:
+                for e in es:
+                    e.render(n)
+                rows.append(np.stack([np.stack([e.preamp_state(False)[:14], e.preamp_state(True)[:14]]) for e in es]))
+        states[name] = rows
+        if g is not None:
+            g.close()
+        else:
+            for e in es:
+                e.close()
+    ref = states["lane pairs"]
+    for name in modes:
+        for b in range(len(lens)):
+            assert states[name][b].tobytes() == ref[b].tobytes(), (name, b)
+    for b in range(len(lens)):
+        a, o = ref[b], states["oracle"][b]
+        volts = np.abs(a[..., 2:10] - o[..., 2:10]) <= 1e-5 * np.abs(o[..., 2:10]) + oracle.ABS_FLOOR_PREAMP
+        vnl = np.abs(a[..., 12:14] - o[..., 12:14]) <= 1e-5 * np.abs(o[..., 12:14]) + oracle.ABS_FLOOR_PREAMP
+        amps = np.abs(a[..., [0, 1, 10, 11]] - o[..., [0, 1, 10, 11]]) <= 1e-5 * np.abs(o[..., [0, 1, 10, 11]]) + 1e-12
+        assert volts.all() and vnl.all() and amps.all(), (b, a - o)
+
+
 def test_chain_stream_is_bit_identical(hiplib, oracle):
     """Big oversampled pools whose block goes to a pinned host block run preamp and output stage as ONE launch (k_chain_stream,
     ow_chain_stream.h: one wavefront per 32 engines alternates between the two per 64-sample chunk and stores the f32 rows straight into

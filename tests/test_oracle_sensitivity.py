@@ -283,3 +283,28 @@ def test_soak_floor_governing_measurement(oracle):
     print(f"\n[floor table] ABS_FLOOR_SOAK {oracle.ABS_FLOOR_SOAK:.1e}: one-ulp {moved:.2e} (seed 5, block 691, engine 0), ratio {oracle.ABS_FLOOR_SOAK / moved:.2f}")
     assert 2e-8 < moved < 6e-8, moved
     assert oracle.ABS_FLOOR_SOAK <= oracle.FLOOR_RULE * moved
+
+
+def test_preamp_state_holds_the_evaluation_its_next_step_opens_with(oracle):
+    """dk_preamp_legacy.rs: the Newton loop of a step opens with bjt_ic_gm(state.v_nl) (:508-509); state.i_nl is bjt_ic(state.v_nl)
+    by construction (at_dc :247, step 9 :548-549) and bjt_ic is the ic half of bjt_ic_gm (:663-666, :686-690).  The product's dk_step
+    carries that evaluation from one step into the next instead of repeating it: this pins the invariant on the
+    reference's restatement -- at creation, block by block through notes, a depth ramp, a release and a reset, main and shadow."""
+    e = oracle.OracleEngine(48000.0)
+    e.set_volume(0.5); e.set_tremolo_depth(0.5); e.set_speaker_character(0.0); e.set_mlp_enabled(True)
+
+    def check(tag):
+        for shadow in (False, True):
+            st = e.preamp_state(shadow)
+            assert st[10].tobytes() == st[14].tobytes() and st[11].tobytes() == st[15].tobytes(), (tag, shadow, st[10:16])
+    check("new")
+    for n in (40, 52, 60, 67, 76, 88):
+        e.note_on(n, 0.9)
+    for b in range(40):
+        e.render(97 if b % 3 else 512)
+        if b == 10: e.set_tremolo_depth(1.0)
+        if b == 20:
+            for n in (40, 60): e.note_off(n)
+        if b == 30: e.reset()
+        check(b)
+    e.close()
