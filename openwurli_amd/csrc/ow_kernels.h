@@ -1317,7 +1317,10 @@ __global__ __launch_bounds__(64) void k_preamp(const OwConsts* __restrict__ K, d
 // stateless (power_amp.rs:206), so the two chain-rate samples of one output sample are solved by the two lanes of a pair and
 // exchanged with one __shfl_xor; both lanes then run the identical half-band / speaker recurrence (no divergence), the phase-0
 // lane owns the state and the output.  Twice the wavefronts of the lane=engine layout, each with ~60 % of the instructions.
-template <bool SPLIT>
+// PAIR (round 6, with SPLIT = false): the oversampled chain with lane = engine -- the lane solves the two chain samples one after the
+// other and runs the half-band / speaker part ONCE: 0.83 of SPLIT's lane-work per engine, for ranges big enough to fill the chip with
+// half the wavefronts (>= 2 per SIMD: the host's choice, `post_pair`).  Same operations per value: the same bits.
+template <bool SPLIT, bool PAIR = false>
 __global__ __launch_bounds__(64) void k_post(const OwConsts* __restrict__ K, double* __restrict__ cs, const OwEngineArgs* __restrict__ args,
                                              OwEngineOut* __restrict__ eout, const double* __restrict__ pre, float* __restrict__ out, int I, int L,
                                              int Lcap, int e0, int ne, float* __restrict__ out2 = nullptr, size_t ld2 = 0) {
@@ -1332,7 +1335,8 @@ __global__ __launch_bounds__(64) void k_post(const OwConsts* __restrict__ K, dou
     const int e_raw = eb + el;
     const bool valid = e_raw < e0 + ne;
     const int e = valid ? e_raw : (e0 + ne - 1);
-    const int osr = SPLIT ? 2 : 1;
+    static_assert(!(SPLIT && PAIR), "PAIR is the lane = engine form of the oversampled chain");
+    const int osr = (SPLIT || PAIR) ? 2 : 1;
     const double sr = K->sr;
     const double thermal_alpha = K->spk_thermal_alpha;
 
@@ -1354,14 +1358,22 @@ __global__ __launch_bounds__(64) void k_post(const OwConsts* __restrict__ K, dou
 
     // the preamp stream is read one host sample ahead (registers): hides the global-load latency behind the previous sample
     double pn = pre[(size_t)phase * I + e];
+    double pn1 = PAIR ? pre[(size_t)I + e] : 0.0;
     for (int base = 0; base < L; base += OW_OCHUNK) {
         const int cn = min(OW_OCHUNK, L - base);
         for (int n = 0; n < cn; ++n) {
-            const double pc = pn;
+            const double pc = pn, pc1 = pn1;
             pn = pre[((size_t)min(base + n + 1, L - 1) * osr + phase) * I + e];
+            if (PAIR) pn1 = pre[((size_t)min(base + n + 1, L - 1) * 2 + 1) * I + e];
             const double y = power_amp(pc * 0.25);
             double o;
-            if (SPLIT) {  // engine.rs:536-553
+            if (PAIR) {   // engine.rs:536-553, both chain samples in this lane
+                const double y1 = power_amp(pc1 * 0.25);
+                const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, y);
+                const double b = allpass3(OW_OS_B0, OW_OS_B1, OW_OS_B2, db, y1);
+                o = (a + dd) * 0.5;
+                dd = b;
+            } else if (SPLIT) {  // engine.rs:536-553
                 const double yo = xor32_t(y);
                 const double y0 = phase ? yo : y, y1 = phase ? y : yo;
                 const double a = allpass3(OW_OS_A0, OW_OS_A1, OW_OS_A2, da, y0);

@@ -1163,6 +1163,36 @@ def test_preamp_state_rows_are_the_references_fields_in_every_chain_kernel(hipli
         assert volts.all() and vnl.all() and amps.all(), (b, a - o)
 
 
+def test_post_pair_is_bit_identical(hiplib):
+    """The oversampled output stage with lane = engine (k_post<false, true>: both chain samples of an output sample solved in one lane,
+    the half-band / speaker part run once; the default for ranges of >= 131 072 engines) against the lane-pair form (k_post<true>): the
+    same bits at the output through notes, speaker-character and volume ramps, a ragged pool (not a multiple of 64 engines) and blocks
+    that are not multiples of the 64-sample store chunk."""
+    import openwurli_amd as ow
+    sr, n_eng = 48000.0, 97
+    outs = {}
+    for pair in (0, 1):
+        g = ow.EnginePool(sr, n_eng); g.set_sample_rate(sr)
+        g.set_switch("chain_fused", 0); g.set_switch("preamp_wide", 0); g.set_switch("post_pair", pair)
+        assert g.get_switch("post_pair") == pair
+        for k in range(n_eng):
+            e = g[k]
+            e.set_tremolo_depth((k % 5) * 0.25); e.set_volume(0.3 + 0.05 * (k % 8)); e.set_speaker_character((k % 3) * 0.5)
+            for note in (40 + k % 30, 60, 65 + k % 20):
+                e.note_on(note, 0.5 + 0.005 * k)
+        blocks = []
+        for b, n in enumerate([512, 97, 64, 1, 300, 512]):
+            if b == 2:
+                for k in range(0, n_eng, 7):
+                    g[k].set_speaker_character(1.0); g[k].set_volume(0.9)
+            blocks.append(g.render(n).copy())
+        outs[pair] = blocks
+        g.close()
+    for b in range(len(outs[0])):
+        assert np.any(outs[0][b] != 0.0)
+        assert outs[0][b].tobytes() == outs[1][b].tobytes(), b
+
+
 def test_chain_stream_is_bit_identical(hiplib, oracle):
     """Big oversampled pools whose block goes to a pinned host block run preamp and output stage as ONE launch (k_chain_stream,
     ow_chain_stream.h: one wavefront per 32 engines alternates between the two per 64-sample chunk and stores the f32 rows straight into
