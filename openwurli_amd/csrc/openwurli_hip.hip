@@ -35,7 +35,6 @@
 #include "ow_midi_kernels.h"
 #include "ow_chain_wide.h"
 #include "ow_chain_stream.h"
-#include "ow_preamp_dual.h"
 #include "ow_vm_kernels.h"
 #include <condition_variable>
 #include <map>

@@ -577,20 +577,7 @@ __device__ inline const OwConsts* k_reload(const OwConsts* K) {
     asm volatile("" : "+s"(z));
     return K + z;
 }
-// What a step takes from R alone (the Sherman-Morrison scalar :486 and the R-corrected K :497-500): the same for the main and the shadow
-// state of an engine -- k_preamp_dual forms it once for both.
-struct DkShared { double sm_k, k00, k01, k10, k11; };
-__device__ inline DkShared dk_shared(double g_ldr, const OwConsts* __restrict__ K0) {
-    const OwConsts* __restrict__ K = k_reload(K0);
-    DkShared h;
-    h.sm_k = ow_div(g_ldr, 1.0 + K->p_s_fb_fb * g_ldr);
-    h.k00 = K->p_k[0][0] - h.sm_k * K->p_nv_sfb[0] * K->p_sfb_ni[0];
-    h.k01 = K->p_k[0][1] - h.sm_k * K->p_nv_sfb[0] * K->p_sfb_ni[1];
-    h.k10 = K->p_k[1][0] - h.sm_k * K->p_nv_sfb[1] * K->p_sfb_ni[0];
-    h.k11 = K->p_k[1][1] - h.sm_k * K->p_nv_sfb[1] * K->p_sfb_ni[1];
-    return h;
-}
-__device__ inline double dk_step(DkSt& st, double input, const DkShared& sh, double g_ldr_prev, const OwConsts* __restrict__ K0) {
+__device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_ldr_prev, const OwConsts* __restrict__ K0) {
     const OwConsts* __restrict__ K = k_reload(K0);
     // rhs = A_neg v (dk_preamp_legacy.rs:466).  A_neg = 2C/T - G has 20 structural non-zeros (resistor/capacitor stamps,
     // :283-309); the reference multiplies the zeros too, which adds exact +-0.0 terms, so skipping them is bit-identical
@@ -637,13 +624,16 @@ __device__ inline double dk_step(DkSt& st, double input, const DkShared& sh, dou
         }
     }
     K = k_reload(K0);
-    const double sm_k = sh.sm_k;
+    const double sm_k = ow_div(g_ldr, 1.0 + K->p_s_fb_fb * g_ldr);
     const double sm_vpred = sm_k * vpb[7];
     double v_pred[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v_pred[i] = vpb[i] - sm_vpred * K->p_s_fb_col[i];
     const double p0 = v_pred[0] - v_pred[1], p1 = v_pred[2] - v_pred[3];
-    const double k00 = sh.k00, k01 = sh.k01, k10 = sh.k10, k11 = sh.k11;
+    const double k00 = K->p_k[0][0] - sm_k * K->p_nv_sfb[0] * K->p_sfb_ni[0];
+    const double k01 = K->p_k[0][1] - sm_k * K->p_nv_sfb[0] * K->p_sfb_ni[1];
+    const double k10 = K->p_k[1][0] - sm_k * K->p_nv_sfb[1] * K->p_sfb_ni[0];
+    const double k11 = K->p_k[1][1] - sm_k * K->p_nv_sfb[1] * K->p_sfb_ni[1];
     double vn0 = st.v_nl[0], vn1 = st.v_nl[1];
     // Newton on the two junctions (:505-532).  (ic, gm) always hold the evaluation AT (vn0, vn1): the state's own on entry (DkSt), a fresh
     // one after every update -- so the residual of a sweep needs no exponential, and the evaluation the reference makes after its loop
@@ -684,11 +674,6 @@ __device__ inline double dk_step(DkSt& st, double input, const DkShared& sh, dou
     st.v_nl[0] = vn0; st.v_nl[1] = vn1;
     st.gm[0] = gm0; st.gm[1] = gm1;
     return st.v[6];
-}
-
-__device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_ldr_prev, const OwConsts* __restrict__ K0) {
-    const DkShared sh = dk_shared(g_ldr, K0);
-    return dk_step(st, input, sh, g_ldr_prev, K0);
 }
 
 // DkPreamp::reset -> full_dc_solve at the current R_ldr (dk_preamp_legacy.rs:369-412,628-640).

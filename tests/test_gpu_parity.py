@@ -1111,8 +1111,7 @@ def test_preamp_state_rows_are_the_references_fields_in_every_chain_kernel(hipli
     are ~1e-4 A and ~1e-6 A: the same relative bar + 1e-12)."""
     import openwurli_amd as ow
     sr, n_eng = 48000.0, 3
-    modes = {"lane pairs": {"chain_fused": 0, "preamp_wide": 0, "preamp_dual": 0}, "quad, two launches": {"chain_fused": 0, "preamp_wide": 1},
-             "lane = engine": {"chain_fused": 0, "preamp_wide": 0, "preamp_dual": 1},
+    modes = {"lane pairs": {"chain_fused": 0, "preamp_wide": 0}, "quad, two launches": {"chain_fused": 0, "preamp_wide": 1},
              "quad, fused": {"chain_fused": 1, "chain_row": 0}, "row": {"chain_fused": 1, "chain_row": 1}}
     lens = [64, 97, 512, 1, 33, 256, 128, 512]
     states = {}
@@ -1162,45 +1161,6 @@ def test_preamp_state_rows_are_the_references_fields_in_every_chain_kernel(hipli
         vnl = np.abs(a[..., 12:14] - o[..., 12:14]) <= 1e-5 * np.abs(o[..., 12:14]) + oracle.ABS_FLOOR_PREAMP
         amps = np.abs(a[..., [0, 1, 10, 11]] - o[..., [0, 1, 10, 11]]) <= 1e-5 * np.abs(o[..., [0, 1, 10, 11]]) + 1e-12
         assert volts.all() and vnl.all() and amps.all(), (b, a - o)
-
-
-def test_preamp_dual_is_bit_identical(hiplib):
-    """The legacy preamp with lane = engine (k_preamp_dual, ow_preamp_dual.h: main and shadow state in one lane, what they share formed
-    once, each kind of state in a Newton loop of its own; an opt-in experiment, measured slower) against k_preamp (lanes l and
-    l + 32): the same bits at the preamp tap and the output, the same NaN resets, through notes, depth ramps, a poked NaN / infinity, an
-    engine reset, a ragged pool and blocks that are not multiples of the 32-sample staging chunk; at 2x oversampling and without."""
-    import openwurli_amd as ow
-    for sr in (48000.0, 96000.0):
-        n_eng = 131
-        res = {}
-        for dual in (0, 1):
-            g = ow.EnginePool(sr, n_eng); g.set_sample_rate(sr)
-            g.set_switch("chain_fused", 0); g.set_switch("preamp_wide", 0); g.set_switch("preamp_dual", dual)
-            assert g.get_switch("preamp_dual") == dual
-            for k in range(n_eng):
-                e = g[k]
-                e.set_tremolo_depth((k % 6) * 0.2); e.set_volume(0.5)
-                for note in (36 + k % 40, 60, 67 + k % 25):
-                    e.note_on(note, 0.4 + 0.004 * k)
-            outs, pres = [], []
-            osr = 2 if sr < 88200.0 else 1
-            for b, n in enumerate([512, 97, 32, 1, 33, 300, 512]):
-                if b == 1:
-                    for k in range(0, n_eng, 5):
-                        g[k].set_tremolo_depth(1.0)
-                if b == 2:
-                    g[1].poke_preamp_node(6, float("nan")); g[70].poke_preamp_node(2, float("nan"), shadow=True); g[130].poke_preamp_node(0, float("inf"))
-                if b == 4:
-                    g[64].reset()
-                outs.append(g.render(n).copy()); pres.append(g.preamp_out(osr * n).copy())
-            resets = [g[k].diag().preamp_nan_resets for k in range(n_eng)]
-            res[dual] = (outs, pres, resets)
-            g.close()
-        assert res[0][2] == res[1][2] and res[0][2][1] >= 1 and res[0][2][70] >= 1 and res[0][2][130] >= 1, res[0][2]
-        for b in range(len(res[0][0])):
-            assert np.any(res[0][1][b] != 0.0)
-            assert res[0][1][b].tobytes() == res[1][1][b].tobytes(), (sr, b, "preamp tap")
-            assert res[0][0][b].tobytes() == res[1][0][b].tobytes(), (sr, b, "output")
 
 
 def test_post_pair_is_bit_identical(hiplib):
