@@ -533,10 +533,17 @@ def main(argv=None):
             """k_steps of the script between barriers; max over ranks"""
             barrier()
             ta = time.perf_counter()
+            trace = [] if os.environ.get("OW_BENCH_STEP_MS") else None      # (diagnostic: wall time of every step to stderr)
             for _ in range(k_steps):
                 sc.step(profile=profile)
+                if trace is not None:
+                    trace.append(time.perf_counter())
+            tb = time.perf_counter()
             barrier()
             el_ = time.perf_counter() - ta
+            if trace is not None:
+                ms_ = np.diff(np.array([ta] + trace)) * 1e3
+                print(f"[step ms] {k_steps} steps: " + " ".join(f"{x:.2f}" for x in ms_) + f" | closing barrier {1e3 * (time.perf_counter() - tb):.2f} ms", file=sys.stderr)
             if dist is not None:
                 t_ = torch.tensor([el_], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t_, op=dist.ReduceOp.MAX)
