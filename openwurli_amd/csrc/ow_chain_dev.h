@@ -518,6 +518,9 @@ OW_DEV double xor32(double x) {
 // being repeated: one exponential pair per Newton UPDATE, none for the opening residual.  gm lives in registers only: dk_load derives it
 // from v_nl once per block, the state rows in HBM are the reference's fields.
 struct DkSt { double j_cin, cin_prev, v[8], i_nl[2], v_nl[2], gm[2]; };
+#ifdef OW_DBG_COUNTERS
+extern __device__ unsigned long long g_ow_dbg[8];      // (ow_melange_dev.h)
+#endif
 
 // exp() for the junction laws below, whose argument is clamped to [-1 V, 0.85 V] / V_T = [-38.5, 32.7]: the device library's f64 exp
 // (x * log2(e) rounded to n, two-step reduction by ln 2, degree-11 polynomial, ldexp) without its overflow / underflow selects
@@ -644,11 +647,19 @@ __device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_
     // its slowest lane anyway) without a divergent loop's execution-mask bookkeeping.
     double ic0 = st.i_nl[0], ic1 = st.i_nl[1], gm0 = st.gm[0], gm1 = st.gm[1];
     bool done = false;
+#ifdef OW_DBG_COUNTERS
+    // development counters (tools/probe_dk_updates.py): Newton updates a lane needs itself, by half of the wavefront (k_preamp: lanes 0-31
+    // main, 32-63 shadow), against the updates its wavefront executes
+    unsigned own_updates = 0u, wave_updates = 0u;
+#endif
     for (int iter = 0; iter < 6; ++iter) {
         const double f0 = vn0 - p0 - k00 * ic0 - k01 * ic1;
         const double f1 = vn1 - p1 - k10 * ic0 - k11 * ic1;
         done = done || (fabs(f0) < 1e-9 && fabs(f1) < 1e-9);
         if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+#ifdef OW_DBG_COUNTERS
+        own_updates += done ? 0u : 1u; wave_updates += 1u;
+#endif
         const double j00 = 1.0 - k00 * gm0, j01 = -k01 * gm1, j10 = -k10 * gm0, j11 = 1.0 - k11 * gm1;
         const double det = j00 * j11 - j01 * j10;
         done = done || fabs(det) < 1e-30;
@@ -660,6 +671,18 @@ __device__ inline double dk_step(DkSt& st, double input, double g_ldr, double g_
         dk_ic_gm(vn0, ic0, gm0);
         dk_ic_gm(vn1, ic1, gm1);
     }
+#ifdef OW_DBG_COUNTERS
+    {
+        const int ln = threadIdx.x & 63;
+        atomicAdd(&g_ow_dbg[ln < 32 ? 0 : 1], (unsigned long long)own_updates);
+        if (ln == 0) { atomicAdd(&g_ow_dbg[2], (unsigned long long)wave_updates); atomicAdd(&g_ow_dbg[3], 1ull); }
+        // (slots 4, 5: the slowest lane of each half)
+        unsigned m = own_updates;
+        for (int o = 16; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if (ln == 0) atomicAdd(&g_ow_dbg[4], (unsigned long long)m);
+        if (ln == 32) atomicAdd(&g_ow_dbg[5], (unsigned long long)m);
+    }
+#endif
     K = k_reload(K0);
     const double dot = K->p_sfb_ni[0] * ic0 + K->p_sfb_ni[1] * ic1;
 #pragma unroll
