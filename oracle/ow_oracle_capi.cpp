@@ -74,6 +74,9 @@ void owo_engine_preamp_state(void* e, int shadow, double* out16) {
     out16[10] = s.i_nl[0]; out16[11] = s.i_nl[1]; out16[12] = s.v_nl[0]; out16[13] = s.v_nl[1];
     out16[14] = dk::bjt_ic(s.v_nl[0]); out16[15] = dk::bjt_ic(s.v_nl[1]);
 }
+// test instrumentation: every r_ldr the engine's tremolo produces from now on is moved by `ulps` doubles (tests/test_oracle_sensitivity.py:
+// what a libm whose pow / exp / sin differ in the last places does to the reference itself)
+void owo_engine_set_r_ulp(void* e, int ulps) { ((WurliEngine*)e)->tremolo.r_ulp = ulps; }
 void owo_engine_poke_pa_node(void* e, int node, double v) { ((WurliEngine*)e)->mel_pa.state.v_prev[node] = v; }
 // render with the power-amp tap (chain rate) besides the output
 void owo_engine_render_pa_tap(void* e, float* out, double* pa, size_t n) {

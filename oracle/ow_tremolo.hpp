@@ -480,6 +480,7 @@ struct Tremolo {
     // `--features legacy-tremolo` (tremolo.rs:8, 53-57, 80-90, 170-178, 195-198): behavioural sine LFO instead of the Twin-T circuit.
     // A cargo feature in the reference, a construction-time kind here (set before init()).
     int kind = 0;                      // 0 = Twin-T circuit (default), 1 = legacy LFO
+    int r_ulp = 0;                     // test instrumentation: the CdS law's result moved by this many doubles (what another libm's pow / exp does to it)
     double phase = 0, phase_inc = 0;
 
     void settle_osc() {  // tremolo.rs:92-102 / 215-222
@@ -531,6 +532,8 @@ struct Tremolo {
         else {
             const double log_r = ln_r_max + ln_min_minus_max * std::pow(drive, gamma);
             r_ldr = std::exp(log_r);
+            for (int k = 0; k < r_ulp; ++k) r_ldr = std::nextafter(r_ldr, 1e300);
+            for (int k = 0; k > r_ulp; --k) r_ldr = std::nextafter(r_ldr, 0.0);
         }
         return shunt_impedance();
     }

@@ -158,6 +158,10 @@ class OracleEngine:
         self.L.owo_engine_preamp_state(self.h, 1 if shadow else 0, out.ctypes.data_as(C.c_void_p))
         return out
 
+    def set_r_ulp(self, ulps):
+        """test instrumentation: the tremolo's r_ldr moved by `ulps` doubles from now on (another libm's pow / exp / sin)"""
+        self.L.owo_engine_set_r_ulp(self.h, int(ulps))
+
     def poke_power_amp_node(self, node, volts): self.L.owo_engine_poke_pa_node(self.h, int(node), C.c_double(volts))
 
     def count_voices_in_state(self, st): return self.L.owo_engine_count_state(self.h, int(st))
@@ -277,6 +281,12 @@ ABS_FLOOR_DENSE = 5e-9
 # own worst samples sit (1.5e-8 / 1.0e-8 / 9.5e-9: profiles/r06_soak.md has the eight seeds side by side).  The dense-play floor above
 # stays what the suites' short scenarios use; a soak is held to 2e-8 = 0.6 x the reference's own movement on the worst seed.
 ABS_FLOOR_SOAK = 2e-8
+# ... and with the `legacy-tremolo` LFO in place of the Twin-T (tremolo_kind 1; first soaked in round 6): the same script passes through the
+# same state (seed 5, block 691, engine 0), where the reference is four times touchier to its tremolo's R than to its preamp's exp(): the
+# oracle against itself with every r_ldr moved to the NEIGHBOURING double (what another libm's sin / pow / exp behind the CdS law does)
+# moves that sample by 1.06e-7 (4.3e-8 with the Twin-T; tests/test_oracle_sensitivity.py::test_soak_floor_legacy_tremolo_governing_measurement).
+# The GPU, whose device library is such a libm, sits at 1.2e-7 there and below 1e-8 everywhere else (profiles/r06_soak.md).
+ABS_FLOOR_SOAK_LFO = 1.5e-7
 # melange 12-node solver.  The reference (and the oracle) re-invert the 12x12 MNA matrix by LU for every sample whose R_ldr
 # moved; the GPU applies the mathematically identical rank-one (Sherman-Morrison) update of the inverse at the nominal pot.
 # While R_ldr is steady the two agree to 4-7e-10 at the preamp node.  While R_ldr moves fast (depth-knob ramp, tremolo trough)
@@ -301,6 +311,7 @@ ABS_FLOOR_MELANGE_LIT_OUTPUT = 3.4e-8
 FLOORS = {
     "ABS_FLOOR_OUTPUT": ABS_FLOOR_OUTPUT, "ABS_FLOOR_PREAMP": ABS_FLOOR_PREAMP, "ABS_FLOOR_BATCH": ABS_FLOOR_BATCH,
     "ABS_FLOOR_AUDIT": ABS_FLOOR_AUDIT, "ABS_FLOOR_DENSE": ABS_FLOOR_DENSE, "ABS_FLOOR_SOAK": ABS_FLOOR_SOAK,
+    "ABS_FLOOR_SOAK_LFO": ABS_FLOOR_SOAK_LFO,
     "ABS_FLOOR_MELANGE_LIT_PREAMP": ABS_FLOOR_MELANGE_LIT_PREAMP, "ABS_FLOOR_MELANGE_LIT_OUTPUT": ABS_FLOOR_MELANGE_LIT_OUTPUT,
 }
 FLOOR_RULE = 2.5

@@ -7,6 +7,7 @@ Usage: python tools/soak_parity.py [seconds] [engines] [preamp_kind] [power_amp_
                      reference algorithm itself does under a different libm, the yardstick for the GPU's ratio
   --no-stop          do not stop at the first block outside the bar: the worst ratio over the whole length is what is wanted
   --ulp-voice        the same with the VOICE path's libm off by one ulp (cos / sin / exp behind every mode's rotation and decay)
+  --ulp-r=K          the same with the plain build and its tremolo's r_ldr moved by K doubles (another libm's sin / pow / exp behind the CdS law)
 Exit codes: 0 ran its length inside the bar; 1 mismatch; 3 (melange power amp only) ended at a divergence-guard event only one side took.
 
 Absolute floor: ABS_FLOOR_SOAK = 2e-8 (tests/oracle_binding.py; DESIGN.md section 2 has its row; --floor X overrides).  The suites' four-note
@@ -34,7 +35,7 @@ def soak(seconds=60.0, n=4, pk=0, pak=0, tk=0, seed=99, ulp=False, verbose=True,
     n, so engine k plays the same part as in the full run at 1 / n of the cost."""
     import oracle_binding as ob
     if floor is None:
-        floor = max(ob.ABS_FLOOR_SOAK, ob.ABS_FLOOR_MELANGE_LIT_OUTPUT) if pk else ob.ABS_FLOOR_SOAK
+        floor = max(ob.ABS_FLOOR_SOAK, ob.ABS_FLOOR_MELANGE_LIT_OUTPUT) if pk else (ob.ABS_FLOOR_SOAK_LFO if tk == 1 else ob.ABS_FLOOR_SOAK)
     sr, length = 48000.0, 512
     class _Phantom:         # an engine of the script that nobody listens to (only=...): every call is a no-op
         def __getattr__(self, name):
@@ -44,11 +45,16 @@ def soak(seconds=60.0, n=4, pk=0, pak=0, tk=0, seed=99, ulp=False, verbose=True,
     if ulp:
         class _Pool:        # the oracle's one-ulp build behind the pool's interface
             def __init__(self):
-                self.e = [ob.OracleEngine(sr, perturbed=ulp, preamp_kind=pk, power_amp_kind=pak, tremolo_kind=tk) if k in live else _Phantom() for k in range(n)]
+                r_ulps = int(ulp.split(":")[1]) if isinstance(ulp, str) and ulp.startswith("r:") else 0      # "r:K": the plain build with its tremolo's R moved by K doubles
+                self.e = [ob.OracleEngine(sr, perturbed=(False if r_ulps else ulp), preamp_kind=pk, power_amp_kind=pak, tremolo_kind=tk) if k in live else _Phantom() for k in range(n)]
+                for k in live:
+                    if r_ulps: self.e[k].set_r_ulp(r_ulps)
             def __getitem__(self, k): return self.e[k]
             def render(self, L): return np.stack([x.render(L) for x in self.e])
             def set_sample_rate(self, r):
                 for x in self.e: x.set_sample_rate(r)
+                for k in live:                                      # (a re-rating builds a new tremolo)
+                    if isinstance(ulp, str) and ulp.startswith("r:"): self.e[k].set_r_ulp(int(ulp.split(":")[1]))
             def close(self):
                 for x in self.e: x.close()
         g = _Pool()
@@ -130,6 +136,9 @@ def main():
         ulp = True; argv.remove("--ulp")
     if "--ulp-voice" in argv:
         ulp = "voice"; argv.remove("--ulp-voice")
+    for a in list(argv):
+        if a.startswith("--ulp-r="):          # the oracle against itself with the tremolo's R moved by K doubles (another libm's pow / exp / sin behind the CdS law)
+            ulp = "r:" + a.split("=")[1]; argv.remove(a)
     floor = None
     if "--floor" in argv:
         i = argv.index("--floor"); floor = float(argv[i + 1]); del argv[i:i + 2]
